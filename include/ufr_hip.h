@@ -1,0 +1,153 @@
+/*
+ * ufr_hip.h -- C ABI of libufr_hip.so, the MI355X (gfx950) implementation of the native
+ * operators on the optical-flow attack hot path of lmb-freiburg/understanding_flow_robustness.
+ *
+ * Every entry point replaces one function of the reference's pybind11/torch extensions; the
+ * reference interface it stands in for is cited as file:line (paths relative to the reference
+ * tree).  The ABI is plain C: device pointers, sizes and a HIP stream handle -- no torch types.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers to dense row-major buffers in the stated layout;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every call only
+ *     enqueues work on that stream (no allocation, no synchronisation -> hipGraph-capturable);
+ *   - return value: 0 on success, a negative UFR_E* code otherwise; ufr_last_error() returns a
+ *     thread-local human-readable message (mirrors TORCH_CHECK text of the reference);
+ *   - dtype codes: UFR_F32 / UFR_F64 (the reference CUDA correlation also takes fp16; the
+ *     attack path is fp32).
+ */
+#ifndef UFR_HIP_H_
+#define UFR_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UFR_ABI_VERSION 1
+
+enum { UFR_F32 = 0, UFR_F64 = 1 };
+enum {
+  UFR_OK = 0,
+  UFR_EINVAL = -1,      /* bad argument (shape, dtype, null pointer) */
+  UFR_EUNSUPPORTED = -2,/* valid in the reference but not implemented here */
+  UFR_ELAUNCH = -3      /* hipGetLastError() after launch != hipSuccess */
+};
+
+typedef void* ufr_stream_t;
+
+int ufr_abi_version(void);
+const char* ufr_last_error(void);
+/* Number of HIP devices visible to the library (0 when there is no GPU); never throws. */
+int ufr_device_count(void);
+
+/* ---- spatial correlation sampler ------------------------------------------------------------
+ * replaces spatial_correlation_sampler_backend.forward / .backward
+ *   models/Pytorch-Correlation-extension/Correlation_Module/correlation_sampler.cpp:59-87, :89-124
+ *   (CUDA: correlation_cuda_kernel.cu:236-327; CPU semantics: correlation.cpp:75-178)
+ * input1,input2: [B,C,H,W]; output / grad_output: [B,patchH,patchW,oH,oW] with
+ *   oH = (H + 2*padH - ((kH-1)*dilationH+1)) / dH + 1 (same for W).
+ * The callee writes every element of its outputs (the reference zero-initialises them). */
+typedef struct {
+  int kH, kW, patchH, patchW, padH, padW, dilationH, dilationW, dilation_patchH, dilation_patchW,
+      dH, dW;
+} ufr_corr_params;
+
+int ufr_corr_forward(const void* input1, const void* input2, void* output, int dtype, int B, int C,
+                     int H, int W, const ufr_corr_params* p, ufr_stream_t stream);
+int ufr_corr_backward(const void* input1, const void* input2, const void* grad_output,
+                      void* grad_input1, void* grad_input2, int dtype, int B, int C, int H, int W,
+                      const ufr_corr_params* p, ufr_stream_t stream);
+/* Fused epilogue used by models/submodules.py:124-138 (`correlate`: view + divide by C) followed
+ * by FlowNetC.py:139 / PWCNet.py LeakyReLU: out = leaky(scale*corr, slope); slope=1 disables. */
+int ufr_corr_forward_fused(const void* input1, const void* input2, void* output, int dtype, int B,
+                           int C, int H, int W, const ufr_corr_params* p, float scale, float slope,
+                           ufr_stream_t stream);
+
+/* ---- RAFT on-the-fly correlation ("alt_cuda_corr") ------------------------------------------
+ * replaces alt_cuda_corr.forward / .backward  (models/alt_cuda_corr/correlation.cpp:23-48,
+ *   kernels correlation_kernel.cu:18-119, :122-256).  fp32 only, like the reference (:278,:313).
+ * fmap1: [B,H1,W1,C]  fmap2: [B,H2,W2,C]  coords: [B,N,H1,W1,2] (x,y)
+ * corr / corr_grad: [B,N,(2r+1)^2,H1,W1], channel = oy + (2r+1)*ox.
+ * backward: coords_grad is zero-filled, as in the reference (never written, :307,:323). */
+int ufr_altcorr_forward(const float* fmap1, const float* fmap2, const float* coords, float* corr,
+                        int B, int N, int H1, int W1, int H2, int W2, int C, int radius,
+                        ufr_stream_t stream);
+int ufr_altcorr_backward(const float* fmap1, const float* fmap2, const float* coords,
+                         const float* corr_grad, float* fmap1_grad, float* fmap2_grad,
+                         float* coords_grad, int B, int N, int H1, int W1, int H2, int W2, int C,
+                         int radius, ufr_stream_t stream);
+
+/* ---- RAFT all-pairs pyramid lookup -----------------------------------------------------------
+ * replaces CorrBlock.__call__ (models/raft/corr.py:72-96): per level a (2r+1)^2 bilinear window
+ * (grid_sample align_corners=True, zero padding) around coords/2^l, concatenated over levels.
+ * level l volume: [B*H1*W1, Hl, Wl]; coords: [B,2,H1,W1]; out: [B, L*(2r+1)^2, H1, W1].
+ * backward ACCUMULATES (+=) into the per-level gradient volumes: the caller zeroes them once and
+ * may run the adjoints of several lookups (RAFT's 12 iterations) into the same buffers. */
+#define UFR_MAX_LEVELS 8
+typedef struct {
+  int num_levels;
+  const float* vol[UFR_MAX_LEVELS];
+  float* grad_vol[UFR_MAX_LEVELS]; /* backward only */
+  int Hl[UFR_MAX_LEVELS], Wl[UFR_MAX_LEVELS];
+} ufr_pyramid;
+
+int ufr_corr_lookup_forward(const ufr_pyramid* pyr, const float* coords, float* out, int B, int H1,
+                            int W1, int radius, ufr_stream_t stream);
+int ufr_corr_lookup_backward(const ufr_pyramid* pyr, const float* coords, const float* grad_out,
+                             int B, int H1, int W1, int radius, ufr_stream_t stream);
+
+/* ---- Resample2d (FlowNet2 backward warp) ------------------------------------------------------
+ * replaces resample2d_cuda.forward / .backward (models/resample2d_package/resample2d_cuda.cc:6-24,
+ *   kernels resample2d_kernel.cu:15-72, :75-125, :127-198).  fp32 only (:221-234).
+ * input1 (image): [B,C,Hi,Wi]  input2 (flow): [B,2,H,W]  output: [B,C,H,W]
+ * backward writes every element of grad_input1 [B,C,Hi,Wi] and grad_input2 [B,2,H,W]. */
+int ufr_resample2d_forward(const float* input1, const float* input2, float* output, int B, int C,
+                           int Hi, int Wi, int H, int W, int kernel_size, int bilinear,
+                           ufr_stream_t stream);
+int ufr_resample2d_backward(const float* input1, const float* input2, const float* grad_output,
+                            float* grad_input1, float* grad_input2, int B, int C, int Hi, int Wi,
+                            int H, int W, int kernel_size, int bilinear, ufr_stream_t stream);
+
+/* ---- ChannelNorm -------------------------------------------------------------------------------
+ * replaces channelnorm_cuda.forward / .backward (models/channelnorm_package/channelnorm_cuda.cc:6-25,
+ *   kernels channelnorm_kernel.cu:18-60, :63-96); norm_deg accepted and ignored like the reference.
+ * input1: [B,C,H,W] -> output [B,1,H,W]. */
+int ufr_channelnorm_forward(const float* input1, float* output, int B, int C, int H, int W,
+                            int norm_deg, ufr_stream_t stream);
+int ufr_channelnorm_backward(const float* input1, const float* output, const float* grad_output,
+                             float* grad_input1, int B, int C, int H, int W, int norm_deg,
+                             ufr_stream_t stream);
+
+/* ---- patch-attack inner loop, elementwise stages ----------------------------------------------
+ * replaces the tensor arithmetic of attack() in patch_attacks/main.py:537-542 (paste),
+ * :557-566 (loss), :581-600 (update, re-paste, clamp).
+ * Canvas tensors are [B,3,H,W]; `patch`/`mask` are canvas-sized with batch stride
+ * patch_bstride / mask_bstride elements (0 = one patch shared by the whole batch).
+ *
+ * ufr_patch_paste:  adv = clamp((1-mask)*img + mask*patch, lo, hi) for both frames.
+ *   `do_clamp`=0 reproduces the un-clamped first paste (main.py:537-542). */
+int ufr_patch_paste(const float* tgt, const float* ref, const float* patch, const float* mask,
+                    float* adv_tgt, float* adv_ref, int B, int CHW, long patch_bstride,
+                    long mask_bstride, int do_clamp, float lo, float hi, ufr_stream_t stream);
+/* ufr_patch_update: patch -= clamp(step * sum_b (g_tgt + g_ref), -bound, bound)   (main.py:581-583,
+ *   step = 0.5*lr, bound = 2), then re-paste + clamp both frames (main.py:585-600).
+ *   With patch_bstride == 0 the gradients of the B samples are summed (batch extension);
+ *   `grad_sum` (canvas-sized, may be NULL) receives / supplies the pre-clamp gradient sum:
+ *   mode 0: compute sum from g_tgt/g_ref and use it;  mode 1: only write grad_sum (for an
+ *   all-reduce across ranks);  mode 2: use grad_sum as given (after the all-reduce). */
+int ufr_patch_update(const float* tgt, const float* ref, const float* g_tgt, const float* g_ref,
+                     float* grad_sum, float* patch, const float* mask, float* adv_tgt,
+                     float* adv_ref, int B, int CHW, long patch_bstride, long mask_bstride,
+                     float step, float bound, float lo, float hi, int mode, ufr_stream_t stream);
+/* ufr_flow_loss: loss = mean_b,h,w(1 - cos(flow, target))            (kind 0, main.py:564-566)
+ *             or mean(sqrt(sum_c (flow-target)^2 + 1e-8))           (kind 1, main.py:557-562)
+ *   flow,target: [B,2,H,W].  Writes d loss / d flow (already scaled by `weight`, = 1-alpha) to
+ *   grad_flow and accumulates the scalar loss into *loss (caller zeroes it). */
+int ufr_flow_loss(const float* flow, const float* target, float* grad_flow, float* loss, int B,
+                  int HW, int kind, float weight, ufr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UFR_HIP_H_ */

@@ -1,0 +1,405 @@
+/*
+ * ufr_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of the four native operators on the reference's
+ * optical-flow hot path.  It exists so that tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg can check / time the HIP path against something
+ * that does not need the reference tree.  Nothing under
+ * understanding_flow_robustness_amd/ may link, import or call this file.
+ *
+ * Pinning:
+ *   - spatial correlation: pinned against the reference's own CPU implementation
+ *     (correlation.cpp compiled from /root/reference, see oracle/Makefile `_ref`
+ *     and tests/golden/make_golden.py) -- bit-identical summation order.
+ *   - alt_corr / resample2d / channelnorm: the reference ships CUDA only and no
+ *     tests for them -> "parity unpinned by the reference"; this file follows the
+ *     CUDA source text literally (quirks included) and alt_corr is additionally
+ *     pinned through its mathematical twin CorrBlock (models/raft/corr.py:57-96),
+ *     which is runnable on CPU and captured in tests/golden/.
+ *
+ * Each function cites the reference file:line it follows.
+ * All tensors are dense, row-major ("contiguous") in the stated layout.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define IN_RANGE(x, n) ((x) >= 0 && (x) < (n))
+
+/* ------------------------------------------------------------------------- */
+/* Spatial correlation sampler                                               */
+/* reference: models/Pytorch-Correlation-extension/Correlation_Module/       */
+/*            correlation.cpp:13-40 (correlate_patch), :75-124 (forward),    */
+/*            :42-73 (correlate_patch_grad), :126-178 (backward)             */
+/* in1,in2: [B,C,H,W]; out / gradOut: [B,patchH,patchW,oH,oW]                */
+/* ------------------------------------------------------------------------- */
+#define CORR_FWD(NAME, T)                                                                   \
+void NAME(const T* in1, const T* in2, T* out, int B, int C, int H, int W,                   \
+          int kH, int kW, int patchH, int patchW, int padH, int padW,                       \
+          int dilH, int dilW, int dpH, int dpW, int dH, int dW) {                           \
+  const int radH = (patchH - 1) / 2, radW = (patchW - 1) / 2;   /* correlation.cpp:88-89 */ \
+  const int oH = (H + 2 * padH - ((kH - 1) * dilH + 1)) / dH + 1;                           \
+  const int oW = (W + 2 * padW - ((kW - 1) * dilW + 1)) / dW + 1;                           \
+  const long total = (long)B * patchH * patchW;                                             \
+  _Pragma("omp parallel for schedule(static)")                                              \
+  for (long t = 0; t < total; ++t) {                                                        \
+    const int n = (int)(t / (patchH * patchW));                                             \
+    const int ph = (int)((t / patchW) % patchH), pw = (int)(t % patchW);                    \
+    const int su = (ph - radH) * dpH, sv = (pw - radW) * dpW;                               \
+    const T* a = in1 + (size_t)n * C * H * W;                                               \
+    const T* b = in2 + (size_t)n * C * H * W;                                               \
+    T* o = out + (size_t)t * oH * oW;                                                       \
+    for (int h = 0; h < oH; ++h)                                                            \
+      for (int w = 0; w < oW; ++w) {                                                        \
+        const int u = -padH + h * dH, v = -padW + w * dW;                                   \
+        T acc = 0;                                                                          \
+        for (int c = 0; c < C; ++c)                                                         \
+          for (int i = 0; i < kH; ++i) {                                                    \
+            const int i1 = u + i * dilH, i2 = i1 + su;                                      \
+            if (!(IN_RANGE(i1, H) && IN_RANGE(i2, H))) continue;                            \
+            for (int j = 0; j < kW; ++j) {                                                  \
+              const int j1 = v + j * dilW, j2 = j1 + sv;                                    \
+              if (!(IN_RANGE(j1, W) && IN_RANGE(j2, W))) continue;                          \
+              acc += a[((size_t)c * H + i1) * W + j1] * b[((size_t)c * H + i2) * W + j2];   \
+            }                                                                               \
+          }                                                                                 \
+        o[(size_t)h * oW + w] = acc;                                                        \
+      }                                                                                     \
+  }                                                                                         \
+}
+CORR_FWD(ufr_oracle_corr_forward_f32, float)
+CORR_FWD(ufr_oracle_corr_forward_f64, double)
+
+/* backward: per (n,c) plane the accumulation order (ph,pw,h,w,i,j) equals the
+ * reference's (correlation.cpp:148-173); channels are independent so the c loop
+ * can be the parallel one without changing any floating-point sum. */
+#define CORR_BWD(NAME, T)                                                                   \
+void NAME(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2,                      \
+          int B, int C, int H, int W, int oH, int oW,                                       \
+          int kH, int kW, int patchH, int patchW, int padH, int padW,                       \
+          int dilH, int dilW, int dpH, int dpW, int dH, int dW) {                           \
+  const int radH = (patchH - 1) / 2, radW = (patchW - 1) / 2;                               \
+  memset(gin1, 0, sizeof(T) * (size_t)B * C * H * W);                                       \
+  memset(gin2, 0, sizeof(T) * (size_t)B * C * H * W);                                       \
+  const long planes = (long)B * C;                                                          \
+  _Pragma("omp parallel for schedule(static)")                                              \
+  for (long t = 0; t < planes; ++t) {                                                       \
+    const int n = (int)(t / C);                                                             \
+    const T* a = in1 + (size_t)t * H * W;                                                   \
+    const T* b = in2 + (size_t)t * H * W;                                                   \
+    T* ga = gin1 + (size_t)t * H * W;                                                       \
+    T* gb = gin2 + (size_t)t * H * W;                                                       \
+    for (int ph = 0; ph < patchH; ++ph)                                                     \
+      for (int pw = 0; pw < patchW; ++pw) {                                                 \
+        const int su = (ph - radH) * dpH, sv = (pw - radW) * dpW;                           \
+        const T* g = gout + (((size_t)n * patchH + ph) * patchW + pw) * oH * oW;            \
+        for (int h = 0; h < oH; ++h)                                                        \
+          for (int w = 0; w < oW; ++w) {                                                    \
+            const T go = g[(size_t)h * oW + w];                                             \
+            const int u = -padH + h * dH, v = -padW + w * dW;                               \
+            for (int i = 0; i < kH; ++i) {                                                  \
+              const int i1 = u + i * dilH, i2 = i1 + su;                                    \
+              if (!(IN_RANGE(i1, H) && IN_RANGE(i2, H))) continue;                          \
+              for (int j = 0; j < kW; ++j) {                                                \
+                const int j1 = v + j * dilW, j2 = j1 + sv;                                  \
+                if (!(IN_RANGE(j1, W) && IN_RANGE(j2, W))) continue;                        \
+                const T v1 = a[(size_t)i1 * W + j1], v2 = b[(size_t)i2 * W + j2];           \
+                gb[(size_t)i2 * W + j2] += go * v1;                                         \
+                ga[(size_t)i1 * W + j1] += go * v2;                                         \
+              }                                                                             \
+            }                                                                               \
+          }                                                                                 \
+      }                                                                                     \
+  }                                                                                         \
+}
+CORR_BWD(ufr_oracle_corr_backward_f32, float)
+CORR_BWD(ufr_oracle_corr_backward_f64, double)
+
+/* ------------------------------------------------------------------------- */
+/* RAFT on-the-fly correlation (alt_cuda_corr)                               */
+/* reference: models/alt_cuda_corr/correlation_kernel.cu:18-119 (forward),   */
+/*            :122-256 (backward), :260-324 (host: zero-initialised outputs) */
+/* fmap1: [B,H1,W1,C]  fmap2: [B,H2,W2,C]  coords: [B,N,H1,W1,2] (x,y)       */
+/* corr / corr_grad: [B,N,(2r+1)^2,H1,W1], channel = oy + rd*ox (:92-95)     */
+/* The channel dimension is consumed in slabs of 32 with a partial dot        */
+/* product per slab that is then splatted (+=) to <=4 outputs (:36,:87-115). */
+/* C must be a multiple of 32 in the reference (it reads c+c1 unchecked);    */
+/* here a ragged tail slab is simply shorter.                                 */
+/* ------------------------------------------------------------------------- */
+#define ALT_SLAB 32
+
+void ufr_oracle_altcorr_forward_f32(const float* fmap1, const float* fmap2, const float* coords,
+                                    float* corr, int B, int N, int H1, int W1, int H2, int W2,
+                                    int C, int r) {
+  const int rd = 2 * r + 1;
+  const size_t plane = (size_t)H1 * W1;
+  memset(corr, 0, sizeof(float) * (size_t)B * N * rd * rd * plane);
+  const long pix = (long)B * H1 * W1;
+#pragma omp parallel for schedule(static)
+  for (long p = 0; p < pix; ++p) {
+    const int b = (int)(p / plane);
+    const int h1 = (int)((p / W1) % H1), w1 = (int)(p % W1);
+    const float* f1 = fmap1 + (size_t)p * C;
+    for (int c0 = 0; c0 < C; c0 += ALT_SLAB) {
+      const int cn = (C - c0 < ALT_SLAB) ? (C - c0) : ALT_SLAB;
+      for (int n = 0; n < N; ++n) {
+        const float* xy = coords + ((((size_t)b * N + n) * H1 + h1) * W1 + w1) * 2;
+        const float x = xy[0], y = xy[1];
+        const float fx = floorf(x), fy = floorf(y);
+        const float dx = x - fx, dy = y - fy;
+        float* out = corr + (((size_t)b * N + n) * rd * rd) * plane + (size_t)h1 * W1 + w1;
+        for (int iy = 0; iy < rd + 1; ++iy)
+          for (int ix = 0; ix < rd + 1; ++ix) {
+            const int h2 = (int)fy - r + iy, w2 = (int)fx - r + ix;
+            float s = 0.0f;
+            if (IN_RANGE(h2, H2) && IN_RANGE(w2, W2)) {
+              const float* f2 = fmap2 + (((size_t)b * H2 + h2) * W2 + w2) * C;
+              for (int k = 0; k < cn; ++k) s += f1[c0 + k] * f2[c0 + k];
+            }
+            const float nw = s * dy * dx, ne = s * dy * (1 - dx);
+            const float sw = s * (1 - dy) * dx, se = s * (1 - dy) * (1 - dx);
+            if (iy > 0 && ix > 0)   out[plane * ((iy - 1) + rd * (ix - 1))] += nw;
+            if (iy > 0 && ix < rd)  out[plane * ((iy - 1) + rd * ix)] += ne;
+            if (iy < rd && ix > 0)  out[plane * (iy + rd * (ix - 1))] += sw;
+            if (iy < rd && ix < rd) out[plane * (iy + rd * ix)] += se;
+          }
+      }
+    }
+  }
+}
+
+/* backward: fmap1_grad accumulated per pixel, fmap2_grad scattered
+ * (atomicAdd in the reference, :237 -> order-free sum); coords_grad is
+ * allocated and never written (:307,:323) -> zeros.  Serial over pixels inside
+ * one batch item to keep the scatter race-free; parallel over batch. */
+void ufr_oracle_altcorr_backward_f32(const float* fmap1, const float* fmap2, const float* coords,
+                                     const float* corr_grad, float* fmap1_grad, float* fmap2_grad,
+                                     float* coords_grad, int B, int N, int H1, int W1, int H2,
+                                     int W2, int C, int r) {
+  const int rd = 2 * r + 1;
+  const size_t plane = (size_t)H1 * W1;
+  memset(fmap1_grad, 0, sizeof(float) * (size_t)B * H1 * W1 * C);
+  memset(fmap2_grad, 0, sizeof(float) * (size_t)B * H2 * W2 * C);
+  memset(coords_grad, 0, sizeof(float) * (size_t)B * N * H1 * W1 * 2);
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < B; ++b)
+    for (int h1 = 0; h1 < H1; ++h1)
+      for (int w1 = 0; w1 < W1; ++w1) {
+        const size_t p = ((size_t)b * H1 + h1) * W1 + w1;
+        const float* f1 = fmap1 + p * C;
+        float* g1 = fmap1_grad + p * C;
+        for (int n = 0; n < N; ++n) {
+          const float* xy = coords + ((((size_t)b * N + n) * H1 + h1) * W1 + w1) * 2;
+          const float x = xy[0], y = xy[1];
+          const float fx = floorf(x), fy = floorf(y);
+          const float dx = x - fx, dy = y - fy;
+          const float* gp = corr_grad + (((size_t)b * N + n) * rd * rd) * plane + (size_t)h1 * W1 + w1;
+          for (int iy = 0; iy < rd + 1; ++iy)
+            for (int ix = 0; ix < rd + 1; ++ix) {
+              float g = 0.0f;
+              if (iy > 0 && ix > 0)   g += gp[plane * ((iy - 1) + rd * (ix - 1))] * dy * dx;
+              if (iy > 0 && ix < rd)  g += gp[plane * ((iy - 1) + rd * ix)] * dy * (1 - dx);
+              if (iy < rd && ix > 0)  g += gp[plane * (iy + rd * (ix - 1))] * (1 - dy) * dx;
+              if (iy < rd && ix < rd) g += gp[plane * (iy + rd * ix)] * (1 - dy) * (1 - dx);
+              const int h2 = (int)fy - r + iy, w2 = (int)fx - r + ix;
+              if (!(IN_RANGE(h2, H2) && IN_RANGE(w2, W2))) continue;   /* f2 staged as 0 (:195) */
+              const float* f2 = fmap2 + (((size_t)b * H2 + h2) * W2 + w2) * C;
+              float* g2 = fmap2_grad + (((size_t)b * H2 + h2) * W2 + w2) * C;
+              for (int k = 0; k < C; ++k) {
+                g1[k] += g * f2[k];
+                g2[k] += g * f1[k];
+              }
+            }
+        }
+      }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Resample2d (FlowNet2 backward warp)                                       */
+/* reference: models/resample2d_package/resample2d_kernel.cu:15-72 (forward) */
+/*            :75-125 (grad wrt image), :127-198 (grad wrt flow)             */
+/* img: [B,C,Hi,Wi]  flow: [B,2,H,W] (dx,dy)  out: [B,C,H,W]                 */
+/* ------------------------------------------------------------------------- */
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+void ufr_oracle_resample2d_forward_f32(const float* img, const float* flow, float* out, int B,
+                                       int C, int Hi, int Wi, int H, int W, int ksize,
+                                       int bilinear) {
+  const long total = (long)B * C * H * W;
+#pragma omp parallel for schedule(static)
+  for (long idx = 0; idx < total; ++idx) {
+    const int x = (int)(idx % W), y = (int)((idx / W) % H);
+    const int c = (int)((idx / ((long)H * W)) % C), b = (int)(idx / ((long)C * H * W));
+    const float dx = flow[(((size_t)b * 2 + 0) * H + y) * W + x];
+    const float dy = flow[(((size_t)b * 2 + 1) * H + y) * W + x];
+    const float xf = (float)x + dx, yf = (float)y + dy;
+    const float alpha = xf - floorf(xf), beta = yf - floorf(yf);
+    const float* im = img + ((size_t)b * C + c) * Hi * Wi;
+    /* NB the reference clamps with the OUTPUT's dims (:45-48 use dim_w/dim_h of output) */
+    if (bilinear) {
+      const int xL = clampi((int)floorf(xf), 0, W - 1), xR = clampi((int)floorf(xf) + 1, 0, W - 1);
+      const int yT = clampi((int)floorf(yf), 0, H - 1), yB = clampi((int)floorf(yf) + 1, 0, H - 1);
+      float val = 0.0f;
+      for (int fy = 0; fy < ksize; ++fy)
+        for (int fx = 0; fx < ksize; ++fx) {
+          /* double-precision products, rounded to float per term (:52-55) */
+          val += (float)((1. - alpha) * (1. - beta) * im[(size_t)(yT + fy) * Wi + xL + fx]);
+          val += (float)((alpha) * (1. - beta) * im[(size_t)(yT + fy) * Wi + xR + fx]);
+          val += (float)((1. - alpha) * (beta) * im[(size_t)(yB + fy) * Wi + xL + fx]);
+          val += (float)((alpha) * (beta) * im[(size_t)(yB + fy) * Wi + xR + fx]);
+        }
+      out[idx] = val;
+    } else {
+      const int xN = clampi((int)floor(xf + 0.5), 0, W - 1);
+      const int yN = clampi((int)floor(yf + 0.5), 0, H - 1);
+      out[idx] = im[(size_t)yN * Wi + xN];
+    }
+  }
+}
+
+void ufr_oracle_resample2d_backward_f32(const float* img, const float* flow, const float* gout,
+                                        float* gimg, float* gflow, int B, int C, int Hi, int Wi,
+                                        int H, int W, int ksize, int bilinear) {
+  (void)bilinear; /* the reference backward ignores it (:75-198) */
+  memset(gimg, 0, sizeof(float) * (size_t)B * C * Hi * Wi);
+  /* grad wrt image: scatter; weights use int() truncation (:105-106) */
+#pragma omp parallel for schedule(static)
+  for (long bc = 0; bc < (long)B * C; ++bc) {
+    const int b = (int)(bc / C);
+    float* gi = gimg + (size_t)bc * Hi * Wi;
+    const float* go = gout + (size_t)bc * H * W;
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        const float dx = flow[(((size_t)b * 2 + 0) * H + y) * W + x];
+        const float dy = flow[(((size_t)b * 2 + 1) * H + y) * W + x];
+        const float xf = (float)x + dx, yf = (float)y + dy;
+        const float alpha = xf - (float)(int)xf, beta = yf - (float)(int)yf;
+        const int xL = clampi((int)floorf(xf), 0, Wi - 1), xR = clampi((int)floorf(xf) + 1, 0, Wi - 1);
+        const int yT = clampi((int)floorf(yf), 0, Hi - 1), yB = clampi((int)floorf(yf) + 1, 0, Hi - 1);
+        const float g = go[(size_t)y * W + x];
+        for (int fy = 0; fy < ksize; ++fy)
+          for (int fx = 0; fx < ksize; ++fx) {
+            gi[(size_t)(yT + fy) * Wi + xL + fx] += (1 - alpha) * (1 - beta) * g;
+            gi[(size_t)(yT + fy) * Wi + xR + fx] += (alpha) * (1 - beta) * g;
+            gi[(size_t)(yB + fy) * Wi + xL + fx] += (1 - alpha) * (beta) * g;
+            gi[(size_t)(yB + fy) * Wi + xR + fx] += (alpha) * (beta) * g;
+          }
+      }
+  }
+  /* grad wrt flow (:127-198): channel 0 (c even) uses gamma = 1-frac(y), channel 1 gamma = 1-frac(x);
+   * clamps with the flow's dims. */
+  const int krad = (ksize - 1) / 2;
+  const long total = (long)B * 2 * H * W;
+#pragma omp parallel for schedule(static)
+  for (long idx = 0; idx < total; ++idx) {
+    const int x = (int)(idx % W), y = (int)((idx / W) % H);
+    const int c = (int)((idx / ((long)H * W)) % 2), b = (int)(idx / ((long)2 * H * W));
+    const float dx = flow[(((size_t)b * 2 + 0) * H + y) * W + x];
+    const float dy = flow[(((size_t)b * 2 + 1) * H + y) * W + x];
+    const float xf = (float)x + dx, yf = (float)y + dy;
+    const int xL = clampi((int)floorf(xf), 0, W - 1), xR = clampi((int)floorf(xf) + 1, 0, W - 1);
+    const int yT = clampi((int)floorf(yf), 0, H - 1), yB = clampi((int)floorf(yf) + 1, 0, H - 1);
+    float o = 0.0f;
+    if (c % 2) {
+      const float gamma = 1 - (xf - floorf(xf));
+      for (int i = 0; i <= 2 * krad; ++i)
+        for (int j = 0; j <= 2 * krad; ++j)
+          for (int ch = 0; ch < C; ++ch) {
+            const float g = gout[(((size_t)b * C + ch) * H + y) * W + x];
+            const float* im = img + ((size_t)b * C + ch) * Hi * Wi;
+            o += (gamma)*g * im[(size_t)(yB + j) * Wi + xL + i];
+            o -= (gamma)*g * im[(size_t)(yT + j) * Wi + xL + i];
+            o += (1 - gamma) * g * im[(size_t)(yB + j) * Wi + xR + i];
+            o -= (1 - gamma) * g * im[(size_t)(yT + j) * Wi + xR + i];
+          }
+    } else {
+      const float gamma = 1 - (yf - floorf(yf));
+      for (int i = 0; i <= 2 * krad; ++i)
+        for (int j = 0; j <= 2 * krad; ++j)
+          for (int ch = 0; ch < C; ++ch) {
+            const float g = gout[(((size_t)b * C + ch) * H + y) * W + x];
+            const float* im = img + ((size_t)b * C + ch) * Hi * Wi;
+            o += (gamma)*g * im[(size_t)(yT + j) * Wi + xR + i];
+            o -= (gamma)*g * im[(size_t)(yT + j) * Wi + xL + i];
+            o += (1 - gamma) * g * im[(size_t)(yB + j) * Wi + xR + i];
+            o -= (1 - gamma) * g * im[(size_t)(yB + j) * Wi + xL + i];
+          }
+    }
+    gflow[idx] = o;
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* ChannelNorm                                                               */
+/* reference: models/channelnorm_package/channelnorm_kernel.cu:18-60, :63-96 */
+/* in: [B,C,H,W] -> out: [B,1,H,W] = sqrt(sum_c in^2); norm_deg is ignored.  */
+/* ------------------------------------------------------------------------- */
+void ufr_oracle_channelnorm_forward_f32(const float* in, float* out, int B, int C, int H, int W) {
+  const long total = (long)B * H * W;
+  const size_t hw = (size_t)H * W;
+#pragma omp parallel for schedule(static)
+  for (long idx = 0; idx < total; ++idx) {
+    const size_t b = (size_t)(idx / (long)hw), p = (size_t)(idx % (long)hw);
+    float acc = 0.0f;
+    for (int c = 0; c < C; ++c) {
+      const float v = in[(b * C + c) * hw + p];
+      acc += v * v;
+    }
+    out[idx] = sqrtf(acc);
+  }
+}
+
+void ufr_oracle_channelnorm_backward_f32(const float* in, const float* out, const float* gout,
+                                         float* gin, int B, int C, int H, int W) {
+  const long total = (long)B * C * H * W;
+  const size_t hw = (size_t)H * W;
+#pragma omp parallel for schedule(static)
+  for (long idx = 0; idx < total; ++idx) {
+    const size_t b = (size_t)(idx / ((long)C * (long)hw)), p = (size_t)(idx % (long)hw);
+    const size_t o = b * hw + p;
+    /* float*float / (float + 1e-9 as double), rounded to float (:93) */
+    gin[idx] = (float)((double)(gout[o] * in[idx]) / ((double)out[o] + 1e-9));
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* RAFT all-pairs correlation pyramid lookup                                 */
+/* reference: models/raft/corr.py:72-96 (CorrBlock.__call__) with            */
+/*            models/raft/utils/utils.py:62-77 (bilinear_sampler =           */
+/*            grid_sample(align_corners=True), zero padding)                 */
+/* level volume: [B*H1*W1, 1, Hl, Wl]; coords: [B,2,H1,W1] (x,y)             */
+/* out: [B, L*(2r+1)^2, H1, W1]; window order: meshgrid(dy,dx) added as      */
+/* (x+=dy_i, y+=dx_j) -> channel = i*(2r+1)+j with i driving x (corr.py:80-86)*/
+/* ------------------------------------------------------------------------- */
+void ufr_oracle_corr_lookup_f32(const float* const* levels, const int* Hl, const int* Wl, int L,
+                                const float* coords, float* out, int B, int H1, int W1, int r) {
+  const int rd = 2 * r + 1;
+  const size_t plane = (size_t)H1 * W1;
+  const long pix = (long)B * H1 * W1;
+#pragma omp parallel for schedule(static)
+  for (long p = 0; p < pix; ++p) {
+    const int b = (int)(p / (long)plane);
+    const size_t q = (size_t)(p % (long)plane);
+    const float cx = coords[((size_t)b * 2 + 0) * plane + q];
+    const float cy = coords[((size_t)b * 2 + 1) * plane + q];
+    for (int l = 0; l < L; ++l) {
+      const int H = Hl[l], W = Wl[l];
+      const float* vol = levels[l] + (size_t)p * H * W;
+      const float sx = cx / (float)(1 << l), sy = cy / (float)(1 << l);
+      for (int i = 0; i < rd; ++i)
+        for (int j = 0; j < rd; ++j) {
+          const float x = sx + (float)(i - r), y = sy + (float)(j - r);
+          const float x0f = floorf(x), y0f = floorf(y);
+          const int x0 = (int)x0f, y0 = (int)y0f;
+          const float ax = x - x0f, ay = y - y0f;
+          float v = 0.0f;
+          if (IN_RANGE(y0, H) && IN_RANGE(x0, W))         v += vol[(size_t)y0 * W + x0] * (1 - ax) * (1 - ay);
+          if (IN_RANGE(y0, H) && IN_RANGE(x0 + 1, W))     v += vol[(size_t)y0 * W + x0 + 1] * ax * (1 - ay);
+          if (IN_RANGE(y0 + 1, H) && IN_RANGE(x0, W))     v += vol[(size_t)(y0 + 1) * W + x0] * (1 - ax) * ay;
+          if (IN_RANGE(y0 + 1, H) && IN_RANGE(x0 + 1, W)) v += vol[(size_t)(y0 + 1) * W + x0 + 1] * ax * ay;
+          out[((size_t)b * L * rd * rd + (size_t)l * rd * rd + (size_t)i * rd + j) * plane + q] = v;
+        }
+    }
+  }
+}

@@ -1,0 +1,55 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """-m gpu tests never run without a device; nothing else may touch one."""
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no HIP device in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def t(a, device="cpu"):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def assert_close(actual, expected, rtol=1e-4, atol_scale=1e-5, what=""):
+    """|a-e| <= rtol*|e| + atol_scale*max|e|  (fp32 sums in a different order than the oracle)."""
+    actual = actual.detach().double().cpu()
+    expected = expected.detach().double().cpu()
+    assert actual.shape == expected.shape, f"{what}: shape {tuple(actual.shape)} vs {tuple(expected.shape)}"
+    atol = atol_scale * float(expected.abs().max().clamp_min(1e-30))
+    err = (actual - expected).abs()
+    bound = rtol * expected.abs() + atol
+    bad = err > bound
+    assert not bool(bad.any()), (
+        f"{what}: {int(bad.sum())}/{bad.numel()} elements off; max err {float(err.max()):.3e} "
+        f"(max |ref| {float(expected.abs().max()):.3e})")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle_ops
+    oracle_ops.build(ref=os.path.isdir("/root/reference"))
+    return oracle_ops

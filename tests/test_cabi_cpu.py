@@ -1,0 +1,105 @@
+"""CPU suite, part 2: the C-ABI library builds, loads and exports every symbol include/ufr_hip.h
+declares; the Python mirrors keep the reference's names and refuse CPU tensors loudly (no fallback)."""
+import ctypes
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "ufr_hip.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ufr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from understanding_flow_robustness_amd import _lib as L
+    lib = ctypes.CDLL(L.LIB_PATH)
+    syms = declared_symbols()
+    assert len(syms) >= 17
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/ufr_hip.h but not exported"
+    # and the ctypes table covers the same set
+    assert set(syms) == set(L.SIGNATURES) | set(L.PLAIN)
+
+
+def test_abi_version_and_error_channel():
+    from understanding_flow_robustness_amd import _lib as L
+    lib = L.lib()
+    assert lib.ufr_abi_version() == 1
+    assert lib.ufr_device_count() >= 0
+    # argument validation happens before any HIP call: usable without a GPU
+    p = L.CorrParams(1, 1, 3, 3, 0, 0, 1, 1, 1, 1, 1, 1)
+    rc = lib.ufr_corr_forward(None, None, None, 0, 1, 1, 4, 4, ctypes.byref(p), None)
+    assert rc == -1 and b"null pointer" in lib.ufr_last_error()
+    with pytest.raises(RuntimeError, match="null pointer"):
+        L.check(rc, "probe")
+    rc = lib.ufr_resample2d_forward(None, None, None, 1, 1, 1, 1, 1, 1, 1, 1, None)
+    assert rc == -1
+    rc = lib.ufr_flow_loss(None, None, None, None, 1, 1, 0, 1.0, None)
+    assert rc == -1
+
+
+def test_mirrors_keep_reference_names_and_signatures():
+    import understanding_flow_robustness_amd as ufr
+    ufr.install(force=True)
+    import alt_cuda_corr
+    import channelnorm_cuda
+    import resample2d_cuda
+    import spatial_correlation_sampler as scs
+    import spatial_correlation_sampler_backend as be
+
+    # correlation_sampler.cpp:59-87 / :89-124 -- 2 (3) tensors + 12 ints
+    fwd = list(inspect.signature(be.forward).parameters)
+    assert fwd[:14] == ["input1", "input2", "kH", "kW", "patchH", "patchW", "padH", "padW", "dilationH",
+                        "dilationW", "dilation_patchH", "dilation_patchW", "dH", "dW"]
+    bwd = list(inspect.signature(be.backward).parameters)
+    assert bwd[:3] == ["input1", "input2", "grad_output"] and len(bwd) == 15
+    # spatial_correlation_sampler.py:8-17 defaults
+    sig = inspect.signature(scs.spatial_correlation_sample)
+    assert [p.default for p in list(sig.parameters.values())[2:]] == [1, 1, 1, 0, 1, 1]
+    assert list(sig.parameters)[2:] == ["kernel_size", "patch_size", "stride", "padding", "dilation",
+                                        "dilation_patch"]
+    m = scs.SpatialCorrelationSampler(1, 21, 1, 0, 1, 2)
+    assert (m.kernel_size, m.patch_size, m.dilation_patch) == (1, 21, 2)
+    assert list(inspect.signature(alt_cuda_corr.forward).parameters) == ["fmap1", "fmap2", "coords", "radius"]
+    assert list(inspect.signature(alt_cuda_corr.backward).parameters) == ["fmap1", "fmap2", "coords",
+                                                                          "corr_grad", "radius"]
+    assert list(inspect.signature(resample2d_cuda.forward).parameters) == ["input1", "input2", "output",
+                                                                            "kernel_size", "bilinear"]
+    assert len(inspect.signature(resample2d_cuda.backward).parameters) == 7
+    assert list(inspect.signature(channelnorm_cuda.forward).parameters) == ["input1", "output", "norm_deg"]
+    assert len(inspect.signature(channelnorm_cuda.backward).parameters) == 5
+
+
+def test_no_cpu_fallback():
+    """Reference CPU tensors dispatch to correlation.cpp; this build must refuse, not emulate."""
+    from understanding_flow_robustness_amd.spatial_correlation_sampler import spatial_correlation_sample
+    from understanding_flow_robustness_amd import alt_cuda_corr, channelnorm_cuda, resample2d_cuda
+    a = torch.zeros(1, 2, 4, 4)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        spatial_correlation_sample(a, a, patch_size=3)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        alt_cuda_corr.forward(torch.zeros(1, 4, 4, 2), torch.zeros(1, 4, 4, 2), torch.zeros(1, 1, 4, 4, 2), 1)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        resample2d_cuda.forward(a, a, a, 1, True)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        channelnorm_cuda.forward(a, a, 2)
+
+
+def test_product_never_imports_oracle():
+    """The judge's rule: nothing under the package may import/call anything under oracle/."""
+    pkg = os.path.join(ROOT, "understanding_flow_robustness_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, f)
+                assert "ufr_oracle" not in src and "libufr_corr_ref" not in src, os.path.join(dp, f)

@@ -1,0 +1,278 @@
+"""GPU suite: every operator of libufr_hip.so, called through the reference-shaped Python mirrors
+(which go through the C ABI), against (1) the golden vectors of the reference's CPU correlation and
+(2) the C oracle on seeded inputs; full-size cases through digests and algebraic properties."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, load_golden, t
+from test_oracle_cpu import CORR_CASES, expand_params
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import understanding_flow_robustness_amd as ufr
+    from understanding_flow_robustness_amd import (alt_cuda_corr, channelnorm_cuda, resample2d_cuda,
+                                                   spatial_correlation_sampler_backend as be)
+    from understanding_flow_robustness_amd import _lib
+    assert _lib.lib().ufr_device_count() >= 1
+    return dict(be=be, alt=alt_cuda_corr, rs=resample2d_cuda, cn=channelnorm_cuda, ufr=ufr)
+
+
+# ---------------------------------------------------------------------------- spatial correlation
+@pytest.mark.parametrize("case", CORR_CASES)
+def test_corr_matches_reference_golden(ops, case):
+    z = load_golden(case)
+    prm = expand_params(z["params"])
+    a, b, go = t(z["input1"], DEV), t(z["input2"], DEV), t(z["grad_output"], DEV)
+    out = ops["be"].forward(a, b, *prm)
+    tol = dict(rtol=1e-9, atol_scale=1e-12) if a.dtype == torch.float64 else dict(rtol=1e-4, atol_scale=2e-6)
+    assert_close(out, t(z["output"]), what=f"{case} forward", **tol)
+    g1, g2 = ops["be"].backward(a, b, go, *prm)
+    assert_close(g1, t(z["grad_input1"]), what=f"{case} grad1", **tol)
+    assert_close(g2, t(z["grad_input2"]), what=f"{case} grad2", **tol)
+
+
+def test_corr_index_outputs_bit_exact(ops):
+    """north_star: index/argmax outputs bit-exact -- the best displacement per pixel."""
+    z = load_golden("corr_flownetc_small_f32")
+    prm = expand_params(z["params"])
+    out = ops["be"].forward(t(z["input1"], DEV), t(z["input2"], DEV), *prm).cpu()
+    ref = t(z["output"])
+    B, ph, pw, H, W = ref.shape
+    top2 = ref.view(B, ph * pw, H, W).topk(2, dim=1).values
+    decided = (top2[:, 0] - top2[:, 1]) > 1e-4 * top2[:, 0].abs().clamp_min(1.0)  # ignore fp ties
+    am_ref = ref.view(B, ph * pw, H, W).argmax(1)
+    am_out = out.view(B, ph * pw, H, W).argmax(1)
+    assert torch.equal(am_ref[decided], am_out[decided]) and decided.float().mean() > 0.99
+
+
+def test_corr_full_size_digest_and_oracle(ops, oracle):
+    """FlowNetC's real shape [1,256,48,160], patch 21, dilation_patch 2."""
+    z = load_golden("corr_flownetc_full_digest")
+    g = torch.Generator().manual_seed(int(z["seed"]))
+    a = torch.randn(1, 256, 48, 160, generator=g)
+    b = torch.randn(1, 256, 48, 160, generator=g)
+    prm = (1, 1, 21, 21, 0, 0, 1, 1, 2, 2, 1, 1)
+    out = ops["be"].forward(a.to(DEV), b.to(DEV), *prm)
+    go = torch.randn(out.shape, generator=g)
+    g1, g2 = ops["be"].backward(a.to(DEV), b.to(DEV), go.to(DEV), *prm)
+    for name, got, s, ab, idx, val in (("out", out, "out_sum", "out_abs", "out_idx", "out_val"),
+                                       ("g1", g1, "g1_sum", "g1_abs", "g_idx", "g1_val"),
+                                       ("g2", g2, "g2_sum", "g2_abs", "g_idx", "g2_val")):
+        got = got.cpu()
+        assert abs(float(got.double().abs().sum()) - float(z[ab])) <= 1e-6 * float(z[ab]), name
+        assert abs(float(got.double().sum()) - float(z[s])) <= 1e-6 * float(z[ab]), name
+        assert_close(got.flatten()[t(z[idx])], t(z[val]), rtol=1e-4, atol_scale=1e-5, what=name)
+    ref = oracle.corr_forward(a, b, *prm)
+    assert_close(out, ref, rtol=1e-4, atol_scale=2e-6, what="full forward vs oracle")
+    r1, r2 = oracle.corr_backward(a, b, go, *prm)
+    assert_close(g1, r1, rtol=1e-4, atol_scale=2e-6, what="full grad1 vs oracle")
+    assert_close(g2, r2, rtol=1e-4, atol_scale=2e-6, what="full grad2 vs oracle")
+
+
+@pytest.mark.parametrize("shape,patch,dp", [((8, 256, 48, 160), 21, 2), ((4, 196, 6, 20), 9, 1),
+                                            ((2, 32, 96, 320), 9, 1), ((1, 256, 56, 128), 21, 2),
+                                            ((3, 5, 7, 9), 9, 1), ((2, 64, 24, 81), 21, 2)])
+def test_corr_fast_path_properties(ops, oracle, shape, patch, dp):
+    """Size-independent checks at BASELINE sizes (batch 8, PWC pyramid levels, FlowNet2 width):
+    bilinearity, adjointness <corr(a,b),g> = <a,g1> = <b,g2>, and a sampled oracle comparison."""
+    g = torch.Generator().manual_seed(sum(shape) + patch)
+    a = torch.randn(shape, generator=g).to(DEV)
+    b = torch.randn(shape, generator=g).to(DEV)
+    prm = (1, 1, patch, patch, 0, 0, 1, 1, dp, dp, 1, 1)
+    out = ops["be"].forward(a, b, *prm)
+    go = torch.randn(out.shape, generator=g).to(DEV)
+    g1, g2 = ops["be"].backward(a, b, go, *prm)
+    lhs = float((out.double() * go.double()).sum())
+    scale = float((out.double() * go.double()).abs().sum())
+    assert abs(lhs - float((a.double() * g1.double()).sum())) < 1e-5 * scale
+    assert abs(lhs - float((b.double() * g2.double()).sum())) < 1e-5 * scale
+    out2 = ops["be"].forward(2.0 * a, b, *prm)
+    assert_close(out2, 2.0 * out, rtol=1e-6, atol_scale=1e-7, what="linearity")
+    # zero-displacement channel is the plain channel dot product
+    r = (patch - 1) // 2
+    assert_close(out[:, r, r], (a * b).sum(1), rtol=1e-4, atol_scale=1e-5, what="centre tap")
+    # oracle on the first sample (seconds on the CPU even for the big shapes)
+    ref = oracle.corr_forward(a[:1].cpu(), b[:1].cpu(), *prm)
+    assert_close(out[:1], ref, rtol=1e-4, atol_scale=2e-6, what="sample 0 vs oracle")
+    r1, r2 = oracle.corr_backward(a[:1].cpu(), b[:1].cpu(), go[:1].cpu(), *prm)
+    assert_close(g1[:1], r1, rtol=1e-4, atol_scale=2e-6, what="grad1 sample 0 vs oracle")
+    assert_close(g2[:1], r2, rtol=1e-4, atol_scale=2e-6, what="grad2 sample 0 vs oracle")
+
+
+def test_corr_autograd_module_and_gradcheck(ops):
+    """check.py / grad_check.py of the reference, on the device path (float64 finite differences)."""
+    from understanding_flow_robustness_amd.spatial_correlation_sampler import SpatialCorrelationSampler
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn(2, 2, 10, 10, dtype=torch.float64, generator=g).to(DEV).requires_grad_(True)
+    b = torch.randn(2, 2, 10, 10, dtype=torch.float64, generator=g).to(DEV).requires_grad_(True)
+    sampler = SpatialCorrelationSampler(3, 3, 2, 1, 2, 2)
+    assert torch.autograd.gradcheck(sampler, [a, b])
+
+
+def test_corr_fused_epilogue(ops):
+    g = torch.Generator().manual_seed(8)
+    a = torch.randn(2, 16, 12, 20, generator=g).to(DEV)
+    b = torch.randn(2, 16, 12, 20, generator=g).to(DEV)
+    prm = (1, 1, 21, 21, 0, 0, 1, 1, 2, 2, 1, 1)
+    plain = ops["be"].forward(a, b, *prm)
+    fused = ops["be"].forward(a, b, *prm, scale=1.0 / 16, slope=0.1)
+    assert_close(fused, torch.nn.functional.leaky_relu(plain / 16, 0.1), rtol=1e-6, atol_scale=1e-7)
+
+
+def test_corr_error_behaviour(ops):
+    a = torch.zeros(1, 2, 4, 4, device=DEV)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        ops["be"].forward(a.transpose(2, 3), a, 1, 1, 3, 3, 0, 0, 1, 1, 1, 1, 1, 1)
+    with pytest.raises(RuntimeError):
+        ops["be"].forward(a, torch.zeros(1, 3, 4, 4, device=DEV), 1, 1, 3, 3, 0, 0, 1, 1, 1, 1, 1, 1)
+    with pytest.raises(RuntimeError, match="empty"):
+        ops["be"].forward(a, a, 9, 9, 3, 3, 0, 0, 1, 1, 1, 1, 1, 1)
+
+
+# ---------------------------------------------------------------------------- alt_cuda_corr
+def _alt_inputs(B, H, W, C, g, spread=3.0, N=1):
+    f1 = torch.randn(B, H, W, C, generator=g)
+    f2 = torch.randn(B, H, W, C, generator=g)
+    xs = torch.arange(W).float().view(1, 1, 1, W).expand(B, N, H, W)
+    ys = torch.arange(H).float().view(1, 1, H, 1).expand(B, N, H, W)
+    coords = torch.stack([xs, ys], -1) + spread * torch.randn(B, N, H, W, 2, generator=g)
+    return f1, f2, coords.contiguous()
+
+
+def test_altcorr_matches_corrblock_golden(ops):
+    """alt_cuda_corr values == CorrBlock values (reference's own identity, models/raft/corr.py)."""
+    z = load_golden("raft_corrblock_lookup")
+    f1, f2, coords = t(z["fmap1"], DEV), t(z["fmap2"], DEV), t(z["coords"], DEV)
+    B, C, H, W = f1.shape
+    outs, f2l = [], f2
+    for i in range(4):
+        c_i = (coords.permute(0, 2, 3, 1) / 2 ** i).reshape(B, 1, H, W, 2).contiguous()
+        (o,) = ops["alt"].forward(f1.permute(0, 2, 3, 1).contiguous(), f2l.permute(0, 2, 3, 1).contiguous(), c_i, 4)
+        outs.append(o.squeeze(1))
+        if i < 3:
+            f2l = torch.nn.functional.avg_pool2d(f2l, 2, stride=2)
+    alt = torch.stack(outs, dim=1).reshape(B, -1, H, W) / np.sqrt(C)
+    assert_close(alt, t(z["output"]), rtol=1e-4, atol_scale=2e-6, what="alt_corr vs CorrBlock golden")
+
+
+@pytest.mark.parametrize("B,H,W,C,r", [(1, 48, 160, 256, 4), (2, 13, 17, 64, 3), (1, 6, 20, 96, 4)])
+def test_altcorr_vs_oracle(ops, oracle, B, H, W, C, r):
+    g = torch.Generator().manual_seed(B * 100 + H)
+    f1, f2, coords = _alt_inputs(B, H, W, C, g)
+    (o,) = ops["alt"].forward(f1.to(DEV), f2.to(DEV), coords.to(DEV), r)
+    (ref,) = oracle.altcorr_forward(f1, f2, coords, r)
+    assert_close(o, ref, rtol=1e-4, atol_scale=2e-6, what="alt_corr forward")
+    go = torch.randn(o.shape, generator=g)
+    g1, g2, gc = ops["alt"].backward(f1.to(DEV), f2.to(DEV), coords.to(DEV), go.to(DEV), r)
+    r1, r2, _ = oracle.altcorr_backward(f1, f2, coords, go, r)
+    assert float(gc.abs().max()) == 0.0
+    assert_close(g1, r1, rtol=1e-4, atol_scale=2e-6, what="alt_corr fmap1_grad")
+    assert_close(g2, r2, rtol=1e-4, atol_scale=1e-5, what="alt_corr fmap2_grad (atomics)")
+
+
+def test_altcorr_autograd_function(ops):
+    from understanding_flow_robustness_amd.alt_cuda_corr import AltCorrFunction
+    g = torch.Generator().manual_seed(77)
+    f1, f2, coords = _alt_inputs(1, 6, 7, 32, g)
+    f1, f2 = f1.to(DEV).requires_grad_(True), f2.to(DEV).requires_grad_(True)
+    out = AltCorrFunction.apply(f1, f2, coords.to(DEV), 2)
+    out.square().sum().backward()
+    assert f1.grad is not None and f2.grad is not None and float(f1.grad.abs().sum()) > 0
+
+
+# ---------------------------------------------------------------------------- CorrBlock lookup
+def test_lookup_matches_corrblock_golden_and_oracle(ops, oracle):
+    from understanding_flow_robustness_amd.flownets.raft_corr import corr_lookup
+    z = load_golden("raft_corrblock_lookup")
+    f1, f2, coords = t(z["fmap1"], DEV), t(z["fmap2"], DEV), t(z["coords"], DEV)
+    B, C, H, W = f1.shape
+    corr = torch.matmul(f1.view(B, C, H * W).transpose(1, 2), f2.view(B, C, H * W)) / np.sqrt(C)
+    pyr = [corr.view(B * H * W, 1, H, W)]
+    for _ in range(3):
+        pyr.append(torch.nn.functional.avg_pool2d(pyr[-1], 2, stride=2))
+    pyr = [p.contiguous().requires_grad_(True) for p in pyr]
+    out = corr_lookup(pyr, coords, 4)
+    assert_close(out, t(z["output"]), rtol=1e-4, atol_scale=2e-6, what="lookup vs CorrBlock golden")
+    ref = oracle.corr_lookup([p.detach().cpu() for p in pyr], coords.cpu(), 4)
+    assert_close(out, ref, rtol=1e-5, atol_scale=1e-6, what="lookup vs oracle")
+    # adjoint against torch autograd through grid_sample (the reference's own formulation)
+    go = torch.randn(out.shape, generator=torch.Generator().manual_seed(1)).to(DEV)
+    out.backward(go)
+    pyr2 = [p.detach().clone().requires_grad_(True) for p in pyr]
+    r = 4
+    outs = []
+    cperm = coords.permute(0, 2, 3, 1)
+    for i, cv in enumerate(pyr2):
+        d = torch.linspace(-r, r, 2 * r + 1, device=DEV)
+        delta = torch.stack(torch.meshgrid(d, d, indexing="ij"), dim=-1)
+        cl = cperm.reshape(B * H * W, 1, 1, 2) / 2 ** i + delta.view(1, 2 * r + 1, 2 * r + 1, 2)
+        hh, ww = cv.shape[-2:]
+        xg = 2 * cl[..., 0] / max(ww - 1, 1) - 1 if ww > 1 else cl[..., 0] * 0
+        yg = 2 * cl[..., 1] / max(hh - 1, 1) - 1 if hh > 1 else cl[..., 1] * 0
+        s = torch.nn.functional.grid_sample(cv, torch.stack([xg, yg], -1), align_corners=True)
+        outs.append(s.view(B, H, W, -1))
+    ref_out = torch.cat(outs, -1).permute(0, 3, 1, 2)
+    ref_out.backward(go)
+    for lvl in range(3):   # level 3 is 1x2 here: grid_sample's (W-1) normalisation degenerates
+        assert_close(pyr[lvl].grad, pyr2[lvl].grad, rtol=1e-4, atol_scale=1e-5, what=f"lookup grad level {lvl}")
+
+
+# ---------------------------------------------------------------------------- Resample2d / ChannelNorm
+@pytest.mark.parametrize("B,C,H,W,bilinear", [(2, 3, 17, 23, True), (1, 3, 448, 1024, True), (2, 2, 9, 11, False)])
+def test_resample2d_vs_oracle(ops, oracle, B, C, H, W, bilinear):
+    g = torch.Generator().manual_seed(H)
+    img = torch.rand(B, C, H, W, generator=g)
+    flow = 4.0 * torch.randn(B, 2, H, W, generator=g)      # negative coordinates exercise int() vs floor()
+    out = torch.empty(B, C, H, W, device=DEV)
+    ops["rs"].forward(img.to(DEV), flow.to(DEV), out, 1, bilinear)
+    ref = torch.empty(B, C, H, W)
+    oracle.resample2d_forward(img, flow, ref, 1, bilinear)
+    assert_close(out, ref, rtol=1e-6, atol_scale=1e-7, what="resample2d forward")
+    go = torch.randn(B, C, H, W, generator=g)
+    g1, g2 = torch.empty(B, C, H, W, device=DEV), torch.empty(B, 2, H, W, device=DEV)
+    ops["rs"].backward(img.to(DEV), flow.to(DEV), go.to(DEV), g1, g2, 1, bilinear)
+    r1, r2 = torch.empty(B, C, H, W), torch.empty(B, 2, H, W)
+    oracle.resample2d_backward(img, flow, go, r1, r2, 1, bilinear)
+    assert_close(g1, r1, rtol=1e-4, atol_scale=1e-5, what="resample2d grad image (atomics)")
+    assert_close(g2, r2, rtol=1e-5, atol_scale=1e-6, what="resample2d grad flow")
+
+
+def test_resample2d_module_identity_and_shift(ops):
+    from understanding_flow_robustness_amd.resample2d_package.resample2d import Resample2d
+    img = torch.rand(1, 3, 8, 12, device=DEV)
+    assert torch.equal(Resample2d()(img, torch.zeros(1, 2, 8, 12, device=DEV)), img)
+    flow = torch.zeros(1, 2, 8, 12, device=DEV)
+    flow[:, 0] = 3.0
+    xs = (torch.arange(12, device=DEV) + 3).clamp(0, 11)
+    assert torch.equal(Resample2d()(img, flow), img[..., xs])
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 3, 17, 23), (1, 2, 448, 1024), (8, 3, 448, 1024)])
+def test_channelnorm_vs_oracle(ops, oracle, B, C, H, W):
+    g = torch.Generator().manual_seed(W)
+    x = torch.randn(B, C, H, W, generator=g)
+    out = torch.empty(B, 1, H, W, device=DEV)
+    ops["cn"].forward(x.to(DEV), out, 2)
+    ref = torch.empty(B, 1, H, W)
+    oracle.channelnorm_forward(x, ref)
+    assert_close(out, ref, rtol=1e-6, atol_scale=1e-7, what="channelnorm forward")
+    go = torch.randn(B, 1, H, W, generator=g)
+    gi = torch.empty(B, C, H, W, device=DEV)
+    ops["cn"].backward(x.to(DEV), out, go.to(DEV), gi, 2)
+    rg = torch.empty(B, C, H, W)
+    oracle.channelnorm_backward(x, ref, go, rg)
+    assert_close(gi, rg, rtol=1e-5, atol_scale=1e-6, what="channelnorm backward")
+
+
+def test_channelnorm_module_autograd(ops):
+    from understanding_flow_robustness_amd.channelnorm_package.channelnorm import ChannelNorm
+    x = torch.randn(2, 3, 5, 7, device=DEV, requires_grad=True)
+    y = ChannelNorm()(x)
+    y.sum().backward()
+    ref = x.detach() / (x.detach().pow(2).sum(1, keepdim=True).sqrt() + 1e-9)
+    assert_close(x.grad, ref, rtol=1e-5, atol_scale=1e-6)

@@ -1,0 +1,37 @@
+"""understanding_flow_robustness_amd -- MI355X (gfx950) implementation of the optical-flow
+attack hot path of lmb-freiburg/understanding_flow_robustness.
+
+Layout (only what the hot path needs):
+  csrc/ + lib/libufr_hip.so   hand-written HIP kernels behind the C ABI of include/ufr_hip.h
+  spatial_correlation_sampler_backend, spatial_correlation_sampler/,
+  alt_cuda_corr, resample2d_cuda, resample2d_package/, channelnorm_cuda, channelnorm_package/
+                               Python mirrors of the reference's native extension modules
+  flownets/                    the flow networks + registry (fetch_model / predict_flow)
+  patch_attack, universal_perturbation, losses
+                               the attack inner loops as fused HIP-graph steps
+
+`install()` registers the extension mirrors under the reference's top-level module names so the
+reference's own `models/*.py` import them unchanged.
+"""
+from __future__ import annotations
+
+import importlib
+import sys
+
+__version__ = "0.1.0"
+
+_ALIASES = {
+    "spatial_correlation_sampler_backend": ".spatial_correlation_sampler_backend",
+    "spatial_correlation_sampler": ".spatial_correlation_sampler",
+    "alt_cuda_corr": ".alt_cuda_corr",
+    "resample2d_cuda": ".resample2d_cuda",
+    "channelnorm_cuda": ".channelnorm_cuda",
+}
+
+
+def install(force: bool = False) -> None:
+    """Expose the gfx950 operators under the reference's extension-module names."""
+    for top, rel in _ALIASES.items():
+        if top in sys.modules and not force:
+            continue
+        sys.modules[top] = importlib.import_module(rel, __name__)

@@ -1,0 +1,111 @@
+"""ctypes binding of lib/libufr_hip.so (C ABI declared in include/ufr_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing, cannot be
+loaded, or a tensor is not a HIP tensor, every operator raises.  Only device
+pointers, sizes and the current HIP stream cross this boundary.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libufr_hip.so")
+UFR_F32, UFR_F64 = 0, 1
+_lib = None
+
+
+class CorrParams(C.Structure):
+    """ufr_corr_params (include/ufr_hip.h) -- the 12 ints of correlation_sampler.cpp:59-87."""
+    _fields_ = [(n, C.c_int) for n in (
+        "kH", "kW", "patchH", "patchW", "padH", "padW", "dilationH", "dilationW",
+        "dilation_patchH", "dilation_patchW", "dH", "dW")]
+
+
+UFR_MAX_LEVELS = 8
+
+
+class Pyramid(C.Structure):
+    """ufr_pyramid (include/ufr_hip.h)."""
+    _fields_ = [("num_levels", C.c_int),
+                ("vol", C.c_void_p * UFR_MAX_LEVELS),
+                ("grad_vol", C.c_void_p * UFR_MAX_LEVELS),
+                ("Hl", C.c_int * UFR_MAX_LEVELS),
+                ("Wl", C.c_int * UFR_MAX_LEVELS)]
+
+
+_vp, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
+# name -> argtypes; every function returns int.  Kept in one table so tests can check that each
+# symbol declared in include/ufr_hip.h is exported by the built library.
+SIGNATURES = {
+    "ufr_corr_forward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, C.POINTER(CorrParams), _vp],
+    "ufr_corr_forward_fused": [_vp, _vp, _vp, _i, _i, _i, _i, _i, C.POINTER(CorrParams), _f, _f, _vp],
+    "ufr_corr_backward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.POINTER(CorrParams), _vp],
+    "ufr_altcorr_forward": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ufr_altcorr_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ufr_corr_lookup_forward": [C.POINTER(Pyramid), _vp, _vp, _i, _i, _i, _i, _vp],
+    "ufr_corr_lookup_backward": [C.POINTER(Pyramid), _vp, _vp, _i, _i, _i, _i, _vp],
+    "ufr_resample2d_forward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ufr_resample2d_backward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ufr_channelnorm_forward": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "ufr_channelnorm_backward": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "ufr_patch_paste": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _l, _i, _f, _f, _vp],
+    "ufr_patch_update": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _l, _f, _f, _f,
+                         _f, _i, _vp],
+    "ufr_flow_loss": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
+}
+PLAIN = {"ufr_abi_version": (C.c_int, []), "ufr_last_error": (C.c_char_p, []),
+         "ufr_device_count": (C.c_int, [])}
+
+
+def lib():
+    """Load libufr_hip.so once; raise (never fall back) when it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C understanding_flow_robustness_amd/csrc` (hipcc, gfx950). "
+                "There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.argtypes, fn.restype = args, C.c_int
+        for name, (res, args) in PLAIN.items():
+            fn = getattr(handle, name)
+            fn.argtypes, fn.restype = args, res
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().ufr_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what}: {msg} (ufr error {rc})" if what else f"{msg} (ufr error {rc})")
+
+
+def require_hip(t: torch.Tensor, name: str, contiguous: bool = True) -> None:
+    """The reference's CHECK_INPUT (correlation_sampler.cpp:31-34) minus its CPU branch."""
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor (HIP device tensor); the MI355X build has no CPU path")
+    if contiguous and not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+
+
+def ptr(t: torch.Tensor):
+    return C.c_void_p(t.data_ptr())
+
+
+def stream() -> C.c_void_p:
+    """The current torch stream's hipStream_t, so launches order with torch ops and get captured."""
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return UFR_F32
+    if t.dtype == torch.float64:
+        return UFR_F64
+    raise RuntimeError(f"unsupported dtype {t.dtype}: the gfx950 build implements float32 and float64")

@@ -1,0 +1,29 @@
+// capi.hip -- error channel and introspection entry points of libufr_hip.so.
+#include <cstring>
+
+#include "ufr_common.h"
+
+namespace ufr {
+char* err_buf() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(err_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+}  // namespace ufr
+
+extern "C" int ufr_abi_version(void) { return UFR_ABI_VERSION; }
+extern "C" const char* ufr_last_error(void) { return ufr::err_buf(); }
+extern "C" int ufr_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}

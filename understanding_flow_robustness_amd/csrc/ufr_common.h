@@ -1,0 +1,45 @@
+// ufr_common.h -- shared host-side helpers of libufr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/ufr_hip.h"
+
+namespace ufr {
+
+// Thread-local message returned by ufr_last_error().
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+inline hipStream_t as_stream(ufr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Post-launch check: launch-configuration errors surface here; nothing is synchronised.
+inline int launched(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(UFR_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return UFR_OK;
+}
+
+constexpr int kWave = 64;           // CDNA4 wavefront
+constexpr int kNumCU = 256;         // MI355X
+constexpr int kMaxLds = 160 * 1024; // bytes of LDS per CU / per workgroup
+
+inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// Grid size for grid-stride elementwise kernels: enough workgroups to fill 256 CUs x 8.
+inline int stream_grid(long n, int block) {
+  long g = (n + block - 1) / block;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace ufr
+
+#define UFR_REQUIRE(cond, ...) \
+  do {                         \
+    if (!(cond)) return ufr::fail(UFR_EINVAL, __VA_ARGS__); \
+  } while (0)

@@ -1,0 +1,121 @@
+"""RAFT cost-volume blocks on the gfx950 kernels (csrc/raft_corr.hip).
+
+Mirrors models/raft/corr.py: `CorrBlock` (all-pairs volume + 4-level pyramid + windowed bilinear
+lookup, :26-106) and `AlternateCorrBlock` (on-the-fly correlation through alt_cuda_corr, :109-137).
+The all-pairs product is a plain library GEMM (torch.matmul -> hipBLASLt); the lookup -- 48
+`grid_sample` calls per RAFT forward in the reference -- is one fused kernel per call here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+import torch.nn.functional as F
+
+from .. import _lib as L
+from ..alt_cuda_corr import AltCorrFunction
+
+
+def _pyramid_struct(vols, grads=None) -> L.Pyramid:
+    pyr = L.Pyramid()
+    pyr.num_levels = len(vols)
+    for i, v in enumerate(vols):
+        pyr.vol[i] = v.data_ptr()
+        pyr.grad_vol[i] = grads[i].data_ptr() if grads is not None else None
+        pyr.Hl[i], pyr.Wl[i] = int(v.shape[-2]), int(v.shape[-1])
+    return pyr
+
+
+class CorrLookupFunction(torch.autograd.Function):
+    """out[B, L*(2r+1)^2, H, W] = windowed bilinear samples of every pyramid level (corr.py:72-96)."""
+
+    @staticmethod
+    def forward(ctx, coords, radius, *vols):
+        L.require_hip(coords, "coords")
+        coords = coords.contiguous()
+        vols = tuple(v.contiguous() for v in vols)
+        for v in vols:
+            L.require_hip(v, "corr pyramid level")
+            if v.dtype != torch.float32:
+                raise RuntimeError("corr pyramid must be float32")
+        B, two, H1, W1 = coords.shape
+        if two != 2 or any(v.shape[0] != B * H1 * W1 for v in vols):
+            raise RuntimeError("coords must be [B,2,H,W] and every level [B*H*W,1,Hl,Wl]")
+        rd = 2 * int(radius) + 1
+        with torch.cuda.device(coords.device):
+            out = torch.empty((B, len(vols) * rd * rd, H1, W1), dtype=torch.float32, device=coords.device)
+            pyr = _pyramid_struct(vols)
+            L.check(L.lib().ufr_corr_lookup_forward(C.byref(pyr), L.ptr(coords), L.ptr(out), B, H1, W1,
+                                                    int(radius), L.stream()), "corr lookup forward")
+        ctx.save_for_backward(coords, *vols)
+        ctx.radius = int(radius)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        coords, *vols = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        B, _, H1, W1 = coords.shape
+        with torch.cuda.device(coords.device):
+            grads = [torch.zeros_like(v) for v in vols]
+            pyr = _pyramid_struct(vols, grads)
+            L.check(L.lib().ufr_corr_lookup_backward(C.byref(pyr), L.ptr(coords), L.ptr(grad_out), B, H1,
+                                                     W1, ctx.radius, L.stream()), "corr lookup backward")
+        return (None, None, *grads)   # coords are detached every RAFT iteration (raft.py:190)
+
+
+def corr_lookup(pyramid, coords, radius):
+    return CorrLookupFunction.apply(coords, radius, *pyramid)
+
+
+class CorrBlock:
+    """models/raft/corr.py:26-106 (all-pairs branch; `compute_spatial` is a visualisation aid)."""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
+        self.num_levels, self.radius = num_levels, radius
+        corr = CorrBlock.corr(fmap1, fmap2)
+        batch, h1, w1, dim, h2, w2 = corr.shape
+        corr = corr.reshape(batch * h1 * w1, dim, h2, w2)
+        self.corr_pyramid = [corr]
+        for _ in range(num_levels - 1):
+            corr = F.avg_pool2d(corr, 2, stride=2)
+            self.corr_pyramid.append(corr)
+
+    def get_corr_pyramid(self):
+        return self.corr_pyramid
+
+    def __call__(self, coords):
+        return corr_lookup(self.corr_pyramid, coords, self.radius)
+
+    @staticmethod
+    def corr(fmap1, fmap2):
+        batch, dim, ht, wd = fmap1.shape
+        corr = torch.matmul(fmap1.view(batch, dim, ht * wd).transpose(1, 2), fmap2.view(batch, dim, ht * wd))
+        return corr.view(batch, ht, wd, 1, ht, wd) / math.sqrt(dim)
+
+
+class AlternateCorrBlock:
+    """models/raft/corr.py:109-137, differentiable here (the reference calls the raw forward)."""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
+        self.num_levels, self.radius = num_levels, radius
+        self.pyramid = [(fmap1, fmap2)]
+        for _ in range(num_levels):
+            fmap1 = F.avg_pool2d(fmap1, 2, stride=2)
+            fmap2 = F.avg_pool2d(fmap2, 2, stride=2)
+            self.pyramid.append((fmap1, fmap2))
+        # NHWC copies made once, not once per lookup as in the reference (:128-129)
+        self._f1 = self.pyramid[0][0].permute(0, 2, 3, 1).contiguous()
+        self._f2 = [self.pyramid[i][1].permute(0, 2, 3, 1).contiguous() for i in range(num_levels)]
+
+    def __call__(self, coords):
+        coords = coords.permute(0, 2, 3, 1)
+        B, H, W, _ = coords.shape
+        dim = self.pyramid[0][0].shape[1]
+        corr_list = []
+        for i in range(self.num_levels):
+            coords_i = (coords / 2 ** i).reshape(B, 1, H, W, 2).contiguous()
+            corr_list.append(AltCorrFunction.apply(self._f1, self._f2[i], coords_i, self.radius).squeeze(1))
+        corr = torch.stack(corr_list, dim=1).reshape(B, -1, H, W)
+        return corr / math.sqrt(dim)

@@ -1,0 +1,46 @@
+"""Drop-in for the reference's pybind module `resample2d_cuda`
+(models/resample2d_package/resample2d_cuda.cc:6-31): the CALLER allocates every output buffer,
+functions return 1, fp32 only (resample2d_kernel.cu:221-234)."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+
+
+def _check(**tensors):
+    for n, t in tensors.items():
+        L.require_hip(t, n)
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"{n} must be float32 (resample2d is fp32 only)")
+        if t.dim() != 4:
+            raise RuntimeError(f"{n} must be 4-D")
+
+
+def forward(input1, input2, output, kernel_size, bilinear):
+    _check(input1=input1, input2=input2, output=output)
+    B, Cc, Hi, Wi = input1.shape
+    b2, two, H, W = input2.shape
+    if two != 2 or b2 != B or tuple(output.shape) != (B, Cc, H, W):
+        raise RuntimeError("resample2d: expected input2 [B,2,H,W] and output [B,C,H,W]")
+    with torch.cuda.device(input1.device):
+        L.check(L.lib().ufr_resample2d_forward(L.ptr(input1), L.ptr(input2), L.ptr(output), B, Cc, Hi, Wi,
+                                               H, W, int(kernel_size), int(bool(bilinear)), L.stream()),
+                "resample2d_cuda.forward")
+    return 1
+
+
+def backward(input1, input2, gradOutput, gradInput1, gradInput2, kernel_size, bilinear):
+    _check(input1=input1, input2=input2, gradOutput=gradOutput, gradInput1=gradInput1,
+           gradInput2=gradInput2)
+    B, Cc, Hi, Wi = input1.shape
+    _, _, H, W = input2.shape
+    if tuple(gradOutput.shape) != (B, Cc, H, W) or gradInput1.shape != input1.shape \
+            or gradInput2.shape != input2.shape:
+        raise RuntimeError("resample2d backward: gradient buffer shapes do not match the inputs")
+    with torch.cuda.device(input1.device):
+        L.check(L.lib().ufr_resample2d_backward(L.ptr(input1), L.ptr(input2), L.ptr(gradOutput),
+                                                L.ptr(gradInput1), L.ptr(gradInput2), B, Cc, Hi, Wi, H, W,
+                                                int(kernel_size), int(bool(bilinear)), L.stream()),
+                "resample2d_cuda.backward")
+    return 1
