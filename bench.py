@@ -1,0 +1,215 @@
+"""bench.py -- headline metric of BASELINE.json on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+metric   : attack-iters/s = frame pairs x I-FGSM patch iterations per second
+workload : configs[1] -- FlowNetC, 384x1280 synthetic frame pairs, batch 8 per GPU, one shared 51x51
+           circular patch, cosine loss, lr 1000 (patch_attacks/main.py defaults), fp32 end to end.
+step     : ONE inner-loop iteration of attack() (main.py:546-611) over the rank's batch:
+           paste -> FlowNetC forward -> loss -> data-gradient backward -> clamp/update/re-paste,
+           replayed as one HIP graph (+ one RCCL all-reduce of the pre-clamp patch gradient when N>1).
+scaling  : weak (8 pairs per GPU); value = N*8*K / max-over-ranks time.
+Inputs are resident in HBM before the timed region.  The JSON line also carries
+  roofline     -- the step against the fp32 MFMA peak (convs are ~98% of the FLOPs) and, under
+                  "kernels", every hand-written kernel against its own bound, timed with HIP events;
+  cpu_baseline -- the CPU oracle (torch-CPU convs + C correlation) on a bounded sample, rank 0, N=1.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from argparse import Namespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W, B_PER_GPU = 384, 1280, 8
+PATCH = 51                      # --patch-size 0.1329 * 384 (utils_patch.py:760-766)
+# algorithmic work per frame pair per iteration, forward + data gradient (SURVEY.md 8d / BASELINE.md)
+GFLOP_PER_PAIR_STEP = 2 * 111.9 + 1.734 + 3.468
+PEAK_FP32_TFLOPS = 157.3        # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
+PEAK_HBM_GBS = 8000.0
+CORR_FWD = dict(gflop=1.734, mbytes=29.3)   # per [1,256,48,160] pair
+CORR_BWD = dict(gflop=3.468, mbytes=44.9)
+
+
+def circle_mask(size):
+    yy, xx = torch.meshgrid(torch.arange(size), torch.arange(size), indexing="ij")
+    c = size // 2
+    return ((yy - c) ** 2 + (xx - c) ** 2 <= (c - 2) ** 2).float()   # utils_patch.py:236-247
+
+
+def synthetic_batch(batch, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    tgt = torch.rand(batch, 3, H, W, generator=g)
+    ref = torch.rand(batch, 3, H, W, generator=g)
+    mask = torch.zeros(batch, 3, H, W)
+    circ = circle_mask(PATCH)
+    for b in range(batch):   # seeded random placement per sample (circle_transform places randomly)
+        y = int(torch.randint(0, H - PATCH, (1,), generator=g))
+        x = int(torch.randint(0, W - PATCH, (1,), generator=g))
+        mask[b, :, y:y + PATCH, x:x + PATCH] = circ
+    return tgt.to(device), ref.to(device), mask.to(device)
+
+
+def event_time(fn, iters, warm=2):
+    """Average duration (ms) of `fn` with HIP events on the stream the kernels are launched on."""
+    for _ in range(warm):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    e.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def kernel_rooflines(device):
+    """Live per-kernel timings of the hand-written kernels on the step's shapes."""
+    from understanding_flow_robustness_amd import spatial_correlation_sampler_backend as be
+    B = B_PER_GPU
+    a = torch.randn(B, 256, H // 8, W // 8, device=device)
+    b = torch.randn(B, 256, H // 8, W // 8, device=device)
+    prm = (1, 1, 21, 21, 0, 0, 1, 1, 2, 2, 1, 1)
+    out = be.forward(a, b, *prm)
+    go = torch.randn_like(out)
+    t_f = event_time(lambda: be.forward(a, b, *prm), 10)
+    t_b = event_time(lambda: be.backward(a, b, go, *prm), 10)
+    ks = []
+    for name, t, w in (("corr_fwd_fast<21,2>", t_f, CORR_FWD), ("corr_bwd_fast<21,2> (both adjoints)", t_b, CORR_BWD)):
+        tf = w["gflop"] * B / t            # GFLOP/ms == TFLOP/s
+        gbs = w["mbytes"] * B / t          # MB/ms == GB/s
+        # arithmetic intensity 59-77 FLOP/B is above the fp32 ridge (~20): the bound is the fp32 VALU/MFMA rate
+        ks.append(dict(kernel=name, ms=round(t, 4), bound="mfma", achieved=round(tf, 2), peak=PEAK_FP32_TFLOPS,
+                       unit="TFLOP/s", frac=round(tf / PEAK_FP32_TFLOPS, 4), hbm_gbs=round(gbs, 1),
+                       hbm_frac=round(gbs / PEAK_HBM_GBS, 4)))
+    return ks
+
+
+def cpu_baseline():
+    """The CPU oracle on a bounded sample of the same workload: ONE attack() call of 2 iterations on
+    one 384x1280 pair (the reference's only batch size), all host threads."""
+    from oracle import flow_oracle as fo
+    from oracle import oracle_ops
+    from understanding_flow_robustness_amd.flownets.flownetc import FlowNetC
+    from understanding_flow_robustness_amd.flownets.weights import synthetic_state_dict
+    oracle_ops.lib()
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = synthetic_state_dict(FlowNetC().state_dict(), seed=0)
+    tgt, ref, mask = synthetic_batch(1, 1234, "cpu")
+    g = torch.Generator().manual_seed(99)
+    patch0 = torch.rand(1, 3, H, W, generator=g) * mask
+    predict = lambda x, y: fo.flownetc_forward(sd, x, y)
+    with torch.no_grad():
+        target = -predict(tgt, ref)           # clean forward doubles as the warm-up (main.py:371,395)
+    t0 = time.time()
+    _, _, _, n, _ = fo.patch_attack(predict, tgt, ref, patch0.clone(), mask, patch0, target, lr=1e3, max_count=2)
+    dt = time.time() - t0
+    return dict(value=round(n / dt, 4), unit="frame-pairs*steps/s", cores=cores, kind="port",
+                sample=f"1 attack() call, {n} iterations, 1 pair 384x1280, FlowNetC fp32, torch-CPU convs + C "
+                       f"oracle correlation (OpenMP over batch*channels; the reference's CPU backward is "
+                       f"single-threaded at batch 1), {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    opt = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    device = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(device)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from understanding_flow_robustness_amd.flownets.utils_model import fetch_model
+    from understanding_flow_robustness_amd.patch_attack import PatchAttackStep, ShardedExchange
+
+    torch.backends.cudnn.benchmark = True      # patch_attacks/main.py:276 (MIOpen find mode)
+    args = Namespace(flownet="FlowNetC", l2=False, alpha=0.0, lr=1000.0, max_count=2)
+    net = fetch_model(args, synthetic_seed=0).to(device)
+    exchange = ShardedExchange() if world > 1 else None
+    step = PatchAttackStep(net, args, B_PER_GPU, H, W, device=device, shared_patch=True, exchange=exchange,
+                           use_graph=not opt.no_graph, warmup=2)
+
+    tgt, ref, mask = synthetic_batch(B_PER_GPU, 1000 + rank, device)
+    g = torch.Generator().manual_seed(7)
+    patch0 = torch.rand(1, 3, H, W, generator=g).to(device)     # same patch on every rank
+    with torch.no_grad():
+        target = -torch.cat([net(tgt[i:i + 1], ref[i:i + 1]) for i in range(B_PER_GPU)])   # main.py:395
+    step.load(tgt, ref, patch0, mask, patch0, target)
+    step.run(0)                                                  # warm-up + graph capture, reloads operands
+    step.state.zero_()
+    step.state[0] = 0
+    # the throughput run must never trip the early exit: an iteration that is skipped is not work done
+    step.enqueue(opt.warmup)
+    torch.cuda.synchronize(device)
+    executed0 = float(step.state[1])
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    step.enqueue(opt.steps)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    executed = float(step.state[1]) - executed0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+    if int(executed) != opt.steps:
+        raise SystemExit(f"only {int(executed)} of {opt.steps} iterations took effect (loss gate tripped): "
+                         "the timed region would contain skipped work")
+
+    if rank == 0:
+        ms = elapsed * 1e3 / opt.steps
+        value = world * B_PER_GPU * opt.steps / elapsed
+        tf = GFLOP_PER_PAIR_STEP * B_PER_GPU / ms          # per-GPU TFLOP/s (GFLOP/ms)
+        line = {
+            "metric": "attack-iters/s", "value": round(value, 3), "unit": "frame-pairs*steps/s",
+            "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "FlowNetC 384x1280 I-FGSM patch attack (configs[1])", "pairs_per_gpu": B_PER_GPU,
+                       "global_pairs": world * B_PER_GPU, "patch": "51x51 circular, shared, canvas-sized update",
+                       "loss": "cosine", "lr": 1000.0, "weights": "synthetic seeded (no checkpoints offline)",
+                       "graph": not opt.no_graph,
+                       "parallelism": f"dp{world}: batch sharded, all-reduce of pre-clamp patch gradient"},
+            "roofline": {"bound": "mfma", "kernel": "attack step = 1 hipGraph launch (MIOpen fp32 convs + ufr_* kernels)",
+                         "achieved": round(tf, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tf / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                         "algorithmic_gflop_per_launch": round(GFLOP_PER_PAIR_STEP * B_PER_GPU, 1)},
+        }
+        if world == 1:
+            line["roofline"]["kernels"] = kernel_rooflines(device)
+            if not opt.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

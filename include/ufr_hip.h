@@ -139,7 +139,17 @@ int ufr_patch_paste(const float* tgt, const float* ref, const float* patch, cons
 int ufr_patch_update(const float* tgt, const float* ref, const float* g_tgt, const float* g_ref,
                      float* grad_sum, float* patch, const float* mask, float* adv_tgt,
                      float* adv_ref, int B, int CHW, long patch_bstride, long mask_bstride,
-                     float step, float bound, float lo, float hi, int mode, ufr_stream_t stream);
+                     float step, float bound, float lo, float hi, int mode, const float* gate_state,
+                     ufr_stream_t stream);
+/* Device-side form of the loop control of attack() (main.py:546 `while loss_scalar > 0.1`, :605
+ * `loss.item()`, :610 `count > max_count-1`): the reference synchronises the host every iteration
+ * to read the loss; here iterations are enqueued back to back and a 3-float state word decides on
+ * the device whether an iteration still takes effect.
+ *   state[0] = stopped (0/1), state[1] = iterations executed, state[2] = loss of the last one.
+ * ufr_patch_update(..., gate_state) is a no-op when gate_state != NULL and gate_state[0] != 0.
+ * ufr_attack_gate runs after it: if not stopped { state[1]+=1; state[2]=*loss_cur;
+ *   if (*loss_cur <= threshold) state[0]=1; }   -- exactly the reference's order of events. */
+int ufr_attack_gate(const float* loss_cur, float* state, float threshold, ufr_stream_t stream);
 /* ufr_flow_loss: loss = mean_b,h,w(1 - cos(flow, target))            (kind 0, main.py:564-566)
  *             or mean(sqrt(sum_c (flow-target)^2 + 1e-8))           (kind 1, main.py:557-562)
  *   flow,target: [B,2,H,W].  Writes d loss / d flow (already scaled by `weight`, = 1-alpha) to

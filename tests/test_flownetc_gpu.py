@@ -1,0 +1,185 @@
+"""GPU suite: FlowNetC + the fused patch-attack step against the reference's golden vectors and the
+CPU oracle (EPE / patch pixels within 1e-4 relative, BASELINE.json north_star)."""
+from argparse import Namespace
+
+import pytest
+import torch
+
+from conftest import assert_close, load_golden, t
+from test_flow_oracle_cpu import ATTACK_CASES
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+REL = 1e-4   # north_star tolerance for floating-point outputs
+
+
+@pytest.fixture(scope="module")
+def net():
+    from understanding_flow_robustness_amd.flownets.utils_model import fetch_model
+    return fetch_model(Namespace(flownet="FlowNetC"), synthetic_seed=0).to(DEV)
+
+
+@pytest.fixture(scope="module")
+def sd(net):
+    return {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+
+
+@pytest.mark.parametrize("case", ["flownetc_fwd_64x128", "flownetc_fwd_128x192"])
+def test_flownetc_forward_and_image_gradients_vs_reference(net, case):
+    from understanding_flow_robustness_amd import losses
+    z = load_golden(case)
+    x1, x2 = t(z["x1"], DEV).requires_grad_(True), t(z["x2"], DEV).requires_grad_(True)
+    flow = net(x1, x2)
+    assert_close(flow, t(z["flow"]), rtol=REL, atol_scale=REL, what="flow")
+    # EPE parity: end-point error between build and reference flow, relative to the flow magnitude
+    epe = (flow.detach().cpu() - t(z["flow"])).pow(2).sum(1).sqrt().mean()
+    mag = t(z["flow"]).pow(2).sum(1).sqrt().mean()
+    assert float(epe) <= REL * float(mag), f"EPE {float(epe):.3e} vs |flow| {float(mag):.3e}"
+    gt = t(z["target"], DEV)
+    assert abs(losses.compute_epe(gt, flow.detach()) - losses.compute_epe(gt.cpu(), t(z["flow"]))) \
+        <= REL * losses.compute_epe(gt.cpu(), t(z["flow"]))
+    loss = (1 - torch.nn.functional.cosine_similarity(flow, gt)).mean()
+    g1, g2 = torch.autograd.grad(loss, (x1, x2))
+    assert abs(float(loss) - float(z["loss"])) < 1e-5
+    assert_close(g1, t(z["g1"]), rtol=1e-3, atol_scale=2e-4, what="d loss / d frame 1")
+    assert_close(g2, t(z["g2"]), rtol=1e-3, atol_scale=2e-4, what="d loss / d frame 2")
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+@pytest.mark.parametrize("name,l2,lr", ATTACK_CASES)
+def test_attack_matches_reference_trace(net, name, l2, lr, use_graph):
+    """attack() of patch_attacks/main.py:523-613, 1 and 2 iterations, HIP-graph and eager forms."""
+    from understanding_flow_robustness_amd.patch_attack import attack
+    z = load_golden("attack_flownetc_64x128")
+    for iters in (1, 2):
+        args = Namespace(flownet="FlowNetC", l2=l2, alpha=0.0, lr=lr, max_count=iters)
+        patch = t(z["patch0"], DEV).clone()
+        a_t, none, a_r, out_patch = attack(net, t(z["tgt"], DEV), None, t(z["ref"], DEV), patch, t(z["mask"], DEV),
+                                           t(z["patch0"], DEV), t(z["target"], DEV), None, args=args,
+                                           use_graph=use_graph)
+        assert none is None and out_patch is patch            # in-place contract (main.py:581)
+        ref_patch = t(z[f"{name}_it{iters}_patch"])
+        upd = (ref_patch - t(z["patch0"])).abs().max()
+        err = (patch.cpu() - ref_patch).abs().max()
+        assert float(err) <= REL * max(float(upd), 1.0) + 2e-4 * float(upd), \
+            f"{name} it{iters}: patch err {float(err):.3e}, update magnitude {float(upd):.3e}"
+        assert_close(a_t[:, :, 20:45, 50:75], t(z[f"{name}_it{iters}_adv_tgt"]), rtol=REL, atol_scale=3e-4)
+        assert_close(a_r[:, :, 20:45, 50:75], t(z[f"{name}_it{iters}_adv_ref"]), rtol=REL, atol_scale=3e-4)
+
+
+def test_attack_fused_kernels_bit_exact_vs_torch(net):
+    """paste / update / loss kernels against the reference's own torch expressions on identical
+    inputs: elementwise stages are bit-exact, the loss scalar to fp32 summation order."""
+    import ctypes as C
+    from understanding_flow_robustness_amd import _lib as L
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 3, 24, 40
+    tgt, ref = torch.rand(B, 3, H, W, generator=g).to(DEV), torch.rand(B, 3, H, W, generator=g).to(DEV)
+    mask = (torch.rand(B, 3, H, W, generator=g) > 0.5).float().to(DEV)
+    patch = (torch.rand(1, 3, H, W, generator=g) * 3 - 1).to(DEV)
+    a_t, a_r = torch.empty_like(tgt), torch.empty_like(tgt)
+    CHW = 3 * H * W
+    L.check(L.lib().ufr_patch_paste(L.ptr(tgt), L.ptr(ref), L.ptr(patch), L.ptr(mask), L.ptr(a_t), L.ptr(a_r), B,
+                                    CHW, 0, CHW, 0, 0.0, 1.0, L.stream()))
+    assert torch.equal(a_t, torch.mul(1 - mask, tgt) + torch.mul(mask, patch))
+    assert torch.equal(a_r, torch.mul(1 - mask, ref) + torch.mul(mask, patch))
+    g_t, g_r = torch.randn(B, 3, H, W, generator=g).to(DEV) * 1e-3, torch.randn(B, 3, H, W, generator=g).to(DEV) * 1e-3
+    gsum = torch.zeros(CHW + 1, device=DEV)
+    p2 = patch.clone()
+    L.check(L.lib().ufr_patch_update(L.ptr(tgt), L.ptr(ref), L.ptr(g_t), L.ptr(g_r), L.ptr(gsum), L.ptr(p2),
+                                     L.ptr(mask), L.ptr(a_t), L.ptr(a_r), B, CHW, 0, CHW, 500.0, 2.0, 0.0, 1.0, 0,
+                                     None, L.stream()))
+    s = torch.zeros(1, 3, H, W, device=DEV)
+    for b in range(B):
+        s = s + (g_t[b:b + 1] + g_r[b:b + 1])
+    want = patch - torch.clamp(500.0 * s, -2, 2)
+    assert torch.equal(p2, want)
+    assert torch.equal(a_t, torch.clamp(torch.mul(1 - mask, tgt) + torch.mul(mask, want), 0, 1))
+    flow, target = torch.randn(B, 2, H, W, generator=g).to(DEV), torch.randn(B, 2, H, W, generator=g).to(DEV)
+    for kind in (0, 1):
+        f = flow.clone().requires_grad_(True)
+        if kind == 0:
+            ref_loss = (1 - torch.nn.functional.cosine_similarity(f, target)).mean()
+        else:
+            ref_loss = (torch.sum((f - target) ** 2, dim=1) + 1e-8).sqrt().mean()
+        (ref_g,) = torch.autograd.grad(ref_loss, f)
+        gf, loss = torch.empty_like(flow), torch.zeros(1, device=DEV)
+        L.check(L.lib().ufr_flow_loss(L.ptr(flow), L.ptr(target), L.ptr(gf), L.ptr(loss), B, H * W, kind, 1.0,
+                                      L.stream()))
+        assert abs(float(loss) - float(ref_loss)) < 1e-5
+        assert_close(gf, ref_g, rtol=1e-4, atol_scale=1e-5, what=f"loss kind {kind} gradient")
+
+
+def test_attack_gate_semantics(net):
+    """`while loss_scalar > 0.1` + `count > max_count-1` on the device: once the loss of iteration k is
+    <= 0.1 the later replays leave patch and frames untouched."""
+    from understanding_flow_robustness_amd.patch_attack import PatchAttackStep
+    args = Namespace(flownet="FlowNetC", l2=False, alpha=0.0, lr=1e3, max_count=4)
+    step = PatchAttackStep(net, args, 1, 64, 128, device=DEV)
+    g = torch.Generator().manual_seed(5)
+    tgt, ref = torch.rand(1, 3, 64, 128, generator=g).to(DEV), torch.rand(1, 3, 64, 128, generator=g).to(DEV)
+    mask = torch.zeros(1, 3, 64, 128, device=DEV)
+    mask[:, :, 10:30, 10:30] = 1
+    patch = torch.rand(1, 3, 64, 128, generator=g).to(DEV)
+    with torch.no_grad():
+        flow = net(tgt * (1 - mask) + mask * patch, ref * (1 - mask) + mask * patch)
+    step.load(tgt, ref, patch, mask, patch, flow)          # target == current flow -> loss ~ 0 at once
+    n, loss = step.run(4)
+    assert n == 1 and loss <= 0.1
+    after_one = step.patch.clone()
+    step.enqueue(3)
+    torch.cuda.synchronize()
+    assert torch.equal(step.patch, after_one)
+    step.load(tgt, ref, patch, mask, patch, -flow)         # opposite target: never converges in 3
+    n, loss = step.run(3)
+    assert n == 3 and loss > 0.1
+
+
+def test_batched_shared_patch_vs_oracle(net, sd, oracle):
+    from oracle import flow_oracle as fo
+    from understanding_flow_robustness_amd.patch_attack import attack
+    g = torch.Generator().manual_seed(17)
+    tgt, ref = torch.rand(2, 3, 64, 128, generator=g), torch.rand(2, 3, 64, 128, generator=g)
+    mask = torch.zeros(2, 3, 64, 128)
+    mask[0, :, 10:30, 20:40] = 1
+    mask[1, :, 30:50, 80:100] = 1
+    patch0 = torch.rand(1, 3, 64, 128, generator=g)
+    target = torch.randn(2, 2, 64, 128, generator=g)
+    cpu_patch = patch0.clone()
+    c_t, c_r, cpu_patch, n, _ = fo.patch_attack(lambda a, b: fo.flownetc_forward(sd, a, b), tgt, ref, cpu_patch,
+                                                mask, patch0, target, lr=1e5, max_count=2)
+    args = Namespace(flownet="FlowNetC", l2=False, alpha=0.0, lr=1e5, max_count=2)
+    gpu_patch = patch0.clone().to(DEV)
+    a_t, _, a_r, _ = attack(net, tgt.to(DEV), None, ref.to(DEV), gpu_patch, mask.to(DEV), patch0.to(DEV),
+                            target.to(DEV), None, args=args)
+    upd = float((cpu_patch - patch0).abs().max())
+    assert float((gpu_patch.cpu() - cpu_patch).abs().max()) <= 3e-4 * max(upd, 1.0)
+    assert_close(a_t, c_t, rtol=REL, atol_scale=3e-4)
+
+
+def test_attack_full_size_properties(net):
+    """BASELINE config C2 (384x1280, batch 8): size-independent properties -- pixels outside the mask
+    are exactly clamp(frame), two identical runs give identical bits (no atomics on the patch path),
+    and the iteration count is the requested one."""
+    from understanding_flow_robustness_amd.patch_attack import PatchAttackStep
+    B, H, W = 8, 384, 1280
+    args = Namespace(flownet="FlowNetC", l2=False, alpha=0.0, lr=1e3, max_count=2)
+    step = PatchAttackStep(net, args, B, H, W, device=DEV)
+    g = torch.Generator().manual_seed(0)
+    tgt, ref = torch.rand(B, 3, H, W, generator=g).to(DEV), torch.rand(B, 3, H, W, generator=g).to(DEV)
+    mask = torch.zeros(B, 3, H, W, device=DEV)
+    for b in range(B):
+        mask[b, :, 100 + 5 * b:151 + 5 * b, 600 - 30 * b:651 - 30 * b] = 1
+    patch = torch.rand(1, 3, H, W, generator=g).to(DEV)
+    with torch.no_grad():
+        target = -torch.cat([net(tgt[i:i + 1], ref[i:i + 1]) for i in range(B)])
+    outs = []
+    for _ in range(2):
+        step.load(tgt, ref, patch, mask, patch, target)
+        n, loss = step.run(2)
+        assert n == 2 and loss == loss
+        outs.append((step.patch.clone(), step.adv_tgt.detach().clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    outside = mask == 0
+    assert torch.equal(outs[0][1][outside], tgt.clamp(0, 1)[outside])
+    assert float((outs[0][0] - patch).abs().max()) > 0

@@ -53,7 +53,8 @@ SIGNATURES = {
     "ufr_channelnorm_backward": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ufr_patch_paste": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _l, _i, _f, _f, _vp],
     "ufr_patch_update": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _l, _f, _f, _f,
-                         _f, _i, _vp],
+                         _f, _i, _vp, _vp],
+    "ufr_attack_gate": [_vp, _vp, _f, _vp],
     "ufr_flow_loss": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
 }
 PLAIN = {"ufr_abi_version": (C.c_int, []), "ufr_last_error": (C.c_char_p, []),

@@ -37,7 +37,11 @@ __global__ void update_shared_kernel(const float* __restrict__ tgt, const float*
                                      float* __restrict__ grad_sum, float* __restrict__ patch,
                                      const float* __restrict__ mask, float* __restrict__ adv_tgt,
                                      float* __restrict__ adv_ref, int B, long CHW, long mstride,
-                                     float step, float bound, float lo, float hi, int mode) {
+                                     float step, float bound, float lo, float hi, int mode,
+                                     const float* __restrict__ gate) {
+  // attack already converged: the iteration is void (mode 1 still refreshes the exchange buffer so
+  // the collective that follows never re-sums stale data)
+  if (mode != 1 && gate != nullptr && gate[0] != 0.f) return;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < CHW;
        e += (long)gridDim.x * blockDim.x) {
     float gs;
@@ -66,7 +70,8 @@ __global__ void update_private_kernel(const float* __restrict__ tgt, const float
                                       float* __restrict__ patch, const float* __restrict__ mask,
                                       float* __restrict__ adv_tgt, float* __restrict__ adv_ref,
                                       long total, long CHW, long pstride, long mstride, float step,
-                                      float bound, float lo, float hi) {
+                                      float bound, float lo, float hi, const float* __restrict__ gate) {
+  if (gate != nullptr && gate[0] != 0.f) return;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long)gridDim.x * blockDim.x) {
     const long b = i / CHW, e = i - b * CHW;
@@ -134,7 +139,22 @@ __global__ void flow_loss_kernel(const float* __restrict__ flow, const float* __
   }
 }
 
+__global__ void gate_kernel(const float* __restrict__ loss_cur, float* __restrict__ state, float thr) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && state[0] == 0.f) {
+    const float l = *loss_cur;
+    state[1] += 1.f;
+    state[2] = l;
+    if (!(l > thr)) state[0] = 1.f;   // `while loss_scalar > 0.1`: a NaN loss also ends the loop
+  }
+}
+
 }  // namespace
+
+extern "C" int ufr_attack_gate(const float* loss_cur, float* state, float threshold, ufr_stream_t stream) {
+  UFR_REQUIRE(loss_cur && state, "attack gate: null pointer argument");
+  hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(64), 0, ufr::as_stream(stream), loss_cur, state, threshold);
+  return ufr::launched("gate_kernel");
+}
 
 extern "C" int ufr_patch_paste(const float* tgt, const float* ref, const float* patch,
                                const float* mask, float* adv_tgt, float* adv_ref, int B, int CHW,
@@ -153,7 +173,8 @@ extern "C" int ufr_patch_update(const float* tgt, const float* ref, const float*
                                 const float* g_ref, float* grad_sum, float* patch,
                                 const float* mask, float* adv_tgt, float* adv_ref, int B, int CHW,
                                 long patch_bstride, long mask_bstride, float step, float bound,
-                                float lo, float hi, int mode, ufr_stream_t stream) {
+                                float lo, float hi, int mode, const float* gate_state,
+                                ufr_stream_t stream) {
   UFR_REQUIRE(B > 0 && CHW > 0, "patch update: bad shape");
   UFR_REQUIRE(mode >= 0 && mode <= 2, "patch update: bad mode %d", mode);
   hipStream_t st = ufr::as_stream(stream);
@@ -164,7 +185,7 @@ extern "C" int ufr_patch_update(const float* tgt, const float* ref, const float*
     const long total = (long)B * CHW;
     hipLaunchKernelGGL(update_private_kernel, dim3(ufr::stream_grid(total, 256)), dim3(256), 0, st,
                        tgt, ref, g_tgt, g_ref, patch, mask, adv_tgt, adv_ref, total, (long)CHW,
-                       patch_bstride, mask_bstride, step, bound, lo, hi);
+                       patch_bstride, mask_bstride, step, bound, lo, hi, gate_state);
     return ufr::launched("update_private_kernel");
   }
   if (mode != 2) UFR_REQUIRE(g_tgt && g_ref, "patch update: null gradient pointer");
@@ -173,7 +194,7 @@ extern "C" int ufr_patch_update(const float* tgt, const float* ref, const float*
     UFR_REQUIRE(tgt && ref && patch && mask && adv_tgt && adv_ref, "patch update: null pointer argument");
   hipLaunchKernelGGL(update_shared_kernel, dim3(ufr::stream_grid(CHW, 256)), dim3(256), 0, st, tgt,
                      ref, g_tgt, g_ref, grad_sum, patch, mask, adv_tgt, adv_ref, B, (long)CHW,
-                     mask_bstride, step, bound, lo, hi, mode);
+                     mask_bstride, step, bound, lo, hi, mode, gate_state);
   return ufr::launched("update_shared_kernel");
 }
 

@@ -1,0 +1,109 @@
+"""FlowNetC (39.2 M parameters) on the gfx950 correlation kernel.
+
+Behavioural mirror of models/FlowNetC.py:11-197 + models/submodules.py:18-138 of the reference
+(same layer names -> the reference's `FlowNet2-C_checkpoint.pth.tar` state_dict loads unchanged):
+siamese conv1-3, 21x21 stride-2 correlation (`correlate`: view + /C), LeakyReLU(0.1), conv_redir,
+conv3_1..conv6_1, coarse-to-fine refinement, flow2*20 upsampled x4.
+The two siamese towers run as ONE batch of 2B images (same arithmetic per image, half the launches).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..spatial_correlation_sampler import spatial_correlation_sample
+
+# models/FlowNetC.py:73-79 -- RGB mean, subtracted in float64 and cast back
+_RGB_MEAN = (0.40066648, 0.39482617, 0.3784785)
+
+
+def _conv(cin, cout, k=3, stride=1):
+    """submodules.py:18-46 (batchNorm=False branch): conv + LeakyReLU(0.1)."""
+    return nn.Sequential(nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, bias=True), nn.LeakyReLU(0.1, inplace=True))
+
+
+def _deconv(cin, cout):
+    """submodules.py:75-82."""
+    return nn.Sequential(nn.ConvTranspose2d(cin, cout, 4, 2, 1, bias=True), nn.LeakyReLU(0.1, inplace=True))
+
+
+def correlate(input1, input2, patch_size=21, dilation_patch=2):
+    """submodules.py:124-138: cost volume as a 4-D tensor [B, P*P, H, W], divided by C."""
+    out = spatial_correlation_sample(input1, input2, kernel_size=1, patch_size=patch_size, stride=1,
+                                     padding=0, dilation_patch=dilation_patch)
+    b, ph, pw, h, w = out.size()
+    return out.view(b, ph * pw, h, w) / input1.size(1)
+
+
+class FlowNetC(nn.Module):
+    # (name, in, out, kernel, stride) in the reference's construction order
+    _ENCODER = (("conv1", 3, 64, 7, 2), ("conv2", 64, 128, 5, 2), ("conv3", 128, 256, 5, 2),
+                ("conv_redir", 256, 32, 1, 1), ("conv3_1", 473, 256, 3, 1), ("conv4", 256, 512, 3, 2),
+                ("conv4_1", 512, 512, 3, 1), ("conv5", 512, 512, 3, 2), ("conv5_1", 512, 512, 3, 1),
+                ("conv6", 512, 1024, 3, 2), ("conv6_1", 1024, 1024, 3, 1))
+    _DECODER = (("deconv5", 1024, 512), ("deconv4", 1026, 256), ("deconv3", 770, 128), ("deconv2", 386, 64))
+    _HEADS = (("predict_flow6", 1024), ("predict_flow5", 1026), ("predict_flow4", 770),
+              ("predict_flow3", 386), ("predict_flow2", 194))
+    _UPS = ("upsampled_flow6_to_5", "upsampled_flow5_to_4", "upsampled_flow4_to_3", "upsampled_flow3_to_2")
+
+    def __init__(self, batchNorm=False, div_flow=20, return_feat_maps=False):
+        super().__init__()
+        if batchNorm:
+            raise NotImplementedError("the attack path uses the batchNorm=False checkpoints")
+        self.div_flow, self.return_feat_maps = div_flow, return_feat_maps
+        for name, cin, cout, k, s in self._ENCODER:
+            setattr(self, name, _conv(cin, cout, k, s))
+        for name, cin, cout in self._DECODER:
+            setattr(self, name, _deconv(cin, cout))
+        for name, cin in self._HEADS:
+            setattr(self, name, nn.Conv2d(cin, 2, 3, 1, 1, bias=True))
+        for name in self._UPS:
+            setattr(self, name, nn.ConvTranspose2d(2, 2, 4, 2, 1, bias=True))
+        for m in self.modules():                       # FlowNetC.py:53-63
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                nn.init.uniform_(m.bias)
+                nn.init.xavier_uniform_(m.weight)
+        self.register_buffer("_mean64", torch.tensor(_RGB_MEAN, dtype=torch.float64).view(1, 3, 1, 1),
+                             persistent=False)
+
+    def normalize_correctly(self, im):
+        """FlowNetC.py:73-79,93-94: float64 mean subtraction, then back to float32."""
+        return (im.double() - self._mean64).float()
+
+    def forward(self, x1, x2, overwrite_feat_maps=None):
+        if overwrite_feat_maps is not None:
+            raise NotImplementedError("feature-map overwriting belongs to the analysis scripts (out of scope)")
+        B = x1.shape[0]
+        x = self.normalize_correctly(torch.cat((x1, x2), 0))
+        c1 = self.conv1(x)
+        c2 = self.conv2(c1)
+        c3 = self.conv3(c2)
+        c2a, c3a, c3b = c2[:B], c3[:B], c3[B:]
+        feats = [c1[:B], c2a, c3a, c1[B:], c2[B:], c3b] if self.return_feat_maps else None
+
+        out_corr = correlate(c3a.contiguous(), c3b.contiguous())
+        if feats is not None:
+            feats.append(out_corr.clone())
+        out_corr = F.leaky_relu(out_corr, 0.1)
+        in_conv3_1 = torch.cat((self.conv_redir(c3a), out_corr), 1)
+
+        c3_1 = self.conv3_1(in_conv3_1)
+        c4 = self.conv4_1(self.conv4(c3_1))
+        c5 = self.conv5_1(self.conv5(c4))
+        c6 = self.conv6_1(self.conv6(c5))
+
+        flow6 = self.predict_flow6(c6)
+        cat5 = torch.cat((c5, self.deconv5(c6), self.upsampled_flow6_to_5(flow6)), 1)
+        flow5 = self.predict_flow5(cat5)
+        cat4 = torch.cat((c4, self.deconv4(cat5), self.upsampled_flow5_to_4(flow5)), 1)
+        flow4 = self.predict_flow4(cat4)
+        cat3 = torch.cat((c3_1, self.deconv3(cat4), self.upsampled_flow4_to_3(flow4)), 1)
+        flow3 = self.predict_flow3(cat3)
+        cat2 = torch.cat((c2a, self.deconv2(cat3), self.upsampled_flow3_to_2(flow3)), 1)
+        flow2 = self.predict_flow2(cat2)
+
+        up = lambda f: F.interpolate(f * self.div_flow, scale_factor=4, mode="bilinear", align_corners=False)
+        if self.training:
+            return tuple(up(f) for f in (flow2, flow3, flow4, flow5, flow6))
+        return (up(flow2), feats) if self.return_feat_maps else up(flow2)
