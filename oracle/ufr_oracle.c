@@ -403,3 +403,9 @@ void ufr_oracle_corr_lookup_f32(const float* const* levels, const int* Hl, const
     }
   }
 }
+
+/* Host-thread control for the cpu_baseline leg of bench.py (the library may be loaded after the
+ * OpenMP runtime has already sized its pool from the environment). */
+#include <omp.h>
+void ufr_oracle_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int ufr_oracle_max_threads(void) { return omp_get_max_threads(); }

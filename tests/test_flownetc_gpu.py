@@ -159,8 +159,8 @@ def test_batched_shared_patch_vs_oracle(net, sd, oracle):
 
 def test_attack_full_size_properties(net):
     """BASELINE config C2 (384x1280, batch 8): size-independent properties -- pixels outside the mask
-    are exactly clamp(frame), two identical runs give identical bits (no atomics on the patch path),
-    and the iteration count is the requested one."""
+    are exactly clamp(frame), two identical runs agree (MIOpen's data-gradient kernels are not
+    bit-reproducible, so to 1e-4 of the update), and the iteration count is the requested one."""
     from understanding_flow_robustness_amd.patch_attack import PatchAttackStep
     B, H, W = 8, 384, 1280
     args = Namespace(flownet="FlowNetC", l2=False, alpha=0.0, lr=1e3, max_count=2)
@@ -179,7 +179,9 @@ def test_attack_full_size_properties(net):
         n, loss = step.run(2)
         assert n == 2 and loss == loss
         outs.append((step.patch.clone(), step.adv_tgt.detach().clone()))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    upd = float((outs[0][0] - patch).abs().max())
+    assert float((outs[0][0] - outs[1][0]).abs().max()) <= 1e-4 * max(upd, 1.0)
+    assert float((outs[0][1] - outs[1][1]).abs().max()) <= 1e-4
     outside = mask == 0
     assert torch.equal(outs[0][1][outside], tgt.clamp(0, 1)[outside])
     assert float((outs[0][0] - patch).abs().max()) > 0

@@ -104,6 +104,19 @@ def test_corr_fast_path_properties(ops, oracle, shape, patch, dp):
     assert_close(g2[:1], r2, rtol=1e-4, atol_scale=2e-6, what="grad2 sample 0 vs oracle")
 
 
+def test_corr_kernels_are_bit_reproducible(ops):
+    """No atomics on the correlation path: two launches give identical bits."""
+    g = torch.Generator().manual_seed(4)
+    a = torch.randn(2, 256, 48, 160, generator=g).to(DEV)
+    b = torch.randn(2, 256, 48, 160, generator=g).to(DEV)
+    prm = (1, 1, 21, 21, 0, 0, 1, 1, 2, 2, 1, 1)
+    o1, o2 = ops["be"].forward(a, b, *prm), ops["be"].forward(a, b, *prm)
+    assert torch.equal(o1, o2)
+    go = torch.randn(o1.shape, generator=g).to(DEV)
+    x, y = ops["be"].backward(a, b, go, *prm), ops["be"].backward(a, b, go, *prm)
+    assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1])
+
+
 def test_corr_autograd_module_and_gradcheck(ops):
     """check.py / grad_check.py of the reference, on the device path (float64 finite differences)."""
     from understanding_flow_robustness_amd.spatial_correlation_sampler import SpatialCorrelationSampler

@@ -16,9 +16,17 @@ reference's own `models/*.py` import them unchanged.
 from __future__ import annotations
 
 import importlib
+import os
 import sys
 
 __version__ = "0.1.0"
+
+# MIOpen's exhaustive search (cudnn.benchmark=True, patch_attacks/main.py:276) also times its naive
+# reference solvers -- ~100 ms per launch at 384x1280, tens of seconds of warm-up.  They are never
+# the winner; keep them out of the search (must be set before MIOpen is first used).
+for _k in ("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_BWD",
+           "MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_WRW"):
+    os.environ.setdefault(_k, "0")
 
 _ALIASES = {
     "spatial_correlation_sampler_backend": ".spatial_correlation_sampler_backend",

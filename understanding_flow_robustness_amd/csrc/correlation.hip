@@ -424,6 +424,9 @@ extern "C" int ufr_corr_forward_fused(const void* input1, const void* input2, vo
     const float* a = (const float*)input1;
     const float* b = (const float*)input2;
     float* o = (float*)output;
+    // aligned single-tile rows: vectorised staging path (correlation_vec.hip); 1 = not covered
+    const int vrc = ufr::corr_fwd_vec_launch(a, b, o, B, C, H, W, p->patchH, p->dilation_patchH, scale, slope, st);
+    if (vrc <= 0) return vrc;
     // few rows in flight -> split the displacement rows finer so that >= ~2 workgroups per CU exist
     const long rows = (long)B * H;
     if (p->patchH == 21)
@@ -461,7 +464,9 @@ extern "C" int ufr_corr_backward(const void* input1, const void* input2, const v
     const float* a = (const float*)input1;
     const float* b = (const float*)input2;
     const float* g = (const float*)grad_output;
-    int rc;
+    int rc = ufr::corr_bwd_vec_launch(a, b, g, (float*)grad_input1, (float*)grad_input2, B, C, H, W,
+                                      p->patchH, p->dilation_patchH, st);
+    if (rc <= 0) return rc;
     if (p->patchH == 21) {
       rc = launch_bwd_fast<21, 2, 32, 4, false>(b, g, (float*)grad_input1, B, C, H, W, st);
       if (rc) return rc;

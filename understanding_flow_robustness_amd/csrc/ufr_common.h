@@ -37,6 +37,12 @@ inline int stream_grid(long n, int block) {
   return (int)g;
 }
 
+// correlation_vec.hip: 0 = launched, 1 = shape not covered (use the general fast path), <0 = error
+int corr_fwd_vec_launch(const float* in1, const float* in2, float* out, int B, int C, int H, int W, int P,
+                        int DP, float scale, float slope, hipStream_t st);
+int corr_bwd_vec_launch(const float* in1, const float* in2, const float* gout, float* gin1, float* gin2,
+                        int B, int C, int H, int W, int P, int DP, hipStream_t st);
+
 }  // namespace ufr
 
 #define UFR_REQUIRE(cond, ...) \
