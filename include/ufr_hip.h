@@ -157,6 +157,29 @@ int ufr_attack_gate(const float* loss_cur, float* state, float threshold, ufr_st
 int ufr_flow_loss(const float* flow, const float* target, float* grad_flow, float* loss, int B,
                   int HW, int kind, float weight, ufr_stream_t stream);
 
+/* ---- universal perturbation / I-FGSM inner loop, elementwise stages ------------------------------
+ * replaces global_attacks/perturb_model.py:102-145 (compute_flow_loss) and the tensor arithmetic of
+ * global_attacks/universal_perturbation.py:477-520 (attack), :667-675 (add_universal_perturbation).
+ *
+ * ufr_flow_loss_ex: kind 0 cossim, 1 l2 (sqrt(.+10e-8)), 2 l1; gt has 2 channels, or 3 with a
+ *   validity mask in the last one.  scale = 1/(averaged element count) or 1/(sum(valid)+1e-8), taken
+ *   from *scale_dev when that device pointer is non-NULL (so a captured graph follows new masks),
+ *   else from `scale`.  Writes d loss/d flow, accumulates the scalar into *loss. */
+int ufr_flow_loss_ex(const float* flow, const float* gt, float* grad_flow, float* loss, int B, int HW,
+                     int gt_channels, int kind, float scale, const float* scale_dev, ufr_stream_t stream);
+/* ufr_universal_update: one sign-gradient step on both frames.
+ *   shared = 0: the reference's per-sample arithmetic; delta is [B,2,3,H,W]
+ *       adv = clamp(adv -/+ lr*dir(g), lo, hi); noise = clamp(adv - img, +-eps); adv = img + noise
+ *   shared = 1: one perturbation [2,3,H,W] for the whole (sharded) batch, direction from the SUM of
+ *       the per-sample gradients; modes as in ufr_patch_update (0 fused, 1 sum only -> grad_sum
+ *       [2*CHW], 2 apply grad_sum) so an all-reduce can sit between 1 and 2.
+ *   use_sign: 1 = I-FGSM (torch.sign), 0 = "ifgm"; frames: bit 0 = frame 0, bit 1 = frame 1
+ *   (perturb_mode both/left/right); ascent: 0 = gradient descent (default), 1 = --add_gaussian. */
+int ufr_universal_update(const float* img0, const float* img1, const float* g0, const float* g1,
+                         float* grad_sum, float* adv0, float* adv1, float* delta, int B, int CHW,
+                         float lr, float eps, float lo, float hi, int use_sign, int frames, int ascent,
+                         int shared, int mode, ufr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

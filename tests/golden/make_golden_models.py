@@ -95,4 +95,129 @@ def gen_losses():
          cos2=losses.compute_cossim(gt2, pred), cos3=losses.compute_cossim(gt3, pred))
 
 
-GENERATORS = {"flownetc": gen_flownetc, "attack": gen_attack, "losses": gen_losses}
+def gen_pwc():
+    """PWC-DC-Net (models/PWCNet.py:225-367): forward flow + image gradients at 128x192 and one
+    attack() call (2 iterations) through patch_attacks/main.py with --flownet PWCNet."""
+    mod = rh.ref_module("models.PWCNet")
+    main = rh.ref_module("patch_attacks.main")
+    net = mod.PWCDCNet().eval()
+    sd = synthetic_state_dict(net.state_dict(), seed=1)
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(61)
+    B, H, W = 1, 128, 192
+    x1 = torch.rand(B, 3, H, W, generator=g).requires_grad_(True)
+    x2 = torch.rand(B, 3, H, W, generator=g).requires_grad_(True)
+    flow = net(x1, x2)
+    tgt = torch.randn(flow.shape, generator=g)
+    loss = (1 - torch.nn.functional.cosine_similarity(flow, tgt)).mean()
+    loss.backward()
+    out = dict(x1=x1, x2=x2, flow=flow, target=tgt, loss=loss, g1=x1.grad, g2=x2.grad,
+               weight_digest=state_dict_digest(sd), weight_seed=1)
+    # attack trace on sample 0
+    a, b = x1[:1].detach(), x2[:1].detach()
+    patch0, mask = _circle_canvas(H, W, 31, 40, 70, g)
+    with torch.no_grad():
+        target = -net(a, b)
+    for iters in (1, 2):
+        main.args = Namespace(flownet="PWCNet", l2=False, alpha=0.0, lr=1.0e4, max_count=iters, log_terminal=False)
+        patch = patch0.clone()
+        _, _, _, p = main.attack(net, a.clone(), None, b.clone(), patch, mask.clone(), patch0.clone(),
+                                 target.clone(), None)
+        out[f"attack_it{iters}_patch"] = p
+    out.update(patch0=patch0, mask=mask, attack_target=target)
+    save("pwcnet_128x192", **out)
+
+
+def gen_raft():
+    """RAFT (models/raft/raft.py:124-233) as fetch_model builds it (utils_model.py:49-75), fp32,
+    12 iterations, through predict_flow (x255, test_mode) -- flow, image gradients, one attack()."""
+    raft = rh.ref_module("models.raft.raft")
+    um = rh.ref_module("models.utils_model")
+    main = rh.ref_module("patch_attacks.main")
+    args = Namespace(flownet="RAFT", small=False, mixed_precision=False, alternate_corr=False, fnorm="instance",
+                     cnorm="batch", no_separate_context=False, corr_levels=4, iters=12, flowNetCEnc=False,
+                     update_no_motion_downsampling=False)
+    net = raft.RAFT(args).eval()
+    sd = synthetic_state_dict(net.state_dict(), seed=2)
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(71)
+    H, W = 128, 192
+    x1 = torch.rand(1, 3, H, W, generator=g).requires_grad_(True)
+    x2 = torch.rand(1, 3, H, W, generator=g).requires_grad_(True)
+    flow = um.predict_flow(net, None, x1, x2, args)
+    tgt = torch.randn(flow.shape, generator=g)
+    loss = (1 - torch.nn.functional.cosine_similarity(flow, tgt)).mean()
+    loss.backward()
+    out = dict(x1=x1, x2=x2, flow=flow, target=tgt, loss=loss, g1=x1.grad, g2=x2.grad,
+               weight_digest=state_dict_digest(sd), weight_seed=2)
+    a, b = x1.detach(), x2.detach()
+    patch0, mask = _circle_canvas(H, W, 31, 40, 70, g)
+    with torch.no_grad():
+        target = -um.predict_flow(net, None, a, b, args)
+    main.args = Namespace(flownet="RAFT", l2=False, alpha=0.0, lr=1.0e4, max_count=2, log_terminal=False,
+                          **{k: v for k, v in vars(args).items() if k != "flownet"})
+    patch = patch0.clone()
+    _, _, _, p = main.attack(net, a.clone(), None, b.clone(), patch, mask.clone(), patch0.clone(), target.clone(), None)
+    out.update(patch0=patch0, mask=mask, attack_target=target, attack_it2_patch=p)
+    save("raft_128x192", **out)
+
+
+def gen_universal():
+    """global_attacks/universal_perturbation.py::attack (:452-530) run verbatim on FlowNetC:
+    3 sign-gradient steps, cossim and masked-l2 losses."""
+    import sys
+    argv, sys.argv = sys.argv, ["universal_perturbation.py"]
+    try:
+        up = rh.ref_module("global_attacks.universal_perturbation")
+    finally:
+        sys.argv = argv
+    net, sd = _ref_flownetc(seed=0)
+    H, W = 64, 128
+    g = torch.Generator().manual_seed(81)
+    img0 = torch.rand(1, 3, H, W, generator=g)
+    img1 = torch.rand(1, 3, H, W, generator=g)
+    delta0 = (torch.rand(1, 2, 3, H, W, generator=g) * 2 - 1) * 0.01
+    with torch.no_grad():
+        clean = net(img0, img1)
+    valid = (torch.rand(1, 1, H, W, generator=g) > 0.2).float()
+    out = dict(img0=img0, img1=img1, delta0=delta0, clean=clean, valid=valid,
+               weight_digest=state_dict_digest(sd), weight_seed=0)
+    for tag, flow_loss, target in (("cossim", "cossim", -clean), ("l2masked", "l2", torch.cat((-clean, valid), 1))):
+        args = Namespace(flownet="FlowNetC", n_step=3, learning_rate=2e-3, output_norm=0.02, flow_loss=flow_loss,
+                         perturb_method="ifgsm", perturb_mode="both", add_gaussian=False)
+        a0, _, a1, d = up.attack(net, img0.clone(), img1.clone(), delta0.clone(), target.clone(), args)
+        out[f"{tag}_adv0"], out[f"{tag}_adv1"], out[f"{tag}_delta"] = a0, a1, d
+    save("universal_flownetc_64x128", **out)
+
+
+def gen_flownet2():
+    """models/flownet2_models.py:122-205.  Resample2d / ChannelNorm are CUDA-only in the reference,
+    so the reference's model code is run with `resample2d_cuda` / `channelnorm_cuda` bound to the C
+    oracle (oracle/oracle_ops.py): this pins the wiring, layer order and every quirk of the model,
+    while those two ops stay 'pinned by restatement only' (SURVEY.md 8c)."""
+    import sys
+    import types
+    from oracle import oracle_ops as oo
+    for name, fwd, bwd in (("resample2d_cuda", oo.resample2d_forward, oo.resample2d_backward),
+                           ("channelnorm_cuda", oo.channelnorm_forward, oo.channelnorm_backward)):
+        m = types.ModuleType(name)
+        m.forward, m.backward = fwd, bwd
+        sys.modules[name] = m
+    mod = rh.ref_module("models.flownet2_models")
+    net = mod.FlowNet2().eval()
+    sd = synthetic_state_dict(net.state_dict(), seed=3)
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(91)
+    H, W = 64, 128
+    x1 = torch.rand(1, 3, H, W, generator=g).requires_grad_(True)
+    x2 = torch.rand(1, 3, H, W, generator=g).requires_grad_(True)
+    flow = net(x1, x2)
+    tgt = torch.randn(flow.shape, generator=g)
+    loss = (1 - torch.nn.functional.cosine_similarity(flow, tgt)).mean()
+    loss.backward()
+    save("flownet2_64x128", x1=x1, x2=x2, flow=flow, target=tgt, loss=loss, g1=x1.grad, g2=x2.grad,
+         weight_digest=state_dict_digest(sd), weight_seed=3)
+
+
+GENERATORS = {"flownetc": gen_flownetc, "attack": gen_attack, "losses": gen_losses, "pwc": gen_pwc,
+              "raft": gen_raft, "universal": gen_universal, "flownet2": gen_flownet2}

@@ -1,0 +1,119 @@
+"""CPU suite, part 4: PWC-Net, RAFT, FlowNet2 and the universal-perturbation loop -- the oracle
+restatements against golden vectors captured from the reference's own modules."""
+from argparse import Namespace
+
+import pytest
+import torch
+
+from conftest import assert_close, load_golden, t
+
+
+def _sd(cls_factory, seed, golden):
+    from understanding_flow_robustness_amd.flownets.weights import state_dict_digest, synthetic_state_dict
+    sd = synthetic_state_dict(cls_factory().state_dict(), seed=seed)
+    assert state_dict_digest(sd) == float(load_golden(golden)["weight_digest"]), "weight generator drifted"
+    return sd
+
+
+def _fwd_grad_check(z, predict, rtol=1e-5):
+    from oracle import flow_oracle as fo
+    x1, x2 = t(z["x1"]).requires_grad_(True), t(z["x2"]).requires_grad_(True)
+    flow = predict(x1, x2)
+    assert_close(flow, t(z["flow"]), rtol=rtol, atol_scale=1e-6, what="flow")
+    loss = fo.flow_loss(flow, t(z["target"]))
+    assert abs(float(loss.detach()) - float(z["loss"])) < 1e-6
+    g1, g2 = torch.autograd.grad(loss, (x1, x2))
+    assert_close(g1, t(z["g1"]), rtol=rtol, atol_scale=1e-6, what="grad frame 1")
+    assert_close(g2, t(z["g2"]), rtol=rtol, atol_scale=1e-6, what="grad frame 2")
+
+
+def test_pwcnet_oracle_matches_reference(oracle):
+    from oracle import flow_oracle as fo
+    from understanding_flow_robustness_amd.flownets.pwcnet import PWCDCNet
+    sd = _sd(PWCDCNet, 1, "pwcnet_128x192")
+    z = load_golden("pwcnet_128x192")
+    _fwd_grad_check(z, lambda a, b: fo.pwcnet_forward(sd, a, b))
+    for it in (1, 2):
+        p = t(z["patch0"]).clone()
+        fo.patch_attack(lambda a, b: fo.pwcnet_forward(sd, a, b), t(z["x1"]), t(z["x2"]), p, t(z["mask"]),
+                        t(z["patch0"]), t(z["attack_target"]), lr=1e4, max_count=it)
+        assert_close(p, t(z[f"attack_it{it}_patch"]), rtol=1e-5, atol_scale=1e-6, what=f"PWC attack it{it}")
+
+
+def test_raft_oracle_matches_reference(oracle):
+    from oracle import flow_oracle as fo
+    from understanding_flow_robustness_amd.flownets.raft import RAFT
+    sd = _sd(lambda: RAFT(Namespace(flownet="RAFT")), 2, "raft_128x192")
+    z = load_golden("raft_128x192")
+    predict = lambda a, b: fo.raft_forward(sd, a * 255.0, b * 255.0)[1]     # utils_model.py:668-671
+    _fwd_grad_check(z, predict)
+    # alt_cuda_corr twin (models/raft/corr.py:109-137) gives the same flow
+    alt = fo.raft_forward(sd, t(z["x1"]) * 255.0, t(z["x2"]) * 255.0, alternate_corr=True)[1]
+    assert_close(alt, t(z["flow"]), rtol=1e-4, atol_scale=1e-5, what="alt_corr RAFT")
+    p = t(z["patch0"]).clone()
+    fo.patch_attack(predict, t(z["x1"]), t(z["x2"]), p, t(z["mask"]), t(z["patch0"]), t(z["attack_target"]),
+                    lr=1e4, max_count=2)
+    assert_close(p, t(z["attack_it2_patch"]), rtol=1e-5, atol_scale=1e-6, what="RAFT attack")
+
+
+def test_flownet2_oracle_matches_reference_wiring(oracle):
+    from oracle import flow_oracle as fo
+    from understanding_flow_robustness_amd.flownets.flownet2 import FlowNet2
+    sd = _sd(FlowNet2, 3, "flownet2_64x128")
+    _fwd_grad_check(load_golden("flownet2_64x128"), lambda a, b: fo.flownet2_forward(sd, a, b))
+
+
+def test_universal_attack_oracle_matches_reference(oracle):
+    from oracle import flow_oracle as fo
+    from understanding_flow_robustness_amd.flownets.flownetc import FlowNetC
+    sd = _sd(FlowNetC, 0, "universal_flownetc_64x128")
+    z = load_golden("universal_flownetc_64x128")
+    predict = lambda a, b: fo.flownetc_forward(sd, a, b)
+    clean, valid = t(z["clean"]), t(z["valid"])
+    for tag, fl, target in (("cossim", "cossim", -clean), ("l2masked", "l2", torch.cat((-clean, valid), 1))):
+        a0, a1, d = fo.universal_attack(predict, t(z["img0"]), t(z["img1"]), t(z["delta0"]), target, n_step=3,
+                                        lr=2e-3, eps=0.02, flow_loss=fl)
+        assert torch.equal(a0, t(z[f"{tag}_adv0"])) and torch.equal(a1, t(z[f"{tag}_adv1"]))
+        assert torch.equal(d, t(z[f"{tag}_delta"]))
+
+
+def test_shared_universal_step_keeps_reference_frames_for_batch_one(oracle):
+    """DESIGN.md claim: at B=1 the shared-delta extension yields the reference's adversarial frames
+    wherever the [0,1] image-range clamp does not bind (there the reference folds the clamp into its
+    per-sample noise, the extension keeps delta image-independent)."""
+    from oracle import flow_oracle as fo
+    from understanding_flow_robustness_amd.flownets.flownetc import FlowNetC
+    from understanding_flow_robustness_amd.flownets.weights import synthetic_state_dict
+    sd = synthetic_state_dict(FlowNetC().state_dict(), seed=0)
+    z = load_golden("universal_flownetc_64x128")
+    predict = lambda a, b: fo.flownetc_forward(sd, a, b)
+    target = -t(z["clean"])
+    zero = torch.zeros_like(t(z["delta0"]))
+    a0, a1, _ = fo.universal_attack(predict, t(z["img0"]), t(z["img1"]), zero, target, n_step=2)
+    b0, b1, _ = fo.universal_attack(predict, t(z["img0"]), t(z["img1"]), zero, target, n_step=2, shared=True)
+    for img, a, b in ((t(z["img0"]), a0, b0), (t(z["img1"]), a1, b1)):
+        free = (img > 0.021) & (img < 0.979)
+        assert float(free.float().mean()) > 0.9
+        assert_close(b[free], a[free], rtol=1e-6, atol_scale=1e-7)
+        assert float((b - a).abs().max()) <= 2 * 2e-3 + 1e-6      # elsewhere: at most the steps taken
+
+
+def test_model_state_dict_layouts():
+    """Layer names and parameter counts the reference's checkpoints need (PWCNet.py, raft.py,
+    flownet2_models.py:11)."""
+    from understanding_flow_robustness_amd.flownets.flownet2 import FlowNet2
+    from understanding_flow_robustness_amd.flownets.pwcnet import PWCDCNet
+    from understanding_flow_robustness_amd.flownets.raft import RAFT
+    n = lambda m: sum(p.numel() for p in m.parameters())
+    pwc = PWCDCNet()
+    assert n(pwc) == 9374340 and "conv6aa.0.weight" in pwc.state_dict() and "dc_conv7.bias" in pwc.state_dict()
+    raft = RAFT(Namespace(flownet="RAFT"))
+    keys = raft.state_dict().keys()
+    assert n(raft) == 5257536 and "cnet.layer2.0.downsample.1.running_mean" in keys
+    assert "cnet.layer2.0.norm3.weight" in keys and "update_block.gru.convq2.bias" in keys
+    torch.manual_seed(0)
+    with torch.device("meta"):
+        fn2 = FlowNet2()
+    assert n(fn2) == 162518834
+    assert "flownets_1.upsampled_flow6_to_5.weight" in fn2.state_dict()
+    assert "flownets_1.upsampled_flow6_to_5.bias" not in fn2.state_dict()     # FlowNetS.py:47-50

@@ -1,0 +1,121 @@
+"""GPU suite: PWC-Net, RAFT (all-pairs and alt_corr), FlowNet2 and the universal-perturbation step
+against the reference's golden vectors / the CPU oracle (1e-4 relative on flow and EPE)."""
+from argparse import Namespace
+
+import pytest
+import torch
+
+from conftest import assert_close, load_golden, t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+REL = 1e-4
+
+
+def _fetch(name, seed, **extra):
+    from understanding_flow_robustness_amd.flownets.utils_model import fetch_model
+    args = Namespace(flownet=name, **extra)
+    return fetch_model(args, synthetic_seed=seed).to(DEV), args
+
+
+def _check(z, net, args, gtol=1e-3):
+    from understanding_flow_robustness_amd.flownets.utils_model import predict_flow
+    x1, x2 = t(z["x1"], DEV).requires_grad_(True), t(z["x2"], DEV).requires_grad_(True)
+    flow = predict_flow(net, None, x1, x2, args)
+    ref = t(z["flow"])
+    assert_close(flow, ref, rtol=REL, atol_scale=REL, what="flow")
+    epe = (flow.detach().cpu() - ref).pow(2).sum(1).sqrt().mean()
+    assert float(epe) <= REL * float(ref.pow(2).sum(1).sqrt().mean()), f"EPE {float(epe):.3e}"
+    loss = (1 - torch.nn.functional.cosine_similarity(flow, t(z["target"], DEV))).mean()
+    assert abs(float(loss.detach()) - float(z["loss"])) < 2e-5
+    g1, g2 = torch.autograd.grad(loss, (x1, x2))
+    assert_close(g1, t(z["g1"]), rtol=gtol, atol_scale=3e-4, what="grad frame 1")
+    assert_close(g2, t(z["g2"]), rtol=gtol, atol_scale=3e-4, what="grad frame 2")
+
+
+def _attack_check(z, net, args, key, lr, iters):
+    from understanding_flow_robustness_amd.patch_attack import attack
+    args.l2, args.alpha, args.lr, args.max_count = False, 0.0, lr, iters
+    patch = t(z["patch0"], DEV).clone()
+    attack(net, t(z["x1"], DEV)[:1], None, t(z["x2"], DEV)[:1], patch, t(z["mask"], DEV), t(z["patch0"], DEV),
+           t(z["attack_target"], DEV), None, args=args)
+    ref = t(z[key])
+    upd = float((ref - t(z["patch0"])).abs().max())
+    err = float((patch.cpu() - ref).abs().max())
+    assert err <= 3e-4 * max(upd, 1.0), f"patch err {err:.3e} vs update {upd:.3e}"
+
+
+def test_pwcnet_vs_reference():
+    z = load_golden("pwcnet_128x192")
+    net, args = _fetch("PWCNet", 1)
+    _check(z, net, args)
+    _attack_check(z, net, args, "attack_it2_patch", 1e4, 2)
+
+
+@pytest.mark.parametrize("alternate", [False, True])
+def test_raft_vs_reference(alternate):
+    z = load_golden("raft_128x192")
+    net, args = _fetch("RAFT", 2, alternate_corr=alternate)
+    args.mixed_precision = False
+    _check(z, net, args, gtol=2e-3)
+    _attack_check(z, net, args, "attack_it2_patch", 1e4, 2)
+
+
+def test_flownet2_vs_reference_wiring():
+    z = load_golden("flownet2_64x128")
+    net, args = _fetch("FlowNet2", 3)
+    _check(z, net, args, gtol=2e-3)
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_universal_attack_vs_reference(use_graph):
+    from understanding_flow_robustness_amd.universal_perturbation import attack
+    z = load_golden("universal_flownetc_64x128")
+    net, _ = _fetch("FlowNetC", 0)
+    clean, valid = t(z["clean"], DEV), t(z["valid"], DEV)
+    for tag, fl, target in (("cossim", "cossim", -clean), ("l2masked", "l2", torch.cat((-clean, valid), 1))):
+        args = Namespace(flownet="FlowNetC", n_step=3, learning_rate=2e-3, output_norm=0.02, flow_loss=fl,
+                         perturb_method="ifgsm", perturb_mode="both", add_gaussian=False)
+        a0, none, a1, d = attack(net, t(z["img0"], DEV), t(z["img1"], DEV), t(z["delta0"], DEV), target, args,
+                                 use_graph=use_graph)
+        assert none is None and tuple(d.shape) == (1, 2, 3, 64, 128)
+        ref_d = t(z[f"{tag}_delta"])
+        # sign() of a gradient that is ~0 may flip between two fp32 implementations: allow a tiny
+        # fraction of pixels to differ by one step (index-like output), everything else exact to 1e-6
+        diff = (d.cpu() - ref_d).abs()
+        assert float((diff > 1e-6).float().mean()) < 2e-3, f"{tag}: {float((diff > 1e-6).float().mean()):.2e} differ"
+        assert float(diff.max()) <= 3 * 2e-3 * 2 + 1e-6
+        assert float(((a0.cpu() - t(z[f"{tag}_adv0"])).abs() > 1e-6).float().mean()) < 2e-3
+
+
+def test_universal_shared_batch_step_vs_oracle(oracle):
+    from oracle import flow_oracle as fo
+    from understanding_flow_robustness_amd.universal_perturbation import UniversalPerturbationStep
+    net, _ = _fetch("FlowNetC", 0)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(23)
+    img0, img1 = torch.rand(2, 3, 64, 128, generator=g), torch.rand(2, 3, 64, 128, generator=g)
+    target = torch.randn(2, 2, 64, 128, generator=g)
+    delta0 = torch.zeros(2, 3, 64, 128)
+    args = Namespace(flownet="FlowNetC", n_step=2, learning_rate=2e-3, output_norm=0.02, flow_loss="cossim",
+                     perturb_method="ifgsm", perturb_mode="both", add_gaussian=False)
+    step = UniversalPerturbationStep(net, args, 2, 64, 128, device=DEV, shared=True)
+    step.load(img0.to(DEV), img1.to(DEV), delta0.to(DEV), target.to(DEV))
+    step.run(2)
+    _, _, d = fo.universal_attack(lambda a, b: fo.flownetc_forward(sd, a, b), img0, img1, delta0, target, n_step=2,
+                                  shared=True)
+    diff = (step.delta.cpu() - d).abs()
+    assert float((diff > 1e-6).float().mean()) < 2e-3
+
+
+def test_raft_full_resolution_smoke():
+    """BASELINE config C3 shape: 384x1280, 12 GRU iterations, forward + image gradient finite."""
+    from understanding_flow_robustness_amd.flownets.utils_model import predict_flow
+    net, args = _fetch("RAFT", 2)
+    g = torch.Generator().manual_seed(1)
+    x1 = torch.rand(1, 3, 384, 1280, generator=g).to(DEV).requires_grad_(True)
+    x2 = torch.rand(1, 3, 384, 1280, generator=g).to(DEV)
+    flow = predict_flow(net, None, x1, x2, args)
+    assert tuple(flow.shape) == (1, 2, 384, 1280)
+    (g1,) = torch.autograd.grad(flow.square().mean(), x1)
+    assert bool(torch.isfinite(flow).all()) and bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0

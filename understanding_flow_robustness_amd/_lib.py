@@ -55,6 +55,9 @@ SIGNATURES = {
     "ufr_patch_update": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _l, _f, _f, _f,
                          _f, _i, _vp, _vp],
     "ufr_attack_gate": [_vp, _vp, _f, _vp],
+    "ufr_flow_loss_ex": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp],
+    "ufr_universal_update": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _i, _i, _i, _i,
+                             _i, _vp],
     "ufr_flow_loss": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
 }
 PLAIN = {"ufr_abi_version": (C.c_int, []), "ufr_last_error": (C.c_char_p, []),

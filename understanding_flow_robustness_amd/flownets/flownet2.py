@@ -1,0 +1,224 @@
+"""FlowNet2 (162.5 M parameters): FlowNetC -> warp -> FlowNetS -> warp -> FlowNetS, FlowNetSD, fusion --
+on the gfx950 correlation / Resample2d / ChannelNorm kernels.
+
+Behavioural mirror of models/flownet2_models.py:14-205 and models/flownet2/{FlowNetC,FlowNetS,
+FlowNetSD,FlowNetFusion}.py with the reference's layer names (`FlowNet2_checkpoint.pth.tar` loads
+unchanged).  Quirks kept: FlowNetSD's flow is DIVIDED by div_flow (:176), FlowNetS-2 / FlowNetSD
+flows are upsampled with `nearest`, FlowNetS's flow up-convolutions have no bias.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..channelnorm_package.channelnorm import ChannelNorm
+from ..resample2d_package.resample2d import Resample2d
+from .flownetc import _RGB_MEAN, _conv, _deconv, correlate
+
+
+def _i_conv(cin, cout, k=3, stride=1, bias=True):
+    """submodules.py:48-72 (batchNorm=False): convolution without activation."""
+    return nn.Sequential(nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, bias=bias))
+
+
+def _flow(cin):
+    return nn.Conv2d(cin, 2, 3, 1, 1, bias=True)
+
+
+def _xavier(module):
+    for m in module.modules():                              # every sub-net's __init__ tail
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            if m.bias is not None:
+                nn.init.uniform_(m.bias)
+            nn.init.xavier_uniform_(m.weight)
+
+
+class _Refinement(nn.Module):
+    """The coarse-to-fine decoder shared by FlowNetC and FlowNetS (levels 6 -> 2)."""
+
+    def _build_refinement(self, up_bias):
+        for name, cin, cout in (("deconv5", 1024, 512), ("deconv4", 1026, 256), ("deconv3", 770, 128),
+                                ("deconv2", 386, 64)):
+            setattr(self, name, _deconv(cin, cout))
+        for name, cin in (("predict_flow6", 1024), ("predict_flow5", 1026), ("predict_flow4", 770),
+                          ("predict_flow3", 386), ("predict_flow2", 194)):
+            setattr(self, name, _flow(cin))
+        for name in ("upsampled_flow6_to_5", "upsampled_flow5_to_4", "upsampled_flow4_to_3", "upsampled_flow3_to_2"):
+            setattr(self, name, nn.ConvTranspose2d(2, 2, 4, 2, 1, bias=up_bias))
+
+    def _refine(self, c6, skips):
+        """skips = (conv5, conv4, conv3, conv2) features; returns flow2."""
+        flow = self.predict_flow6(c6)
+        x = c6
+        for lvl, skip in zip((5, 4, 3, 2), skips):
+            up = getattr(self, f"upsampled_flow{lvl + 1}_to_{lvl}")(flow)
+            x = torch.cat((skip, getattr(self, f"deconv{lvl}")(x), up), 1)
+            flow = getattr(self, f"predict_flow{lvl}")(x)
+        return flow
+
+
+class FlowNetC(_Refinement):
+    """models/flownet2/FlowNetC.py:10-131: 6-channel input, returns a tuple like the reference."""
+
+    def __init__(self, batchNorm=False, div_flow=20):
+        super().__init__()
+        assert not batchNorm
+        self.div_flow = div_flow
+        for name, cin, cout, k, s in (("conv1", 3, 64, 7, 2), ("conv2", 64, 128, 5, 2), ("conv3", 128, 256, 5, 2),
+                                      ("conv_redir", 256, 32, 1, 1), ("conv3_1", 473, 256, 3, 1),
+                                      ("conv4", 256, 512, 3, 2), ("conv4_1", 512, 512, 3, 1),
+                                      ("conv5", 512, 512, 3, 2), ("conv5_1", 512, 512, 3, 1),
+                                      ("conv6", 512, 1024, 3, 2), ("conv6_1", 1024, 1024, 3, 1)):
+            setattr(self, name, _conv(cin, cout, k, s))
+        self._build_refinement(up_bias=True)
+        _xavier(self)
+
+    def forward(self, x):
+        B = x.shape[0]
+        both = torch.cat((x[:, 0:3], x[:, 3:]), 0)
+        c2 = self.conv2(self.conv1(both))
+        c3 = self.conv3(c2)
+        c2a, c3a, c3b = c2[:B], c3[:B], c3[B:]
+        corr = F.leaky_relu(correlate(c3a.contiguous(), c3b.contiguous()), 0.1)
+        c3_1 = self.conv3_1(torch.cat((self.conv_redir(c3a), corr), 1))
+        c4 = self.conv4_1(self.conv4(c3_1))
+        c5 = self.conv5_1(self.conv5(c4))
+        c6 = self.conv6_1(self.conv6(c5))
+        return (self._refine(c6, (c5, c4, c3_1, c2a)),)
+
+
+class FlowNetS(_Refinement):
+    """models/flownet2/FlowNetS.py:15-104."""
+
+    def __init__(self, input_channels=12, batchNorm=False):
+        super().__init__()
+        assert not batchNorm
+        for name, cin, cout, k, s in (("conv1", input_channels, 64, 7, 2), ("conv2", 64, 128, 5, 2),
+                                      ("conv3", 128, 256, 5, 2), ("conv3_1", 256, 256, 3, 1),
+                                      ("conv4", 256, 512, 3, 2), ("conv4_1", 512, 512, 3, 1),
+                                      ("conv5", 512, 512, 3, 2), ("conv5_1", 512, 512, 3, 1),
+                                      ("conv6", 512, 1024, 3, 2), ("conv6_1", 1024, 1024, 3, 1)):
+            setattr(self, name, _conv(cin, cout, k, s))
+        self._build_refinement(up_bias=False)
+        _xavier(self)
+
+    def forward(self, x):
+        c2 = self.conv2(self.conv1(x))
+        c3 = self.conv3_1(self.conv3(c2))
+        c4 = self.conv4_1(self.conv4(c3))
+        c5 = self.conv5_1(self.conv5(c4))
+        c6 = self.conv6_1(self.conv6(c5))
+        return (self._refine(c6, (c5, c4, c3, c2)),)
+
+
+class FlowNetSD(nn.Module):
+    """models/flownet2/FlowNetSD.py:12-126: small-displacement net with inter-convolutions."""
+
+    def __init__(self, batchNorm=False):
+        super().__init__()
+        assert not batchNorm
+        for name, cin, cout, s in (("conv0", 6, 64, 1), ("conv1", 64, 64, 2), ("conv1_1", 64, 128, 1),
+                                   ("conv2", 128, 128, 2), ("conv2_1", 128, 128, 1), ("conv3", 128, 256, 2),
+                                   ("conv3_1", 256, 256, 1), ("conv4", 256, 512, 2), ("conv4_1", 512, 512, 1),
+                                   ("conv5", 512, 512, 2), ("conv5_1", 512, 512, 1), ("conv6", 512, 1024, 2),
+                                   ("conv6_1", 1024, 1024, 1)):
+            setattr(self, name, _conv(cin, cout, 3, s))
+        for name, cin, cout in (("deconv5", 1024, 512), ("deconv4", 1026, 256), ("deconv3", 770, 128),
+                                ("deconv2", 386, 64)):
+            setattr(self, name, _deconv(cin, cout))
+        for name, cin, cout in (("inter_conv5", 1026, 512), ("inter_conv4", 770, 256), ("inter_conv3", 386, 128),
+                                ("inter_conv2", 194, 64)):
+            setattr(self, name, _i_conv(cin, cout))
+        for name, cin in (("predict_flow6", 1024), ("predict_flow5", 512), ("predict_flow4", 256),
+                          ("predict_flow3", 128), ("predict_flow2", 64)):
+            setattr(self, name, _flow(cin))
+        for name in ("upsampled_flow6_to_5", "upsampled_flow5_to_4", "upsampled_flow4_to_3", "upsampled_flow3_to_2"):
+            setattr(self, name, nn.ConvTranspose2d(2, 2, 4, 2, 1))
+        _xavier(self)
+
+    def forward(self, x):
+        c0 = self.conv0(x)
+        c1 = self.conv1_1(self.conv1(c0))
+        c2 = self.conv2_1(self.conv2(c1))
+        c3 = self.conv3_1(self.conv3(c2))
+        c4 = self.conv4_1(self.conv4(c3))
+        c5 = self.conv5_1(self.conv5(c4))
+        c6 = self.conv6_1(self.conv6(c5))
+        flow, feat = self.predict_flow6(c6), c6
+        for lvl, skip in zip((5, 4, 3, 2), (c5, c4, c3, c2)):
+            up = getattr(self, f"upsampled_flow{lvl + 1}_to_{lvl}")(flow)
+            feat = torch.cat((skip, getattr(self, f"deconv{lvl}")(feat), up), 1)
+            flow = getattr(self, f"predict_flow{lvl}")(getattr(self, f"inter_conv{lvl}")(feat))
+        return (flow,)
+
+
+class FlowNetFusion(nn.Module):
+    """models/flownet2/FlowNetFusion.py:12-71: full-resolution fusion of the two flow candidates."""
+
+    def __init__(self, batchNorm=False):
+        super().__init__()
+        assert not batchNorm
+        for name, cin, cout, s in (("conv0", 11, 64, 1), ("conv1", 64, 64, 2), ("conv1_1", 64, 128, 1),
+                                   ("conv2", 128, 128, 2), ("conv2_1", 128, 128, 1)):
+            setattr(self, name, _conv(cin, cout, 3, s))
+        self.deconv1, self.deconv0 = _deconv(128, 32), _deconv(162, 16)
+        self.inter_conv1, self.inter_conv0 = _i_conv(162, 32), _i_conv(82, 16)
+        self.predict_flow2, self.predict_flow1, self.predict_flow0 = _flow(128), _flow(32), _flow(16)
+        self.upsampled_flow2_to_1 = nn.ConvTranspose2d(2, 2, 4, 2, 1)
+        self.upsampled_flow1_to_0 = nn.ConvTranspose2d(2, 2, 4, 2, 1)
+        _xavier(self)
+
+    def forward(self, x):
+        c0 = self.conv0(x)
+        c1 = self.conv1_1(self.conv1(c0))
+        c2 = self.conv2_1(self.conv2(c1))
+        flow2 = self.predict_flow2(c2)
+        cat1 = torch.cat((c1, self.deconv1(c2), self.upsampled_flow2_to_1(flow2)), 1)
+        flow1 = self.predict_flow1(self.inter_conv1(cat1))
+        cat0 = torch.cat((c0, self.deconv0(cat1), self.upsampled_flow1_to_0(flow1)), 1)
+        return self.predict_flow0(self.inter_conv0(cat0))
+
+
+class FlowNet2(nn.Module):
+    def __init__(self, batchNorm=False, div_flow=20.0, return_feat_maps: bool = False):
+        super().__init__()
+        self.div_flow = div_flow
+        self.channelnorm = ChannelNorm()
+        self.flownetc = FlowNetC(batchNorm=batchNorm)
+        self.resample1 = Resample2d()
+        self.flownets_1 = FlowNetS(batchNorm=batchNorm)
+        self.resample2 = Resample2d()
+        self.flownets_2 = FlowNetS(batchNorm=batchNorm)
+        self.flownets_d = FlowNetSD(batchNorm=batchNorm)
+        self.resample3 = Resample2d()
+        self.resample4 = Resample2d()
+        self.flownetfusion = FlowNetFusion(batchNorm=batchNorm)
+        self.register_buffer("_mean64", torch.tensor(_RGB_MEAN, dtype=torch.float64).view(1, 3, 1, 1),
+                             persistent=False)
+
+    def _warp_stage(self, x, flow):
+        """flownet2_models.py:138-145: warp frame 2 by `flow`, brightness error and its channel norm."""
+        resampled = self.resample1(x[:, 3:], flow)
+        diff = x[:, :3] - resampled
+        return torch.cat((x, resampled, flow / self.div_flow, self.channelnorm(diff)), dim=1)
+
+    def forward(self, x1, x2):
+        x1 = (x1.double() - self._mean64).float()                  # :93-96, :124-125
+        x2 = (x2.double() - self._mean64).float()
+        x = torch.cat((x1, x2), dim=1)
+        up_bl = lambda f: F.interpolate(f, scale_factor=4, mode="bilinear", align_corners=False)
+        up_nn = lambda f: F.interpolate(f, scale_factor=4, mode="nearest")
+
+        flow_c = up_bl(self.flownetc(x)[0] * self.div_flow)
+        flow_s1 = up_bl(self.flownets_1(self._warp_stage(x, flow_c))[0] * self.div_flow)
+        flow_s2 = up_nn(self.flownets_2(self._warp_stage(x, flow_s1))[0] * self.div_flow)
+        norm_s2 = self.channelnorm(flow_s2)
+        err_s2 = self.channelnorm(x[:, :3] - self.resample4(x[:, 3:], flow_s2))
+
+        flow_sd = up_nn(self.flownets_d(x)[0] / self.div_flow)     # sic: divided (:176)
+        norm_sd = self.channelnorm(flow_sd)
+        err_sd = self.channelnorm(x[:, :3] - self.resample3(x[:, 3:], flow_sd))
+
+        fused_in = torch.cat((x[:, :3], flow_sd, flow_s2, norm_sd, norm_s2, err_sd, err_s2), dim=1)
+        return self.flownetfusion(fused_in)

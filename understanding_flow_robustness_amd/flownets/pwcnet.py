@@ -1,0 +1,117 @@
+"""PWC-DC-Net (9.4 M parameters) on the gfx950 correlation kernel.
+
+Behavioural mirror of models/PWCNet.py:52-367 (layer names kept, so the reference's
+`pwc_net_chairs.pth.tar` / adversarially trained state_dicts load unchanged): 6-level siamese
+pyramid, per level  warp(second-frame features, upsampled flow * scale) -> 9x9 correlation (`/C`)
+-> LeakyReLU -> DenseNet decoder -> flow, then the dilated context network; output 20 * upsample x4.
+The two pyramids run as one batch of 2B images.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .flownetc import correlate as _correlate
+
+
+def _conv(cin, cout, k=3, stride=1, padding=1, dilation=1):
+    """PWCNet.py:17-30."""
+    return nn.Sequential(nn.Conv2d(int(cin), int(cout), k, stride, padding, dilation, bias=True), nn.LeakyReLU(0.1))
+
+
+def correlate(input1, input2):
+    """PWCNet.py:42-50: 9x9 displacements, dilation_patch 1, divided by C."""
+    return _correlate(input1, input2, patch_size=9, dilation_patch=1)
+
+
+def warp(x, flo):
+    """PWCNet.py:164-204: bilinear backward warp (grid_sample, default align_corners=False, grid
+    normalised with (W-1)) times the validity mask `warp(ones) >= 0.0001`."""
+    B, _, H, W = x.shape
+    xx = torch.arange(W, device=x.device, dtype=x.dtype).view(1, 1, 1, W)
+    yy = torch.arange(H, device=x.device, dtype=x.dtype).view(1, 1, H, 1)
+    vx = 2.0 * (xx + flo[:, 0:1]) / max(W - 1, 1) - 1.0
+    vy = 2.0 * (yy + flo[:, 1:2]) / max(H - 1, 1) - 1.0
+    vgrid = torch.cat((vx, vy), 1).permute(0, 2, 3, 1)
+    output = F.grid_sample(x, vgrid, align_corners=False)
+    mask = F.grid_sample(torch.ones_like(x[:, :1]), vgrid, align_corners=False)
+    return output * (mask >= 0.0001).to(x.dtype)
+
+
+class PWCDCNet(nn.Module):
+    _PYRAMID = ((3, 16, "1a", "1aa", "1b"), (16, 32, "2a", "2aa", "2b"), (32, 64, "3a", "3aa", "3b"),
+                (64, 96, "4a", "4aa", "4b"), (96, 128, "5a", "5aa", "5b"), (128, 196, "6aa", "6a", "6b"))
+    _FLOW_SCALE = {5: 0.625, 4: 1.25, 3: 2.5, 2: 5.0}     # PWCNet.py:286,301,316,332
+
+    def __init__(self, md=4, pretrained=False, return_feat_maps=False):
+        super().__init__()
+        if return_feat_maps:
+            raise NotImplementedError("feature-map capture is analysis-only (out of scope)")
+        for cin, cout, first, second, third in self._PYRAMID:
+            setattr(self, "conv" + first, _conv(cin, cout, 3, 2))
+            setattr(self, "conv" + second, _conv(cout, cout, 3, 1))
+            setattr(self, "conv" + third, _conv(cout, cout, 3, 1))
+        nd = (2 * md + 1) ** 2
+        dd = np.cumsum([128, 128, 96, 64, 32])
+        feat = {6: 0, 5: 128, 4: 96, 3: 64, 2: 32}
+        for lvl in (6, 5, 4, 3, 2):
+            od = nd if lvl == 6 else nd + feat[lvl] + 4
+            for i, (extra, cout) in enumerate(zip((0, dd[0], dd[1], dd[2], dd[3]), (128, 128, 96, 64, 32))):
+                setattr(self, f"conv{lvl}_{i}", _conv(od + extra, cout))
+            setattr(self, f"predict_flow{lvl}", nn.Conv2d(int(od + dd[4]), 2, 3, 1, 1, bias=True))
+            setattr(self, f"deconv{lvl}", nn.ConvTranspose2d(2, 2, 4, 2, 1, bias=True))
+            if lvl > 2:
+                setattr(self, f"upfeat{lvl}", nn.ConvTranspose2d(int(od + dd[4]), 2, 4, 2, 1, bias=True))
+        od = nd + 32 + 4
+        for i, (cin, cout, dil) in enumerate(((od + dd[4], 128, 1), (128, 128, 2), (128, 128, 4), (128, 96, 8),
+                                              (96, 64, 16), (64, 32, 1)), start=1):
+            setattr(self, f"dc_conv{i}", _conv(cin, cout, 3, 1, dil, dil))
+        self.dc_conv7 = nn.Conv2d(32, 2, 3, 1, 1, bias=True)
+        for m in self.modules():                                   # PWCNet.py:154-158
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                nn.init.kaiming_normal_(m.weight.data, mode="fan_in")
+                if m.bias is not None:
+                    m.bias.data.zero_()
+
+    def _decode(self, lvl, x):
+        for i in range(5):                                         # DenseNet connections
+            x = torch.cat((getattr(self, f"conv{lvl}_{i}")(x), x), 1)
+        return x, getattr(self, f"predict_flow{lvl}")(x)
+
+    def forward(self, im1, im2):
+        B = im1.shape[0]
+        x = torch.cat((im1, im2), 0).flip(1)                       # RGB -> BGR (PWCNet.py:230-231)
+        feats = []
+        for _, _, first, second, third in self._PYRAMID:
+            x = getattr(self, "conv" + third)(getattr(self, "conv" + second)(getattr(self, "conv" + first)(x)))
+            feats.append(x)
+        c1 = {lvl: feats[lvl - 1][:B] for lvl in range(2, 7)}
+        c2 = {lvl: feats[lvl - 1][B:] for lvl in range(2, 7)}
+
+        corr = F.leaky_relu(correlate(c1[6].contiguous(), c2[6].contiguous()), 0.1)
+        x, flow = self._decode(6, corr)
+        flows = {6: flow}
+        for lvl in (5, 4, 3, 2):
+            up_flow = getattr(self, f"deconv{lvl + 1}")(flow)
+            up_feat = getattr(self, f"upfeat{lvl + 1}")(x)
+            warped = warp(c2[lvl], up_flow * self._FLOW_SCALE[lvl])
+            corr = F.leaky_relu(correlate(c1[lvl].contiguous(), warped.contiguous()), 0.1)
+            x, flow = self._decode(lvl, torch.cat((corr, c1[lvl], up_flow, up_feat), 1))
+            flows[lvl] = flow
+        x = self.dc_conv4(self.dc_conv3(self.dc_conv2(self.dc_conv1(x))))
+        flow2 = flows[2] + self.dc_conv7(self.dc_conv6(self.dc_conv5(x)))
+        up = lambda f: F.interpolate(f, scale_factor=4, mode="bilinear", align_corners=False)
+        if self.training:
+            return tuple(up(f) for f in (flow2, flows[3], flows[4], flows[5], flows[6]))
+        return 20 * up(flow2)
+
+
+def pwc_dc_net(path=None, return_feat_maps=False):
+    """PWCNet.py:381-390."""
+    model = PWCDCNet(return_feat_maps=return_feat_maps)
+    if path is not None:
+        data = torch.load(path, map_location="cpu")
+        model.load_state_dict(data["state_dict"] if "state_dict" in data else data)
+    return model

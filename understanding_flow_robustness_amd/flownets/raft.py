@@ -1,0 +1,232 @@
+"""RAFT (raft-things configuration: BasicEncoder x2, 4-level all-pairs correlation, SepConvGRU update
+block, convex x8 upsampling, 12 iterations) on the gfx950 cost-volume kernels.
+
+Behavioural mirror of models/raft/raft.py:26-233, update.py, extractor.py:1-215 with the layer names
+of the reference (so `raft-things.pth` loads unchanged).  Differences, all on purpose:
+  * the per-iteration lookup is ONE fused kernel (flownets/raft_corr.py) instead of 4 grid_samples;
+  * `alternate_corr=True` is differentiable (the reference calls alt_cuda_corr's raw forward);
+  * fp32 throughout: `args.mixed_precision` is honoured only as an opt-in bf16 autocast, because the
+    1e-4 EPE gate is defined against the fp32 path ("RAFT precision").
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .raft_corr import AlternateCorrBlock, CorrBlock
+
+
+def _norm(kind, planes, groups=None):
+    if kind == "group":
+        return nn.GroupNorm(num_groups=groups or planes // 8, num_channels=planes)
+    if kind == "batch":
+        return nn.BatchNorm2d(planes)
+    if kind == "instance":
+        return nn.InstanceNorm2d(planes)
+    return nn.Sequential()
+
+
+class ResidualBlock(nn.Module):
+    """extractor.py:5-78."""
+
+    def __init__(self, in_planes, planes, norm_fn="group", stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_planes, planes, 3, padding=1, stride=stride)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1)
+        self.non_linearity = nn.ReLU(inplace=True)
+        self.norm1, self.norm2 = _norm(norm_fn, planes), _norm(norm_fn, planes)
+        self.downsample = None
+        if stride != 1:
+            self.norm3 = _norm(norm_fn, planes)          # registered twice on purpose: the reference's
+            self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, 1, stride=stride), self.norm3)  # keys
+
+    def forward(self, x):
+        y = self.non_linearity(self.norm1(self.conv1(x)))
+        y = self.non_linearity(self.norm2(self.conv2(y)))
+        if self.downsample is not None:
+            x = self.downsample(x)
+        return self.non_linearity(x + y)
+
+
+class BasicEncoder(nn.Module):
+    """extractor.py:142-215: 7x7/2 stem, three residual stages (64, 96/2, 128/2), 1x1 head."""
+
+    def __init__(self, output_dim=128, norm_fn="batch", dropout=0.0):
+        super().__init__()
+        self.norm_fn = norm_fn
+        self.norm1 = _norm(norm_fn, 64, groups=8)
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.layer1 = nn.Sequential(ResidualBlock(64, 64, norm_fn, 1), ResidualBlock(64, 64, norm_fn, 1))
+        self.layer2 = nn.Sequential(ResidualBlock(64, 96, norm_fn, 2), ResidualBlock(96, 96, norm_fn, 1))
+        self.layer3 = nn.Sequential(ResidualBlock(96, 128, norm_fn, 2), ResidualBlock(128, 128, norm_fn, 1))
+        self.conv2 = nn.Conv2d(128, output_dim, 1)
+        self.dropout = nn.Dropout2d(p=dropout) if dropout > 0 else None
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, (nn.BatchNorm2d, nn.InstanceNorm2d, nn.GroupNorm)):
+                if m.weight is not None:
+                    nn.init.constant_(m.weight, 1)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        pair = isinstance(x, (tuple, list))
+        if pair:
+            n = x[0].shape[0]
+            x = torch.cat(x, dim=0)
+        x = self.relu1(self.norm1(self.conv1(x)))
+        x = self.conv2(self.layer3(self.layer2(self.layer1(x))))
+        if self.training and self.dropout is not None:
+            x = self.dropout(x)
+        return torch.split(x, [n, n], dim=0) if pair else x
+
+
+class FlowHead(nn.Module):
+    """update.py:6-14."""
+
+    def __init__(self, input_dim=128, hidden_dim=256):
+        super().__init__()
+        self.conv1 = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
+        self.conv2 = nn.Conv2d(hidden_dim, 2, 3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        return self.conv2(self.relu(self.conv1(x)))
+
+
+class SepConvGRU(nn.Module):
+    """update.py:35-73: a horizontal (1x5) then a vertical (5x1) convolutional GRU step."""
+
+    def __init__(self, hidden_dim=128, input_dim=192 + 128):
+        super().__init__()
+        for tag, k, pad in (("1", (1, 5), (0, 2)), ("2", (5, 1), (2, 0))):
+            for gate in "zrq":
+                setattr(self, f"conv{gate}{tag}", nn.Conv2d(hidden_dim + input_dim, hidden_dim, k, padding=pad))
+
+    def _half(self, h, x, tag):
+        hx = torch.cat([h, x], dim=1)
+        z = torch.sigmoid(getattr(self, "convz" + tag)(hx))
+        r = torch.sigmoid(getattr(self, "convr" + tag)(hx))
+        q = torch.tanh(getattr(self, "convq" + tag)(torch.cat([r * h, x], dim=1)))
+        return (1 - z) * h + z * q
+
+    def forward(self, h, x):
+        return self._half(self._half(h, x, "1"), x, "2")
+
+
+class BasicMotionEncoder(nn.Module):
+    """update.py:94-120."""
+
+    def __init__(self, args):
+        super().__init__()
+        cor_planes = args.corr_levels * (2 * args.corr_radius + 1) ** 2
+        self.args = args
+        self.convc1 = nn.Conv2d(cor_planes, 256, 1, padding=0)
+        self.convc2 = nn.Conv2d(256, 192, 3, padding=1)
+        self.convf1 = nn.Conv2d(2, 128, 7, padding=3)
+        self.convf2 = nn.Conv2d(128, 64, 3, padding=1)
+        self.conv = nn.Conv2d(64 + 192, 128 - 2, 3, padding=1)
+
+    def forward(self, flow, corr):
+        cor = F.relu(self.convc1(corr))
+        if not getattr(self.args, "update_no_motion_downsampling", False):
+            cor = F.relu(self.convc2(cor))
+        flo = F.relu(self.convf2(F.relu(self.convf1(flow))))
+        out = F.relu(self.conv(torch.cat([cor, flo], dim=1)))
+        return torch.cat([out, flow], dim=1)
+
+
+class BasicUpdateBlock(nn.Module):
+    """update.py:139-162."""
+
+    def __init__(self, args, hidden_dim=128):
+        super().__init__()
+        self.args = args
+        self.encoder = BasicMotionEncoder(args)
+        self.gru = SepConvGRU(hidden_dim=hidden_dim, input_dim=128 + hidden_dim)
+        self.flow_head = FlowHead(hidden_dim, hidden_dim=256)
+        self.mask = nn.Sequential(nn.Conv2d(128, 256, 3, padding=1), nn.ReLU(inplace=True),
+                                  nn.Conv2d(256, 64 * 9, 1, padding=0))
+
+    def forward(self, net, inp, corr, flow, want_mask=True):
+        motion_features = self.encoder(flow, corr)
+        net = self.gru(net, torch.cat([inp, motion_features], dim=1))
+        delta_flow = self.flow_head(net)
+        # the x8 convex-upsampling mask only matters for the iteration whose flow is returned
+        mask = 0.25 * self.mask(net) if want_mask else None
+        return net, mask, delta_flow
+
+
+def coords_grid(batch, ht, wd, device):
+    """utils/utils.py:80-83: channel 0 = x, channel 1 = y."""
+    ys, xs = torch.meshgrid(torch.arange(ht, device=device), torch.arange(wd, device=device), indexing="ij")
+    return torch.stack((xs, ys), dim=0).float()[None].repeat(batch, 1, 1, 1)
+
+
+class RAFT(nn.Module):
+    def __init__(self, args, return_feat_maps: bool = False):
+        super().__init__()
+        if return_feat_maps:
+            raise NotImplementedError("feature-map capture is analysis-only (out of scope)")
+        if getattr(args, "small", False) or getattr(args, "flowNetCEnc", False) or getattr(args, "no_separate_context", False):
+            raise NotImplementedError("only the raft-things configuration (BasicEncoder x2) is in scope")
+        self.args = args
+        self.hidden_dim = self.context_dim = 128
+        args.corr_radius = 4                                           # raft.py:43-52 inject defaults
+        for k, v in (("dropout", 0), ("alternate_corr", False), ("compute_spatial", False),
+                     ("corr_levels", 4), ("iters", 12), ("fnorm", "instance"), ("cnorm", "batch")):
+            if not hasattr(args, k):
+                setattr(args, k, v)
+        self.fnet = BasicEncoder(output_dim=256, norm_fn=args.fnorm, dropout=args.dropout)
+        self.cnet = BasicEncoder(output_dim=256, norm_fn=args.cnorm, dropout=args.dropout)
+        self.update_block = BasicUpdateBlock(args, hidden_dim=128)
+
+    def freeze_bn(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.eval()
+
+    @staticmethod
+    def upsample_flow(flow, mask):
+        """raft.py:111-122: [N,2,H,W] -> [N,2,8H,8W], softmax-weighted combination of the 3x3 coarse
+        neighbours."""
+        N, _, H, W = flow.shape
+        mask = torch.softmax(mask.view(N, 1, 9, 8, 8, H, W), dim=2)
+        up = F.unfold(8 * flow, [3, 3], padding=1).view(N, 2, 9, 1, 1, H, W)
+        up = torch.sum(mask * up, dim=2).permute(0, 1, 4, 2, 5, 3)
+        return up.reshape(N, 2, 8 * H, 8 * W)
+
+    def forward(self, image1, image2, iters=12, flow_init=None, test_mode=False):
+        iters = self.args.iters                                        # raft.py:126 (argument ignored)
+        image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
+        image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
+        fmap1, fmap2 = self.fnet([image1, image2])
+        fmap1, fmap2 = fmap1.float().contiguous(), fmap2.float().contiguous()
+        if self.args.alternate_corr:
+            corr_fn = AlternateCorrBlock(fmap1, fmap2, radius=self.args.corr_radius)
+        else:
+            corr_fn = CorrBlock(fmap1, fmap2, num_levels=self.args.corr_levels, radius=self.args.corr_radius)
+        net, inp = torch.split(self.cnet(image1), [128, 128], dim=1)
+        net, inp = torch.tanh(net), torch.relu(inp)
+
+        N, _, H, W = image1.shape
+        coords0 = coords_grid(N, H // 8, W // 8, image1.device)
+        coords1 = coords0.clone()
+        if flow_init is not None:
+            coords1 = coords1 + flow_init
+        flow_predictions, flow_up = [], None
+        for it in range(iters):
+            coords1 = coords1.detach()
+            corr = corr_fn(coords1)
+            want = (not test_mode) or it == iters - 1
+            net, up_mask, delta_flow = self.update_block(net, inp, corr, coords1 - coords0, want_mask=want)
+            coords1 = coords1 + delta_flow
+            if want:
+                flow_up = self.upsample_flow(coords1 - coords0, up_mask)
+                flow_predictions.append(flow_up)
+        if test_mode:
+            return coords1 - coords0, flow_up
+        return flow_predictions
