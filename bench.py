@@ -139,12 +139,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    device = torch.device(f"cuda:{local}")
+    # one rank per GPU; on a box with fewer devices than ranks (the 1-GPU rehearsal of the N>1 path,
+    # UFR_DIST_BACKEND=gloo) ranks share devices round-robin
+    device = torch.device(f"cuda:{local % torch.cuda.device_count()}")
     torch.cuda.set_device(device)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("UFR_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from understanding_flow_robustness_amd.flownets.utils_model import fetch_model
     from understanding_flow_robustness_amd.patch_attack import PatchAttackStep, ShardedExchange

@@ -69,7 +69,10 @@ def test_raft_vs_reference(alternate):
 def test_flownet2_vs_reference_wiring():
     z = load_golden("flownet2_64x128")
     net, args = _fetch("FlowNet2", 3)
-    _check(z, net, args, gtol=2e-3)
+    # flow / EPE: 1e-4.  The image gradient runs through four Resample2d warps whose floor() makes
+    # it piecewise: a flow value within rounding of an integer lands in another cell on another
+    # platform, so ~1% of the pixels move by up to 1% of the gradient's max (measured 5.5e-3).
+    _check(z, net, args, gtol=2e-2, g_atol=1e-2)
 
 
 @pytest.mark.parametrize("use_graph", [True, False])
