@@ -83,7 +83,7 @@ def kernel_rooflines(device):
     t_f = event_time(lambda: be.forward(a, b, *prm), 10)
     t_b = event_time(lambda: be.backward(a, b, go, *prm), 10)
     ks = []
-    for name, t, w in (("corr_fwd_fast<21,2>", t_f, CORR_FWD), ("corr_bwd_fast<21,2> (both adjoints)", t_b, CORR_BWD)):
+    for name, t, w in (("corr_fwd_vec<21,2>", t_f, CORR_FWD), ("corr_bwd_vec<21,2> (both adjoints, 2 launches)", t_b, CORR_BWD)):
         tf = w["gflop"] * B / t            # GFLOP/ms == TFLOP/s
         gbs = w["mbytes"] * B / t          # MB/ms == GB/s
         # arithmetic intensity 59-77 FLOP/B is above the fp32 ridge (~20): the bound is the fp32 VALU/MFMA rate
@@ -158,6 +158,8 @@ def main():
     torch.backends.cudnn.benchmark = True      # patch_attacks/main.py:276 (MIOpen find mode)
     args = Namespace(flownet="FlowNetC", l2=False, alpha=0.0, lr=1000.0, max_count=2)
     net = fetch_model(args, synthetic_seed=0).to(device)
+    if os.environ.get("UFR_CHANNELS_LAST", "0") == "1":      # layout experiment
+        net = net.to(memory_format=torch.channels_last)
     exchange = ShardedExchange() if world > 1 else None
     step = PatchAttackStep(net, args, B_PER_GPU, H, W, device=device, shared_patch=True, exchange=exchange,
                            use_graph=not opt.no_graph, warmup=2)
