@@ -1,0 +1,99 @@
+"""Step times of the other BASELINE.json configs on one MI355X (not the bench.py headline line):
+    C2 FlowNetC patch attack B=8 | C3 RAFT (all-pairs / alt_corr) patch attack | C4 PWC-Net patch attack B=8
+    C5 FlowNet2 448x1024 universal-perturbation step
+Prints one JSON object per config: ms per inner-loop iteration, pairs*iterations/s.
+    python tools/bench_configs.py [c2 c3 c3alt c4 c5] [--steps K]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from argparse import Namespace
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from understanding_flow_robustness_amd.flownets.utils_model import fetch_model, predict_flow  # noqa: E402
+from understanding_flow_robustness_amd.patch_attack import PatchAttackStep  # noqa: E402
+from understanding_flow_robustness_amd.universal_perturbation import UniversalPerturbationStep  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def timed(step, steps):
+    step.enqueue(2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step.enqueue(steps)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3 / steps
+
+
+def patch_case(name, flownet, seed, B, H, W, steps, **extra):
+    args = Namespace(flownet=flownet, l2=False, alpha=0.0, lr=1000.0, max_count=2, **extra)
+    net = fetch_model(args, synthetic_seed=seed).to(DEV)
+    args.mixed_precision = False
+    g = torch.Generator().manual_seed(0)
+    tgt, ref = torch.rand(B, 3, H, W, generator=g).to(DEV), torch.rand(B, 3, H, W, generator=g).to(DEV)
+    mask = torch.zeros(B, 3, H, W, device=DEV)
+    mask[:, :, 100:151, 600:651] = 1
+    patch = torch.rand(1, 3, H, W, generator=g).to(DEV)
+    with torch.no_grad():
+        target = -torch.cat([predict_flow(net, None, tgt[i:i + 1], ref[i:i + 1], args) for i in range(B)])
+    step = PatchAttackStep(net, args, B, H, W, device=DEV)
+    step.load(tgt, ref, patch, mask, patch, target)
+    step.run(0)
+    ms = timed(step, steps)
+    mem = torch.cuda.max_memory_allocated() / 2 ** 30
+    return dict(config=name, pairs=B, ms_per_iteration=round(ms, 3), attack_iters_per_s=round(B * 1e3 / ms, 2),
+                peak_mem_gib=round(mem, 2))
+
+
+def universal_case(steps):
+    B, H, W = 1, 448, 1024
+    args = Namespace(flownet="FlowNet2", n_step=10, learning_rate=2e-3, output_norm=0.02, flow_loss="cossim",
+                     perturb_method="ifgsm", perturb_mode="both", add_gaussian=False)
+    net = fetch_model(args, synthetic_seed=3).to(DEV)
+    g = torch.Generator().manual_seed(0)
+    i0, i1 = torch.rand(B, 3, H, W, generator=g).to(DEV), torch.rand(B, 3, H, W, generator=g).to(DEV)
+    with torch.no_grad():
+        target = -predict_flow(net, None, i0, i1, args)
+    step = UniversalPerturbationStep(net, args, B, H, W, device=DEV, shared=True)
+    step.load(i0, i1, torch.zeros(2, 3, H, W, device=DEV), target)
+    step.run(0)
+    step.run(2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step.run(steps)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    return dict(config="c5 FlowNet2 448x1024 universal perturbation step", pairs=B, ms_per_iteration=round(ms, 3),
+                attack_iters_per_s=round(B * 1e3 / ms, 2), peak_mem_gib=round(torch.cuda.max_memory_allocated() / 2 ** 30, 2))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("which", nargs="*", default=["c2", "c3", "c3alt", "c4", "c5"])
+    ap.add_argument("--steps", type=int, default=10)
+    opt = ap.parse_args()
+    torch.backends.cudnn.benchmark = True
+    for w in opt.which:
+        torch.cuda.reset_peak_memory_stats()
+        if w == "c2":
+            r = patch_case("c2 FlowNetC 384x1280 patch attack", "FlowNetC", 0, 8, 384, 1280, opt.steps)
+        elif w == "c3":
+            r = patch_case("c3 RAFT 384x1280 all-pairs, 12 GRU iterations, patch attack", "RAFT", 2, 1, 384, 1280, opt.steps)
+        elif w == "c3alt":
+            r = patch_case("c3 RAFT 384x1280 alt_cuda_corr, 12 GRU iterations, patch attack", "RAFT", 2, 1, 384, 1280,
+                           opt.steps, alternate_corr=True)
+        elif w == "c4":
+            r = patch_case("c4 PWC-Net 384x1280 patch attack", "PWCNet", 1, 8, 384, 1280, opt.steps)
+        else:
+            r = universal_case(opt.steps)
+        print(json.dumps(r), flush=True)
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
