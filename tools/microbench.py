@@ -62,8 +62,12 @@ def run_once():
 
 def sweep():
     base = None
-    for fv, bv in ((4, 4), (0, 0), (1, 1), (2, 2), (3, 0)):
-        env = dict(os.environ, UFR_CORR_FWD_VARIANT=str(fv), UFR_CORR_BWD_VARIANT=str(bv))
+    combos = [(4, 4, 0, 0), (1, 0, 0, 0), (1, 0, 1, 1), (0, 1, 1, 1), (2, 2, 1, 1), (3, 0, 1, 0)]
+    if len(sys.argv) > 2:
+        combos = [combos[0]] + [tuple(int(v) for v in a.split(",")) for a in sys.argv[2:]]
+    for fv, bv, fs, bs in combos:
+        env = dict(os.environ, UFR_CORR_FWD_VARIANT=str(fv), UFR_CORR_BWD_VARIANT=str(bv),
+                   UFR_CORR_FWD_SWZ=str(fs), UFR_CORR_BWD_SWZ=str(bs))
         out = subprocess.run([sys.executable, __file__], env=env, capture_output=True, text=True)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if not line:
@@ -73,7 +77,8 @@ def sweep():
         if base is None:
             base = res
         ok = all(abs(x - y) <= 1e-5 * abs(y) for k in res for x, y in zip(res[k]["chk"], base[k]["chk"]))
-        print(f"== fwd variant {fv}, bwd variant {bv}: checksums {'match' if ok else 'DIFFER from'} the general path")
+        print(f"== fwd variant {fv} (XCD swizzle {fs}), bwd variant {bv} (XCD swizzle {bs}): checksums "
+              f"{'match' if ok else 'DIFFER from'} the general path")
         for k, v in res.items():
             print(f"   {k:24s} fwd {v['fwd_ms']:8.4f} ms  bwd {v['bwd_ms']:8.4f} ms"
                   + (f"   ({v['fwd_tflops']} / {v['bwd_tflops']} TFLOP/s)" if "fwd_tflops" in v else ""))

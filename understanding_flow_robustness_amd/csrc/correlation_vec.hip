@@ -20,6 +20,18 @@ namespace {
 using ufr::ceil_div;
 constexpr int kVecMaxThreads = 384;
 
+// LDS row strides (in floats) that make the 16-byte window reads bank-conflict free.
+// Lane tid = G*j + g reads the 16-byte slot (rowbase(j)/4 + g); ds_read_b128 is serviced in 16-lane
+// groups whose lane ids are distinct mod 16, so it is conflict-free iff slot == tid (mod 16), i.e.
+// rowbase(j) == 4*G*j (mod 64 floats).  A row of U = 4G pixels + 2R halo is therefore padded to
+// U + 64*ceil(2R/64); measured before the padding: SQ_LDS_BANK_CONFLICT = 36% (forward) and 65%
+// (backward) of SQ_LDS_IDX_ACTIVE (profiles/r1_corr_pmc*.txt).
+__host__ __device__ constexpr int padded_row(int U, int R) { return U + ((2 * R + 63) / 64) * 64; }
+// backward: thread-row j = cs*DP + p lives at cs*SC + (t*DP + p)*LU; SC must be == 4*G*DP (mod 64)
+__host__ __device__ constexpr int chunk_stride(int LU, int G, int DP, int CT) {
+  return CT * DP * LU + ((4 * G * DP - CT * DP * LU) % 64 + 64) % 64;
+}
+
 template <int DP>
 __device__ __forceinline__ void lds_put_quad(float* plane0, int plane_stride, const float4 v) {
   if (DP == 2) {   // columns c..c+3 -> plane 0 gets (c, c+2), plane 1 gets (c+1, c+3)
@@ -38,17 +50,36 @@ template <int P, int DP, int PHB, int CK>
 __global__ void __launch_bounds__(kVecMaxThreads) corr_fwd_vec(const float* __restrict__ in1,
                                                                 const float* __restrict__ in2,
                                                                 float* __restrict__ out, int C, int H,
-                                                                int W, int G, float scale, float slope) {
+                                                                int W, int G, float scale, float slope,
+                                                                int swz) {
   constexpr int R = (P - 1) / 2, HALO = R * DP, NB4 = (4 + 2 * R) / 4;
   static_assert(HALO % 4 == 0 && (4 + 2 * R) % 4 == 0, "aligned halo/window required");
   constexpr int NPHG = (P + PHB - 1) / PHB;
   constexpr int N2 = CK, N1 = (CK + PHB - 1) / PHB;   // 16-byte pieces per thread and chunk
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int U = 4 * G, LU = U + 2 * R, QW = W >> 2;
+  const int U = 4 * G, LU = padded_row(U, R), QW = W >> 2;
   float* s1 = smem;
   float* s2 = smem + CK * DP * U;
 
-  const int h = blockIdx.y / NPHG, phg = blockIdx.y % NPHG, n = blockIdx.z;
+  // Workgroup -> (n, h, displacement-row group).  Workgroups (h, phg) and (h + S, phg - 1), S = DP*PHB,
+  // read the SAME in2 rows (h - R*DP + S*phg + DP*{0..PHB-1}): up to NPHG workgroups form a family
+  // f = h + S*phg.  swz 1 enumerates (family, phg) instead of (h, phg) and gives every family to one
+  // XCD (pid % 8 labels the XCD; its L2 then serves NPHG-1 of the NPHG reads of those rows);
+  // (family, phg) pairs whose h falls outside the image are empty workgroups.  Speed only.
+  int h, phg, n;
+  if (swz == 1) {
+    constexpr int S = DP * PHB;
+    const int F = H + S * (NPHG - 1), FQ = (F + 7) >> 3;
+    const int pid = blockIdx.x, x = pid & 7;
+    int t = pid >> 3;
+    phg = t % NPHG; t /= NPHG;
+    const int f = 8 * (t % FQ) + x;
+    n = t / FQ;
+    h = f - S * phg;
+    if (f >= F || h < 0 || h >= H) return;
+  } else {
+    h = blockIdx.x / NPHG; phg = blockIdx.x % NPHG; n = blockIdx.y;
+  }
   const int tid = threadIdx.x, NT = blockDim.x;
   const int phl = tid / (DP * G);
   const int rem = tid - phl * (DP * G);
@@ -165,16 +196,38 @@ template <int P, int DP, int CB, int CT, bool WRT2>
 __global__ void __launch_bounds__(bwd_max_threads(P)) corr_bwd_vec(const float* __restrict__ other,
                                                                     const float* __restrict__ gout,
                                                                     float* __restrict__ gin, int C, int H,
-                                                                    int W, int G) {
+                                                                    int W, int G, int swz) {
   constexpr int R = (P - 1) / 2, HALO = R * DP, NB4 = (4 + 2 * R) / 4;
   constexpr int MAXS = CT, MAXG = (P + CB / CT - 1) / (CB / CT);
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int U = 4 * G, LU = U + 2 * R, QW = W >> 2;
+  const int U = 4 * G, LU = padded_row(U, R), QW = W >> 2;
+  const int SC = chunk_stride(LU, G, DP, CT);
   float* ssrc = smem;
-  float* sg = smem + CB * DP * LU;
+  float* sg = smem + (CB / CT) * SC;
 
   const int NCB = (C + CB - 1) / CB;
-  const int y = blockIdx.y / NCB, c0 = (blockIdx.y % NCB) * CB, n = blockIdx.z;
+  // Workgroup -> (n, y, channel chunk).  Workgroups are dealt round-robin over the 8 XCDs (private
+  // L2s), so pid % 8 labels the XCD.  swz selects which workgroups share an L2 (speed only; every
+  // choice is a bijection):
+  //   swz 0: XCD = channel chunk  -> the 21 re-reads of a source row hit L2, but the gradient rows of
+  //          (n, y) are fetched by all 8 XCDs;
+  //   swz 1: XCD = 2*(y%4) + chunk/4 -> an XCD owns 4 chunks of every 4th row: gradient rows are
+  //          fetched by 2 XCDs, the source rows it re-reads (one row parity, 4 chunks) still fit its L2.
+  int y, c0, n;
+  {
+    const int pid = blockIdx.x;
+    if (swz == 1) {
+      const int x = pid & 7, slot = pid >> 3;
+      const int hq = H >> 2;
+      c0 = (4 * (x & 1) + (slot & 3)) * CB;
+      y = 4 * ((slot >> 2) % hq) + (x >> 1);
+      n = (slot >> 2) / hq;
+    } else {
+      c0 = (pid % NCB) * CB;
+      y = (pid / NCB) % H;
+      n = pid / (NCB * H);
+    }
+  }
   const int tid = threadIdx.x, NT = blockDim.x;
   const int cs = tid / (DP * G);
   const int rem = tid - cs * (DP * G);
@@ -183,7 +236,7 @@ __global__ void __launch_bounds__(bwd_max_threads(P)) corr_bwd_vec(const float* 
   const bool active = cs < CB / CT;
   const long HW = (long)H * W;
 
-  for (int i = tid; i < CB * DP * LU + P * DP * U; i += NT) smem[i] = 0.f;
+  for (int i = tid; i < (CB / CT) * SC + P * DP * U; i += NT) smem[i] = 0.f;
 
   // source-row pieces: offset relative to (channel c0, row 0); the row term ys*W is added per ph
   int gos[MAXS], los[MAXS];
@@ -195,7 +248,7 @@ __global__ void __launch_bounds__(bwd_max_threads(P)) corr_bwd_vec(const float* 
       const int cb = e / QW, q = e - cb * QW;
       if (c0 + cb < C) {
         gos[j] = cb * (int)HW + 4 * q;
-        los[j] = (cb * DP) * LU + (4 * q + HALO) / DP;
+        los[j] = (cb / CT) * SC + ((cb % CT) * DP) * LU + (4 * q + HALO) / DP;
       }
     }
   }
@@ -261,7 +314,7 @@ __global__ void __launch_bounds__(bwd_max_threads(P)) corr_bwd_vec(const float* 
       float b[CT][4 * NB4];
 #pragma unroll
       for (int t = 0; t < CT; ++t) {
-        const float4* bp = reinterpret_cast<const float4*>(&ssrc[((cs * CT + t) * DP + p) * LU + 4 * g]);
+        const float4* bp = reinterpret_cast<const float4*>(&ssrc[cs * SC + (t * DP + p) * LU + 4 * g]);
 #pragma unroll
         for (int q = 0; q < NB4; ++q) {
           const float4 v4 = bp[q];
@@ -310,12 +363,20 @@ int launch_fwd(const float* in1, const float* in2, float* out, int B, int C, int
   constexpr int R = (P - 1) / 2;
   const int G = ceil_div(ceil_div(W, DP), 4);
   const int NT = ufr::round_up(PHB * DP * G, 64);
-  const size_t lds = (size_t)CK * (DP * 4 * G + PHB * DP * (4 * G + 2 * R)) * sizeof(float);
+  const size_t lds = (size_t)CK * (DP * 4 * G + PHB * DP * padded_row(4 * G, R)) * sizeof(float);
   if (NT > kVecMaxThreads || lds > (size_t)ufr::kMaxLds) return 1;   // not eligible: caller falls back
   auto kern = corr_fwd_vec<P, DP, PHB, CK>;
   if (int rc = set_lds(kern, lds)) return rc;
-  dim3 grid(1, H * ((P + PHB - 1) / PHB), B);
-  hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, in1, in2, out, C, H, W, G, scale, slope);
+  static const int swz_env = [] { const char* e = getenv("UFR_CORR_FWD_SWZ"); return e ? atoi(e) : 1; }();
+  constexpr int NPHG = (P + PHB - 1) / PHB;
+  if (swz_env == 1) {
+    const int F = H + DP * PHB * (NPHG - 1), FQ = (F + 7) / 8;
+    const long nblk = (long)B * FQ * NPHG * 8;
+    if (nblk >= 2147483647L) return 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NT), lds, st, in1, in2, out, C, H, W, G, scale, slope, 1);
+  } else {
+    hipLaunchKernelGGL(kern, dim3(H * NPHG, B), dim3(NT), lds, st, in1, in2, out, C, H, W, G, scale, slope, 0);
+  }
   return ufr::launched("corr_fwd_vec");
 }
 
@@ -324,13 +385,17 @@ int launch_bwd(const float* other, const float* gout, float* gin, int B, int C, 
   constexpr int R = (P - 1) / 2;
   const int G = ceil_div(ceil_div(W, DP), 4);
   const int NT = ufr::round_up((CB / CT) * DP * G, 64);
-  const size_t lds = (size_t)(CB * DP * (4 * G + 2 * R) + P * DP * 4 * G) * sizeof(float);
+  const size_t lds = (size_t)((CB / CT) * chunk_stride(padded_row(4 * G, R), G, DP, CT) + P * DP * 4 * G) * sizeof(float);
   if (NT > bwd_max_threads(P) || lds > (size_t)ufr::kMaxLds) return 1;
   if ((long)CB * H * W >= 2147483647L) return 1;   // 32-bit piece offsets
   auto kern = corr_bwd_vec<P, DP, CB, CT, WRT2>;
   if (int rc = set_lds(kern, lds)) return rc;
-  dim3 grid(1, H * ceil_div(C, CB), B);
-  hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, other, gout, gin, C, H, W, G);
+  static const int swz_env = [] { const char* e = getenv("UFR_CORR_BWD_SWZ"); return e ? atoi(e) : 1; }();
+  const int ncb = ceil_div(C, CB);
+  const long nblk = (long)B * H * ncb;
+  const int swz = (swz_env == 1 && ncb == 8 && H % 4 == 0 && nblk % 8 == 0) ? 1 : 0;
+  if (nblk >= 2147483647L) return 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NT), lds, st, other, gout, gin, C, H, W, G, swz);
   return ufr::launched("corr_bwd_vec");
 }
 
@@ -368,11 +433,15 @@ int corr_fwd_vec_launch(const float* in1, const float* in2, float* out, int B, i
 int corr_bwd_vec_launch(const float* in1, const float* in2, const float* gout, float* gin1, float* gin2,
                         int B, int C, int H, int W, int P, int DP, hipStream_t st) {
   if (W % 4 != 0) return 1;
-  static const int variant = [] { const char* e = getenv("UFR_CORR_BWD_VARIANT"); return e ? atoi(e) : 0; }();
+  static const int variant = [] { const char* e = getenv("UFR_CORR_BWD_VARIANT"); return e ? atoi(e) : 3; }();
   if (variant == 4) return 1;
+  if (variant == 3) {   // MFMA formulation (correlation_mfma.hip); 1 = shape not covered -> VALU kernels below
+    const int rc = ufr::corr_bwd_mfma_launch(in1, in2, gout, gin1, gin2, B, C, H, W, P, DP, st);
+    if (rc <= 0) return rc;
+  }
   int rc;
   if (P == 21 && DP == 2) {
-    if (variant == 1) {
+    if (variant == 1 || variant == 3) {
       rc = launch_bwd<21, 2, 16, 4, false>(in2, gout, gin1, B, C, H, W, st);
       if (rc) return rc;
       return launch_bwd<21, 2, 16, 4, true>(in1, gout, gin2, B, C, H, W, st);

@@ -43,6 +43,10 @@ int corr_fwd_vec_launch(const float* in1, const float* in2, float* out, int B, i
 int corr_bwd_vec_launch(const float* in1, const float* in2, const float* gout, float* gin1, float* gin2,
                         int B, int C, int H, int W, int P, int DP, hipStream_t st);
 
+// correlation_mfma.hip: both adjoints on the fp32 matrix cores; same return convention
+int corr_bwd_mfma_launch(const float* in1, const float* in2, const float* gout, float* gin1, float* gin2,
+                         int B, int C, int H, int W, int P, int DP, hipStream_t st);
+
 }  // namespace ufr
 
 #define UFR_REQUIRE(cond, ...) \

@@ -31,7 +31,10 @@ class CorrLookupFunction(torch.autograd.Function):
     """out[B, L*(2r+1)^2, H, W] = windowed bilinear samples of every pyramid level (corr.py:72-96)."""
 
     @staticmethod
-    def forward(ctx, coords, radius, *vols):
+    def forward(ctx, coords, radius, shared, *vols):
+        """`shared`: None, or a `_SharedGrad` through which all lookups of one pyramid (RAFT's 12
+        iterations) accumulate their adjoints into ONE set of buffers: the kernel's `+=` replaces
+        12 zero-fills and 11 full-volume additions of autograd's gradient accumulation."""
         L.require_hip(coords, "coords")
         coords = coords.contiguous()
         vols = tuple(v.contiguous() for v in vols)
@@ -50,6 +53,9 @@ class CorrLookupFunction(torch.autograd.Function):
                                                     int(radius), L.stream()), "corr lookup forward")
         ctx.save_for_backward(coords, *vols)
         ctx.radius = int(radius)
+        ctx.shared = shared
+        if shared is not None:
+            shared.pending += 1
         return out
 
     @staticmethod
@@ -57,23 +63,44 @@ class CorrLookupFunction(torch.autograd.Function):
         coords, *vols = ctx.saved_tensors
         grad_out = grad_out.contiguous()
         B, _, H1, W1 = coords.shape
+        shared = ctx.shared
         with torch.cuda.device(coords.device):
-            grads = [torch.zeros_like(v) for v in vols]
+            if shared is None:
+                grads = [torch.zeros_like(v) for v in vols]
+            else:
+                if shared.acc is None:
+                    shared.acc = [torch.zeros_like(v) for v in vols]
+                grads = shared.acc
             pyr = _pyramid_struct(vols, grads)
             L.check(L.lib().ufr_corr_lookup_backward(C.byref(pyr), L.ptr(coords), L.ptr(grad_out), B, H1,
                                                      W1, ctx.radius, L.stream()), "corr lookup backward")
-        return (None, None, *grads)   # coords are detached every RAFT iteration (raft.py:190)
+        if shared is not None:
+            shared.pending -= 1
+            if shared.pending > 0:          # more adjoints to come: hand autograd nothing yet
+                return (None, None, None, *([None] * len(vols)))
+            shared.acc = None               # the last adjoint delivers the accumulated volumes
+        return (None, None, None, *grads)   # coords are detached every RAFT iteration (raft.py:190)
 
 
-def corr_lookup(pyramid, coords, radius):
-    return CorrLookupFunction.apply(coords, radius, *pyramid)
+class _SharedGrad:
+    """Accumulation state shared by every lookup of one CorrBlock (see CorrLookupFunction.forward).
+    Valid when every lookup's output reaches the loss (true for RAFT: the hidden state chains the
+    iterations), because the last adjoint to run is the one that returns the sum."""
+
+    def __init__(self):
+        self.acc, self.pending = None, 0
+
+
+def corr_lookup(pyramid, coords, radius, shared=None):
+    return CorrLookupFunction.apply(coords, radius, shared, *pyramid)
 
 
 class CorrBlock:
     """models/raft/corr.py:26-106 (all-pairs branch; `compute_spatial` is a visualisation aid)."""
 
-    def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4, share_grad=True):
         self.num_levels, self.radius = num_levels, radius
+        self._shared = _SharedGrad() if share_grad else None
         corr = CorrBlock.corr(fmap1, fmap2)
         batch, h1, w1, dim, h2, w2 = corr.shape
         corr = corr.reshape(batch * h1 * w1, dim, h2, w2)
@@ -86,7 +113,8 @@ class CorrBlock:
         return self.corr_pyramid
 
     def __call__(self, coords):
-        return corr_lookup(self.corr_pyramid, coords, self.radius)
+        needs_grad = torch.is_grad_enabled() and any(v.requires_grad for v in self.corr_pyramid)
+        return corr_lookup(self.corr_pyramid, coords, self.radius, self._shared if needs_grad else None)
 
     @staticmethod
     def corr(fmap1, fmap2):
