@@ -219,5 +219,38 @@ def gen_flownet2():
          weight_digest=state_dict_digest(sd), weight_seed=3)
 
 
+def gen_patch_host():
+    """patch_attacks/utils_patch.py:236-358 under fixed np.random seeds, and one
+    full loader item through patch_attacks/main.py::train (:345-520) with FlowNetC."""
+    up = rh.ref_module("patch_attacks.utils_patch")
+    main = rh.ref_module("patch_attacks.main")
+    out = {}
+    np.random.seed(1234)
+    patch, mask, shape = up.init_patch_circle(384, 0.1329)            # 51x51 like the README command
+    out.update(init_patch=patch, init_mask=mask, init_shape=np.array(shape))
+    for tag, seed, dshape in (("t0", 7, (1, 3, 256, 256)), ("t1", 8, (1, 3, 384, 1280))):
+        np.random.seed(seed)
+        x, xm, xp, rx, ry, pshape = up.circle_transform(patch.copy(), mask.copy(), patch.copy(), dshape, shape, True)
+        ys, xs = slice(ry, ry + pshape[-2]), slice(rx, rx + pshape[-1])
+        out.update({f"{tag}_patch": x[:, :, ys, xs], f"{tag}_mask": xm[:, :, ys, xs], f"{tag}_init": xp[:, :, ys, xs],
+                    f"{tag}_loc": np.array([rx, ry]), f"{tag}_shape": np.array(pshape),
+                    f"{tag}_sum": np.array([x.sum(), xm.sum(), xp.sum()])})
+    # one loader item through the reference's train()
+    net, sd = _ref_flownetc(seed=0)
+    g = torch.Generator().manual_seed(101)
+    tgt, ref = torch.rand(1, 3, 128, 192, generator=g), torch.rand(1, 3, 128, 192, generator=g)
+    np.random.seed(99)
+    p0, m0, sh0 = up.init_patch_circle(128, 0.2)                       # 25x25 patch on a 128x192 frame
+    main.args = Namespace(flownet="FlowNetC", l2=False, alpha=0.0, lr=1.0e5, max_count=2, log_terminal=False,
+                          patch_type="circle", norotate=False, training_output_freq=0, epoch_size=1)
+    main.n_iter = 0
+    np.random.seed(5)
+    p1, m1, pi1, sh1 = main.train(p0.copy(), m0.copy(), p0.copy(), sh0, [(tgt, [ref, ref])], net)
+    out.update(train_tgt=tgt, train_ref=ref, train_patch0=p0, train_mask0=m0, train_patch1=p1, train_mask1=m1,
+               train_init1=pi1, train_shape1=np.array(sh1), weight_digest=state_dict_digest(sd))
+    save("patch_host_transform", **out)
+
+
 GENERATORS = {"flownetc": gen_flownetc, "attack": gen_attack, "losses": gen_losses, "pwc": gen_pwc,
+              "patch_host": gen_patch_host,
               "raft": gen_raft, "universal": gen_universal, "flownet2": gen_flownet2}

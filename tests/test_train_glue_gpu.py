@@ -1,0 +1,32 @@
+"""GPU suite: one loader item of patch_attacks/main.py::train (:363-461) through the product's
+`train_sample` (host transform + fused HIP attack step + crop/zoom) against the reference's trace."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_train_sample_matches_reference():
+    from understanding_flow_robustness_amd import utils_patch as up
+    from understanding_flow_robustness_amd.flownets.utils_model import fetch_model
+    from understanding_flow_robustness_amd.patch_attack import train_sample
+    z = load_golden("patch_host_transform")
+    args = Namespace(flownet="FlowNetC", l2=False, alpha=0.0, lr=1.0e5, max_count=2, patch_type="circle")
+    net = fetch_model(args, synthetic_seed=0).to(DEV)
+    np.random.seed(99)
+    p0, m0, sh0 = up.init_patch_circle(128, 0.2)
+    np.random.seed(5)
+    p1, m1, i1, sh1 = train_sample(net, t(z["train_tgt"], DEV), t(z["train_ref"], DEV), t(z["train_ref"], DEV),
+                                   p0.copy(), m0.copy(), p0.copy(), sh0, sh0, args)
+    assert tuple(sh1) == tuple(z["train_shape1"])
+    assert np.array_equal(m1, z["train_mask1"])                      # placement / mask: index outputs, exact
+    assert np.allclose(i1, z["train_init1"], rtol=0, atol=1e-7)
+    upd = float(np.abs(z["train_patch1"] - z["train_patch0"] * z["train_mask0"]).max())
+    err = float(np.abs(p1 - z["train_patch1"]).max())
+    assert err <= 1e-4 * max(upd, 1.0) + 2e-4 * upd, f"patch err {err:.3e}, update {upd:.3e}"

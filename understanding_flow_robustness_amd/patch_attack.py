@@ -229,3 +229,29 @@ def attack(flow_net, tgt_img_var, ref_past_img_var, ref_future_img_var, patch_va
     with torch.no_grad():
         patch_var.copy_(step.patch)
     return step.adv_tgt.detach().clone(), None, step.adv_ref.detach().clone(), patch_var
+
+
+def train_sample(flow_net, tgt_img, ref_past_img, ref_future_img, patch, mask, patch_init, patch_shape,
+                 patch_shape_orig, args: Namespace, use_graph=True):
+    """One loader item of patch_attacks/main.py::train (:363-461): clean forward, host-side
+    `circle_transform` (numpy RNG consumed like the reference), H2D, the fused `attack`, D2H, crop at
+    the placement and resample to the original patch size.  numpy patch state in, numpy patch state out:
+    returns (patch, mask, patch_init, patch_shape).  Batch 1, like the reference (`patch[i]` indexing)."""
+    from .utils_patch import circle_transform, crop_and_restore
+    dev = tgt_img.device
+    with torch.no_grad():
+        flow_pred = predict_flow(flow_net, ref_past_img, tgt_img, ref_future_img, args)
+    if getattr(args, "patch_type", "circle") != "circle":
+        raise NotImplementedError("only --patch_type circle (the README's configuration) is mirrored")
+    # NB the reference passes `True` as the 6th positional argument, i.e. margin=1 (main.py:377)
+    patch, mask, patch_init, rx, ry, patch_shape = circle_transform(
+        patch, mask, patch_init, tuple(tgt_img.shape), patch_shape, True)
+    patch_t = torch.FloatTensor(patch).to(dev)
+    mask_t = torch.FloatTensor(mask).to(dev)
+    init_t = torch.FloatTensor(patch_init).to(dev)
+    target = -flow_pred.detach()
+    _, _, _, patch_t = attack(flow_net, tgt_img, ref_past_img, ref_future_img, patch_t, mask_t, init_t, target,
+                              None, args=args, use_graph=use_graph)
+    masked = torch.mul(mask_t, patch_t)
+    return crop_and_restore(masked.cpu().numpy(), mask_t.cpu().numpy(), init_t.cpu().numpy(), rx, ry, patch_shape,
+                            patch_shape_orig)
