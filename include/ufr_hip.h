@@ -157,6 +157,24 @@ int ufr_attack_gate(const float* loss_cur, float* state, float threshold, ufr_st
 int ufr_flow_loss(const float* flow, const float* target, float* grad_flow, float* loss, int B,
                   int HW, int kind, float weight, ufr_stream_t stream);
 
+/* ---- RAFT SepConvGRU gate arithmetic -----------------------------------------------------------
+ * replaces the elementwise half of models/raft/update.py:61-73 (10 launches forward per half-step):
+ *   gates: z = sigmoid(zr_pre[:, :Ch]);  rh = sigmoid(zr_pre[:, Ch:]) * h      zr_pre: [B,2Ch,HW]
+ *          rh is written with batch stride rh_bstride (>= Ch*HW) so it can land inside the
+ *          [r*h | x] buffer that feeds convq.
+ *   blend: h' = (1 - z)*h + z*tanh(q_pre)
+ * backward entry points return every input gradient of the fused expression (g_h is the part of
+ * d/dh that flows through this stage only; the caller adds the stages together). */
+int ufr_gru_gates_forward(const float* zr_pre, const float* h, float* z_out, float* rh_out, int B, int Ch,
+                          int HW, long rh_bstride, ufr_stream_t stream);
+int ufr_gru_gates_backward(const float* zr_pre, const float* h, const float* g_z, const float* g_rh,
+                           float* g_zr, float* g_h, int B, int Ch, int HW, long grh_bstride,
+                           ufr_stream_t stream);
+int ufr_gru_blend_forward(const float* q_pre, const float* z, const float* h, float* h_out, long total,
+                          ufr_stream_t stream);
+int ufr_gru_blend_backward(const float* q_pre, const float* z, const float* h, const float* g, float* g_qpre,
+                           float* g_z, float* g_h, long total, ufr_stream_t stream);
+
 /* ---- universal perturbation / I-FGSM inner loop, elementwise stages ------------------------------
  * replaces global_attacks/perturb_model.py:102-145 (compute_flow_loss) and the tensor arithmetic of
  * global_attacks/universal_perturbation.py:477-520 (attack), :667-675 (add_universal_perturbation).

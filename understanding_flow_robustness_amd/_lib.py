@@ -55,6 +55,10 @@ SIGNATURES = {
     "ufr_patch_update": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _l, _f, _f, _f,
                          _f, _i, _vp, _vp],
     "ufr_attack_gate": [_vp, _vp, _f, _vp],
+    "ufr_gru_gates_forward": [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _vp],
+    "ufr_gru_gates_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _l, _vp],
+    "ufr_gru_blend_forward": [_vp, _vp, _vp, _vp, _l, _vp],
+    "ufr_gru_blend_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp],
     "ufr_flow_loss_ex": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp],
     "ufr_universal_update": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _i, _i, _i, _i,
                              _i, _vp],

@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import _lib as L
 from .raft_corr import AlternateCorrBlock, CorrBlock
 
 
@@ -97,24 +98,81 @@ class FlowHead(nn.Module):
         return self.conv2(self.relu(self.conv1(x)))
 
 
+class _GruGates(torch.autograd.Function):
+    """z = sigmoid(zr[:, :Ch]); rh = sigmoid(zr[:, Ch:]) * h   (csrc/gru.hip)."""
+
+    @staticmethod
+    def forward(ctx, zr_pre, h):
+        zr_pre, h = zr_pre.contiguous(), h.contiguous()
+        B, Ch, H, W = h.shape
+        z, rh = torch.empty_like(h), torch.empty_like(h)
+        L.check(L.lib().ufr_gru_gates_forward(L.ptr(zr_pre), L.ptr(h), L.ptr(z), L.ptr(rh), B, Ch, H * W,
+                                              Ch * H * W, L.stream()), "gru gates forward")
+        ctx.save_for_backward(zr_pre, h)
+        return z, rh
+
+    @staticmethod
+    def backward(ctx, g_z, g_rh):
+        zr_pre, h = ctx.saved_tensors
+        B, Ch, H, W = h.shape
+        g_z = torch.zeros_like(h) if g_z is None else g_z.contiguous()
+        g_rh = torch.zeros_like(h) if g_rh is None else g_rh.contiguous()
+        g_zr, g_h = torch.empty_like(zr_pre), torch.empty_like(h)
+        L.check(L.lib().ufr_gru_gates_backward(L.ptr(zr_pre), L.ptr(h), L.ptr(g_z), L.ptr(g_rh), L.ptr(g_zr),
+                                               L.ptr(g_h), B, Ch, H * W, Ch * H * W, L.stream()), "gru gates backward")
+        return g_zr, g_h
+
+
+class _GruBlend(torch.autograd.Function):
+    """h' = (1 - z)*h + z*tanh(q_pre)   (csrc/gru.hip)."""
+
+    @staticmethod
+    def forward(ctx, q_pre, z, h):
+        q_pre, z, h = q_pre.contiguous(), z.contiguous(), h.contiguous()
+        out = torch.empty_like(h)
+        L.check(L.lib().ufr_gru_blend_forward(L.ptr(q_pre), L.ptr(z), L.ptr(h), L.ptr(out), h.numel(), L.stream()),
+                "gru blend forward")
+        ctx.save_for_backward(q_pre, z, h)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q_pre, z, h = ctx.saved_tensors
+        g = g.contiguous()
+        g_q, g_z, g_h = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
+        L.check(L.lib().ufr_gru_blend_backward(L.ptr(q_pre), L.ptr(z), L.ptr(h), L.ptr(g), L.ptr(g_q), L.ptr(g_z),
+                                               L.ptr(g_h), h.numel(), L.stream()), "gru blend backward")
+        return g_q, g_z, g_h
+
+
 class SepConvGRU(nn.Module):
-    """update.py:35-73: a horizontal (1x5) then a vertical (5x1) convolutional GRU step."""
+    """update.py:35-73: a horizontal (1x5) then a vertical (5x1) convolutional GRU step.
+    On the device the z and r convolutions of a half-step run as ONE convolution (weights stacked
+    once per forward, `cache`) and the gate arithmetic is two fused kernels instead of ten."""
 
     def __init__(self, hidden_dim=128, input_dim=192 + 128):
         super().__init__()
+        self._pads = {"1": (0, 2), "2": (2, 0)}
         for tag, k, pad in (("1", (1, 5), (0, 2)), ("2", (5, 1), (2, 0))):
             for gate in "zrq":
                 setattr(self, f"conv{gate}{tag}", nn.Conv2d(hidden_dim + input_dim, hidden_dim, k, padding=pad))
 
-    def _half(self, h, x, tag):
-        hx = torch.cat([h, x], dim=1)
-        z = torch.sigmoid(getattr(self, "convz" + tag)(hx))
-        r = torch.sigmoid(getattr(self, "convr" + tag)(hx))
-        q = torch.tanh(getattr(self, "convq" + tag)(torch.cat([r * h, x], dim=1)))
-        return (1 - z) * h + z * q
+    def _half(self, h, x, tag, cache):
+        convz, convr, convq = (getattr(self, f"conv{g}{tag}") for g in "zrq")
+        if not (h.is_cuda and h.dtype == torch.float32):
+            raise RuntimeError("SepConvGRU runs on float32 HIP tensors (no CPU path in this build)")
+        if cache is None or tag not in cache:
+            fused = (torch.cat([convz.weight, convr.weight]), torch.cat([convz.bias, convr.bias]))
+            if cache is not None:
+                cache[tag] = fused
+        else:
+            fused = cache[tag]
+        zr = F.conv2d(torch.cat([h, x], dim=1), fused[0], fused[1], padding=self._pads[tag])
+        z, rh = _GruGates.apply(zr, h)
+        return _GruBlend.apply(convq(torch.cat([rh, x], dim=1)), z, h)
 
-    def forward(self, h, x):
-        return self._half(self._half(h, x, "1"), x, "2")
+    def forward(self, h, x, cache=None):
+        return self._half(self._half(h, x, "1", cache), x, "2", cache)
 
 
 class BasicMotionEncoder(nn.Module):
@@ -151,9 +209,9 @@ class BasicUpdateBlock(nn.Module):
         self.mask = nn.Sequential(nn.Conv2d(128, 256, 3, padding=1), nn.ReLU(inplace=True),
                                   nn.Conv2d(256, 64 * 9, 1, padding=0))
 
-    def forward(self, net, inp, corr, flow, want_mask=True):
+    def forward(self, net, inp, corr, flow, want_mask=True, cache=None):
         motion_features = self.encoder(flow, corr)
-        net = self.gru(net, torch.cat([inp, motion_features], dim=1))
+        net = self.gru(net, torch.cat([inp, motion_features], dim=1), cache)
         delta_flow = self.flow_head(net)
         # the x8 convex-upsampling mask only matters for the iteration whose flow is returned
         mask = 0.25 * self.mask(net) if want_mask else None
@@ -218,11 +276,13 @@ class RAFT(nn.Module):
         if flow_init is not None:
             coords1 = coords1 + flow_init
         flow_predictions, flow_up = [], None
+        gru_cache = {}                      # stacked z|r gate weights, built once per forward
         for it in range(iters):
             coords1 = coords1.detach()
             corr = corr_fn(coords1)
             want = (not test_mode) or it == iters - 1
-            net, up_mask, delta_flow = self.update_block(net, inp, corr, coords1 - coords0, want_mask=want)
+            net, up_mask, delta_flow = self.update_block(net, inp, corr, coords1 - coords0, want_mask=want,
+                                                         cache=gru_cache)
             coords1 = coords1 + delta_flow
             if want:
                 flow_up = self.upsample_flow(coords1 - coords0, up_mask)
