@@ -83,13 +83,21 @@ def kernel_rooflines(device):
     t_f = event_time(lambda: be.forward(a, b, *prm), 10)
     t_b = event_time(lambda: be.backward(a, b, go, *prm), 10)
     ks = []
-    for name, t, w in (("corr_fwd_vec<21,2>", t_f, CORR_FWD), ("corr_bwd_vec<21,2> (both adjoints, 2 launches)", t_b, CORR_BWD)):
+    # HBM-side bytes per launch from the PMC passes of this round (never measured live: rocprofv3 only)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_corr_traffic.json")) as f:
+            pmc = json.load(f)
+    except OSError:
+        pmc = {}
+    for name, t, w in (("corr_fwd_vec<21,2>", t_f, CORR_FWD), ("corr_bwd_mfma<21,2> (both adjoints)", t_b, CORR_BWD)):
         tf = w["gflop"] * B / t            # GFLOP/ms == TFLOP/s
         gbs = w["mbytes"] * B / t          # MB/ms == GB/s
         # arithmetic intensity 59-77 FLOP/B is above the fp32 ridge (~20): the bound is the fp32 VALU/MFMA rate
         ks.append(dict(kernel=name, ms=round(t, 4), bound="mfma", achieved=round(tf, 2), peak=PEAK_FP32_TFLOPS,
                        unit="TFLOP/s", frac=round(tf / PEAK_FP32_TFLOPS, 4), hbm_gbs=round(gbs, 1),
-                       hbm_frac=round(gbs / PEAK_HBM_GBS, 4)))
+                       hbm_frac=round(gbs / PEAK_HBM_GBS, 4),
+                       traffic=(pmc[name]["fetch_bytes"] + pmc[name]["write_bytes"]) if name in pmc else None,
+                       algorithmic_bytes=int(w["mbytes"] * 1e6 * B)))
     return ks
 
 

@@ -251,6 +251,29 @@ def gen_patch_host():
     save("patch_host_transform", **out)
 
 
+def gen_validate():
+    """patch_attacks/main.py::validate_flow_with_gt (:616-784) over a 3-item list loader (KITTI-style
+    3-channel ground truth with a validity mask), FlowNetC."""
+    up = rh.ref_module("patch_attacks.utils_patch")
+    main = rh.ref_module("patch_attacks.main")
+    net, sd = _ref_flownetc(seed=0)
+    g = torch.Generator().manual_seed(111)
+    items = []
+    for _ in range(3):
+        tgt, ref = torch.rand(1, 3, 128, 192, generator=g), torch.rand(1, 3, 128, 192, generator=g)
+        gt = torch.cat((4 * torch.randn(1, 2, 100, 150, generator=g),
+                        (torch.rand(1, 1, 100, 150, generator=g) > 0.3).float()), 1)
+        items.append((ref, tgt, ref, gt, None, None, None))
+    np.random.seed(17)
+    p0, m0, sh0 = up.init_patch_circle(128, 0.2)
+    main.args = Namespace(flownet="FlowNetC", patch_type="circle", norotate=False, log_output=False, log_terminal=False)
+    np.random.seed(23)
+    avg, names = main.validate_flow_with_gt(p0.copy(), m0.copy(), sh0, items, net, 0, None, None)
+    save("validate_flownetc", tgt=torch.cat([i[1] for i in items]), ref=torch.cat([i[2] for i in items]),
+         gt=torch.cat([i[3] for i in items]), patch0=p0, mask0=m0, errors=np.array(avg), weight_digest=state_dict_digest(sd))
+    print(dict(zip(names, avg)))
+
+
 GENERATORS = {"flownetc": gen_flownetc, "attack": gen_attack, "losses": gen_losses, "pwc": gen_pwc,
-              "patch_host": gen_patch_host,
+              "patch_host": gen_patch_host, "validate": gen_validate,
               "raft": gen_raft, "universal": gen_universal, "flownet2": gen_flownet2}

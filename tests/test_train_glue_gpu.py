@@ -30,3 +30,20 @@ def test_train_sample_matches_reference():
     upd = float(np.abs(z["train_patch1"] - z["train_patch0"] * z["train_mask0"]).max())
     err = float(np.abs(p1 - z["train_patch1"]).max())
     assert err <= 1e-4 * max(upd, 1.0) + 2e-4 * upd, f"patch err {err:.3e}, update {upd:.3e}"
+
+
+def test_validate_flow_with_gt_matches_reference():
+    """patch_attacks/main.py::validate_flow_with_gt (:616-784): clean/adversarial EPE and cosine
+    similarity averaged over a 3-item loader; batched on the device, one host sync."""
+    from understanding_flow_robustness_amd.flownets.utils_model import fetch_model
+    from understanding_flow_robustness_amd.patch_attack import validate_flow_with_gt
+    z = load_golden("validate_flownetc")
+    args = Namespace(flownet="FlowNetC", patch_type="circle")
+    net = fetch_model(args, synthetic_seed=0).to(DEV)
+    tgt, ref, gt = t(z["tgt"], DEV), t(z["ref"], DEV), t(z["gt"], DEV)
+    items = [(ref[i:i + 1], tgt[i:i + 1], ref[i:i + 1], gt[i:i + 1]) for i in range(3)]
+    np.random.seed(23)
+    avg, names = validate_flow_with_gt(z["patch0"].copy(), z["mask0"].copy(), tuple(z["patch0"].shape), items, net, args)
+    assert names == ["epe", "adv_epe", "cos_sim", "adv_cos_sim"]
+    for got, want, n in zip(avg, z["errors"], names):
+        assert abs(got - want) <= 1e-4 * max(abs(want), 1e-3), f"{n}: {got} vs {want}"

@@ -13,7 +13,8 @@ def _resize(pred, gt):
     return F.interpolate(pred, size=gt.shape[-2:], mode="bilinear", align_corners=False)
 
 
-def compute_epe(gt, pred):
+def epe_tensor(gt, pred):
+    """compute_epe without the host read: a 0-d tensor (batched validation keeps it on the device)."""
     _, _, h_pred, w_pred = pred.size()
     bs, nc, h_gt, w_gt = gt.size()
     pred = _resize(pred, gt)
@@ -22,18 +23,26 @@ def compute_epe(gt, pred):
     epe = torch.sqrt(torch.pow(gt[:, 0] - u_pred, 2) + torch.pow(gt[:, 1] - v_pred, 2))
     if nc == 3:
         valid = gt[:, 2]
-        return ((epe * valid).sum() / (valid.sum() + epsilon)).item()
-    return (epe.sum() / (bs * h_gt * w_gt)).item()
+        return (epe * valid).sum() / (valid.sum() + epsilon)
+    return epe.sum() / (bs * h_gt * w_gt)
 
 
-def compute_cossim(gt, pred):
+def cossim_tensor(gt, pred):
     bs, nc, h_gt, w_gt = gt.size()
     pred = _resize(pred, gt)
     similarity = F.cosine_similarity(gt[:, :2], pred)
     if nc == 3:
         valid = gt[:, 2]
-        return ((similarity * valid).sum() / (valid.sum() + epsilon)).item()
-    return (similarity.sum() / (bs * h_gt * w_gt)).item()
+        return (similarity * valid).sum() / (valid.sum() + epsilon)
+    return similarity.sum() / (bs * h_gt * w_gt)
+
+
+def compute_epe(gt, pred):
+    return epe_tensor(gt, pred).item()
+
+
+def compute_cossim(gt, pred):
+    return cossim_tensor(gt, pred).item()
 
 
 def multiscale_cossim(gt, pred):

@@ -255,3 +255,45 @@ def train_sample(flow_net, tgt_img, ref_past_img, ref_future_img, patch, mask, p
     masked = torch.mul(mask_t, patch_t)
     return crop_and_restore(masked.cpu().numpy(), mask_t.cpu().numpy(), init_t.cpu().numpy(), rx, ry, patch_shape,
                             patch_shape_orig)
+
+
+ERROR_NAMES = ["epe", "adv_epe", "cos_sim", "adv_cos_sim"]
+
+
+def validate_flow_with_gt(patch, mask, patch_shape, val_loader, flow_net, args: Namespace):
+    """patch_attacks/main.py::validate_flow_with_gt (:616-784): for every validation item place the
+    patch (host `circle_transform`, same RNG order), run the clean and the patched pair, and average
+    EPE / cosine similarity against the ground-truth flow.  Returns `(errors_avg, error_names)`.
+
+    Differences from the reference, none of them numeric: the clean and the adversarial pair run as
+    ONE batch of two, paste+clamp is the fused kernel, the four metrics stay on the device and the
+    host synchronises once at the end instead of four times per item (`.item()` in losses.py)."""
+    from . import losses
+    from .utils_patch import circle_transform
+    if getattr(args, "patch_type", "circle") != "circle":
+        raise NotImplementedError("only --patch_type circle is mirrored")
+    flow_net.eval()
+    lo, hi = _pixel_range(args.flownet)
+    sums, count = None, 0
+    with torch.no_grad():
+        for item in val_loader:
+            ref_past, tgt, ref_future, flow_gt = item[0], item[1], item[2], item[3]
+            dev = tgt.device
+            L.require_hip(tgt, "tgt_img", contiguous=False)
+            patch_full, mask_full, _, _, _, _ = circle_transform(patch, mask, patch.copy(), tuple(tgt.shape), patch_shape)
+            patch_t = torch.FloatTensor(patch_full).to(dev)
+            mask_t = torch.FloatTensor(mask_full).to(dev)
+            tgt, ref_future = tgt.contiguous(), ref_future.contiguous()
+            B, _, H, W = tgt.shape
+            adv_tgt, adv_ref = torch.empty_like(tgt), torch.empty_like(ref_future)
+            L.check(L.lib().ufr_patch_paste(L.ptr(tgt), L.ptr(ref_future), L.ptr(patch_t), L.ptr(mask_t), L.ptr(adv_tgt),
+                                            L.ptr(adv_ref), B, 3 * H * W, 3 * H * W, 3 * H * W, 1, lo, hi, L.stream()),
+                    "patch paste")
+            flows = predict_flow(flow_net, None, torch.cat((tgt, adv_tgt)), torch.cat((ref_future, adv_ref)), args)
+            flow_fwd, adv_flow = flows[:B], flows[B:]
+            vals = torch.stack([losses.epe_tensor(flow_gt, flow_fwd), losses.epe_tensor(flow_gt, adv_flow),
+                                losses.cossim_tensor(flow_gt, flow_fwd), losses.cossim_tensor(flow_gt, adv_flow)])
+            sums = vals if sums is None else sums + vals
+            count += 1
+    avg = (sums / max(count, 1)).tolist() if sums is not None else [0.0] * 4
+    return avg, list(ERROR_NAMES)
