@@ -277,3 +277,29 @@ def gen_validate():
 GENERATORS = {"flownetc": gen_flownetc, "attack": gen_attack, "losses": gen_losses, "pwc": gen_pwc,
               "patch_host": gen_patch_host, "validate": gen_validate,
               "raft": gen_raft, "universal": gen_universal, "flownet2": gen_flownet2}
+
+
+def gen_perturb_model():
+    """global_attacks/perturb_model.py::PerturbationsModel.forward (:211-272) for flow: FGSM, I-FGSM
+    (3 steps, untargeted and targeted) and MI-FGSM (3 steps) on FlowNetC."""
+    pm = rh.ref_module("global_attacks.perturb_model")
+    net, sd = _ref_flownetc(seed=0)
+    H, W = 64, 128
+    g = torch.Generator().manual_seed(121)
+    i0, i1 = torch.rand(1, 3, H, W, generator=g), torch.rand(1, 3, H, W, generator=g)
+    with torch.no_grad():
+        gt = net(i0, i1)                          # perturb_main.py attacks away from the clean prediction
+    out = dict(img0=i0, img1=i1, gt=gt, weight_digest=state_dict_digest(sd))
+    args = Namespace(flownet="FlowNetC", flow_loss="l2")
+    for tag, method, targeted in (("fgsm", "fgsm", False), ("ifgsm", "ifgsm", False), ("ifgsm_targeted", "ifgsm", True),
+                                  ("mifgsm", "mifgsm", False)):
+        model = pm.PerturbationsModel(perturb_method=method, perturb_mode="both", output_norm=0.02, n_step=3,
+                                      learning_rate=0.008, momentum=0.47, probability_diverse_input=0.0,
+                                      device=torch.device("cpu"), disparity=False, targeted=targeted, print_out=False,
+                                      args=args)
+        n0, n1, a0, a1 = model.forward(net, i0.clone(), i1.clone(), gt.clone())
+        out[f"{tag}_noise0"], out[f"{tag}_noise1"], out[f"{tag}_adv0"] = n0, n1, a0
+    save("perturb_model_flownetc", **out)
+
+
+GENERATORS["perturb_model"] = gen_perturb_model

@@ -46,4 +46,4 @@ def test_validate_flow_with_gt_matches_reference():
     avg, names = validate_flow_with_gt(z["patch0"].copy(), z["mask0"].copy(), tuple(z["patch0"].shape), items, net, args)
     assert names == ["epe", "adv_epe", "cos_sim", "adv_cos_sim"]
     for got, want, n in zip(avg, z["errors"], names):
-        assert abs(got - want) <= 1e-4 * max(abs(want), 1e-3), f"{n}: {got} vs {want}"
+        assert abs(got - want) <= 1e-4 * abs(want) + 1e-5, f"{n}: {got} vs {want}"   # cos-sim averages ~2e-3 here
