@@ -287,8 +287,8 @@ def gen_perturb_model():
     H, W = 64, 128
     g = torch.Generator().manual_seed(121)
     i0, i1 = torch.rand(1, 3, H, W, generator=g), torch.rand(1, 3, H, W, generator=g)
-    with torch.no_grad():
-        gt = net(i0, i1)                          # perturb_main.py attacks away from the clean prediction
+    with torch.no_grad():                         # a ground truth away from the prediction: at gt == prediction
+        gt = net(i0, i1) + 3.0 * torch.randn(1, 2, H, W, generator=g)   # the L2 loss has a zero gradient
     out = dict(img0=i0, img1=i1, gt=gt, weight_digest=state_dict_digest(sd))
     args = Namespace(flownet="FlowNetC", flow_loss="l2")
     for tag, method, targeted in (("fgsm", "fgsm", False), ("ifgsm", "ifgsm", False), ("ifgsm_targeted", "ifgsm", True),
