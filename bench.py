@@ -32,7 +32,23 @@ sys.path.insert(0, ROOT)
 H, W, B_PER_GPU = 384, 1280, 8
 PATCH = 51                      # --patch-size 0.1329 * 384 (utils_patch.py:760-766)
 # algorithmic work per frame pair per iteration, forward + data gradient (SURVEY.md 8d / BASELINE.md)
-GFLOP_PER_PAIR_STEP = 2 * 111.9 + 1.734 + 3.468
+GFLOP_NET_FWD = 111.9           # FlowNetC convolutions, one pair, forward
+GFLOP_PREFIX_FWD = 2 * (2.312 + 12.583 + 12.583)   # conv1-3 on both frames (2*Cin*Cout*k*k*Hout*Wout)
+GFLOP_CORR = 1.734 + 3.468
+
+
+def gflop_per_pair_step(window_hw, max_count):
+    """FLOPs the step EXECUTES per pair and iteration.  Full-frame: whole network forward + data gradient.
+    Windowed prefix (patch_attack.py): head forward + adjoint at full size, conv1-3 forward + adjoint on
+    the window, plus the one full-frame conv1-3 forward per attack() call spread over its iterations."""
+    if window_hw is None:
+        return 2 * GFLOP_NET_FWD + GFLOP_CORR
+    frac = window_hw[0] * window_hw[1] / float(H * W)
+    head = GFLOP_NET_FWD - GFLOP_PREFIX_FWD
+    return 2 * head + GFLOP_CORR + 2 * GFLOP_PREFIX_FWD * frac + GFLOP_PREFIX_FWD / max_count
+
+
+GFLOP_PER_PAIR_STEP = gflop_per_pair_step(None, 2)
 PEAK_FP32_TFLOPS = 157.3        # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
 PEAK_HBM_GBS = 8000.0
 CORR_FWD = dict(gflop=1.734, mbytes=29.3)   # per [1,256,48,160] pair (SURVEY.md 8d)
@@ -142,6 +158,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--max-count", type=int, default=2, help="iterations per attack() call (main.py:79)")
     opt = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -174,30 +191,49 @@ def main():
     step = PatchAttackStep(net, args, B_PER_GPU, H, W, device=device, shared_patch=True, exchange=exchange,
                            use_graph=not opt.no_graph, warmup=2)
 
-    tgt, ref, mask = synthetic_batch(B_PER_GPU, 1000 + rank, device)
+    # two resident batches (frames AND patch placements differ): consecutive attack() calls never see
+    # the same operands, so nothing cached for one call can serve the next
     g = torch.Generator().manual_seed(7)
     patch0 = torch.rand(1, 3, H, W, generator=g).to(device)     # same patch on every rank
-    with torch.no_grad():
-        target = -torch.cat([net(tgt[i:i + 1], ref[i:i + 1]) for i in range(B_PER_GPU)])   # main.py:395
-    step.load(tgt, ref, patch0, mask, patch0, target)
+    batches = []
+    for k in range(2):
+        tgt, ref, mask = synthetic_batch(B_PER_GPU, 1000 + 17 * k + rank, device)
+        with torch.no_grad():
+            target = -torch.cat([net(tgt[i:i + 1], ref[i:i + 1]) for i in range(B_PER_GPU)])   # main.py:395
+        batches.append((tgt, ref, patch0, mask, patch0, target))
+    step.load(*batches[0])
     step.run(0)                                                  # warm-up + graph capture, reloads operands
-    step.state.zero_()
-    step.state[0] = 0
+    mc = max(1, opt.max_count)
+    executed_acc = torch.zeros(1, device=device)
+
+    def attack_calls(iterations, first_call):
+        """`iterations` inner-loop iterations as attack() calls of `max_count` (main.py:79 default 2): every
+        call loads a different batch (new frames, new placement: paste, window placement, full-frame prefix)
+        and then replays the captured iteration.  Nothing is read back."""
+        call, left = first_call, iterations
+        while left > 0:
+            step.load(*batches[call % 2])
+            n = min(mc, left)
+            step.enqueue(n)
+            executed_acc.add_(step.state[1])
+            call, left = call + 1, left - n
+        return call
+
     # the throughput run must never trip the early exit: an iteration that is skipped is not work done
-    step.enqueue(opt.warmup)
+    calls_done = attack_calls(opt.warmup, 0)
     torch.cuda.synchronize(device)
-    executed0 = float(step.state[1])
+    executed0 = float(executed_acc)
 
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    step.enqueue(opt.steps)
+    attack_calls(opt.steps, calls_done)
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    executed = float(step.state[1]) - executed0
+    executed = float(executed_acc) - executed0
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -205,11 +241,14 @@ def main():
     if int(executed) != opt.steps:
         raise SystemExit(f"only {int(executed)} of {opt.steps} iterations took effect (loss gate tripped): "
                          "the timed region would contain skipped work")
+    if float(step.state[3]) != 0.0:
+        raise SystemExit("a patch window overflowed inside the timed region")
 
     if rank == 0:
         ms = elapsed * 1e3 / opt.steps
         value = world * B_PER_GPU * opt.steps / elapsed
-        tf = GFLOP_PER_PAIR_STEP * B_PER_GPU / ms          # per-GPU TFLOP/s (GFLOP/ms)
+        gflop = gflop_per_pair_step(step.win_hw if step.cone is not None else None, mc)
+        tf = gflop * B_PER_GPU / ms                        # per-GPU TFLOP/s (GFLOP/ms), executed work only
         line = {
             "metric": "attack-iters/s", "value": round(value, 3), "unit": "frame-pairs*steps/s",
             "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(ms, 3),
@@ -217,13 +256,17 @@ def main():
             "data": "synthetic",
             "config": {"workload": "FlowNetC 384x1280 I-FGSM patch attack (configs[1])", "pairs_per_gpu": B_PER_GPU,
                        "global_pairs": world * B_PER_GPU, "patch": "51x51 circular, shared, canvas-sized update",
+                       "calls": f"attack() calls of max_count={mc} iterations, new frames + placement per call",
+                       "prefix": (f"conv1-3 on a {step.win_hw[0]}x{step.win_hw[1]} window per pair"
+                                  if step.cone is not None else "full frame"),
                        "loss": "cosine", "lr": 1000.0, "weights": "synthetic seeded (no checkpoints offline)",
                        "graph": not opt.no_graph,
                        "parallelism": f"dp{world}: batch sharded, all-reduce of pre-clamp patch gradient"},
             "roofline": {"bound": "mfma", "kernel": "attack step = 1 hipGraph launch (MIOpen fp32 convs + ufr_* kernels)",
                          "achieved": round(tf, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tf / PEAK_FP32_TFLOPS, 4), "traffic": None,
-                         "algorithmic_gflop_per_launch": round(GFLOP_PER_PAIR_STEP * B_PER_GPU, 1)},
+                         "algorithmic_gflop_per_launch": round(gflop * B_PER_GPU, 1),
+                         "full_frame_gflop_per_launch": round(GFLOP_PER_PAIR_STEP * B_PER_GPU, 1)},
         }
         if world == 1:
             line["roofline"]["kernels"] = kernel_rooflines(device)

@@ -135,7 +135,11 @@ int ufr_patch_paste(const float* tgt, const float* ref, const float* patch, cons
  *   With patch_bstride == 0 the gradients of the B samples are summed (batch extension);
  *   `grad_sum` (canvas-sized, may be NULL) receives / supplies the pre-clamp gradient sum:
  *   mode 0: compute sum from g_tgt/g_ref and use it;  mode 1: only write grad_sum (for an
- *   all-reduce across ranks);  mode 2: use grad_sum as given (after the all-reduce). */
+ *   all-reduce across ranks);  mode 2: use grad_sum as given (after the all-reduce).
+ *   mode | UFR_UPDATE_MASKED_SUM: sample b enters the sum only where mask_b != 0 -- the gradient of
+ *   the batch loss with respect to the shared patch.  Without it the sum is the reference's unmasked
+ *   g_tgt + g_ref (main.py:575-583; identical wherever the mask shows the patch when B = 1). */
+#define UFR_UPDATE_MASKED_SUM 4
 int ufr_patch_update(const float* tgt, const float* ref, const float* g_tgt, const float* g_ref,
                      float* grad_sum, float* patch, const float* mask, float* adv_tgt,
                      float* adv_ref, int B, int CHW, long patch_bstride, long mask_bstride,
@@ -197,6 +201,37 @@ int ufr_universal_update(const float* img0, const float* img1, const float* g0, 
                          float* grad_sum, float* adv0, float* adv1, float* delta, int B, int CHW,
                          float lr, float eps, float lo, float hi, int use_sign, int frames, int ascent,
                          int shared, int mode, ufr_stream_t stream);
+
+/* ---- patch cone-of-influence windows --------------------------------------------------------------
+ * No counterpart in the reference: patch_attacks/main.py:537-600 keeps only mask*gradient and changes
+ * only masked pixels between iterations, so a convolutional encoder prefix (models/FlowNetC.py:96-104,
+ * conv1-3) needs its adjoint -- and from the second iteration of an attack() call its forward -- only
+ * inside the patch's cone.  The host runs that prefix on a window; these entry points move data
+ * between full tensors and the window at an origin held in DEVICE memory (graph-capturable).
+ *
+ * ufr_cone_chain: the prefix, input to output (kernel/stride/pad per layer), and the layers whose
+ *   outputs leave the prefix ("taps", sorted), each with the width of its inexact rim: the number of
+ *   cells next to an interior window edge where zero padding of the window differs from the image.
+ * win: int[N][8] = {y0, x0, need_h, need_w, ymin, ymax, xmin, xmax} in input pixels. */
+#define UFR_MAX_CONE_LAYERS 8
+typedef struct ufr_cone_chain {
+  int n_layers;
+  int kernel[UFR_MAX_CONE_LAYERS], stride[UFR_MAX_CONE_LAYERS], pad[UFR_MAX_CONE_LAYERS];
+  int n_taps;
+  int tap_layer[UFR_MAX_CONE_LAYERS], tap_margin[UFR_MAX_CONE_LAYERS];
+} ufr_cone_chain;
+/* Bounding box of mask != 0 per sample (mask [N,C,H,W], mask_bstride elements between samples), its
+ * cone at every tap widened by the rim, and a window origin (multiple of the chain's total stride,
+ * window inside the image).  *overflow += 1 when the needed extent exceeds win_h x win_w. */
+int ufr_cone_window(const float* mask, int N, long mask_bstride, int C, int H, int W,
+                    const ufr_cone_chain* chain, int win_h, int win_w, int* win, float* overflow,
+                    ufr_stream_t stream);
+/* dst[N,C,wh,ww] = src[N,C,Hs,Ws] at win[n % n_win] / level_stride; rim cells (margin, interior
+ * edges only) are written as 0.  scatter is the inverse and skips the rim. */
+int ufr_window_gather(const float* src, float* dst, const int* win, int n_win, int N, int C, int Hs, int Ws,
+                      int wh, int ww, int level_stride, int margin, ufr_stream_t stream);
+int ufr_window_scatter(const float* src, float* dst, const int* win, int n_win, int N, int C, int Hd, int Wd,
+                       int wh, int ww, int level_stride, int margin, ufr_stream_t stream);
 
 #ifdef __cplusplus
 }

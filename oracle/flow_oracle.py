@@ -328,8 +328,10 @@ def patch_attack(predict, tgt, ref, patch, mask, patch_init, target, lr=1e3, alp
 
     `patch` is updated in place like the reference's patch_var; returns
     (adv_tgt, adv_ref, patch, executed_iterations, last_loss).  With a batch of B > 1 the patch is
-    shared ([1,3,H,W]) and the per-sample gradients are summed before the clamp (the build's batch
-    extension); B = 1 is the reference's arithmetic exactly.
+    shared ([1,3,H,W]) and the per-sample gradients are summed before the clamp, each sample
+    contributing only where ITS mask shows the patch -- the gradient of the batch loss with respect to
+    the shared patch (the build's batch extension); B = 1 is the reference's arithmetic
+    exactly (it adds the image gradient outside the mask too, where nothing ever reads the patch).
     """
     adv_tgt = (1 - mask) * tgt + mask * patch                   # :537-542
     adv_ref = (1 - mask) * ref + mask * patch
@@ -345,7 +347,7 @@ def patch_attack(predict, tgt, ref, patch, mask, patch_init, target, lr=1e3, alp
         g_tgt, g_ref = torch.autograd.grad(loss, (adv_tgt, adv_ref))
         g = g_tgt + g_ref
         if patch.shape[0] == 1 and g.shape[0] > 1:
-            g = g.sum(0, keepdim=True)
+            g = (g * (mask != 0).float()).sum(0, keepdim=True)
         patch -= torch.clamp(0.5 * lr * g, -2, 2)               # :581-583
         adv_tgt = torch.clamp((1 - mask) * tgt + mask * patch, *clamp)   # :585-600
         adv_ref = torch.clamp((1 - mask) * ref + mask * patch, *clamp)

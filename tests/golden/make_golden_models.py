@@ -303,3 +303,34 @@ def gen_perturb_model():
 
 
 GENERATORS["perturb_model"] = gen_perturb_model
+
+
+def gen_attack_cone():
+    """patch_attacks/main.py:523-613 at a frame size where the product runs FlowNetC's conv1-3 on a
+    window around the patch (cone.py): a patch touching the top edge near the right edge, and one in the
+    interior; two iterations, unclamped and clamped step."""
+    main = rh.ref_module("patch_attacks.main")
+    net, sd = _ref_flownetc(seed=0)
+    for p in net.parameters():
+        p.requires_grad_(True)
+    H, W, S = 192, 320, 25
+    g = torch.Generator().manual_seed(47)
+    tgt = torch.rand(1, 3, H, W, generator=g)
+    ref = torch.rand(1, 3, H, W, generator=g)
+    with torch.no_grad():
+        target = -net(tgt, ref)
+    out = dict(tgt=tgt, ref=ref, target=target, weight_digest=state_dict_digest(sd), weight_seed=0)
+    for place, (cy, cx) in (("edge", (0, 290)), ("mid", (77, 131))):
+        patch0, mask = _circle_canvas(H, W, S, cy, cx, g)
+        out[f"{place}_patch0"], out[f"{place}_mask"], out[f"{place}_yx"] = patch0, mask, torch.tensor([cy, cx])
+        for name, lr in (("lr5", 5.0), ("lr1e6", 1.0e6)):
+            main.args = Namespace(flownet="FlowNetC", l2=False, alpha=0.0, lr=lr, max_count=2, log_terminal=False)
+            a_t, _, a_r, p = main.attack(net, tgt.clone(), None, ref.clone(), patch0.clone(), mask.clone(),
+                                         patch0.clone(), target.clone(), None)
+            out[f"{place}_{name}_adv_tgt"] = a_t[:, :, cy:cy + S, cx:cx + S]
+            out[f"{place}_{name}_adv_ref"] = a_r[:, :, cy:cy + S, cx:cx + S]
+            out[f"{place}_{name}_patch"] = p[:, :, cy:cy + S, cx:cx + S]
+    save("attack_flownetc_cone_192x320", **out)
+
+
+GENERATORS["attack_cone"] = gen_attack_cone

@@ -50,7 +50,8 @@ def _rank_main(rank, world, port, out_dir):
         flow = fo.flownetc_forward(sd, adv_t, adv_r)
         loss = fo.flow_loss(flow, target) / world     # PatchAttackStep: weight (1-alpha)/world
         g_t, g_r = torch.autograd.grad(loss, (adv_t, adv_r))
-        packed = torch.cat(((g_t + g_r).sum(0).reshape(-1), loss.detach().reshape(1)))   # mode 1
+        gsum = ((g_t + g_r) * (mask != 0).float()).sum(0)                                 # mode 1 | MASKED_SUM
+        packed = torch.cat((gsum.reshape(-1), loss.detach().reshape(1)))
         exchange(packed)                              # all-reduce(sum) over gloo
         patch = patch - torch.clamp(0.5 * lr * packed[:CHW].view_as(patch), -CLAMP_BOUND, CLAMP_BOUND)  # mode 2
     torch.save(dict(patch=patch, loss=packed[CHW:].clone()), os.path.join(out_dir, f"rank{rank}.pt"))

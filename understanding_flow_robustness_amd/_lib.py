@@ -36,6 +36,18 @@ class Pyramid(C.Structure):
                 ("Wl", C.c_int * UFR_MAX_LEVELS)]
 
 
+UFR_MAX_CONE_LAYERS = 8
+
+
+class ConeChain(C.Structure):
+    """ufr_cone_chain (include/ufr_hip.h)."""
+    _fields_ = [("n_layers", C.c_int),
+                ("kernel", C.c_int * UFR_MAX_CONE_LAYERS), ("stride", C.c_int * UFR_MAX_CONE_LAYERS),
+                ("pad", C.c_int * UFR_MAX_CONE_LAYERS),
+                ("n_taps", C.c_int),
+                ("tap_layer", C.c_int * UFR_MAX_CONE_LAYERS), ("tap_margin", C.c_int * UFR_MAX_CONE_LAYERS)]
+
+
 _vp, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
 # name -> argtypes; every function returns int.  Kept in one table so tests can check that each
 # symbol declared in include/ufr_hip.h is exported by the built library.
@@ -63,6 +75,9 @@ SIGNATURES = {
     "ufr_universal_update": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _i, _i, _i, _i,
                              _i, _vp],
     "ufr_flow_loss": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
+    "ufr_cone_window": [_vp, _i, _l, _i, _i, _i, C.POINTER(ConeChain), _i, _i, _vp, _vp, _vp],
+    "ufr_window_gather": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ufr_window_scatter": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
 }
 PLAIN = {"ufr_abi_version": (C.c_int, []), "ufr_last_error": (C.c_char_p, []),
          "ufr_device_count": (C.c_int, [])}

@@ -37,7 +37,7 @@ __global__ void update_shared_kernel(const float* __restrict__ tgt, const float*
                                      float* __restrict__ grad_sum, float* __restrict__ patch,
                                      const float* __restrict__ mask, float* __restrict__ adv_tgt,
                                      float* __restrict__ adv_ref, int B, long CHW, long mstride,
-                                     float step, float bound, float lo, float hi, int mode,
+                                     float step, float bound, float lo, float hi, int mode, int masked,
                                      const float* __restrict__ gate) {
   // attack already converged: the iteration is void (mode 1 still refreshes the exchange buffer so
   // the collective that follows never re-sums stale data)
@@ -49,7 +49,9 @@ __global__ void update_shared_kernel(const float* __restrict__ tgt, const float*
       gs = grad_sum[e];
     } else {
       gs = 0.f;
-      for (int b = 0; b < B; ++b) gs += g_tgt[b * CHW + e] + g_ref[b * CHW + e];
+      // masked: a pair contributes only where ITS mask shows the patch (d batch-loss / d shared patch)
+      for (int b = 0; b < B; ++b)
+        if (!masked || mask[b * mstride + e] != 0.f) gs += g_tgt[b * CHW + e] + g_ref[b * CHW + e];
       if (grad_sum) grad_sum[e] = gs;
       if (mode == 1) continue;
     }
@@ -176,6 +178,8 @@ extern "C" int ufr_patch_update(const float* tgt, const float* ref, const float*
                                 float lo, float hi, int mode, const float* gate_state,
                                 ufr_stream_t stream) {
   UFR_REQUIRE(B > 0 && CHW > 0, "patch update: bad shape");
+  const int masked = (mode & UFR_UPDATE_MASKED_SUM) != 0;
+  mode &= ~UFR_UPDATE_MASKED_SUM;
   UFR_REQUIRE(mode >= 0 && mode <= 2, "patch update: bad mode %d", mode);
   hipStream_t st = ufr::as_stream(stream);
   if (patch_bstride != 0) {
@@ -192,9 +196,10 @@ extern "C" int ufr_patch_update(const float* tgt, const float* ref, const float*
   if (mode != 0) UFR_REQUIRE(grad_sum, "patch update: mode %d needs grad_sum", mode);
   if (mode != 1)
     UFR_REQUIRE(tgt && ref && patch && mask && adv_tgt && adv_ref, "patch update: null pointer argument");
+  if (masked && mode != 2) UFR_REQUIRE(mask, "patch update: masked sum needs the masks");
   hipLaunchKernelGGL(update_shared_kernel, dim3(ufr::stream_grid(CHW, 256)), dim3(256), 0, st, tgt,
                      ref, g_tgt, g_ref, grad_sum, patch, mask, adv_tgt, adv_ref, B, (long)CHW,
-                     mask_bstride, step, bound, lo, hi, mode, gate_state);
+                     mask_bstride, step, bound, lo, hi, mode, masked, gate_state);
   return ufr::launched("update_shared_kernel");
 }
 

@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..cone import ConeSpec
 from ..spatial_correlation_sampler import spatial_correlation_sample
 
 # models/FlowNetC.py:73-79 -- RGB mean, subtracted in float64 and cast back
@@ -71,6 +72,20 @@ class FlowNetC(nn.Module):
         """FlowNetC.py:73-79,93-94: float64 mean subtraction, then back to float32."""
         return (im.double() - self._mean64).float()
 
+    # conv1-3 are a purely convolutional prefix: the patch attack runs them on a window around the patch
+    # (cone.py, patch_attack.py); taps = conv2 (skip connection, first frame) and conv3 (both frames).
+    CONE = ConeSpec(layers=((7, 2, 3), (5, 2, 2), (5, 2, 2)), taps=(1, 2), frames=(1, 2))
+
+    def encode(self, x):
+        """Siamese prefix on a stack of raw frames [N,3,h,w] (h, w multiples of 8): (conv2, conv3)."""
+        c1 = self.conv1(self.normalize_correctly(x))
+        c2 = self.conv2(c1)
+        return c2, self.conv3(c2)
+
+    def head(self, c2a, c3a, c3b):
+        """Everything after the prefix: correlation, conv_redir, conv3_1..6_1, refinement -> flow."""
+        return self._rest(c2a, c3a, c3b, None)
+
     def forward(self, x1, x2, overwrite_feat_maps=None):
         if overwrite_feat_maps is not None:
             raise NotImplementedError("feature-map overwriting belongs to the analysis scripts (out of scope)")
@@ -81,7 +96,9 @@ class FlowNetC(nn.Module):
         c3 = self.conv3(c2)
         c2a, c3a, c3b = c2[:B], c3[:B], c3[B:]
         feats = [c1[:B], c2a, c3a, c1[B:], c2[B:], c3b] if self.return_feat_maps else None
+        return self._rest(c2a, c3a, c3b, feats)
 
+    def _rest(self, c2a, c3a, c3b, feats):
         out_corr = correlate(c3a.contiguous(), c3b.contiguous())
         if feats is not None:
             feats.append(out_corr.clone())

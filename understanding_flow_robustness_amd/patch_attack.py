@@ -11,14 +11,23 @@ captured once into a HIP graph and replayed; the host reads the 3-float gate sta
 attack() call instead of once per iteration.
 
 Batch semantics (an extension: the reference is batch-1): B frame pairs share ONE
-canvas-sized patch; the loss is the mean over all B*H*W pixels, so the update uses
-sum_b d(loss)/d(adv_b) -- for B = 1 exactly the reference.  With N ranks each holds B/N pairs; the
-pre-clamp gradient sum (+ the loss) is all-reduced over RCCL before the non-linear update, so every
-rank applies the identical update (`ShardedExchange`).
+canvas-sized patch; the loss is the mean over all B*H*W pixels and the update uses the gradient of that
+loss with respect to the patch, sum_b [mask_b != 0] * d(loss)/d(adv_b).  For B = 1 the reference's
+unmasked `g_tgt + g_ref` is used as is (same values wherever the mask shows the patch).  With N ranks
+each holds B/N pairs; the pre-clamp gradient sum (+ the loss) is all-reduced over RCCL before the
+non-linear update, so every rank applies the identical update (`ShardedExchange`).
+
+Cone of influence (cone.py, csrc/window.hip): only `mask * gradient` is ever used and only masked pixels
+change between the iterations of one attack() call, so for networks that expose a convolutional prefix
+(FlowNetC conv1-3 = 48% of its FLOPs) the prefix runs on a ~128x128 window around each pair's patch:
+its adjoint every iteration, its forward from the second iteration on (the first full-frame prefix of a
+call is computed once in load()).  Patch pixels outside the window -- never visible through the mask --
+are left as loaded, where the reference adds image gradient to them.
 """
 from __future__ import annotations
 
 import ctypes as C
+import os
 from argparse import Namespace
 
 import torch
@@ -28,6 +37,7 @@ from .flownets.utils_model import predict_flow
 
 LOSS_THRESHOLD = 0.1      # main.py:546
 CLAMP_BOUND = 2.0         # main.py:581-583
+UPDATE_MASKED_SUM = 4     # include/ufr_hip.h
 
 
 def _pixel_range(flownet: str):
@@ -54,7 +64,7 @@ class PatchAttackStep:
     """Static buffers + the captured iteration for one (network, batch, resolution)."""
 
     def __init__(self, flow_net, args, batch, height, width, device="cuda:0", shared_patch=True,
-                 exchange: ShardedExchange | None = None, use_graph=True, warmup=3):
+                 exchange: ShardedExchange | None = None, use_graph=True, warmup=3, use_cone=None):
         L.lib()   # fail loudly, now, if libufr_hip.so is missing
         self.net, self.args = flow_net, args
         self.B, self.H, self.W = batch, height, width
@@ -64,6 +74,8 @@ class PatchAttackStep:
         self.world = exchange.world if exchange is not None else 1
         if self.world > 1 and not shared_patch:
             raise ValueError("per-sample patches need no exchange; shard them as independent replicas")
+        # several pairs behind one patch: each pair's gradient counts only where its own mask shows the patch
+        self.masked_sum = shared_patch and batch * self.world > 1
         self.lo, self.hi = _pixel_range(args.flownet)
         self.kind = 1 if getattr(args, "l2", False) else 0
         self.alpha = float(getattr(args, "alpha", 0.0))
@@ -90,6 +102,15 @@ class PatchAttackStep:
         self.graph = self.graph_b = None
         self.use_graph = use_graph
         self._warmup = warmup
+        # windowed encoder (cone.py): networks that expose a convolutional prefix as CONE/encode/head
+        if use_cone is None:
+            use_cone = os.environ.get("UFR_CONE", "1") != "0"
+        spec = getattr(flow_net, "CONE", None)
+        self.cone = spec if (use_cone and spec is not None and height % spec.total_stride == 0
+                             and width % spec.total_stride == 0) else None
+        self.win_hw = None                     # static window size in pixels, fixed at the first load()
+        self.win = torch.zeros(batch, 8, dtype=torch.int32, device=self.dev)     # one window per pair
+        self.patch_loaded = torch.zeros_like(self.patch) if self.cone is not None else None
 
     # ------------------------------------------------------------------------------------ C ABI calls
     def _paste(self, do_clamp):
@@ -103,14 +124,101 @@ class PatchAttackStep:
                                          L.ptr(g_ref) if g_ref is not None else None, L.ptr(self.packed),
                                          L.ptr(self.patch), L.ptr(self.mask), L.ptr(self.adv_tgt),
                                          L.ptr(self.adv_ref), self.B, self.CHW, 0 if self.shared else self.CHW,
-                                         self.CHW, self.step, CLAMP_BOUND, self.lo, self.hi, mode,
+                                         self.CHW, self.step, CLAMP_BOUND, self.lo, self.hi,
+                                         mode | (UPDATE_MASKED_SUM if self.masked_sum else 0),
                                          L.ptr(self.state), L.stream()), "patch update")
+
+    # ------------------------------------------------------------------------------------ windowed encoder
+    def _mask_extent(self):
+        """Host read (once per window size): largest bounding-box extent of the loaded masks, over every
+        rank so that all ranks size (and later re-size) their windows alike."""
+        m = self.mask.amax(dim=1) != 0
+        rows, cols = m.any(dim=2).cpu(), m.any(dim=1).cpu()
+        ext = lambda v: max([int(r.nonzero().max() - r.nonzero().min()) + 1 if bool(r.any()) else 0 for r in v] + [1])
+        eh, ew = ext(rows), ext(cols)
+        if self.world > 1:
+            both = torch.tensor([eh, ew], dtype=torch.float32, device=self.dev)
+            self.exchange.dist.all_reduce(both, op=self.exchange.dist.ReduceOp.MAX, group=self.exchange.group)
+            eh, ew = (int(v) for v in both.tolist())
+        return eh, ew
+
+    def _setup_cone(self):
+        """Size the window for the loaded masks and allocate the window-sized / cached tensors; fall back
+        to the full-frame iteration when the window would not be much smaller than the frame."""
+        spec, B, H, W = self.cone, self.B, self.H, self.W
+        eh, ew = self._mask_extent()
+        wh, ww = spec.window_size(eh, H), spec.window_size(ew, W)
+        self.graph = self.graph_b = None
+        if self._warmup < 0:
+            self._warmup = 1                   # re-capture after the window grew
+        if wh * ww * 2 > H * W:
+            self.cone = None
+            return
+        self.win_hw = (wh, ww)
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.xw = torch.zeros(2 * B, 3, wh, ww, **f32).requires_grad_(True)
+        self.taps = []                         # (level stride, margin, frames, full leaf, window gradient)
+        with torch.no_grad():
+            feats = self.net.encode(torch.zeros(2, 3, spec.total_stride * 2, spec.total_stride * 2, **f32))
+        for t, m, fr, f in zip(spec.taps, spec.tap_margins(), spec.frames, feats):
+            ls = spec.level_stride(t)
+            n = B * fr                         # frames = 1: the head reads this tap for the first frame only
+            full = torch.zeros(n, f.shape[1], H // ls, W // ls, **f32).requires_grad_(True)
+            gwin = torch.zeros(n, f.shape[1], wh // ls, ww // ls, **f32)
+            self.taps.append((ls, m, n, full, gwin))
+        self.g_tgt_full = torch.zeros_like(self.tgt)
+        self.g_ref_full = torch.zeros_like(self.tgt)
+        self._chain = spec.to_c()
+
+    def _win_copy(self, fn, src, dst, n, c, hf, wf, ls, margin):
+        wh, ww = self.win_hw
+        L.check(fn(L.ptr(src), L.ptr(dst), L.ptr(self.win), self.B, n, c, hf, wf, wh // ls, ww // ls, ls, margin,
+                   L.stream()), "window copy")
+
+    def _cone_refresh(self):
+        """New frames / new placement: window origin on the device, full prefix once (no autograd)."""
+        lib = L.lib()
+        wh, ww = self.win_hw
+        L.check(lib.ufr_cone_window(L.ptr(self.mask), self.B, self.CHW, 3, self.H, self.W, C.byref(self._chain),
+                                    wh, ww, L.ptr(self.win), L.ptr(self.state[3:]), L.stream()), "cone window")
+        self.g_tgt_full.zero_(); self.g_ref_full.zero_()
+        feats = self.net.encode(torch.cat((self.adv_tgt.detach(), self.adv_ref.detach()), 0))
+        for (ls, m, n, full, _), f in zip(self.taps, feats):
+            full.detach().copy_(f[:n])
+
+    def _forward_cone(self):
+        """Prefix on the window, paste into the cached full features, head at full size."""
+        lib, B, H, W = L.lib(), self.B, self.H, self.W
+        self._win_copy(lib.ufr_window_gather, self.adv_tgt, self.xw, B, 3, H, W, 1, 0)
+        self._win_copy(lib.ufr_window_gather, self.adv_ref, self.xw[B:], B, 3, H, W, 1, 0)
+        self._feats_w = [f[:n] for f, (_, _, n, _, _) in zip(self.net.encode(self.xw), self.taps)]
+        for f, (ls, m, n, full, _) in zip(self._feats_w, self.taps):
+            self._win_copy(lib.ufr_window_scatter, f, full, n, f.shape[1], H // ls, W // ls, ls, m)
+        full = [t[3] for t in self.taps]
+        return self.net.head(*full[:-1], full[-1][:B], full[-1][B:])
+
+    def _backward_cone(self, flow):
+        """Adjoint of the head at full size, of the prefix on the window; canvas-sized gradients that are
+        zero outside the window (only mask * gradient is ever used, main.py:575-583)."""
+        lib, B, H, W = L.lib(), self.B, self.H, self.W
+        g_full = torch.autograd.grad(flow, [t[3] for t in self.taps], self.g_flow)
+        for g, (ls, m, n, _, gwin) in zip(g_full, self.taps):
+            self._win_copy(lib.ufr_window_gather, g.contiguous(), gwin, n, g.shape[1], H // ls, W // ls, ls, m)
+        gxw, = torch.autograd.grad(self._feats_w, (self.xw,), [t[4] for t in self.taps])
+        self._feats_w = None
+        gxw = gxw.contiguous()
+        self._win_copy(lib.ufr_window_scatter, gxw, self.g_tgt_full, B, 3, H, W, 1, 0)
+        self._win_copy(lib.ufr_window_scatter, gxw[B:], self.g_ref_full, B, 3, H, W, 1, 0)
+        return self.g_tgt_full, self.g_ref_full
 
     # ------------------------------------------------------------------------------------ one iteration
     def _part_a(self):
         """forward -> loss (+ d loss/d flow) -> data-gradient backward -> [N>1: local gradient sum]."""
         self.loss_cur.zero_()
-        flow = predict_flow(self.net, None, self.adv_tgt, self.adv_ref, self.args)
+        if self.cone is not None:
+            flow = self._forward_cone()
+        else:
+            flow = predict_flow(self.net, None, self.adv_tgt, self.adv_ref, self.args)
         if not flow.is_contiguous():
             flow = flow.contiguous()
         # shared patch: loss = mean over the GLOBAL batch; private: every sample its own mean
@@ -122,8 +230,11 @@ class PatchAttackStep:
         if self.alpha != 0.0:                       # main.py:568-571 (scalar only: no gradient path)
             reg = torch.nn.functional.l1_loss(self.mask * self.patch, self.mask * self.patch_init)
             self.loss_cur.add_(self.alpha * reg / self.world)
-        g_tgt, g_ref = torch.autograd.grad(flow, (self.adv_tgt, self.adv_ref), self.g_flow)
-        g_tgt, g_ref = g_tgt.contiguous(), g_ref.contiguous()
+        if self.cone is not None:
+            g_tgt, g_ref = self._backward_cone(flow)
+        else:
+            g_tgt, g_ref = torch.autograd.grad(flow, (self.adv_tgt, self.adv_ref), self.g_flow)
+            g_tgt, g_ref = g_tgt.contiguous(), g_ref.contiguous()
         if self.world > 1:
             self._update(g_tgt, g_ref, 1)            # local sum -> packed; the collective follows
         else:
@@ -182,6 +293,12 @@ class PatchAttackStep:
             self.patch.copy_(patch); self.patch_init.copy_(patch_init); self.target.copy_(target)
             self.state.zero_()
             self._paste(do_clamp=False)
+            if self.cone is not None:
+                self.patch_loaded.copy_(self.patch)
+                if self.win_hw is None:
+                    self._setup_cone()
+                if self.cone is not None:
+                    self._cone_refresh()
 
     def run(self, max_count):
         """Enqueue up to `max_count` iterations back to back; returns (executed, last_loss) after ONE
@@ -194,7 +311,20 @@ class PatchAttackStep:
                 self.load(*[saved[i] for i in (0, 1, 3, 2, 4, 5)])
             for _ in range(int(max_count)):
                 self._iteration()
+            if self.cone is not None and self.world > 1:      # a window overflow anywhere redoes the call everywhere
+                self.exchange.dist.all_reduce(self.state[3:], op=self.exchange.dist.ReduceOp.MAX,
+                                              group=self.exchange.group)
             st = self.state.tolist()
+            if self.cone is not None and st[3] != 0.0:
+                # a mask larger than the window this step was sized for: grow the window, re-capture, redo
+                with torch.no_grad():
+                    self.patch.copy_(self.patch_loaded)
+                    self.state.zero_()
+                    self._paste(do_clamp=False)
+                    self._setup_cone()
+                    if self.cone is not None:
+                        self._cone_refresh()
+                return self.run(max_count)
         return int(st[1]), float(st[2])
 
     def enqueue(self, iterations):
