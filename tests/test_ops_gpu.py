@@ -188,6 +188,36 @@ def test_altcorr_vs_oracle(ops, oracle, B, H, W, C, r):
     assert_close(g2, r2, rtol=1e-4, atol_scale=1e-5, what="alt_corr fmap2_grad (atomics)")
 
 
+@pytest.mark.parametrize("case", ["pyramid_level", "wild_flow", "two_lookups", "ragged_channels", "smooth"])
+def test_altcorr_backward_tiled_scatter_vs_oracle(ops, oracle, case):
+    """The fmap2 adjoint accumulates in an LDS copy of the region a pixel tile's windows land in and falls
+    back to global atomics outside it: pooled fmap2 (coords / 2), windows far outside the image, N = 2,
+    a channel count that is not a multiple of the 32-channel slab, and a smooth flow (all-LDS path)."""
+    g = torch.Generator().manual_seed(len(case))
+    B, H, W, C, r, N, spread, lvl = 1, 24, 40, 64, 4, 1, 3.0, 1
+    if case == "pyramid_level":
+        lvl = 2
+    elif case == "wild_flow":
+        spread = 60.0
+    elif case == "two_lookups":
+        B, N = 2, 2
+    elif case == "ragged_channels":
+        C, r = 40, 3
+    elif case == "smooth":
+        spread = 0.3
+    f1, _, coords = _alt_inputs(B, H, W, C, g, spread=spread, N=N)
+    f2 = torch.randn(B, H // lvl, W // lvl, C, generator=g)
+    coords = (coords / lvl).contiguous()
+    (o,) = ops["alt"].forward(f1.to(DEV), f2.to(DEV), coords.to(DEV), r)
+    (ref,) = oracle.altcorr_forward(f1, f2, coords, r)
+    assert_close(o, ref, rtol=1e-4, atol_scale=2e-6, what=f"{case}: forward")
+    go = torch.randn(o.shape, generator=g)
+    g1, g2, _ = ops["alt"].backward(f1.to(DEV), f2.to(DEV), coords.to(DEV), go.to(DEV), r)
+    r1, r2, _ = oracle.altcorr_backward(f1, f2, coords, go, r)
+    assert_close(g1, r1, rtol=1e-4, atol_scale=2e-6, what=f"{case}: fmap1_grad")
+    assert_close(g2, r2, rtol=1e-4, atol_scale=1e-5, what=f"{case}: fmap2_grad")
+
+
 def test_altcorr_autograd_function(ops):
     from understanding_flow_robustness_amd.alt_cuda_corr import AltCorrFunction
     g = torch.Generator().manual_seed(77)

@@ -8,6 +8,8 @@
 //   corr[oy + rd*ox] = (1-dy)(1-dx) s[oy][ox] + (1-dy)dx s[oy][ox+1] + dy(1-dx) s[oy+1][ox] + dy dx s[oy+1][ox+1]
 // The reference accumulates this per 32-channel slab; here one workgroup owns one pixel and the
 // whole channel axis, so the dot products are complete before the bilinear blend.
+#include <cstdlib>
+
 #include "ufr_common.h"
 
 namespace {
@@ -73,6 +75,7 @@ __global__ void altcorr_fwd(const float* __restrict__ fmap1, const float* __rest
 // (strided when C > blockDim): fmap1_grad is owned by the workgroup (plain store, summed over n
 // through `+=` in registers is impossible across n-blocks, so N>1 uses atomics too);
 // fmap2_grad is scattered with float atomics, 256 contiguous bytes per wave instruction.
+template <bool SCATTER>
 __global__ void altcorr_bwd(const float* __restrict__ fmap1, const float* __restrict__ fmap2,
                             const float* __restrict__ coords, const float* __restrict__ corr_grad,
                             float* __restrict__ fmap1_grad, float* __restrict__ fmap2_grad, int N,
@@ -116,10 +119,159 @@ __global__ void altcorr_bwd(const float* __restrict__ fmap1, const float* __rest
         const float g = gs[iy * gd + ix];
         const size_t o = (((size_t)b * H2 + h2) * W2 + w2) * C + c;
         acc = fmaf(g, fmap2[o], acc);
-        atomicAdd(&fmap2_grad[o], g * f1);
+        if (SCATTER) atomicAdd(&fmap2_grad[o], g * f1);
       }
     }
     if (N == 1) g1g[c] = acc; else atomicAdd(&g1g[c], acc);
+  }
+}
+
+// fmap2 adjoint without one global atomic per (pixel, window point, channel), owner-computes form.
+// A workgroup takes a tile of 8x8 pixels and a slab of 64 channels.  Flow fields are smooth, so the 64
+// windows of a tile land in a small region of fmap2; a 24x24 region anchored at the tile's smallest
+// window corner is OWNED by the workgroup, one thread per cell (576 threads), 64 channel accumulators in
+// registers.  For every pixel p of the tile a thread looks up its coefficient
+//     A = gs[p][cell - corner_p]   (0 when the cell is outside p's window; gs = adjoint of the bilinear blend)
+// and adds A * fmap1[p][0..63], the fmap1 row coming from LDS as broadcast 16-byte reads; a wave whose 64
+// cells all miss p's window skips the row.  It is a 576x64x64 product per tile with a 17%-dense A, done
+// on the VALU with no atomics and a fixed summation order.  Accumulators are transposed through LDS and
+// flushed with one global atomic per touched (cell, channel), 64 contiguous bytes per cell (tiles
+// overlap by the window halo).  Window points outside the owned region (discontinuous flow) are added
+// directly with global atomics afterwards: always correct, fast when the flow is smooth.
+constexpr int AT_TH = 8, AT_TW = 8, AT_PIX = AT_TH * AT_TW;   // pixels per tile
+constexpr int AT_CS = 64;                                     // channels per slab
+constexpr int AT_RH = 24, AT_RW = 24;                         // region owned by the workgroup
+constexpr int AT_NT = AT_RH * AT_RW;                          // 576 threads = 9 waves
+constexpr int AT_WAVES = AT_NT / 64;
+constexpr int AT_CHUNK = 16;                                  // channels per transpose pass
+
+template <int RADIUS>
+__global__ __launch_bounds__(AT_NT) void altcorr_bwd2_tiled(
+    const float* __restrict__ fmap1, const float* __restrict__ coords, const float* __restrict__ corr_grad,
+    float* __restrict__ fmap2_grad, int N, int H1, int W1, int H2, int W2, int C, int tiles_x) {
+  constexpr int r = RADIUS, rd = 2 * r + 1, gd = rd + 1, npt = gd * gd;
+  constexpr int kCg = rd * rd * AT_PIX, kGs = AT_PIX * npt, kTr = AT_WAVES * 64 * (AT_CHUNK + 1);
+  constexpr int kScratch = (kCg + kGs) > kTr ? (kCg + kGs) : kTr;
+  __shared__ __attribute__((aligned(16))) float scratch[kScratch];   // cg | gs, later the transpose buffer
+  __shared__ __attribute__((aligned(16))) float f1s[AT_PIX * AT_CS];
+  __shared__ int cxs[AT_PIX], cys[AT_PIX];
+  __shared__ float dxs[AT_PIX], dys[AT_PIX];
+  __shared__ int org[2];
+  float* cg = scratch;                                         // corr_grad of the tile, [channel][pixel]
+  float* gs = scratch + kCg;                                   // [pixel][iy*gd+ix]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = blockIdx.x, c0 = blockIdx.y * AT_CS, bn = blockIdx.z;   // bn = b*N + n
+  const int b = bn / N;
+  const int ty0 = (tile / tiles_x) * AT_TH, tx0 = (tile % tiles_x) * AT_TW;
+  const size_t plane = (size_t)H1 * W1;
+
+  if (tid == 0) { org[0] = 0x7fffffff; org[1] = 0x7fffffff; }
+  __syncthreads();
+  if (tid < AT_PIX) {
+    const int h1 = ty0 + tid / AT_TW, w1 = tx0 + tid % AT_TW;
+    int cx = 0x3fffffff, cy = 0x3fffffff;                      // invalid pixel: never inside the image
+    float dx = 0.f, dy = 0.f;
+    if (h1 < H1 && w1 < W1) {
+      const size_t pix = (size_t)bn * plane + (size_t)h1 * W1 + w1;
+      const float x = coords[pix * 2 + 0], y = coords[pix * 2 + 1];
+      const float fx = floorf(x), fy = floorf(y);
+      dx = x - fx; dy = y - fy;
+      // clamp far-away windows so the integer arithmetic below cannot overflow; they stay outside
+      cx = (int)fminf(fmaxf(fx, -1.0e6f), 1.0e6f) - r;
+      cy = (int)fminf(fmaxf(fy, -1.0e6f), 1.0e6f) - r;
+      if (cx + gd > 0 && cx < W2 && cy + gd > 0 && cy < H2) {   // window meets the image
+        atomicMin(&org[0], max(cy, 0));
+        atomicMin(&org[1], max(cx, 0));
+      }
+    }
+    cxs[tid] = cx; cys[tid] = cy; dxs[tid] = dx; dys[tid] = dy;
+  }
+  for (int i = tid; i < kCg; i += AT_NT) {                     // 8 consecutive pixels = 32 contiguous bytes
+    const int p = i % AT_PIX, ch = i / AT_PIX;
+    const int h1 = ty0 + p / AT_TW, w1 = tx0 + p % AT_TW;
+    cg[i] = (h1 < H1 && w1 < W1) ? corr_grad[((size_t)bn * rd * rd + ch) * plane + (size_t)h1 * W1 + w1] : 0.f;
+  }
+  for (int i = tid; i < AT_PIX * AT_CS; i += AT_NT) {
+    const int p = i / AT_CS, c = i % AT_CS;
+    const int h1 = ty0 + p / AT_TW, w1 = tx0 + p % AT_TW;
+    f1s[i] = (h1 < H1 && w1 < W1 && c0 + c < C) ? fmap1[(((size_t)b * H1 + h1) * W1 + w1) * C + c0 + c] : 0.f;
+  }
+  __syncthreads();
+  // gs[p][iy*gd+ix] (correlation_kernel.cu:196-214): channel of corr_grad = oy + rd*ox
+  for (int i = tid; i < kGs; i += AT_NT) {
+    const int p = i % AT_PIX, t = i / AT_PIX;
+    const int iy = t / gd, ix = t - iy * gd;
+    const float dx = dxs[p], dy = dys[p];
+    float g = 0.f;
+    if (iy > 0 && ix > 0)   g += cg[((iy - 1) + rd * (ix - 1)) * AT_PIX + p] * dy * dx;
+    if (iy > 0 && ix < rd)  g += cg[((iy - 1) + rd * ix) * AT_PIX + p] * dy * (1 - dx);
+    if (iy < rd && ix > 0)  g += cg[(iy + rd * (ix - 1)) * AT_PIX + p] * (1 - dy) * dx;
+    if (iy < rd && ix < rd) g += cg[(iy + rd * ix) * AT_PIX + p] * (1 - dy) * (1 - dx);
+    gs[p * npt + t] = g;
+  }
+  __syncthreads();
+  const int oy = org[0], ox = org[1];
+  if (oy == 0x7fffffff) return;                                // no window of this tile meets the image
+
+  const int h2 = oy + tid / AT_RW, w2 = ox + tid % AT_RW;      // this thread's cell
+  float acc[AT_CS];
+#pragma unroll
+  for (int c = 0; c < AT_CS; ++c) acc[c] = 0.f;
+  for (int p = 0; p < AT_PIX; ++p) {
+    const int iy = h2 - cys[p], ix = w2 - cxs[p];
+    const bool hit = (unsigned)iy < (unsigned)gd && (unsigned)ix < (unsigned)gd;
+    if (__ballot(hit) == 0) continue;                          // none of the wave's 64 cells is in p's window
+    const float A = hit ? gs[p * npt + iy * gd + ix] : 0.f;
+    const float4* f1v = reinterpret_cast<const float4*>(f1s + p * AT_CS);
+#pragma unroll
+    for (int c4 = 0; c4 < AT_CS / 4; ++c4) {
+      const float4 f = f1v[c4];                                // same address in every lane: LDS broadcast
+      acc[4 * c4 + 0] = fmaf(A, f.x, acc[4 * c4 + 0]);
+      acc[4 * c4 + 1] = fmaf(A, f.y, acc[4 * c4 + 1]);
+      acc[4 * c4 + 2] = fmaf(A, f.z, acc[4 * c4 + 2]);
+      acc[4 * c4 + 3] = fmaf(A, f.w, acc[4 * c4 + 3]);
+    }
+  }
+
+  // window points outside the owned region: lane = channel, one pixel per wave at a time
+  if (c0 + lane < C) {
+    for (int p = wave; p < AT_PIX; p += AT_WAVES) {
+      const int cy = cys[p], cx = cxs[p];
+      if (cy >= oy && cy + gd <= oy + AT_RH && cx >= ox && cx + gd <= ox + AT_RW) continue;   // fully owned
+      if (cy + gd <= 0 || cy >= H2 || cx + gd <= 0 || cx >= W2) continue;                     // off the image
+      const float f1 = f1s[p * AT_CS + lane];
+      for (int iy = 0; iy < gd; ++iy) {
+        const int hh = cy + iy;
+        if (hh < 0 || hh >= H2) continue;
+        for (int ix = 0; ix < gd; ++ix) {
+          const int ww = cx + ix;
+          if (ww < 0 || ww >= W2) continue;
+          if (hh >= oy && hh < oy + AT_RH && ww >= ox && ww < ox + AT_RW) continue;           // owned: in acc
+          atomicAdd(&fmap2_grad[(((size_t)b * H2 + hh) * W2 + ww) * C + c0 + lane], gs[p * npt + iy * gd + ix] * f1);
+        }
+      }
+    }
+  }
+  __syncthreads();                                             // gs / cg are dead: reuse as transpose buffer
+
+  // flush: 16 channels at a time through LDS so that one atomic instruction covers 4 cells x 64 bytes
+  float* tr = scratch + wave * 64 * (AT_CHUNK + 1);
+#pragma unroll
+  for (int ch0 = 0; ch0 < AT_CS; ch0 += AT_CHUNK) {
+#pragma unroll
+    for (int i = 0; i < AT_CHUNK; ++i) tr[lane * (AT_CHUNK + 1) + i] = acc[ch0 + i];
+    __builtin_amdgcn_wave_barrier();
+    const int cc = lane % AT_CHUNK;
+#pragma unroll
+    for (int i = 0; i < 64 / (64 / AT_CHUNK); ++i) {           // 16 passes of 4 cells
+      const int cell_l = i * (64 / AT_CHUNK) + lane / AT_CHUNK;
+      const float v = tr[cell_l * (AT_CHUNK + 1) + cc];
+      const int cell = wave * 64 + cell_l;
+      const int hh = oy + cell / AT_RW, ww = ox + cell % AT_RW;
+      if (v != 0.f && hh < H2 && ww < W2 && c0 + ch0 + cc < C)
+        atomicAdd(&fmap2_grad[(((size_t)b * H2 + hh) * W2 + ww) * C + c0 + ch0 + cc], v);
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -263,10 +415,26 @@ extern "C" int ufr_altcorr_backward(const float* fmap1, const float* fmap2, cons
   if (e == hipSuccess && N > 1) e = hipMemsetAsync(fmap1_grad, 0, sizeof(float) * (size_t)B * H1 * W1 * C, st);
   if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "alt_corr backward: memset: %s", hipGetErrorString(e));
   const long blocks = (long)B * N * H1 * W1;
+  UFR_REQUIRE(blocks < 2147483647L, "alt_corr backward: too many pixels");
   const int nt = C >= 256 ? 256 : ufr::round_up(C, 64);
-  hipLaunchKernelGGL(altcorr_bwd, dim3((unsigned)blocks), dim3(nt), 0, st, fmap1, fmap2, coords,
+  static const int variant = [] { const char* e = getenv("UFR_ALTCORR_BWD_VARIANT"); return e ? atoi(e) : 1; }();
+  if (variant == 0 || (long)B * N > 65535 || (radius != 4 && radius != 3)) {
+    // v1: one workgroup per pixel does both adjoints, global atomics
+    hipLaunchKernelGGL(altcorr_bwd<true>, dim3((unsigned)blocks), dim3(nt), 0, st, fmap1, fmap2, coords,
+                       corr_grad, fmap1_grad, fmap2_grad, N, H1, W1, H2, W2, C, radius);
+    return ufr::launched("altcorr_bwd");
+  }
+  hipLaunchKernelGGL(altcorr_bwd<false>, dim3((unsigned)blocks), dim3(nt), 0, st, fmap1, fmap2, coords,
                      corr_grad, fmap1_grad, fmap2_grad, N, H1, W1, H2, W2, C, radius);
-  return ufr::launched("altcorr_bwd");
+  const int tiles_x = ufr::ceil_div(W1, AT_TW), tiles_y = ufr::ceil_div(H1, AT_TH);
+  const dim3 grid(tiles_x * tiles_y, ufr::ceil_div(C, AT_CS), B * N);
+  if (radius == 4)
+    hipLaunchKernelGGL(altcorr_bwd2_tiled<4>, grid, dim3(AT_NT), 0, st, fmap1, coords, corr_grad, fmap2_grad,
+                       N, H1, W1, H2, W2, C, tiles_x);
+  else
+    hipLaunchKernelGGL(altcorr_bwd2_tiled<3>, grid, dim3(AT_NT), 0, st, fmap1, coords, corr_grad, fmap2_grad,
+                       N, H1, W1, H2, W2, C, tiles_x);
+  return ufr::launched("altcorr_bwd2_tiled");
 }
 
 static int check_pyr(const ufr_pyramid* pyr, bool need_grad) {
