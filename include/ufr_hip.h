@@ -233,6 +233,27 @@ int ufr_window_gather(const float* src, float* dst, const int* win, int n_win, i
 int ufr_window_scatter(const float* src, float* dst, const int* win, int n_win, int N, int C, int Hd, int Wd,
                        int wh, int ww, int level_stride, int margin, ufr_stream_t stream);
 
+/* ---- patch placement on the device ------------------------------------------------------------------
+ * replaces the host round trip of patch_attacks/utils_patch.py:257-358 (circle_transform: scipy zoom /
+ * rotate, three canvas-sized np.zeros + H2D per sample) and patch_attacks/main.py:408-461 (D2H, crop,
+ * scipy zoom back).  The patch state is float64 [C,h,w] like the reference's numpy arrays; the host keeps
+ * drawing np.random in the reference's order and passes the numbers in.
+ *
+ * ufr_affine_resample_f64: dst[c,y,x] = src[c] sampled at (m00*y + m01*x + off0, m10*y + m11*x + off1)
+ *   with scipy.ndimage semantics for mode='constant', cval=0: order 1 (linear) or 0 (floor(cc+0.5));
+ *   a coordinate below 0 or above n-1 gives 0.  zoom: m00 = (Hs-1)/(Hd-1), m11 = (Ws-1)/(Wd-1);
+ *   rotate(reshape=False): the 2x2 matrix and offset of scipy.ndimage.rotate.
+ * ufr_patch_place: zero the three float32 canvases [C,H,W] and paste patch / mask / patch_init at (y, x).
+ * ufr_patch_crop_f64: dst = float64(canvas[crop] * factor[crop]) (float32 product; factor may be NULL). */
+int ufr_affine_resample_f64(const double* src, double* dst, int C, int Hs, int Ws, int Hd, int Wd,
+                            double m00, double m01, double m10, double m11, double off0, double off1,
+                            int order, ufr_stream_t stream);
+int ufr_patch_place(const double* patch, const double* mask, const double* init, int C, int h, int w,
+                    float* canvas_patch, float* canvas_mask, float* canvas_init, int H, int W, int y, int x,
+                    ufr_stream_t stream);
+int ufr_patch_crop_f64(const float* canvas, const float* factor, double* dst, int C, int H, int W, int y,
+                       int x, int h, int w, ufr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,7 +48,7 @@ class ConeChain(C.Structure):
                 ("tap_layer", C.c_int * UFR_MAX_CONE_LAYERS), ("tap_margin", C.c_int * UFR_MAX_CONE_LAYERS)]
 
 
-_vp, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
+_vp, _i, _f, _l, _d = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_double
 # name -> argtypes; every function returns int.  Kept in one table so tests can check that each
 # symbol declared in include/ufr_hip.h is exported by the built library.
 SIGNATURES = {
@@ -78,6 +78,9 @@ SIGNATURES = {
     "ufr_cone_window": [_vp, _i, _l, _i, _i, _i, C.POINTER(ConeChain), _i, _i, _vp, _vp, _vp],
     "ufr_window_gather": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ufr_window_scatter": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ufr_affine_resample_f64": [_vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _d, _d, _d, _i, _vp],
+    "ufr_patch_place": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ufr_patch_crop_f64": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
 }
 PLAIN = {"ufr_abi_version": (C.c_int, []), "ufr_last_error": (C.c_char_p, []),
          "ufr_device_count": (C.c_int, [])}

@@ -387,6 +387,25 @@ def train_sample(flow_net, tgt_img, ref_past_img, ref_future_img, patch, mask, p
                             patch_shape_orig)
 
 
+def train_sample_device(flow_net, tgt_img, ref_past_img, ref_future_img, patch, mask, patch_init, patch_shape,
+                        patch_shape_orig, args: Namespace, use_graph=True):
+    """`train_sample` with the patch state resident on the device (float64 HIP tensors [1,3,S,S], SURVEY.md 8
+    f2): placement, attack, crop and resampling all run on the GPU (patch_transform.py); the only host work is
+    drawing the reference's `np.random` numbers.  Returns (patch, mask, patch_init, patch_shape) as HIP tensors."""
+    from .patch_transform import circle_transform_device, crop_and_restore_device
+    with torch.no_grad():
+        flow_pred = predict_flow(flow_net, ref_past_img, tgt_img, ref_future_img, args)
+        if getattr(args, "patch_type", "circle") != "circle":
+            raise NotImplementedError("only --patch_type circle (the README's configuration) is mirrored")
+        patch_t, mask_t, init_t, rx, ry, patch_shape = circle_transform_device(
+            patch, mask, patch_init, tuple(tgt_img.shape), patch_shape, True)     # margin=1, main.py:377
+    target = -flow_pred.detach()
+    _, _, _, patch_t = attack(flow_net, tgt_img, ref_past_img, ref_future_img, patch_t, mask_t, init_t, target,
+                              None, args=args, use_graph=use_graph)
+    with torch.no_grad():
+        return crop_and_restore_device(patch_t, mask_t, init_t, rx, ry, patch_shape, patch_shape_orig)
+
+
 ERROR_NAMES = ["epe", "adv_epe", "cos_sim", "adv_cos_sim"]
 
 
