@@ -254,6 +254,29 @@ int ufr_patch_place(const double* patch, const double* mask, const double* init,
 int ufr_patch_crop_f64(const float* canvas, const float* factor, double* dst, int C, int H, int W, int y,
                        int x, int h, int w, ufr_stream_t stream);
 
+/* ---- loaders: image resize and tensor conversion on the device ----------------------------------------
+ * replaces dataset_utils/data_utils.py:26-32 (imresize = PIL.Image.resize(BILINEAR) on uint8),
+ * dataset_utils/custom_transforms.py:47-57 (ArrayToTensor), :60-122 (flip / crop / Scale) and the
+ * arithmetic of flowutils/flow_io.py:104-127 (flow_read_png).  Images are uint8 [H,W,C] (C = 1, 3, 4).
+ * bounds[2*i] = first source index, bounds[2*i+1] = tap count, kk[i*ksize + t] = 22-bit fixed-point
+ * coefficient of output index i -- Pillow's precompute_coeffs / normalize_coeffs_8bpc tables, computed by
+ * the host (input_pipeline.resize_tables).  Each pass rounds to uint8 like Pillow's two-pass resampler;
+ * `flip` reads the source row mirrored (RandomHorizontalFlip happens before the resize). */
+int ufr_resample_u8_horizontal(const unsigned char* src, unsigned char* dst, int H, int Ws, int Wd, int C, int flip,
+                               const int* bounds, const int* kk, int ksize, ufr_stream_t stream);
+int ufr_resample_u8_vertical(const unsigned char* src, unsigned char* dst, int Hs, int Hd, int W, int C,
+                             const int* bounds, const int* kk, int ksize, ufr_stream_t stream);
+/* dst[c,y,x] (float32, [C,crop_h,crop_w]) = float(src[crop_y+y, crop_x+x, c]) / divisor */
+int ufr_u8_to_tensor(const unsigned char* src, float* dst, int H, int W, int C, int crop_y, int crop_x, int crop_h,
+                     int crop_w, float divisor, ufr_stream_t stream);
+/* KITTI flow PNG samples, uint16 [H,W,3] -> float32 [3,H,W]: u = (x-2^15)/64, v likewise, valid as is */
+int ufr_kitti_flow_decode(const unsigned short* src, float* dst, int H, int W, ufr_stream_t stream);
+
+/* HOST function (no GPU work): PNG scanline reconstruction (filter types 0-4) for the 16-bit KITTI flow maps
+ * that the reference reads with PyPNG (flowutils/flow_io.py:104-127).  data = rows x (1 + stride) inflated
+ * bytes, out = rows x stride, bpp = bytes per complete pixel. */
+int ufr_host_png_unfilter(const unsigned char* data, unsigned char* out, int rows, int stride, int bpp);
+
 #ifdef __cplusplus
 }
 #endif

@@ -334,3 +334,29 @@ def gen_attack_cone():
 
 
 GENERATORS["attack_cone"] = gen_attack_cone
+
+
+def gen_input_pipeline():
+    """dataset_utils/custom_transforms.py through the reference's own classes (train: flip + scale-crop +
+    to-tensor under fixed `random` / `np.random` seeds, both flip outcomes; valid: Scale + to-tensor)."""
+    import random
+    ct = rh.ref_module("dataset_utils.custom_transforms")
+    rng = np.random.default_rng(21)
+    imgs = [rng.integers(0, 256, size=(100, 140, 3), dtype=np.uint8) for _ in range(3)]
+    out = dict(imgs=np.stack(imgs))
+    flips = []
+    for seed in (1, 2, 3, 4):
+        random.seed(seed); np.random.seed(seed + 10)
+        state = random.getstate()
+        flips.append(random.random() < 0.5)
+        random.setstate(state)
+        tr = ct.Compose([ct.RandomHorizontalFlip(), ct.RandomScaleCrop(h=64, w=64), ct.ArrayToTensor()])
+        res = tr([im.astype(np.float32) for im in imgs])            # load_as_float hands float32 arrays over
+        out[f"train_seed{seed}"] = torch.stack(res)
+    assert any(flips) and not all(flips), flips
+    va = ct.Compose([ct.Scale(h=96, w=160), ct.ArrayToTensor()])
+    out["valid"] = torch.stack(va([im.astype(np.float32) for im in imgs]))
+    save("input_pipeline", **out)
+
+
+GENERATORS["input_pipeline"] = gen_input_pipeline

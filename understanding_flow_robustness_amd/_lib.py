@@ -81,6 +81,11 @@ SIGNATURES = {
     "ufr_affine_resample_f64": [_vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _d, _d, _d, _i, _vp],
     "ufr_patch_place": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_patch_crop_f64": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ufr_resample_u8_horizontal": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
+    "ufr_resample_u8_vertical": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp],
+    "ufr_u8_to_tensor": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "ufr_kitti_flow_decode": [_vp, _vp, _i, _i, _vp],
+    "ufr_host_png_unfilter": [_vp, _vp, _i, _i, _i],
 }
 PLAIN = {"ufr_abi_version": (C.c_int, []), "ufr_last_error": (C.c_char_p, []),
          "ufr_device_count": (C.c_int, [])}
