@@ -37,15 +37,22 @@ GFLOP_PREFIX_FWD = 2 * (2.312 + 12.583 + 12.583)   # conv1-3 on both frames (2*C
 GFLOP_CORR = 1.734 + 3.468
 
 
-def gflop_per_pair_step(window_hw, max_count):
+GFLOP_BAND_LAYERS = 16.74 + 4.53 + 9.06 + 2.26     # data gradients of conv3_1, conv4, conv4_1, conv5 (one pair)
+
+
+def gflop_per_pair_step(window_hw, max_count, band_width=None):
     """FLOPs the step EXECUTES per pair and iteration.  Full-frame: whole network forward + data gradient.
     Windowed prefix (patch_attack.py): head forward + adjoint at full size, conv1-3 forward + adjoint on
-    the window, plus the one full-frame conv1-3 forward per attack() call spread over its iterations."""
+    the window, plus the one full-frame conv1-3 forward per attack() call spread over its iterations;
+    with a column band (band_conv.py) four head data gradients shrink to band_width / W."""
     if window_hw is None:
         return 2 * GFLOP_NET_FWD + GFLOP_CORR
     frac = window_hw[0] * window_hw[1] / float(H * W)
     head = GFLOP_NET_FWD - GFLOP_PREFIX_FWD
-    return 2 * head + GFLOP_CORR + 2 * GFLOP_PREFIX_FWD * frac + GFLOP_PREFIX_FWD / max_count
+    total = 2 * head + GFLOP_CORR + 2 * GFLOP_PREFIX_FWD * frac + GFLOP_PREFIX_FWD / max_count
+    if band_width is not None:
+        total -= GFLOP_BAND_LAYERS * (1.0 - band_width / float(W))
+    return total
 
 
 GFLOP_PER_PAIR_STEP = gflop_per_pair_step(None, 2)
@@ -247,7 +254,9 @@ def main():
     if rank == 0:
         ms = elapsed * 1e3 / opt.steps
         value = world * B_PER_GPU * opt.steps / elapsed
-        gflop = gflop_per_pair_step(step.win_hw if step.cone is not None else None, mc)
+        band = getattr(step, "band", None) if step.cone is not None else None
+        gflop = gflop_per_pair_step(step.win_hw if step.cone is not None else None, mc,
+                                    band.width if band is not None else None)
         tf = gflop * B_PER_GPU / ms                        # per-GPU TFLOP/s (GFLOP/ms), executed work only
         line = {
             "metric": "attack-iters/s", "value": round(value, 3), "unit": "frame-pairs*steps/s",
@@ -259,6 +268,8 @@ def main():
                        "calls": f"attack() calls of max_count={mc} iterations, new frames + placement per call",
                        "prefix": (f"conv1-3 on a {step.win_hw[0]}x{step.win_hw[1]} window per pair"
                                   if step.cone is not None else "full frame"),
+                       "head_adjoint": (f"conv3_1/4/4_1/5 data gradients on a {band.width}-pixel column band"
+                                        if band is not None else "full width"),
                        "loss": "cosine", "lr": 1000.0, "weights": "synthetic seeded (no checkpoints offline)",
                        "graph": not opt.no_graph,
                        "parallelism": f"dp{world}: batch sharded, all-reduce of pre-clamp patch gradient"},

@@ -163,6 +163,7 @@ def test_windowed_step_equals_full_frame_step_at_bench_size(net):
         s_cone, _, cone = _run_step(net, True, [first, second], B, H, W, lr, shared)
         assert s_full.cone is None and s_cone.cone is not None
         assert s_cone.win_hw == (128, 128), s_cone.win_hw
+        assert s_cone.band is not None and s_cone.band.width == 608       # conv3_1..conv5 adjoints on a column band
         graph_before = s_cone.graph
         for (pf, af, nf, lf), (pc, ac, nc, lc), mask in zip(full, cone, (first, second)):
             sel = mask.amax(0, keepdim=True) if shared else mask

@@ -30,3 +30,39 @@ def test_perturbations_model_matches_reference(tag, method, targeted):
         frac = float((diff > 1e-6).float().mean())
         assert frac < 5e-3, f"{key}: {frac:.2e} of the pixels differ"
         assert float(diff.max()) <= 2 * 0.02 + 1e-6
+
+
+def test_adversarial_training_batch_composes_the_pinned_pieces():
+    """training/train.py:171-222: attack in eval mode, EPE of the attacked prediction, clean + adversarial
+    batch; parameters trainable and the module back in train mode afterwards; the captured step is reused."""
+    from understanding_flow_robustness_amd.flownets.utils_model import fetch_model, predict_flow
+    from understanding_flow_robustness_amd.losses import compute_epe
+    from understanding_flow_robustness_amd.perturb_model import PerturbationsModel, adversarial_training_batch
+    args = Namespace(flownet="FlowNetC", flow_loss="l2", perturb_method="ifgsm", perturb_mode="both", output_norm=0.02,
+                     perturb_n_step=3, perturb_learning_rate=0.005, perturb_momentum=0.47, probability_diverse_input=0.0)
+    net = fetch_model(args, synthetic_seed=0).to(DEV)
+    for p in net.parameters():
+        p.requires_grad_(True)
+    net.train()
+    g = torch.Generator().manual_seed(3)
+    i1, i2 = torch.rand(2, 3, 64, 128, generator=g).to(DEV), torch.rand(2, 3, 64, 128, generator=g).to(DEV)
+    flow = (3 * torch.randn(2, 2, 64, 128, generator=g)).to(DEV)
+    valid = (torch.rand(2, 64, 128, generator=g) > 0.2).float().to(DEV)
+    gt_full = torch.cat((flow, valid[:, None]), 1)
+    for _ in range(2):
+        b1, b2, bf, bv, epe = adversarial_training_batch(net, i1, i2, flow, valid, gt_full, args)
+    assert b1.shape == (4, 3, 64, 128) and bf.shape == (4, 2, 64, 128) and bv.shape == (4, 64, 128)
+    assert torch.equal(b1[:2], i1) and torch.equal(bf[2:], flow)
+    assert net.training and all(p.requires_grad for p in net.parameters())
+    assert len(net.__dict__["_ufr_perturb_steps"]) == 1
+    net.eval()
+    pm = PerturbationsModel("ifgsm", "both", 0.02, 3, 0.005, 0.47, 0.0, args=args)
+    _, _, a1, a2 = pm.forward(net, i1, i2, gt_full)
+    assert float((a1 - b1[2:]).abs().max()) <= 1e-6 and float((a2 - b2[2:]).abs().max()) <= 1e-6
+    assert float((b1[2:] - i1).abs().max()) <= 0.02 + 1e-6                      # inside the epsilon ball
+    with torch.no_grad():
+        want = compute_epe(gt=gt_full, pred=predict_flow(net, None, a1, a2, args))
+    assert abs(float(epe) - float(want)) <= 1e-4 * abs(float(want))
+    loss = net(b1, b2)
+    (loss[0] if isinstance(loss, tuple) else loss).mean().backward()             # the fine-tuning step still differentiates
+    assert net.conv1[0].weight.grad is not None

@@ -1,0 +1,67 @@
+"""Column-band data gradients for the convolutions behind a windowed prefix (patch_attack.py, cone.py).
+
+When FlowNetC's conv1-3 run on a window around the patch, the rest of the network still needs its adjoint
+only where activations depend on that window.  Behind the 21x21 stride-2 correlation that is every row but
+less than half of the columns for conv3_1 / conv4 / conv4_1 / conv5 (the most expensive data gradients of
+the head).  `band_conv2d` is `F.conv2d` whose backward computes the input gradient on a column band only:
+    gather the band of grad_output (origin in device memory: one captured graph serves every placement)
+    -> MIOpen backward-data on the band -> scatter the exact columns into a zeroed full-size gradient.
+Columns within `kernel - 1 - padding` cells of an interior band edge miss contributions from outside the
+band and are left zero; the band is sized (patch_attack.py) so that they are never needed.  Weights get no
+gradient: the attack differentiates with respect to the frames only.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+
+
+class Band:
+    """A per-sample column band: `win` int32 [B,8] with win[:,1] = first pixel column (win[:,0] = 0), `width`
+    pixels wide; both multiples of every level stride the band is used at."""
+
+    def __init__(self, win: torch.Tensor, width: int):
+        self.win, self.width = win, int(width)
+
+
+class _BandConv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, band, in_stride):
+        ctx.save_for_backward(weight)
+        ctx.meta = (tuple(x.shape), int(stride), int(padding), band, int(in_stride))
+        return F.conv2d(x, weight, bias, stride, padding)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (weight,) = ctx.saved_tensors
+        (B, Cin, Hi, Wi), s, p, band, ls_in = ctx.meta
+        k = weight.shape[-1]
+        ls_out = ls_in * s
+        wib, wob = band.width // ls_in, band.width // ls_out
+        _, Cout, Ho, Wo = gy.shape
+        lib, st = L.lib(), L.stream()
+        gy = gy.contiguous()
+        gyb = torch.empty(B, Cout, Ho, wob, dtype=gy.dtype, device=gy.device)
+        L.check(lib.ufr_window_gather(L.ptr(gy), L.ptr(gyb), L.ptr(band.win), B, B, Cout, Ho, Wo, Ho, wob, ls_out, 0, st),
+                "band gather")
+        gxb = torch.ops.aten.convolution_backward(gyb, gyb.new_empty((B, Cin, Hi, wib)), weight, None, (s, s), (p, p),
+                                                  (1, 1), False, (0, 0), 1, (True, False, False))[0]
+        gx = torch.zeros(B, Cin, Hi, Wi, dtype=gy.dtype, device=gy.device)
+        L.check(lib.ufr_window_scatter(L.ptr(gxb.contiguous()), L.ptr(gx), L.ptr(band.win), B, B, Cin, Hi, Wi, Hi, wib,
+                                       ls_in, k - 1 - p, st), "band scatter")
+        return gx, None, None, None, None, None, None
+
+
+def band_conv2d(x, conv: torch.nn.Conv2d, band: Band | None, in_stride: int):
+    """`conv(x)`; with a band, the data gradient is computed on the band's columns only.  `in_stride` = pixels
+    per cell of x."""
+    if band is None or not x.requires_grad:
+        return conv(x)
+    s, p = conv.stride[0], conv.padding[0]
+    if conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1] or conv.dilation != (1, 1) or conv.groups != 1:
+        raise NotImplementedError("band_conv2d: square stride / padding, no dilation or groups")
+    if band.width % (in_stride * s) or x.shape[-1] * in_stride < band.width:
+        raise ValueError("band width must be a multiple of the output cell size and fit the frame")
+    return _BandConv2d.apply(x, conv.weight, conv.bias, s, p, band, in_stride)

@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..band_conv import band_conv2d
 from ..cone import ConeSpec
 from ..spatial_correlation_sampler import spatial_correlation_sample
 
@@ -82,9 +83,23 @@ class FlowNetC(nn.Module):
         c2 = self.conv2(c1)
         return c2, self.conv3(c2)
 
-    def head(self, c2a, c3a, c3b):
-        """Everything after the prefix: correlation, conv_redir, conv3_1..6_1, refinement -> flow."""
-        return self._rest(c2a, c3a, c3b, None)
+    def head(self, c2a, c3a, c3b, band=None):
+        """Everything after the prefix: correlation, conv_redir, conv3_1..6_1, refinement -> flow.
+        `band` (band_conv.Band): c3a / c3b differ from constants only inside a window whose 21x21
+        correlation reach lies within the band, so conv3_1 / conv4 / conv4_1 / conv5 compute their data
+        gradient on the band's columns only."""
+        return self._rest(c2a, c3a, c3b, None, band)
+
+    # head convolutions whose data gradient is banded, with the pixel stride of their input
+    BAND_LAYERS = (("conv3_1", 8), ("conv4", 8), ("conv4_1", 16), ("conv5", 16))
+    # pixels beyond the prefix window that the band's exact zone must reach (worst layer: conv5's input):
+    # 20 cells of correlation displacement (160) + conv3_1 (8) + conv4 (8 left / 16 right) + conv4_1 (16)
+    # + one /16 cell of inexact rim next to an interior band edge (16)
+    BAND_REACH = 160 + 8 + 16 + 16 + 16
+
+    def _banded(self, name, x, band, in_stride):
+        seq = getattr(self, name)
+        return seq[1](band_conv2d(x, seq[0], band, in_stride))
 
     def forward(self, x1, x2, overwrite_feat_maps=None):
         if overwrite_feat_maps is not None:
@@ -98,16 +113,16 @@ class FlowNetC(nn.Module):
         feats = [c1[:B], c2a, c3a, c1[B:], c2[B:], c3b] if self.return_feat_maps else None
         return self._rest(c2a, c3a, c3b, feats)
 
-    def _rest(self, c2a, c3a, c3b, feats):
+    def _rest(self, c2a, c3a, c3b, feats, band=None):
         out_corr = correlate(c3a.contiguous(), c3b.contiguous())
         if feats is not None:
             feats.append(out_corr.clone())
         out_corr = F.leaky_relu(out_corr, 0.1)
         in_conv3_1 = torch.cat((self.conv_redir(c3a), out_corr), 1)
 
-        c3_1 = self.conv3_1(in_conv3_1)
-        c4 = self.conv4_1(self.conv4(c3_1))
-        c5 = self.conv5_1(self.conv5(c4))
+        c3_1 = self._banded("conv3_1", in_conv3_1, band, 8)
+        c4 = self._banded("conv4_1", self._banded("conv4", c3_1, band, 8), band, 16)
+        c5 = self.conv5_1(self._banded("conv5", c4, band, 16))
         c6 = self.conv6_1(self.conv6(c5))
 
         flow6 = self.predict_flow6(c6)

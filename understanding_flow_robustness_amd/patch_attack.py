@@ -169,6 +169,14 @@ class PatchAttackStep:
         self.g_tgt_full = torch.zeros_like(self.tgt)
         self.g_ref_full = torch.zeros_like(self.tgt)
         self._chain = spec.to_c()
+        # column band for the head's most expensive data gradients (band_conv.py)
+        self.band, reach = None, getattr(self.net, "BAND_REACH", None)
+        if reach is not None and W % 32 == 0 and os.environ.get("UFR_BAND", "1") != "0":
+            bw = -(-(ww + 2 * reach + 31) // 32) * 32
+            if bw * 4 <= W * 3:
+                from .band_conv import Band
+                self._band_reach = reach
+                self.band = Band(torch.zeros(B, 8, dtype=torch.int32, device=self.dev), bw)
 
     def _win_copy(self, fn, src, dst, n, c, hf, wf, ls, margin):
         wh, ww = self.win_hw
@@ -182,6 +190,9 @@ class PatchAttackStep:
         L.check(lib.ufr_cone_window(L.ptr(self.mask), self.B, self.CHW, 3, self.H, self.W, C.byref(self._chain),
                                     wh, ww, L.ptr(self.win), L.ptr(self.state[3:]), L.stream()), "cone window")
         self.g_tgt_full.zero_(); self.g_ref_full.zero_()
+        if self.band is not None:              # band start: 32-pixel aligned, `reach` left of the window, inside the frame
+            start = torch.div(self.win[:, 1] - self._band_reach, 32, rounding_mode="floor") * 32
+            self.band.win[:, 1] = start.clamp(0, self.W - self.band.width)
         feats = self.net.encode(torch.cat((self.adv_tgt.detach(), self.adv_ref.detach()), 0))
         for (ls, m, n, full, _), f in zip(self.taps, feats):
             full.detach().copy_(f[:n])
@@ -195,7 +206,8 @@ class PatchAttackStep:
         for f, (ls, m, n, full, _) in zip(self._feats_w, self.taps):
             self._win_copy(lib.ufr_window_scatter, f, full, n, f.shape[1], H // ls, W // ls, ls, m)
         full = [t[3] for t in self.taps]
-        return self.net.head(*full[:-1], full[-1][:B], full[-1][B:])
+        extra = {"band": self.band} if self.band is not None else {}
+        return self.net.head(*full[:-1], full[-1][:B], full[-1][B:], **extra)
 
     def _backward_cone(self, flow):
         """Adjoint of the head at full size, of the prefix on the window; canvas-sized gradients that are

@@ -38,6 +38,41 @@ def compute_flow_loss(flow_net, image0, image1, ground_truth, args):
     return loss.mean()
 
 
+def adversarial_training_batch(model, image1, image2, flow, valid, gt_full, args, arbitrary_gt=None):
+    """The adversarial-training step of training/train.py:171-222 up to the optimiser: attack the current
+    batch with `PerturbationsModel` (model in eval mode), measure the EPE of the attacked prediction, and
+    return the clean + adversarial batch for fine-tuning:
+        (image1, image2, flow, valid, epe_attacked)   with batch size doubled.
+    `arbitrary_gt` = (flow, valid) of another sample turns the attack into the targeted one (:188-198).
+    The fused attack steps freeze the parameters while they run; their `requires_grad` flags and the
+    module's train/eval mode are restored before returning, so the caller's optimiser step works."""
+    from .flownets.utils_model import predict_flow as _predict
+    from .losses import compute_epe
+    flags = [p.requires_grad for p in model.parameters()]
+    was_training = model.training
+    model.eval()
+    try:
+        pm = PerturbationsModel(perturb_method=args.perturb_method, perturb_mode=args.perturb_mode,
+                                output_norm=args.output_norm, n_step=args.perturb_n_step,
+                                learning_rate=args.perturb_learning_rate, momentum=args.perturb_momentum,
+                                probability_diverse_input=args.probability_diverse_input, disparity=False,
+                                targeted=arbitrary_gt is not None, args=args)
+        if arbitrary_gt is not None:
+            perturb_gt = torch.cat((arbitrary_gt[0], arbitrary_gt[1][:, None, ...]), dim=1)
+        else:
+            perturb_gt = torch.cat((flow, valid[:, None, ...]), dim=1)
+        _, _, image1_adv, image2_adv = pm.forward(model, image1, image2, perturb_gt)
+        with torch.no_grad():
+            flow_output = _predict(model, None, image1_adv, image2_adv, args)
+        epe_attacked = compute_epe(gt=gt_full, pred=flow_output)
+    finally:
+        for p, f in zip(model.parameters(), flags):
+            p.requires_grad_(f)
+        model.train(was_training)
+    return (torch.cat((image1, image1_adv)), torch.cat((image2, image2_adv)), torch.cat((flow, flow)),
+            torch.cat((valid, valid)), epe_attacked)
+
+
 class PerturbationsModel:
     """perturb_model.py:148-272: same constructor vocabulary and `forward` contract
     `(noise0, noise1, image0_adv, image1_adv)`."""
@@ -96,7 +131,11 @@ class PerturbationsModel:
 
     def _iterative_step(self, model, image0, ground_truth):
         B, _, H, W = image0.shape
-        key = (B, H, W, ground_truth.shape[1])
+        # cached on the network (a new PerturbationsModel per training batch, train.py:172-186, must not
+        # re-capture the graph): weights are read through their storage, so optimiser updates are seen
+        self._steps = model.__dict__.setdefault("_ufr_perturb_steps", {})
+        key = (B, H, W, ground_truth.shape[1], self.method, self.mode, self.lr, self.eps, self.targeted, self.use_graph,
+               getattr(self.args, "flow_loss", None), getattr(self.args, "flownet", None))
         step = self._steps.get(key)
         if step is None:
             sargs = Namespace(**vars(self.args))
