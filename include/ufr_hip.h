@@ -233,6 +233,15 @@ int ufr_window_gather(const float* src, float* dst, const int* win, int n_win, i
 int ufr_window_scatter(const float* src, float* dst, const int* win, int n_win, int N, int C, int Hd, int Wd,
                        int wh, int ww, int level_stride, int margin, ufr_stream_t stream);
 
+/* Both adjoints of ufr_corr_forward (kernel 1, stride 1, padding 0, fp32) for the cells of a per-sample
+ * window only -- win[n] / level_stride, wh x ww cells, as for ufr_window_gather; every other element of
+ * grad_input1 / grad_input2 [B,C,H,W] is written as zero.  Behind a windowed prefix only these cells of
+ * correlation_cuda_kernel.cu:86-233's result are read. */
+int ufr_corr_backward_window(const float* input1, const float* input2, const float* grad_output,
+                             float* grad_input1, float* grad_input2, int B, int C, int H, int W, int patch,
+                             int dilation_patch, const int* win, int level_stride, int wh, int ww,
+                             ufr_stream_t stream);
+
 /* ---- patch placement on the device ------------------------------------------------------------------
  * replaces the host round trip of patch_attacks/utils_patch.py:257-358 (circle_transform: scipy zoom /
  * rotate, three canvas-sized np.zeros + H2D per sample) and patch_attacks/main.py:408-461 (D2H, crop,

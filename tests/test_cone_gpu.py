@@ -189,3 +189,31 @@ def test_window_grows_when_a_larger_mask_arrives(net):
     for (pf, _, nf, _), (pc, _, nc, _), mask in zip(full, cone, (small, large)):
         upd = float(((pf - p0) * mask).abs().max())
         assert float(((pf - pc) * mask).abs().max()) <= 1e-4 * upd + 1e-6 and nf == nc
+
+
+@pytest.mark.parametrize("P,DP,C", [(21, 2, 256), (9, 1, 30)])
+def test_corr_backward_window_equals_full_adjoint_on_the_window(P, DP, C):
+    """csrc/correlation_window.hip against the full adjoint (pinned to the reference by tests/test_ops_gpu.py):
+    equal on each sample's window cells (corners, edges, interior), exactly zero elsewhere."""
+    from understanding_flow_robustness_amd import _lib as L
+    from understanding_flow_robustness_amd import spatial_correlation_sampler_backend as be
+    g = torch.Generator().manual_seed(P)
+    B, H, W, wh, ww, ls = 4, 24, 40, 6, 8, 8
+    a, b = torch.randn(B, C, H, W, generator=g).to(DEV), torch.randn(B, C, H, W, generator=g).to(DEV)
+    go = torch.randn(B, P, P, H, W, generator=g).to(DEV)
+    want1, want2 = be.backward(a, b, go, 1, 1, P, P, 0, 0, 1, 1, DP, DP, 1, 1)
+    origins = [(0, 0), (H - wh, W - ww), (0, 17), (9, 11)]
+    win = torch.zeros(B, 8, dtype=torch.int32, device=DEV)
+    for n, (y, x) in enumerate(origins):
+        win[n, 0], win[n, 1] = y * ls, x * ls
+    g1, g2 = torch.full_like(a, 7.0), torch.full_like(b, 7.0)
+    L.check(L.lib().ufr_corr_backward_window(L.ptr(a), L.ptr(b), L.ptr(go), L.ptr(g1), L.ptr(g2), B, C, H, W, P, DP,
+                                             L.ptr(win), ls, wh, ww, L.stream()))
+    inside = torch.zeros(B, 1, H, W, dtype=torch.bool, device=DEV)
+    for n, (y, x) in enumerate(origins):
+        inside[n, :, y:y + wh, x:x + ww] = True
+    for got, want, name in ((g1, want1, "grad_input1"), (g2, want2, "grad_input2")):
+        assert float(got.masked_select(~inside.expand_as(got)).abs().max()) == 0.0, name
+        scale = float(want.abs().max())
+        err = float(((got - want) * inside).abs().max())
+        assert err <= 1e-5 * scale, f"{name}: {err:.3e} of {scale:.3e}"

@@ -22,8 +22,40 @@ class Band:
     """A per-sample column band: `win` int32 [B,8] with win[:,1] = first pixel column (win[:,0] = 0), `width`
     pixels wide; both multiples of every level stride the band is used at."""
 
-    def __init__(self, win: torch.Tensor, width: int):
+    def __init__(self, win: torch.Tensor, width: int, cone_win: torch.Tensor | None = None, cone_hw=None):
         self.win, self.width = win, int(width)
+        # the prefix window itself (pixels): the correlation's adjoint is needed on its cells only
+        self.cone_win, self.cone_hw = cone_win, cone_hw
+
+
+class _WindowCorrelation(torch.autograd.Function):
+    """spatial_correlation_sample(kernel 1, stride 1, padding 0) whose backward fills only the cells of the
+    prefix window (csrc/correlation_window.hip); everything else of both input gradients is zero."""
+
+    @staticmethod
+    def forward(ctx, input1, input2, patch, dilation_patch, band, in_stride):
+        from . import spatial_correlation_sampler_backend as correlation
+        ctx.save_for_backward(input1, input2)
+        ctx.meta = (int(patch), int(dilation_patch), band, int(in_stride))
+        return correlation.forward(input1, input2, 1, 1, patch, patch, 0, 0, 1, 1, dilation_patch, dilation_patch, 1, 1)
+
+    @staticmethod
+    def backward(ctx, gout):
+        input1, input2 = ctx.saved_tensors
+        patch, dil, band, ls = ctx.meta
+        B, Cn, H, W = input1.shape
+        g1, g2 = torch.empty_like(input1), torch.empty_like(input2)
+        L.check(L.lib().ufr_corr_backward_window(L.ptr(input1), L.ptr(input2), L.ptr(gout.contiguous()), L.ptr(g1), L.ptr(g2),
+                                                 B, Cn, H, W, patch, dil, L.ptr(band.cone_win), ls, band.cone_hw[0] // ls,
+                                                 band.cone_hw[1] // ls, L.stream()), "corr backward window")
+        return g1, g2, None, None, None, None
+
+
+def window_correlation(input1, input2, patch, dilation_patch, band: Band, in_stride: int):
+    """Cost volume [B,P,P,H,W] of two feature maps that vary only inside `band.cone_win`."""
+    if input1.dtype != torch.float32 or not input1.is_contiguous() or not input2.is_contiguous():
+        raise TypeError("window_correlation: contiguous float32 feature maps")
+    return _WindowCorrelation.apply(input1, input2, patch, dilation_patch, band, in_stride)
 
 
 class _BandConv2d(torch.autograd.Function):
@@ -57,7 +89,7 @@ class _BandConv2d(torch.autograd.Function):
 def band_conv2d(x, conv: torch.nn.Conv2d, band: Band | None, in_stride: int):
     """`conv(x)`; with a band, the data gradient is computed on the band's columns only.  `in_stride` = pixels
     per cell of x."""
-    if band is None or not x.requires_grad:
+    if band is None or not band.width or not x.requires_grad:
         return conv(x)
     s, p = conv.stride[0], conv.padding[0]
     if conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1] or conv.dilation != (1, 1) or conv.groups != 1:

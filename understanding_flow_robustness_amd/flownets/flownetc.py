@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..band_conv import band_conv2d
+from ..band_conv import band_conv2d, window_correlation
 from ..cone import ConeSpec
 from ..spatial_correlation_sampler import spatial_correlation_sample
 
@@ -30,10 +30,14 @@ def _deconv(cin, cout):
     return nn.Sequential(nn.ConvTranspose2d(cin, cout, 4, 2, 1, bias=True), nn.LeakyReLU(0.1, inplace=True))
 
 
-def correlate(input1, input2, patch_size=21, dilation_patch=2):
-    """submodules.py:124-138: cost volume as a 4-D tensor [B, P*P, H, W], divided by C."""
-    out = spatial_correlation_sample(input1, input2, kernel_size=1, patch_size=patch_size, stride=1,
-                                     padding=0, dilation_patch=dilation_patch)
+def correlate(input1, input2, patch_size=21, dilation_patch=2, band=None, in_stride=8):
+    """submodules.py:124-138: cost volume as a 4-D tensor [B, P*P, H, W], divided by C.  With a band that
+    carries the prefix window, the adjoint is computed on the window's cells only."""
+    if band is not None and band.cone_win is not None and input1.requires_grad:
+        out = window_correlation(input1, input2, patch_size, dilation_patch, band, in_stride)
+    else:
+        out = spatial_correlation_sample(input1, input2, kernel_size=1, patch_size=patch_size, stride=1,
+                                         padding=0, dilation_patch=dilation_patch)
     b, ph, pw, h, w = out.size()
     return out.view(b, ph * pw, h, w) / input1.size(1)
 
@@ -114,7 +118,7 @@ class FlowNetC(nn.Module):
         return self._rest(c2a, c3a, c3b, feats)
 
     def _rest(self, c2a, c3a, c3b, feats, band=None):
-        out_corr = correlate(c3a.contiguous(), c3b.contiguous())
+        out_corr = correlate(c3a.contiguous(), c3b.contiguous(), band=band)
         if feats is not None:
             feats.append(out_corr.clone())
         out_corr = F.leaky_relu(out_corr, 0.1)

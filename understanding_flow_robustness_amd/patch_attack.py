@@ -171,12 +171,14 @@ class PatchAttackStep:
         self._chain = spec.to_c()
         # column band for the head's most expensive data gradients (band_conv.py)
         self.band, reach = None, getattr(self.net, "BAND_REACH", None)
-        if reach is not None and W % 32 == 0 and os.environ.get("UFR_BAND", "1") != "0":
+        if reach is not None and os.environ.get("UFR_BAND", "1") != "0":
+            from .band_conv import Band
             bw = -(-(ww + 2 * reach + 31) // 32) * 32
-            if bw * 4 <= W * 3:
-                from .band_conv import Band
-                self._band_reach = reach
-                self.band = Band(torch.zeros(B, 8, dtype=torch.int32, device=self.dev), bw)
+            if W % 32 != 0 or bw * 4 > W * 3:
+                bw = 0                         # frame too narrow for a band: only the correlation's adjoint is windowed
+            self._band_reach = reach
+            self.band = Band(torch.zeros(B, 8, dtype=torch.int32, device=self.dev), bw, cone_win=self.win,
+                             cone_hw=(wh, ww))
 
     def _win_copy(self, fn, src, dst, n, c, hf, wf, ls, margin):
         wh, ww = self.win_hw
@@ -190,7 +192,7 @@ class PatchAttackStep:
         L.check(lib.ufr_cone_window(L.ptr(self.mask), self.B, self.CHW, 3, self.H, self.W, C.byref(self._chain),
                                     wh, ww, L.ptr(self.win), L.ptr(self.state[3:]), L.stream()), "cone window")
         self.g_tgt_full.zero_(); self.g_ref_full.zero_()
-        if self.band is not None:              # band start: 32-pixel aligned, `reach` left of the window, inside the frame
+        if self.band is not None and self.band.width:   # band start: 32-pixel aligned, `reach` left of the window, inside the frame
             start = torch.div(self.win[:, 1] - self._band_reach, 32, rounding_mode="floor") * 32
             self.band.win[:, 1] = start.clamp(0, self.W - self.band.width)
         feats = self.net.encode(torch.cat((self.adv_tgt.detach(), self.adv_ref.detach()), 0))
