@@ -242,6 +242,15 @@ int ufr_corr_backward_window(const float* input1, const float* input2, const flo
                              int dilation_patch, const int* win, int level_stride, int wh, int ww,
                              ufr_stream_t stream);
 
+/* ---- convolution epilogue --------------------------------------------------------------------------
+ * models/submodules.py:18-46, :75-82: Conv2d / ConvTranspose2d(bias=True) + LeakyReLU(0.1).  The host runs
+ * the convolution without bias; x [B,C,HW] becomes LeakyReLU(x + bias[c]) in place (one pass instead of a
+ * broadcast add and an activation).  ufr_leaky_backward: grad_x = y > 0 ? grad_y : slope * grad_y, from the
+ * OUTPUT y like torch's in-place form.  Bit-identical to the torch pair. */
+int ufr_bias_leaky_forward(float* x, const float* bias, int B, int C, long HW, float slope, ufr_stream_t stream);
+int ufr_leaky_backward(const float* y, const float* grad_y, float* grad_x, long total, float slope,
+                       ufr_stream_t stream);
+
 /* ---- patch placement on the device ------------------------------------------------------------------
  * replaces the host round trip of patch_attacks/utils_patch.py:257-358 (circle_transform: scipy zoom /
  * rotate, three canvas-sized np.zeros + H2D per sample) and patch_attacks/main.py:408-461 (D2H, crop,

@@ -110,6 +110,38 @@ def test_attack_fused_kernels_bit_exact_vs_torch(net):
         assert_close(gf, ref_g, rtol=1e-4, atol_scale=1e-5, what=f"loss kind {kind} gradient")
 
 
+@pytest.mark.parametrize("shape", [(2, 5, 7, 12), (1, 3, 5, 7), (3, 64, 24, 40)])
+def test_fused_conv_epilogue_bit_exact_vs_torch(shape):
+    """csrc/bias_act.hip: LeakyReLU(x + bias) in place and its adjoint equal the torch pair bit for bit
+    (vectorised and scalar paths), and `conv_leaky` equals the module pair on a block of FlowNetC."""
+    from understanding_flow_robustness_amd import _lib as L
+    from understanding_flow_robustness_amd.band_conv import conv_leaky
+    g = torch.Generator().manual_seed(shape[1])
+    x = torch.randn(*shape, generator=g).to(DEV)
+    bias = torch.randn(shape[1], generator=g).to(DEV)
+    want = torch.nn.functional.leaky_relu(x + bias.view(1, -1, 1, 1), 0.1)
+    y = x.clone()
+    L.check(L.lib().ufr_bias_leaky_forward(L.ptr(y), L.ptr(bias), shape[0], shape[1], shape[2] * shape[3], 0.1, L.stream()))
+    assert torch.equal(y, want)
+    gy = torch.randn(*shape, generator=g).to(DEV)
+    gx = torch.empty_like(gy)
+    L.check(L.lib().ufr_leaky_backward(L.ptr(y), L.ptr(gy), L.ptr(gx), gy.numel(), 0.1, L.stream()))
+    assert torch.equal(gx, torch.ops.aten.leaky_relu_backward(gy, want, 0.1, True))
+    for block in (torch.nn.Sequential(torch.nn.Conv2d(shape[1], 6, 3, 2, 1), torch.nn.LeakyReLU(0.1, inplace=True)),
+                  torch.nn.Sequential(torch.nn.ConvTranspose2d(shape[1], 6, 4, 2, 1), torch.nn.LeakyReLU(0.1, inplace=True))):
+        block = block.to(DEV)
+        xin = x.clone().requires_grad_(True)
+        ref = block(xin)                                        # parameters trainable: the plain modules run
+        (g_ref,) = torch.autograd.grad(ref.sum() + (ref ** 2).sum(), xin)
+        for p in block.parameters():
+            p.requires_grad_(False)
+        xin2 = x.clone().requires_grad_(True)
+        out = conv_leaky(xin2, block)
+        assert torch.equal(out, ref)
+        (g_out,) = torch.autograd.grad(out.sum() + (out ** 2).sum(), xin2)
+        assert torch.equal(g_out, g_ref)
+
+
 def test_attack_gate_semantics(net):
     """`while loss_scalar > 0.1` + `count > max_count-1` on the device: once the loss of iteration k is
     <= 0.1 the later replays leave patch and frames untouched."""

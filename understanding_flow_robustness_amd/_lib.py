@@ -79,6 +79,8 @@ SIGNATURES = {
     "ufr_window_gather": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ufr_window_scatter": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ufr_corr_backward_window": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp],
+    "ufr_bias_leaky_forward": [_vp, _vp, _i, _i, _l, _f, _vp],
+    "ufr_leaky_backward": [_vp, _vp, _vp, _l, _f, _vp],
     "ufr_affine_resample_f64": [_vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _d, _d, _d, _i, _vp],
     "ufr_patch_place": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_patch_crop_f64": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],

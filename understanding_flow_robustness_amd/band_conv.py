@@ -86,14 +86,58 @@ class _BandConv2d(torch.autograd.Function):
         return gx, None, None, None, None, None, None
 
 
-def band_conv2d(x, conv: torch.nn.Conv2d, band: Band | None, in_stride: int):
+class _BiasLeaky(torch.autograd.Function):
+    """y = LeakyReLU(x + bias[c]) in place on x (csrc/bias_act.hip); no gradient for the frozen bias."""
+
+    @staticmethod
+    def forward(ctx, x, bias, slope):
+        B, Cn = x.shape[0], x.shape[1]
+        L.check(L.lib().ufr_bias_leaky_forward(L.ptr(x), L.ptr(bias), B, Cn, x.numel() // (B * Cn), float(slope),
+                                               L.stream()), "bias leaky forward")
+        ctx.mark_dirty(x)
+        ctx.save_for_backward(x)
+        ctx.slope = float(slope)
+        return x
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = torch.empty_like(gy)
+        L.check(L.lib().ufr_leaky_backward(L.ptr(y), L.ptr(gy), L.ptr(gx), gy.numel(), ctx.slope, L.stream()),
+                "leaky backward")
+        return gx, None, None
+
+
+def conv_leaky(x, seq, band: Band | None = None, in_stride: int = 0):
+    """The reference's `conv` / `deconv` block (models/submodules.py:18-46, :75-82) = Sequential(Conv2d or
+    ConvTranspose2d with bias, LeakyReLU): on a HIP float32 tensor the convolution runs without bias and
+    bias + activation are one in-place pass; with frozen parameters only.  Otherwise the plain modules."""
+    conv, act = seq[0], seq[1]
+    frozen = not (conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad))
+    fused = (x.is_cuda and x.dtype == torch.float32 and conv.bias is not None and act.negative_slope > 0
+             and (frozen or not torch.is_grad_enabled()))
+    if not fused:
+        return act(band_conv2d(x, conv, band, in_stride)) if isinstance(conv, torch.nn.Conv2d) else act(conv(x))
+    if isinstance(conv, torch.nn.Conv2d):
+        y = band_conv2d(x, conv, band, in_stride, with_bias=False)
+    else:
+        y = F.conv_transpose2d(x, conv.weight, None, conv.stride, conv.padding, conv.output_padding, conv.groups,
+                               conv.dilation)
+    if not y.is_contiguous():
+        y = y.contiguous()
+    return _BiasLeaky.apply(y, conv.bias, act.negative_slope)
+
+
+def band_conv2d(x, conv: torch.nn.Conv2d, band: Band | None, in_stride: int, with_bias: bool = True):
     """`conv(x)`; with a band, the data gradient is computed on the band's columns only.  `in_stride` = pixels
     per cell of x."""
+    bias = conv.bias if with_bias else None
     if band is None or not band.width or not x.requires_grad:
-        return conv(x)
+        return F.conv2d(x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
     s, p = conv.stride[0], conv.padding[0]
     if conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1] or conv.dilation != (1, 1) or conv.groups != 1:
         raise NotImplementedError("band_conv2d: square stride / padding, no dilation or groups")
     if band.width % (in_stride * s) or x.shape[-1] * in_stride < band.width:
         raise ValueError("band width must be a multiple of the output cell size and fit the frame")
-    return _BandConv2d.apply(x, conv.weight, conv.bias, s, p, band, in_stride)
+    return _BandConv2d.apply(x, conv.weight, bias, s, p, band, in_stride)

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..band_conv import band_conv2d, window_correlation
+from ..band_conv import conv_leaky, window_correlation
 from ..cone import ConeSpec
 from ..spatial_correlation_sampler import spatial_correlation_sample
 
@@ -83,9 +83,9 @@ class FlowNetC(nn.Module):
 
     def encode(self, x):
         """Siamese prefix on a stack of raw frames [N,3,h,w] (h, w multiples of 8): (conv2, conv3)."""
-        c1 = self.conv1(self.normalize_correctly(x))
-        c2 = self.conv2(c1)
-        return c2, self.conv3(c2)
+        c1 = self._cl("conv1", self.normalize_correctly(x))
+        c2 = self._cl("conv2", c1)
+        return c2, self._cl("conv3", c2)
 
     def head(self, c2a, c3a, c3b, band=None):
         """Everything after the prefix: correlation, conv_redir, conv3_1..6_1, refinement -> flow.
@@ -101,18 +101,18 @@ class FlowNetC(nn.Module):
     # + one /16 cell of inexact rim next to an interior band edge (16)
     BAND_REACH = 160 + 8 + 16 + 16 + 16
 
-    def _banded(self, name, x, band, in_stride):
-        seq = getattr(self, name)
-        return seq[1](band_conv2d(x, seq[0], band, in_stride))
+    def _cl(self, name, x, band=None, in_stride=0):
+        """One `conv` / `deconv` block (convolution + bias + LeakyReLU), fused epilogue on the device."""
+        return conv_leaky(x, getattr(self, name), band, in_stride)
 
     def forward(self, x1, x2, overwrite_feat_maps=None):
         if overwrite_feat_maps is not None:
             raise NotImplementedError("feature-map overwriting belongs to the analysis scripts (out of scope)")
         B = x1.shape[0]
         x = self.normalize_correctly(torch.cat((x1, x2), 0))
-        c1 = self.conv1(x)
-        c2 = self.conv2(c1)
-        c3 = self.conv3(c2)
+        c1 = self._cl("conv1", x)
+        c2 = self._cl("conv2", c1)
+        c3 = self._cl("conv3", c2)
         c2a, c3a, c3b = c2[:B], c3[:B], c3[B:]
         feats = [c1[:B], c2a, c3a, c1[B:], c2[B:], c3b] if self.return_feat_maps else None
         return self._rest(c2a, c3a, c3b, feats)
@@ -122,21 +122,21 @@ class FlowNetC(nn.Module):
         if feats is not None:
             feats.append(out_corr.clone())
         out_corr = F.leaky_relu(out_corr, 0.1)
-        in_conv3_1 = torch.cat((self.conv_redir(c3a), out_corr), 1)
+        in_conv3_1 = torch.cat((self._cl("conv_redir", c3a), out_corr), 1)
 
-        c3_1 = self._banded("conv3_1", in_conv3_1, band, 8)
-        c4 = self._banded("conv4_1", self._banded("conv4", c3_1, band, 8), band, 16)
-        c5 = self.conv5_1(self._banded("conv5", c4, band, 16))
-        c6 = self.conv6_1(self.conv6(c5))
+        c3_1 = self._cl("conv3_1", in_conv3_1, band, 8)
+        c4 = self._cl("conv4_1", self._cl("conv4", c3_1, band, 8), band, 16)
+        c5 = self._cl("conv5_1", self._cl("conv5", c4, band, 16))
+        c6 = self._cl("conv6_1", self._cl("conv6", c5))
 
         flow6 = self.predict_flow6(c6)
-        cat5 = torch.cat((c5, self.deconv5(c6), self.upsampled_flow6_to_5(flow6)), 1)
+        cat5 = torch.cat((c5, self._cl("deconv5", c6), self.upsampled_flow6_to_5(flow6)), 1)
         flow5 = self.predict_flow5(cat5)
-        cat4 = torch.cat((c4, self.deconv4(cat5), self.upsampled_flow5_to_4(flow5)), 1)
+        cat4 = torch.cat((c4, self._cl("deconv4", cat5), self.upsampled_flow5_to_4(flow5)), 1)
         flow4 = self.predict_flow4(cat4)
-        cat3 = torch.cat((c3_1, self.deconv3(cat4), self.upsampled_flow4_to_3(flow4)), 1)
+        cat3 = torch.cat((c3_1, self._cl("deconv3", cat4), self.upsampled_flow4_to_3(flow4)), 1)
         flow3 = self.predict_flow3(cat3)
-        cat2 = torch.cat((c2a, self.deconv2(cat3), self.upsampled_flow3_to_2(flow3)), 1)
+        cat2 = torch.cat((c2a, self._cl("deconv2", cat3), self.upsampled_flow3_to_2(flow3)), 1)
         flow2 = self.predict_flow2(cat2)
 
         up = lambda f: F.interpolate(f * self.div_flow, scale_factor=4, mode="bilinear", align_corners=False)
