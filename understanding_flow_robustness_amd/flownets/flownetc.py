@@ -20,14 +20,22 @@ from ..spatial_correlation_sampler import spatial_correlation_sample
 _RGB_MEAN = (0.40066648, 0.39482617, 0.3784785)
 
 
+class ConvLeaky(nn.Sequential):
+    """Sequential(convolution with bias, LeakyReLU) -- same parameter names as the reference's blocks -- whose
+    forward fuses bias + activation on the device (band_conv.conv_leaky)."""
+
+    def forward(self, x):
+        return conv_leaky(x, self)
+
+
 def _conv(cin, cout, k=3, stride=1):
     """submodules.py:18-46 (batchNorm=False branch): conv + LeakyReLU(0.1)."""
-    return nn.Sequential(nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, bias=True), nn.LeakyReLU(0.1, inplace=True))
+    return ConvLeaky(nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, bias=True), nn.LeakyReLU(0.1, inplace=True))
 
 
 def _deconv(cin, cout):
     """submodules.py:75-82."""
-    return nn.Sequential(nn.ConvTranspose2d(cin, cout, 4, 2, 1, bias=True), nn.LeakyReLU(0.1, inplace=True))
+    return ConvLeaky(nn.ConvTranspose2d(cin, cout, 4, 2, 1, bias=True), nn.LeakyReLU(0.1, inplace=True))
 
 
 def correlate(input1, input2, patch_size=21, dilation_patch=2, band=None, in_stride=8):

@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..band_conv import conv_leaky
 from .flownetc import correlate as _correlate
 
 
@@ -75,9 +76,13 @@ class PWCDCNet(nn.Module):
                 if m.bias is not None:
                     m.bias.data.zero_()
 
+    def _cl(self, name, x):
+        """One conv + bias + LeakyReLU block; bias and activation are one in-place pass on the device."""
+        return conv_leaky(x, getattr(self, name))
+
     def _decode(self, lvl, x):
         for i in range(5):                                         # DenseNet connections
-            x = torch.cat((getattr(self, f"conv{lvl}_{i}")(x), x), 1)
+            x = torch.cat((self._cl(f"conv{lvl}_{i}", x), x), 1)
         return x, getattr(self, f"predict_flow{lvl}")(x)
 
     def forward(self, im1, im2):
@@ -85,7 +90,7 @@ class PWCDCNet(nn.Module):
         x = torch.cat((im1, im2), 0).flip(1)                       # RGB -> BGR (PWCNet.py:230-231)
         feats = []
         for _, _, first, second, third in self._PYRAMID:
-            x = getattr(self, "conv" + third)(getattr(self, "conv" + second)(getattr(self, "conv" + first)(x)))
+            x = self._cl("conv" + third, self._cl("conv" + second, self._cl("conv" + first, x)))
             feats.append(x)
         c1 = {lvl: feats[lvl - 1][:B] for lvl in range(2, 7)}
         c2 = {lvl: feats[lvl - 1][B:] for lvl in range(2, 7)}
@@ -100,8 +105,8 @@ class PWCDCNet(nn.Module):
             corr = F.leaky_relu(correlate(c1[lvl].contiguous(), warped.contiguous()), 0.1)
             x, flow = self._decode(lvl, torch.cat((corr, c1[lvl], up_flow, up_feat), 1))
             flows[lvl] = flow
-        x = self.dc_conv4(self.dc_conv3(self.dc_conv2(self.dc_conv1(x))))
-        flow2 = flows[2] + self.dc_conv7(self.dc_conv6(self.dc_conv5(x)))
+        x = self._cl("dc_conv4", self._cl("dc_conv3", self._cl("dc_conv2", self._cl("dc_conv1", x))))
+        flow2 = flows[2] + self.dc_conv7(self._cl("dc_conv6", self._cl("dc_conv5", x)))
         up = lambda f: F.interpolate(f, scale_factor=4, mode="bilinear", align_corners=False)
         if self.training:
             return tuple(up(f) for f in (flow2, flows[3], flows[4], flows[5], flows[6]))
