@@ -121,6 +121,23 @@ def kernel_rooflines(device):
                        hbm_frac=round(gbs / PEAK_HBM_GBS, 4),
                        traffic=(pmc[name]["fetch_bytes"] + pmc[name]["write_bytes"]) if name in pmc else None,
                        algorithmic_bytes=int(w["mbytes"] * 1e6 * B)))
+    ks[-1]["note"] = "full-frame iteration only (UFR_CONE=0); the windowed step runs corr_bwd_window"
+    # the adjoint the windowed step actually runs: 16x16 cells per pair, both inputs
+    from understanding_flow_robustness_amd import _lib as L
+    win = torch.zeros(B, 8, dtype=torch.int32, device=device)
+    win[:, 0], win[:, 1] = 128, 512
+    g1, g2 = torch.empty_like(a), torch.empty_like(b)
+    t_w = event_time(lambda: L.check(L.lib().ufr_corr_backward_window(
+        L.ptr(a), L.ptr(b), L.ptr(go), L.ptr(g1), L.ptr(g2), B, 256, H // 8, W // 8, 21, 2, L.ptr(win), 8, 16, 16,
+        L.stream())), 10)
+    cells = 16 * 16
+    gflop_w = 2 * 2 * 256 * 441 * cells * B / 1e9                       # both adjoints
+    bytes_w = B * (2 * 441 * cells * 4 + 2 * 256 * 56 * 56 * 4 + 2 * 256 * (H // 8) * (W // 8) * 4)   # gout, regions, zero-filled outputs
+    ks.append(dict(kernel="corr_bwd_window<8,21,2> (both adjoints, 16x16 cells per pair)", ms=round(t_w, 4), bound="hbm",
+                   achieved=round(bytes_w / t_w / 1e6, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                   frac=round(bytes_w / t_w / 1e6 / PEAK_HBM_GBS, 4), tflops=round(gflop_w / t_w, 2), traffic=None,
+                   algorithmic_bytes=int(bytes_w),
+                   note="bound in practice by L2->L1 traffic: 32 channel groups re-read the window's grad_output"))
     return ks
 
 

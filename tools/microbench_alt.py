@@ -36,7 +36,14 @@ def main():
                 alt_cuda_corr.backward(f1, f2, coords, go, r)
             e.record()
             e.synchronize()
-            print(f"{name:7s} level {lvl}: {s.elapsed_time(e) / 20 * 1e3:8.1f} us / backward call", flush=True)
+            t_b = s.elapsed_time(e) / 20 * 1e3
+            s.record()
+            for _ in range(20):
+                alt_cuda_corr.forward(f1, f2, coords, r)
+            e.record()
+            e.synchronize()
+            print(f"{name:7s} level {lvl}: {t_b:8.1f} us / backward call, {s.elapsed_time(e) / 20 * 1e3:7.1f} us / forward call",
+                  flush=True)
 
 
 if __name__ == "__main__":
