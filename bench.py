@@ -141,6 +141,16 @@ def kernel_rooflines(device):
     return ks
 
 
+def step_traffic():
+    """HBM-side bytes of one iteration of the windowed step from this round's PMC passes
+    (tools/pmc_step_traffic.py -> profiles/r1_step_traffic.json); counters cannot be read live."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_step_traffic.json")) as f:
+            return int(json.load(f)["traffic_bytes_per_iteration"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline():
     """The CPU oracle on a bounded sample of the same workload: ONE attack() call of 2 iterations on
     one 384x1280 pair (the reference's only batch size), all host threads."""
@@ -292,7 +302,7 @@ def main():
                        "parallelism": f"dp{world}: batch sharded, all-reduce of pre-clamp patch gradient"},
             "roofline": {"bound": "mfma", "kernel": "attack step = 1 hipGraph launch (MIOpen fp32 convs + ufr_* kernels)",
                          "achieved": round(tf, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(tf / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                         "frac": round(tf / PEAK_FP32_TFLOPS, 4), "traffic": step_traffic(),
                          "algorithmic_gflop_per_launch": round(gflop * B_PER_GPU, 1),
                          "full_frame_gflop_per_launch": round(GFLOP_PER_PAIR_STEP * B_PER_GPU, 1)},
         }

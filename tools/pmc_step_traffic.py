@@ -1,0 +1,49 @@
+"""HBM-side traffic of one attack iteration from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline
+    python tools/pmc_step_traffic.py /tmp/pf/*/*counter_collection.csv /tmp/pw/*/*counter_collection.csv 4
+
+Sums the counter over the dispatches of the last `iters` iterations (delimited by gate_kernel, the last kernel
+of every iteration; the per-call load() kernels fall inside and are averaged in), per iteration.
+Units and the gfx950 correction follow MI355X_MICROARCH.md: both counters are in kilobytes, FETCH_SIZE is
+doubled."""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+
+def per_iteration(path, counter, iters):
+    rows = [r for r in csv.DictReader(open(path)) if r.get("Counter_Name", r.get("counter_name")) == counter]
+    key = lambda r, *names: next(r[n] for n in names if n in r)
+    rows.sort(key=lambda r: int(key(r, "Dispatch_Id", "dispatch_id")))
+    names = [key(r, "Kernel_Name", "kernel_name") for r in rows]
+    vals = [float(key(r, "Counter_Value", "counter_value")) for r in rows]
+    marks = [i for i, n in enumerate(names) if "gate_kernel" in n]
+    if len(marks) < iters + 1:
+        raise SystemExit(f"{path}: only {len(marks)} iterations recorded")
+    lo, hi = marks[-iters - 1] + 1, marks[-1] + 1
+    per_kernel = defaultdict(float)
+    for n, v in zip(names[lo:hi], vals[lo:hi]):
+        per_kernel[n.split("(")[0][-60:]] += v / iters
+    return sum(vals[lo:hi]) / iters, per_kernel
+
+
+def main(fetch_csv, write_csv, iters):
+    f_kb, f_k = per_iteration(fetch_csv, "FETCH_SIZE", iters)
+    w_kb, w_k = per_iteration(write_csv, "WRITE_SIZE", iters)
+    fetch_b, write_b = 2.0 * f_kb * 1024.0, w_kb * 1024.0              # FETCH_SIZE doubled on gfx950
+    out = {"_provenance": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes with --kernel-trace only, over "
+                          "bench.py --steps 6 --warmup 2 --no-cpu-baseline; mean over the last %d iterations "
+                          "(load() of every second iteration included); KB -> bytes, FETCH_SIZE x2 per "
+                          "MI355X_MICROARCH.md" % iters,
+           "fetch_bytes_per_iteration": round(fetch_b), "write_bytes_per_iteration": round(write_b),
+           "traffic_bytes_per_iteration": round(fetch_b + write_b),
+           "top_fetch_kernels_MB": {k: round(2.0 * v * 1024 / 1e6, 1) for k, v in sorted(f_k.items(), key=lambda kv: -kv[1])[:8]},
+           "top_write_kernels_MB": {k: round(v * 1024 / 1e6, 1) for k, v in sorted(w_k.items(), key=lambda kv: -kv[1])[:8]}}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 4)
