@@ -30,6 +30,7 @@ import ctypes as C
 import os
 from argparse import Namespace
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -425,27 +426,30 @@ ERROR_NAMES = ["epe", "adv_epe", "cos_sim", "adv_cos_sim"]
 
 def validate_flow_with_gt(patch, mask, patch_shape, val_loader, flow_net, args: Namespace):
     """patch_attacks/main.py::validate_flow_with_gt (:616-784): for every validation item place the
-    patch (host `circle_transform`, same RNG order), run the clean and the patched pair, and average
+    patch (`circle_transform`, same RNG order), run the clean and the patched pair, and average
     EPE / cosine similarity against the ground-truth flow.  Returns `(errors_avg, error_names)`.
+    `patch` / `mask` may be the reference's numpy arrays or float64 HIP tensors.
 
-    Differences from the reference, none of them numeric: the clean and the adversarial pair run as
-    ONE batch of two, paste+clamp is the fused kernel, the four metrics stay on the device and the
+    Differences from the reference, none of them numeric: the placement runs on the device
+    (patch_transform.py: no canvas-sized host arrays, no H2D per item), the clean and the adversarial pair
+    run as ONE batch of two, paste+clamp is the fused kernel, the four metrics stay on the device and the
     host synchronises once at the end instead of four times per item (`.item()` in losses.py)."""
     from . import losses
-    from .utils_patch import circle_transform
+    from .patch_transform import circle_transform_device
     if getattr(args, "patch_type", "circle") != "circle":
         raise NotImplementedError("only --patch_type circle is mirrored")
     flow_net.eval()
     lo, hi = _pixel_range(args.flownet)
-    sums, count = None, 0
+    sums, count, patch_d, mask_d = None, 0, None, None
     with torch.no_grad():
         for item in val_loader:
             ref_past, tgt, ref_future, flow_gt = item[0], item[1], item[2], item[3]
             dev = tgt.device
             L.require_hip(tgt, "tgt_img", contiguous=False)
-            patch_full, mask_full, _, _, _, _ = circle_transform(patch, mask, patch.copy(), tuple(tgt.shape), patch_shape)
-            patch_t = torch.FloatTensor(patch_full).to(dev)
-            mask_t = torch.FloatTensor(mask_full).to(dev)
+            if patch_d is None:
+                f64 = lambda a: (a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))).to(dev, torch.float64)
+                patch_d, mask_d = f64(patch), f64(mask)
+            patch_t, mask_t, _, _, _, _ = circle_transform_device(patch_d, mask_d, patch_d, tuple(tgt.shape), patch_shape)
             tgt, ref_future = tgt.contiguous(), ref_future.contiguous()
             B, _, H, W = tgt.shape
             adv_tgt, adv_ref = torch.empty_like(tgt), torch.empty_like(ref_future)
