@@ -251,6 +251,24 @@ int ufr_bias_leaky_forward(float* x, const float* bias, int B, int C, long HW, f
 int ufr_leaky_backward(const float* y, const float* grad_y, float* grad_x, long total, float slope,
                        ufr_stream_t stream);
 
+/* ---- 2-channel layers ---------------------------------------------------------------------------------
+ * predict_flow* = Conv2d(Cin, 2, 3, 1, 1) and upsampled_flow* = ConvTranspose2d(2, 2, 4, 2, 1)
+ * (models/FlowNetC.py:43-50, models/submodules.py:85-90; the same layers close FlowNetS/SD and PWC-Net).
+ * One HBM pass each instead of implicit-GEMM tiles sized for wide outputs.  Layouts are torch's:
+ * x [B,Cin,H,W], conv weight [2,Cin,3,3], transposed-conv weight [2,2,4,4] (in, out, ky, kx), bias [2].
+ * The forward convolution splits the channels over workgroups on small images and adds the partial sums
+ * in a fixed order: pass a workspace of ufr_conv3x3_c2_workspace_floats() floats (0 = none needed). */
+long ufr_conv3x3_c2_workspace_floats(int B, int Cin, int H, int W);
+int ufr_conv3x3_c2_forward(const float* x, const float* weight, const float* bias, float* y, float* workspace,
+                           int B, int Cin, int H, int W, ufr_stream_t stream);
+int ufr_conv3x3_c2_backward_data(const float* grad_y, const float* weight, float* grad_x, int B, int Cin, int H,
+                                 int W, ufr_stream_t stream);
+/* x [B,2,H,W] -> y [B,2,2H,2W]; bias may be NULL */
+int ufr_deconv4x4s2_c2_forward(const float* x, const float* weight, const float* bias, float* y, int B, int H, int W,
+                               ufr_stream_t stream);
+int ufr_deconv4x4s2_c2_backward_data(const float* grad_y, const float* weight, float* grad_x, int B, int H, int W,
+                                     ufr_stream_t stream);
+
 /* ---- patch placement on the device ------------------------------------------------------------------
  * replaces the host round trip of patch_attacks/utils_patch.py:257-358 (circle_transform: scipy zoom /
  * rotate, three canvas-sized np.zeros + H2D per sample) and patch_attacks/main.py:408-461 (D2H, crop,

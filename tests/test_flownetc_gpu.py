@@ -110,6 +110,45 @@ def test_attack_fused_kernels_bit_exact_vs_torch(net):
         assert_close(gf, ref_g, rtol=1e-4, atol_scale=1e-5, what=f"loss kind {kind} gradient")
 
 
+@pytest.mark.parametrize("B,Cin,H,W", [(8, 1024, 6, 20), (2, 194, 24, 40), (3, 37, 7, 9), (1, 16, 1, 5), (1, 770, 24, 80)])
+def test_two_channel_layers_vs_torch(B, Cin, H, W):
+    """csrc/small_cout.hip: predict_flow (Conv2d(Cin,2,3,1,1)) and upsampled_flow (ConvTranspose2d(2,2,4,2,1))
+    forward and data gradient against torch, channel-split and direct paths, ragged sizes, with / without bias."""
+    from understanding_flow_robustness_amd.band_conv import flow_head, flow_upsample
+    g = torch.Generator().manual_seed(Cin + H)
+    conv = torch.nn.Conv2d(Cin, 2, 3, 1, 1).to(DEV)
+    x = torch.randn(B, Cin, H, W, generator=g).to(DEV)
+    xr = x.clone().requires_grad_(True)
+    ref = conv(xr)
+    gy = torch.randn(B, 2, H, W, generator=g).to(DEV)
+    (g_ref,) = torch.autograd.grad(ref, xr, gy)
+    for p in conv.parameters():
+        p.requires_grad_(False)
+    xo = x.clone().requires_grad_(True)
+    out = flow_head(xo, conv)
+    assert out.grad_fn is not None and type(out.grad_fn).__name__.startswith("_Conv3x3C2"), "fast path not taken"
+    assert_close(out, ref, rtol=1e-5, atol_scale=1e-6, what="predict_flow forward")
+    (g_out,) = torch.autograd.grad(out, xo, gy)
+    assert_close(g_out, g_ref, rtol=1e-5, atol_scale=1e-6, what="predict_flow data gradient")
+    again = flow_head(x, conv)
+    assert torch.equal(again, out.detach()), "channel-split reduction must be deterministic"
+    for bias in (True, False):
+        up = torch.nn.ConvTranspose2d(2, 2, 4, 2, 1, bias=bias).to(DEV)
+        f = torch.randn(B, 2, H, W, generator=g).to(DEV)
+        fr = f.clone().requires_grad_(True)
+        r = up(fr)
+        gu = torch.randn_like(r)
+        (gr,) = torch.autograd.grad(r, fr, gu)
+        for p in up.parameters():
+            p.requires_grad_(False)
+        fo = f.clone().requires_grad_(True)
+        o = flow_upsample(fo, up)
+        assert type(o.grad_fn).__name__.startswith("_Deconv4x4C2")
+        assert_close(o, r, rtol=1e-5, atol_scale=1e-6, what="upsampled_flow forward")
+        (go,) = torch.autograd.grad(o, fo, gu)
+        assert_close(go, gr, rtol=1e-5, atol_scale=1e-6, what="upsampled_flow data gradient")
+
+
 @pytest.mark.parametrize("shape", [(2, 5, 7, 12), (1, 3, 5, 7), (3, 64, 24, 40)])
 def test_fused_conv_epilogue_bit_exact_vs_torch(shape):
     """csrc/bias_act.hip: LeakyReLU(x + bias) in place and its adjoint equal the torch pair bit for bit

@@ -81,6 +81,10 @@ SIGNATURES = {
     "ufr_corr_backward_window": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp],
     "ufr_bias_leaky_forward": [_vp, _vp, _i, _i, _l, _f, _vp],
     "ufr_leaky_backward": [_vp, _vp, _vp, _l, _f, _vp],
+    "ufr_conv3x3_c2_forward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ufr_conv3x3_c2_backward_data": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ufr_deconv4x4s2_c2_forward": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "ufr_deconv4x4s2_c2_backward_data": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "ufr_affine_resample_f64": [_vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _d, _d, _d, _i, _vp],
     "ufr_patch_place": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_patch_crop_f64": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -91,7 +95,8 @@ SIGNATURES = {
     "ufr_host_png_unfilter": [_vp, _vp, _i, _i, _i],
 }
 PLAIN = {"ufr_abi_version": (C.c_int, []), "ufr_last_error": (C.c_char_p, []),
-         "ufr_device_count": (C.c_int, [])}
+         "ufr_device_count": (C.c_int, []),
+         "ufr_conv3x3_c2_workspace_floats": (C.c_long, [_i, _i, _i, _i])}
 
 
 def lib():

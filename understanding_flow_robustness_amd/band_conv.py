@@ -109,6 +109,76 @@ class _BiasLeaky(torch.autograd.Function):
         return gx, None, None
 
 
+class _Conv3x3C2(torch.autograd.Function):
+    """Conv2d(Cin, 2, 3, 1, 1) with frozen parameters (csrc/small_cout.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        B, Cin, H, W = x.shape
+        y = torch.empty(B, 2, H, W, dtype=x.dtype, device=x.device)
+        n_ws = L.lib().ufr_conv3x3_c2_workspace_floats(B, Cin, H, W)
+        ws = torch.empty(n_ws, dtype=x.dtype, device=x.device) if n_ws else None
+        L.check(L.lib().ufr_conv3x3_c2_forward(L.ptr(x), L.ptr(weight), L.ptr(bias), L.ptr(y), L.ptr(ws) if n_ws else None,
+                                               B, Cin, H, W, L.stream()), "conv3x3 c2 forward")
+        ctx.save_for_backward(weight)
+        ctx.shape = (B, Cin, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (weight,) = ctx.saved_tensors
+        B, Cin, H, W = ctx.shape
+        gx = torch.empty(B, Cin, H, W, dtype=gy.dtype, device=gy.device)
+        L.check(L.lib().ufr_conv3x3_c2_backward_data(L.ptr(gy.contiguous()), L.ptr(weight), L.ptr(gx), B, Cin, H, W,
+                                                     L.stream()), "conv3x3 c2 backward")
+        return gx, None, None
+
+
+class _Deconv4x4C2(torch.autograd.Function):
+    """ConvTranspose2d(2, 2, 4, 2, 1) with frozen parameters (csrc/small_cout.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        B, _, H, W = x.shape
+        y = torch.empty(B, 2, 2 * H, 2 * W, dtype=x.dtype, device=x.device)
+        L.check(L.lib().ufr_deconv4x4s2_c2_forward(L.ptr(x), L.ptr(weight), L.ptr(bias) if bias is not None else None,
+                                                   L.ptr(y), B, H, W, L.stream()), "deconv4x4s2 c2 forward")
+        ctx.save_for_backward(weight)
+        ctx.shape = (B, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (weight,) = ctx.saved_tensors
+        B, H, W = ctx.shape
+        gx = torch.empty(B, 2, H, W, dtype=gy.dtype, device=gy.device)
+        L.check(L.lib().ufr_deconv4x4s2_c2_backward_data(L.ptr(gy.contiguous()), L.ptr(weight), L.ptr(gx), B, H, W,
+                                                         L.stream()), "deconv4x4s2 c2 backward")
+        return gx, None, None
+
+
+def _frozen(mod):
+    return not (mod.weight.requires_grad or (mod.bias is not None and mod.bias.requires_grad))
+
+
+def flow_head(x, conv: torch.nn.Conv2d):
+    """`predict_flow*` (Conv2d(Cin, 2, 3, 1, 1), models/submodules.py:85-86): one pass over x on the device when
+    the parameters are frozen (or autograd is off); the module itself otherwise."""
+    ok = (x.is_cuda and x.dtype == torch.float32 and conv.out_channels == 2 and conv.kernel_size == (3, 3)
+          and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+          and conv.bias is not None and (_frozen(conv) or not torch.is_grad_enabled()))
+    return _Conv3x3C2.apply(x.contiguous(), conv.weight, conv.bias) if ok else conv(x)
+
+
+def flow_upsample(x, deconv: torch.nn.ConvTranspose2d):
+    """`upsampled_flow*_to_*` (ConvTranspose2d(2, 2, 4, 2, 1), models/submodules.py:89-90), same conditions."""
+    ok = (x.is_cuda and x.dtype == torch.float32 and deconv.in_channels == 2 and deconv.out_channels == 2
+          and deconv.kernel_size == (4, 4) and deconv.stride == (2, 2) and deconv.padding == (1, 1)
+          and deconv.output_padding == (0, 0) and deconv.dilation == (1, 1) and deconv.groups == 1
+          and (_frozen(deconv) or not torch.is_grad_enabled()))
+    return _Deconv4x4C2.apply(x.contiguous(), deconv.weight, deconv.bias) if ok else deconv(x)
+
+
 def conv_leaky(x, seq, band: Band | None = None, in_stride: int = 0):
     """The reference's `conv` / `deconv` block (models/submodules.py:18-46, :75-82) = Sequential(Conv2d or
     ConvTranspose2d with bias, LeakyReLU): on a HIP float32 tensor the convolution runs without bias and

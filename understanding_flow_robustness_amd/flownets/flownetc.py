@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..band_conv import conv_leaky, window_correlation
+from ..band_conv import conv_leaky, flow_head, flow_upsample, window_correlation
 from ..cone import ConeSpec
 from ..spatial_correlation_sampler import spatial_correlation_sample
 
@@ -137,15 +137,15 @@ class FlowNetC(nn.Module):
         c5 = self._cl("conv5_1", self._cl("conv5", c4, band, 16))
         c6 = self._cl("conv6_1", self._cl("conv6", c5))
 
-        flow6 = self.predict_flow6(c6)
-        cat5 = torch.cat((c5, self._cl("deconv5", c6), self.upsampled_flow6_to_5(flow6)), 1)
-        flow5 = self.predict_flow5(cat5)
-        cat4 = torch.cat((c4, self._cl("deconv4", cat5), self.upsampled_flow5_to_4(flow5)), 1)
-        flow4 = self.predict_flow4(cat4)
-        cat3 = torch.cat((c3_1, self._cl("deconv3", cat4), self.upsampled_flow4_to_3(flow4)), 1)
-        flow3 = self.predict_flow3(cat3)
-        cat2 = torch.cat((c2a, self._cl("deconv2", cat3), self.upsampled_flow3_to_2(flow3)), 1)
-        flow2 = self.predict_flow2(cat2)
+        flow6 = flow_head(c6, self.predict_flow6)
+        cat5 = torch.cat((c5, self._cl("deconv5", c6), flow_upsample(flow6, self.upsampled_flow6_to_5)), 1)
+        flow5 = flow_head(cat5, self.predict_flow5)
+        cat4 = torch.cat((c4, self._cl("deconv4", cat5), flow_upsample(flow5, self.upsampled_flow5_to_4)), 1)
+        flow4 = flow_head(cat4, self.predict_flow4)
+        cat3 = torch.cat((c3_1, self._cl("deconv3", cat4), flow_upsample(flow4, self.upsampled_flow4_to_3)), 1)
+        flow3 = flow_head(cat3, self.predict_flow3)
+        cat2 = torch.cat((c2a, self._cl("deconv2", cat3), flow_upsample(flow3, self.upsampled_flow3_to_2)), 1)
+        flow2 = flow_head(cat2, self.predict_flow2)
 
         up = lambda f: F.interpolate(f * self.div_flow, scale_factor=4, mode="bilinear", align_corners=False)
         if self.training:
