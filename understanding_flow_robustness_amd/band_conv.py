@@ -167,7 +167,9 @@ def flow_head(x, conv: torch.nn.Conv2d):
     ok = (x.is_cuda and x.dtype == torch.float32 and conv.out_channels == 2 and conv.kernel_size == (3, 3)
           and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
           and conv.bias is not None and (_frozen(conv) or not torch.is_grad_enabled()))
-    return _Conv3x3C2.apply(x.contiguous(), conv.weight, conv.bias) if ok else conv(x)
+    if ok:
+        return _Conv3x3C2.apply(x.contiguous(), conv.weight, conv.bias)
+    return F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
 def flow_upsample(x, deconv: torch.nn.ConvTranspose2d):
@@ -176,7 +178,24 @@ def flow_upsample(x, deconv: torch.nn.ConvTranspose2d):
           and deconv.kernel_size == (4, 4) and deconv.stride == (2, 2) and deconv.padding == (1, 1)
           and deconv.output_padding == (0, 0) and deconv.dilation == (1, 1) and deconv.groups == 1
           and (_frozen(deconv) or not torch.is_grad_enabled()))
-    return _Deconv4x4C2.apply(x.contiguous(), deconv.weight, deconv.bias) if ok else deconv(x)
+    if ok:
+        return _Deconv4x4C2.apply(x.contiguous(), deconv.weight, deconv.bias)
+    return F.conv_transpose2d(x, deconv.weight, deconv.bias, deconv.stride, deconv.padding, deconv.output_padding,
+                              deconv.groups, deconv.dilation)
+
+
+class FlowHead(torch.nn.Conv2d):
+    """`predict_flow*`: a Conv2d (same parameter names, so checkpoints load unchanged) that runs `flow_head`."""
+
+    def forward(self, x):
+        return flow_head(x, self)
+
+
+class FlowUpsample(torch.nn.ConvTranspose2d):
+    """`upsampled_flow*` / PWC-Net's `deconv*`: a ConvTranspose2d that runs `flow_upsample`."""
+
+    def forward(self, x, output_size=None):
+        return flow_upsample(x, self)
 
 
 def conv_leaky(x, seq, band: Band | None = None, in_stride: int = 0):

@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..band_conv import FlowHead, FlowUpsample
 from ..channelnorm_package.channelnorm import ChannelNorm
 from ..resample2d_package.resample2d import Resample2d
 from .flownetc import _RGB_MEAN, _conv, _deconv, correlate
@@ -23,7 +24,7 @@ def _i_conv(cin, cout, k=3, stride=1, bias=True):
 
 
 def _flow(cin):
-    return nn.Conv2d(cin, 2, 3, 1, 1, bias=True)
+    return FlowHead(cin, 2, 3, 1, 1, bias=True)
 
 
 def _xavier(module):
@@ -45,7 +46,7 @@ class _Refinement(nn.Module):
                           ("predict_flow3", 386), ("predict_flow2", 194)):
             setattr(self, name, _flow(cin))
         for name in ("upsampled_flow6_to_5", "upsampled_flow5_to_4", "upsampled_flow4_to_3", "upsampled_flow3_to_2"):
-            setattr(self, name, nn.ConvTranspose2d(2, 2, 4, 2, 1, bias=up_bias))
+            setattr(self, name, FlowUpsample(2, 2, 4, 2, 1, bias=up_bias))
 
     def _refine(self, c6, skips):
         """skips = (conv5, conv4, conv3, conv2) features; returns flow2."""
@@ -134,7 +135,7 @@ class FlowNetSD(nn.Module):
                           ("predict_flow3", 128), ("predict_flow2", 64)):
             setattr(self, name, _flow(cin))
         for name in ("upsampled_flow6_to_5", "upsampled_flow5_to_4", "upsampled_flow4_to_3", "upsampled_flow3_to_2"):
-            setattr(self, name, nn.ConvTranspose2d(2, 2, 4, 2, 1))
+            setattr(self, name, FlowUpsample(2, 2, 4, 2, 1))
         _xavier(self)
 
     def forward(self, x):
@@ -165,8 +166,8 @@ class FlowNetFusion(nn.Module):
         self.deconv1, self.deconv0 = _deconv(128, 32), _deconv(162, 16)
         self.inter_conv1, self.inter_conv0 = _i_conv(162, 32), _i_conv(82, 16)
         self.predict_flow2, self.predict_flow1, self.predict_flow0 = _flow(128), _flow(32), _flow(16)
-        self.upsampled_flow2_to_1 = nn.ConvTranspose2d(2, 2, 4, 2, 1)
-        self.upsampled_flow1_to_0 = nn.ConvTranspose2d(2, 2, 4, 2, 1)
+        self.upsampled_flow2_to_1 = FlowUpsample(2, 2, 4, 2, 1)
+        self.upsampled_flow1_to_0 = FlowUpsample(2, 2, 4, 2, 1)
         _xavier(self)
 
     def forward(self, x):

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..band_conv import conv_leaky, flow_head, flow_upsample, window_correlation
+from ..band_conv import FlowHead, FlowUpsample, conv_leaky, flow_head, flow_upsample, window_correlation
 from ..cone import ConeSpec
 from ..spatial_correlation_sampler import spatial_correlation_sample
 
@@ -71,9 +71,9 @@ class FlowNetC(nn.Module):
         for name, cin, cout in self._DECODER:
             setattr(self, name, _deconv(cin, cout))
         for name, cin in self._HEADS:
-            setattr(self, name, nn.Conv2d(cin, 2, 3, 1, 1, bias=True))
+            setattr(self, name, FlowHead(cin, 2, 3, 1, 1, bias=True))
         for name in self._UPS:
-            setattr(self, name, nn.ConvTranspose2d(2, 2, 4, 2, 1, bias=True))
+            setattr(self, name, FlowUpsample(2, 2, 4, 2, 1, bias=True))
         for m in self.modules():                       # FlowNetC.py:53-63
             if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
                 nn.init.uniform_(m.bias)

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..band_conv import conv_leaky
+from ..band_conv import FlowHead, FlowUpsample, conv_leaky
 from .flownetc import correlate as _correlate
 
 
@@ -61,15 +61,15 @@ class PWCDCNet(nn.Module):
             od = nd if lvl == 6 else nd + feat[lvl] + 4
             for i, (extra, cout) in enumerate(zip((0, dd[0], dd[1], dd[2], dd[3]), (128, 128, 96, 64, 32))):
                 setattr(self, f"conv{lvl}_{i}", _conv(od + extra, cout))
-            setattr(self, f"predict_flow{lvl}", nn.Conv2d(int(od + dd[4]), 2, 3, 1, 1, bias=True))
-            setattr(self, f"deconv{lvl}", nn.ConvTranspose2d(2, 2, 4, 2, 1, bias=True))
+            setattr(self, f"predict_flow{lvl}", FlowHead(int(od + dd[4]), 2, 3, 1, 1, bias=True))
+            setattr(self, f"deconv{lvl}", FlowUpsample(2, 2, 4, 2, 1, bias=True))
             if lvl > 2:
                 setattr(self, f"upfeat{lvl}", nn.ConvTranspose2d(int(od + dd[4]), 2, 4, 2, 1, bias=True))
         od = nd + 32 + 4
         for i, (cin, cout, dil) in enumerate(((od + dd[4], 128, 1), (128, 128, 2), (128, 128, 4), (128, 96, 8),
                                               (96, 64, 16), (64, 32, 1)), start=1):
             setattr(self, f"dc_conv{i}", _conv(cin, cout, 3, 1, dil, dil))
-        self.dc_conv7 = nn.Conv2d(32, 2, 3, 1, 1, bias=True)
+        self.dc_conv7 = FlowHead(32, 2, 3, 1, 1, bias=True)
         for m in self.modules():                                   # PWCNet.py:154-158
             if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
                 nn.init.kaiming_normal_(m.weight.data, mode="fan_in")
