@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib as L
+from ..band_conv import FlowHead as _FlowConv
 from .raft_corr import AlternateCorrBlock, CorrBlock
 
 
@@ -91,7 +92,7 @@ class FlowHead(nn.Module):
     def __init__(self, input_dim=128, hidden_dim=256):
         super().__init__()
         self.conv1 = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
-        self.conv2 = nn.Conv2d(hidden_dim, 2, 3, padding=1)
+        self.conv2 = _FlowConv(hidden_dim, 2, 3, padding=1)      # 2 output channels: single-pass kernel (small_cout.hip)
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
