@@ -176,6 +176,32 @@ def test_windowed_step_equals_full_frame_step_at_bench_size(net):
         assert s_cone.graph is graph_before
 
 
+def test_windowed_step_random_placements(net):
+    """24 seeded random placements (8 pairs x 3 attack() calls of one captured step, private patches) at the
+    benchmark size: window, column band and windowed correlation adjoint against the full-frame step."""
+    B, H, W = 8, 384, 1280
+    g = torch.Generator().manual_seed(1234)
+    yy, xx = torch.meshgrid(torch.arange(51, device=DEV), torch.arange(51, device=DEV), indexing="ij")
+    disc = (((yy - 25) ** 2 + (xx - 25) ** 2) <= 23 ** 2).float()
+    masks = []
+    for _ in range(3):
+        m = torch.zeros(B, 3, H, W, device=DEV)
+        for b in range(B):
+            y = int(torch.randint(0, H - 51 + 1, (1,), generator=g))
+            x = int(torch.randint(0, W - 51 + 1, (1,), generator=g))
+            m[b, :, y:y + 51, x:x + 51] = disc
+        masks.append(m)
+    lr = _unclamped_lr(net, masks[0], B, H, W, False)
+    s_full, p0, full = _run_step(net, False, masks, B, H, W, lr, False, iters=2)
+    s_cone, _, cone = _run_step(net, True, masks, B, H, W, lr, False, iters=2)
+    assert s_cone.cone is not None and s_cone.band is not None and s_cone.band.width > 0
+    for (pf, _, nf, _), (pc, _, nc, _), mask in zip(full, cone, masks):
+        upd = float(((pf - p0) * mask).abs().max())
+        err = float(((pf - pc) * mask).abs().max())
+        assert upd > 1e-3 and err <= 1e-4 * upd + 1e-6, f"windowed vs full {err:.3e} (update {upd:.3e})"
+        assert nf == nc
+
+
 def test_window_grows_when_a_larger_mask_arrives(net):
     """A step sized for a 21-pixel patch receives a 51-pixel one: the device flags the overflow, the host
     re-sizes, re-captures and redoes the call; the result equals the full-frame step."""
