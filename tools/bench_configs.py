@@ -87,6 +87,9 @@ def main():
         elif w == "c3alt":
             r = patch_case("c3 RAFT 384x1280 alt_cuda_corr, 12 GRU iterations, patch attack", "RAFT", 2, 1, 384, 1280,
                            opt.steps, alternate_corr=True)
+        elif w in ("c3b8", "c3altb8"):      # the same RAFT step with 8 pairs behind one patch (batch extension)
+            r = patch_case(f"c3 RAFT 384x1280 {'alt_cuda_corr' if 'alt' in w else 'all-pairs'}, 12 GRU iterations, "
+                           "patch attack, 8 pairs", "RAFT", 2, 8, 384, 1280, opt.steps, alternate_corr="alt" in w)
         elif w == "c4":
             r = patch_case("c4 PWC-Net 384x1280 patch attack", "PWCNet", 1, 8, 384, 1280, opt.steps)
         else:
