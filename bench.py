@@ -40,7 +40,10 @@ GFLOP_CORR = 1.734 + 3.468
 GFLOP_BAND_LAYERS = 16.74 + 4.53 + 9.06 + 2.26     # data gradients of conv3_1, conv4, conv4_1, conv5 (one pair)
 
 
-def gflop_per_pair_step(window_hw, max_count, band_width=None):
+GFLOP_INC_LAYERS = 16.74 + 4.53 + 9.06            # forward of conv3_1, conv4, conv4_1 (one pair)
+
+
+def gflop_per_pair_step(window_hw, max_count, band_width=None, incremental=False):
     """FLOPs the step EXECUTES per pair and iteration.  Full-frame: whole network forward + data gradient.
     Windowed prefix (patch_attack.py): head forward + adjoint at full size, conv1-3 forward + adjoint on
     the window, plus the one full-frame conv1-3 forward per attack() call spread over its iterations;
@@ -52,6 +55,8 @@ def gflop_per_pair_step(window_hw, max_count, band_width=None):
     total = 2 * head + GFLOP_CORR + 2 * GFLOP_PREFIX_FWD * frac + GFLOP_PREFIX_FWD / max_count
     if band_width is not None:
         total -= GFLOP_BAND_LAYERS * (1.0 - band_width / float(W))
+        if incremental:    # conv3_1 / conv4 / conv4_1 forward on the band only, from the 2nd iteration of a call on
+            total -= GFLOP_INC_LAYERS * (1.0 - band_width / float(W)) * (max_count - 1) / max_count
     return total
 
 
@@ -283,7 +288,8 @@ def main():
         value = world * B_PER_GPU * opt.steps / elapsed
         band = getattr(step, "band", None) if step.cone is not None else None
         gflop = gflop_per_pair_step(step.win_hw if step.cone is not None else None, mc,
-                                    band.width if band is not None else None)
+                                    band.width if band is not None and band.width else None,
+                                    bool(band is not None and band.inc_layers))
         tf = gflop * B_PER_GPU / ms                        # per-GPU TFLOP/s (GFLOP/ms), executed work only
         line = {
             "metric": "attack-iters/s", "value": round(value, 3), "unit": "frame-pairs*steps/s",

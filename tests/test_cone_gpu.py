@@ -143,10 +143,53 @@ def _unclamped_lr(net, mask, B, H, W, shared):
     return 0.5 / float(((out[0][0] - p0) * sel).abs().max())
 
 
+def _same_update(pf, pc, p0, sel, what):
+    """Two implementations of the same multi-iteration attack.  From the second iteration on a one-ulp
+    difference (MIOpen's split-K data gradients are not bit-reproducible) can flip a LeakyReLU somewhere and
+    move the gradient entries behind it by a few 1e-4 of the largest update, so: at least 95% of the patch
+    pixels agree to 1e-4 of the update and every pixel to 5e-3 (a misplaced window or band is off by O(1))."""
+    upd = float(((pf - p0) * sel).abs().max())
+    err = ((pf - pc) * sel).abs()
+    assert 1e-3 < upd < 1.9, f"{what}: test lr leaves the update degenerate ({upd})"
+    off = float((err > 1e-4 * upd + 1e-6).sum()) / max(float((sel != 0).sum()), 1.0)
+    assert off <= 0.05 and float(err.max()) <= 5e-3 * upd, \
+        f"{what}: {off:.2%} of the patch pixels differ by more than 1e-4, worst {float(err.max()) / upd:.2e} of the update"
+    return upd
+
+
+def test_incremental_head_forward_equals_full_forward(net):
+    """The deterministic half of the windowed step, checked strictly: after an update of the patch, the flow
+    from the band-only recomputation of conv3_1 / conv4 / conv4_1 (cached activations of the previous
+    iteration elsewhere) equals the flow of the full head forward."""
+    from understanding_flow_robustness_amd.patch_attack import PatchAttackStep
+    B, H, W = 4, 384, 1280
+    args = Namespace(flownet="FlowNetC", l2=False, alpha=0.0, lr=1.0e7, max_count=3)     # saturating step: a large change
+    step = PatchAttackStep(net, args, B, H, W, device=DEV, shared_patch=False, use_graph=False)
+    g = torch.Generator().manual_seed(3)
+    tgt, ref = torch.rand(B, 3, H, W, generator=g).to(DEV), torch.rand(B, 3, H, W, generator=g).to(DEV)
+    patch = torch.rand(B, 3, H, W, generator=g).to(DEV)
+    target = torch.randn(B, 2, H, W, generator=g).to(DEV)
+    mask = torch.zeros(B, 3, H, W, device=DEV)
+    for b, (y, x) in enumerate([(0, 0), (333, 1229), (170, 615), (100, 1100)]):
+        mask[b, :, y:y + 51, x:x + 51] = 1
+    step.load(tgt, ref, patch, mask, patch, target)
+    assert step.band is not None and step.band.inc_layers
+    before = step.adv_tgt.detach().clone()
+    step._iteration()                                        # first iteration: full forward, caches filled, patch updated
+    assert float((step.adv_tgt.detach() - before).abs().max()) > 1e-3, "the update must change the frames"
+    with torch.enable_grad():
+        step.band.incremental = True
+        f_inc = step._forward_cone().detach().clone()
+        step.band.incremental = False
+        f_full = step._forward_cone().detach().clone()
+    scale = float(f_full.abs().max())
+    assert float((f_inc - f_full).abs().max()) <= 1e-5 * scale, float((f_inc - f_full).abs().max()) / scale
+
+
 def test_windowed_step_equals_full_frame_step_at_bench_size(net):
     """384x1280 (BASELINE configs[1] frame size), per-sample placements in the corners, on the edges and in
     the interior, re-placed between attack() calls of ONE captured step: same patch as the full-frame
-    iteration to 1e-4 of the update; the second call grows nothing and re-captures nothing."""
+    iteration (`_same_update`); the second call grows nothing and re-captures nothing."""
     B, H, W = 4, 384, 1280
     def masks_for(places):
         m = torch.zeros(B, 3, H, W, device=DEV)
@@ -167,12 +210,9 @@ def test_windowed_step_equals_full_frame_step_at_bench_size(net):
         graph_before = s_cone.graph
         for (pf, af, nf, lf), (pc, ac, nc, lc), mask in zip(full, cone, (first, second)):
             sel = mask.amax(0, keepdim=True) if shared else mask
-            upd = float(((pf - p0) * sel).abs().max())
-            err = float(((pf - pc) * sel).abs().max())
-            assert 1e-3 < upd < 1.9, f"test lr leaves the update degenerate ({upd})"
-            assert err <= 1e-4 * upd + 1e-6, f"shared={shared}: windowed vs full patch {err:.3e} (update {upd:.3e})"
-            assert nf == nc and abs(lf - lc) <= 1e-5 * max(abs(lf), 1.0)
-            assert float((af - ac).abs().max()) <= 1e-4 * upd + 1e-6
+            upd = _same_update(pf, pc, p0, sel, f"shared={shared}")
+            assert nf == nc and abs(lf - lc) <= 1e-4 * max(abs(lf), 1.0)
+            assert float((af - ac).abs().max()) <= 5e-3 * upd + 1e-6
         assert s_cone.graph is graph_before
 
 
@@ -193,13 +233,19 @@ def test_windowed_step_random_placements(net):
         masks.append(m)
     lr = _unclamped_lr(net, masks[0], B, H, W, False)
     s_full, p0, full = _run_step(net, False, masks, B, H, W, lr, False, iters=2)
-    s_cone, _, cone = _run_step(net, True, masks, B, H, W, lr, False, iters=2)
-    assert s_cone.cone is not None and s_cone.band is not None and s_cone.band.width > 0
-    for (pf, _, nf, _), (pc, _, nc, _), mask in zip(full, cone, masks):
-        upd = float(((pf - p0) * mask).abs().max())
-        err = float(((pf - pc) * mask).abs().max())
-        assert upd > 1e-3 and err <= 1e-4 * upd + 1e-6, f"windowed vs full {err:.3e} (update {upd:.3e})"
-        assert nf == nc
+    for use_graph in (True, False):          # two captured graphs (first / later iterations) and the eager form
+        s_cone, _, cone = _run_step(net, True, masks, B, H, W, lr, False, iters=3 if use_graph else 2, use_graph=use_graph)
+        assert s_cone.cone is not None and s_cone.band is not None and s_cone.band.width > 0
+        assert s_cone.band.inc_layers == ("conv3_1", "conv4", "conv4_1") and set(s_cone.band.caches) == set(s_cone.band.inc_layers)
+        if use_graph:
+            assert s_cone.graph_next is not None and s_cone.graph_next is not s_cone.graph
+            s_ref, _, ref3 = _run_step(net, False, masks, B, H, W, lr, False, iters=3)
+            want = ref3
+        else:
+            want = full
+        for (pf, _, nf, _), (pc, _, nc, _), mask in zip(want, cone, masks):
+            _same_update(pf, pc, p0, mask, f"graph={use_graph}")
+            assert nf == nc
 
 
 def test_window_grows_when_a_larger_mask_arrives(net):
@@ -213,8 +259,8 @@ def test_window_grows_when_a_larger_mask_arrives(net):
     s_cone, _, cone = _run_step(net, True, [small, large], B, H, W, lr, True, iters=2)
     assert s_cone.win_hw is not None and s_cone.win_hw[0] >= 128
     for (pf, _, nf, _), (pc, _, nc, _), mask in zip(full, cone, (small, large)):
-        upd = float(((pf - p0) * mask).abs().max())
-        assert float(((pf - pc) * mask).abs().max()) <= 1e-4 * upd + 1e-6 and nf == nc
+        _same_update(pf, pc, p0, mask, "grown window")
+        assert nf == nc
 
 
 @pytest.mark.parametrize("P,DP,C", [(21, 2, 256), (9, 1, 30)])

@@ -26,6 +26,10 @@ class Band:
         self.win, self.width = win, int(width)
         # the prefix window itself (pixels): the correlation's adjoint is needed on its cells only
         self.cone_win, self.cone_hw = cone_win, cone_hw
+        # incremental forward (second and later iterations of an attack() call): the blocks named in
+        # `inc_layers` recompute the band's columns only and paste them into `caches[name]`, the activations of
+        # the previous iteration; `incremental` is switched by the step between its two captured graphs
+        self.inc_layers, self.incremental, self.caches = (), False, {}
 
 
 class _WindowCorrelation(torch.autograd.Function):
@@ -68,22 +72,64 @@ class _BandConv2d(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         (weight,) = ctx.saved_tensors
-        (B, Cin, Hi, Wi), s, p, band, ls_in = ctx.meta
-        k = weight.shape[-1]
-        ls_out = ls_in * s
-        wib, wob = band.width // ls_in, band.width // ls_out
-        _, Cout, Ho, Wo = gy.shape
+        in_shape, s, p, band, ls_in = ctx.meta
+        return _band_data_gradient(gy, weight, in_shape, s, p, band, ls_in), None, None, None, None, None, None
+
+
+def _band_data_gradient(gy, weight, in_shape, s, p, band, ls_in):
+    """Input gradient of conv2d(weight, stride s, padding p) on the band's columns, zero elsewhere."""
+    B, Cin, Hi, Wi = in_shape
+    k = weight.shape[-1]
+    ls_out = ls_in * s
+    wib, wob = band.width // ls_in, band.width // ls_out
+    _, Cout, Ho, Wo = gy.shape
+    lib, st = L.lib(), L.stream()
+    gy = gy.contiguous()
+    gyb = torch.empty(B, Cout, Ho, wob, dtype=gy.dtype, device=gy.device)
+    L.check(lib.ufr_window_gather(L.ptr(gy), L.ptr(gyb), L.ptr(band.win), B, B, Cout, Ho, Wo, Ho, wob, ls_out, 0, st),
+            "band gather")
+    gxb = torch.ops.aten.convolution_backward(gyb, gyb.new_empty((B, Cin, Hi, wib)), weight, None, (s, s), (p, p),
+                                              (1, 1), False, (0, 0), 1, (True, False, False))[0]
+    gx = torch.zeros(B, Cin, Hi, Wi, dtype=gy.dtype, device=gy.device)
+    L.check(lib.ufr_window_scatter(L.ptr(gxb.contiguous()), L.ptr(gx), L.ptr(band.win), B, B, Cin, Hi, Wi, Hi, wib,
+                                   ls_in, k - 1 - p, st), "band scatter")
+    return gx
+
+
+class _IncrementalConvLeaky(torch.autograd.Function):
+    """A conv + bias + LeakyReLU block whose input differs from the previous iteration's only inside the band:
+    gather the band of x, convolve, apply the epilogue, paste the exact columns into `cache` (the previous
+    iteration's activations, updated in place and returned).  Backward = the banded data gradient."""
+
+    @staticmethod
+    def forward(ctx, x, cache, weight, bias, stride, padding, slope, band, in_stride):
+        B, Cin, Hi, Wi = x.shape
+        s, p, k = int(stride), int(padding), weight.shape[-1]
+        ls_out = in_stride * s
+        wib, wob = band.width // in_stride, band.width // ls_out
+        _, Cout, Ho, Wo = cache.shape
         lib, st = L.lib(), L.stream()
-        gy = gy.contiguous()
-        gyb = torch.empty(B, Cout, Ho, wob, dtype=gy.dtype, device=gy.device)
-        L.check(lib.ufr_window_gather(L.ptr(gy), L.ptr(gyb), L.ptr(band.win), B, B, Cout, Ho, Wo, Ho, wob, ls_out, 0, st),
+        xb = torch.empty(B, Cin, Hi, wib, dtype=x.dtype, device=x.device)
+        L.check(lib.ufr_window_gather(L.ptr(x), L.ptr(xb), L.ptr(band.win), B, B, Cin, Hi, Wi, Hi, wib, in_stride, 0, st),
                 "band gather")
-        gxb = torch.ops.aten.convolution_backward(gyb, gyb.new_empty((B, Cin, Hi, wib)), weight, None, (s, s), (p, p),
-                                                  (1, 1), False, (0, 0), 1, (True, False, False))[0]
-        gx = torch.zeros(B, Cin, Hi, Wi, dtype=gy.dtype, device=gy.device)
-        L.check(lib.ufr_window_scatter(L.ptr(gxb.contiguous()), L.ptr(gx), L.ptr(band.win), B, B, Cin, Hi, Wi, Hi, wib,
-                                       ls_in, k - 1 - p, st), "band scatter")
-        return gx, None, None, None, None, None, None
+        yb = F.conv2d(xb, weight, None, s, p).contiguous()
+        L.check(lib.ufr_bias_leaky_forward(L.ptr(yb), L.ptr(bias), B, Cout, Ho * wob, float(slope), st), "bias leaky")
+        L.check(lib.ufr_window_scatter(L.ptr(yb), L.ptr(cache), L.ptr(band.win), B, B, Cout, Ho, Wo, Ho, wob, ls_out,
+                                       k - 1 - p, st), "band paste")
+        ctx.mark_dirty(cache)
+        ctx.save_for_backward(weight, cache)
+        ctx.meta = ((B, Cin, Hi, Wi), s, p, float(slope), band, int(in_stride))
+        return cache
+
+    @staticmethod
+    def backward(ctx, gy):
+        weight, y = ctx.saved_tensors
+        in_shape, s, p, slope, band, ls_in = ctx.meta
+        gy = gy.contiguous()
+        g_pre = torch.empty_like(gy)
+        L.check(L.lib().ufr_leaky_backward(L.ptr(y), L.ptr(gy), L.ptr(g_pre), gy.numel(), slope, L.stream()),
+                "leaky backward")
+        return _band_data_gradient(g_pre, weight, in_shape, s, p, band, ls_in), None, None, None, None, None, None, None, None
 
 
 class _BiasLeaky(torch.autograd.Function):
@@ -198,16 +244,24 @@ class FlowUpsample(torch.nn.ConvTranspose2d):
         return flow_upsample(x, self)
 
 
-def conv_leaky(x, seq, band: Band | None = None, in_stride: int = 0):
+def conv_leaky(x, seq, band: Band | None = None, in_stride: int = 0, name: str | None = None):
     """The reference's `conv` / `deconv` block (models/submodules.py:18-46, :75-82) = Sequential(Conv2d or
     ConvTranspose2d with bias, LeakyReLU): on a HIP float32 tensor the convolution runs without bias and
-    bias + activation are one in-place pass; with frozen parameters only.  Otherwise the plain modules."""
+    bias + activation are one in-place pass; with frozen parameters only.  Otherwise the plain modules.
+    A block listed in `band.inc_layers` keeps its activations in `band.caches[name]` and, when
+    `band.incremental` is set, recomputes the band's columns only."""
     conv, act = seq[0], seq[1]
     frozen = not (conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad))
     fused = (x.is_cuda and x.dtype == torch.float32 and conv.bias is not None and act.negative_slope > 0
              and (frozen or not torch.is_grad_enabled()))
     if not fused:
         return act(band_conv2d(x, conv, band, in_stride)) if isinstance(conv, torch.nn.Conv2d) else act(conv(x))
+    tracked = (band is not None and band.width and name in band.inc_layers and x.requires_grad
+               and isinstance(conv, torch.nn.Conv2d))
+    if tracked and band.incremental:
+        # a detached alias: the Function marks its cache argument dirty, the stored tensor itself stays a plain buffer
+        return _IncrementalConvLeaky.apply(x.contiguous(), band.caches[name].detach(), conv.weight, conv.bias, conv.stride[0],
+                                           conv.padding[0], act.negative_slope, band, in_stride)
     if isinstance(conv, torch.nn.Conv2d):
         y = band_conv2d(x, conv, band, in_stride, with_bias=False)
     else:
@@ -215,7 +269,14 @@ def conv_leaky(x, seq, band: Band | None = None, in_stride: int = 0):
                                conv.dilation)
     if not y.is_contiguous():
         y = y.contiguous()
-    return _BiasLeaky.apply(y, conv.bias, act.negative_slope)
+    y = _BiasLeaky.apply(y, conv.bias, act.negative_slope)
+    if tracked:                                   # first iteration of a call: remember the activations
+        with torch.no_grad():
+            cache = band.caches.get(name)
+            if cache is None:
+                cache = band.caches[name] = torch.empty_like(y)
+            cache.copy_(y)
+    return y
 
 
 def band_conv2d(x, conv: torch.nn.Conv2d, band: Band | None, in_stride: int, with_bias: bool = True):

@@ -111,7 +111,11 @@ class FlowNetC(nn.Module):
 
     def _cl(self, name, x, band=None, in_stride=0):
         """One `conv` / `deconv` block (convolution + bias + LeakyReLU), fused epilogue on the device."""
-        return conv_leaky(x, getattr(self, name), band, in_stride)
+        return conv_leaky(x, getattr(self, name), band, in_stride, name)
+
+    # blocks whose forward is incremental from the second iteration of an attack() call on: their inputs
+    # change only inside the band (the changed columns of conv4_1's output stay 16 pixels inside it)
+    INCREMENTAL_LAYERS = ("conv3_1", "conv4", "conv4_1")
 
     def forward(self, x1, x2, overwrite_feat_maps=None):
         if overwrite_feat_maps is not None:

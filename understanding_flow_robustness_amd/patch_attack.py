@@ -100,7 +100,8 @@ class PatchAttackStep:
         for p in self.net.parameters():        # data gradient only: skips a third of the reference's FLOPs
             p.requires_grad_(False)
         self.net.eval()
-        self.graph = self.graph_b = None
+        self.graph = self.graph_b = self.graph_next = None
+        self._first = True
         self.use_graph = use_graph
         self._warmup = warmup
         # windowed encoder (cone.py): networks that expose a convolutional prefix as CONE/encode/head
@@ -149,7 +150,7 @@ class PatchAttackStep:
         spec, B, H, W = self.cone, self.B, self.H, self.W
         eh, ew = self._mask_extent()
         wh, ww = spec.window_size(eh, H), spec.window_size(ew, W)
-        self.graph = self.graph_b = None
+        self.graph = self.graph_b = self.graph_next = None
         if self._warmup < 0:
             self._warmup = 1                   # re-capture after the window grew
         if wh * ww * 2 > H * W:
@@ -180,6 +181,8 @@ class PatchAttackStep:
             self._band_reach = reach
             self.band = Band(torch.zeros(B, 8, dtype=torch.int32, device=self.dev), bw, cone_win=self.win,
                              cone_hw=(wh, ww))
+            if bw and os.environ.get("UFR_INCREMENTAL", "1") != "0":
+                self.band.inc_layers = tuple(getattr(self.net, "INCREMENTAL_LAYERS", ()))
 
     def _win_copy(self, fn, src, dst, n, c, hf, wf, ls, margin):
         wh, ww = self.win_hw
@@ -265,11 +268,20 @@ class PatchAttackStep:
         L.check(L.lib().ufr_attack_gate(L.ptr(self.loss_cur), L.ptr(self.state), LOSS_THRESHOLD, L.stream()),
                 "attack gate")
 
+    def _incremental_now(self):
+        """From the second iteration after a load() the head's first blocks recompute the band only."""
+        band = getattr(self, "band", None)
+        return bool(self.cone is not None and band is not None and band.inc_layers and not self._first)
+
     def _iteration(self):
+        inc = self._incremental_now()
         if self.graph is not None:
-            self.graph.replay()
+            (self.graph_next if inc else self.graph).replay()
         else:
+            if getattr(self, "band", None) is not None:
+                self.band.incremental = inc
             self._part_a()
+        self._first = False
         if self.world > 1:
             self.exchange(self.packed)               # RCCL all-reduce of [grad sum | loss], eager, same stream
             if self.graph_b is not None:
@@ -283,15 +295,25 @@ class PatchAttackStep:
         side = torch.cuda.Stream(device=self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(side):
-            for _ in range(max(self._warmup, 1)):
+            for _ in range(max(self._warmup, 2)):      # at least one full and one incremental iteration
                 self._iteration()
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
         if not self.use_graph:
             return
+        band = getattr(self, "band", None) if self.cone is not None else None
+        if band is not None:
+            band.incremental = False
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             self._part_a()
+        self.graph_next = graph
+        if band is not None and band.inc_layers:      # second and later iterations of a call: band-only forward
+            band.incremental = True
+            self.graph_next = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_next):
+                self._part_a()
+            band.incremental = False
         graph_b = None
         if self.world > 1:
             graph_b = torch.cuda.CUDAGraph()
@@ -308,6 +330,7 @@ class PatchAttackStep:
             self.patch.copy_(patch); self.patch_init.copy_(patch_init); self.target.copy_(target)
             self.state.zero_()
             self._paste(do_clamp=False)
+            self._first = True                 # the next iteration sees new frames: full head forward
             if self.cone is not None:
                 self.patch_loaded.copy_(self.patch)
                 if self.win_hw is None:
