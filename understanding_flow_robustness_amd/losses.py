@@ -1,6 +1,8 @@
-"""EPE / cosine-similarity metrics (patch_attacks/losses.py:8-50): bilinear resize of the prediction
-to the ground truth's size, u/v rescale, optional validity mask (3rd GT channel).  Returned as
-Python floats like the reference (one host sync per call)."""
+"""End-point error and cosine similarity against a ground-truth flow (the metrics of
+patch_attacks/losses.py:8-50).  The prediction is brought to the ground truth's size bilinearly and its
+components are rescaled by the size ratio; a third ground-truth channel, when present, is a validity mask
+and the mean runs over valid pixels only.  `*_tensor` keep the result on the device (batched validation
+reads once at the end); `compute_*` return Python floats like the reference."""
 from __future__ import annotations
 
 import torch
@@ -9,32 +11,27 @@ import torch.nn.functional as F
 epsilon = 1e-8
 
 
-def _resize(pred, gt):
+def _at_gt_size(gt, pred):
     return F.interpolate(pred, size=gt.shape[-2:], mode="bilinear", align_corners=False)
 
 
-def epe_tensor(gt, pred):
-    """compute_epe without the host read: a 0-d tensor (batched validation keeps it on the device)."""
-    _, _, h_pred, w_pred = pred.size()
-    bs, nc, h_gt, w_gt = gt.size()
-    pred = _resize(pred, gt)
-    u_pred = pred[:, 0] * (w_gt / w_pred)
-    v_pred = pred[:, 1] * (h_gt / h_pred)
-    epe = torch.sqrt(torch.pow(gt[:, 0] - u_pred, 2) + torch.pow(gt[:, 1] - v_pred, 2))
-    if nc == 3:
+def _mean_over_valid(per_pixel, gt):
+    """Mean of a [B,H,W] map: over the pixels flagged in gt[:, 2] when there is such a channel, else over all."""
+    if gt.shape[1] == 3:
         valid = gt[:, 2]
-        return (epe * valid).sum() / (valid.sum() + epsilon)
-    return epe.sum() / (bs * h_gt * w_gt)
+        return (per_pixel * valid).sum() / (valid.sum() + epsilon)
+    return per_pixel.sum() / (gt.shape[0] * gt.shape[2] * gt.shape[3])
+
+
+def epe_tensor(gt, pred):
+    scale_u, scale_v = gt.shape[3] / pred.shape[3], gt.shape[2] / pred.shape[2]
+    pred = _at_gt_size(gt, pred)
+    du, dv = gt[:, 0] - pred[:, 0] * scale_u, gt[:, 1] - pred[:, 1] * scale_v
+    return _mean_over_valid(torch.sqrt(torch.pow(du, 2) + torch.pow(dv, 2)), gt)
 
 
 def cossim_tensor(gt, pred):
-    bs, nc, h_gt, w_gt = gt.size()
-    pred = _resize(pred, gt)
-    similarity = F.cosine_similarity(gt[:, :2], pred)
-    if nc == 3:
-        valid = gt[:, 2]
-        return (similarity * valid).sum() / (valid.sum() + epsilon)
-    return similarity.sum() / (bs * h_gt * w_gt)
+    return _mean_over_valid(F.cosine_similarity(gt[:, :2], _at_gt_size(gt, pred)), gt)
 
 
 def compute_epe(gt, pred):
@@ -46,5 +43,6 @@ def compute_cossim(gt, pred):
 
 
 def multiscale_cossim(gt, pred):
+    """Negative mean cosine similarity summed over the scales of a flow pyramid."""
     assert len(gt) == len(pred)
     return sum(-F.cosine_similarity(g, p).mean() for g, p in zip(gt, pred))
