@@ -179,6 +179,15 @@ int ufr_gru_blend_forward(const float* q_pre, const float* z, const float* h, fl
 int ufr_gru_blend_backward(const float* q_pre, const float* z, const float* h, const float* g, float* g_qpre,
                            float* g_z, float* g_h, long total, ufr_stream_t stream);
 
+/* ---- RAFT convex upsampling ------------------------------------------------------------------------
+ * replaces RAFT.upsample_flow (models/raft/raft.py:111-122): flow [N,2,H,W], mask [N,576,H,W] (9 x 8 x 8 logits
+ * per coarse pixel) -> up [N,2,8H,8W] = softmax-weighted combination of the 3x3 neighbours of 8*flow.
+ * backward writes grad_flow [N,2,H,W] and grad_mask [N,576,H,W]; workspace: N*2*9*H*W floats. */
+int ufr_convex_upsample_forward(const float* flow, const float* mask, float* up, int N, int H, int W,
+                                ufr_stream_t stream);
+int ufr_convex_upsample_backward(const float* flow, const float* mask, const float* grad_up, float* grad_flow,
+                                 float* grad_mask, float* workspace, int N, int H, int W, ufr_stream_t stream);
+
 /* ---- universal perturbation / I-FGSM inner loop, elementwise stages ------------------------------
  * replaces global_attacks/perturb_model.py:102-145 (compute_flow_loss) and the tensor arithmetic of
  * global_attacks/universal_perturbation.py:477-520 (attack), :667-675 (add_universal_perturbation).

@@ -86,6 +86,31 @@ class BasicEncoder(nn.Module):
         return torch.split(x, [n, n], dim=0) if pair else x
 
 
+class _ConvexUpsample(torch.autograd.Function):
+    """RAFT.upsample_flow as one kernel forward, two backward (csrc/convex_upsample.hip)."""
+
+    @staticmethod
+    def forward(ctx, flow, mask):
+        N, _, H, W = flow.shape
+        if mask.shape != (N, 576, H, W):
+            raise RuntimeError("upsample_flow: mask must be [N, 9*8*8, H, W]")
+        up = torch.empty(N, 2, 8 * H, 8 * W, dtype=flow.dtype, device=flow.device)
+        L.check(L.lib().ufr_convex_upsample_forward(L.ptr(flow), L.ptr(mask), L.ptr(up), N, H, W, L.stream()),
+                "convex upsample forward")
+        ctx.save_for_backward(flow, mask)
+        return up
+
+    @staticmethod
+    def backward(ctx, g_up):
+        flow, mask = ctx.saved_tensors
+        N, _, H, W = flow.shape
+        g_flow, g_mask = torch.empty_like(flow), torch.empty_like(mask)
+        ws = torch.empty(N, 2, 9, H, W, dtype=flow.dtype, device=flow.device)
+        L.check(L.lib().ufr_convex_upsample_backward(L.ptr(flow), L.ptr(mask), L.ptr(g_up.contiguous()), L.ptr(g_flow),
+                                                     L.ptr(g_mask), L.ptr(ws), N, H, W, L.stream()), "convex upsample backward")
+        return g_flow, g_mask
+
+
 class FlowHead(nn.Module):
     """update.py:6-14."""
 
@@ -251,7 +276,9 @@ class RAFT(nn.Module):
     @staticmethod
     def upsample_flow(flow, mask):
         """raft.py:111-122: [N,2,H,W] -> [N,2,8H,8W], softmax-weighted combination of the 3x3 coarse
-        neighbours."""
+        neighbours.  One fused kernel on the device (csrc/convex_upsample.hip); the torch spelling elsewhere."""
+        if flow.is_cuda and flow.dtype == torch.float32 and mask.dtype == torch.float32:
+            return _ConvexUpsample.apply(flow.contiguous(), mask.contiguous())
         N, _, H, W = flow.shape
         mask = torch.softmax(mask.view(N, 1, 9, 8, 8, H, W), dim=2)
         up = F.unfold(8 * flow, [3, 3], padding=1).view(N, 2, 9, 1, 1, H, W)
