@@ -197,6 +197,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-full-frame", action="store_true", help="skip the full-frame side measurement")
     ap.add_argument("--max-count", type=int, default=2, help="iterations per attack() call (main.py:79)")
     opt = ap.parse_args()
 
@@ -314,6 +315,23 @@ def main():
         }
         if world == 1:
             line["roofline"]["kernels"] = kernel_rooflines(device)
+            if step.cone is not None and not opt.no_full_frame:
+                # the same protocol with every frame-sized shortcut off (UFR_CONE=0): what the windowed prefix,
+                # band and incremental forward are worth, measured in this very process
+                ref_step = PatchAttackStep(net, args, B_PER_GPU, H, W, device=device, shared_patch=True,
+                                           use_graph=not opt.no_graph, warmup=2, use_cone=False)
+                ref_step.load(*batches[0])
+                ref_step.run(0)
+                k = 6
+                for c in range(2):
+                    ref_step.load(*batches[c % 2]); ref_step.enqueue(mc)
+                torch.cuda.synchronize(device)
+                t1 = time.perf_counter()
+                done = 0
+                while done < k:
+                    ref_step.load(*batches[(done // mc) % 2]); ref_step.enqueue(min(mc, k - done)); done += mc
+                torch.cuda.synchronize(device)
+                line["config"]["full_frame_attack_iters_per_s"] = round(B_PER_GPU * k / (time.perf_counter() - t1), 2)
             if not opt.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

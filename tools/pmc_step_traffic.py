@@ -1,7 +1,7 @@
 """HBM-side traffic of one attack iteration from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
 
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline
-    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-full-frame
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-full-frame
     python tools/pmc_step_traffic.py /tmp/pf/*/*counter_collection.csv /tmp/pw/*/*counter_collection.csv 4
 
 Sums the counter over the dispatches of the last `iters` iterations (delimited by gate_kernel, the last kernel
@@ -35,7 +35,7 @@ def main(fetch_csv, write_csv, iters):
     w_kb, w_k = per_iteration(write_csv, "WRITE_SIZE", iters)
     fetch_b, write_b = 2.0 * f_kb * 1024.0, w_kb * 1024.0              # FETCH_SIZE doubled on gfx950
     out = {"_provenance": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes with --kernel-trace only, over "
-                          "bench.py --steps 6 --warmup 2 --no-cpu-baseline; mean over the last %d iterations "
+                          "bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-full-frame; mean over the last %d iterations "
                           "(load() of every second iteration included); KB -> bytes, FETCH_SIZE x2 per "
                           "MI355X_MICROARCH.md" % iters,
            "fetch_bytes_per_iteration": round(fetch_b), "write_bytes_per_iteration": round(write_b),

@@ -4,6 +4,7 @@ MIOpen's algorithm search and the eager warm-up dominate a whole-process --stats
 tool keeps only the steady state: the dispatches between the last `iters`+1 occurrences of the
 marker kernel (default gate_kernel, the last kernel of every attack iteration).
     python tools/summarize_trace.py <kernel_trace.csv> <iters> [marker] > profiles/xxx.md
+(trace bench.py with --no-cpu-baseline --no-full-frame so that the last iterations are the windowed step's)
 """
 import csv
 import re
