@@ -244,6 +244,16 @@ class FlowUpsample(torch.nn.ConvTranspose2d):
         return flow_upsample(x, self)
 
 
+def conv_relu(x, conv: torch.nn.Conv2d):
+    """`F.relu(conv(x))` of RAFT's motion encoder and heads (models/raft/update.py): convolution without bias,
+    then bias + ReLU as one in-place pass, under the same conditions as `conv_leaky`."""
+    if (x.is_cuda and x.dtype == torch.float32 and conv.bias is not None
+            and (_frozen(conv) or not torch.is_grad_enabled())):
+        y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        return _BiasLeaky.apply(y.contiguous(), conv.bias, 0.0)
+    return F.relu(conv(x))
+
+
 def conv_leaky(x, seq, band: Band | None = None, in_stride: int = 0, name: str | None = None):
     """The reference's `conv` / `deconv` block (models/submodules.py:18-46, :75-82) = Sequential(Conv2d or
     ConvTranspose2d with bias, LeakyReLU): on a HIP float32 tensor the convolution runs without bias and

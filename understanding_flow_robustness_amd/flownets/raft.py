@@ -16,6 +16,7 @@ import torch.nn.functional as F
 
 from .. import _lib as L
 from ..band_conv import FlowHead as _FlowConv
+from ..band_conv import conv_relu
 from .raft_corr import AlternateCorrBlock, CorrBlock
 
 
@@ -121,7 +122,7 @@ class FlowHead(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        return self.conv2(self.relu(self.conv1(x)))
+        return self.conv2(conv_relu(x, self.conv1))
 
 
 class _GruGates(torch.autograd.Function):
@@ -215,11 +216,11 @@ class BasicMotionEncoder(nn.Module):
         self.conv = nn.Conv2d(64 + 192, 128 - 2, 3, padding=1)
 
     def forward(self, flow, corr):
-        cor = F.relu(self.convc1(corr))
+        cor = conv_relu(corr, self.convc1)
         if not getattr(self.args, "update_no_motion_downsampling", False):
-            cor = F.relu(self.convc2(cor))
-        flo = F.relu(self.convf2(F.relu(self.convf1(flow))))
-        out = F.relu(self.conv(torch.cat([cor, flo], dim=1)))
+            cor = conv_relu(cor, self.convc2)
+        flo = conv_relu(conv_relu(flow, self.convf1), self.convf2)
+        out = conv_relu(torch.cat([cor, flo], dim=1), self.conv)
         return torch.cat([out, flow], dim=1)
 
 
