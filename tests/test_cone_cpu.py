@@ -40,12 +40,18 @@ def test_margins_flownetc():
     assert SPEC.total_stride == 8 and SPEC.level_stride(1) == 4
 
 
+# a second chain (3x3 convolutions, one stride-2 layer, taps after the first and the last layer) checks that nothing is
+# specific to FlowNetC's kernel sizes
+SPEC_B = ConeSpec(layers=((3, 1, 1), (3, 2, 1), (3, 1, 1)), taps=(0, 2), frames=(1, 2))
+
+
+@pytest.mark.parametrize("spec", [SPEC, SPEC_B], ids=["flownetc", "3x3-chain"])
 @pytest.mark.parametrize("ext", [(9, 9), (17, 5), (1, 1)])
-def test_windowed_prefix_equals_full(ext):
+def test_windowed_prefix_equals_full(ext, spec):
     H, W = 128, 160
     eh, ew = ext
-    encode = _prefix(SPEC)
-    wh, ww = SPEC.window_size(eh, H), SPEC.window_size(ew, W)
+    encode = _prefix(spec)
+    wh, ww = spec.window_size(eh, H), spec.window_size(ew, W)
     assert wh < H and ww < W
     ys = sorted({0, 1, 7, 13, 22, H - eh - 9, H - eh - 1, H - eh})
     xs = sorted({0, 3, 8, 31, 40, W - ew - 8, W - ew - 2, W - ew})
@@ -57,15 +63,15 @@ def test_windowed_prefix_equals_full(ext):
         img.requires_grad_(True)
         cached = [f.detach().clone() for f in encode(base)]           # features of the previous iteration
         want = encode(img)
-        assert SPEC.need(y, y + eh - 1, H)[1] * 8 <= wh and SPEC.need(x, x + ew - 1, W)[1] * 8 <= ww
-        oy, ox = SPEC.origin(y, y + eh - 1, H, wh), SPEC.origin(x, x + ew - 1, W, ww)
-        assert oy % 8 == 0 and ox % 8 == 0 and 0 <= oy <= H - wh and 0 <= ox <= W - ww
+        assert spec.need(y, y + eh - 1, H)[1] * spec.total_stride <= wh and spec.need(x, x + ew - 1, W)[1] * spec.total_stride <= ww
+        oy, ox = spec.origin(y, y + eh - 1, H, wh), spec.origin(x, x + ew - 1, W, ww)
+        assert oy % spec.total_stride == 0 and ox % spec.total_stride == 0 and 0 <= oy <= H - wh and 0 <= ox <= W - ww
         xw = img.detach()[:, :, oy:oy + wh, ox:ox + ww].clone().requires_grad_(True)
         got_w = encode(xw)
         g_full = [torch.randn(f.shape, generator=g, dtype=torch.float64) for f in want]
         g_win = []
-        for f_w, f_c, f_want, gf, t, m in zip(got_w, cached, want, g_full, SPEC.taps, SPEC.tap_margins()):
-            ls = SPEC.level_stride(t)
+        for f_w, f_c, f_want, gf, t, m in zip(got_w, cached, want, g_full, spec.taps, spec.tap_margins()):
+            ls = spec.level_stride(t)
             a0, b0 = _rim(H // ls, oy // ls, wh // ls, m)
             a1, b1 = _rim(W // ls, ox // ls, ww // ls, m)
             pasted = f_c.clone()
