@@ -103,3 +103,29 @@ def test_train_sample_device_matches_reference():
     upd = float(np.abs(z["train_patch1"] - z["train_patch0"] * z["train_mask0"]).max())
     err = float(np.abs(p1.cpu().numpy() - z["train_patch1"]).max())
     assert err <= 1e-4 * max(upd, 1.0) + 2e-4 * upd, f"patch err {err:.3e}, update {upd:.3e}"
+
+
+def test_train_sample_device_seeded_prefix_equals_recomputed(monkeypatch):
+    """At 192x320 the attack runs conv1-3 on a window; `train_sample_device` seeds the attack's feature cache
+    with the clean forward's conv1-3 (no second full-frame prefix).  Same result as recomputing it."""
+    from understanding_flow_robustness_amd import utils_patch as up
+    from understanding_flow_robustness_amd.flownets.utils_model import fetch_model
+    from understanding_flow_robustness_amd.patch_attack import _STEP_CACHE_ATTR, train_sample_device
+    args = Namespace(flownet="FlowNetC", l2=False, alpha=0.0, lr=1.0e6, max_count=2, patch_type="circle")
+    net = fetch_model(args, synthetic_seed=0).to(DEV)
+    g = torch.Generator().manual_seed(12)
+    tgt, ref = torch.rand(1, 3, 192, 320, generator=g).to(DEV), torch.rand(1, 3, 192, 320, generator=g).to(DEV)
+    np.random.seed(3)
+    p0, m0, sh0 = up.init_patch_circle(192, 0.13)
+    outs = []
+    for seed_prefix in ("1", "0"):
+        monkeypatch.setenv("UFR_SEED_PREFIX", seed_prefix)
+        np.random.seed(8)
+        p1, m1, i1, sh1 = train_sample_device(net, tgt, ref, ref, _dev64(p0), _dev64(m0), _dev64(p0), sh0, sh0, args)
+        outs.append((p1, m1, tuple(sh1)))
+    steps = [s for s in net.__dict__[_STEP_CACHE_ATTR].values() if (s.H, s.W) == (192, 320)]
+    assert steps and all(s.cone is not None for s in steps), "the windowed path must be the one compared"
+    (pa, ma, sa), (pb, mb, sb) = outs
+    assert sa == sb and torch.equal(ma, mb)
+    differing = float(((pa - pb).abs() > 1e-4 * 4.0).float().mean())         # updates saturate at +-2 per iteration
+    assert differing <= 0.01, f"{differing:.2%} of the patch pixels differ"

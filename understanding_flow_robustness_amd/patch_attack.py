@@ -189,8 +189,12 @@ class PatchAttackStep:
         L.check(fn(L.ptr(src), L.ptr(dst), L.ptr(self.win), self.B, n, c, hf, wf, wh // ls, ww // ls, ls, margin,
                    L.stream()), "window copy")
 
-    def _cone_refresh(self):
-        """New frames / new placement: window origin on the device, full prefix once (no autograd)."""
+    def _cone_refresh(self, prefix_features=None):
+        """New frames / new placement: window origin on the device, full prefix once (no autograd).
+        `prefix_features` = `net.encode(cat(tgt, ref))` of the CLEAN frames, when the caller has just computed
+        the clean forward anyway (train() does, for the target): outside the patch's cone they equal the
+        adversarial frames' features and the first iteration's window pass overwrites the rest, so the
+        full-frame prefix of this call is skipped."""
         lib = L.lib()
         wh, ww = self.win_hw
         L.check(lib.ufr_cone_window(L.ptr(self.mask), self.B, self.CHW, 3, self.H, self.W, C.byref(self._chain),
@@ -199,8 +203,11 @@ class PatchAttackStep:
         if self.band is not None and self.band.width:   # band start: 32-pixel aligned, `reach` left of the window, inside the frame
             start = torch.div(self.win[:, 1] - self._band_reach, 32, rounding_mode="floor") * 32
             self.band.win[:, 1] = start.clamp(0, self.W - self.band.width)
-        feats = self.net.encode(torch.cat((self.adv_tgt.detach(), self.adv_ref.detach()), 0))
+        feats = prefix_features if prefix_features is not None else \
+            self.net.encode(torch.cat((self.adv_tgt.detach(), self.adv_ref.detach()), 0))
         for (ls, m, n, full, _), f in zip(self.taps, feats):
+            if f.shape[0] < n or f.shape[1:] != full.shape[1:]:
+                raise ValueError("prefix_features do not match this step's frames")
             full.detach().copy_(f[:n])
 
     def _forward_cone(self):
@@ -322,9 +329,10 @@ class PatchAttackStep:
         self.graph, self.graph_b = graph, graph_b
 
     # ------------------------------------------------------------------------------------ public API
-    def load(self, tgt, ref, patch, mask, patch_init, target):
+    def load(self, tgt, ref, patch, mask, patch_init, target, prefix_features=None):
         """Copy one attack() call's operands into the static buffers and do the first, un-clamped
-        paste (main.py:537-542).  Must be called after capture (warm-up iterations move the patch)."""
+        paste (main.py:537-542).  Must be called after capture (warm-up iterations move the patch).
+        `prefix_features`: see `_cone_refresh` (ignored by the full-frame iteration)."""
         with torch.no_grad():
             self.tgt.copy_(tgt); self.ref.copy_(ref); self.mask.copy_(mask.expand_as(self.mask))
             self.patch.copy_(patch); self.patch_init.copy_(patch_init); self.target.copy_(target)
@@ -336,7 +344,7 @@ class PatchAttackStep:
                 if self.win_hw is None:
                     self._setup_cone()
                 if self.cone is not None:
-                    self._cone_refresh()
+                    self._cone_refresh(prefix_features)
 
     def run(self, max_count):
         """Enqueue up to `max_count` iterations back to back; returns (executed, last_loss) after ONE
@@ -375,7 +383,8 @@ _STEP_CACHE_ATTR = "_ufr_patch_steps"
 
 
 def attack(flow_net, tgt_img_var, ref_past_img_var, ref_future_img_var, patch_var, mask_var,
-           patch_init_var, target_var, logger=None, args: Namespace | None = None, use_graph=True):
+           patch_init_var, target_var, logger=None, args: Namespace | None = None, use_graph=True,
+           prefix_features=None):
     """Drop-in for patch_attacks/main.py::attack (:523-613): same positional arguments and return
     tuple `(adv_tgt, None, adv_ref_future, patch_var)`; `patch_var` is updated IN PLACE (:581).
     The reference reads the module-global `args`; pass it as `args=` (fields flownet, lr, alpha, l2,
@@ -392,7 +401,8 @@ def attack(flow_net, tgt_img_var, ref_past_img_var, ref_future_img_var, patch_va
     if step is None:
         step = cache[key] = PatchAttackStep(flow_net, args, B, H, W, device=tgt_img_var.device,
                                             shared_patch=shared, use_graph=use_graph)
-    step.load(tgt_img_var, ref_future_img_var, patch_var, mask_var, patch_init_var, target_var)
+    step.load(tgt_img_var, ref_future_img_var, patch_var, mask_var, patch_init_var, target_var,
+              prefix_features=prefix_features)
     step.run(getattr(args, "max_count", 2))
     with torch.no_grad():
         patch_var.copy_(step.patch)
@@ -432,14 +442,23 @@ def train_sample_device(flow_net, tgt_img, ref_past_img, ref_future_img, patch, 
     drawing the reference's `np.random` numbers.  Returns (patch, mask, patch_init, patch_shape) as HIP tensors."""
     from .patch_transform import circle_transform_device, crop_and_restore_device
     with torch.no_grad():
-        flow_pred = predict_flow(flow_net, ref_past_img, tgt_img, ref_future_img, args)
+        prefix = None
+        if (getattr(flow_net, "CONE", None) is not None and not flow_net.training
+                and os.environ.get("UFR_SEED_PREFIX", "1") != "0"):
+            # the clean forward in two halves: its conv1-3 features seed the attack's cache (no second
+            # full-frame prefix in load()); same operations as flow_net(tgt, ref)
+            B = tgt_img.shape[0]
+            prefix = flow_net.encode(torch.cat((tgt_img, ref_future_img), 0))
+            flow_pred = flow_net.head(*[f[:B] for f in prefix[:-1]], prefix[-1][:B], prefix[-1][B:])
+        else:
+            flow_pred = predict_flow(flow_net, ref_past_img, tgt_img, ref_future_img, args)
         if getattr(args, "patch_type", "circle") != "circle":
             raise NotImplementedError("only --patch_type circle (the README's configuration) is mirrored")
         patch_t, mask_t, init_t, rx, ry, patch_shape = circle_transform_device(
             patch, mask, patch_init, tuple(tgt_img.shape), patch_shape, True)     # margin=1, main.py:377
     target = -flow_pred.detach()
     _, _, _, patch_t = attack(flow_net, tgt_img, ref_past_img, ref_future_img, patch_t, mask_t, init_t, target,
-                              None, args=args, use_graph=use_graph)
+                              None, args=args, use_graph=use_graph, prefix_features=prefix)
     with torch.no_grad():
         return crop_and_restore_device(patch_t, mask_t, init_t, rx, ry, patch_shape, patch_shape_orig)
 
