@@ -289,3 +289,39 @@ def test_corr_backward_window_equals_full_adjoint_on_the_window(P, DP, C):
         scale = float(want.abs().max())
         err = float(((got - want) * inside).abs().max())
         assert err <= 1e-5 * scale, f"{name}: {err:.3e} of {scale:.3e}"
+
+
+def test_pwc_windowed_pyramid_prefix_equals_full_frame_step():
+    """PWC-Net: pyramid levels 1-2 on a 120x120 window per pair (cone.py) against the full-frame iteration at
+    384x1280: strictly after one iteration (same state, gradients differ by rounding only), robustly after two."""
+    from understanding_flow_robustness_amd.flownets.utils_model import fetch_model
+    from understanding_flow_robustness_amd.patch_attack import PatchAttackStep
+    B, H, W = 2, 384, 1280
+    net = fetch_model(Namespace(flownet="PWCNet"), synthetic_seed=1).to(DEV)
+    g = torch.Generator().manual_seed(21)
+    tgt, ref = torch.rand(B, 3, H, W, generator=g).to(DEV), torch.rand(B, 3, H, W, generator=g).to(DEV)
+    patch = torch.rand(B, 3, H, W, generator=g).to(DEV)
+    target = torch.randn(B, 2, H, W, generator=g).to(DEV)
+    mask = torch.zeros(B, 3, H, W, device=DEV)
+    for b, (y, x) in enumerate([(0, 1229), (170, 600)]):
+        mask[b, :, y:y + 51, x:x + 51] = 1
+
+    def run(use_cone, lr, iters):
+        args = Namespace(flownet="PWCNet", l2=False, alpha=0.0, lr=lr, max_count=iters)
+        step = PatchAttackStep(net, args, B, H, W, device=DEV, shared_patch=False, use_cone=use_cone, use_graph=False)
+        step.load(tgt, ref, patch, mask, patch, target)
+        n, _ = step.run(iters)
+        return step, step.patch.clone(), n
+    _, probe, _ = run(False, 1.0, 1)
+    lr = 0.5 / float(((probe - patch) * mask).abs().max())
+    for iters in (1, 2):
+        s_full, pf, nf = run(False, lr, iters)
+        s_cone, pc, nc = run(True, lr, iters)
+        assert s_full.cone is None and s_cone.cone is not None and s_cone.win_hw == (120, 120)
+        assert nf == nc == iters
+        if iters == 1:
+            upd = float(((pf - patch) * mask).abs().max())
+            err = float(((pf - pc) * mask).abs().max())
+            assert err <= 1e-4 * upd + 1e-6, f"one iteration: {err:.3e} of {upd:.3e}"
+        else:
+            _same_update(pf, pc, patch, mask, "PWC-Net, two iterations")

@@ -14,6 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..band_conv import FlowHead, FlowUpsample, conv_leaky
+from ..cone import ConeSpec
 from .flownetc import correlate as _correlate
 
 
@@ -85,13 +86,34 @@ class PWCDCNet(nn.Module):
             x = torch.cat((self._cl(f"conv{lvl}_{i}", x), x), 1)
         return x, getattr(self, f"predict_flow{lvl}")(x)
 
-    def forward(self, im1, im2):
-        B = im1.shape[0]
-        x = torch.cat((im1, im2), 0).flip(1)                       # RGB -> BGR (PWCNet.py:230-231)
-        feats = []
-        for _, _, first, second, third in self._PYRAMID:
+    # pyramid levels 1-2 are a purely convolutional prefix at 1/2 and 1/4 resolution (16 / 32 channels: few FLOPs,
+    # 6 GB of activation traffic per iteration at batch 8): the patch attack runs them on a window (cone.py).
+    # One tap: the level-2 features of both frames; level 1 feeds nothing else.
+    CONE = ConeSpec(layers=((3, 2, 1), (3, 1, 1), (3, 1, 1), (3, 2, 1), (3, 1, 1), (3, 1, 1)), taps=(5,), frames=(2,))
+
+    def encode(self, x):
+        """Levels 1-2 of the feature pyramid on a stack of raw frames [N,3,h,w] -> [level-2 features]."""
+        x = x.flip(1)                                              # RGB -> BGR (PWCNet.py:230-231)
+        for _, _, first, second, third in self._PYRAMID[:2]:
+            x = self._cl("conv" + third, self._cl("conv" + second, self._cl("conv" + first, x)))
+        return [x]
+
+    def head(self, f2a, f2b):
+        """Pyramid levels 3-6, the coarse-to-fine decoder and the context network."""
+        B = f2a.shape[0]
+        x = torch.cat((f2a, f2b), 0)
+        feats = [None, x]
+        for _, _, first, second, third in self._PYRAMID[2:]:
             x = self._cl("conv" + third, self._cl("conv" + second, self._cl("conv" + first, x)))
             feats.append(x)
+        return self._decoder(feats, B)
+
+    def forward(self, im1, im2):
+        B = im1.shape[0]
+        (f2,) = self.encode(torch.cat((im1, im2), 0))
+        return self.head(f2[:B], f2[B:])
+
+    def _decoder(self, feats, B):
         c1 = {lvl: feats[lvl - 1][:B] for lvl in range(2, 7)}
         c2 = {lvl: feats[lvl - 1][B:] for lvl in range(2, 7)}
 
