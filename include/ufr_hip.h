@@ -179,6 +179,16 @@ int ufr_gru_blend_forward(const float* q_pre, const float* z, const float* h, fl
 int ufr_gru_blend_backward(const float* q_pre, const float* z, const float* h, const float* g, float* g_qpre,
                            float* g_z, float* g_h, long total, ufr_stream_t stream);
 
+/* ---- PWC-Net backward warp ----------------------------------------------------------------------
+ * replaces PWCDCNet.warp (models/PWCNet.py:164-204): grid from the flow (normalised with W-1, sampled with
+ * align_corners=False, as the reference does), bilinear grid_sample with zero padding, times the validity mask
+ * `grid_sample(ones) >= 0.0001`.  x [B,C,H,W], flow [B,2,H,W]; backward writes grad_x (zero-filled, then
+ * scattered) and grad_flow. */
+int ufr_pwc_warp_forward(const float* x, const float* flow, float* out, int B, int C, int H, int W,
+                         ufr_stream_t stream);
+int ufr_pwc_warp_backward(const float* x, const float* flow, const float* grad_out, float* grad_x, float* grad_flow,
+                          int B, int C, int H, int W, ufr_stream_t stream);
+
 /* ---- RAFT convex upsampling ------------------------------------------------------------------------
  * replaces RAFT.upsample_flow (models/raft/raft.py:111-122): flow [N,2,H,W], mask [N,576,H,W] (9 x 8 x 8 logits
  * per coarse pixel) -> up [N,2,8H,8W] = softmax-weighted combination of the 3x3 neighbours of 8*flow.

@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import _lib as L
 from ..band_conv import FlowHead, FlowUpsample, conv_leaky
 from ..cone import ConeSpec
 from .flownetc import correlate as _correlate
@@ -28,9 +29,37 @@ def correlate(input1, input2):
     return _correlate(input1, input2, patch_size=9, dilation_patch=1)
 
 
+class _PwcWarp(torch.autograd.Function):
+    """`warp` as one kernel forward, one backward (csrc/pwc_warp.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, flo):
+        B, Cn, H, W = x.shape
+        out = torch.empty_like(x)
+        L.check(L.lib().ufr_pwc_warp_forward(L.ptr(x), L.ptr(flo), L.ptr(out), B, Cn, H, W, L.stream()), "pwc warp forward")
+        ctx.save_for_backward(x, flo)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, flo = ctx.saved_tensors
+        B, Cn, H, W = x.shape
+        gx, gf = torch.empty_like(x), torch.empty_like(flo)
+        L.check(L.lib().ufr_pwc_warp_backward(L.ptr(x), L.ptr(flo), L.ptr(g.contiguous()), L.ptr(gx), L.ptr(gf), B, Cn, H, W,
+                                              L.stream()), "pwc warp backward")
+        return gx, gf
+
+
 def warp(x, flo):
     """PWCNet.py:164-204: bilinear backward warp (grid_sample, default align_corners=False, grid
-    normalised with (W-1)) times the validity mask `warp(ones) >= 0.0001`."""
+    normalised with (W-1)) times the validity mask `warp(ones) >= 0.0001`.  Fused kernel on the device."""
+    if x.is_cuda and x.dtype == torch.float32 and flo.dtype == torch.float32:
+        return _PwcWarp.apply(x.contiguous(), flo.contiguous())
+    return _warp_torch(x, flo)
+
+
+def _warp_torch(x, flo):
+    """The reference's spelling (also the checker of tests/test_pwc_warp_gpu.py)."""
     B, _, H, W = x.shape
     xx = torch.arange(W, device=x.device, dtype=x.dtype).view(1, 1, 1, W)
     yy = torch.arange(H, device=x.device, dtype=x.dtype).view(1, 1, H, 1)
