@@ -360,3 +360,26 @@ def gen_input_pipeline():
 
 
 GENERATORS["input_pipeline"] = gen_input_pipeline
+
+
+def gen_perturb_noise():
+    """global_attacks/perturb_model.py::PerturbationsModel.forward with `perturb_method="uniform"` (:332-382) under
+    a fixed `np.random` seed, all three perturb modes.  ("gaussian" goes through skimage, absent here.)"""
+    import numpy as np
+    pm = rh.ref_module("global_attacks.perturb_model")
+    g = torch.Generator().manual_seed(5)
+    i0, i1 = torch.rand(1, 3, 8, 12, generator=g), torch.rand(1, 3, 8, 12, generator=g)
+    out = dict(img0=i0, img1=i1, seed=torch.tensor(17))
+    for mode in ("both", "left", "right"):
+        model = pm.PerturbationsModel(perturb_method="uniform", perturb_mode=mode, output_norm=0.05, n_step=1,
+                                      learning_rate=0.01, momentum=0.47, probability_diverse_input=0.0,
+                                      device=torch.device("cpu"), disparity=False, targeted=False, print_out=False,
+                                      args=Namespace(flownet="FlowNetC", flow_loss="l2"))
+        np.random.seed(17)
+        n0, n1, a0, a1 = model.forward(None, i0.clone(), i1.clone(), None)
+        out[f"{mode}_noise0"], out[f"{mode}_noise1"], out[f"{mode}_adv0"], out[f"{mode}_adv1"] = n0, n1, a0, a1
+        out[f"{mode}_next_draw"] = torch.tensor(np.random.uniform())          # the stream position afterwards
+    save("perturb_noise_uniform", **out)
+
+
+GENERATORS["perturb_noise"] = gen_perturb_noise

@@ -66,3 +66,34 @@ def test_adversarial_training_batch_composes_the_pinned_pieces():
     loss = net(b1, b2)
     (loss[0] if isinstance(loss, tuple) else loss).mean().backward()             # the fine-tuning step still differentiates
     assert net.conv1[0].weight.grad is not None
+
+
+@pytest.mark.parametrize("mode", ["both", "left", "right"])
+def test_uniform_noise_follows_the_reference_np_random_stream(mode):
+    """perturb_model.py:332-382: two host draws whatever the mode; bit-exact under the same seed."""
+    import numpy as np
+    from understanding_flow_robustness_amd.perturb_model import PerturbationsModel
+    z = load_golden("perturb_noise_uniform")
+    pm = PerturbationsModel(perturb_method="uniform", perturb_mode=mode, output_norm=0.05,
+                            args=Namespace(flownet="FlowNetC", flow_loss="l2"))
+    np.random.seed(int(z["seed"]))
+    n0, n1, a0, a1 = pm.forward(None, t(z["img0"], DEV), t(z["img1"], DEV), None)
+    assert np.float32(np.random.uniform()) == np.float32(z[f"{mode}_next_draw"]), "np.random consumed differently"
+    for got, key in ((n0, "noise0"), (n1, "noise1"), (a0, "adv0"), (a1, "adv1")):
+        assert np.array_equal(got.cpu().numpy(), z[f"{mode}_{key}"]), key
+
+
+def test_gaussian_noise_statistics_and_clipping():
+    """perturb_model.py:274-330 (skimage random_noise restated): sigma = eps/4, result clipped to [0,1]."""
+    import numpy as np
+    from understanding_flow_robustness_amd.perturb_model import PerturbationsModel
+    pm = PerturbationsModel(perturb_method="gaussian", perturb_mode="left", output_norm=0.08,
+                            args=Namespace(flownet="FlowNetC", flow_loss="l2"))
+    img = torch.full((1, 3, 64, 96), 0.5, device=DEV)
+    np.random.seed(3)
+    n0, n1, a0, a1 = pm.forward(None, img, img.clone(), None)
+    assert float(n1.abs().max()) == 0.0 and torch.equal(a1, img)
+    assert abs(float(n0.std()) - 0.02) < 1e-3 and abs(float(n0.mean())) < 1e-3
+    edge = torch.zeros(1, 3, 64, 96, device=DEV)
+    _, _, a0, _ = pm.forward(None, edge, edge.clone(), None)
+    assert float(a0.min()) == 0.0 and float(a0.max()) > 0.0

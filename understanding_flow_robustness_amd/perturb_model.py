@@ -4,14 +4,16 @@
 
 The iterative methods reuse the fused universal-perturbation step (universal_perturbation.py): the
 reference's I-FGSM is the same arithmetic with gradient ASCENT (`image + lr*sign(grad)`, :557-571),
-descent when `targeted`.  Noise / image-corruption methods (gaussian, uniform, imagecorruptions) are CPU
-image-library code and out of the hot path's scope.
+descent when `targeted`.  The two noise methods (uniform :332-382, gaussian :274-330) draw on the host like
+the reference and upload once; `imagecorruptions` methods are CPU image-library code and out of the hot
+path's scope.
 """
 from __future__ import annotations
 
 import random
 from argparse import Namespace
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -179,6 +181,26 @@ class PerturbationsModel:
                                                  frames, 1, 0, 0, L.stream()), "iterative update")
         return delta[:, 0].clone(), delta[:, 1].clone()
 
+    def _uniform(self, image0, image1):
+        """:332-382: two `np.random.uniform` draws (left frame first) whatever the mode, float64 -> float32."""
+        draws = [np.random.uniform(size=tuple(im.shape), low=-self.eps, high=self.eps) for im in (image0, image1)]
+        n0, n1 = (torch.from_numpy(d).float().to(image0.device) for d in draws)
+        return self._mode_mask(n0, n1)
+
+    def _gaussian(self, image0, image1):
+        """:274-330 through `skimage.util.random_noise(mode="gaussian", var=(eps/4)^2)`, restated (skimage is not
+        in this image): image + N(0, var) in float64, clipped to [0,1] ([-1,1] for an image with negative values),
+        cast to float32; the noise is the difference to the input.  skimage >= 0.19 draws from an unseeded
+        `default_rng()`, so no stream is reproducible; this one follows the `np.random` global state."""
+        sigma = self.eps / 4.0
+        out = []
+        for im in (image0, image1):
+            x = im.detach().cpu().numpy()
+            low = -1.0 if x.min() < 0 else 0.0
+            noisy = np.clip(x + np.random.normal(0.0, sigma, x.shape), low, 1.0)
+            out.append(torch.from_numpy(noisy).float().to(im.device) - im)
+        return self._mode_mask(*out)
+
     # ------------------------------------------------------------------------------------------ API
     def forward(self, model, image0, image1, ground_truth):
         """perturb_model.py:211-272."""
@@ -189,10 +211,14 @@ class PerturbationsModel:
             noise0, noise1 = self._ifgsm(model, image0, image1, ground_truth)
         elif self.method in ("mifgsm", "mifgm"):
             noise0, noise1 = self._iterative_eager(model, image0, image1, ground_truth, momentum=True)
+        elif self.method == "gaussian":
+            noise0, noise1 = self._gaussian(image0, image1)
+        elif self.method == "uniform":
+            noise0, noise1 = self._uniform(image0, image1)
         elif self.method == "none":
             noise0, noise1 = torch.zeros_like(image0), torch.zeros_like(image1)
         else:
-            raise NotImplementedError(f"perturbation method {self.method!r} (noise / image corruptions) is out of scope")
+            raise NotImplementedError(f"perturbation method {self.method!r} (imagecorruptions) is out of scope")
         image0_output = torch.clamp(image0 + noise0, 0.0, 1.0)
         image1_output = torch.clamp(image1 + noise1, 0.0, 1.0)
         return image0_output - image0, image1_output - image1, image0_output, image1_output
