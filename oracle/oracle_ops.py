@@ -33,7 +33,7 @@ def build(ref: bool = True) -> None:
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "libufr_oracle.so")
+        path = os.environ.get("UFR_ORACLE_LIB") or os.path.join(_HERE, "libufr_oracle.so")   # `make sanitize`
         if not os.path.exists(path):
             build(ref=False)
         _LIB = C.CDLL(path)
