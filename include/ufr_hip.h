@@ -189,6 +189,16 @@ int ufr_pwc_warp_forward(const float* x, const float* flow, float* out, int B, i
 int ufr_pwc_warp_backward(const float* x, const float* flow, const float* grad_out, float* grad_x, float* grad_flow,
                           int B, int C, int H, int W, ufr_stream_t stream);
 
+/* ---- float32-accurate GEMM on the bf16 matrix cores (building block, not yet on the product path) ------
+ * The convolutions of models/FlowNetC.py:22-50 etc. reach the GPU through MIOpen's fp32 kernels; DESIGN.md 10
+ * plans their replacement by implicit GEMMs of this kind.  ufr_split_bf16x3: x[n] -> planes[3][n] bf16 with
+ * x = p0 + p1 + p2 exactly.  ufr_gemm_split_nt: C[M,N] (fp32) = A[M,K] * B[N,K]^T from pre-split planes
+ * ([3][M*K] and [3][N*K] bf16); `products` 6 (float32-accurate), 3 or 1 leading-order bf16 products, fp32
+ * accumulation.  M, N multiples of 128, K of 32. */
+int ufr_split_bf16x3(const float* x, void* planes, long n, ufr_stream_t stream);
+int ufr_gemm_split_nt(const void* a_planes, const void* b_planes, float* c, int M, int N, int K, int products,
+                      ufr_stream_t stream);
+
 /* ---- RAFT convex upsampling ------------------------------------------------------------------------
  * replaces RAFT.upsample_flow (models/raft/raft.py:111-122): flow [N,2,H,W], mask [N,576,H,W] (9 x 8 x 8 logits
  * per coarse pixel) -> up [N,2,8H,8W] = softmax-weighted combination of the 3x3 neighbours of 8*flow.

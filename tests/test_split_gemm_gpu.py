@@ -1,0 +1,52 @@
+"""GPU test of the split-precision GEMM (csrc/split_gemm.hip): a float32 product computed as six bf16 MFMA
+products must be as close to float64 as a plain float32 GEMM is.  Tolerances from tools/probe_split_precision.py."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_split_is_exact():
+    from understanding_flow_robustness_amd.split_gemm import split_bf16x3
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(3, 1000, generator=g) * torch.logspace(-6, 6, 1000)).to(DEV)
+    p = split_bf16x3(x)
+    assert p.shape == (3, 3, 1000) and p.dtype == torch.bfloat16
+    assert torch.equal(p[0].float() + p[1].float() + p[2].float(), x)
+    assert torch.equal(p[0], x.bfloat16())
+
+
+def test_identity_times_asymmetric_matrix():
+    """A = I with an asymmetric B: catches a transposed accumulator layout or a swapped fragment map."""
+    from understanding_flow_robustness_amd.split_gemm import gemm_split_nt, split_bf16x3
+    M = N = K = 256
+    a = torch.eye(M, K, device=DEV)
+    b = (torch.arange(N, device=DEV)[:, None] * 1000.0 + torch.arange(K, device=DEV)[None, :]).float() / 7.0
+    c = gemm_split_nt(split_bf16x3(a), split_bf16x3(b), 6)
+    assert torch.equal(c, b.t().contiguous())          # C = I * B^T, every entry a single exact product sum
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 384, 4256), (384, 128, 608)])
+def test_matches_float64(M, N, K):
+    from understanding_flow_robustness_amd.split_gemm import gemm_split_nt, split_bf16x3
+    g = torch.Generator().manual_seed(M + N + K)
+    a, b = torch.randn(M, K, generator=g), 0.02 * torch.randn(N, K, generator=g)
+    ref = a.double() @ b.double().t()
+    scale = float(ref.abs().max())
+    ap, bp = split_bf16x3(a.to(DEV)), split_bf16x3(b.to(DEV))
+    # the MFMA's internal 32-term sums are not IEEE-rounded: 1.8e-6 measured at K = 4256 (plain fp32: 4e-7)
+    for products, tol in ((6, 4e-6), (3, 3e-5), (1, 1e-2)):
+        c = gemm_split_nt(ap, bp, products).cpu().double()
+        err = float((c - ref).abs().max()) / scale
+        assert err <= tol, f"{products} products: {err:.3e}"
+    fp32 = float(((a @ b.t()).double() - ref).abs().max()) / scale
+    six = float((gemm_split_nt(ap, bp, 6).cpu().double() - ref).abs().max()) / scale
+    assert six <= 10.0 * fp32 + 1e-7, f"six products {six:.3e} vs plain float32 {fp32:.3e}"
+
+
+def test_shape_errors():
+    from understanding_flow_robustness_amd.split_gemm import gemm_split_nt, split_bf16x3
+    a = split_bf16x3(torch.randn(100, 32, device=DEV))
+    with pytest.raises(RuntimeError, match="multiples of 128"):
+        gemm_split_nt(a, a, 6)

@@ -87,6 +87,8 @@ SIGNATURES = {
     "ufr_deconv4x4s2_c2_backward_data": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "ufr_pwc_warp_forward": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_pwc_warp_backward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ufr_split_bf16x3": [_vp, _vp, _l, _vp],
+    "ufr_gemm_split_nt": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_convex_upsample_forward": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "ufr_convex_upsample_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ufr_affine_resample_f64": [_vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _d, _d, _d, _i, _vp],

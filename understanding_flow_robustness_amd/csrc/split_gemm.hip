@@ -1,0 +1,144 @@
+// split_gemm.hip -- float32-accurate matrix product on the bf16 matrix cores (the round-2 lever).
+//
+// Not on the product path yet: this is the measured building block for replacing MIOpen's fp32 convolutions
+// (which top out at the 157 TFLOP/s fp32 peak) by implicit GEMMs on the 2.5 PFLOP/s bf16 MFMA pipe.
+//
+//   a = a1 + a2 + a3 exactly, each piece a bf16 (8 significant bits each, 24 together = a float32 significand)
+//   a*b ~= a1b1 + (a1b2 + a2b1) + (a2b2 + a1b3 + a3b1)          six bf16 products, float32 accumulation
+//
+// tools/probe_split_precision.py (CPU): the six-product sum is as close to the float64 result as a plain fp32
+// GEMM is (2.6e-7 vs 3.8e-7 of max |out| at K = 4257); three products give 5e-6, one product 2.7e-3.
+//
+// ufr_split_bf16x3: x[n] -> planes[3][n] bf16 (round-to-nearest-even, residuals exact in float32).
+// ufr_gemm_split_nt: C[M,N] = A[M,K] * B[N,K]^T from pre-split planes.  128x128x32 tile, 4 waves as 2x2, each
+// wave a 64x64 block of 4x4 `v_mfma_f32_16x16x32_bf16` accumulators.  One LDS image per (operand, plane):
+// [128 rows][32 k] bf16 = 64 B per row, the 16-byte k-chunk XOR-swizzled with (row >> 1) & 3, which makes
+// every ds_read_b128 lane group of a fragment read hit 16 distinct bank quads (MI355X_MICROARCH.md, LDS
+// table).  The next K-tile's global loads are issued before the MFMA block and land in registers while it
+// runs.  Per wave and K-tile: 96 MFMAs (1536 cycles) against 24 ds_read_b128 + 12 global loads.
+#include "ufr_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+__global__ void split3_kernel(const float* __restrict__ x, __bf16* __restrict__ planes, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    const __bf16 p1 = (__bf16)v;
+    const float r1 = v - (float)p1;
+    const __bf16 p2 = (__bf16)r1;
+    const float r2 = r1 - (float)p2;
+    planes[i] = p1;
+    planes[n + i] = p2;
+    planes[2 * n + i] = (__bf16)r2;
+  }
+}
+
+constexpr int BM = 128, BN = 128, BK = 32;
+
+// (a plane, b plane) of each product, smallest magnitude first
+__device__ constexpr int PROD_A[6] = {2, 0, 1, 1, 0, 0};
+__device__ constexpr int PROD_B[6] = {0, 2, 1, 0, 1, 0};
+
+template <int NPROD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_split_nt_kernel(const __bf16* __restrict__ Ap, const __bf16* __restrict__ Bp,
+                                                            float* __restrict__ C, int M, int N, int K) {
+  constexpr int NPL = NPROD == 1 ? 1 : (NPROD == 3 ? 2 : 3);   // planes needed per operand
+  constexpr int FIRST = 6 - NPROD;                              // NPROD leading-order products = the last ones
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * NPL][BM * BK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
+  const size_t planeA = (size_t)M * K, planeB = (size_t)N * K;
+
+  // staging: 512 16-byte chunks per image, two per thread
+  const int srow0 = tid >> 2, sch = tid & 3;
+  u32x4 sa[NPL][2], sb[NPL][2];
+  const __bf16* ga = Ap + (size_t)(bm + srow0) * K + sch * 8;
+  const __bf16* gb = Bp + (size_t)(bn + srow0) * K + sch * 8;
+  const int soff0 = srow0 * BK + ((sch ^ ((srow0 >> 1) & 3)) << 3);   // row + 64 keeps (row >> 1) & 3
+#define UFR_SG_LOAD(k0)                                                                             \
+  _Pragma("unroll") for (int p = 0; p < NPL; ++p) _Pragma("unroll") for (int i = 0; i < 2; ++i) {   \
+    sa[p][i] = *reinterpret_cast<const u32x4*>(ga + p * planeA + (size_t)(64 * i) * K + (k0));      \
+    sb[p][i] = *reinterpret_cast<const u32x4*>(gb + p * planeB + (size_t)(64 * i) * K + (k0));      \
+  }
+#define UFR_SG_STORE()                                                                              \
+  _Pragma("unroll") for (int p = 0; p < NPL; ++p) _Pragma("unroll") for (int i = 0; i < 2; ++i) {   \
+    *reinterpret_cast<u32x4*>(&lds[p][soff0 + 64 * i * BK]) = sa[p][i];                             \
+    *reinterpret_cast<u32x4*>(&lds[NPL + p][soff0 + 64 * i * BK]) = sb[p][i];                       \
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment address inside an image: row = base + (lane & 15), chunk = lane >> 4, swizzle from the row's low bits
+  const int frow = lane & 15;
+  const int foff = frow * BK + ((((lane >> 4)) ^ ((frow >> 1) & 3)) << 3);
+
+  UFR_SG_LOAD(0)
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    __syncthreads();          // everyone is done reading the previous tile
+    UFR_SG_STORE()
+    __syncthreads();
+    if (k0 + BK < K) { UFR_SG_LOAD(k0 + BK) }
+    bf16x8 a[NPL][4];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        a[p][m] = *reinterpret_cast<const bf16x8*>(&lds[p][(wr * 64 + m * 16) * BK + foff]);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      bf16x8 b[NPL];
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) b[p] = *reinterpret_cast<const bf16x8*>(&lds[NPL + p][(wc * 64 + n * 16) * BK + foff]);
+#pragma unroll
+      for (int t = FIRST; t < 6; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PROD_A[t]][m], b[PROD_B[t]], acc[m][n], 0, 0, 0);
+    }
+  }
+
+  // C/D layout of the 16x16 forms: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        C[(size_t)(bm + wr * 64 + m * 16 + (lane >> 4) * 4 + j) * N + bn + wc * 64 + n * 16 + (lane & 15)] = acc[m][n][j];
+}
+
+#undef UFR_SG_LOAD
+#undef UFR_SG_STORE
+
+}  // namespace
+
+extern "C" int ufr_split_bf16x3(const float* x, void* planes, long n, ufr_stream_t stream) {
+  UFR_REQUIRE(x && planes, "split bf16x3: null pointer");
+  UFR_REQUIRE(n > 0, "split bf16x3: bad size");
+  split3_kernel<<<ufr::stream_grid(n, 256), 256, 0, ufr::as_stream(stream)>>>(x, static_cast<__bf16*>(planes), n);
+  return ufr::launched("split3_kernel");
+}
+
+extern "C" int ufr_gemm_split_nt(const void* a_planes, const void* b_planes, float* c, int M, int N, int K,
+                                 int products, ufr_stream_t stream) {
+  UFR_REQUIRE(a_planes && b_planes && c, "split gemm: null pointer");
+  UFR_REQUIRE(M > 0 && N > 0 && K > 0 && M % BM == 0 && N % BN == 0 && K % BK == 0,
+              "split gemm: M and N must be multiples of 128, K of 32");
+  UFR_REQUIRE(products == 6 || products == 3 || products == 1, "split gemm: products must be 6, 3 or 1");
+  const dim3 grid(N / BN, M / BM);
+  hipStream_t st = ufr::as_stream(stream);
+  const __bf16* a = static_cast<const __bf16*>(a_planes);
+  const __bf16* b = static_cast<const __bf16*>(b_planes);
+  if (products == 6) gemm_split_nt_kernel<6><<<grid, 256, 0, st>>>(a, b, c, M, N, K);
+  else if (products == 3) gemm_split_nt_kernel<3><<<grid, 256, 0, st>>>(a, b, c, M, N, K);
+  else gemm_split_nt_kernel<1><<<grid, 256, 0, st>>>(a, b, c, M, N, K);
+  return ufr::launched("gemm_split_nt_kernel");
+}
