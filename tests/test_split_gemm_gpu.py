@@ -50,3 +50,29 @@ def test_shape_errors():
     a = split_bf16x3(torch.randn(100, 32, device=DEV))
     with pytest.raises(RuntimeError, match="multiples of 128"):
         gemm_split_nt(a, a, 6)
+
+
+@pytest.mark.parametrize("B,C,H,W,N", [(2, 40, 13, 20, 128), (1, 32, 16, 24, 256), (3, 70, 5, 7, 100)])
+def test_conv3x3_split_matches_float64(B, C, H, W, N):
+    """Ragged pixel count (not a multiple of the 128-row tile), padded channels, padded output channels; forward
+    and the data gradient through the same kernel."""
+    import torch.nn.functional as F
+    from understanding_flow_robustness_amd.split_gemm import conv3x3_split, conv3x3_weight_planes, nchw_to_nhwc_split3
+    g = torch.Generator().manual_seed(B * 100 + C)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(N, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    xp = nchw_to_nhwc_split3(x.to(DEV))
+    assert torch.equal(xp[0].float() + xp[1].float() + xp[2].float(),
+                       F.pad(x.permute(0, 2, 3, 1).reshape(B * H * W, C), (0, xp.shape[2] - C)).to(DEV))
+    wp = conv3x3_weight_planes(w.to(DEV))
+    for products, tol in ((6, 4e-6), (3, 3e-5)):
+        y = conv3x3_split(xp, wp, B, H, W, products)[:, :N].reshape(B, H, W, N).permute(0, 3, 1, 2)
+        err = float((y.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+        assert err <= tol, f"forward, {products} products: {err:.3e}"
+    gy = torch.randn(B, N, H, W, generator=g)
+    gref = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), padding=1)
+    gx = conv3x3_split(nchw_to_nhwc_split3(gy.to(DEV)), conv3x3_weight_planes(w.to(DEV), data_gradient=True), B, H, W, 6)
+    gx = gx[:, :C].reshape(B, H, W, C).permute(0, 3, 1, 2)
+    err = float((gx.cpu().double() - gref).abs().max()) / float(gref.abs().max())
+    assert err <= 4e-6, f"data gradient: {err:.3e}"

@@ -118,6 +118,134 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef UFR_SG_LOAD
 #undef UFR_SG_STORE
 
+// ---- 3x3 stride-1 pad-1 convolution as an implicit GEMM over the same tile machinery ---------------------------
+// activations: three bf16 planes, NHWC with the channels zero-padded to a multiple of 32: Xp[3][B*H*W][Cpad]
+// weights:     Wp[3][N][9][Cpad] (tap = ky*3 + kx), pre-split once (they are frozen during an attack)
+// output:      Y[B*H*W][N] float32 (NHWC).  K tiles run tap-major; a tile row is one pixel's 32-channel chunk of
+// one tap, zero when the tap falls outside the frame.
+template <int NPROD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_split_kernel(
+    const __bf16* __restrict__ Xp, const __bf16* __restrict__ Wp, float* __restrict__ Y, int B, int H, int W, int Cpad,
+    int N) {
+  constexpr int NPL = NPROD == 1 ? 1 : (NPROD == 3 ? 2 : 3);
+  constexpr int FIRST = 6 - NPROD;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * NPL][BM * BK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
+  const int M = B * H * W, K = 9 * Cpad, KC = Cpad / BK, KT = 9 * KC;
+  const size_t planeA = (size_t)M * Cpad, planeB = (size_t)N * K;
+
+  const int srow0 = tid >> 2, sch = tid & 3;
+  int pm[2], py[2], px[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    pm[i] = bm + srow0 + 64 * i;
+    px[i] = pm[i] % W;
+    py[i] = pm[i] < M ? (pm[i] / W) % H : -4;      // rows past the end never pass the bounds test
+  }
+  u32x4 sa[NPL][2], sb[NPL][2];
+  const __bf16* gb = Wp + (size_t)(bn + srow0) * K + sch * 8;
+  const int soff0 = srow0 * BK + ((sch ^ ((srow0 >> 1) & 3)) << 3);
+#define UFR_SC_LOAD(kt)                                                                               \
+  {                                                                                                   \
+    const int tap = (kt) / KC, c0 = ((kt) - tap * KC) * BK, dyo = tap / 3 - 1, dxo = tap % 3 - 1;      \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                   \
+      const bool ok = (unsigned)(py[i] + dyo) < (unsigned)H && (unsigned)(px[i] + dxo) < (unsigned)W;  \
+      const __bf16* src = Xp + (size_t)(ok ? pm[i] + dyo * W + dxo : 0) * Cpad + c0 + sch * 8;         \
+      _Pragma("unroll") for (int p = 0; p < NPL; ++p) {                                               \
+        const u32x4 v = *reinterpret_cast<const u32x4*>(src + p * planeA);                            \
+        sa[p][i] = ok ? v : u32x4{0u, 0u, 0u, 0u};                                                    \
+        sb[p][i] = *reinterpret_cast<const u32x4*>(gb + p * planeB + (size_t)(64 * i) * K + tap * Cpad + c0); \
+      }                                                                                               \
+    }                                                                                                 \
+  }
+#define UFR_SC_STORE()                                                                              \
+  _Pragma("unroll") for (int p = 0; p < NPL; ++p) _Pragma("unroll") for (int i = 0; i < 2; ++i) {   \
+    *reinterpret_cast<u32x4*>(&lds[p][soff0 + 64 * i * BK]) = sa[p][i];                             \
+    *reinterpret_cast<u32x4*>(&lds[NPL + p][soff0 + 64 * i * BK]) = sb[p][i];                       \
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15;
+  const int foff = frow * BK + ((((lane >> 4)) ^ ((frow >> 1) & 3)) << 3);
+
+  UFR_SC_LOAD(0)
+  for (int kt = 0; kt < KT; ++kt) {
+    __syncthreads();
+    UFR_SC_STORE()
+    __syncthreads();
+    if (kt + 1 < KT) UFR_SC_LOAD(kt + 1)
+    bf16x8 a[NPL][4];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        a[p][m] = *reinterpret_cast<const bf16x8*>(&lds[p][(wr * 64 + m * 16) * BK + foff]);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      bf16x8 b[NPL];
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) b[p] = *reinterpret_cast<const bf16x8*>(&lds[NPL + p][(wc * 64 + n * 16) * BK + foff]);
+#pragma unroll
+      for (int t = FIRST; t < 6; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PROD_A[t]][m], b[PROD_B[t]], acc[m][n], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = bm + wr * 64 + m * 16 + (lane >> 4) * 4 + j;
+      if (row < M) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) Y[(size_t)row * N + bn + wc * 64 + n * 16 + (lane & 15)] = acc[m][n][j];
+      }
+    }
+}
+#undef UFR_SC_LOAD
+#undef UFR_SC_STORE
+
+// x[B][C][H*W] float32 -> planes[3][B*H*W][Cpad] bf16 (channels C..Cpad-1 zero).  Tile: 32 channels x 64 pixels
+// through LDS so that both the NCHW reads and the NHWC 16-byte writes are contiguous.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_split3_kernel(const float* __restrict__ x, __bf16* __restrict__ planes,
+                                                                  int B, int C, int HW, int Cpad) {
+  __shared__ float tile[32][65];
+  const int c0 = blockIdx.x * 32, p0 = blockIdx.y * 64, b = blockIdx.z, tid = threadIdx.x;
+  {
+    const int p = tid & 63;
+#pragma unroll
+    for (int cc = tid >> 6; cc < 32; cc += 4) {
+      const int c = c0 + cc;
+      tile[cc][p] = (c < C && p0 + p < HW) ? x[((size_t)b * C + c) * HW + p0 + p] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int p = tid >> 2, ch = tid & 3;
+  if (p0 + p >= HW) return;
+  const size_t plane = (size_t)B * HW * Cpad;
+  __bf16* dst = planes + ((size_t)b * HW + p0 + p) * Cpad + c0 + ch * 8;
+  bf16x8 q0, q1, q2;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = tile[ch * 8 + j][p];
+    const __bf16 a = (__bf16)v;
+    const float r1 = v - (float)a;
+    const __bf16 bq = (__bf16)r1;
+    q0[j] = a;
+    q1[j] = bq;
+    q2[j] = (__bf16)(r1 - (float)bq);
+  }
+  *reinterpret_cast<bf16x8*>(dst) = q0;
+  *reinterpret_cast<bf16x8*>(dst + plane) = q1;
+  *reinterpret_cast<bf16x8*>(dst + 2 * plane) = q2;
+}
+
 }  // namespace
 
 extern "C" int ufr_split_bf16x3(const float* x, void* planes, long n, ufr_stream_t stream) {
@@ -141,4 +269,32 @@ extern "C" int ufr_gemm_split_nt(const void* a_planes, const void* b_planes, flo
   else if (products == 3) gemm_split_nt_kernel<3><<<grid, 256, 0, st>>>(a, b, c, M, N, K);
   else gemm_split_nt_kernel<1><<<grid, 256, 0, st>>>(a, b, c, M, N, K);
   return ufr::launched("gemm_split_nt_kernel");
+}
+
+extern "C" int ufr_nchw_to_nhwc_split3(const float* x, void* planes, int B, int C, int H, int W, int Cpad,
+                                       ufr_stream_t stream) {
+  UFR_REQUIRE(x && planes, "nchw -> nhwc split: null pointer");
+  UFR_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C && Cpad % BK == 0 && B < 65536,
+              "nchw -> nhwc split: bad shape (Cpad must be a multiple of 32, >= C)");
+  const dim3 grid(Cpad / 32, (H * W + 63) / 64, B);
+  nchw_to_nhwc_split3_kernel<<<grid, 256, 0, ufr::as_stream(stream)>>>(x, static_cast<__bf16*>(planes), B, C, H * W, Cpad);
+  return ufr::launched("nchw_to_nhwc_split3_kernel");
+}
+
+extern "C" int ufr_conv3x3_split(const void* x_planes, const void* w_planes, float* y, int B, int H, int W, int Cpad,
+                                 int N, int products, ufr_stream_t stream) {
+  UFR_REQUIRE(x_planes && w_planes && y, "split conv: null pointer");
+  UFR_REQUIRE(B > 0 && H > 0 && W > 0 && Cpad > 0 && Cpad % BK == 0 && N > 0 && N % BN == 0,
+              "split conv: Cpad must be a multiple of 32, the output channels of 128");
+  UFR_REQUIRE((long)B * H * W < (1L << 31) / 2, "split conv: too many pixels");
+  UFR_REQUIRE(products == 6 || products == 3 || products == 1, "split conv: products must be 6, 3 or 1");
+  const int M = B * H * W;
+  const dim3 grid(N / BN, (M + BM - 1) / BM);
+  hipStream_t st = ufr::as_stream(stream);
+  const __bf16* a = static_cast<const __bf16*>(x_planes);
+  const __bf16* b = static_cast<const __bf16*>(w_planes);
+  if (products == 6) conv3x3_split_kernel<6><<<grid, 256, 0, st>>>(a, b, y, B, H, W, Cpad, N);
+  else if (products == 3) conv3x3_split_kernel<3><<<grid, 256, 0, st>>>(a, b, y, B, H, W, Cpad, N);
+  else conv3x3_split_kernel<1><<<grid, 256, 0, st>>>(a, b, y, B, H, W, Cpad, N);
+  return ufr::launched("conv3x3_split_kernel");
 }

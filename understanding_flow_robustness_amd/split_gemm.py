@@ -32,3 +32,43 @@ def gemm_split_nt(a_planes: torch.Tensor, b_planes: torch.Tensor, products: int 
     L.check(L.lib().ufr_gemm_split_nt(L.ptr(a_planes), L.ptr(b_planes), L.ptr(c), M, N, K, int(products), L.stream()),
             "split gemm")
     return c
+
+
+def _pad32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+def nchw_to_nhwc_split3(x: torch.Tensor) -> torch.Tensor:
+    """x [B,C,H,W] float32 -> [3, B*H*W, Cpad] bfloat16 planes (channels zero-padded to a multiple of 32)."""
+    L.require_hip(x, "x")
+    B, C, H, W = x.shape
+    planes = torch.empty(3, B * H * W, _pad32(C), dtype=torch.bfloat16, device=x.device)
+    L.check(L.lib().ufr_nchw_to_nhwc_split3(L.ptr(x), L.ptr(planes), B, C, H, W, _pad32(C), L.stream()), "nchw -> nhwc split")
+    return planes
+
+
+def conv3x3_weight_planes(weight: torch.Tensor, data_gradient: bool = False) -> torch.Tensor:
+    """Conv2d(C, N, 3, 1, 1).weight [N,C,3,3] -> [3, Npad, 9*Cpad] planes in (tap, channel) order; done once, the
+    weights are frozen during an attack.  `data_gradient`: the planes of the adjoint convolution (taps flipped,
+    channel roles swapped), so the same kernel computes d loss / d input from d loss / d output."""
+    if data_gradient:
+        weight = weight.flip(2, 3).transpose(0, 1)
+    N, C = weight.shape[:2]
+    npad, cpad = (N + 127) // 128 * 128, _pad32(C)
+    w = torch.zeros(npad, 3, 3, cpad, dtype=torch.float32, device=weight.device)
+    w[:N, :, :, :C] = weight.detach().float().permute(0, 2, 3, 1)
+    return split_bf16x3(w.reshape(npad, 9 * cpad).contiguous())
+
+
+def conv3x3_split(x_planes: torch.Tensor, w_planes: torch.Tensor, B: int, H: int, W: int, products: int = 6) -> torch.Tensor:
+    """-> y [B*H*W, Npad] float32 (NHWC rows)."""
+    L.require_hip(x_planes, "x_planes")
+    L.require_hip(w_planes, "w_planes")
+    _, M, cpad = x_planes.shape
+    _, npad, k = w_planes.shape
+    if M != B * H * W or k != 9 * cpad or x_planes.dtype != torch.bfloat16 or w_planes.dtype != torch.bfloat16:
+        raise RuntimeError("conv3x3_split: plane shapes do not match")
+    y = torch.empty(M, npad, dtype=torch.float32, device=x_planes.device)
+    L.check(L.lib().ufr_conv3x3_split(L.ptr(x_planes), L.ptr(w_planes), L.ptr(y), B, H, W, cpad, npad, int(products),
+                                      L.stream()), "split conv")
+    return y
