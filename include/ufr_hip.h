@@ -194,17 +194,18 @@ int ufr_pwc_warp_backward(const float* x, const float* flow, const float* grad_o
  * plans their replacement by implicit GEMMs of this kind.  ufr_split_bf16x3: x[n] -> planes[3][n] bf16 with
  * x = p0 + p1 + p2 exactly.  ufr_gemm_split_nt: C[M,N] (fp32) = A[M,K] * B[N,K]^T from pre-split planes
  * ([3][M*K] and [3][N*K] bf16); `products` 6 (float32-accurate), 3 or 1 leading-order bf16 products, fp32
- * accumulation.  M, N multiples of 128, K of 32. */
+ * accumulation.  M, N multiples of 128, K of 32.  `chunk_major` = 1: planes stored [3][K/32][rows][32] (a 128-row
+ * tile of one K chunk is a contiguous 8 KB run) instead of row-major [3][rows][K]. */
 int ufr_split_bf16x3(const float* x, void* planes, long n, ufr_stream_t stream);
 int ufr_gemm_split_nt(const void* a_planes, const void* b_planes, float* c, int M, int N, int K, int products,
-                      ufr_stream_t stream);
+                      int chunk_major, ufr_stream_t stream);
 /* The same tiles as an implicit GEMM: Conv2d(C, N, 3, stride 1, padding 1) (submodules.py:18-46 blocks).
  * ufr_nchw_to_nhwc_split3: x [B,C,H,W] fp32 -> planes [3][B*H*W][Cpad] bf16, channels zero-padded to Cpad (a multiple
  * of 32).  ufr_conv3x3_split: x planes, weight planes [3][N][9][Cpad] (tap = ky*3+kx; N a multiple of 128) ->
  * y [B*H*W][N] fp32 (NHWC), no bias. */
 int ufr_nchw_to_nhwc_split3(const float* x, void* planes, int B, int C, int H, int W, int Cpad, ufr_stream_t stream);
 int ufr_conv3x3_split(const void* x_planes, const void* w_planes, float* y, int B, int H, int W, int Cpad, int N,
-                      int products, ufr_stream_t stream);
+                      int products, int chunk_major, ufr_stream_t stream);
 
 /* ---- RAFT convex upsampling ------------------------------------------------------------------------
  * replaces RAFT.upsample_flow (models/raft/raft.py:111-122): flow [N,2,H,W], mask [N,576,H,W] (9 x 8 x 8 logits

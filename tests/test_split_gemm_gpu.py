@@ -36,10 +36,12 @@ def test_matches_float64(M, N, K):
     scale = float(ref.abs().max())
     ap, bp = split_bf16x3(a.to(DEV)), split_bf16x3(b.to(DEV))
     # the MFMA's internal 32-term sums are not IEEE-rounded: 1.8e-6 measured at K = 4256 (plain fp32: 4e-7)
+    from understanding_flow_robustness_amd.split_gemm import chunk_major
     for products, tol in ((6, 4e-6), (3, 3e-5), (1, 1e-2)):
-        c = gemm_split_nt(ap, bp, products).cpu().double()
-        err = float((c - ref).abs().max()) / scale
+        c = gemm_split_nt(ap, bp, products)
+        err = float((c.cpu().double() - ref).abs().max()) / scale
         assert err <= tol, f"{products} products: {err:.3e}"
+        assert torch.equal(gemm_split_nt(chunk_major(ap), chunk_major(bp), products, chunked=True), c), "chunk-major layout"
     fp32 = float(((a @ b.t()).double() - ref).abs().max()) / scale
     six = float((gemm_split_nt(ap, bp, 6).cpu().double() - ref).abs().max()) / scale
     assert six <= 10.0 * fp32 + 1e-7, f"six products {six:.3e} vs plain float32 {fp32:.3e}"
@@ -57,7 +59,8 @@ def test_conv3x3_split_matches_float64(B, C, H, W, N):
     """Ragged pixel count (not a multiple of the 128-row tile), padded channels, padded output channels; forward
     and the data gradient through the same kernel."""
     import torch.nn.functional as F
-    from understanding_flow_robustness_amd.split_gemm import conv3x3_split, conv3x3_weight_planes, nchw_to_nhwc_split3
+    from understanding_flow_robustness_amd.split_gemm import (chunk_major, conv3x3_split, conv3x3_weight_planes,
+                                                              nchw_to_nhwc_split3)
     g = torch.Generator().manual_seed(B * 100 + C)
     x = torch.randn(B, C, H, W, generator=g)
     w = torch.randn(N, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5
@@ -70,6 +73,8 @@ def test_conv3x3_split_matches_float64(B, C, H, W, N):
         y = conv3x3_split(xp, wp, B, H, W, products)[:, :N].reshape(B, H, W, N).permute(0, 3, 1, 2)
         err = float((y.cpu().double() - ref).abs().max()) / float(ref.abs().max())
         assert err <= tol, f"forward, {products} products: {err:.3e}"
+        yc = conv3x3_split(chunk_major(xp), chunk_major(wp), B, H, W, products, chunked=True)
+        assert torch.equal(yc[:, :N].reshape(B, H, W, N).permute(0, 3, 1, 2), y), "chunk-major layout"
     gy = torch.randn(B, N, H, W, generator=g)
     gref = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), padding=1)
     gx = conv3x3_split(nchw_to_nhwc_split3(gy.to(DEV)), conv3x3_weight_planes(w.to(DEV), data_gradient=True), B, H, W, 6)

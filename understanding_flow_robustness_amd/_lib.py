@@ -88,9 +88,9 @@ SIGNATURES = {
     "ufr_pwc_warp_forward": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_pwc_warp_backward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_split_bf16x3": [_vp, _vp, _l, _vp],
-    "ufr_gemm_split_nt": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ufr_gemm_split_nt": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ufr_nchw_to_nhwc_split3": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "ufr_conv3x3_split": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "ufr_conv3x3_split": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ufr_convex_upsample_forward": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "ufr_convex_upsample_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ufr_affine_resample_f64": [_vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _d, _d, _d, _i, _vp],

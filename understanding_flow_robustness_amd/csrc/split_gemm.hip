@@ -45,7 +45,8 @@ __device__ constexpr int PROD_B[6] = {0, 2, 1, 0, 1, 0};
 
 template <int NPROD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_split_nt_kernel(const __bf16* __restrict__ Ap, const __bf16* __restrict__ Bp,
-                                                            float* __restrict__ C, int M, int N, int K) {
+                                                            float* __restrict__ C, int M, int N, int K, long rsA,
+                                                            long ksA, long rsB, long ksB) {
   constexpr int NPL = NPROD == 1 ? 1 : (NPROD == 3 ? 2 : 3);   // planes needed per operand
   constexpr int FIRST = 6 - NPROD;                              // NPROD leading-order products = the last ones
   __shared__ __attribute__((aligned(16))) __bf16 lds[2 * NPL][BM * BK];
@@ -56,13 +57,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // staging: 512 16-byte chunks per image, two per thread
   const int srow0 = tid >> 2, sch = tid & 3;
   u32x4 sa[NPL][2], sb[NPL][2];
-  const __bf16* ga = Ap + (size_t)(bm + srow0) * K + sch * 8;
-  const __bf16* gb = Bp + (size_t)(bn + srow0) * K + sch * 8;
+  // row stride rs / K-chunk stride ks: (K, 32) for row-major [rows][K] planes, (32, rows*32) for the
+  // chunk-major [K/32][rows][32] layout whose tiles are contiguous 8 KB runs (full 128-byte lines)
+  const __bf16* ga = Ap + (size_t)(bm + srow0) * rsA + sch * 8;
+  const __bf16* gb = Bp + (size_t)(bn + srow0) * rsB + sch * 8;
   const int soff0 = srow0 * BK + ((sch ^ ((srow0 >> 1) & 3)) << 3);   // row + 64 keeps (row >> 1) & 3
-#define UFR_SG_LOAD(k0)                                                                             \
-  _Pragma("unroll") for (int p = 0; p < NPL; ++p) _Pragma("unroll") for (int i = 0; i < 2; ++i) {   \
-    sa[p][i] = *reinterpret_cast<const u32x4*>(ga + p * planeA + (size_t)(64 * i) * K + (k0));      \
-    sb[p][i] = *reinterpret_cast<const u32x4*>(gb + p * planeB + (size_t)(64 * i) * K + (k0));      \
+#define UFR_SG_LOAD(k0)                                                                                       \
+  _Pragma("unroll") for (int p = 0; p < NPL; ++p) _Pragma("unroll") for (int i = 0; i < 2; ++i) {             \
+    sa[p][i] = *reinterpret_cast<const u32x4*>(ga + p * planeA + (size_t)(64 * i) * rsA + ((k0) / BK) * ksA); \
+    sb[p][i] = *reinterpret_cast<const u32x4*>(gb + p * planeB + (size_t)(64 * i) * rsB + ((k0) / BK) * ksB); \
   }
 #define UFR_SG_STORE()                                                                              \
   _Pragma("unroll") for (int p = 0; p < NPL; ++p) _Pragma("unroll") for (int i = 0; i < 2; ++i) {   \
@@ -124,9 +127,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // output:      Y[B*H*W][N] float32 (NHWC).  K tiles run tap-major; a tile row is one pixel's 32-channel chunk of
 // one tap, zero when the tap falls outside the frame.
 template <int NPROD>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_split_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPROD == 6 ? 2 : 3, NPROD == 6 ? 2 : 3))) void conv3x3_split_kernel(
     const __bf16* __restrict__ Xp, const __bf16* __restrict__ Wp, float* __restrict__ Y, int B, int H, int W, int Cpad,
-    int N) {
+    int N, long rsA, long ksA, long rsB, long ksB) {
   constexpr int NPL = NPROD == 1 ? 1 : (NPROD == 3 ? 2 : 3);
   constexpr int FIRST = 6 - NPROD;
   __shared__ __attribute__((aligned(16))) __bf16 lds[2 * NPL][BM * BK];
@@ -144,18 +147,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     py[i] = pm[i] < M ? (pm[i] / W) % H : -4;      // rows past the end never pass the bounds test
   }
   u32x4 sa[NPL][2], sb[NPL][2];
-  const __bf16* gb = Wp + (size_t)(bn + srow0) * K + sch * 8;
+  const __bf16* gb = Wp + (size_t)(bn + srow0) * rsB + sch * 8;
   const int soff0 = srow0 * BK + ((sch ^ ((srow0 >> 1) & 3)) << 3);
 #define UFR_SC_LOAD(kt)                                                                               \
   {                                                                                                   \
-    const int tap = (kt) / KC, c0 = ((kt) - tap * KC) * BK, dyo = tap / 3 - 1, dxo = tap % 3 - 1;      \
+    const int tap = (kt) / KC, kc = (kt) - tap * KC, dyo = tap / 3 - 1, dxo = tap % 3 - 1;             \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                   \
       const bool ok = (unsigned)(py[i] + dyo) < (unsigned)H && (unsigned)(px[i] + dxo) < (unsigned)W;  \
-      const __bf16* src = Xp + (size_t)(ok ? pm[i] + dyo * W + dxo : 0) * Cpad + c0 + sch * 8;         \
+      const __bf16* src = Xp + (size_t)(ok ? pm[i] + dyo * W + dxo : 0) * rsA + kc * ksA + sch * 8;    \
       _Pragma("unroll") for (int p = 0; p < NPL; ++p) {                                               \
         const u32x4 v = *reinterpret_cast<const u32x4*>(src + p * planeA);                            \
         sa[p][i] = ok ? v : u32x4{0u, 0u, 0u, 0u};                                                    \
-        sb[p][i] = *reinterpret_cast<const u32x4*>(gb + p * planeB + (size_t)(64 * i) * K + tap * Cpad + c0); \
+        sb[p][i] = *reinterpret_cast<const u32x4*>(gb + p * planeB + (size_t)(64 * i) * rsB + (kt) * ksB);    \
       }                                                                                               \
     }                                                                                                 \
   }
@@ -256,7 +259,7 @@ extern "C" int ufr_split_bf16x3(const float* x, void* planes, long n, ufr_stream
 }
 
 extern "C" int ufr_gemm_split_nt(const void* a_planes, const void* b_planes, float* c, int M, int N, int K,
-                                 int products, ufr_stream_t stream) {
+                                 int products, int chunk_major, ufr_stream_t stream) {
   UFR_REQUIRE(a_planes && b_planes && c, "split gemm: null pointer");
   UFR_REQUIRE(M > 0 && N > 0 && K > 0 && M % BM == 0 && N % BN == 0 && K % BK == 0,
               "split gemm: M and N must be multiples of 128, K of 32");
@@ -265,9 +268,11 @@ extern "C" int ufr_gemm_split_nt(const void* a_planes, const void* b_planes, flo
   hipStream_t st = ufr::as_stream(stream);
   const __bf16* a = static_cast<const __bf16*>(a_planes);
   const __bf16* b = static_cast<const __bf16*>(b_planes);
-  if (products == 6) gemm_split_nt_kernel<6><<<grid, 256, 0, st>>>(a, b, c, M, N, K);
-  else if (products == 3) gemm_split_nt_kernel<3><<<grid, 256, 0, st>>>(a, b, c, M, N, K);
-  else gemm_split_nt_kernel<1><<<grid, 256, 0, st>>>(a, b, c, M, N, K);
+  const long rsA = chunk_major ? BK : K, ksA = chunk_major ? (long)M * BK : BK;
+  const long rsB = chunk_major ? BK : K, ksB = chunk_major ? (long)N * BK : BK;
+  if (products == 6) gemm_split_nt_kernel<6><<<grid, 256, 0, st>>>(a, b, c, M, N, K, rsA, ksA, rsB, ksB);
+  else if (products == 3) gemm_split_nt_kernel<3><<<grid, 256, 0, st>>>(a, b, c, M, N, K, rsA, ksA, rsB, ksB);
+  else gemm_split_nt_kernel<1><<<grid, 256, 0, st>>>(a, b, c, M, N, K, rsA, ksA, rsB, ksB);
   return ufr::launched("gemm_split_nt_kernel");
 }
 
@@ -282,7 +287,7 @@ extern "C" int ufr_nchw_to_nhwc_split3(const float* x, void* planes, int B, int 
 }
 
 extern "C" int ufr_conv3x3_split(const void* x_planes, const void* w_planes, float* y, int B, int H, int W, int Cpad,
-                                 int N, int products, ufr_stream_t stream) {
+                                 int N, int products, int chunk_major, ufr_stream_t stream) {
   UFR_REQUIRE(x_planes && w_planes && y, "split conv: null pointer");
   UFR_REQUIRE(B > 0 && H > 0 && W > 0 && Cpad > 0 && Cpad % BK == 0 && N > 0 && N % BN == 0,
               "split conv: Cpad must be a multiple of 32, the output channels of 128");
@@ -293,8 +298,10 @@ extern "C" int ufr_conv3x3_split(const void* x_planes, const void* w_planes, flo
   hipStream_t st = ufr::as_stream(stream);
   const __bf16* a = static_cast<const __bf16*>(x_planes);
   const __bf16* b = static_cast<const __bf16*>(w_planes);
-  if (products == 6) conv3x3_split_kernel<6><<<grid, 256, 0, st>>>(a, b, y, B, H, W, Cpad, N);
-  else if (products == 3) conv3x3_split_kernel<3><<<grid, 256, 0, st>>>(a, b, y, B, H, W, Cpad, N);
-  else conv3x3_split_kernel<1><<<grid, 256, 0, st>>>(a, b, y, B, H, W, Cpad, N);
+  const long rsA = chunk_major ? BK : Cpad, ksA = chunk_major ? (long)M * BK : BK;
+  const long rsB = chunk_major ? BK : 9L * Cpad, ksB = chunk_major ? (long)N * BK : BK;
+  if (products == 6) conv3x3_split_kernel<6><<<grid, 256, 0, st>>>(a, b, y, B, H, W, Cpad, N, rsA, ksA, rsB, ksB);
+  else if (products == 3) conv3x3_split_kernel<3><<<grid, 256, 0, st>>>(a, b, y, B, H, W, Cpad, N, rsA, ksA, rsB, ksB);
+  else conv3x3_split_kernel<1><<<grid, 256, 0, st>>>(a, b, y, B, H, W, Cpad, N, rsA, ksA, rsB, ksB);
   return ufr::launched("conv3x3_split_kernel");
 }

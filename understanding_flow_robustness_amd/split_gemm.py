@@ -18,8 +18,16 @@ def split_bf16x3(x: torch.Tensor) -> torch.Tensor:
     return planes
 
 
-def gemm_split_nt(a_planes: torch.Tensor, b_planes: torch.Tensor, products: int = 6) -> torch.Tensor:
-    """C[M,N] = A[M,K] @ B[N,K]^T from `split_bf16x3` planes ([3,M,K] and [3,N,K])."""
+def chunk_major(planes: torch.Tensor) -> torch.Tensor:
+    """[3, rows, K] row-major planes -> the same shape holding the [3, K/32, rows, 32] chunk-major image: every
+    (128-row, 32-wide) tile becomes one contiguous 8 KB run, i.e. whole 128-byte lines for the tile loads."""
+    p, rows, k = planes.shape
+    return planes.view(p, rows, k // 32, 32).permute(0, 2, 1, 3).contiguous().view(p, rows, k)
+
+
+def gemm_split_nt(a_planes: torch.Tensor, b_planes: torch.Tensor, products: int = 6, chunked: bool = False) -> torch.Tensor:
+    """C[M,N] = A[M,K] @ B[N,K]^T from `split_bf16x3` planes ([3,M,K] and [3,N,K]; `chunked`: both passed
+    through `chunk_major`)."""
     L.require_hip(a_planes, "a_planes")
     L.require_hip(b_planes, "b_planes")
     if a_planes.dtype != torch.bfloat16 or b_planes.dtype != torch.bfloat16 or a_planes.dim() != 3 or b_planes.dim() != 3:
@@ -29,8 +37,8 @@ def gemm_split_nt(a_planes: torch.Tensor, b_planes: torch.Tensor, products: int 
     if K != Kb or a_planes.shape[0] != 3 or b_planes.shape[0] != 3:
         raise RuntimeError("gemm_split_nt: plane shapes do not match")
     c = torch.empty(M, N, dtype=torch.float32, device=a_planes.device)
-    L.check(L.lib().ufr_gemm_split_nt(L.ptr(a_planes), L.ptr(b_planes), L.ptr(c), M, N, K, int(products), L.stream()),
-            "split gemm")
+    L.check(L.lib().ufr_gemm_split_nt(L.ptr(a_planes), L.ptr(b_planes), L.ptr(c), M, N, K, int(products), int(chunked),
+                                      L.stream()), "split gemm")
     return c
 
 
@@ -60,8 +68,9 @@ def conv3x3_weight_planes(weight: torch.Tensor, data_gradient: bool = False) -> 
     return split_bf16x3(w.reshape(npad, 9 * cpad).contiguous())
 
 
-def conv3x3_split(x_planes: torch.Tensor, w_planes: torch.Tensor, B: int, H: int, W: int, products: int = 6) -> torch.Tensor:
-    """-> y [B*H*W, Npad] float32 (NHWC rows)."""
+def conv3x3_split(x_planes: torch.Tensor, w_planes: torch.Tensor, B: int, H: int, W: int, products: int = 6,
+                  chunked: bool = False) -> torch.Tensor:
+    """-> y [B*H*W, Npad] float32 (NHWC rows).  `chunked`: both plane sets passed through `chunk_major`."""
     L.require_hip(x_planes, "x_planes")
     L.require_hip(w_planes, "w_planes")
     _, M, cpad = x_planes.shape
@@ -70,5 +79,5 @@ def conv3x3_split(x_planes: torch.Tensor, w_planes: torch.Tensor, B: int, H: int
         raise RuntimeError("conv3x3_split: plane shapes do not match")
     y = torch.empty(M, npad, dtype=torch.float32, device=x_planes.device)
     L.check(L.lib().ufr_conv3x3_split(L.ptr(x_planes), L.ptr(w_planes), L.ptr(y), B, H, W, cpad, npad, int(products),
-                                      L.stream()), "split conv")
+                                      int(chunked), L.stream()), "split conv")
     return y
