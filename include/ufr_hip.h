@@ -206,6 +206,10 @@ int ufr_gemm_split_nt(const void* a_planes, const void* b_planes, float* c, int 
 int ufr_nchw_to_nhwc_split3(const float* x, void* planes, int B, int C, int H, int W, int Cpad, ufr_stream_t stream);
 int ufr_conv3x3_split(const void* x_planes, const void* w_planes, float* y, int B, int H, int W, int Cpad, int N,
                       int products, int chunk_major, ufr_stream_t stream);
+/* EXPERIMENTAL (compiled, not yet run on hardware): the same convolution on 128 x 256 tiles with two LDS buffers
+ * (csrc/split_conv_wide.hip); N a multiple of 256. */
+int ufr_conv3x3_split_wide(const void* x_planes, const void* w_planes, float* y, int B, int H, int W, int Cpad, int N,
+                           int products, int chunk_major, ufr_stream_t stream);
 
 /* ---- RAFT convex upsampling ------------------------------------------------------------------------
  * replaces RAFT.upsample_flow (models/raft/raft.py:111-122): flow [N,2,H,W], mask [N,576,H,W] (9 x 8 x 8 logits

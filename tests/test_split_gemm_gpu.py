@@ -81,3 +81,18 @@ def test_conv3x3_split_matches_float64(B, C, H, W, N):
     gx = gx[:, :C].reshape(B, H, W, C).permute(0, 3, 1, 2)
     err = float((gx.cpu().double() - gref).abs().max()) / float(gref.abs().max())
     assert err <= 4e-6, f"data gradient: {err:.3e}"
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("UFR_EXPERIMENTAL"),
+                    reason="csrc/split_conv_wide.hip has not run on hardware yet (written after round 1's GPU budget)")
+@pytest.mark.parametrize("B,C,H,W,N", [(2, 40, 13, 20, 256), (1, 96, 16, 24, 512)])
+def test_wide_tile_conv_equals_the_128x128_kernel(B, C, H, W, N):
+    from understanding_flow_robustness_amd.split_gemm import (chunk_major, conv3x3_split, conv3x3_weight_planes,
+                                                              nchw_to_nhwc_split3)
+    g = torch.Generator().manual_seed(C)
+    xp = nchw_to_nhwc_split3(torch.randn(B, C, H, W, generator=g).to(DEV))
+    wp = conv3x3_weight_planes((torch.randn(N, C, 3, 3, generator=g) * 0.05).to(DEV))
+    for products in (6, 3, 1):
+        want = conv3x3_split(xp, wp, B, H, W, products)
+        assert torch.equal(conv3x3_split(xp, wp, B, H, W, products, wide=True), want)
+        assert torch.equal(conv3x3_split(chunk_major(xp), chunk_major(wp), B, H, W, products, chunked=True, wide=True), want)

@@ -48,6 +48,10 @@ for name, C, N, H, W in (("conv3_1", 473, 256, 48, 160), ("conv4_1", 512, 512, 2
     for products in (6, 3):
         ms = timed(lambda: conv3x3_split(xc, wc, B, H, W, products, chunked=True))
         row[f"chunked{products}_ms"], row[f"chunked{products}_tflops"] = round(ms, 4), round(flop / ms * 1e-9, 1)
+    if os.environ.get("UFR_EXPERIMENTAL") and N % 256 == 0:           # csrc/split_conv_wide.hip
+        for products in (6, 3):
+            ms = timed(lambda: conv3x3_split(xc, wc, B, H, W, products, chunked=True, wide=True))
+            row[f"wide{products}_ms"], row[f"wide{products}_tflops"] = round(ms, 4), round(flop / ms * 1e-9, 1)
     if not skip_miopen:
         ref = F.conv2d(x[:1], w, padding=1)
         y = conv3x3_split(xp, wp, B, H, W, 6)[: H * W, :N].reshape(1, H, W, N).permute(0, 3, 1, 2)

@@ -1,0 +1,135 @@
+// split_conv_wide.hip -- EXPERIMENTAL (compiled, not yet run on hardware at the end of round 1; its tests are gated
+// by UFR_EXPERIMENTAL=1).  The next schedule step for csrc/split_gemm.hip's implicit-GEMM convolution, written
+// from the traffic arithmetic in DESIGN.md 10: a 128 (pixels) x 256 (output channels) tile, so that FlowNetC's
+// conv3_1 (N = 256) stages every activation tile once instead of twice, eight waves as 2 x 4 (each still a 64x64
+// block of 4x4 `v_mfma_f32_16x16x32_bf16` accumulators), one workgroup per CU and therefore room for TWO LDS
+// buffers (2 x 72 KB): the next K tile is written while the current one is multiplied, one barrier per K step.
+//
+// Same operands as ufr_conv3x3_split (three bf16 planes per operand, row-major or chunk-major), same result
+// definition; N must be a multiple of 256.
+#include "ufr_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+constexpr int WM = 128, WN = 256, BK = 32;
+constexpr int A_IMG = WM * BK, B_IMG = WN * BK;   // bf16 elements of one plane's tile
+
+__device__ constexpr int PROD_A[6] = {2, 0, 1, 1, 0, 0};   // as in split_gemm.hip: smallest products first
+__device__ constexpr int PROD_B[6] = {0, 2, 1, 0, 1, 0};
+
+template <int NPROD>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_split_wide_kernel(
+    const __bf16* __restrict__ Xp, const __bf16* __restrict__ Wp, float* __restrict__ Y, int B, int H, int W, int Cpad,
+    int N, long rsA, long ksA, long rsB, long ksB) {
+  constexpr int NPL = NPROD == 1 ? 1 : (NPROD == 3 ? 2 : 3);
+  constexpr int FIRST = 6 - NPROD;
+  constexpr int BUF = NPL * (A_IMG + B_IMG);
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BUF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 2, wc = wave & 3;
+  const int bm = blockIdx.y * WM, bn = blockIdx.x * WN;
+  const int M = B * H * W, KC = Cpad / BK, KT = 9 * KC;
+  const size_t planeA = (size_t)M * Cpad, planeB = (size_t)N * 9 * Cpad;
+
+  // staging: one activation chunk and two weight chunks (rows r and r + 128) per thread and plane
+  const int srow = tid >> 2, sch = tid & 3;
+  const int pm = bm + srow, px = pm % W, py = pm < M ? (pm / W) % H : -4;
+  const __bf16* gb = Wp + (size_t)(bn + srow) * rsB + sch * 8;
+  const int soff = srow * BK + ((sch ^ ((srow >> 1) & 3)) << 3);      // + 128 rows keeps (row >> 1) & 3
+  u32x4 sa[NPL], sb[NPL][2];
+#define UFR_SW_LOAD(kt)                                                                             \
+  {                                                                                                 \
+    const int tap = (kt) / KC, kc = (kt) - tap * KC, dyo = tap / 3 - 1, dxo = tap % 3 - 1;           \
+    const bool ok = (unsigned)(py + dyo) < (unsigned)H && (unsigned)(px + dxo) < (unsigned)W;        \
+    const __bf16* src = Xp + (size_t)(ok ? pm + dyo * W + dxo : 0) * rsA + kc * ksA + sch * 8;       \
+    _Pragma("unroll") for (int p = 0; p < NPL; ++p) {                                               \
+      const u32x4 v = *reinterpret_cast<const u32x4*>(src + p * planeA);                            \
+      sa[p] = ok ? v : u32x4{0u, 0u, 0u, 0u};                                                       \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
+        sb[p][i] = *reinterpret_cast<const u32x4*>(gb + p * planeB + (size_t)(128 * i) * rsB + (kt) * ksB); \
+    }                                                                                               \
+  }
+#define UFR_SW_STORE(buf)                                                                           \
+  _Pragma("unroll") for (int p = 0; p < NPL; ++p) {                                                 \
+    *reinterpret_cast<u32x4*>(&lds[(buf) * BUF + p * A_IMG + soff]) = sa[p];                        \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                   \
+      *reinterpret_cast<u32x4*>(&lds[(buf) * BUF + NPL * A_IMG + p * B_IMG + soff + 128 * i * BK]) = sb[p][i]; \
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15;
+  const int foff = frow * BK + ((((lane >> 4)) ^ ((frow >> 1) & 3)) << 3);
+
+  UFR_SW_LOAD(0)
+  UFR_SW_STORE(0)
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < KT;
+    if (more) UFR_SW_LOAD(kt + 1)
+    const __bf16* la = lds + cur * BUF;
+    const __bf16* lb = la + NPL * A_IMG;
+    bf16x8 a[NPL][4];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        a[p][m] = *reinterpret_cast<const bf16x8*>(&la[p * A_IMG + (wr * 64 + m * 16) * BK + foff]);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      bf16x8 b[NPL];
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) b[p] = *reinterpret_cast<const bf16x8*>(&lb[p * B_IMG + (wc * 64 + n * 16) * BK + foff]);
+#pragma unroll
+      for (int t = FIRST; t < 6; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PROD_A[t]][m], b[PROD_B[t]], acc[m][n], 0, 0, 0);
+    }
+    // the other buffer was last read in iteration kt - 1, and every wave has passed that iteration's barrier
+    if (more) { UFR_SW_STORE(cur ^ 1) }
+    __syncthreads();
+  }
+#undef UFR_SW_LOAD
+#undef UFR_SW_STORE
+
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = bm + wr * 64 + m * 16 + (lane >> 4) * 4 + j;
+      if (row < M) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) Y[(size_t)row * N + bn + wc * 64 + n * 16 + (lane & 15)] = acc[m][n][j];
+      }
+    }
+}
+
+}  // namespace
+
+extern "C" int ufr_conv3x3_split_wide(const void* x_planes, const void* w_planes, float* y, int B, int H, int W,
+                                      int Cpad, int N, int products, int chunk_major, ufr_stream_t stream) {
+  UFR_REQUIRE(x_planes && w_planes && y, "split conv (wide): null pointer");
+  UFR_REQUIRE(B > 0 && H > 0 && W > 0 && Cpad > 0 && Cpad % BK == 0 && N > 0 && N % WN == 0,
+              "split conv (wide): Cpad must be a multiple of 32, the output channels of 256");
+  UFR_REQUIRE((long)B * H * W < (1L << 31) / 2, "split conv (wide): too many pixels");
+  UFR_REQUIRE(products == 6 || products == 3 || products == 1, "split conv (wide): products must be 6, 3 or 1");
+  const int M = B * H * W;
+  const dim3 grid(N / WN, (M + WM - 1) / WM);
+  hipStream_t st = ufr::as_stream(stream);
+  const __bf16* a = static_cast<const __bf16*>(x_planes);
+  const __bf16* b = static_cast<const __bf16*>(w_planes);
+  const long rsA = chunk_major ? BK : Cpad, ksA = chunk_major ? (long)M * BK : BK;
+  const long rsB = chunk_major ? BK : 9L * Cpad, ksB = chunk_major ? (long)N * BK : BK;
+  if (products == 6) conv3x3_split_wide_kernel<6><<<grid, 512, 0, st>>>(a, b, y, B, H, W, Cpad, N, rsA, ksA, rsB, ksB);
+  else if (products == 3) conv3x3_split_wide_kernel<3><<<grid, 512, 0, st>>>(a, b, y, B, H, W, Cpad, N, rsA, ksA, rsB, ksB);
+  else conv3x3_split_wide_kernel<1><<<grid, 512, 0, st>>>(a, b, y, B, H, W, Cpad, N, rsA, ksA, rsB, ksB);
+  return ufr::launched("conv3x3_split_wide_kernel");
+}

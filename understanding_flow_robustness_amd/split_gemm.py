@@ -69,8 +69,9 @@ def conv3x3_weight_planes(weight: torch.Tensor, data_gradient: bool = False) -> 
 
 
 def conv3x3_split(x_planes: torch.Tensor, w_planes: torch.Tensor, B: int, H: int, W: int, products: int = 6,
-                  chunked: bool = False) -> torch.Tensor:
-    """-> y [B*H*W, Npad] float32 (NHWC rows).  `chunked`: both plane sets passed through `chunk_major`."""
+                  chunked: bool = False, wide: bool = False) -> torch.Tensor:
+    """-> y [B*H*W, Npad] float32 (NHWC rows).  `chunked`: both plane sets passed through `chunk_major`.
+    `wide`: the experimental 128x256-tile kernel (csrc/split_conv_wide.hip; Npad a multiple of 256)."""
     L.require_hip(x_planes, "x_planes")
     L.require_hip(w_planes, "w_planes")
     _, M, cpad = x_planes.shape
@@ -78,6 +79,7 @@ def conv3x3_split(x_planes: torch.Tensor, w_planes: torch.Tensor, B: int, H: int
     if M != B * H * W or k != 9 * cpad or x_planes.dtype != torch.bfloat16 or w_planes.dtype != torch.bfloat16:
         raise RuntimeError("conv3x3_split: plane shapes do not match")
     y = torch.empty(M, npad, dtype=torch.float32, device=x_planes.device)
-    L.check(L.lib().ufr_conv3x3_split(L.ptr(x_planes), L.ptr(w_planes), L.ptr(y), B, H, W, cpad, npad, int(products),
-                                      int(chunked), L.stream()), "split conv")
+    entry = L.lib().ufr_conv3x3_split_wide if wide else L.lib().ufr_conv3x3_split
+    L.check(entry(L.ptr(x_planes), L.ptr(w_planes), L.ptr(y), B, H, W, cpad, npad, int(products), int(chunked), L.stream()),
+            "split conv")
     return y
