@@ -70,7 +70,6 @@ def test_attack_matches_reference_trace(net, name, l2, lr, use_graph):
 def test_attack_fused_kernels_bit_exact_vs_torch(net):
     """paste / update / loss kernels against the reference's own torch expressions on identical
     inputs: elementwise stages are bit-exact, the loss scalar to fp32 summation order."""
-    import ctypes as C
     from understanding_flow_robustness_amd import _lib as L
     g = torch.Generator().manual_seed(3)
     B, H, W = 3, 24, 40

@@ -2,7 +2,6 @@
 restatements against golden vectors captured from the reference's own modules."""
 from argparse import Namespace
 
-import pytest
 import torch
 
 from conftest import assert_close, load_golden, t

@@ -4,7 +4,6 @@ from argparse import Namespace
 
 import numpy as np
 import pytest
-import torch
 
 from conftest import load_golden, t
 

@@ -5,7 +5,7 @@ from argparse import Namespace
 import torch, torch.nn.functional as F
 from conftest import load_golden, t
 from understanding_flow_robustness_amd.flownets.utils_model import fetch_model
-from understanding_flow_robustness_amd.flownets import raft_corr, raft as raft_mod
+from understanding_flow_robustness_amd.flownets import raft_corr
 
 z = load_golden("raft_128x192")
 

@@ -1,5 +1,5 @@
 """Probe: MIOpen backward-data time of FlowNetC head convolutions at full width vs a column band."""
-import torch, time
+import torch
 import torch.nn.functional as F
 torch.backends.cudnn.benchmark = True
 dev = "cuda:0"
