@@ -1,0 +1,86 @@
+"""CPU check of `split_gemm.SplitConv3x3` (the opt-in UFR_SPLIT_CONV wiring): the three HIP entry points are
+replaced by torch emulations of what they compute (each one is tested against float64 on the GPU in
+tests/test_split_gemm_gpu.py), so this pins the composition: plane layouts, chunk-major images, the adjoint's
+flipped / transposed weights, channel padding and the NHWC <-> NCHW copies."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from understanding_flow_robustness_amd import split_gemm as sg
+
+
+def _split(x):
+    parts, r = [], x.float().clone()
+    for _ in range(3):
+        p = r.bfloat16()
+        parts.append(p)
+        r = r - p.float()
+    return torch.stack(parts)
+
+
+def _emu_to_planes(x):
+    B, C, H, W = x.shape
+    cpad = (C + 31) // 32 * 32
+    rows = F.pad(x.permute(0, 2, 3, 1).reshape(B * H * W, C), (0, cpad - C))
+    return _split(rows)
+
+
+def _unchunk(planes):
+    p, rows, k = planes.shape
+    return planes.view(p, k // 32, rows, 32).permute(0, 2, 1, 3).reshape(p, rows, k)
+
+
+def _emu_conv(x_planes, w_planes, B, H, W, products=6, chunked=False, wide=False):
+    if chunked:
+        x_planes, w_planes = _unchunk(x_planes), _unchunk(w_planes)
+    x = x_planes.float().sum(0)                                    # exact: the pieces add back to the float32
+    w = w_planes.float().sum(0)
+    cpad, npad = x.shape[1], w.shape[0]
+    x = x.view(B, H, W, cpad).permute(0, 3, 1, 2)
+    w = w.view(npad, 3, 3, cpad).permute(0, 3, 1, 2)
+    return F.conv2d(x, w, padding=1).permute(0, 2, 3, 1).reshape(B * H * W, npad).contiguous()
+
+
+@pytest.fixture
+def emulated(monkeypatch):
+    monkeypatch.setattr(sg, "split_bf16x3", _split)
+    monkeypatch.setattr(sg, "nchw_to_nhwc_split3", _emu_to_planes)
+    monkeypatch.setattr(sg, "conv3x3_split", _emu_conv)
+    sg._WEIGHT_PLANES.clear()
+    yield
+    sg._WEIGHT_PLANES.clear()
+
+
+def test_chunk_major_round_trip():
+    planes = torch.arange(3 * 6 * 64, dtype=torch.float32).view(3, 6, 64).bfloat16()
+    cm = sg.chunk_major(planes)
+    assert cm.shape == planes.shape and torch.equal(_unchunk(cm), planes)
+    assert torch.equal(cm.view(3, 2, 6, 32)[1, 1, 4], planes[1, 4, 32:])       # [plane][chunk][row][32]
+
+
+@pytest.mark.parametrize("B,C,H,W,N", [(2, 40, 9, 11, 100), (1, 64, 8, 8, 128)])
+def test_split_conv_function_equals_conv2d_and_its_adjoint(emulated, B, C, H, W, N):
+    g = torch.Generator().manual_seed(N)
+    x = torch.randn(B, C, H, W, generator=g, requires_grad=True)
+    w = torch.randn(N, C, 3, 3, generator=g) * 0.1
+    y = sg.SplitConv3x3.apply(x, w, 6)
+    want = F.conv2d(x, w, padding=1)
+    assert y.shape == want.shape
+    assert float((y - want).detach().abs().max()) <= 2e-5 * float(want.detach().abs().max())
+    gy = torch.randn(want.shape, generator=g)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    (gx_want,) = torch.autograd.grad(want, x, gy)
+    assert float((gx - gx_want).abs().max()) <= 2e-5 * float(gx_want.abs().max())
+    assert len(sg._WEIGHT_PLANES) == 2                                         # forward + adjoint planes, cached
+
+
+def test_split_conv_knob(monkeypatch):
+    monkeypatch.delenv("UFR_SPLIT_CONV", raising=False)
+    assert sg.split_conv_products() == 0
+    monkeypatch.setenv("UFR_SPLIT_CONV", "3")
+    assert sg.split_conv_products() == 3
+    monkeypatch.setenv("UFR_SPLIT_CONV", "4")
+    with pytest.raises(ValueError):
+        sg.split_conv_products()
+    conv = torch.nn.Conv2d(64, 64, 3, 1, 1)
+    assert not sg.split_conv_applicable(torch.zeros(1, 64, 96, 96), conv)      # CPU tensors never qualify

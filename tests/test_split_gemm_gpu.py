@@ -96,3 +96,30 @@ def test_wide_tile_conv_equals_the_128x128_kernel(B, C, H, W, N):
         want = conv3x3_split(xp, wp, B, H, W, products)
         assert torch.equal(conv3x3_split(xp, wp, B, H, W, products, wide=True), want)
         assert torch.equal(conv3x3_split(chunk_major(xp), chunk_major(wp), B, H, W, products, chunked=True, wide=True), want)
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("UFR_EXPERIMENTAL"),
+                    reason="the UFR_SPLIT_CONV wiring has only run with emulated kernels (tests/test_split_conv_wiring_cpu.py)")
+@pytest.mark.parametrize("products,tol", [(6, 1e-5), (3, 5e-5)])
+def test_conv_leaky_through_the_split_kernels(monkeypatch, products, tol):
+    """One reference `conv` block (models/submodules.py:18-46) with UFR_SPLIT_CONV on and off: output and input gradient."""
+    from understanding_flow_robustness_amd.band_conv import conv_leaky
+    torch.manual_seed(0)
+    seq = torch.nn.Sequential(torch.nn.Conv2d(96, 160, 3, 1, 1), torch.nn.LeakyReLU(0.1)).to(DEV)
+    for p in seq.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(2, 96, 64, 96, device=DEV)
+    gy = torch.randn(2, 160, 64, 96, device=DEV)
+    outs = []
+    for knob in ("0", str(products)):
+        monkeypatch.setenv("UFR_SPLIT_CONV", knob)
+        xi = x.clone().requires_grad_(True)
+        y = conv_leaky(xi, seq)
+        (gx,) = torch.autograd.grad(y, xi, gy)
+        outs.append((y.detach(), gx))
+    (y0, g0), (y1, g1) = outs
+    assert float((y1 - y0).abs().max()) <= tol * float(y0.abs().max())
+    # LeakyReLU's slope flips where the pre-activation is within rounding of zero: compare away from those pixels
+    stable = y0.abs() > 1e-4
+    assert float(((y1 - y0) * stable).abs().max()) <= tol * float(y0.abs().max())
+    assert float((g1 - g0).abs().max()) <= 50 * tol * float(g0.abs().max())

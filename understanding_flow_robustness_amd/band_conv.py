@@ -16,6 +16,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib as L
+from .split_gemm import SplitConv3x3, split_conv_applicable, split_conv_products
 
 
 class Band:
@@ -249,7 +250,7 @@ def conv_relu(x, conv: torch.nn.Conv2d):
     then bias + ReLU as one in-place pass, under the same conditions as `conv_leaky`."""
     if (x.is_cuda and x.dtype == torch.float32 and conv.bias is not None
             and (_frozen(conv) or not torch.is_grad_enabled())):
-        y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        y = band_conv2d(x, conv, None, 0, with_bias=False)
         return _BiasLeaky.apply(y.contiguous(), conv.bias, 0.0)
     return F.relu(conv(x))
 
@@ -294,6 +295,10 @@ def band_conv2d(x, conv: torch.nn.Conv2d, band: Band | None, in_stride: int, wit
     per cell of x."""
     bias = conv.bias if with_bias else None
     if band is None or not band.width or not x.requires_grad:
+        products = split_conv_products()                       # UFR_SPLIT_CONV, off by default (split_gemm.py)
+        if products and (_frozen(conv) or not torch.is_grad_enabled()) and split_conv_applicable(x, conv):
+            y = SplitConv3x3.apply(x, conv.weight, products)
+            return y if bias is None else y + bias.view(1, -1, 1, 1)
         return F.conv2d(x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
     s, p = conv.stride[0], conv.padding[0]
     if conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1] or conv.dilation != (1, 1) or conv.groups != 1:

@@ -83,3 +83,55 @@ def conv3x3_split(x_planes: torch.Tensor, w_planes: torch.Tensor, B: int, H: int
     L.check(entry(L.ptr(x_planes), L.ptr(w_planes), L.ptr(y), B, H, W, cpad, npad, int(products), int(chunked), L.stream()),
             "split conv")
     return y
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Opt-in wiring (UFR_SPLIT_CONV=6|3|1, default off): Conv2d(C, N, 3, 1, 1) with frozen weights through the kernels
+# above.  A thin composition of the GPU-tested pieces (planes pass, convolution, its adjoint through the flipped
+# weights) plus torch layout copies; the composition itself is checked on the CPU with emulated kernels
+# (tests/test_split_conv_wiring_cpu.py).  Not measured inside a network yet: DESIGN.md 10, plan for round 2.
+_WEIGHT_PLANES: dict = {}
+
+
+def split_conv_products() -> int:
+    import os
+    v = int(os.environ.get("UFR_SPLIT_CONV", "0") or 0)
+    if v not in (0, 1, 3, 6):
+        raise ValueError("UFR_SPLIT_CONV must be 0 (off), 6, 3 or 1 bf16 products")
+    return v
+
+
+def split_conv_applicable(x: torch.Tensor, conv: torch.nn.Conv2d) -> bool:
+    """3x3 / stride 1 / padding 1 layers big enough for 128-row tiles to fill the chip."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels >= 32
+            and conv.out_channels >= 64 and x.shape[0] * x.shape[2] * x.shape[3] >= 8192)
+
+
+def _weight_planes(weight: torch.Tensor, adjoint: bool) -> torch.Tensor:
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), adjoint)
+    hit = _WEIGHT_PLANES.get(key)
+    if hit is None:
+        if len(_WEIGHT_PLANES) >= 512:
+            _WEIGHT_PLANES.clear()
+        hit = _WEIGHT_PLANES[key] = chunk_major(conv3x3_weight_planes(weight, data_gradient=adjoint))
+    return hit
+
+
+class SplitConv3x3(torch.autograd.Function):
+    """y = conv2d(x, weight, padding=1) without bias; d/dx through the same kernel; no weight gradient (frozen)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, products):
+        B, C, H, W = x.shape
+        xp = chunk_major(nchw_to_nhwc_split3(x.contiguous()))
+        y = conv3x3_split(xp, _weight_planes(weight, False), B, H, W, products, chunked=True)
+        ctx.weight, ctx.products, ctx.in_shape = weight, products, (B, C, H, W)
+        return y.view(B, H, W, -1)[..., : weight.shape[0]].permute(0, 3, 1, 2).contiguous()
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, C, H, W = ctx.in_shape
+        gp = chunk_major(nchw_to_nhwc_split3(gy.contiguous()))
+        gx = conv3x3_split(gp, _weight_planes(ctx.weight, True), B, H, W, ctx.products, chunked=True)
+        return gx.view(B, H, W, -1)[..., :C].permute(0, 3, 1, 2).contiguous(), None, None
