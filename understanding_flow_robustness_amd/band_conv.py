@@ -16,7 +16,8 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib as L
-from .split_gemm import SplitConv3x3, split_conv_applicable, split_conv_products
+from .split_gemm import (SplitConv3x3, split_conv3x3_forward, split_conv3x3_input_gradient, split_conv_applicable,
+                         split_conv_ok, split_conv_products)
 
 
 class Band:
@@ -63,11 +64,24 @@ def window_correlation(input1, input2, patch, dilation_patch, band: Band, in_str
     return _WindowCorrelation.apply(input1, input2, patch, dilation_patch, band, in_stride)
 
 
+def _conv_forward(x, weight, s, p):
+    """conv2d without bias inside the band Functions (no autograd here); UFR_SPLIT_CONV routes the 3x3 stride-1
+    layers through split_gemm.py."""
+    products = split_conv_products()
+    if products and split_conv_ok(x, weight, s, p):
+        return split_conv3x3_forward(x, weight, products)
+    return F.conv2d(x, weight, None, s, p)
+
+
 class _BandConv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, band, in_stride):
         ctx.save_for_backward(weight)
         ctx.meta = (tuple(x.shape), int(stride), int(padding), band, int(in_stride))
+        products = split_conv_products()
+        if products and split_conv_ok(x, weight, int(stride), int(padding)):
+            y = split_conv3x3_forward(x, weight, products)
+            return y if bias is None else y + bias.view(1, -1, 1, 1)
         return F.conv2d(x, weight, bias, stride, padding)
 
     @staticmethod
@@ -89,8 +103,12 @@ def _band_data_gradient(gy, weight, in_shape, s, p, band, ls_in):
     gyb = torch.empty(B, Cout, Ho, wob, dtype=gy.dtype, device=gy.device)
     L.check(lib.ufr_window_gather(L.ptr(gy), L.ptr(gyb), L.ptr(band.win), B, B, Cout, Ho, Wo, Ho, wob, ls_out, 0, st),
             "band gather")
-    gxb = torch.ops.aten.convolution_backward(gyb, gyb.new_empty((B, Cin, Hi, wib)), weight, None, (s, s), (p, p),
-                                              (1, 1), False, (0, 0), 1, (True, False, False))[0]
+    products = split_conv_products()
+    if products and split_conv_ok(gyb, weight.transpose(0, 1), s, p):          # the adjoint's channel roles
+        gxb = split_conv3x3_input_gradient(gyb, weight, products)
+    else:
+        gxb = torch.ops.aten.convolution_backward(gyb, gyb.new_empty((B, Cin, Hi, wib)), weight, None, (s, s), (p, p),
+                                                  (1, 1), False, (0, 0), 1, (True, False, False))[0]
     gx = torch.zeros(B, Cin, Hi, Wi, dtype=gy.dtype, device=gy.device)
     L.check(lib.ufr_window_scatter(L.ptr(gxb.contiguous()), L.ptr(gx), L.ptr(band.win), B, B, Cin, Hi, Wi, Hi, wib,
                                    ls_in, k - 1 - p, st), "band scatter")
@@ -113,7 +131,7 @@ class _IncrementalConvLeaky(torch.autograd.Function):
         xb = torch.empty(B, Cin, Hi, wib, dtype=x.dtype, device=x.device)
         L.check(lib.ufr_window_gather(L.ptr(x), L.ptr(xb), L.ptr(band.win), B, B, Cin, Hi, Wi, Hi, wib, in_stride, 0, st),
                 "band gather")
-        yb = F.conv2d(xb, weight, None, s, p).contiguous()
+        yb = _conv_forward(xb, weight, s, p).contiguous()
         L.check(lib.ufr_bias_leaky_forward(L.ptr(yb), L.ptr(bias), B, Cout, Ho * wob, float(slope), st), "bias leaky")
         L.check(lib.ufr_window_scatter(L.ptr(yb), L.ptr(cache), L.ptr(band.win), B, B, Cout, Ho, Wo, Ho, wob, ls_out,
                                        k - 1 - p, st), "band paste")

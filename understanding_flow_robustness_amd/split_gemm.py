@@ -105,7 +105,7 @@ def split_conv_applicable(x: torch.Tensor, conv: torch.nn.Conv2d) -> bool:
     """3x3 / stride 1 / padding 1 layers big enough for 128-row tiles to fill the chip."""
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
             and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels >= 32
-            and conv.out_channels >= 64 and x.shape[0] * x.shape[2] * x.shape[3] >= 8192)
+            and conv.out_channels >= 64 and x.shape[0] * x.shape[2] * x.shape[3] >= 4096)
 
 
 def _weight_planes(weight: torch.Tensor, adjoint: bool) -> torch.Tensor:
@@ -118,20 +118,37 @@ def _weight_planes(weight: torch.Tensor, adjoint: bool) -> torch.Tensor:
     return hit
 
 
+def split_conv_ok(x: torch.Tensor, weight: torch.Tensor, stride: int, padding: int) -> bool:
+    """The same test for call sites that hold the weight, not the module (the band machinery)."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3) and stride == 1
+            and padding == 1 and weight.shape[1] >= 32 and weight.shape[0] >= 64 and weight.shape[1] == x.shape[1]
+            and x.shape[0] * x.shape[2] * x.shape[3] >= 4096)
+
+
+def split_conv3x3_forward(x: torch.Tensor, weight: torch.Tensor, products: int) -> torch.Tensor:
+    """conv2d(x, weight, padding=1), no bias, NCHW in and out."""
+    B, _, H, W = x.shape
+    xp = chunk_major(nchw_to_nhwc_split3(x.contiguous()))
+    y = conv3x3_split(xp, _weight_planes(weight, False), B, H, W, products, chunked=True)
+    return y.view(B, H, W, -1)[..., : weight.shape[0]].permute(0, 3, 1, 2).contiguous()
+
+
+def split_conv3x3_input_gradient(gy: torch.Tensor, weight: torch.Tensor, products: int) -> torch.Tensor:
+    """d/dx of conv2d(x, weight, padding=1) given d/dy: the same kernel with the flipped, transposed weights."""
+    B, _, H, W = gy.shape
+    gp = chunk_major(nchw_to_nhwc_split3(gy.contiguous()))
+    gx = conv3x3_split(gp, _weight_planes(weight, True), B, H, W, products, chunked=True)
+    return gx.view(B, H, W, -1)[..., : weight.shape[1]].permute(0, 3, 1, 2).contiguous()
+
+
 class SplitConv3x3(torch.autograd.Function):
     """y = conv2d(x, weight, padding=1) without bias; d/dx through the same kernel; no weight gradient (frozen)."""
 
     @staticmethod
     def forward(ctx, x, weight, products):
-        B, C, H, W = x.shape
-        xp = chunk_major(nchw_to_nhwc_split3(x.contiguous()))
-        y = conv3x3_split(xp, _weight_planes(weight, False), B, H, W, products, chunked=True)
-        ctx.weight, ctx.products, ctx.in_shape = weight, products, (B, C, H, W)
-        return y.view(B, H, W, -1)[..., : weight.shape[0]].permute(0, 3, 1, 2).contiguous()
+        ctx.weight, ctx.products = weight, products
+        return split_conv3x3_forward(x, weight, products)
 
     @staticmethod
     def backward(ctx, gy):
-        B, C, H, W = ctx.in_shape
-        gp = chunk_major(nchw_to_nhwc_split3(gy.contiguous()))
-        gx = conv3x3_split(gp, _weight_planes(ctx.weight, True), B, H, W, ctx.products, chunked=True)
-        return gx.view(B, H, W, -1)[..., :C].permute(0, 3, 1, 2).contiguous(), None, None
+        return split_conv3x3_input_gradient(gy, ctx.weight, ctx.products), None, None
