@@ -210,6 +210,11 @@ int ufr_conv3x3_split(const void* x_planes, const void* w_planes, float* y, int 
  * (csrc/split_conv_wide.hip); N a multiple of 256. */
 int ufr_conv3x3_split_wide(const void* x_planes, const void* w_planes, float* y, int B, int H, int W, int Cpad, int N,
                            int products, int chunk_major, ufr_stream_t stream);
+/* EXPERIMENTAL layout passes around it: x [B,C,H,W] -> chunk-major planes [3][Cpad/32][B*H*W][32] in one pass;
+ * rows y [B*H*W][Npad] -> out [B,N,H,W] = act(y + bias[c]) (bias may be NULL; slope 1 = identity). */
+int ufr_nchw_to_planes_cm(const float* x, void* planes, int B, int C, int H, int W, int Cpad, ufr_stream_t stream);
+int ufr_rows_to_nchw(const float* y, const float* bias, float* out, int B, int N, int H, int W, int Npad, float slope,
+                     ufr_stream_t stream);
 
 /* ---- RAFT convex upsampling ------------------------------------------------------------------------
  * replaces RAFT.upsample_flow (models/raft/raft.py:111-122): flow [N,2,H,W], mask [N,576,H,W] (9 x 8 x 8 logits

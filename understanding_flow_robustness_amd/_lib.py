@@ -92,6 +92,8 @@ SIGNATURES = {
     "ufr_nchw_to_nhwc_split3": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ufr_conv3x3_split": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ufr_conv3x3_split_wide": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ufr_nchw_to_planes_cm": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "ufr_rows_to_nchw": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
     "ufr_convex_upsample_forward": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "ufr_convex_upsample_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ufr_affine_resample_f64": [_vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _d, _d, _d, _i, _vp],

@@ -112,6 +112,71 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// x[B][C][H*W] float32 -> chunk-major planes[3][Cpad/32][B*H*W][32] bf16 directly (split_gemm.hip's
+// nchw_to_nhwc_split3_kernel writes the row-major image, which torch then permutes: one pass saved per layer).
+__global__ __launch_bounds__(256) void nchw_to_planes_cm_kernel(const float* __restrict__ x, __bf16* __restrict__ planes,
+                                                                int B, int C, int HW, int Cpad) {
+  __shared__ float tile[32][65];
+  const int c0 = blockIdx.x * 32, p0 = blockIdx.y * 64, b = blockIdx.z, tid = threadIdx.x;
+  {
+    const int p = tid & 63;
+#pragma unroll
+    for (int cc = tid >> 6; cc < 32; cc += 4) {
+      const int c = c0 + cc;
+      tile[cc][p] = (c < C && p0 + p < HW) ? x[((size_t)b * C + c) * HW + p0 + p] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int p = tid >> 2, ch = tid & 3;
+  if (p0 + p >= HW) return;
+  const size_t rows = (size_t)B * HW, plane = rows * Cpad;
+  __bf16* dst = planes + ((size_t)blockIdx.x * rows + (size_t)b * HW + p0 + p) * 32 + ch * 8;
+  bf16x8 q0, q1, q2;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = tile[ch * 8 + j][p];
+    const __bf16 a = (__bf16)v;
+    const float r1 = v - (float)a;
+    const __bf16 bq = (__bf16)r1;
+    q0[j] = a;
+    q1[j] = bq;
+    q2[j] = (__bf16)(r1 - (float)bq);
+  }
+  *reinterpret_cast<bf16x8*>(dst) = q0;
+  *reinterpret_cast<bf16x8*>(dst + plane) = q1;
+  *reinterpret_cast<bf16x8*>(dst + 2 * plane) = q2;
+}
+
+// y[B*H*W][Npad] float32 (the convolution's NHWC rows) -> out[B][N][H*W] = act(y + bias[c]); bias may be null,
+// slope 1 = no activation (the data-gradient direction).
+__global__ __launch_bounds__(256) void rows_to_nchw_kernel(const float* __restrict__ y, const float* __restrict__ bias,
+                                                           float* __restrict__ out, int B, int N, int HW, int Npad,
+                                                           float slope) {
+  __shared__ float tile[32][65];
+  const int c0 = blockIdx.x * 32, p0 = blockIdx.y * 64, b = blockIdx.z, tid = threadIdx.x;
+  {
+    const int p = tid >> 2, q = tid & 3;
+    if (p0 + p < HW) {
+      const float4* src = reinterpret_cast<const float4*>(y + ((size_t)b * HW + p0 + p) * Npad + c0 + q * 8);
+      const float4 v0 = src[0], v1 = src[1];
+      tile[q * 8 + 0][p] = v0.x; tile[q * 8 + 1][p] = v0.y; tile[q * 8 + 2][p] = v0.z; tile[q * 8 + 3][p] = v0.w;
+      tile[q * 8 + 4][p] = v1.x; tile[q * 8 + 5][p] = v1.y; tile[q * 8 + 6][p] = v1.z; tile[q * 8 + 7][p] = v1.w;
+    }
+  }
+  __syncthreads();
+  const int p = tid & 63;
+  if (p0 + p >= HW) return;
+#pragma unroll
+  for (int cc = tid >> 6; cc < 32; cc += 4) {
+    const int c = c0 + cc;
+    if (c < N) {
+      float v = tile[cc][p] + (bias ? bias[c] : 0.f);
+      v = v > 0.f ? v : v * slope;
+      out[((size_t)b * N + c) * HW + p0 + p] = v;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int ufr_conv3x3_split_wide(const void* x_planes, const void* w_planes, float* y, int B, int H, int W,
@@ -132,4 +197,24 @@ extern "C" int ufr_conv3x3_split_wide(const void* x_planes, const void* w_planes
   else if (products == 3) conv3x3_split_wide_kernel<3><<<grid, 512, 0, st>>>(a, b, y, B, H, W, Cpad, N, rsA, ksA, rsB, ksB);
   else conv3x3_split_wide_kernel<1><<<grid, 512, 0, st>>>(a, b, y, B, H, W, Cpad, N, rsA, ksA, rsB, ksB);
   return ufr::launched("conv3x3_split_wide_kernel");
+}
+
+extern "C" int ufr_nchw_to_planes_cm(const float* x, void* planes, int B, int C, int H, int W, int Cpad,
+                                     ufr_stream_t stream) {
+  UFR_REQUIRE(x && planes, "nchw -> chunk-major planes: null pointer");
+  UFR_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C && Cpad % BK == 0 && B < 65536,
+              "nchw -> chunk-major planes: bad shape (Cpad must be a multiple of 32, >= C)");
+  const dim3 grid(Cpad / 32, (H * W + 63) / 64, B);
+  nchw_to_planes_cm_kernel<<<grid, 256, 0, ufr::as_stream(stream)>>>(x, static_cast<__bf16*>(planes), B, C, H * W, Cpad);
+  return ufr::launched("nchw_to_planes_cm_kernel");
+}
+
+extern "C" int ufr_rows_to_nchw(const float* y, const float* bias, float* out, int B, int N, int H, int W, int Npad,
+                                float slope, ufr_stream_t stream) {
+  UFR_REQUIRE(y && out, "rows -> nchw: null pointer");
+  UFR_REQUIRE(B > 0 && N > 0 && H > 0 && W > 0 && Npad >= N && Npad % 32 == 0 && B < 65536,
+              "rows -> nchw: bad shape (Npad must be a multiple of 32, >= N)");
+  const dim3 grid((N + 31) / 32, (H * W + 63) / 64, B);
+  rows_to_nchw_kernel<<<grid, 256, 0, ufr::as_stream(stream)>>>(y, bias, out, B, N, H * W, Npad, slope);
+  return ufr::launched("rows_to_nchw_kernel");
 }

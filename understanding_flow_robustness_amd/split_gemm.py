@@ -118,6 +118,31 @@ def _weight_planes(weight: torch.Tensor, adjoint: bool) -> torch.Tensor:
     return hit
 
 
+def _experimental() -> bool:
+    """UFR_EXPERIMENTAL=1: the kernels of csrc/split_conv_wide.hip (written after round 1's GPU budget, not yet run)."""
+    import os
+    return bool(os.environ.get("UFR_EXPERIMENTAL"))
+
+
+def nchw_to_planes_cm(x: torch.Tensor) -> torch.Tensor:
+    """EXPERIMENTAL: == chunk_major(nchw_to_nhwc_split3(x)) in one pass."""
+    L.require_hip(x, "x")
+    B, C, H, W = x.shape
+    planes = torch.empty(3, B * H * W, _pad32(C), dtype=torch.bfloat16, device=x.device)
+    L.check(L.lib().ufr_nchw_to_planes_cm(L.ptr(x), L.ptr(planes), B, C, H, W, _pad32(C), L.stream()), "nchw -> planes")
+    return planes
+
+
+def rows_to_nchw(y: torch.Tensor, B: int, N: int, H: int, W: int, bias: torch.Tensor | None = None,
+                 slope: float = 1.0) -> torch.Tensor:
+    """EXPERIMENTAL: the convolution's rows [B*H*W, Npad] -> [B,N,H,W], optionally + bias and LeakyReLU."""
+    L.require_hip(y, "y")
+    out = torch.empty(B, N, H, W, dtype=torch.float32, device=y.device)
+    L.check(L.lib().ufr_rows_to_nchw(L.ptr(y), L.ptr(bias) if bias is not None else None, L.ptr(out), B, N, H, W,
+                                     y.shape[1], float(slope), L.stream()), "rows -> nchw")
+    return out
+
+
 def split_conv_ok(x: torch.Tensor, weight: torch.Tensor, stride: int, padding: int) -> bool:
     """The same test for call sites that hold the weight, not the module (the band machinery)."""
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3) and stride == 1
@@ -128,6 +153,10 @@ def split_conv_ok(x: torch.Tensor, weight: torch.Tensor, stride: int, padding: i
 def split_conv3x3_forward(x: torch.Tensor, weight: torch.Tensor, products: int) -> torch.Tensor:
     """conv2d(x, weight, padding=1), no bias, NCHW in and out."""
     B, _, H, W = x.shape
+    if _experimental():
+        wp = _weight_planes(weight, False)
+        y = conv3x3_split(nchw_to_planes_cm(x.contiguous()), wp, B, H, W, products, chunked=True, wide=wp.shape[1] % 256 == 0)
+        return rows_to_nchw(y, B, weight.shape[0], H, W)
     xp = chunk_major(nchw_to_nhwc_split3(x.contiguous()))
     y = conv3x3_split(xp, _weight_planes(weight, False), B, H, W, products, chunked=True)
     return y.view(B, H, W, -1)[..., : weight.shape[0]].permute(0, 3, 1, 2).contiguous()
@@ -136,6 +165,10 @@ def split_conv3x3_forward(x: torch.Tensor, weight: torch.Tensor, products: int) 
 def split_conv3x3_input_gradient(gy: torch.Tensor, weight: torch.Tensor, products: int) -> torch.Tensor:
     """d/dx of conv2d(x, weight, padding=1) given d/dy: the same kernel with the flipped, transposed weights."""
     B, _, H, W = gy.shape
+    if _experimental():
+        wp = _weight_planes(weight, True)
+        gx = conv3x3_split(nchw_to_planes_cm(gy.contiguous()), wp, B, H, W, products, chunked=True, wide=wp.shape[1] % 256 == 0)
+        return rows_to_nchw(gx, B, weight.shape[1], H, W)
     gp = chunk_major(nchw_to_nhwc_split3(gy.contiguous()))
     gx = conv3x3_split(gp, _weight_planes(weight, True), B, H, W, products, chunked=True)
     return gx.view(B, H, W, -1)[..., : weight.shape[1]].permute(0, 3, 1, 2).contiguous()
