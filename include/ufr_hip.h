@@ -213,6 +213,10 @@ int ufr_conv3x3_split_wide(const void* x_planes, const void* w_planes, float* y,
 /* EXPERIMENTAL layout passes around it: x [B,C,H,W] -> chunk-major planes [3][Cpad/32][B*H*W][32] in one pass;
  * rows y [B*H*W][Npad] -> out [B,N,H,W] = act(y + bias[c]) (bias may be NULL; slope 1 = identity). */
 int ufr_nchw_to_planes_cm(const float* x, void* planes, int B, int C, int H, int W, int Cpad, ufr_stream_t stream);
+/* EXPERIMENTAL: forward Conv2d(C, N, (KH,KW), stride, pad) on the 128x128 tile; weight planes [3][N][KH*KW][Cpad];
+ * y [B*Ho*Wo][N] with Ho = (Hi + 2 pad - KH) / stride + 1. */
+int ufr_conv_split_general(const void* x_planes, const void* w_planes, float* y, int B, int Hi, int Wi, int Cpad, int N,
+                           int KH, int KW, int stride, int pad, int products, int chunk_major, ufr_stream_t stream);
 int ufr_rows_to_nchw(const float* y, const float* bias, float* out, int B, int N, int H, int W, int Npad, float slope,
                      ufr_stream_t stream);
 

@@ -140,3 +140,26 @@ def test_experimental_layout_passes(B, C, H, W):
     assert torch.equal(rows_to_nchw(rows, B, C, H, W), want)
     bias = torch.randn(C, generator=g).to(DEV)
     assert torch.equal(rows_to_nchw(rows, B, C, H, W, bias, 0.1), F.leaky_relu(want + bias.view(1, -1, 1, 1), 0.1))
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("UFR_EXPERIMENTAL"),
+                    reason="csrc/split_conv_wide.hip's general convolution has not run on hardware yet")
+@pytest.mark.parametrize("B,C,Hi,Wi,N,k,s,p", [(2, 40, 13, 20, 100, 3, 2, 1), (1, 64, 17, 23, 128, 5, 2, 2),
+                                              (2, 3, 30, 41, 64, 7, 2, 3), (2, 96, 9, 11, 256, 1, 1, 0),
+                                              (1, 48, 12, 16, 128, 3, 1, 1)])
+def test_general_split_conv_matches_float64(B, C, Hi, Wi, N, k, s, p):
+    import torch.nn.functional as F
+    from understanding_flow_robustness_amd.split_gemm import (chunk_major, conv_split_general, conv_weight_planes,
+                                                              nchw_to_nhwc_split3)
+    g = torch.Generator().manual_seed(k * 10 + s)
+    x = torch.randn(B, C, Hi, Wi, generator=g)
+    w = torch.randn(N, C, k, k, generator=g) * (2.0 / (k * k * C)) ** 0.5
+    ref = F.conv2d(x.double(), w.double(), stride=s, padding=p)
+    Ho, Wo = ref.shape[2:]
+    xp, wp = nchw_to_nhwc_split3(x.to(DEV)), conv_weight_planes(w.to(DEV))
+    y = conv_split_general(xp, wp, B, Hi, Wi, (k, k), s, p, 6)
+    yc = conv_split_general(chunk_major(xp), chunk_major(wp), B, Hi, Wi, (k, k), s, p, 6, chunked=True)
+    assert torch.equal(y, yc)
+    y = y[:, :N].reshape(B, Ho, Wo, N).permute(0, 3, 1, 2)
+    err = float((y.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+    assert err <= 4e-6, f"{err:.3e}"

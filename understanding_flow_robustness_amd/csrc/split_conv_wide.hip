@@ -112,6 +112,103 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// General forward convolution (KH x KW taps, stride s, padding p, no dilation / groups) on the measured 128 x 128
+// tile of split_gemm.hip: the tile rows are OUTPUT pixels, a tap's row is the input pixel (yo*s + ky - p,
+// xo*s + kx - p).  For the strided 3x3 / 5x5 / 7x7 layers and 1x1 projections; their adjoints (transposed
+// convolutions) are not this kernel.
+constexpr int GM = 128, GN = 128;
+
+template <int NPROD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_split_general_kernel(
+    const __bf16* __restrict__ Xp, const __bf16* __restrict__ Wp, float* __restrict__ Y, int B, int Hi, int Wi, int Ho,
+    int Wo, int Cpad, int N, int KH, int KW, int stride, int pad, long rsA, long ksA, long rsB, long ksB) {
+  constexpr int NPL = NPROD == 1 ? 1 : (NPROD == 3 ? 2 : 3);
+  constexpr int FIRST = 6 - NPROD;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * NPL][GM * BK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int bm = blockIdx.y * GM, bn = blockIdx.x * GN;
+  const int M = B * Ho * Wo, Min = B * Hi * Wi, KC = Cpad / BK, KT = KH * KW * KC;
+  const size_t planeA = (size_t)Min * Cpad, planeB = (size_t)N * KH * KW * Cpad;
+
+  const int srow0 = tid >> 2, sch = tid & 3;
+  int ybase[2], xbase[2], ibase[2];                 // input row / column of tap (0,0), and the image's first pixel
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pm = bm + srow0 + 64 * i;
+    const int xo = pm % Wo, yo = (pm / Wo) % Ho, b = pm / (Wo * Ho);
+    xbase[i] = xo * stride - pad;
+    ybase[i] = pm < M ? yo * stride - pad : -(1 << 20);    // rows past the end never pass the bounds test
+    ibase[i] = pm < M ? b * Hi * Wi : 0;
+  }
+  u32x4 sa[NPL][2], sb[NPL][2];
+  const __bf16* gb = Wp + (size_t)(bn + srow0) * rsB + sch * 8;
+  const int soff0 = srow0 * BK + ((sch ^ ((srow0 >> 1) & 3)) << 3);
+#define UFR_GC_LOAD(kt)                                                                               \
+  {                                                                                                   \
+    const int tap = (kt) / KC, kc = (kt) - tap * KC, ky = tap / KW, kx = tap - ky * KW;                \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                   \
+      const int yi = ybase[i] + ky, xi = xbase[i] + kx;                                               \
+      const bool ok = (unsigned)yi < (unsigned)Hi && (unsigned)xi < (unsigned)Wi;                      \
+      const __bf16* src = Xp + (size_t)(ok ? ibase[i] + yi * Wi + xi : 0) * rsA + kc * ksA + sch * 8;  \
+      _Pragma("unroll") for (int p = 0; p < NPL; ++p) {                                               \
+        const u32x4 v = *reinterpret_cast<const u32x4*>(src + p * planeA);                            \
+        sa[p][i] = ok ? v : u32x4{0u, 0u, 0u, 0u};                                                    \
+        sb[p][i] = *reinterpret_cast<const u32x4*>(gb + p * planeB + (size_t)(64 * i) * rsB + (kt) * ksB);    \
+      }                                                                                               \
+    }                                                                                                 \
+  }
+#define UFR_GC_STORE()                                                                              \
+  _Pragma("unroll") for (int p = 0; p < NPL; ++p) _Pragma("unroll") for (int i = 0; i < 2; ++i) {   \
+    *reinterpret_cast<u32x4*>(&lds[p][soff0 + 64 * i * BK]) = sa[p][i];                             \
+    *reinterpret_cast<u32x4*>(&lds[NPL + p][soff0 + 64 * i * BK]) = sb[p][i];                       \
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15;
+  const int foff = frow * BK + ((((lane >> 4)) ^ ((frow >> 1) & 3)) << 3);
+
+  UFR_GC_LOAD(0)
+  for (int kt = 0; kt < KT; ++kt) {
+    __syncthreads();
+    UFR_GC_STORE()
+    __syncthreads();
+    if (kt + 1 < KT) UFR_GC_LOAD(kt + 1)
+    bf16x8 a[NPL][4];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        a[p][m] = *reinterpret_cast<const bf16x8*>(&lds[p][(wr * 64 + m * 16) * BK + foff]);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      bf16x8 b[NPL];
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) b[p] = *reinterpret_cast<const bf16x8*>(&lds[NPL + p][(wc * 64 + n * 16) * BK + foff]);
+#pragma unroll
+      for (int t = FIRST; t < 6; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PROD_A[t]][m], b[PROD_B[t]], acc[m][n], 0, 0, 0);
+    }
+  }
+#undef UFR_GC_LOAD
+#undef UFR_GC_STORE
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = bm + wr * 64 + m * 16 + (lane >> 4) * 4 + j;
+      if (row < M) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) Y[(size_t)row * N + bn + wc * 64 + n * 16 + (lane & 15)] = acc[m][n][j];
+      }
+    }
+}
+
 // x[B][C][H*W] float32 -> chunk-major planes[3][Cpad/32][B*H*W][32] bf16 directly (split_gemm.hip's
 // nchw_to_nhwc_split3_kernel writes the row-major image, which torch then permutes: one pass saved per layer).
 __global__ __launch_bounds__(256) void nchw_to_planes_cm_kernel(const float* __restrict__ x, __bf16* __restrict__ planes,
@@ -217,4 +314,34 @@ extern "C" int ufr_rows_to_nchw(const float* y, const float* bias, float* out, i
   const dim3 grid((N + 31) / 32, (H * W + 63) / 64, B);
   rows_to_nchw_kernel<<<grid, 256, 0, ufr::as_stream(stream)>>>(y, bias, out, B, N, H * W, Npad, slope);
   return ufr::launched("rows_to_nchw_kernel");
+}
+
+extern "C" int ufr_conv_split_general(const void* x_planes, const void* w_planes, float* y, int B, int Hi, int Wi,
+                                      int Cpad, int N, int KH, int KW, int stride, int pad, int products,
+                                      int chunk_major, ufr_stream_t stream) {
+  UFR_REQUIRE(x_planes && w_planes && y, "split conv (general): null pointer");
+  UFR_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Cpad > 0 && Cpad % BK == 0 && N > 0 && N % GN == 0,
+              "split conv (general): Cpad must be a multiple of 32, the output channels of 128");
+  UFR_REQUIRE(KH > 0 && KW > 0 && KH <= 11 && KW <= 11 && stride > 0 && pad >= 0 && pad < KH && pad < KW,
+              "split conv (general): bad kernel / stride / padding");
+  const int Ho = (Hi + 2 * pad - KH) / stride + 1, Wo = (Wi + 2 * pad - KW) / stride + 1;
+  UFR_REQUIRE(Ho > 0 && Wo > 0, "split conv (general): empty output");
+  UFR_REQUIRE((long)B * Hi * Wi < (1L << 31) / 2, "split conv (general): too many pixels");
+  UFR_REQUIRE(products == 6 || products == 3 || products == 1, "split conv (general): products must be 6, 3 or 1");
+  const int M = B * Ho * Wo;
+  const dim3 grid(N / GN, (M + GM - 1) / GM);
+  hipStream_t st = ufr::as_stream(stream);
+  const __bf16* a = static_cast<const __bf16*>(x_planes);
+  const __bf16* b = static_cast<const __bf16*>(w_planes);
+  const long Min = (long)B * Hi * Wi, K = (long)KH * KW * Cpad;
+  const long rsA = chunk_major ? BK : Cpad, ksA = chunk_major ? Min * BK : BK;
+  const long rsB = chunk_major ? BK : K, ksB = chunk_major ? (long)N * BK : BK;
+#define UFR_GC_LAUNCH(P)                                                                                             \
+  conv_split_general_kernel<P><<<grid, 256, 0, st>>>(a, b, y, B, Hi, Wi, Ho, Wo, Cpad, N, KH, KW, stride, pad, rsA, ksA, \
+                                                     rsB, ksB)
+  if (products == 6) UFR_GC_LAUNCH(6);
+  else if (products == 3) UFR_GC_LAUNCH(3);
+  else UFR_GC_LAUNCH(1);
+#undef UFR_GC_LAUNCH
+  return ufr::launched("conv_split_general_kernel");
 }

@@ -143,6 +143,34 @@ def rows_to_nchw(y: torch.Tensor, B: int, N: int, H: int, W: int, bias: torch.Te
     return out
 
 
+def conv_weight_planes(weight: torch.Tensor) -> torch.Tensor:
+    """EXPERIMENTAL companion of `conv_split_general`: Conv2d weight [N,C,KH,KW] -> [3, Npad, KH*KW*Cpad] planes in
+    (tap, channel) order."""
+    N, C, KH, KW = weight.shape
+    npad, cpad = (N + 127) // 128 * 128, _pad32(C)
+    w = torch.zeros(npad, KH, KW, cpad, dtype=torch.float32, device=weight.device)
+    w[:N, :, :, :C] = weight.detach().float().permute(0, 2, 3, 1)
+    return split_bf16x3(w.reshape(npad, KH * KW * cpad).contiguous())
+
+
+def conv_split_general(x_planes: torch.Tensor, w_planes: torch.Tensor, B: int, Hi: int, Wi: int, kernel: tuple, stride: int,
+                       padding: int, products: int = 6, chunked: bool = False) -> torch.Tensor:
+    """EXPERIMENTAL: forward convolution with any kernel size / stride -> rows [B*Ho*Wo, Npad] float32."""
+    L.require_hip(x_planes, "x_planes")
+    L.require_hip(w_planes, "w_planes")
+    KH, KW = kernel
+    _, Min, cpad = x_planes.shape
+    _, npad, k = w_planes.shape
+    if Min != B * Hi * Wi or k != KH * KW * cpad:
+        raise RuntimeError("conv_split_general: plane shapes do not match")
+    Ho, Wo = (Hi + 2 * padding - KH) // stride + 1, (Wi + 2 * padding - KW) // stride + 1
+    y = torch.empty(B * Ho * Wo, npad, dtype=torch.float32, device=x_planes.device)
+    L.check(L.lib().ufr_conv_split_general(L.ptr(x_planes), L.ptr(w_planes), L.ptr(y), B, Hi, Wi, cpad, npad, KH, KW,
+                                           int(stride), int(padding), int(products), int(chunked), L.stream()),
+            "split conv (general)")
+    return y
+
+
 def split_conv_ok(x: torch.Tensor, weight: torch.Tensor, stride: int, padding: int) -> bool:
     """The same test for call sites that hold the weight, not the module (the band machinery)."""
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3) and stride == 1
