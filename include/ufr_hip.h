@@ -217,6 +217,12 @@ int ufr_nchw_to_planes_cm(const float* x, void* planes, int B, int C, int H, int
  * y [B*Ho*Wo][N] with Ho = (Hi + 2 pad - KH) / stride + 1. */
 int ufr_conv_split_general(const void* x_planes, const void* w_planes, float* y, int B, int Hi, int Wi, int Cpad, int N,
                            int KH, int KW, int stride, int pad, int products, int chunk_major, ufr_stream_t stream);
+/* EXPERIMENTAL: stride-2 transposed convolution (ConvTranspose2d(., ., 4, 2, 1), models/submodules.py:75-82, and the
+ * data gradients of the stride-2 Conv2d layers) as four phase GEMMs.  x: chunk-major planes of the coarse tensor;
+ * w_planes: [3][w_plane_elems], per phase a [taps*Cpad/32][N][32] image; plan_host (host memory): 4 x 36 longs =
+ * per phase {ntaps, oy0, ox0, weight offset, 16 x (dy, dx)}; y [B*2Hi*2Wi][N]. */
+int ufr_deconv_split(const void* x_planes_cm, const void* w_planes, float* y, int B, int Hi, int Wi, int Cpad, int N,
+                     long w_plane_elems, const long* plan_host, int products, ufr_stream_t stream);
 int ufr_rows_to_nchw(const float* y, const float* bias, float* out, int B, int N, int H, int W, int Npad, float slope,
                      ufr_stream_t stream);
 

@@ -84,3 +84,66 @@ def test_split_conv_knob(monkeypatch):
         sg.split_conv_products()
     conv = torch.nn.Conv2d(64, 64, 3, 1, 1)
     assert not sg.split_conv_applicable(torch.zeros(1, 64, 96, 96), conv)      # CPU tensors never qualify
+
+
+@pytest.mark.parametrize("K,p", [(4, 1), (3, 1), (5, 2), (7, 3)])
+def test_deconv_plan_reproduces_conv_transpose2d(K, p):
+    """The four-phase gather plan executed with dense torch ops (the HIP kernel executes the same plan)."""
+    g = torch.Generator().manual_seed(K)
+    B, C, N, H, W = 2, 5, 7, 6, 9
+    x = torch.randn(B, C, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(C, N, K, K, generator=g, dtype=torch.float64)
+    want = F.conv_transpose2d(x, w, stride=2, padding=p, output_padding=2 + 2 * p - K)
+    assert want.shape == (B, N, 2 * H, 2 * W)
+    got = torch.zeros_like(want)
+    seen = set()
+    for oy0, ox0, taps in sg.deconv_plan(K, p):
+        for ky, kx, dy, dx in taps:
+            seen.add((ky, kx))
+            shifted = torch.zeros_like(x)                       # shifted[qy, qx] = x[qy + dy, qx + dx], zero outside
+            ys, xs = slice(max(0, -dy), min(H, H - dy)), slice(max(0, -dx), min(W, W - dx))
+            yd, xd = slice(max(0, dy), min(H, H + dy)), slice(max(0, dx), min(W, W + dx))
+            shifted[:, :, ys, xs] = x[:, :, yd, xd]
+            got[:, :, oy0::2, ox0::2] += torch.einsum("bchw,cn->bnhw", shifted, w[:, :, ky, kx])
+    assert len(seen) == K * K                                   # every tap belongs to exactly one phase
+    assert float((got - want).abs().max()) <= 1e-12 * float(want.abs().max())
+    # a stride-2 Conv2d's data gradient is the same plan on the same weight tensor
+    xin = torch.randn(B, N, 2 * H, 2 * W, generator=g, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(xin, w, stride=2, padding=p) if K != 4 else None
+    if y is not None and y.shape[2:] == (H, W):
+        (gx,) = torch.autograd.grad(y, xin, x)
+        assert float((gx - want).abs().max()) <= 1e-12 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("K,p", [(4, 1), (3, 1)])
+def test_deconv_weight_image_as_the_kernel_addresses_it(emulated, K, p):
+    """`deconv_weight_planes` + the plan, read back with csrc/split_conv_wide.hip::deconv_split_kernel's address
+    arithmetic (weights: off[z] + (kt*N + n)*32 + j with kt = tap*KC + kc; activations: chunk-major [KC][M][32])."""
+    g = torch.Generator().manual_seed(K + 40)
+    B, C, N, H, W = 2, 40, 70, 5, 6
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, N, K, K, generator=g)
+    want = F.conv_transpose2d(x.double(), w.double(), stride=2, padding=p, output_padding=2 + 2 * p - K)
+    planes, offsets, npad, cpad = sg.deconv_weight_planes(w, p)
+    wflat = planes.float().sum(0).double()                                    # [total]
+    xcm = sg.chunk_major(_emu_to_planes(x)).float().sum(0).double()           # chunk-major image of [M][cpad]
+    M, KC = B * H * W, cpad // 32
+    xcm = xcm.view(KC, M, 32)
+    out = torch.zeros(B, 2 * H, 2 * W, npad, dtype=torch.float64)
+    pix = torch.arange(M)
+    qx, qy, qb = pix % W, (pix // W) % H, pix // (W * H)
+    for z, ((oy0, ox0, taps), off) in enumerate(zip(sg.deconv_plan(K, p), offsets)):
+        acc = torch.zeros(M, npad, dtype=torch.float64)
+        for t, (_, _, dy, dx) in enumerate(taps):
+            yi, xi = qy + dy, qx + dx
+            ok = (yi >= 0) & (yi < H) & (xi >= 0) & (xi < W)
+            src = torch.where(ok, qb * H * W + yi * W + xi, torch.zeros_like(pix))
+            for kc in range(KC):
+                a = xcm[kc][src] * ok[:, None]                                # [M,32]
+                kt = t * KC + kc
+                bmat = wflat[off + kt * npad * 32: off + (kt + 1) * npad * 32].view(npad, 32)
+                acc += a @ bmat.t()
+        out[qb, 2 * qy + oy0, 2 * qx + ox0] = acc
+    got = out[..., :N].permute(0, 3, 1, 2)
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    assert float(out[..., N:].abs().max()) == 0.0

@@ -163,3 +163,21 @@ def test_general_split_conv_matches_float64(B, C, Hi, Wi, N, k, s, p):
     y = y[:, :N].reshape(B, Ho, Wo, N).permute(0, 3, 1, 2)
     err = float((y.cpu().double() - ref).abs().max()) / float(ref.abs().max())
     assert err <= 4e-6, f"{err:.3e}"
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("UFR_EXPERIMENTAL"),
+                    reason="csrc/split_conv_wide.hip's transposed convolution has not run on hardware yet")
+@pytest.mark.parametrize("B,C,H,W,N,K,p", [(2, 40, 6, 10, 100, 4, 1), (1, 64, 12, 20, 128, 3, 1), (2, 96, 5, 8, 64, 5, 2)])
+def test_deconv_split_matches_float64(B, C, H, W, N, K, p):
+    import torch.nn.functional as F
+    from understanding_flow_robustness_amd.split_gemm import (chunk_major, deconv_split, deconv_weight_planes,
+                                                              nchw_to_nhwc_split3)
+    g = torch.Generator().manual_seed(K * 7 + C)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, N, K, K, generator=g) * (4.0 / (K * K * C)) ** 0.5
+    ref = F.conv_transpose2d(x.double(), w.double(), stride=2, padding=p, output_padding=2 + 2 * p - K)
+    wp, offsets, npad, _ = deconv_weight_planes(w.to(DEV), p)
+    y = deconv_split(chunk_major(nchw_to_nhwc_split3(x.to(DEV))), wp, offsets, npad, B, H, W, K, p, 6)
+    y = y[:, :N].reshape(B, 2 * H, 2 * W, N).permute(0, 3, 1, 2)
+    err = float((y.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+    assert err <= 4e-6, f"{err:.3e}"

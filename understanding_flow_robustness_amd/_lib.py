@@ -94,6 +94,7 @@ SIGNATURES = {
     "ufr_conv3x3_split_wide": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ufr_nchw_to_planes_cm": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ufr_conv_split_general": [_vp, _vp, _vp] + [_i] * 11 + [_vp],
+    "ufr_deconv_split": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _l, _vp, _i, _vp],
     "ufr_rows_to_nchw": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
     "ufr_convex_upsample_forward": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "ufr_convex_upsample_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],

@@ -209,6 +209,108 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// Stride-2 transposed convolution by phases (split_gemm.py::deconv_plan): blockIdx.z = phase; the tile rows are the
+// COARSE pixels q, every tap reads coarse pixel q + (dy, dx), the result lands on fine pixel (2qy + oy0, 2qx + ox0).
+// Chunk-major planes only; weights: per phase a [taps*Cpad/32][N][32] image at w_off[phase].
+struct DeconvPlan {
+  int ntaps[4], oy0[4], ox0[4];
+  int dy[4][16], dx[4][16];
+  long w_off[4];
+};
+
+template <int NPROD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void deconv_split_kernel(
+    const __bf16* __restrict__ Xp, const __bf16* __restrict__ Wp, float* __restrict__ Y, int B, int Hi, int Wi, int Cpad,
+    int N, long planeB, DeconvPlan plan) {
+  constexpr int NPL = NPROD == 1 ? 1 : (NPROD == 3 ? 2 : 3);
+  constexpr int FIRST = 6 - NPROD;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * NPL][GM * BK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int bm = blockIdx.y * GM, bn = blockIdx.x * GN, z = blockIdx.z;
+  const int M = B * Hi * Wi, KC = Cpad / BK, KT = plan.ntaps[z] * KC;
+  const size_t planeA = (size_t)M * Cpad;
+
+  const int srow0 = tid >> 2, sch = tid & 3;
+  int qy[2], qx[2], ibase[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pm = bm + srow0 + 64 * i;
+    qx[i] = pm % Wi;
+    qy[i] = pm < M ? (pm / Wi) % Hi : -(1 << 20);
+    ibase[i] = pm < M ? (pm / (Wi * Hi)) * Hi * Wi : 0;
+  }
+  u32x4 sa[NPL][2], sb[NPL][2];
+  const __bf16* gb = Wp + plan.w_off[z] + (size_t)(bn + srow0) * BK + sch * 8;
+  const int soff0 = srow0 * BK + ((sch ^ ((srow0 >> 1) & 3)) << 3);
+#define UFR_DC_LOAD(kt)                                                                               \
+  {                                                                                                   \
+    const int tap = (kt) / KC, kc = (kt) - tap * KC, dyo = plan.dy[z][tap], dxo = plan.dx[z][tap];     \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                   \
+      const int yi = qy[i] + dyo, xi = qx[i] + dxo;                                                   \
+      const bool ok = (unsigned)yi < (unsigned)Hi && (unsigned)xi < (unsigned)Wi;                      \
+      const __bf16* src = Xp + ((size_t)kc * M + (ok ? ibase[i] + yi * Wi + xi : 0)) * BK + sch * 8;   \
+      _Pragma("unroll") for (int p = 0; p < NPL; ++p) {                                               \
+        const u32x4 v = *reinterpret_cast<const u32x4*>(src + p * planeA);                            \
+        sa[p][i] = ok ? v : u32x4{0u, 0u, 0u, 0u};                                                    \
+        sb[p][i] = *reinterpret_cast<const u32x4*>(gb + p * planeB + ((size_t)(kt) * N + 64 * i) * BK); \
+      }                                                                                               \
+    }                                                                                                 \
+  }
+#define UFR_DC_STORE()                                                                              \
+  _Pragma("unroll") for (int p = 0; p < NPL; ++p) _Pragma("unroll") for (int i = 0; i < 2; ++i) {   \
+    *reinterpret_cast<u32x4*>(&lds[p][soff0 + 64 * i * BK]) = sa[p][i];                             \
+    *reinterpret_cast<u32x4*>(&lds[NPL + p][soff0 + 64 * i * BK]) = sb[p][i];                       \
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15;
+  const int foff = frow * BK + ((((lane >> 4)) ^ ((frow >> 1) & 3)) << 3);
+
+  UFR_DC_LOAD(0)
+  for (int kt = 0; kt < KT; ++kt) {
+    __syncthreads();
+    UFR_DC_STORE()
+    __syncthreads();
+    if (kt + 1 < KT) UFR_DC_LOAD(kt + 1)
+    bf16x8 a[NPL][4];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        a[p][m] = *reinterpret_cast<const bf16x8*>(&lds[p][(wr * 64 + m * 16) * BK + foff]);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      bf16x8 b[NPL];
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) b[p] = *reinterpret_cast<const bf16x8*>(&lds[NPL + p][(wc * 64 + n * 16) * BK + foff]);
+#pragma unroll
+      for (int t = FIRST; t < 6; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PROD_A[t]][m], b[PROD_B[t]], acc[m][n], 0, 0, 0);
+    }
+  }
+#undef UFR_DC_LOAD
+#undef UFR_DC_STORE
+  const int oy0 = plan.oy0[z], ox0 = plan.ox0[z];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = bm + wr * 64 + m * 16 + (lane >> 4) * 4 + j;
+      if (row < M) {
+        const int x = row % Wi, y = (row / Wi) % Hi, b = row / (Wi * Hi);
+        const size_t orow = ((size_t)b * 2 * Hi + 2 * y + oy0) * (2 * Wi) + 2 * x + ox0;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) Y[orow * N + bn + wc * 64 + n * 16 + (lane & 15)] = acc[m][n][j];
+      }
+    }
+}
+
 // x[B][C][H*W] float32 -> chunk-major planes[3][Cpad/32][B*H*W][32] bf16 directly (split_gemm.hip's
 // nchw_to_nhwc_split3_kernel writes the row-major image, which torch then permutes: one pass saved per layer).
 __global__ __launch_bounds__(256) void nchw_to_planes_cm_kernel(const float* __restrict__ x, __bf16* __restrict__ planes,
@@ -344,4 +446,36 @@ extern "C" int ufr_conv_split_general(const void* x_planes, const void* w_planes
   else UFR_GC_LAUNCH(1);
 #undef UFR_GC_LAUNCH
   return ufr::launched("conv_split_general_kernel");
+}
+
+/* plan: 4 phases x (ntaps, oy0, ox0, w_off, then 16 x (dy, dx)) = 4 x 36 longs, as split_gemm.py::deconv_plan lays it out */
+extern "C" int ufr_deconv_split(const void* x_planes_cm, const void* w_planes, float* y, int B, int Hi, int Wi, int Cpad,
+                                int N, long w_plane_elems, const long* plan_host, int products, ufr_stream_t stream) {
+  UFR_REQUIRE(x_planes_cm && w_planes && y && plan_host, "split deconv: null pointer");
+  UFR_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Cpad > 0 && Cpad % BK == 0 && N > 0 && N % GN == 0 && w_plane_elems > 0,
+              "split deconv: Cpad must be a multiple of 32, the output channels of 128");
+  UFR_REQUIRE((long)B * Hi * Wi < (1L << 31) / 8, "split deconv: too many pixels");
+  UFR_REQUIRE(products == 6 || products == 3 || products == 1, "split deconv: products must be 6, 3 or 1");
+  DeconvPlan plan;
+  for (int z = 0; z < 4; ++z) {
+    const long* q = plan_host + z * 36;
+    UFR_REQUIRE(q[0] >= 1 && q[0] <= 16 && (q[1] | 1) == 1 && (q[2] | 1) == 1 && q[3] >= 0 &&
+                    q[3] + q[0] * (long)Cpad * N <= w_plane_elems,
+                "split deconv: bad plan");
+    plan.ntaps[z] = (int)q[0]; plan.oy0[z] = (int)q[1]; plan.ox0[z] = (int)q[2]; plan.w_off[z] = q[3];
+    for (int t = 0; t < 16; ++t) {
+      const long dy = t < q[0] ? q[4 + 2 * t] : 0, dx = t < q[0] ? q[5 + 2 * t] : 0;
+      UFR_REQUIRE(dy >= -8 && dy <= 8 && dx >= -8 && dx <= 8, "split deconv: bad tap offset");
+      plan.dy[z][t] = (int)dy; plan.dx[z][t] = (int)dx;
+    }
+  }
+  const int M = B * Hi * Wi;
+  const dim3 grid(N / GN, (M + GM - 1) / GM, 4);
+  hipStream_t st = ufr::as_stream(stream);
+  const __bf16* a = static_cast<const __bf16*>(x_planes_cm);
+  const __bf16* b = static_cast<const __bf16*>(w_planes);
+  if (products == 6) deconv_split_kernel<6><<<grid, 256, 0, st>>>(a, b, y, B, Hi, Wi, Cpad, N, w_plane_elems, plan);
+  else if (products == 3) deconv_split_kernel<3><<<grid, 256, 0, st>>>(a, b, y, B, Hi, Wi, Cpad, N, w_plane_elems, plan);
+  else deconv_split_kernel<1><<<grid, 256, 0, st>>>(a, b, y, B, Hi, Wi, Cpad, N, w_plane_elems, plan);
+  return ufr::launched("deconv_split_kernel");
 }

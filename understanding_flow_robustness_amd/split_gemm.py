@@ -213,3 +213,66 @@ class SplitConv3x3(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         return split_conv3x3_input_gradient(gy, ctx.weight, ctx.products), None, None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Stride-2 transposed convolutions (the decoder's ConvTranspose2d(., ., 4, 2, 1) and the data gradients of the stride-2
+# Conv2d layers) as four ordinary gathers: output pixel (2*qy + oy0, 2*qx + ox0) of phase (oy0, ox0) sums the taps
+# ky = ry + 2*ty, ry = (oy0 + p) % 2, reading input row qy + cy - ty with cy = (oy0 + p - ry) / 2.  The plan is pure
+# index arithmetic (checked on the CPU against F.conv_transpose2d, tests/test_split_conv_wiring_cpu.py); the kernel
+# that executes it (csrc/split_conv_wide.hip, ufr_deconv_split) is EXPERIMENTAL like the rest of that file.
+def deconv_plan(kernel: int, padding: int):
+    """-> list of 4 phases (oy0, ox0, taps) with taps = [(ky, kx, dy, dx)]: out[2qy+oy0, 2qx+ox0] += w[ky,kx] * x[qy+dy, qx+dx].
+    Output size is exactly twice the input size (output_padding = 2 + 2*padding - kernel, 0 or 1)."""
+    if not 0 <= 2 + 2 * padding - kernel <= 1:
+        raise ValueError("deconv_plan: kernel / padding do not give an output of twice the input size")
+    phases = []
+    for oy0 in (0, 1):
+        for ox0 in (0, 1):
+            ry, rx = (oy0 + padding) % 2, (ox0 + padding) % 2
+            cy, cx = (oy0 + padding - ry) // 2, (ox0 + padding - rx) // 2
+            taps = [(ky, kx, cy - (ky - ry) // 2, cx - (kx - rx) // 2)
+                    for ky in range(ry, kernel, 2) for kx in range(rx, kernel, 2)]
+            phases.append((oy0, ox0, taps))
+    return phases
+
+
+def deconv_weight_planes(weight: torch.Tensor, padding: int):
+    """ConvTranspose2d weight [Cin, Cout, K, K] (== a Conv2d weight [N, C, K, K] read as its own adjoint) ->
+    (planes [3, total] bf16, per-phase element offsets, Npad, Cpad): for every phase a chunk-major
+    [taps*Cpad/32][Npad][32] image, concatenated."""
+    cin, cout, K, _ = weight.shape
+    npad, cpad = (cout + 127) // 128 * 128, _pad32(cin)
+    images, offsets, total = [], [], 0
+    for _, _, taps in deconv_plan(K, padding):
+        w = torch.zeros(npad, len(taps), cpad, dtype=torch.float32, device=weight.device)
+        for t, (ky, kx, _, _) in enumerate(taps):
+            w[:cout, t, :cin] = weight.detach().float()[:, :, ky, kx].t()
+        img = w.view(npad, len(taps) * cpad // 32, 32).permute(1, 0, 2).contiguous().view(-1)      # chunk-major
+        offsets.append(total)
+        total += img.numel()
+        images.append(img)
+    return split_bf16x3(torch.cat(images)), offsets, npad, cpad
+
+
+def deconv_split(x_planes_cm: torch.Tensor, w_planes: torch.Tensor, offsets, npad: int, B: int, Hi: int, Wi: int, kernel: int,
+                 padding: int, products: int = 6) -> torch.Tensor:
+    """EXPERIMENTAL: rows [B*2Hi*2Wi, Npad] of the stride-2 transposed convolution; `x_planes_cm` = chunk-major planes
+    of the coarse tensor, `w_planes, offsets, npad` from `deconv_weight_planes`."""
+    import ctypes as C
+    L.require_hip(x_planes_cm, "x_planes_cm")
+    L.require_hip(w_planes, "w_planes")
+    _, M, cpad = x_planes_cm.shape
+    if M != B * Hi * Wi:
+        raise RuntimeError("deconv_split: plane shapes do not match")
+    host = []
+    for (oy0, ox0, taps), off in zip(deconv_plan(kernel, padding), offsets):
+        row = [len(taps), oy0, ox0, off]
+        for _, _, dy, dx in taps:
+            row += [dy, dx]
+        host += row + [0] * (36 - len(row))
+    plan = (C.c_long * 144)(*host)
+    y = torch.empty(B * 4 * Hi * Wi, npad, dtype=torch.float32, device=x_planes_cm.device)
+    L.check(L.lib().ufr_deconv_split(L.ptr(x_planes_cm), L.ptr(w_planes), L.ptr(y), B, Hi, Wi, cpad, npad,
+                                     w_planes.shape[1], C.cast(plan, C.c_void_p), int(products), L.stream()), "split deconv")
+    return y
