@@ -147,3 +147,81 @@ def test_deconv_weight_image_as_the_kernel_addresses_it(emulated, K, p):
     got = out[..., :N].permute(0, 3, 1, 2)
     assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
     assert float(out[..., N:].abs().max()) == 0.0
+
+
+# ---- the EXPERIMENTAL any-kernel wiring (split_gemm.SplitConv2d / SplitDeconv2x) with emulated kernels ------------
+def _emu_general(x_planes, w_planes, B, Hi, Wi, kernel, stride, padding, products=6, chunked=False):
+    if chunked:
+        x_planes, w_planes = _unchunk(x_planes), _unchunk(w_planes)
+    x, w = x_planes.float().sum(0), w_planes.float().sum(0)
+    cpad, npad = x.shape[1], w.shape[0]
+    x = x.view(B, Hi, Wi, cpad).permute(0, 3, 1, 2)
+    w = w.view(npad, kernel[0], kernel[1], cpad).permute(0, 3, 1, 2)
+    y = F.conv2d(x, w, stride=stride, padding=padding)
+    return y.permute(0, 2, 3, 1).reshape(-1, npad).contiguous()
+
+
+def _emu_deconv(x_planes_cm, w_planes, offsets, npad, B, Hi, Wi, kernel, padding, products=6):
+    """The address arithmetic of deconv_split_kernel (as in test_deconv_weight_image_as_the_kernel_addresses_it)."""
+    wflat = w_planes.float().sum(0).double()
+    cpad = x_planes_cm.shape[2]
+    M, KC = B * Hi * Wi, cpad // 32
+    xcm = x_planes_cm.float().sum(0).double().view(KC, M, 32)
+    out = torch.zeros(B, 2 * Hi, 2 * Wi, npad, dtype=torch.float64)
+    pix = torch.arange(M)
+    qx, qy, qb = pix % Wi, (pix // Wi) % Hi, pix // (Wi * Hi)
+    for (oy0, ox0, taps), off in zip(sg.deconv_plan(kernel, padding), offsets):
+        acc = torch.zeros(M, npad, dtype=torch.float64)
+        for t, (_, _, dy, dx) in enumerate(taps):
+            yi, xi = qy + dy, qx + dx
+            ok = (yi >= 0) & (yi < Hi) & (xi >= 0) & (xi < Wi)
+            src = torch.where(ok, qb * Hi * Wi + yi * Wi + xi, torch.zeros_like(pix))
+            for kc in range(KC):
+                kt = t * KC + kc
+                bmat = wflat[off + kt * npad * 32: off + (kt + 1) * npad * 32].view(npad, 32)
+                acc += (xcm[kc][src] * ok[:, None]) @ bmat.t()
+        out[qb, 2 * qy + oy0, 2 * qx + ox0] = acc
+    return out.view(-1, npad).float()
+
+
+@pytest.fixture
+def emulated_any(emulated, monkeypatch):
+    monkeypatch.setattr(sg, "nchw_to_planes_cm", lambda x: sg.chunk_major(_emu_to_planes(x)))
+    monkeypatch.setattr(sg, "rows_to_nchw",
+                        lambda y, B, N, H, W, bias=None, slope=1.0: y.view(B, H, W, -1)[..., :N].permute(0, 3, 1, 2).contiguous())
+    monkeypatch.setattr(sg, "conv_split_general", _emu_general)
+    monkeypatch.setattr(sg, "deconv_split", _emu_deconv)
+    sg._ANY_PLANES.clear()
+    yield
+    sg._ANY_PLANES.clear()
+
+
+@pytest.mark.parametrize("K,s,p,H,W", [(3, 1, 1, 8, 10), (3, 2, 1, 8, 10), (5, 2, 2, 8, 12), (7, 2, 3, 12, 8), (1, 1, 0, 6, 7),
+                                       (5, 1, 2, 7, 9)])
+def test_split_conv2d_function_any_kernel(emulated_any, K, s, p, H, W):
+    g = torch.Generator().manual_seed(K * 10 + s)
+    x = torch.randn(2, 40, H, W, generator=g, requires_grad=True)
+    w = torch.randn(70, 40, K, K, generator=g) * 0.1
+    y = sg.SplitConv2d.apply(x, w, s, p, 6)
+    want = F.conv2d(x, w, stride=s, padding=p)
+    assert y.shape == want.shape
+    assert float((y - want).detach().abs().max()) <= 2e-5 * float(want.detach().abs().max())
+    gy = torch.randn(want.shape, generator=g)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    (gx_want,) = torch.autograd.grad(want, x, gy)
+    assert float((gx - gx_want).abs().max()) <= 2e-5 * float(gx_want.abs().max())
+
+
+@pytest.mark.parametrize("K,p", [(4, 1), (3, 1)])
+def test_split_deconv_function(emulated_any, K, p):
+    g = torch.Generator().manual_seed(K)
+    x = torch.randn(2, 40, 5, 7, generator=g, requires_grad=True)
+    w = torch.randn(40, 70, K, K, generator=g) * 0.1
+    y = sg.SplitDeconv2x.apply(x, w, p, 6)
+    want = F.conv_transpose2d(x, w, stride=2, padding=p, output_padding=2 + 2 * p - K)
+    assert y.shape == want.shape
+    assert float((y - want).detach().abs().max()) <= 2e-5 * float(want.detach().abs().max())
+    gy = torch.randn(want.shape, generator=g)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    (gx_want,) = torch.autograd.grad(want, x, gy)
+    assert float((gx - gx_want).abs().max()) <= 2e-5 * float(gx_want.abs().max())

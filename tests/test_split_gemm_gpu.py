@@ -181,3 +181,29 @@ def test_deconv_split_matches_float64(B, C, H, W, N, K, p):
     y = y[:, :N].reshape(B, 2 * H, 2 * W, N).permute(0, 3, 1, 2)
     err = float((y.cpu().double() - ref).abs().max()) / float(ref.abs().max())
     assert err <= 4e-6, f"{err:.3e}"
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("UFR_EXPERIMENTAL"),
+                    reason="the any-kernel UFR_SPLIT_CONV wiring has only run with emulated kernels")
+@pytest.mark.parametrize("block", ["conv3x3s2", "conv5x5s2", "deconv4x4s2"])
+def test_strided_blocks_through_the_split_kernels(monkeypatch, block):
+    """The reference's strided `conv` and `deconv` blocks (models/submodules.py:18-46, :75-82), split kernels on / off."""
+    from understanding_flow_robustness_amd.band_conv import conv_leaky
+    torch.manual_seed(1)
+    layer = {"conv3x3s2": torch.nn.Conv2d(96, 160, 3, 2, 1), "conv5x5s2": torch.nn.Conv2d(64, 128, 5, 2, 2),
+             "deconv4x4s2": torch.nn.ConvTranspose2d(96, 64, 4, 2, 1)}[block]
+    seq = torch.nn.Sequential(layer, torch.nn.LeakyReLU(0.1)).to(DEV)
+    for p in seq.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(2, layer.in_channels, 96, 128, device=DEV)
+    outs = []
+    for knob in ("0", "6"):
+        monkeypatch.setenv("UFR_SPLIT_CONV", knob)
+        xi = x.clone().requires_grad_(True)
+        y = conv_leaky(xi, seq)
+        gy = torch.ones_like(y) * torch.linspace(-1, 1, y.shape[-1], device=DEV)
+        (gx,) = torch.autograd.grad(y, xi, gy)
+        outs.append((y.detach(), gx))
+    (y0, g0), (y1, g1) = outs
+    assert y1.shape == y0.shape and float((y1 - y0).abs().max()) <= 1e-5 * float(y0.abs().max())
+    assert float((g1 - g0).abs().max()) <= 5e-4 * float(g0.abs().max())

@@ -12,7 +12,9 @@ UFR_EXPERIMENTAL=1 UFR_SKIP_MIOPEN=1 timeout -k 10 120 python tools/microbench_s
 # 3. whole steps with the opt-in wiring: headline (bands on), then FlowNet2's universal step (no bands)
 timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-full-frame > $out/bench_off.json 2>$out/bench_off.err &&
 UFR_SPLIT_CONV=6 timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-full-frame > $out/bench_split6.json 2>$out/bench_split6.err &&
-UFR_SPLIT_CONV=3 timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-full-frame > $out/bench_split3.json 2>$out/bench_split3.err
+UFR_SPLIT_CONV=3 timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-full-frame > $out/bench_split3.json 2>$out/bench_split3.err &&
+# 4. every frozen conv / deconv block on the split kernels (strided and transposed variants included)
+UFR_EXPERIMENTAL=1 UFR_SPLIT_CONV=6 timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-full-frame > $out/bench_all6.json 2>$out/bench_all6.err
 rc=$?
 tail -n 3 $out/tests.log; tail -n 4 $out/layers.jsonl | cut -c1-400; for f in $out/bench_*.json; do echo $f; tail -n 1 $f | cut -c1-300; done
 exit $rc

@@ -16,8 +16,8 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib as L
-from .split_gemm import (SplitConv3x3, split_conv3x3_forward, split_conv3x3_input_gradient, split_conv_applicable,
-                         split_conv_ok, split_conv_products)
+from .split_gemm import (SplitConv2d, SplitConv3x3, SplitDeconv2x, _experimental, split_any_ok, split_conv3x3_forward,
+                         split_conv3x3_input_gradient, split_conv_applicable, split_conv_ok, split_conv_products)
 
 
 class Band:
@@ -294,8 +294,15 @@ def conv_leaky(x, seq, band: Band | None = None, in_stride: int = 0, name: str |
     if isinstance(conv, torch.nn.Conv2d):
         y = band_conv2d(x, conv, band, in_stride, with_bias=False)
     else:
-        y = F.conv_transpose2d(x, conv.weight, None, conv.stride, conv.padding, conv.output_padding, conv.groups,
-                               conv.dilation)
+        products = split_conv_products()
+        k, pd = conv.kernel_size[0], conv.padding[0]
+        if (products and _experimental() and conv.kernel_size == (k, k) and conv.stride == (2, 2) and conv.padding == (pd, pd)
+                and conv.output_padding == (0, 0) and 2 + 2 * pd - k == 0 and conv.dilation == (1, 1) and conv.groups == 1
+                and split_any_ok(x, conv.weight, 4 * x.shape[0] * x.shape[2] * x.shape[3])):
+            y = SplitDeconv2x.apply(x, conv.weight, pd, products)
+        else:
+            y = F.conv_transpose2d(x, conv.weight, None, conv.stride, conv.padding, conv.output_padding, conv.groups,
+                                   conv.dilation)
     if not y.is_contiguous():
         y = y.contiguous()
     y = _BiasLeaky.apply(y, conv.bias, act.negative_slope)
@@ -317,6 +324,14 @@ def band_conv2d(x, conv: torch.nn.Conv2d, band: Band | None, in_stride: int, wit
         if products and (_frozen(conv) or not torch.is_grad_enabled()) and split_conv_applicable(x, conv):
             y = SplitConv3x3.apply(x, conv.weight, products)
             return y if bias is None else y + bias.view(1, -1, 1, 1)
+        if (products and _experimental() and (_frozen(conv) or not torch.is_grad_enabled()) and conv.dilation == (1, 1)
+                and conv.groups == 1 and conv.stride in ((1, 1), (2, 2)) and conv.padding[0] == conv.padding[1]
+                and conv.padding_mode == "zeros"):
+            k, sd, pd = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+            out_pixels = x.shape[0] * ((x.shape[2] + 2 * pd - k) // sd + 1) * ((x.shape[3] + 2 * pd - k) // sd + 1)
+            if conv.kernel_size[0] == conv.kernel_size[1] and split_any_ok(x, conv.weight, out_pixels):
+                y = SplitConv2d.apply(x, conv.weight, sd, pd, products)
+                return y if bias is None else y + bias.view(1, -1, 1, 1)
         return F.conv2d(x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
     s, p = conv.stride[0], conv.padding[0]
     if conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1] or conv.dilation != (1, 1) or conv.groups != 1:

@@ -276,3 +276,91 @@ def deconv_split(x_planes_cm: torch.Tensor, w_planes: torch.Tensor, offsets, npa
     L.check(L.lib().ufr_deconv_split(L.ptr(x_planes_cm), L.ptr(w_planes), L.ptr(y), B, Hi, Wi, cpad, npad,
                                      w_planes.shape[1], C.cast(plan, C.c_void_p), int(products), L.stream()), "split deconv")
     return y
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# EXPERIMENTAL (UFR_EXPERIMENTAL=1 together with UFR_SPLIT_CONV): every frozen convolution of the conv / deconv blocks
+# through csrc/split_conv_wide.hip -- any square kernel, stride 1 or 2, and ConvTranspose2d(., ., K, 2, p) -- so that
+# round 2 can time whole networks on the bf16 pipe before fusing anything.  Composition checked with emulated kernels.
+_ANY_PLANES: dict = {}
+
+
+def _cached(key, make):
+    hit = _ANY_PLANES.get(key)
+    if hit is None:
+        if len(_ANY_PLANES) >= 512:
+            _ANY_PLANES.clear()
+        hit = _ANY_PLANES[key] = make()
+    return hit
+
+
+def _wkey(weight, kind):
+    return (weight.data_ptr(), weight._version, tuple(weight.shape), kind)
+
+
+def split_any_ok(x: torch.Tensor, weight: torch.Tensor, out_pixels: int) -> bool:
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and weight.shape[2] == weight.shape[3]
+            and min(weight.shape[0], weight.shape[1]) >= 32 and out_pixels >= 4096)
+
+
+def split_conv2d_forward(x, weight, stride, padding, products):
+    """conv2d(x, weight, stride, padding) without bias, NCHW in / out, through `conv_split_general`."""
+    B, _, Hi, Wi = x.shape
+    N, _, K, _ = weight.shape
+    wp = _cached(_wkey(weight, "conv"), lambda: chunk_major(conv_weight_planes(weight)))
+    rows = conv_split_general(nchw_to_planes_cm(x.contiguous()), wp, B, Hi, Wi, (K, K), stride, padding, products, chunked=True)
+    return rows_to_nchw(rows, B, N, (Hi + 2 * padding - K) // stride + 1, (Wi + 2 * padding - K) // stride + 1)
+
+
+def split_conv2d_input_gradient(gy, weight, in_hw, stride, padding, products):
+    """d/dx of conv2d(x, weight, stride, padding); None when the shape has no split kernel (caller falls back)."""
+    B, _, Ho, Wo = gy.shape
+    N, C, K, _ = weight.shape
+    if stride == 1 and K - 1 - padding >= 0:
+        wp = _cached(_wkey(weight, "adj"), lambda: chunk_major(conv_weight_planes(weight.flip(2, 3).transpose(0, 1))))
+        rows = conv_split_general(nchw_to_planes_cm(gy.contiguous()), wp, B, Ho, Wo, (K, K), 1, K - 1 - padding, products,
+                                  chunked=True)
+        return rows_to_nchw(rows, B, C, Ho + K - 1 - 2 * padding, Wo + K - 1 - 2 * padding)
+    if stride == 2 and tuple(in_hw) == (2 * Ho, 2 * Wo) and 0 <= 2 + 2 * padding - K <= 1:
+        wp, offsets, npad, _ = _cached(_wkey(weight, ("deconv", padding)), lambda: deconv_weight_planes(weight, padding))
+        rows = deconv_split(nchw_to_planes_cm(gy.contiguous()), wp, offsets, npad, B, Ho, Wo, K, padding, products)
+        return rows_to_nchw(rows, B, C, 2 * Ho, 2 * Wo)
+    return None
+
+
+class SplitConv2d(torch.autograd.Function):
+    """Frozen Conv2d (square kernel, stride 1 or 2) on the split kernels; falls back to ATen for an adjoint shape
+    without a split kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, padding, products):
+        ctx.weight, ctx.meta = weight, (tuple(x.shape), int(stride), int(padding), int(products))
+        return split_conv2d_forward(x, weight, int(stride), int(padding), int(products))
+
+    @staticmethod
+    def backward(ctx, gy):
+        in_shape, s, p, products = ctx.meta
+        gx = split_conv2d_input_gradient(gy, ctx.weight, in_shape[2:], s, p, products)
+        if gx is None:
+            gx = torch.ops.aten.convolution_backward(gy, gy.new_empty(in_shape), ctx.weight, None, (s, s), (p, p), (1, 1),
+                                                     False, (0, 0), 1, (True, False, False))[0]
+        return gx, None, None, None, None
+
+
+class SplitDeconv2x(torch.autograd.Function):
+    """Frozen ConvTranspose2d(Cin, Cout, K, 2, p) with an output of twice the input size: forward = four phase GEMMs,
+    input gradient = the stride-2 convolution with the same weight tensor."""
+
+    @staticmethod
+    def forward(ctx, x, weight, padding, products):
+        B, _, H, W = x.shape
+        K = weight.shape[2]
+        wp, offsets, npad, _ = _cached(_wkey(weight, ("deconv", int(padding))), lambda: deconv_weight_planes(weight, int(padding)))
+        rows = deconv_split(nchw_to_planes_cm(x.contiguous()), wp, offsets, npad, B, H, W, K, int(padding), int(products))
+        ctx.weight, ctx.meta = weight, (int(padding), int(products))
+        return rows_to_nchw(rows, B, weight.shape[1], 2 * H, 2 * W)
+
+    @staticmethod
+    def backward(ctx, gy):
+        p, products = ctx.meta
+        return split_conv2d_forward(gy, ctx.weight, 2, p, products), None, None, None
