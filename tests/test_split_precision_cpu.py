@@ -41,3 +41,25 @@ def test_six_products_match_float32_accuracy():
     assert err[6] <= 2.0 * plain + 1e-7, (err, plain)
     assert err[3] <= 2e-5 and err[1] >= 1e-4, err
     assert err[6] < err[3] < err[1]
+
+
+def _tile_of_block(bx, by, gx, gy):
+    """Python mirror of csrc/split_gemm.hip::split_tile_of_block (UFR_SPLIT_XCD=1)."""
+    nwg, orig = gx * gy, by * gx + bx
+    q, r, xcd, idx = nwg // 8, nwg % 8, orig % 8, orig // 8
+    wgid = (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + idx
+    return wgid % gx, wgid // gx
+
+
+def test_xcd_tile_order_is_a_bijection_with_contiguous_runs():
+    for gx, gy in ((2, 480), (4, 120), (8, 8), (1, 7), (3, 5), (2, 3), (5, 13), (32, 32), (1, 1), (7, 1)):
+        seen, runs = set(), {}
+        for by in range(gy):
+            for bx in range(gx):
+                tx, ty = _tile_of_block(bx, by, gx, gy)
+                assert 0 <= tx < gx and 0 <= ty < gy
+                seen.add((tx, ty))
+                runs.setdefault((by * gx + bx) % 8, []).append(ty * gx + tx)
+        assert len(seen) == gx * gy, (gx, gy)                       # every tile computed exactly once
+        for tiles in runs.values():                                 # one XCD = one contiguous run of tiles
+            assert tiles == list(range(tiles[0], tiles[0] + len(tiles))), (gx, gy)

@@ -18,19 +18,41 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 constexpr int WM = 128, WN = 256, BK = 32;
 constexpr int A_IMG = WM * BK, B_IMG = WN * BK;   // bf16 elements of one plane's tile
 
+// XCD-aware tile order (UFR_SPLIT_XCD=1, off by default until measured): workgroups are dealt round-robin to the 8
+// XCDs in launch order, so the launch index i is remapped to tile (i % 8) * ceil(n/8) + i / 8 (the bijective form for
+// n % 8 != 0, cdna_hip_programming.md): every XCD then owns one contiguous run of tiles -- the N-tiles of one pixel tile
+// and the neighbouring pixel tiles, whose activation rows overlap -- and its private L2 sees their re-reads.
+__device__ __forceinline__ void split_tile_of_block(int swz, int& bx, int& by) {
+  bx = blockIdx.x;
+  by = blockIdx.y;
+  if (!swz) return;
+  const int gx = gridDim.x, nwg = gx * gridDim.y, orig = by * gx + bx;
+  const int q = nwg / 8, r = nwg % 8, xcd = orig % 8, idx = orig / 8;
+  const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  bx = wgid % gx;
+  by = wgid / gx;
+}
+
+static int split_xcd_swizzle() {
+  static const int v = [] { const char* e = getenv("UFR_SPLIT_XCD"); return e && e[0] == '1' ? 1 : 0; }();
+  return v;
+}
+
 __device__ constexpr int PROD_A[6] = {2, 0, 1, 1, 0, 0};   // as in split_gemm.hip: smallest products first
 __device__ constexpr int PROD_B[6] = {0, 2, 1, 0, 1, 0};
 
 template <int NPROD>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_split_wide_kernel(
     const __bf16* __restrict__ Xp, const __bf16* __restrict__ Wp, float* __restrict__ Y, int B, int H, int W, int Cpad,
-    int N, long rsA, long ksA, long rsB, long ksB) {
+    int N, long rsA, long ksA, long rsB, long ksB, int swz) {
   constexpr int NPL = NPROD == 1 ? 1 : (NPROD == 3 ? 2 : 3);
   constexpr int FIRST = 6 - NPROD;
   constexpr int BUF = NPL * (A_IMG + B_IMG);
   __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 2, wc = wave & 3;
-  const int bm = blockIdx.y * WM, bn = blockIdx.x * WN;
+  int tile_x, tile_y;
+  split_tile_of_block(swz, tile_x, tile_y);
+  const int bm = tile_y * WM, bn = tile_x * WN;
   const int M = B * H * W, KC = Cpad / BK, KT = 9 * KC;
   const size_t planeA = (size_t)M * Cpad, planeB = (size_t)N * 9 * Cpad;
 
@@ -121,12 +143,14 @@ constexpr int GM = 128, GN = 128;
 template <int NPROD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_split_general_kernel(
     const __bf16* __restrict__ Xp, const __bf16* __restrict__ Wp, float* __restrict__ Y, int B, int Hi, int Wi, int Ho,
-    int Wo, int Cpad, int N, int KH, int KW, int stride, int pad, long rsA, long ksA, long rsB, long ksB) {
+    int Wo, int Cpad, int N, int KH, int KW, int stride, int pad, long rsA, long ksA, long rsB, long ksB, int swz) {
   constexpr int NPL = NPROD == 1 ? 1 : (NPROD == 3 ? 2 : 3);
   constexpr int FIRST = 6 - NPROD;
   __shared__ __attribute__((aligned(16))) __bf16 lds[2 * NPL][GM * BK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
-  const int bm = blockIdx.y * GM, bn = blockIdx.x * GN;
+  int tile_x, tile_y;
+  split_tile_of_block(swz, tile_x, tile_y);
+  const int bm = tile_y * GM, bn = tile_x * GN;
   const int M = B * Ho * Wo, Min = B * Hi * Wi, KC = Cpad / BK, KT = KH * KW * KC;
   const size_t planeA = (size_t)Min * Cpad, planeB = (size_t)N * KH * KW * Cpad;
 
@@ -221,12 +245,14 @@ struct DeconvPlan {
 template <int NPROD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void deconv_split_kernel(
     const __bf16* __restrict__ Xp, const __bf16* __restrict__ Wp, float* __restrict__ Y, int B, int Hi, int Wi, int Cpad,
-    int N, long planeB, DeconvPlan plan) {
+    int N, long planeB, DeconvPlan plan, int swz) {
   constexpr int NPL = NPROD == 1 ? 1 : (NPROD == 3 ? 2 : 3);
   constexpr int FIRST = 6 - NPROD;
   __shared__ __attribute__((aligned(16))) __bf16 lds[2 * NPL][GM * BK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
-  const int bm = blockIdx.y * GM, bn = blockIdx.x * GN, z = blockIdx.z;
+  int tile_x, tile_y;
+  split_tile_of_block(swz, tile_x, tile_y);
+  const int bm = tile_y * GM, bn = tile_x * GN, z = blockIdx.z;
   const int M = B * Hi * Wi, KC = Cpad / BK, KT = plan.ntaps[z] * KC;
   const size_t planeA = (size_t)M * Cpad;
 
@@ -392,9 +418,9 @@ extern "C" int ufr_conv3x3_split_wide(const void* x_planes, const void* w_planes
   const __bf16* b = static_cast<const __bf16*>(w_planes);
   const long rsA = chunk_major ? BK : Cpad, ksA = chunk_major ? (long)M * BK : BK;
   const long rsB = chunk_major ? BK : 9L * Cpad, ksB = chunk_major ? (long)N * BK : BK;
-  if (products == 6) conv3x3_split_wide_kernel<6><<<grid, 512, 0, st>>>(a, b, y, B, H, W, Cpad, N, rsA, ksA, rsB, ksB);
-  else if (products == 3) conv3x3_split_wide_kernel<3><<<grid, 512, 0, st>>>(a, b, y, B, H, W, Cpad, N, rsA, ksA, rsB, ksB);
-  else conv3x3_split_wide_kernel<1><<<grid, 512, 0, st>>>(a, b, y, B, H, W, Cpad, N, rsA, ksA, rsB, ksB);
+  if (products == 6) conv3x3_split_wide_kernel<6><<<grid, 512, 0, st>>>(a, b, y, B, H, W, Cpad, N, rsA, ksA, rsB, ksB, split_xcd_swizzle());
+  else if (products == 3) conv3x3_split_wide_kernel<3><<<grid, 512, 0, st>>>(a, b, y, B, H, W, Cpad, N, rsA, ksA, rsB, ksB, split_xcd_swizzle());
+  else conv3x3_split_wide_kernel<1><<<grid, 512, 0, st>>>(a, b, y, B, H, W, Cpad, N, rsA, ksA, rsB, ksB, split_xcd_swizzle());
   return ufr::launched("conv3x3_split_wide_kernel");
 }
 
@@ -440,7 +466,7 @@ extern "C" int ufr_conv_split_general(const void* x_planes, const void* w_planes
   const long rsB = chunk_major ? BK : K, ksB = chunk_major ? (long)N * BK : BK;
 #define UFR_GC_LAUNCH(P)                                                                                             \
   conv_split_general_kernel<P><<<grid, 256, 0, st>>>(a, b, y, B, Hi, Wi, Ho, Wo, Cpad, N, KH, KW, stride, pad, rsA, ksA, \
-                                                     rsB, ksB)
+                                                     rsB, ksB, split_xcd_swizzle())
   if (products == 6) UFR_GC_LAUNCH(6);
   else if (products == 3) UFR_GC_LAUNCH(3);
   else UFR_GC_LAUNCH(1);
@@ -474,8 +500,8 @@ extern "C" int ufr_deconv_split(const void* x_planes_cm, const void* w_planes, f
   hipStream_t st = ufr::as_stream(stream);
   const __bf16* a = static_cast<const __bf16*>(x_planes_cm);
   const __bf16* b = static_cast<const __bf16*>(w_planes);
-  if (products == 6) deconv_split_kernel<6><<<grid, 256, 0, st>>>(a, b, y, B, Hi, Wi, Cpad, N, w_plane_elems, plan);
-  else if (products == 3) deconv_split_kernel<3><<<grid, 256, 0, st>>>(a, b, y, B, Hi, Wi, Cpad, N, w_plane_elems, plan);
-  else deconv_split_kernel<1><<<grid, 256, 0, st>>>(a, b, y, B, Hi, Wi, Cpad, N, w_plane_elems, plan);
+  if (products == 6) deconv_split_kernel<6><<<grid, 256, 0, st>>>(a, b, y, B, Hi, Wi, Cpad, N, w_plane_elems, plan, split_xcd_swizzle());
+  else if (products == 3) deconv_split_kernel<3><<<grid, 256, 0, st>>>(a, b, y, B, Hi, Wi, Cpad, N, w_plane_elems, plan, split_xcd_swizzle());
+  else deconv_split_kernel<1><<<grid, 256, 0, st>>>(a, b, y, B, Hi, Wi, Cpad, N, w_plane_elems, plan, split_xcd_swizzle());
   return ufr::launched("deconv_split_kernel");
 }

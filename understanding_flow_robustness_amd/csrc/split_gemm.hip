@@ -39,6 +39,26 @@ __global__ void split3_kernel(const float* __restrict__ x, __bf16* __restrict__ 
 
 constexpr int BM = 128, BN = 128, BK = 32;
 
+// XCD-aware tile order (UFR_SPLIT_XCD=1, off by default until measured): workgroups are dealt round-robin to the 8
+// XCDs in launch order, so the launch index i is remapped to tile (i % 8) * ceil(n/8) + i / 8 (the bijective form for
+// n % 8 != 0, cdna_hip_programming.md): every XCD then owns one contiguous run of tiles -- the N-tiles of one pixel tile
+// and the neighbouring pixel tiles, whose activation rows overlap -- and its private L2 sees their re-reads.
+__device__ __forceinline__ void split_tile_of_block(int swz, int& bx, int& by) {
+  bx = blockIdx.x;
+  by = blockIdx.y;
+  if (!swz) return;
+  const int gx = gridDim.x, nwg = gx * gridDim.y, orig = by * gx + bx;
+  const int q = nwg / 8, r = nwg % 8, xcd = orig % 8, idx = orig / 8;
+  const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  bx = wgid % gx;
+  by = wgid / gx;
+}
+
+static int split_xcd_swizzle() {
+  static const int v = [] { const char* e = getenv("UFR_SPLIT_XCD"); return e && e[0] == '1' ? 1 : 0; }();
+  return v;
+}
+
 // (a plane, b plane) of each product, smallest magnitude first
 __device__ constexpr int PROD_A[6] = {2, 0, 1, 1, 0, 0};
 __device__ constexpr int PROD_B[6] = {0, 2, 1, 0, 1, 0};
@@ -46,12 +66,14 @@ __device__ constexpr int PROD_B[6] = {0, 2, 1, 0, 1, 0};
 template <int NPROD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_split_nt_kernel(const __bf16* __restrict__ Ap, const __bf16* __restrict__ Bp,
                                                             float* __restrict__ C, int M, int N, int K, long rsA,
-                                                            long ksA, long rsB, long ksB) {
+                                                            long ksA, long rsB, long ksB, int swz) {
   constexpr int NPL = NPROD == 1 ? 1 : (NPROD == 3 ? 2 : 3);   // planes needed per operand
   constexpr int FIRST = 6 - NPROD;                              // NPROD leading-order products = the last ones
   __shared__ __attribute__((aligned(16))) __bf16 lds[2 * NPL][BM * BK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
-  const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
+  int tile_x, tile_y;
+  split_tile_of_block(swz, tile_x, tile_y);
+  const int bm = tile_y * BM, bn = tile_x * BN;
   const size_t planeA = (size_t)M * K, planeB = (size_t)N * K;
 
   // staging: 512 16-byte chunks per image, two per thread
@@ -129,12 +151,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 template <int NPROD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPROD == 6 ? 2 : 3, NPROD == 6 ? 2 : 3))) void conv3x3_split_kernel(
     const __bf16* __restrict__ Xp, const __bf16* __restrict__ Wp, float* __restrict__ Y, int B, int H, int W, int Cpad,
-    int N, long rsA, long ksA, long rsB, long ksB) {
+    int N, long rsA, long ksA, long rsB, long ksB, int swz) {
   constexpr int NPL = NPROD == 1 ? 1 : (NPROD == 3 ? 2 : 3);
   constexpr int FIRST = 6 - NPROD;
   __shared__ __attribute__((aligned(16))) __bf16 lds[2 * NPL][BM * BK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
-  const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
+  int tile_x, tile_y;
+  split_tile_of_block(swz, tile_x, tile_y);
+  const int bm = tile_y * BM, bn = tile_x * BN;
   const int M = B * H * W, K = 9 * Cpad, KC = Cpad / BK, KT = 9 * KC;
   const size_t planeA = (size_t)M * Cpad, planeB = (size_t)N * K;
 
@@ -268,11 +292,12 @@ extern "C" int ufr_gemm_split_nt(const void* a_planes, const void* b_planes, flo
   hipStream_t st = ufr::as_stream(stream);
   const __bf16* a = static_cast<const __bf16*>(a_planes);
   const __bf16* b = static_cast<const __bf16*>(b_planes);
+  const int swz = split_xcd_swizzle();
   const long rsA = chunk_major ? BK : K, ksA = chunk_major ? (long)M * BK : BK;
   const long rsB = chunk_major ? BK : K, ksB = chunk_major ? (long)N * BK : BK;
-  if (products == 6) gemm_split_nt_kernel<6><<<grid, 256, 0, st>>>(a, b, c, M, N, K, rsA, ksA, rsB, ksB);
-  else if (products == 3) gemm_split_nt_kernel<3><<<grid, 256, 0, st>>>(a, b, c, M, N, K, rsA, ksA, rsB, ksB);
-  else gemm_split_nt_kernel<1><<<grid, 256, 0, st>>>(a, b, c, M, N, K, rsA, ksA, rsB, ksB);
+  if (products == 6) gemm_split_nt_kernel<6><<<grid, 256, 0, st>>>(a, b, c, M, N, K, rsA, ksA, rsB, ksB, swz);
+  else if (products == 3) gemm_split_nt_kernel<3><<<grid, 256, 0, st>>>(a, b, c, M, N, K, rsA, ksA, rsB, ksB, swz);
+  else gemm_split_nt_kernel<1><<<grid, 256, 0, st>>>(a, b, c, M, N, K, rsA, ksA, rsB, ksB, swz);
   return ufr::launched("gemm_split_nt_kernel");
 }
 
@@ -298,10 +323,11 @@ extern "C" int ufr_conv3x3_split(const void* x_planes, const void* w_planes, flo
   hipStream_t st = ufr::as_stream(stream);
   const __bf16* a = static_cast<const __bf16*>(x_planes);
   const __bf16* b = static_cast<const __bf16*>(w_planes);
+  const int swz = split_xcd_swizzle();
   const long rsA = chunk_major ? BK : Cpad, ksA = chunk_major ? (long)M * BK : BK;
   const long rsB = chunk_major ? BK : 9L * Cpad, ksB = chunk_major ? (long)N * BK : BK;
-  if (products == 6) conv3x3_split_kernel<6><<<grid, 256, 0, st>>>(a, b, y, B, H, W, Cpad, N, rsA, ksA, rsB, ksB);
-  else if (products == 3) conv3x3_split_kernel<3><<<grid, 256, 0, st>>>(a, b, y, B, H, W, Cpad, N, rsA, ksA, rsB, ksB);
-  else conv3x3_split_kernel<1><<<grid, 256, 0, st>>>(a, b, y, B, H, W, Cpad, N, rsA, ksA, rsB, ksB);
+  if (products == 6) conv3x3_split_kernel<6><<<grid, 256, 0, st>>>(a, b, y, B, H, W, Cpad, N, rsA, ksA, rsB, ksB, swz);
+  else if (products == 3) conv3x3_split_kernel<3><<<grid, 256, 0, st>>>(a, b, y, B, H, W, Cpad, N, rsA, ksA, rsB, ksB, swz);
+  else conv3x3_split_kernel<1><<<grid, 256, 0, st>>>(a, b, y, B, H, W, Cpad, N, rsA, ksA, rsB, ksB, swz);
   return ufr::launched("conv3x3_split_kernel");
 }
