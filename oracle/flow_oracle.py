@@ -203,6 +203,15 @@ def flownet2_forward(sd, x1, x2, div_flow=20.0):
     return _fn2_fusion(sd, "flownetfusion.", torch.cat((x[:, :3], flow_sd, flow_s2, norm_sd, norm_s2, err_sd, err_s2), 1))
 
 
+def flownet2s_forward(sd, x1, x2):
+    """models/FlowNet2S.py:62-108 (the registry's `FlowNetS`, models/__init__.py:2): own RGB mean in float64, the
+    FlowNetS trunk on cat(x1, x2), eval output `upsample1(flow2 * 20)`."""
+    mean = torch.tensor((0.4114511, 0.43205959, 0.45015125), dtype=torch.float64).view(1, 3, 1, 1)
+    x = torch.cat(((x1.double() - mean).float(), (x2.double() - mean).float()), dim=1)
+    flow2 = _fn2_flownets(sd, "", x)
+    return F.interpolate(flow2 * 20, scale_factor=4, mode="bilinear", align_corners=False)
+
+
 # ------------------------------------------------------------------------------------------- RAFT
 def _raft_norm(sd, prefix, x, kind):
     if kind == "instance":                                           # nn.InstanceNorm2d: no affine, no stats

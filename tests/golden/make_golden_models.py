@@ -219,6 +219,23 @@ def gen_flownet2():
          weight_digest=state_dict_digest(sd), weight_seed=3)
 
 
+def gen_flownet2s():
+    """models/FlowNet2S.py:15-108 = the registry's `FlowNetS` (models/__init__.py:2): flow and image gradients."""
+    mod = rh.ref_module("models.FlowNet2S")
+    net = mod.FlowNet2S().eval()
+    sd = synthetic_state_dict(net.state_dict(), seed=4)
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(92)
+    x1 = torch.rand(1, 3, 64, 128, generator=g).requires_grad_(True)
+    x2 = torch.rand(1, 3, 64, 128, generator=g).requires_grad_(True)
+    flow = net(x1, x2)
+    tgt = torch.randn(flow.shape, generator=g)
+    loss = (1 - torch.nn.functional.cosine_similarity(flow, tgt)).mean()
+    loss.backward()
+    save("flownet2s_64x128", x1=x1, x2=x2, flow=flow, target=tgt, loss=loss, g1=x1.grad, g2=x2.grad,
+         weight_digest=state_dict_digest(sd), weight_seed=4)
+
+
 def gen_patch_host():
     """patch_attacks/utils_patch.py:236-358 under fixed np.random seeds, and one
     full loader item through patch_attacks/main.py::train (:345-520) with FlowNetC."""
@@ -383,3 +400,5 @@ def gen_perturb_noise():
 
 
 GENERATORS["perturb_noise"] = gen_perturb_noise
+
+GENERATORS["flownet2s"] = gen_flownet2s

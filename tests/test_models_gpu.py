@@ -129,3 +129,31 @@ def test_raft_full_resolution_smoke():
     assert tuple(flow.shape) == (1, 2, 384, 1280)
     (g1,) = torch.autograd.grad(flow.square().mean(), x1)
     assert bool(torch.isfinite(flow).all()) and bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0
+
+
+def test_flownet2s_matches_reference_golden():
+    """`--flownet FlowNetS` (models/__init__.py:2 -> models/FlowNet2S.py:62-108) through fetch_model + predict_flow."""
+    from understanding_flow_robustness_amd.flownets.utils_model import fetch_model, predict_flow
+    z = load_golden("flownet2s_64x128")
+    args = Namespace(flownet="FlowNetS")
+    net = fetch_model(args, synthetic_seed=4).to(DEV)
+    x1, x2 = t(z["x1"], DEV).requires_grad_(True), t(z["x2"], DEV).requires_grad_(True)
+    flow = predict_flow(net, None, x1, x2, args)
+    assert_close(flow, t(z["flow"]), rtol=1e-4, atol_scale=1e-5, what="FlowNet2S flow")
+    loss = (1 - torch.nn.functional.cosine_similarity(flow, t(z["target"], DEV))).mean()
+    g1, g2 = torch.autograd.grad(loss, (x1, x2))
+    assert_close(g1, t(z["g1"]), rtol=1e-3, atol_scale=1e-3, what="FlowNet2S grad 1")
+    assert_close(g2, t(z["g2"]), rtol=1e-3, atol_scale=1e-3, what="FlowNet2S grad 2")
+
+
+def test_predict_flow_for_every_implemented_name():
+    from understanding_flow_robustness_amd.flownets import utils_model as um
+    g = torch.Generator().manual_seed(3)
+    x1, x2 = torch.rand(1, 3, 64, 128, generator=g).to(DEV), torch.rand(1, 3, 64, 128, generator=g).to(DEV)
+    for name in um._IMPLEMENTED:
+        args = Namespace(flownet=name)
+        net = um.fetch_model(args, synthetic_seed=0).to(DEV)
+        with torch.no_grad():
+            flow = um.predict_flow(net, None, x1, x2, args)
+        assert tuple(flow.shape) == (1, 2, 64, 128) and bool(torch.isfinite(flow).all()), name
+        del net

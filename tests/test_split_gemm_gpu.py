@@ -83,7 +83,7 @@ def test_conv3x3_split_matches_float64(B, C, H, W, N):
     assert err <= 4e-6, f"data gradient: {err:.3e}"
 
 
-@pytest.mark.skipif(not __import__("os").environ.get("UFR_EXPERIMENTAL"),
+@pytest.mark.skipif(__import__("os").environ.get("UFR_EXPERIMENTAL") != "1",
                     reason="csrc/split_conv_wide.hip has not run on hardware yet (written after round 1's GPU budget)")
 @pytest.mark.parametrize("B,C,H,W,N", [(2, 40, 13, 20, 256), (1, 96, 16, 24, 512)])
 def test_wide_tile_conv_equals_the_128x128_kernel(B, C, H, W, N):
@@ -98,7 +98,7 @@ def test_wide_tile_conv_equals_the_128x128_kernel(B, C, H, W, N):
         assert torch.equal(conv3x3_split(chunk_major(xp), chunk_major(wp), B, H, W, products, chunked=True, wide=True), want)
 
 
-@pytest.mark.skipif(not __import__("os").environ.get("UFR_EXPERIMENTAL"),
+@pytest.mark.skipif(__import__("os").environ.get("UFR_EXPERIMENTAL") != "1",
                     reason="the UFR_SPLIT_CONV wiring has only run with emulated kernels (tests/test_split_conv_wiring_cpu.py)")
 @pytest.mark.parametrize("products,tol", [(6, 1e-5), (3, 5e-5)])
 def test_conv_leaky_through_the_split_kernels(monkeypatch, products, tol):
@@ -110,6 +110,12 @@ def test_conv_leaky_through_the_split_kernels(monkeypatch, products, tol):
         p.requires_grad_(False)
     x = torch.randn(2, 96, 64, 96, device=DEV)
     gy = torch.randn(2, 160, 64, 96, device=DEV)
+    # LeakyReLU's slope flips where the pre-activation is within rounding of zero: the gradient is seeded away
+    # from those pixels only (one flip moves the input gradient by 0.9 * |gy| * |w|, unrelated to the kernels)
+    monkeypatch.setenv("UFR_SPLIT_CONV", "0")
+    with torch.no_grad():
+        stable = conv_leaky(x, seq).abs() > 1e-3
+    gy = gy * stable
     outs = []
     for knob in ("0", str(products)):
         monkeypatch.setenv("UFR_SPLIT_CONV", knob)
@@ -119,13 +125,11 @@ def test_conv_leaky_through_the_split_kernels(monkeypatch, products, tol):
         outs.append((y.detach(), gx))
     (y0, g0), (y1, g1) = outs
     assert float((y1 - y0).abs().max()) <= tol * float(y0.abs().max())
-    # LeakyReLU's slope flips where the pre-activation is within rounding of zero: compare away from those pixels
-    stable = y0.abs() > 1e-4
     assert float(((y1 - y0) * stable).abs().max()) <= tol * float(y0.abs().max())
     assert float((g1 - g0).abs().max()) <= 50 * tol * float(g0.abs().max())
 
 
-@pytest.mark.skipif(not __import__("os").environ.get("UFR_EXPERIMENTAL"),
+@pytest.mark.skipif(__import__("os").environ.get("UFR_EXPERIMENTAL") != "1",
                     reason="csrc/split_conv_wide.hip's layout passes have not run on hardware yet")
 @pytest.mark.parametrize("B,C,H,W", [(2, 40, 13, 20), (1, 96, 16, 24), (3, 473, 6, 10)])
 def test_experimental_layout_passes(B, C, H, W):
@@ -142,7 +146,7 @@ def test_experimental_layout_passes(B, C, H, W):
     assert torch.equal(rows_to_nchw(rows, B, C, H, W, bias, 0.1), F.leaky_relu(want + bias.view(1, -1, 1, 1), 0.1))
 
 
-@pytest.mark.skipif(not __import__("os").environ.get("UFR_EXPERIMENTAL"),
+@pytest.mark.skipif(__import__("os").environ.get("UFR_EXPERIMENTAL") != "1",
                     reason="csrc/split_conv_wide.hip's general convolution has not run on hardware yet")
 @pytest.mark.parametrize("B,C,Hi,Wi,N,k,s,p", [(2, 40, 13, 20, 100, 3, 2, 1), (1, 64, 17, 23, 128, 5, 2, 2),
                                               (2, 3, 30, 41, 64, 7, 2, 3), (2, 96, 9, 11, 256, 1, 1, 0),
@@ -165,7 +169,7 @@ def test_general_split_conv_matches_float64(B, C, Hi, Wi, N, k, s, p):
     assert err <= 4e-6, f"{err:.3e}"
 
 
-@pytest.mark.skipif(not __import__("os").environ.get("UFR_EXPERIMENTAL"),
+@pytest.mark.skipif(__import__("os").environ.get("UFR_EXPERIMENTAL") != "1",
                     reason="csrc/split_conv_wide.hip's transposed convolution has not run on hardware yet")
 @pytest.mark.parametrize("B,C,H,W,N,K,p", [(2, 40, 6, 10, 100, 4, 1), (1, 64, 12, 20, 128, 3, 1), (2, 96, 5, 8, 64, 5, 2)])
 def test_deconv_split_matches_float64(B, C, H, W, N, K, p):
@@ -183,7 +187,7 @@ def test_deconv_split_matches_float64(B, C, H, W, N, K, p):
     assert err <= 4e-6, f"{err:.3e}"
 
 
-@pytest.mark.skipif(not __import__("os").environ.get("UFR_EXPERIMENTAL"),
+@pytest.mark.skipif(__import__("os").environ.get("UFR_EXPERIMENTAL") != "1",
                     reason="the any-kernel UFR_SPLIT_CONV wiring has only run with emulated kernels")
 @pytest.mark.parametrize("block", ["conv3x3s2", "conv5x5s2", "deconv4x4s2"])
 def test_strided_blocks_through_the_split_kernels(monkeypatch, block):

@@ -113,6 +113,45 @@ class FlowNetS(_Refinement):
         return (self._refine(c6, (c5, c4, c3, c2)),)
 
 
+class FlowNet2S(FlowNetS):
+    """The registry's `FlowNetS` (models/__init__.py:2 binds it to models/FlowNet2S.py:15-108): two frames in,
+    its own RGB mean subtracted in float64 (:62-68), the FlowNetS trunk on cat(x1, x2), and in eval mode
+    `upsample1(flow2 * 20)` (bilinear x4, :105-108); in training the five raw flows (:102-103).  Same layer names as
+    the reference, so `FlowNet2-S_checkpoint.pth.tar` loads unchanged."""
+
+    _MEAN = (0.4114511, 0.43205959, 0.45015125)
+
+    def __init__(self, input_channels=6, batchNorm=False, return_feat_maps=False):
+        super().__init__(input_channels=input_channels, batchNorm=batchNorm)
+        self.return_feat_maps = return_feat_maps
+        self.register_buffer("_mean64", torch.tensor(self._MEAN, dtype=torch.float64).view(1, 3, 1, 1),
+                             persistent=False)
+
+    def _refine_all(self, c6, skips):
+        flows = [self.predict_flow6(c6)]
+        x = c6
+        for lvl, skip in zip((5, 4, 3, 2), skips):
+            up = getattr(self, f"upsampled_flow{lvl + 1}_to_{lvl}")(flows[-1])
+            x = torch.cat((skip, getattr(self, f"deconv{lvl}")(x), up), 1)
+            flows.append(getattr(self, f"predict_flow{lvl}")(x))
+        return flows[::-1]                                        # flow2 ... flow6
+
+    def forward(self, x1, x2):
+        x1 = (x1.double() - self._mean64).float()
+        x2 = (x2.double() - self._mean64).float()
+        x = torch.cat((x1, x2), dim=1)
+        c2 = self.conv2(self.conv1(x))
+        c3 = self.conv3_1(self.conv3(c2))
+        c4 = self.conv4_1(self.conv4(c3))
+        c5 = self.conv5_1(self.conv5(c4))
+        c6 = self.conv6_1(self.conv6(c5))
+        flows = self._refine_all(c6, (c5, c4, c3, c2))
+        if self.training:
+            return tuple(flows)
+        up = F.interpolate(flows[0] * 20, scale_factor=4, mode="bilinear", align_corners=False)
+        return (up, []) if self.return_feat_maps else up
+
+
 class FlowNetSD(nn.Module):
     """models/flownet2/FlowNetSD.py:12-126: small-displacement net with inter-convolutions."""
 

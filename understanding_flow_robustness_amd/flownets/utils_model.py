@@ -59,8 +59,8 @@ def _build(args, return_feat_maps):
         from .flownet2 import FlowNet2
         return FlowNet2()
     if name == "FlowNetS":
-        from .flownet2 import FlowNetS
-        return FlowNetS(input_channels=6)
+        from .flownet2 import FlowNet2S                 # models/__init__.py:2: FlowNet2S as FlowNetS
+        return FlowNet2S(return_feat_maps=return_feat_maps)
     raise NotImplementedError(
         f"{name!r} is in the reference registry but outside this build's hot-path scope "
         f"(implemented: {', '.join(_IMPLEMENTED)})")
@@ -68,16 +68,22 @@ def _build(args, return_feat_maps):
 
 def fetch_model(args, pretrained_path: str = "pretrained_models", return_feat_maps: bool = False,
                 synthetic_seed: int | None = None) -> torch.nn.Module:
-    """utils_model.py:27-157.  Loads the reference's checkpoint files when they exist; offline
-    (`synthetic_seed` given, or no checkpoint on disk) the model gets seeded synthetic weights."""
+    """utils_model.py:27-157.  Loads the reference's checkpoint file; a missing file raises FileNotFoundError
+    like the reference's `torch.load`.  Seeded synthetic weights (there are no checkpoints offline) are used
+    only when `synthetic_seed` is passed explicitly."""
     if args.flownet not in get_flownet_choices():
         raise ValueError(f"unknown flownet {args.flownet!r}")
     net = _build(args, return_feat_maps)
     fname, key = _CHECKPOINTS.get(args.flownet, (None, None))
     path = os.path.join(str(pretrained_path), fname) if fname else None
-    if synthetic_seed is None and path and os.path.exists(path):
+    if synthetic_seed is None:
+        if not (path and os.path.exists(path)):
+            raise FileNotFoundError(
+                f"fetch_model({args.flownet!r}): checkpoint {path!r} not found (pass synthetic_seed=<int> for "
+                f"seeded synthetic weights)")
         weights = torch.load(path, map_location="cpu")
-        weights = weights[key] if key and key in weights else weights
+        if isinstance(weights, dict) and "state_dict" in weights:   # wrapped checkpoints, whatever `key` says
+            weights = weights["state_dict"]
         try:
             net.load_state_dict(weights)
         except RuntimeError:
@@ -87,7 +93,7 @@ def fetch_model(args, pretrained_path: str = "pretrained_models", return_feat_ma
                 own[k] = v
             net.load_state_dict(own)
     else:
-        net.load_state_dict(synthetic_state_dict(net.state_dict(), seed=synthetic_seed or 0))
+        net.load_state_dict(synthetic_state_dict(net.state_dict(), seed=synthetic_seed))
     return net.eval()
 
 

@@ -109,19 +109,25 @@ def split_conv_applicable(x: torch.Tensor, conv: torch.nn.Conv2d) -> bool:
 
 
 def _weight_planes(weight: torch.Tensor, adjoint: bool) -> torch.Tensor:
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), adjoint)
+    """Pre-split planes of a frozen weight, cached per tensor OBJECT (weak reference + version counter): an address
+    reused by the allocator for another tensor can never return stale planes."""
+    import weakref
+    key = (id(weight), adjoint)
     hit = _WEIGHT_PLANES.get(key)
-    if hit is None:
-        if len(_WEIGHT_PLANES) >= 512:
-            _WEIGHT_PLANES.clear()
-        hit = _WEIGHT_PLANES[key] = chunk_major(conv3x3_weight_planes(weight, data_gradient=adjoint))
-    return hit
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
+        return hit[2]
+    if len(_WEIGHT_PLANES) >= 512:
+        for k in [k for k, v in _WEIGHT_PLANES.items() if v[0]() is None]:
+            del _WEIGHT_PLANES[k]
+    planes = chunk_major(conv3x3_weight_planes(weight, data_gradient=adjoint))
+    _WEIGHT_PLANES[key] = (weakref.ref(weight), weight._version, planes)
+    return planes
 
 
 def _experimental() -> bool:
     """UFR_EXPERIMENTAL=1: the kernels of csrc/split_conv_wide.hip (written after round 1's GPU budget, not yet run)."""
     import os
-    return bool(os.environ.get("UFR_EXPERIMENTAL"))
+    return os.environ.get("UFR_EXPERIMENTAL") == "1"
 
 
 def nchw_to_planes_cm(x: torch.Tensor) -> torch.Tensor:
