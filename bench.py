@@ -4,11 +4,12 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 metric   : attack-iters/s = frame pairs x I-FGSM patch iterations per second
-workload : configs[1] -- FlowNetC, 384x1280 synthetic frame pairs, batch 8 per GPU, one shared 51x51
-           circular patch, cosine loss, lr 1000 (patch_attacks/main.py defaults), fp32 end to end.
+workload : configs[1] -- FlowNetC, 384x1280 synthetic frame pairs, batch 8 per GPU, ONE 51x51 circular patch in
+           patch coordinates shown by every pair at its own placement, cosine loss, lr 1000
+           (patch_attacks/main.py defaults), fp32 end to end.
 step     : ONE inner-loop iteration of attack() (main.py:546-611) over the rank's batch:
-           paste -> FlowNetC forward -> loss -> data-gradient backward -> clamp/update/re-paste,
-           replayed as one HIP graph (+ one RCCL all-reduce of the pre-clamp patch gradient when N>1).
+           paste -> FlowNetC forward -> loss -> data-gradient backward -> crop to [3,51,51] + sum -> clamp/update/re-paste,
+           replayed as one HIP graph (N>1: two graphs around one RCCL all-gather of the 31 KB [crop | loss] rows).
 scaling  : weak (8 pairs per GPU); value = N*8*K / max-over-ranks time.
 Inputs are resident in HBM before the timed region.  The JSON line also carries
   roofline     -- the step against the fp32 MFMA peak (convs are ~98% of the FLOPs) and, under
@@ -74,16 +75,13 @@ def circle_mask(size):
 
 
 def synthetic_batch(batch, seed, device):
+    """Frames + one seeded random placement (row, column) per pair (circle_transform places randomly)."""
     g = torch.Generator().manual_seed(seed)
     tgt = torch.rand(batch, 3, H, W, generator=g)
     ref = torch.rand(batch, 3, H, W, generator=g)
-    mask = torch.zeros(batch, 3, H, W)
-    circ = circle_mask(PATCH)
-    for b in range(batch):   # seeded random placement per sample (circle_transform places randomly)
-        y = int(torch.randint(0, H - PATCH, (1,), generator=g))
-        x = int(torch.randint(0, W - PATCH, (1,), generator=g))
-        mask[b, :, y:y + PATCH, x:x + PATCH] = circ
-    return tgt.to(device), ref.to(device), mask.to(device)
+    origins = [(int(torch.randint(0, H - PATCH, (1,), generator=g)), int(torch.randint(0, W - PATCH, (1,), generator=g)))
+               for _ in range(batch)]
+    return tgt.to(device), ref.to(device), origins
 
 
 def event_time(fn, iters, warm=2):
@@ -173,7 +171,8 @@ def cpu_baseline():
     torch.set_num_threads(cores)
     oracle_ops.lib().ufr_oracle_set_threads(cores)
     sd = synthetic_state_dict(FlowNetC().state_dict(), seed=0)
-    tgt, ref, mask = synthetic_batch(1, 1234, "cpu")
+    tgt, ref, origins = synthetic_batch(1, 1234, "cpu")
+    mask = fo.place(circle_mask(PATCH).expand(1, 3, PATCH, PATCH), origins, H, W)      # the reference's canvas form
     g = torch.Generator().manual_seed(99)
     patch0 = torch.rand(1, 3, H, W, generator=g) * mask
     predict = lambda x, y: fo.flownetc_forward(sd, x, y)
@@ -229,19 +228,20 @@ def main():
         net = net.to(memory_format=torch.channels_last)
     exchange = ShardedExchange() if world > 1 else None
     step = PatchAttackStep(net, args, B_PER_GPU, H, W, device=device, shared_patch=True, exchange=exchange,
-                           use_graph=not opt.no_graph, warmup=2)
+                           use_graph=not opt.no_graph, warmup=2, patch_hw=(PATCH, PATCH))
 
     # two resident batches (frames AND patch placements differ): consecutive attack() calls never see
     # the same operands, so nothing cached for one call can serve the next
     g = torch.Generator().manual_seed(7)
-    patch0 = torch.rand(1, 3, H, W, generator=g).to(device)     # same patch on every rank
+    patch0 = torch.rand(1, 3, PATCH, PATCH, generator=g).to(device)     # same patch on every rank
+    mask_p = circle_mask(PATCH).expand(1, 3, PATCH, PATCH).contiguous().to(device)
     batches = []
     for k in range(2):
-        tgt, ref, mask = synthetic_batch(B_PER_GPU, 1000 + 17 * k + rank, device)
+        tgt, ref, origins = synthetic_batch(B_PER_GPU, 1000 + 17 * k + rank, device)
         with torch.no_grad():
             target = -torch.cat([net(tgt[i:i + 1], ref[i:i + 1]) for i in range(B_PER_GPU)])   # main.py:395
-        batches.append((tgt, ref, patch0, mask, patch0, target))
-    step.load(*batches[0])
+        batches.append(dict(args=(tgt, ref, patch0, mask_p, patch0, target), origins=origins))
+    step.load(*batches[0]["args"], origins=batches[0]["origins"])
     step.run(0)                                                  # warm-up + graph capture, reloads operands
     mc = max(1, opt.max_count)
     executed_acc = torch.zeros(1, device=device)
@@ -252,7 +252,7 @@ def main():
         and then replays the captured iteration.  Nothing is read back."""
         call, left = first_call, iterations
         while left > 0:
-            step.load(*batches[call % 2])
+            step.load(*batches[call % 2]["args"], origins=batches[call % 2]["origins"])
             n = min(mc, left)
             step.enqueue(n)
             executed_acc.add_(step.state[1])
@@ -298,7 +298,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "FlowNetC 384x1280 I-FGSM patch attack (configs[1])", "pairs_per_gpu": B_PER_GPU,
-                       "global_pairs": world * B_PER_GPU, "patch": "51x51 circular, shared, canvas-sized update",
+                       "global_pairs": world * B_PER_GPU, "patch": "ONE 51x51 circular patch in patch coordinates, shown by every pair at its own placement",
                        "calls": f"attack() calls of max_count={mc} iterations, new frames + placement per call",
                        "prefix": (f"conv1-3 on a {step.win_hw[0]}x{step.win_hw[1]} window per pair"
                                   if step.cone is not None else "full frame"),
@@ -306,7 +306,8 @@ def main():
                                         if band is not None else "full width"),
                        "loss": "cosine", "lr": 1000.0, "weights": "synthetic seeded (no checkpoints offline)",
                        "graph": not opt.no_graph,
-                       "parallelism": f"dp{world}: batch sharded, all-reduce of pre-clamp patch gradient"},
+                       "parallelism": (f"dp{world}: pairs sharded, per-rank crop of the pre-clamp gradient to [3,51,51], "
+                                       f"all-gather of {world} x 31 KB rows + fixed-order sum before the clamp")},
             "roofline": {"bound": "mfma", "kernel": "attack step = 1 hipGraph launch (MIOpen fp32 convs + ufr_* kernels)",
                          "achieved": round(tf, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tf / PEAK_FP32_TFLOPS, 4), "traffic": step_traffic(),
@@ -319,17 +320,18 @@ def main():
                 # the same protocol with every frame-sized shortcut off (UFR_CONE=0): what the windowed prefix,
                 # band and incremental forward are worth, measured in this very process
                 ref_step = PatchAttackStep(net, args, B_PER_GPU, H, W, device=device, shared_patch=True,
-                                           use_graph=not opt.no_graph, warmup=2, use_cone=False)
-                ref_step.load(*batches[0])
+                                           use_graph=not opt.no_graph, warmup=2, use_cone=False, patch_hw=(PATCH, PATCH))
+                ref_load = lambda c: ref_step.load(*batches[c % 2]["args"], origins=batches[c % 2]["origins"])
+                ref_load(0)
                 ref_step.run(0)
                 k = 6
                 for c in range(2):
-                    ref_step.load(*batches[c % 2]); ref_step.enqueue(mc)
+                    ref_load(c); ref_step.enqueue(mc)
                 torch.cuda.synchronize(device)
                 t1 = time.perf_counter()
                 done = 0
                 while done < k:
-                    ref_step.load(*batches[(done // mc) % 2]); ref_step.enqueue(min(mc, k - done)); done += mc
+                    ref_load(done // mc); ref_step.enqueue(min(mc, k - done)); done += mc
                 torch.cuda.synchronize(device)
                 line["config"]["full_frame_attack_iters_per_s"] = round(B_PER_GPU * k / (time.perf_counter() - t1), 2)
             if not opt.no_cpu_baseline:

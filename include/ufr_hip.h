@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define UFR_ABI_VERSION 1
+#define UFR_ABI_VERSION 2
 
 enum { UFR_F32 = 0, UFR_F64 = 1 };
 enum {
@@ -130,21 +130,14 @@ int ufr_channelnorm_backward(const float* input1, const float* output, const flo
 int ufr_patch_paste(const float* tgt, const float* ref, const float* patch, const float* mask,
                     float* adv_tgt, float* adv_ref, int B, int CHW, long patch_bstride,
                     long mask_bstride, int do_clamp, float lo, float hi, ufr_stream_t stream);
-/* ufr_patch_update: patch -= clamp(step * sum_b (g_tgt + g_ref), -bound, bound)   (main.py:581-583,
- *   step = 0.5*lr, bound = 2), then re-paste + clamp both frames (main.py:585-600).
- *   With patch_bstride == 0 the gradients of the B samples are summed (batch extension);
- *   `grad_sum` (canvas-sized, may be NULL) receives / supplies the pre-clamp gradient sum:
- *   mode 0: compute sum from g_tgt/g_ref and use it;  mode 1: only write grad_sum (for an
- *   all-reduce across ranks);  mode 2: use grad_sum as given (after the all-reduce).
- *   mode | UFR_UPDATE_MASKED_SUM: sample b enters the sum only where mask_b != 0 -- the gradient of
- *   the batch loss with respect to the shared patch.  Without it the sum is the reference's unmasked
- *   g_tgt + g_ref (main.py:575-583; identical wherever the mask shows the patch when B = 1). */
-#define UFR_UPDATE_MASKED_SUM 4
+/* ufr_patch_update: patch -= clamp(step * (g_tgt + g_ref), -bound, bound)   (main.py:581-583,
+ *   step = 0.5*lr, bound = 2), then re-paste + clamp both frames (main.py:585-600): the reference's
+ *   canvas-sized arithmetic, for one pair (patch_bstride 0, B = 1) or B independent attacks with their own
+ *   canvas patches (patch_bstride = CHW).  One patch behind several pairs is the patch-coordinate family below. */
 int ufr_patch_update(const float* tgt, const float* ref, const float* g_tgt, const float* g_ref,
-                     float* grad_sum, float* patch, const float* mask, float* adv_tgt,
-                     float* adv_ref, int B, int CHW, long patch_bstride, long mask_bstride,
-                     float step, float bound, float lo, float hi, int mode, const float* gate_state,
-                     ufr_stream_t stream);
+                     float* patch, const float* mask, float* adv_tgt, float* adv_ref, int B, int CHW,
+                     long patch_bstride, long mask_bstride, float step, float bound, float lo, float hi,
+                     const float* gate_state, ufr_stream_t stream);
 /* Device-side form of the loop control of attack() (main.py:546 `while loss_scalar > 0.1`, :605
  * `loss.item()`, :610 `count > max_count-1`): the reference synchronises the host every iteration
  * to read the loss; here iterations are enqueued back to back and a 3-float state word decides on
@@ -154,12 +147,37 @@ int ufr_patch_update(const float* tgt, const float* ref, const float* g_tgt, con
  * ufr_attack_gate runs after it: if not stopped { state[1]+=1; state[2]=*loss_cur;
  *   if (*loss_cur <= threshold) state[0]=1; }   -- exactly the reference's order of events. */
 int ufr_attack_gate(const float* loss_cur, float* state, float threshold, ufr_stream_t stream);
+/* ---- one patch shared by several pairs, in PATCH coordinates ------------------------
+ * The reference keeps the patch canvas-sized inside attack() and crops it at the sample's placement
+ * (ry, rx) back to patch_shape afterwards (patch_attacks/main.py:396-424, :408 mask, :410-424 crop).  With B pairs
+ * (and N ranks) behind ONE patch the common object is therefore the cropped patch P[3,ph,pw] with its mask
+ * Mp[3,ph,pw]; pair b shows it at origins[2b] = row, origins[2b+1] = column (int32, device-resident so one
+ * captured graph serves every placement; `origins_host`, optional, lets the call validate the placements).
+ * ufr_patch_grad_crop: rows[g][e] = [Mp[e] != 0] * sum over the pairs of group g, ascending, of
+ *   (g_tgt + g_ref)[b, c, row_b + i, col_b + j]; rows is [groups][3*ph*pw + 1], the last column carries the
+ *   rank's loss (*loss_local, row 0).  A rank contributes its rows to an all-gather (31 KB per row at 51x51).
+ * ufr_patch_apply: G = sum of n_rows rows in ascending order (bit-identical on every rank),
+ *   P -= clamp(step*G, +-bound) (main.py:581-583), *loss = sum of the rows' last column.
+ * ufr_patch_paste_placed: adv = clamp((1-M_b)*img + M_b*place(P)) for both frames of every pair
+ *   (main.py:537-542 with do_clamp = 0, :585-600 with 1); mask_out (optional) receives the canvas masks M_b. */
+int ufr_patch_grad_crop(const float* g_tgt, const float* g_ref, const float* mask_p, const int* origins,
+                        const int* origins_host, const float* loss_local, float* rows, int B, int H, int W,
+                        int ph, int pw, int groups, ufr_stream_t stream);
+int ufr_patch_apply(const float* rows, int n_rows, float* patch_p, float* loss, int ph, int pw, float step,
+                    float bound, const float* gate_state, ufr_stream_t stream);
+int ufr_patch_paste_placed(const float* tgt, const float* ref, const float* patch_p, const float* mask_p,
+                           const int* origins, const int* origins_host, float* adv_tgt, float* adv_ref,
+                           float* mask_out, int B, int H, int W, int ph, int pw, int do_clamp, float lo, float hi,
+                           const float* gate_state, ufr_stream_t stream);
 /* ufr_flow_loss: loss = mean_b,h,w(1 - cos(flow, target))            (kind 0, main.py:564-566)
  *             or mean(sqrt(sum_c (flow-target)^2 + 1e-8))           (kind 1, main.py:557-562)
  *   flow,target: [B,2,H,W].  Writes d loss / d flow (already scaled by `weight`, = 1-alpha) to
- *   grad_flow and accumulates the scalar loss into *loss (caller zeroes it). */
+ *   grad_flow and accumulates the scalar loss into *loss (caller zeroes it).  `partials` = workspace of
+ *   UFR_LOSS_PARTIALS floats: the workgroups' partial sums, added in a fixed order by a second one-wave
+ *   kernel, so the scalar behind `while loss_scalar > 0.1` (main.py:546) is bit-reproducible run to run. */
+#define UFR_LOSS_PARTIALS 512
 int ufr_flow_loss(const float* flow, const float* target, float* grad_flow, float* loss, int B,
-                  int HW, int kind, float weight, ufr_stream_t stream);
+                  int HW, int kind, float weight, float* partials, ufr_stream_t stream);
 
 /* ---- RAFT SepConvGRU gate arithmetic -----------------------------------------------------------
  * replaces the elementwise half of models/raft/update.py:61-73 (10 launches forward per half-step):
@@ -242,15 +260,16 @@ int ufr_convex_upsample_backward(const float* flow, const float* mask, const flo
  * ufr_flow_loss_ex: kind 0 cossim, 1 l2 (sqrt(.+10e-8)), 2 l1; gt has 2 channels, or 3 with a
  *   validity mask in the last one.  scale = 1/(averaged element count) or 1/(sum(valid)+1e-8), taken
  *   from *scale_dev when that device pointer is non-NULL (so a captured graph follows new masks),
- *   else from `scale`.  Writes d loss/d flow, accumulates the scalar into *loss. */
+ *   else from `scale`.  Writes d loss/d flow, accumulates the scalar into *loss (`partials`: as ufr_flow_loss). */
 int ufr_flow_loss_ex(const float* flow, const float* gt, float* grad_flow, float* loss, int B, int HW,
-                     int gt_channels, int kind, float scale, const float* scale_dev, ufr_stream_t stream);
+                     int gt_channels, int kind, float scale, const float* scale_dev, float* partials,
+                     ufr_stream_t stream);
 /* ufr_universal_update: one sign-gradient step on both frames.
  *   shared = 0: the reference's per-sample arithmetic; delta is [B,2,3,H,W]
  *       adv = clamp(adv -/+ lr*dir(g), lo, hi); noise = clamp(adv - img, +-eps); adv = img + noise
  *   shared = 1: one perturbation [2,3,H,W] for the whole (sharded) batch, direction from the SUM of
- *       the per-sample gradients; modes as in ufr_patch_update (0 fused, 1 sum only -> grad_sum
- *       [2*CHW], 2 apply grad_sum) so an all-reduce can sit between 1 and 2.
+ *       the per-sample gradients; mode 0 fused, 1 sum only -> grad_sum
+ *       [2*CHW], 2 apply grad_sum, so an all-reduce can sit between 1 and 2.
  *   use_sign: 1 = I-FGSM (torch.sign), 0 = "ifgm"; frames: bit 0 = frame 0, bit 1 = frame 1
  *   (perturb_mode both/left/right); ascent: 0 = gradient descent (default), 1 = --add_gaussian. */
 int ufr_universal_update(const float* img0, const float* img1, const float* g0, const float* g1,

@@ -248,7 +248,7 @@ def _raft_lookup(pyramid, coords, r=4):
     B, H, W, _ = coords.shape
     out = []
     for i, corr in enumerate(pyramid):
-        d = torch.linspace(-r, r, 2 * r + 1)
+        d = torch.linspace(-r, r, 2 * r + 1, dtype=coords.dtype, device=coords.device)
         delta = torch.stack(torch.meshgrid(d, d, indexing="ij"), dim=-1)
         cl = coords.reshape(B * H * W, 1, 1, 2) / 2 ** i + delta.view(1, 2 * r + 1, 2 * r + 1, 2)
         hh, ww = corr.shape[-2:]
@@ -256,11 +256,16 @@ def _raft_lookup(pyramid, coords, r=4):
         yg = 2 * cl[..., 1:2] / (hh - 1) - 1
         s = F.grid_sample(corr, torch.cat([xg, yg], dim=-1), align_corners=True)
         out.append(s.view(B, H, W, -1))
-    return torch.cat(out, dim=-1).permute(0, 3, 1, 2).contiguous().float()
+    return torch.cat(out, dim=-1).permute(0, 3, 1, 2).contiguous().to(coords.dtype)     # `.float()` in the reference
 
 
 def raft_forward(sd, image1, image2, iters=12, levels=4, radius=4, alternate_corr=False):
-    """models/raft/raft.py:124-233, test_mode=True, fp32; returns (flow_low, flow_up)."""
+    """models/raft/raft.py:124-233, test_mode=True; returns (flow_low, flow_up).  Runs in the dtype and on the device
+    of its inputs: float32 on the CPU is the reference's arithmetic operation for operation (the `.float()` casts of
+    the reference are no-ops there); float64 serves as the conditioning-free truth of the RAFT gradient tests, and
+    HIP tensors give the pure-torch spelling (grid_sample lookup, torch GRU, unfold upsampling) on the same device
+    as the product's kernels."""
+    dt, dev = image1.dtype, image1.device
     def conv(name, t, pad=None):
         w = sd[name + ".weight"]
         pad = ((w.shape[-2] - 1) // 2, (w.shape[-1] - 1) // 2) if pad is None else pad
@@ -270,7 +275,7 @@ def raft_forward(sd, image1, image2, iters=12, levels=4, radius=4, alternate_cor
     image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
     f = _raft_encoder(sd, "fnet", torch.cat([image1, image2], 0), "instance")
     B = image1.shape[0]
-    fmap1, fmap2 = f[:B].float(), f[B:].float()
+    fmap1, fmap2 = f[:B].to(dt), f[B:].to(dt)
     _, C, H, W = fmap1.shape
     if alternate_corr:
         f2_levels = [fmap2]
@@ -278,14 +283,14 @@ def raft_forward(sd, image1, image2, iters=12, levels=4, radius=4, alternate_cor
             f2_levels.append(F.avg_pool2d(f2_levels[-1], 2, stride=2))
     else:
         corr = torch.matmul(fmap1.view(B, C, H * W).transpose(1, 2), fmap2.view(B, C, H * W))
-        corr = (corr.view(B, H, W, 1, H, W) / torch.sqrt(torch.tensor(C).float())).reshape(B * H * W, 1, H, W)
+        corr = (corr.view(B, H, W, 1, H, W) / torch.sqrt(torch.tensor(C, device=dev).to(dt))).reshape(B * H * W, 1, H, W)
         pyramid = [corr]
         for _ in range(levels - 1):
             pyramid.append(F.avg_pool2d(pyramid[-1], 2, stride=2))
     cnet = _raft_encoder(sd, "cnet", image1, "batch")
     net, inp = torch.tanh(cnet[:, :128]), torch.relu(cnet[:, 128:])
-    ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
-    coords0 = torch.stack([xs, ys], dim=0).float()[None].repeat(B, 1, 1, 1)
+    ys, xs = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
+    coords0 = torch.stack([xs, ys], dim=0).to(dt)[None].repeat(B, 1, 1, 1)
     coords1 = coords0.clone()
     flow_up = None
     ub = "update_block."
@@ -298,7 +303,7 @@ def raft_forward(sd, image1, image2, iters=12, levels=4, radius=4, alternate_cor
                 (o,) = oo.altcorr_forward(fmap1.detach().permute(0, 2, 3, 1).contiguous(),
                                           f2_levels[i].detach().permute(0, 2, 3, 1).contiguous(), c_i, radius)
                 outs.append(o.squeeze(1))
-            corr_feat = torch.stack(outs, dim=1).reshape(B, -1, H, W) / torch.sqrt(torch.tensor(C).float())
+            corr_feat = torch.stack(outs, dim=1).reshape(B, -1, H, W) / torch.sqrt(torch.tensor(C, device=dev).to(dt))
         else:
             corr_feat = _raft_lookup(pyramid, coords1, radius)
         flow = coords1 - coords0
@@ -336,11 +341,11 @@ def patch_attack(predict, tgt, ref, patch, mask, patch_init, target, lr=1e3, alp
     """patch_attacks/main.py:523-613 for a `predict(adv_tgt, adv_ref) -> flow` callable.
 
     `patch` is updated in place like the reference's patch_var; returns
-    (adv_tgt, adv_ref, patch, executed_iterations, last_loss).  With a batch of B > 1 the patch is
-    shared ([1,3,H,W]) and the per-sample gradients are summed before the clamp, each sample
-    contributing only where ITS mask shows the patch -- the gradient of the batch loss with respect to
-    the shared patch (the build's batch extension); B = 1 is the reference's arithmetic
-    exactly (it adds the image gradient outside the mask too, where nothing ever reads the patch).
+    (adv_tgt, adv_ref, patch, executed_iterations, last_loss).  B = 1 is the reference's arithmetic
+    exactly (it adds the image gradient outside the mask too, where nothing ever reads the patch); with
+    per-sample canvas patches ([B,3,H,W]) every sample is its own reference attack.  (A [1,3,H,W] canvas patch
+    with B > 1 sums masked canvas gradients: kept for the CPU tests of round 1; ONE patch behind several
+    pairs is `patch_attack_placed`, in patch coordinates.)
     """
     adv_tgt = (1 - mask) * tgt + mask * patch                   # :537-542
     adv_ref = (1 - mask) * ref + mask * patch
@@ -367,6 +372,58 @@ def patch_attack(predict, tgt, ref, patch, mask, patch_init, target, lr=1e3, alp
         if count > max_count - 1:                               # :610-611
             break
     return adv_tgt.detach(), adv_ref.detach(), patch, count, loss_scalar
+
+
+def place(patch_p, origins, H, W):
+    """[1,3,ph,pw] at per-pair (row, column) origins -> canvases [B,3,H,W], zero elsewhere."""
+    ph, pw = patch_p.shape[-2:]
+    out = patch_p.new_zeros(len(origins), patch_p.shape[1], H, W)
+    for b, (oy, ox) in enumerate(origins):
+        out[b, :, oy:oy + ph, ox:ox + pw] = patch_p[0]
+    return out
+
+
+def patch_attack_placed(predict, tgt, ref, patch_p, mask_p, origins, target, lr=1e3, max_count=2, l2=False,
+                        clamp=(0.0, 1.0), groups=1, trace=None):
+    """The batch extension of patch_attacks/main.py:523-613: ONE patch in PATCH coordinates --
+    what the reference carries between samples is the canvas cropped at the placement (ry, rx) back to
+    `patch_shape`, main.py:396-424 -- behind B pairs that show it at `origins[b] = (row, column)`.
+    Per iteration: loss = mean over all B*H*W pixels; every pair's pre-clamp gradient (g_tgt + g_ref) is cropped at
+    its placement, masked by [mask_p != 0], and summed -- pairs of a group in ascending order, then the groups in
+    ascending order (`groups` = the ranks of a sharded run: same summation tree, bit for bit) -- before
+    `P -= clamp(0.5*lr*G, +-2)`.  `patch_p` [1,3,ph,pw] is updated in place.
+    Returns (adv_tgt, adv_ref, patch_p, executed_iterations, last_loss)."""
+    B, _, H, W = tgt.shape
+    ph, pw = patch_p.shape[-2:]
+    mask = place(mask_p, origins, H, W)
+    shown = (mask_p != 0).float()
+    adv_tgt = (1 - mask) * tgt + mask * place(patch_p, origins, H, W)        # :537-542
+    adv_ref = (1 - mask) * ref + mask * place(patch_p, origins, H, W)
+    count, loss_scalar = 0, 1.0
+    per = B // groups
+    while loss_scalar > 0.1:                                               # :546
+        count += 1
+        adv_tgt = adv_tgt.detach().requires_grad_(True)
+        adv_ref = adv_ref.detach().requires_grad_(True)
+        loss = flow_loss(predict(adv_tgt, adv_ref), target, l2)
+        g_tgt, g_ref = torch.autograd.grad(loss, (adv_tgt, adv_ref))
+        G = torch.zeros_like(patch_p)
+        for gi in range(groups):
+            row = torch.zeros_like(patch_p)
+            for b in range(gi * per, (gi + 1) * per):
+                oy, ox = origins[b]
+                row = row + (g_tgt[b:b + 1, :, oy:oy + ph, ox:ox + pw] + g_ref[b:b + 1, :, oy:oy + ph, ox:ox + pw])
+            G = G + row * shown
+        patch_p -= torch.clamp(0.5 * lr * G, -2, 2)                        # :581-583
+        canvas = place(patch_p, origins, H, W)
+        adv_tgt = torch.clamp((1 - mask) * tgt + mask * canvas, *clamp)    # :585-600
+        adv_ref = torch.clamp((1 - mask) * ref + mask * canvas, *clamp)
+        loss_scalar = float(loss.detach())                                 # :605
+        if trace is not None:
+            trace.append(dict(loss=loss_scalar, patch=patch_p.clone(), G=G.clone(), g_tgt=g_tgt.clone(), g_ref=g_ref.clone()))
+        if count > max_count - 1:                                          # :610-611
+            break
+    return adv_tgt.detach(), adv_ref.detach(), patch_p, count, loss_scalar
 
 
 def compute_flow_loss(flow_output, ground_truth, flow_loss="cossim"):

@@ -61,10 +61,10 @@ def test_attack_matches_reference_trace(net, name, l2, lr, use_graph):
         ref_patch = t(z[f"{name}_it{iters}_patch"])
         upd = (ref_patch - t(z["patch0"])).abs().max()
         err = (patch.cpu() - ref_patch).abs().max()
-        assert float(err) <= REL * max(float(upd), 1.0) + 2e-4 * float(upd), \
+        assert float(err) <= REL * max(float(upd), 1.0), \
             f"{name} it{iters}: patch err {float(err):.3e}, update magnitude {float(upd):.3e}"
-        assert_close(a_t[:, :, 20:45, 50:75], t(z[f"{name}_it{iters}_adv_tgt"]), rtol=REL, atol_scale=3e-4)
-        assert_close(a_r[:, :, 20:45, 50:75], t(z[f"{name}_it{iters}_adv_ref"]), rtol=REL, atol_scale=3e-4)
+        assert_close(a_t[:, :, 20:45, 50:75], t(z[f"{name}_it{iters}_adv_tgt"]), rtol=REL, atol_scale=REL)
+        assert_close(a_r[:, :, 20:45, 50:75], t(z[f"{name}_it{iters}_adv_ref"]), rtol=REL, atol_scale=REL)
 
 
 def test_attack_fused_kernels_bit_exact_vs_torch(net):
@@ -83,17 +83,62 @@ def test_attack_fused_kernels_bit_exact_vs_torch(net):
     assert torch.equal(a_t, torch.mul(1 - mask, tgt) + torch.mul(mask, patch))
     assert torch.equal(a_r, torch.mul(1 - mask, ref) + torch.mul(mask, patch))
     g_t, g_r = torch.randn(B, 3, H, W, generator=g).to(DEV) * 1e-3, torch.randn(B, 3, H, W, generator=g).to(DEV) * 1e-3
-    gsum = torch.zeros(CHW + 1, device=DEV)
-    p2 = patch.clone()
-    L.check(L.lib().ufr_patch_update(L.ptr(tgt), L.ptr(ref), L.ptr(g_t), L.ptr(g_r), L.ptr(gsum), L.ptr(p2),
-                                     L.ptr(mask), L.ptr(a_t), L.ptr(a_r), B, CHW, 0, CHW, 500.0, 2.0, 0.0, 1.0, 0,
-                                     None, L.stream()))
-    s = torch.zeros(1, 3, H, W, device=DEV)
-    for b in range(B):
-        s = s + (g_t[b:b + 1] + g_r[b:b + 1])
-    want = patch - torch.clamp(500.0 * s, -2, 2)
+    # canvas form, per-sample patches: the reference's B=1 arithmetic sample by sample (main.py:575-600)
+    pp = (torch.rand(B, 3, H, W, generator=g) * 3 - 1).to(DEV)
+    p2 = pp.clone()
+    L.check(L.lib().ufr_patch_update(L.ptr(tgt), L.ptr(ref), L.ptr(g_t), L.ptr(g_r), L.ptr(p2), L.ptr(mask), L.ptr(a_t),
+                                     L.ptr(a_r), B, CHW, CHW, CHW, 500.0, 2.0, 0.0, 1.0, None, L.stream()))
+    want = pp - torch.clamp(500.0 * (g_t + g_r), -2, 2)
     assert torch.equal(p2, want)
     assert torch.equal(a_t, torch.clamp(torch.mul(1 - mask, tgt) + torch.mul(mask, want), 0, 1))
+    # one canvas patch behind several pairs is refused: that case lives in patch coordinates
+    rc = L.lib().ufr_patch_update(L.ptr(tgt), L.ptr(ref), L.ptr(g_t), L.ptr(g_r), L.ptr(p2), L.ptr(mask), L.ptr(a_t),
+                                  L.ptr(a_r), B, CHW, 0, CHW, 500.0, 2.0, 0.0, 1.0, None, L.stream())
+    assert rc != 0
+    # patch-coordinate family: crop + group sums, fixed-order apply, placed paste -- against torch expressions
+    ph, pw = 7, 9
+    B4 = 4
+    tgt4, ref4 = torch.rand(B4, 3, H, W, generator=g).to(DEV), torch.rand(B4, 3, H, W, generator=g).to(DEV)
+    g4t, g4r = torch.randn(B4, 3, H, W, generator=g).to(DEV) * 1e-3, torch.randn(B4, 3, H, W, generator=g).to(DEV) * 1e-3
+    P = (torch.rand(1, 3, ph, pw, generator=g) * 3 - 1).to(DEV)
+    Mp = (torch.rand(1, 3, ph, pw, generator=g) > 0.3).float().to(DEV)
+    org = [(0, 0), (17, 31), (5, 12), (10, 3)]
+    origins = torch.tensor(org, dtype=torch.int32, device=DEV)
+    loss_local = torch.tensor([0.625], device=DEV)
+    n = 3 * ph * pw
+    for groups in (1, 2, 4):
+        rows = torch.full((groups, n + 1), float("nan"), device=DEV)
+        L.check(L.lib().ufr_patch_grad_crop(L.ptr(g4t), L.ptr(g4r), L.ptr(Mp), L.ptr(origins), None, L.ptr(loss_local),
+                                            L.ptr(rows), B4, H, W, ph, pw, groups, L.stream()))
+        per = B4 // groups
+        for gi in range(groups):
+            acc = torch.zeros(3, ph, pw, device=DEV)
+            for b in range(gi * per, (gi + 1) * per):
+                oy, ox = org[b]
+                acc = acc + (g4t[b, :, oy:oy + ph, ox:ox + pw] + g4r[b, :, oy:oy + ph, ox:ox + pw])
+            assert torch.equal(rows[gi, :n].view(3, ph, pw), acc * (Mp[0] != 0))
+            assert float(rows[gi, n]) == (0.625 if gi == 0 else 0.0)
+        P2, loss = P.clone(), torch.zeros(1, device=DEV)
+        L.check(L.lib().ufr_patch_apply(L.ptr(rows), groups, L.ptr(P2), L.ptr(loss), ph, pw, 500.0, 2.0, None, L.stream()))
+        G = torch.zeros(n, device=DEV)
+        for gi in range(groups):
+            G = G + rows[gi, :n]
+        assert torch.equal(P2.view(-1), P.view(-1) - torch.clamp(500.0 * G, -2, 2)) and float(loss) == 0.625
+    a4t, a4r, m4 = torch.empty_like(tgt4), torch.empty_like(tgt4), torch.empty_like(tgt4)
+    L.check(L.lib().ufr_patch_paste_placed(L.ptr(tgt4), L.ptr(ref4), L.ptr(P), L.ptr(Mp), L.ptr(origins), None, L.ptr(a4t),
+                                           L.ptr(a4r), L.ptr(m4), B4, H, W, ph, pw, 1, 0.0, 1.0, None, L.stream()))
+    canvas_m, canvas_p = torch.zeros_like(tgt4), torch.zeros_like(tgt4)
+    for b, (oy, ox) in enumerate(org):
+        canvas_m[b, :, oy:oy + ph, ox:ox + pw] = Mp[0]
+        canvas_p[b, :, oy:oy + ph, ox:ox + pw] = P[0]
+    assert torch.equal(m4, canvas_m)
+    assert torch.equal(a4t, torch.clamp(torch.mul(1 - canvas_m, tgt4) + torch.mul(canvas_m, canvas_p), 0, 1))
+    assert torch.equal(a4r, torch.clamp(torch.mul(1 - canvas_m, ref4) + torch.mul(canvas_m, canvas_p), 0, 1))
+    import numpy as np
+    bad = np.array([[0, 0], [20, 31], [5, 12], [10, 3]], dtype=np.int32)       # 20 + 7 > 24: leaves the frame
+    rc = L.lib().ufr_patch_paste_placed(L.ptr(tgt4), L.ptr(ref4), L.ptr(P), L.ptr(Mp), L.ptr(origins), bad.ctypes.data,
+                                        L.ptr(a4t), L.ptr(a4r), None, B4, H, W, ph, pw, 1, 0.0, 1.0, None, L.stream())
+    assert rc != 0
     flow, target = torch.randn(B, 2, H, W, generator=g).to(DEV), torch.randn(B, 2, H, W, generator=g).to(DEV)
     for kind in (0, 1):
         f = flow.clone().requires_grad_(True)
@@ -102,10 +147,14 @@ def test_attack_fused_kernels_bit_exact_vs_torch(net):
         else:
             ref_loss = (torch.sum((f - target) ** 2, dim=1) + 1e-8).sqrt().mean()
         (ref_g,) = torch.autograd.grad(ref_loss, f)
-        gf, loss = torch.empty_like(flow), torch.zeros(1, device=DEV)
+        gf, loss, ws = torch.empty_like(flow), torch.zeros(1, device=DEV), torch.empty(L.LOSS_PARTIALS, device=DEV)
         L.check(L.lib().ufr_flow_loss(L.ptr(flow), L.ptr(target), L.ptr(gf), L.ptr(loss), B, H * W, kind, 1.0,
-                                      L.stream()))
+                                      L.ptr(ws), L.stream()))
         assert abs(float(loss) - float(ref_loss)) < 1e-5
+        again = torch.zeros(1, device=DEV)                    # fixed-order reduction: the scalar is bit-reproducible
+        L.check(L.lib().ufr_flow_loss(L.ptr(flow), L.ptr(target), L.ptr(gf), L.ptr(again), B, H * W, kind, 1.0,
+                                      L.ptr(ws), L.stream()))
+        assert torch.equal(loss, again)
         assert_close(gf, ref_g, rtol=1e-4, atol_scale=1e-5, what=f"loss kind {kind} gradient")
 
 
@@ -206,52 +255,115 @@ def test_attack_gate_semantics(net):
 
 
 def test_batched_shared_patch_vs_oracle(net, sd, oracle):
+    """ONE patch in patch coordinates behind two pairs at different placements against the oracle's
+    `patch_attack_placed`, through the drop-in attack() with `origins=`; with sum_groups the single-process step
+    reproduces the sharded summation tree."""
     from oracle import flow_oracle as fo
-    from understanding_flow_robustness_amd.patch_attack import attack
+    from understanding_flow_robustness_amd.patch_attack import PatchAttackStep, attack
     g = torch.Generator().manual_seed(17)
     tgt, ref = torch.rand(2, 3, 64, 128, generator=g), torch.rand(2, 3, 64, 128, generator=g)
-    mask = torch.zeros(2, 3, 64, 128)
-    mask[0, :, 10:30, 20:40] = 1
-    mask[1, :, 30:50, 80:100] = 1
-    patch0 = torch.rand(1, 3, 64, 128, generator=g)
+    origins = [(10, 20), (30, 80)]
+    mask_p = torch.ones(1, 3, 20, 20)
+    mask_p[:, :, :3, :3] = 0                                  # part of the square is not shown
+    patch0 = torch.rand(1, 3, 20, 20, generator=g)
     target = torch.randn(2, 2, 64, 128, generator=g)
     cpu_patch = patch0.clone()
-    c_t, c_r, cpu_patch, n, _ = fo.patch_attack(lambda a, b: fo.flownetc_forward(sd, a, b), tgt, ref, cpu_patch,
-                                                mask, patch0, target, lr=1e5, max_count=2)
+    trace = []
+    c_t, c_r, cpu_patch, n, _ = fo.patch_attack_placed(lambda a, b: fo.flownetc_forward(sd, a, b), tgt, ref, cpu_patch,
+                                                       mask_p, origins, target, lr=1e5, max_count=2, trace=trace)
     args = Namespace(flownet="FlowNetC", l2=False, alpha=0.0, lr=1e5, max_count=2)
     gpu_patch = patch0.clone().to(DEV)
-    a_t, _, a_r, _ = attack(net, tgt.to(DEV), None, ref.to(DEV), gpu_patch, mask.to(DEV), patch0.to(DEV),
-                            target.to(DEV), None, args=args)
+    a_t, _, a_r, _ = attack(net, tgt.to(DEV), None, ref.to(DEV), gpu_patch, mask_p.to(DEV), patch0.to(DEV),
+                            target.to(DEV), None, args=args, origins=origins)
     upd = float((cpu_patch - patch0).abs().max())
-    assert float((gpu_patch.cpu() - cpu_patch).abs().max()) <= 3e-4 * max(upd, 1.0)
-    assert_close(a_t, c_t, rtol=REL, atol_scale=3e-4)
+    assert 1e-2 < upd
+    assert float((gpu_patch.cpu() - cpu_patch).abs().max()) <= REL * max(upd, 1.0)
+    assert_close(a_t, c_t, rtol=REL, atol_scale=REL)
+    assert torch.equal(gpu_patch.cpu()[:, :, :3, :3], patch0[:, :, :3, :3])          # unseen pixels get no gradient
+    # both pairs' gradients reach the same patch pixel
+    G = trace[0]["G"]
+    one = (trace[0]["g_tgt"][0:1, :, 10:30, 20:40] + trace[0]["g_ref"][0:1, :, 10:30, 20:40]) * (mask_p != 0)
+    assert float((G - one).abs().max()) > 0.1 * float(G.abs().max())
+    # the same with two summation groups (what two ranks with one pair each compute): bit-identical here, where a
+    # group holds one pair
+    step = PatchAttackStep(net, args, 2, 64, 128, device=DEV, patch_hw=(20, 20), sum_groups=2)
+    step.load(tgt.to(DEV), ref.to(DEV), patch0.to(DEV), mask_p.to(DEV), patch0.to(DEV), target.to(DEV), origins=origins)
+    step.run(2)
+    assert float((step.patch.cpu() - cpu_patch).abs().max()) <= REL * max(upd, 1.0)
+    with pytest.raises(ValueError, match="patch coordinates"):
+        PatchAttackStep(net, args, 2, 64, 128, device=DEV)                            # canvas patch behind two pairs
+    with pytest.raises(ValueError, match="leaves the frame"):
+        step.load(tgt.to(DEV), ref.to(DEV), patch0.to(DEV), mask_p.to(DEV), patch0.to(DEV), target.to(DEV),
+                  origins=[(10, 20), (50, 80)])
+
+
+def _bench_placements(B, H, W, size=51):
+    return [(100 + 5 * b, 600 - 30 * b) for b in range(B)]
+
+
+def _disc(size=51, radius=23):
+    yy, xx = torch.meshgrid(torch.arange(size), torch.arange(size), indexing="ij")
+    c = size // 2
+    return (((yy - c) ** 2 + (xx - c) ** 2) <= radius ** 2).float().expand(1, 3, size, size).contiguous()
 
 
 def test_attack_full_size_properties(net):
-    """BASELINE config C2 (384x1280, batch 8): size-independent properties -- pixels outside the mask
-    are exactly clamp(frame), two identical runs agree (MIOpen's data-gradient kernels are not
+    """BASELINE config C2 (384x1280, 8 pairs behind one 51x51 patch): size-independent properties -- pixels outside
+    the placed masks are exactly clamp(frame), two identical runs agree (MIOpen's data-gradient kernels are not
     bit-reproducible, so to 1e-4 of the update), and the iteration count is the requested one."""
     from understanding_flow_robustness_amd.patch_attack import PatchAttackStep
     B, H, W = 8, 384, 1280
     args = Namespace(flownet="FlowNetC", l2=False, alpha=0.0, lr=1e3, max_count=2)
-    step = PatchAttackStep(net, args, B, H, W, device=DEV)
+    step = PatchAttackStep(net, args, B, H, W, device=DEV, patch_hw=(51, 51))
     g = torch.Generator().manual_seed(0)
     tgt, ref = torch.rand(B, 3, H, W, generator=g).to(DEV), torch.rand(B, 3, H, W, generator=g).to(DEV)
-    mask = torch.zeros(B, 3, H, W, device=DEV)
-    for b in range(B):
-        mask[b, :, 100 + 5 * b:151 + 5 * b, 600 - 30 * b:651 - 30 * b] = 1
-    patch = torch.rand(1, 3, H, W, generator=g).to(DEV)
+    origins, mask_p = _bench_placements(B, H, W), _disc().to(DEV)
+    patch = torch.rand(1, 3, 51, 51, generator=g).to(DEV)
     with torch.no_grad():
         target = -torch.cat([net(tgt[i:i + 1], ref[i:i + 1]) for i in range(B)])
     outs = []
     for _ in range(2):
-        step.load(tgt, ref, patch, mask, patch, target)
+        step.load(tgt, ref, patch, mask_p, patch, target, origins=origins)
         n, loss = step.run(2)
         assert n == 2 and loss == loss
         outs.append((step.patch.clone(), step.adv_tgt.detach().clone()))
     upd = float((outs[0][0] - patch).abs().max())
     assert float((outs[0][0] - outs[1][0]).abs().max()) <= 1e-4 * max(upd, 1.0)
     assert float((outs[0][1] - outs[1][1]).abs().max()) <= 1e-4
-    outside = mask == 0
+    outside = step.mask == 0
     assert torch.equal(outs[0][1][outside], tgt.clamp(0, 1)[outside])
     assert float((outs[0][0] - patch).abs().max()) > 0
+
+
+@pytest.mark.timeout(1500)
+def test_headline_configuration_vs_cpu_oracle(net, sd, oracle):
+    """The benchmark's own configuration -- 8 pairs at 384x1280 behind one 51x51 circular patch, windowed prefix,
+    column band, incremental head forward, captured graphs, 2 iterations -- against the CPU oracle's
+    `patch_attack_placed` (minutes of CPU work, once): patch pixels to 1e-4 relative."""
+    from oracle import flow_oracle as fo
+    from understanding_flow_robustness_amd.patch_attack import PatchAttackStep
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    B, H, W = 8, 384, 1280
+    g = torch.Generator().manual_seed(2)
+    tgt, ref = torch.rand(B, 3, H, W, generator=g), torch.rand(B, 3, H, W, generator=g)
+    origins, mask_p = _bench_placements(B, H, W), _disc()
+    patch0 = torch.rand(1, 3, 51, 51, generator=g)
+    predict = lambda a, b: fo.flownetc_forward(sd, a, b)
+    with torch.no_grad():
+        target = -torch.cat([predict(tgt[i:i + 1], ref[i:i + 1]) for i in range(B)])
+    # lr: random-init gradients are tiny; pick the step whose first update peaks near 0.5 so the +-2 clamp (which
+    # would hide gradient errors) stays inactive
+    probe, trace = patch0.clone(), []
+    fo.patch_attack_placed(predict, tgt, ref, probe, mask_p, origins, target, lr=1.0, max_count=1, trace=trace)
+    lr = 0.5 / (0.5 * float(trace[0]["G"].abs().max()))
+    cpu_patch = patch0.clone()
+    fo.patch_attack_placed(predict, tgt, ref, cpu_patch, mask_p, origins, target, lr=lr, max_count=2)
+    args = Namespace(flownet="FlowNetC", l2=False, alpha=0.0, lr=lr, max_count=2)
+    step = PatchAttackStep(net, args, B, H, W, device=DEV, patch_hw=(51, 51))
+    step.load(tgt.to(DEV), ref.to(DEV), patch0.to(DEV), mask_p.to(DEV), patch0.to(DEV), target.to(DEV), origins=origins)
+    n, _ = step.run(2)
+    assert n == 2 and step.cone is not None and step.band is not None and step.band.width > 0 and step.graph_next is not None
+    upd = float((cpu_patch - patch0).abs().max())
+    err = float((step.patch.cpu() - cpu_patch).abs().max())
+    assert 0.3 < upd < 1.9
+    assert err <= REL * max(upd, 1.0), f"headline configuration: patch err {err:.3e}, update {upd:.3e}"

@@ -102,7 +102,7 @@ def test_train_sample_device_matches_reference():
     assert np.allclose(i1.cpu().numpy(), z["train_init1"], rtol=0, atol=1e-7)
     upd = float(np.abs(z["train_patch1"] - z["train_patch0"] * z["train_mask0"]).max())
     err = float(np.abs(p1.cpu().numpy() - z["train_patch1"]).max())
-    assert err <= 1e-4 * max(upd, 1.0) + 2e-4 * upd, f"patch err {err:.3e}, update {upd:.3e}"
+    assert err <= 1e-4 * max(upd, 1.0), f"patch err {err:.3e}, update {upd:.3e}"
 
 
 def test_train_sample_device_seeded_prefix_equals_recomputed(monkeypatch):

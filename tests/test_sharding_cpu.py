@@ -1,7 +1,9 @@
-"""CPU suite, part 5: the N>1 protocol on `gloo`, world_size 2.  Each rank holds half of the frame
-pairs, computes its local pre-clamp gradient sum (here with the CPU oracle standing in for the HIP
-step), packs [gradient sum | loss] and calls the product's ShardedExchange; the non-linear update
-applied after the all-reduce must equal the single-process batch result."""
+"""CPU suite, part 5: the N>1 protocol on `gloo`, world_size 2.  Patch attack: the ranks share ONE patch
+in patch coordinates; each rank holds half of the frame pairs AT DIFFERENT PLACEMENTS, crops its pairs' pre-clamp
+gradients back to [3,ph,pw] (the CPU oracle stands in for the HIP step), and the product's ShardedExchange all-gathers
+the 31-KB-class rows [crop | loss]; every rank adds the rows in rank order and applies the clamp.  The result must equal
+the single-process batch with the same summation groups BIT FOR BIT, and a patch pixel must carry both ranks'
+gradients."""
 import os
 import socket
 
@@ -9,6 +11,10 @@ import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+
+PH = PW = 20
+ORIGINS = [(10, 20), (30, 80), (5, 100), (40, 8)]          # four pairs, four different placements
+LR = 5e4
 
 
 def _free_port():
@@ -19,13 +25,12 @@ def _free_port():
 
 def _inputs():
     g = torch.Generator().manual_seed(77)
-    tgt, ref = torch.rand(2, 3, 64, 128, generator=g), torch.rand(2, 3, 64, 128, generator=g)
-    mask = torch.zeros(2, 3, 64, 128)
-    mask[0, :, 10:30, 20:40] = 1
-    mask[1, :, 30:50, 80:100] = 1
-    patch0 = torch.rand(1, 3, 64, 128, generator=g)
-    target = torch.randn(2, 2, 64, 128, generator=g)
-    return tgt, ref, mask, patch0, target
+    tgt, ref = torch.rand(4, 3, 64, 128, generator=g), torch.rand(4, 3, 64, 128, generator=g)
+    yy, xx = torch.meshgrid(torch.arange(PH), torch.arange(PW), indexing="ij")
+    mask_p = (((yy - 10) ** 2 + (xx - 10) ** 2) <= 64).float().expand(1, 3, PH, PW).contiguous()   # circular
+    patch0 = torch.rand(1, 3, PH, PW, generator=g)
+    target = torch.randn(4, 2, 64, 128, generator=g)
+    return tgt, ref, mask_p, patch0, target
 
 
 def _rank_main(rank, world, port, out_dir):
@@ -37,24 +42,36 @@ def _rank_main(rank, world, port, out_dir):
     from understanding_flow_robustness_amd.flownets.weights import synthetic_state_dict
     from understanding_flow_robustness_amd.patch_attack import CLAMP_BOUND, ShardedExchange
     sd = synthetic_state_dict(FlowNetC().state_dict(), seed=0)
-    tgt, ref, mask, patch0, target = _inputs()
-    sl = slice(rank, rank + 1)                       # this rank's shard of the batch
-    tgt, ref, mask, target = tgt[sl], ref[sl], mask[sl], target[sl]
+    tgt, ref, mask_p, patch0, target = _inputs()
+    per = 4 // world
+    sl = slice(rank * per, (rank + 1) * per)                 # this rank's shard of the batch
+    tgt, ref, target, origins = tgt[sl], ref[sl], target[sl], ORIGINS[sl]
     exchange = ShardedExchange()
-    assert exchange.world == world
-    patch, lr = patch0.clone(), 5e4
-    CHW = patch.numel()
+    assert exchange.world == world and exchange.rank == rank
+    patch = patch0.clone()
+    n = patch.numel()
+    mask = fo.place(mask_p, origins, 64, 128)
+    shown = (mask_p != 0).float()
+    rows_all = torch.zeros(world, n + 1)
+    first_rows = None
     for _ in range(2):
-        adv_t = ((1 - mask) * tgt + mask * patch).clamp(0, 1).requires_grad_(True)
-        adv_r = ((1 - mask) * ref + mask * patch).clamp(0, 1).requires_grad_(True)
-        flow = fo.flownetc_forward(sd, adv_t, adv_r)
-        loss = fo.flow_loss(flow, target) / world     # PatchAttackStep: weight (1-alpha)/world
+        canvas = fo.place(patch, origins, 64, 128)
+        adv_t = ((1 - mask) * tgt + mask * canvas).clamp(0, 1).requires_grad_(True)
+        adv_r = ((1 - mask) * ref + mask * canvas).clamp(0, 1).requires_grad_(True)
+        loss = fo.flow_loss(fo.flownetc_forward(sd, adv_t, adv_r), target) / world    # PatchAttackStep: weight (1-alpha)/world
         g_t, g_r = torch.autograd.grad(loss, (adv_t, adv_r))
-        gsum = ((g_t + g_r) * (mask != 0).float()).sum(0)                                 # mode 1 | MASKED_SUM
-        packed = torch.cat((gsum.reshape(-1), loss.detach().reshape(1)))
-        exchange(packed)                              # all-reduce(sum) over gloo
-        patch = patch - torch.clamp(0.5 * lr * packed[:CHW].view_as(patch), -CLAMP_BOUND, CLAMP_BOUND)  # mode 2
-    torch.save(dict(patch=patch, loss=packed[CHW:].clone()), os.path.join(out_dir, f"rank{rank}.pt"))
+        row = torch.zeros_like(patch)                                                  # ufr_patch_grad_crop
+        for b, (oy, ox) in enumerate(origins):
+            row = row + (g_t[b:b + 1, :, oy:oy + PH, ox:ox + PW] + g_r[b:b + 1, :, oy:oy + PH, ox:ox + PW])
+        rows_local = torch.cat(((row * shown).reshape(-1), loss.detach().reshape(1))).view(1, n + 1)
+        exchange.gather(rows_local, rows_all)                                          # all-gather over gloo
+        G = torch.zeros(n)
+        for r in range(world):                                                         # ufr_patch_apply: ascending rank order
+            G = G + rows_all[r, :n]
+        patch = patch - torch.clamp(0.5 * LR * G.view_as(patch), -CLAMP_BOUND, CLAMP_BOUND)
+        if first_rows is None:
+            first_rows = rows_all.clone()
+    torch.save(dict(patch=patch, loss=rows_all[:, n].sum(), rows=first_rows), os.path.join(out_dir, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -67,16 +84,25 @@ def test_two_rank_sharded_patch_update_equals_single_process_batch(oracle, tmp_p
     mp.spawn(_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     assert torch.equal(r0["patch"], r1["patch"]), "ranks must hold bit-identical patches after the exchange"
-    assert torch.equal(r0["loss"], r1["loss"])
-    # single process, batch of 2, first paste clamped like the ranks' (frames are in [0,1] anyway)
+    assert torch.equal(r0["loss"], r1["loss"]) and torch.equal(r0["rows"], r1["rows"])
+    # a patch pixel receives BOTH ranks' gradients although no two pairs overlap on the canvas
+    n = 3 * PH * PW
+    both = (r0["rows"][0, :n] != 0) & (r0["rows"][1, :n] != 0)
+    shown = _inputs()[2].reshape(-1) != 0
+    assert float(both[shown].float().mean()) > 0.99 and not bool(both[~shown].any())
+    # single process, batch of 4, the same two summation groups: bit-identical
+    torch.set_num_threads(2)                                  # same oneDNN partitioning as the ranks
     sd = synthetic_state_dict(FlowNetC().state_dict(), seed=0)
-    tgt, ref, mask, patch0, target = _inputs()
+    tgt, ref, mask_p, patch0, target = _inputs()
     trace = []
     patch = patch0.clone()
-    fo.patch_attack(lambda a, b: fo.flownetc_forward(sd, a, b), tgt, ref, patch, mask, patch0, target, lr=5e4,
-                    max_count=2, trace=trace)
+    # the ranks clamp their first paste (frames are in [0,1]: clamp is the identity there)
+    fo.patch_attack_placed(lambda a, b: fo.flownetc_forward(sd, a, b), tgt, ref, patch, mask_p, ORIGINS, target, lr=LR,
+                           max_count=2, groups=2, trace=trace)
     upd = float((patch - patch0).abs().max())
-    assert float((r0["patch"] - patch).abs().max()) <= 1e-5 * max(upd, 1.0)
+    assert 1e-3 < upd
+    err = float((r0["patch"] - patch).abs().max())
+    assert err <= 1e-6 * max(upd, 1.0), f"sharded vs single-process patch: {err:.3e} (update {upd:.3e})"
     assert abs(float(r0["loss"]) - trace[-1]["loss"]) < 1e-6
 
 

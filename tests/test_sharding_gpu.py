@@ -1,7 +1,8 @@
-"""GPU suite: the N>1 path of the fused step on real kernels.  Two ranks share the single device of
-the test box (gloo moves the packed gradient; on a multi-GPU node the same code runs over RCCL):
-part-A graph -> all-reduce of [gradient sum | loss] -> part-B graph must reproduce the
-single-process batch-2 step, and both ranks must end with bit-identical patches."""
+"""GPU suite: the N>1 path of the fused step on real kernels.  Two ranks hold two frame pairs each, at
+four different placements, behind ONE patch in patch coordinates: part-A graph -> all-gather of the [crop | loss] rows
+-> part-B graph.  With two visible devices the ranks take one each and the exchange runs over RCCL (backend "nccl");
+on the one-GPU test box they share the device and gloo moves the rows.  Both ranks must end with bit-identical patches
+that equal the single-process step run with the same two summation groups."""
 import json
 import os
 import socket
@@ -17,6 +18,8 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+PH = PW = 20
+ORIGINS = [(10, 20), (30, 80), (5, 100), (40, 8)]
 
 
 def _free_port():
@@ -27,36 +30,42 @@ def _free_port():
 
 def _inputs():
     g = torch.Generator().manual_seed(5)
-    tgt, ref = torch.rand(2, 3, 64, 128, generator=g), torch.rand(2, 3, 64, 128, generator=g)
-    mask = torch.zeros(2, 3, 64, 128)
-    mask[0, :, 10:30, 20:40] = 1
-    mask[1, :, 30:50, 80:100] = 1
-    patch0 = torch.rand(1, 3, 64, 128, generator=g)
-    target = torch.randn(2, 2, 64, 128, generator=g)
-    return tgt, ref, mask, patch0, target
+    tgt, ref = torch.rand(4, 3, 64, 128, generator=g), torch.rand(4, 3, 64, 128, generator=g)
+    yy, xx = torch.meshgrid(torch.arange(PH), torch.arange(PW), indexing="ij")
+    mask_p = (((yy - 10) ** 2 + (xx - 10) ** 2) <= 64).float().expand(1, 3, PH, PW).contiguous()
+    patch0 = torch.rand(1, 3, PH, PW, generator=g)
+    target = torch.randn(4, 2, 64, 128, generator=g)
+    return tgt, ref, mask_p, patch0, target
 
 
-def _make_step(batch, exchange):
+def _make_step(batch, exchange, dev, groups=1):
     from argparse import Namespace
     from understanding_flow_robustness_amd.flownets.utils_model import fetch_model
     from understanding_flow_robustness_amd.patch_attack import PatchAttackStep
     args = Namespace(flownet="FlowNetC", l2=False, alpha=0.0, lr=5e4, max_count=2)
-    net = fetch_model(args, synthetic_seed=0).to(DEV)
-    return PatchAttackStep(net, args, batch, 64, 128, device=DEV, exchange=exchange)
+    net = fetch_model(args, synthetic_seed=0).to(dev)
+    return PatchAttackStep(net, args, batch, 64, 128, device=dev, exchange=exchange, patch_hw=(PH, PW), sum_groups=groups)
 
 
 def _rank_main(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    two_devices = torch.cuda.device_count() >= world
+    dev = f"cuda:{rank}" if two_devices else DEV
+    torch.cuda.set_device(dev)
+    if two_devices:                                    # RCCL over xGMI: the production transport
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from understanding_flow_robustness_amd.patch_attack import ShardedExchange
-    tgt, ref, mask, patch0, target = _inputs()
-    sl = slice(rank, rank + 1)
-    step = _make_step(1, ShardedExchange())
-    step.load(tgt[sl].to(DEV), ref[sl].to(DEV), patch0.to(DEV), mask[sl].to(DEV), patch0.to(DEV), target[sl].to(DEV))
+    tgt, ref, mask_p, patch0, target = _inputs()
+    sl = slice(2 * rank, 2 * rank + 2)
+    step = _make_step(2, ShardedExchange(), dev)
+    step.load(tgt[sl].to(dev), ref[sl].to(dev), patch0.to(dev), mask_p.to(dev), patch0.to(dev), target[sl].to(dev),
+              origins=ORIGINS[sl])
     n, loss = step.run(2)
-    torch.save(dict(patch=step.patch.cpu(), n=n, loss=loss, graphs=(step.graph is not None, step.graph_b is not None)),
-               os.path.join(out_dir, f"rank{rank}.pt"))
+    torch.save(dict(patch=step.patch.cpu(), n=n, loss=loss, graphs=(step.graph is not None, step.graph_b is not None),
+                    backend=dist.get_backend(), rows=step.rows_all.cpu()), os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -66,12 +75,19 @@ def test_two_ranks_match_single_process_batch(tmp_path):
     mp.spawn(_rank_main, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     assert r0["graphs"] == (True, True) and r0["n"] == r1["n"] == 2
-    assert torch.equal(r0["patch"], r1["patch"])
-    tgt, ref, mask, patch0, target = _inputs()
-    step = _make_step(2, None)
-    step.load(tgt.to(DEV), ref.to(DEV), patch0.to(DEV), mask.to(DEV), patch0.to(DEV), target.to(DEV))
-    n, loss = step.run(2)
+    assert r0["backend"] == ("nccl" if torch.cuda.device_count() >= 2 else "gloo")
+    assert torch.equal(r0["patch"], r1["patch"]) and torch.equal(r0["rows"], r1["rows"])
+    n = 3 * PH * PW
+    shown = _inputs()[1 + 1].reshape(-1) != 0
+    both = (r0["rows"][0, :n] != 0) & (r0["rows"][1, :n] != 0)     # a patch pixel carries both ranks' gradients
+    assert float(both[shown].float().mean()) > 0.99
+    tgt, ref, mask_p, patch0, target = _inputs()
+    step = _make_step(4, None, DEV, groups=2)              # same summation tree as the two ranks
+    step.load(tgt.to(DEV), ref.to(DEV), patch0.to(DEV), mask_p.to(DEV), patch0.to(DEV), target.to(DEV), origins=ORIGINS)
+    n_it, loss = step.run(2)
     upd = float((step.patch.cpu() - patch0).abs().max())
+    assert n_it == 2 and upd > 1e-3
+    # the convolutions of a batch of 2 and of a batch of 4 may take different MIOpen kernels: 1e-4 of the update
     assert float((step.patch.cpu() - r0["patch"]).abs().max()) <= 1e-4 * max(upd, 1.0)
     assert abs(loss - r0["loss"]) < 1e-5
 

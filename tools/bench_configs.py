@@ -36,13 +36,19 @@ def patch_case(name, flownet, seed, B, H, W, steps, **extra):
     args.mixed_precision = False
     g = torch.Generator().manual_seed(0)
     tgt, ref = torch.rand(B, 3, H, W, generator=g).to(DEV), torch.rand(B, 3, H, W, generator=g).to(DEV)
-    mask = torch.zeros(B, 3, H, W, device=DEV)
-    mask[:, :, 100:151, 600:651] = 1
-    patch = torch.rand(1, 3, H, W, generator=g).to(DEV)
+    if B > 1:          # one patch in patch coordinates behind the B pairs
+        mask = torch.ones(1, 3, 51, 51, device=DEV)
+        patch = torch.rand(1, 3, 51, 51, generator=g).to(DEV)
+        placed = dict(origins=[(100, 600)] * B)
+    else:
+        mask = torch.zeros(B, 3, H, W, device=DEV)
+        mask[:, :, 100:151, 600:651] = 1
+        patch = torch.rand(1, 3, H, W, generator=g).to(DEV)
+        placed = {}
     with torch.no_grad():
         target = -torch.cat([predict_flow(net, None, tgt[i:i + 1], ref[i:i + 1], args) for i in range(B)])
-    step = PatchAttackStep(net, args, B, H, W, device=DEV)
-    step.load(tgt, ref, patch, mask, patch, target)
+    step = PatchAttackStep(net, args, B, H, W, device=DEV, patch_hw=(51, 51) if B > 1 else None)
+    step.load(tgt, ref, patch, mask, patch, target, **placed)
     step.run(0)
     ms = timed(step, steps)
     mem = torch.cuda.max_memory_allocated() / 2 ** 30

@@ -51,6 +51,7 @@ class ConeChain(C.Structure):
 _vp, _i, _f, _l, _d = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_double
 # name -> argtypes; every function returns int.  Kept in one table so tests can check that each
 # symbol declared in include/ufr_hip.h is exported by the built library.
+LOSS_PARTIALS = 512      # UFR_LOSS_PARTIALS (include/ufr_hip.h)
 SIGNATURES = {
     "ufr_corr_forward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, C.POINTER(CorrParams), _vp],
     "ufr_corr_forward_fused": [_vp, _vp, _vp, _i, _i, _i, _i, _i, C.POINTER(CorrParams), _f, _f, _vp],
@@ -64,17 +65,19 @@ SIGNATURES = {
     "ufr_channelnorm_forward": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ufr_channelnorm_backward": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ufr_patch_paste": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _l, _i, _f, _f, _vp],
-    "ufr_patch_update": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _l, _f, _f, _f,
-                         _f, _i, _vp, _vp],
+    "ufr_patch_update": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _l, _f, _f, _f, _f, _vp, _vp],
     "ufr_attack_gate": [_vp, _vp, _f, _vp],
     "ufr_gru_gates_forward": [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _vp],
     "ufr_gru_gates_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _l, _vp],
     "ufr_gru_blend_forward": [_vp, _vp, _vp, _vp, _l, _vp],
     "ufr_gru_blend_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp],
-    "ufr_flow_loss_ex": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp],
+    "ufr_flow_loss_ex": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp],
     "ufr_universal_update": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _i, _i, _i, _i,
                              _i, _vp],
-    "ufr_flow_loss": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
+    "ufr_flow_loss": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp],
+    "ufr_patch_grad_crop": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "ufr_patch_apply": [_vp, _i, _vp, _vp, _i, _i, _f, _f, _vp, _vp],
+    "ufr_patch_paste_placed": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp],
     "ufr_cone_window": [_vp, _i, _l, _i, _i, _i, C.POINTER(ConeChain), _i, _i, _vp, _vp, _vp],
     "ufr_window_gather": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ufr_window_scatter": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

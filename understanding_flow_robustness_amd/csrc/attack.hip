@@ -28,45 +28,8 @@ __global__ void paste_kernel(const float* __restrict__ tgt, const float* __restr
   }
 }
 
-// main.py:575-600 fused.  One thread per canvas element e (not per batch element): the thread
-// sums the B per-sample gradients (batch extension: one shared patch), updates the patch once and
-// re-pastes all B frame pairs.
-//   mode 0: sum, update, paste     mode 1: sum only -> grad_sum     mode 2: update+paste from grad_sum
-__global__ void update_shared_kernel(const float* __restrict__ tgt, const float* __restrict__ ref,
-                                     const float* __restrict__ g_tgt, const float* __restrict__ g_ref,
-                                     float* __restrict__ grad_sum, float* __restrict__ patch,
-                                     const float* __restrict__ mask, float* __restrict__ adv_tgt,
-                                     float* __restrict__ adv_ref, int B, long CHW, long mstride,
-                                     float step, float bound, float lo, float hi, int mode, int masked,
-                                     const float* __restrict__ gate) {
-  // attack already converged: the iteration is void (mode 1 still refreshes the exchange buffer so
-  // the collective that follows never re-sums stale data)
-  if (mode != 1 && gate != nullptr && gate[0] != 0.f) return;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < CHW;
-       e += (long)gridDim.x * blockDim.x) {
-    float gs;
-    if (mode == 2) {
-      gs = grad_sum[e];
-    } else {
-      gs = 0.f;
-      // masked: a pair contributes only where ITS mask shows the patch (d batch-loss / d shared patch)
-      for (int b = 0; b < B; ++b)
-        if (!masked || mask[b * mstride + e] != 0.f) gs += g_tgt[b * CHW + e] + g_ref[b * CHW + e];
-      if (grad_sum) grad_sum[e] = gs;
-      if (mode == 1) continue;
-    }
-    const float pv = patch[e] - clampf(step * gs, -bound, bound);
-    patch[e] = pv;
-    for (int b = 0; b < B; ++b) {
-      const float m = mask[b * mstride + e];
-      const float mp = m * pv, om = 1.0f - m;
-      adv_tgt[b * CHW + e] = clampf(om * tgt[b * CHW + e] + mp, lo, hi);
-      adv_ref[b * CHW + e] = clampf(om * ref[b * CHW + e] + mp, lo, hi);
-    }
-  }
-}
-
-// Per-sample patches (patch_bstride != 0): exactly the reference's B=1 arithmetic per sample.
+// main.py:575-600 fused (grad sum, step, clamp, patch update, re-paste, clamp: 9 elementwise torch kernels in the
+// reference): exactly the reference's B=1 arithmetic, per sample when every sample has its own canvas patch.
 __global__ void update_private_kernel(const float* __restrict__ tgt, const float* __restrict__ ref,
                                       const float* __restrict__ g_tgt, const float* __restrict__ g_ref,
                                       float* __restrict__ patch, const float* __restrict__ mask,
@@ -87,14 +50,23 @@ __global__ void update_private_kernel(const float* __restrict__ tgt, const float
   }
 }
 
+// Fixed-order second stage of the loss reductions (flow_loss_kernel, universal.hip's flow_loss_ex_kernel): one wave
+// adds the workgroups' partial sums -- lane l takes partials l, l+64, ... in order, then a fixed shuffle tree -- so the
+// scalar that drives `while loss > 0.1` (main.py:546) is bit-reproducible from run to run (no float atomics).
+__global__ void loss_finalize_kernel(const float* __restrict__ partials, int n, float* __restrict__ loss) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) s += partials[i];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (threadIdx.x == 0) *loss += s;
+}
+
 // Loss + its gradient wrt the flow in one pass (replaces the autograd graph of main.py:557-566).
 //  kind 0: mean(1 - cos(f,t)),  cos = <f,t> / max(|f|*|t|, 1e-8)   (torch cosine_similarity, eps 1e-8)
 //          d/df = -( t/(|f||t|) - cos * f/|f|^2 ) / Npix
 //  kind 1: mean(sqrt(|f-t|^2 + 1e-8)),  d/df = (f-t)/sqrt(.) / Npix
-// Block-level reduction in LDS, one atomicAdd per workgroup (order-dependent in the last bits; the
-// scalar is only used for the `loss <= 0.1` early exit and for logging).
+// Block-level reduction in LDS; every workgroup stores its partial sum, loss_finalize_kernel adds them in a fixed order.
 __global__ void flow_loss_kernel(const float* __restrict__ flow, const float* __restrict__ target,
-                                 float* __restrict__ gflow, float* __restrict__ loss, int B, long HW,
+                                 float* __restrict__ gflow, float* __restrict__ partials, int B, long HW,
                                  int kind, float weight) {
   __shared__ float red[256 / 64];
   const long npix = (long)B * HW;
@@ -137,7 +109,79 @@ __global__ void flow_loss_kernel(const float* __restrict__ flow, const float* __
   if (threadIdx.x == 0) {
     float s = 0.f;
     for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s += red[k];
-    atomicAdd(loss, s * invn);
+    partials[blockIdx.x] = s * invn;
+  }
+}
+
+// ---- shared patch in PATCH coordinates (patch_attacks/main.py:396-424 crops the canvas at (ry, rx) back
+// to patch_shape after every sample) -------------------------------------------------------------------------------
+// B pairs show ONE patch P[3,ph,pw] (mask Mp[3,ph,pw]) at per-pair origins (oy_b, ox_b).
+//   crop:   rows[g][c,i,j] = [Mp != 0] * sum_{b in group g, ascending} (g_tgt + g_ref)[b, c, oy_b+i, ox_b+j]
+//           rows[g][3*ph*pw] = this rank's loss (row 0) or 0: the scalar travels with the gradient
+//   apply:  G = sum_r rows[r] (ascending r: the fixed order that keeps every rank's patch bit-identical),
+//           P -= clamp(step*G, +-bound); *loss = sum_r rows[r][3*ph*pw]
+//   paste:  adv_b = clamp((1-M_b)*img_b + M_b*place(P, origin_b)), M_b = place(Mp, origin_b); optionally writes M_b
+__global__ void patch_grad_crop_kernel(const float* __restrict__ g_tgt, const float* __restrict__ g_ref,
+                                       const float* __restrict__ mask_p, const int* __restrict__ origins,
+                                       const float* __restrict__ loss_local, float* __restrict__ rows, int B, int H,
+                                       int W, int ph, int pw, int groups) {
+  const int n = 3 * ph * pw, per = B / groups;
+  const long HW = (long)H * W;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e <= n; e += gridDim.x * blockDim.x) {
+    if (e == n) {
+      for (int g = 0; g < groups; ++g) rows[(long)g * (n + 1) + n] = (g == 0) ? *loss_local : 0.f;
+      continue;
+    }
+    const int c = e / (ph * pw), r = e - c * ph * pw, i = r / pw, j = r - i * pw;
+    const bool shown = mask_p[e] != 0.f;
+    for (int g = 0; g < groups; ++g) {
+      float s = 0.f;
+      if (shown)
+        for (int b = g * per; b < (g + 1) * per; ++b) {
+          const long o = ((long)b * 3 + c) * HW + (long)(origins[2 * b] + i) * W + origins[2 * b + 1] + j;
+          s += g_tgt[o] + g_ref[o];
+        }
+      rows[(long)g * (n + 1) + e] = s;
+    }
+  }
+}
+
+__global__ void patch_apply_kernel(const float* __restrict__ rows, int n_rows, float* __restrict__ patch_p,
+                                   float* __restrict__ loss, int n, float step, float bound,
+                                   const float* __restrict__ gate) {
+  const bool stopped = gate != nullptr && gate[0] != 0.f;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e <= n; e += gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int r = 0; r < n_rows; ++r) s += rows[(long)r * (n + 1) + e];
+    if (e == n) *loss = s;                                    // the gate reads it even for a void iteration
+    else if (!stopped) patch_p[e] -= clampf(step * s, -bound, bound);
+  }
+}
+
+__global__ void paste_placed_kernel(const float* __restrict__ tgt, const float* __restrict__ ref,
+                                    const float* __restrict__ patch_p, const float* __restrict__ mask_p,
+                                    const int* __restrict__ origins, float* __restrict__ adv_tgt,
+                                    float* __restrict__ adv_ref, float* __restrict__ mask_out, long total, int H, int W,
+                                    int ph, int pw, int do_clamp, float lo, float hi, const float* __restrict__ gate) {
+  if (gate != nullptr && gate[0] != 0.f) return;
+  const long HW = (long)H * W;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long bc = idx / HW, pix = idx - bc * HW;
+    const int b = (int)(bc / 3), c = (int)(bc - 3L * b);
+    const int y = (int)(pix / W), x = (int)(pix - (long)y * W);
+    const int i = y - origins[2 * b], j = x - origins[2 * b + 1];
+    float m = 0.f, pv = 0.f;
+    if ((unsigned)i < (unsigned)ph && (unsigned)j < (unsigned)pw) {
+      const int e = (c * ph + i) * pw + j;
+      m = mask_p[e];
+      pv = patch_p[e];
+    }
+    const float mp = m * pv, om = 1.0f - m;
+    float a = om * tgt[idx] + mp, r = om * ref[idx] + mp;
+    if (do_clamp) { a = clampf(a, lo, hi); r = clampf(r, lo, hi); }
+    adv_tgt[idx] = a;
+    adv_ref[idx] = r;
+    if (mask_out) mask_out[idx] = m;
   }
 }
 
@@ -172,45 +216,84 @@ extern "C" int ufr_patch_paste(const float* tgt, const float* ref, const float* 
 }
 
 extern "C" int ufr_patch_update(const float* tgt, const float* ref, const float* g_tgt,
-                                const float* g_ref, float* grad_sum, float* patch,
-                                const float* mask, float* adv_tgt, float* adv_ref, int B, int CHW,
-                                long patch_bstride, long mask_bstride, float step, float bound,
-                                float lo, float hi, int mode, const float* gate_state,
+                                const float* g_ref, float* patch, const float* mask, float* adv_tgt,
+                                float* adv_ref, int B, int CHW, long patch_bstride, long mask_bstride,
+                                float step, float bound, float lo, float hi, const float* gate_state,
                                 ufr_stream_t stream) {
   UFR_REQUIRE(B > 0 && CHW > 0, "patch update: bad shape");
-  const int masked = (mode & UFR_UPDATE_MASKED_SUM) != 0;
-  mode &= ~UFR_UPDATE_MASKED_SUM;
-  UFR_REQUIRE(mode >= 0 && mode <= 2, "patch update: bad mode %d", mode);
-  hipStream_t st = ufr::as_stream(stream);
-  if (patch_bstride != 0) {
-    UFR_REQUIRE(mode == 0, "patch update: per-sample patches have no cross-sample gradient sum");
-    UFR_REQUIRE(tgt && ref && g_tgt && g_ref && patch && mask && adv_tgt && adv_ref,
-                "patch update: null pointer argument");
-    const long total = (long)B * CHW;
-    hipLaunchKernelGGL(update_private_kernel, dim3(ufr::stream_grid(total, 256)), dim3(256), 0, st,
-                       tgt, ref, g_tgt, g_ref, patch, mask, adv_tgt, adv_ref, total, (long)CHW,
-                       patch_bstride, mask_bstride, step, bound, lo, hi, gate_state);
-    return ufr::launched("update_private_kernel");
-  }
-  if (mode != 2) UFR_REQUIRE(g_tgt && g_ref, "patch update: null gradient pointer");
-  if (mode != 0) UFR_REQUIRE(grad_sum, "patch update: mode %d needs grad_sum", mode);
-  if (mode != 1)
-    UFR_REQUIRE(tgt && ref && patch && mask && adv_tgt && adv_ref, "patch update: null pointer argument");
-  if (masked && mode != 2) UFR_REQUIRE(mask, "patch update: masked sum needs the masks");
-  hipLaunchKernelGGL(update_shared_kernel, dim3(ufr::stream_grid(CHW, 256)), dim3(256), 0, st, tgt,
-                     ref, g_tgt, g_ref, grad_sum, patch, mask, adv_tgt, adv_ref, B, (long)CHW,
-                     mask_bstride, step, bound, lo, hi, mode, masked, gate_state);
-  return ufr::launched("update_shared_kernel");
+  UFR_REQUIRE(patch_bstride != 0 || B == 1,
+              "patch update: one canvas patch behind %d pairs is not defined -- a shared patch lives in patch "
+              "coordinates (ufr_patch_grad_crop / ufr_patch_apply / ufr_patch_paste_placed)", B);
+  UFR_REQUIRE(tgt && ref && g_tgt && g_ref && patch && mask && adv_tgt && adv_ref,
+              "patch update: null pointer argument");
+  const long total = (long)B * CHW;
+  hipLaunchKernelGGL(update_private_kernel, dim3(ufr::stream_grid(total, 256)), dim3(256), 0, ufr::as_stream(stream),
+                     tgt, ref, g_tgt, g_ref, patch, mask, adv_tgt, adv_ref, total, (long)CHW,
+                     patch_bstride, mask_bstride, step, bound, lo, hi, gate_state);
+  return ufr::launched("update_private_kernel");
 }
 
 extern "C" int ufr_flow_loss(const float* flow, const float* target, float* grad_flow, float* loss,
-                             int B, int HW, int kind, float weight, ufr_stream_t stream) {
-  UFR_REQUIRE(flow && target && grad_flow && loss, "flow loss: null pointer argument");
+                             int B, int HW, int kind, float weight, float* partials, ufr_stream_t stream) {
+  UFR_REQUIRE(flow && target && grad_flow && loss && partials, "flow loss: null pointer argument");
   UFR_REQUIRE(B > 0 && HW > 0 && (kind == 0 || kind == 1), "flow loss: bad argument");
   const long npix = (long)B * HW;
   int grid = ufr::stream_grid(npix, 256);
-  if (grid > 512) grid = 512;
+  if (grid > UFR_LOSS_PARTIALS) grid = UFR_LOSS_PARTIALS;
   hipLaunchKernelGGL(flow_loss_kernel, dim3(grid), dim3(256), 0, ufr::as_stream(stream), flow,
-                     target, grad_flow, loss, B, (long)HW, kind, weight);
+                     target, grad_flow, partials, B, (long)HW, kind, weight);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, ufr::as_stream(stream), partials, grid, loss);
   return ufr::launched("flow_loss_kernel");
+}
+
+namespace ufr {
+void loss_finalize_launch(const float* partials, int n, float* loss, hipStream_t st) {
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, partials, n, loss);
+}
+}  // namespace ufr
+
+static int check_placed(const int* origins_host, int B, int H, int W, int ph, int pw) {
+  if (!origins_host) return 1;
+  for (int b = 0; b < B; ++b)
+    if (origins_host[2 * b] < 0 || origins_host[2 * b] + ph > H || origins_host[2 * b + 1] < 0 ||
+        origins_host[2 * b + 1] + pw > W)
+      return 0;
+  return 1;
+}
+
+extern "C" int ufr_patch_grad_crop(const float* g_tgt, const float* g_ref, const float* mask_p, const int* origins,
+                                   const int* origins_host, const float* loss_local, float* rows, int B, int H, int W,
+                                   int ph, int pw, int groups, ufr_stream_t stream) {
+  UFR_REQUIRE(g_tgt && g_ref && mask_p && origins && loss_local && rows, "patch grad crop: null pointer argument");
+  UFR_REQUIRE(B > 0 && H > 0 && W > 0 && ph > 0 && pw > 0 && ph <= H && pw <= W, "patch grad crop: bad shape");
+  UFR_REQUIRE(groups > 0 && B % groups == 0, "patch grad crop: the pairs must split evenly into %d groups", groups);
+  UFR_REQUIRE(check_placed(origins_host, B, H, W, ph, pw), "patch grad crop: a placement leaves the frame");
+  const int n = 3 * ph * pw + 1;
+  hipLaunchKernelGGL(patch_grad_crop_kernel, dim3(ufr::ceil_div(n, 256)), dim3(256), 0, ufr::as_stream(stream), g_tgt,
+                     g_ref, mask_p, origins, loss_local, rows, B, H, W, ph, pw, groups);
+  return ufr::launched("patch_grad_crop_kernel");
+}
+
+extern "C" int ufr_patch_apply(const float* rows, int n_rows, float* patch_p, float* loss, int ph, int pw, float step,
+                               float bound, const float* gate_state, ufr_stream_t stream) {
+  UFR_REQUIRE(rows && patch_p && loss, "patch apply: null pointer argument");
+  UFR_REQUIRE(n_rows > 0 && ph > 0 && pw > 0, "patch apply: bad shape");
+  const int n = 3 * ph * pw;
+  hipLaunchKernelGGL(patch_apply_kernel, dim3(ufr::ceil_div(n + 1, 256)), dim3(256), 0, ufr::as_stream(stream), rows,
+                     n_rows, patch_p, loss, n, step, bound, gate_state);
+  return ufr::launched("patch_apply_kernel");
+}
+
+extern "C" int ufr_patch_paste_placed(const float* tgt, const float* ref, const float* patch_p, const float* mask_p,
+                                      const int* origins, const int* origins_host, float* adv_tgt, float* adv_ref,
+                                      float* mask_out, int B, int H, int W, int ph, int pw, int do_clamp, float lo,
+                                      float hi, const float* gate_state, ufr_stream_t stream) {
+  UFR_REQUIRE(tgt && ref && patch_p && mask_p && origins && adv_tgt && adv_ref, "placed paste: null pointer argument");
+  UFR_REQUIRE(B > 0 && H > 0 && W > 0 && ph > 0 && pw > 0 && ph <= H && pw <= W, "placed paste: bad shape");
+  UFR_REQUIRE(check_placed(origins_host, B, H, W, ph, pw), "placed paste: a placement leaves the frame");
+  const long total = (long)B * 3 * H * W;
+  hipLaunchKernelGGL(paste_placed_kernel, dim3(ufr::stream_grid(total, 256)), dim3(256), 0, ufr::as_stream(stream), tgt,
+                     ref, patch_p, mask_p, origins, adv_tgt, adv_ref, mask_out, total, H, W, ph, pw, do_clamp, lo, hi,
+                     gate_state);
+  return ufr::launched("paste_placed_kernel");
 }

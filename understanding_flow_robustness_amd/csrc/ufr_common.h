@@ -47,6 +47,9 @@ int corr_bwd_vec_launch(const float* in1, const float* in2, const float* gout, f
 int corr_bwd_mfma_launch(const float* in1, const float* in2, const float* gout, float* gin1, float* gin2,
                          int B, int C, int H, int W, int P, int DP, hipStream_t st);
 
+// attack.hip: *loss += sum of the n workgroup partials, in a fixed order (one wave)
+void loss_finalize_launch(const float* partials, int n, float* loss, hipStream_t st);
+
 }  // namespace ufr
 
 #define UFR_REQUIRE(cond, ...) \

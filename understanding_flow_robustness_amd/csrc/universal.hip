@@ -16,7 +16,7 @@ __device__ __forceinline__ float signf(float v) { return (v > 0.f) ? 1.f : ((v <
 // gt has Cg = 2 or 3 channels; with 3 the last one is a validity mask and `scale` must be
 // 1/(sum(valid)+1e-8), otherwise 1/(number of averaged elements).
 __global__ void flow_loss_ex_kernel(const float* __restrict__ flow, const float* __restrict__ gt,
-                                    float* __restrict__ gflow, float* __restrict__ loss, int B, long HW,
+                                    float* __restrict__ gflow, float* __restrict__ partials, int B, long HW,
                                     int Cg, int kind, float scale_val, const float* __restrict__ scale_dev) {
   __shared__ float red[256 / 64];
   const float scale = scale_dev ? *scale_dev : scale_val;   // device-resident so a captured graph sees updates
@@ -57,7 +57,7 @@ __global__ void flow_loss_ex_kernel(const float* __restrict__ flow, const float*
   if (threadIdx.x == 0) {
     float s = 0.f;
     for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s += red[k];
-    atomicAdd(loss, s * scale);
+    partials[blockIdx.x] = s * scale;      // added in a fixed order by attack.hip's loss_finalize_kernel
   }
 }
 
@@ -117,15 +117,16 @@ __global__ void universal_update_kernel(const float* __restrict__ img0, const fl
 
 extern "C" int ufr_flow_loss_ex(const float* flow, const float* gt, float* grad_flow, float* loss, int B,
                                 int HW, int gt_channels, int kind, float scale, const float* scale_dev,
-                                ufr_stream_t stream) {
-  UFR_REQUIRE(flow && gt && grad_flow && loss, "flow loss: null pointer argument");
+                                float* partials, ufr_stream_t stream) {
+  UFR_REQUIRE(flow && gt && grad_flow && loss && partials, "flow loss: null pointer argument");
   UFR_REQUIRE(B > 0 && HW > 0 && kind >= 0 && kind <= 2 && (gt_channels == 2 || gt_channels == 3),
               "flow loss: bad argument (kind %d, gt channels %d)", kind, gt_channels);
   const long npix = (long)B * HW;
   int grid = ufr::stream_grid(npix, 256);
-  if (grid > 512) grid = 512;
+  if (grid > UFR_LOSS_PARTIALS) grid = UFR_LOSS_PARTIALS;
   hipLaunchKernelGGL(flow_loss_ex_kernel, dim3(grid), dim3(256), 0, ufr::as_stream(stream), flow, gt, grad_flow,
-                     loss, B, (long)HW, gt_channels, kind, scale, scale_dev);
+                     partials, B, (long)HW, gt_channels, kind, scale, scale_dev);
+  ufr::loss_finalize_launch(partials, grid, loss, ufr::as_stream(stream));
   return ufr::launched("flow_loss_ex_kernel");
 }
 

@@ -10,12 +10,17 @@ Here one iteration is
 captured once into a HIP graph and replayed; the host reads the 3-float gate state once per
 attack() call instead of once per iteration.
 
-Batch semantics (an extension: the reference is batch-1): B frame pairs share ONE
-canvas-sized patch; the loss is the mean over all B*H*W pixels and the update uses the gradient of that
-loss with respect to the patch, sum_b [mask_b != 0] * d(loss)/d(adv_b).  For B = 1 the reference's
-unmasked `g_tgt + g_ref` is used as is (same values wherever the mask shows the patch).  With N ranks
-each holds B/N pairs; the pre-clamp gradient sum (+ the loss) is all-reduced over RCCL before the
-non-linear update, so every rank applies the identical update (`ShardedExchange`).
+Batch semantics (an extension: the reference is batch-1): B frame pairs (x N ranks) share ONE
+patch in PATCH coordinates -- the object the reference carries from sample to sample is the canvas cropped at the
+sample's placement (ry, rx) back to `patch_shape` (main.py:396-424).  The step holds P [1,3,ph,pw], its mask
+[1,3,ph,pw] and a device-resident origin table [B,2]; pair b shows P at its own origin.  The loss is the mean over all
+B*N*H*W pixels; per iteration every rank crops each pair's pre-clamp gradient at its placement, sums its pairs in
+ascending order into [3,ph,pw] (31 KB at 51x51), all-gathers the N rows (+ the loss scalar in a 4-byte tail), and every
+rank adds the rows in ascending rank order before `P -= clamp(0.5*lr*G, +-2)`: bit-identical patches on all ranks, a
+patch pixel receives the gradient of every pair that shows it.  `sum_groups` splits a single process's pairs into the
+same groups a sharded run has, which reproduces the N-rank summation tree bit for bit.
+For ONE pair on one rank the reference's canvas-sized arithmetic is used as is (unmasked `g_tgt + g_ref`, main.py:581).
+`shared_patch=False` runs B independent reference attacks (per-sample canvas patches, no exchange).
 
 Cone of influence (cone.py, csrc/window.hip): only `mask * gradient` is ever used and only masked pixels
 change between the iterations of one attack() call, so for networks that expose a convolutional prefix
@@ -38,7 +43,6 @@ from .flownets.utils_model import predict_flow
 
 LOSS_THRESHOLD = 0.1      # main.py:546
 CLAMP_BOUND = 2.0         # main.py:581-583
-UPDATE_MASKED_SUM = 4     # include/ufr_hip.h
 
 
 def _pixel_range(flownet: str):
@@ -47,25 +51,36 @@ def _pixel_range(flownet: str):
 
 
 class ShardedExchange:
-    """All-reduce(sum) of the packed [pre-clamp gradient sum | loss] buffer across the ranks that
-    share the patch.  One collective per iteration, issued before the non-linear update."""
+    """The one exchange per iteration between the ranks that share a patch (RCCL: backend "nccl"; gloo in the CPU
+    tests).  `gather`: all-gather of each rank's [groups, 3*ph*pw + 1] rows (cropped pre-clamp gradient sum | loss),
+    issued before the non-linear update; every rank then adds the rows in the same order.  `__call__`: all-reduce(sum)
+    of a packed buffer (the universal perturbation's image-sized gradient, universal_perturbation.py)."""
 
     def __init__(self, group=None):
         import torch.distributed as dist
         self.dist, self.group = dist, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
     def __call__(self, packed: torch.Tensor) -> torch.Tensor:
         if self.world > 1:
             self.dist.all_reduce(packed, op=self.dist.ReduceOp.SUM, group=self.group)
         return packed
 
+    def gather(self, rows_local: torch.Tensor, rows_all: torch.Tensor) -> torch.Tensor:
+        """rows_all[r*g:(r+1)*g] = rank r's rows_local ([g, n]); rows_all is [world*g, n], contiguous."""
+        if self.world > 1:
+            g = rows_local.shape[0]
+            self.dist.all_gather([rows_all[r * g:(r + 1) * g] for r in range(self.world)], rows_local, group=self.group)
+        return rows_all
+
 
 class PatchAttackStep:
     """Static buffers + the captured iteration for one (network, batch, resolution)."""
 
     def __init__(self, flow_net, args, batch, height, width, device="cuda:0", shared_patch=True,
-                 exchange: ShardedExchange | None = None, use_graph=True, warmup=3, use_cone=None):
+                 exchange: ShardedExchange | None = None, use_graph=True, warmup=3, use_cone=None, patch_hw=None,
+                 sum_groups=1):
         L.lib()   # fail loudly, now, if libufr_hip.so is missing
         self.net, self.args = flow_net, args
         self.B, self.H, self.W = batch, height, width
@@ -75,8 +90,16 @@ class PatchAttackStep:
         self.world = exchange.world if exchange is not None else 1
         if self.world > 1 and not shared_patch:
             raise ValueError("per-sample patches need no exchange; shard them as independent replicas")
-        # several pairs behind one patch: each pair's gradient counts only where its own mask shows the patch
-        self.masked_sum = shared_patch and batch * self.world > 1
+        # several pairs behind one patch: the patch lives in patch coordinates (module docstring)
+        self.placed = patch_hw is not None
+        if shared_patch and batch * self.world > 1 and not self.placed:
+            raise ValueError("one patch behind several pairs is defined in patch coordinates: pass patch_hw=(ph, pw) "
+                             "and load() a [1,3,ph,pw] patch / mask with per-pair origins (SURVEY.md 8e)")
+        if self.placed and not shared_patch:
+            raise ValueError("patch_hw: per-sample patches stay canvas-sized like the reference's")
+        self.groups = int(sum_groups)
+        if self.groups < 1 or batch % self.groups or (self.groups > 1 and not self.placed):
+            raise ValueError("sum_groups must divide the pairs of a patch-coordinate step")
         self.lo, self.hi = _pixel_range(args.flownet)
         self.kind = 1 if getattr(args, "l2", False) else 0
         self.alpha = float(getattr(args, "alpha", 0.0))
@@ -86,16 +109,30 @@ class PatchAttackStep:
         pb = 1 if shared_patch else batch
         self.tgt = torch.zeros(batch, 3, height, width, **f32)
         self.ref = torch.zeros_like(self.tgt)
-        self.mask = torch.zeros_like(self.tgt)
-        self.patch = torch.zeros(pb, 3, height, width, **f32)
+        self.mask = torch.zeros_like(self.tgt)            # canvas masks (placed mode: written by the placed paste)
+        if self.placed:
+            ph, pw = (int(v) for v in patch_hw)
+            if not (0 < ph <= height and 0 < pw <= width):
+                raise ValueError("patch_hw does not fit the frame")
+            self.ph, self.pw, self.n_p = ph, pw, 3 * ph * pw
+            self.patch = torch.zeros(1, 3, ph, pw, **f32)
+            self.mask_p = torch.zeros(1, 3, ph, pw, **f32)
+            self.origins = torch.zeros(batch, 2, dtype=torch.int32, device=self.dev)
+            self.origins_host = None
+            self.rows_local = torch.zeros(self.groups, self.n_p + 1, **f32)
+            self.rows_all = torch.zeros(self.world * self.groups, self.n_p + 1, **f32) if self.world > 1 else self.rows_local
+            self.loss_local = torch.zeros(1, **f32)
+            self.loss_cur = torch.zeros(1, **f32)
+        else:
+            self.patch = torch.zeros(pb, 3, height, width, **f32)
+            self.loss_cur = torch.zeros(1, **f32)
+            self.loss_local = self.loss_cur
         self.patch_init = torch.zeros_like(self.patch)
         self.target = torch.zeros(batch, 2, height, width, **f32)
         self.adv_tgt = torch.zeros_like(self.tgt).requires_grad_(True)
         self.adv_ref = torch.zeros_like(self.tgt).requires_grad_(True)
         self.g_flow = torch.zeros_like(self.target)
-        # packed exchange buffer: [3*H*W pre-clamp gradient sum | loss of this iteration]
-        self.packed = torch.zeros(self.CHW + 1, **f32)
-        self.loss_cur = self.packed[self.CHW:]
+        self.loss_ws = torch.zeros(L.LOSS_PARTIALS, **f32)     # workgroup partials of the fixed-order loss reduction
         self.state = torch.zeros(4, **f32)     # stopped, executed, last loss, (pad)
         for p in self.net.parameters():        # data gradient only: skips a third of the reference's FLOPs
             p.requires_grad_(False)
@@ -115,20 +152,41 @@ class PatchAttackStep:
         self.patch_loaded = torch.zeros_like(self.patch) if self.cone is not None else None
 
     # ------------------------------------------------------------------------------------ C ABI calls
-    def _paste(self, do_clamp):
+    def _paste(self, do_clamp, gate=False, write_mask=False):
+        if self.placed:
+            L.check(L.lib().ufr_patch_paste_placed(
+                L.ptr(self.tgt), L.ptr(self.ref), L.ptr(self.patch), L.ptr(self.mask_p), L.ptr(self.origins),
+                self.origins_host.ctypes.data if (write_mask and self.origins_host is not None) else None,
+                L.ptr(self.adv_tgt), L.ptr(self.adv_ref), L.ptr(self.mask) if write_mask else None, self.B, self.H,
+                self.W, self.ph, self.pw, int(do_clamp), self.lo, self.hi, L.ptr(self.state) if gate else None,
+                L.stream()), "placed paste")
+            return
         L.check(L.lib().ufr_patch_paste(L.ptr(self.tgt), L.ptr(self.ref), L.ptr(self.patch), L.ptr(self.mask),
                                         L.ptr(self.adv_tgt), L.ptr(self.adv_ref), self.B, self.CHW,
                                         0 if self.shared else self.CHW, self.CHW, int(do_clamp), self.lo,
                                         self.hi, L.stream()), "patch paste")
 
-    def _update(self, g_tgt, g_ref, mode):
-        L.check(L.lib().ufr_patch_update(L.ptr(self.tgt), L.ptr(self.ref), L.ptr(g_tgt) if g_tgt is not None else None,
-                                         L.ptr(g_ref) if g_ref is not None else None, L.ptr(self.packed),
+    def _update(self, g_tgt, g_ref):
+        """Canvas form (one pair, or per-sample patches): the reference's arithmetic, main.py:575-600."""
+        L.check(L.lib().ufr_patch_update(L.ptr(self.tgt), L.ptr(self.ref), L.ptr(g_tgt), L.ptr(g_ref),
                                          L.ptr(self.patch), L.ptr(self.mask), L.ptr(self.adv_tgt),
                                          L.ptr(self.adv_ref), self.B, self.CHW, 0 if self.shared else self.CHW,
                                          self.CHW, self.step, CLAMP_BOUND, self.lo, self.hi,
-                                         mode | (UPDATE_MASKED_SUM if self.masked_sum else 0),
                                          L.ptr(self.state), L.stream()), "patch update")
+
+    def _crop(self, g_tgt, g_ref):
+        """Patch-coordinate form, local half: this rank's rows [groups, 3*ph*pw + 1] (cropped gradient sums | loss)."""
+        L.check(L.lib().ufr_patch_grad_crop(L.ptr(g_tgt), L.ptr(g_ref), L.ptr(self.mask_p), L.ptr(self.origins), None,
+                                            L.ptr(self.loss_local), L.ptr(self.rows_local), self.B, self.H, self.W,
+                                            self.ph, self.pw, self.groups, L.stream()), "patch grad crop")
+
+    def _apply(self):
+        """Patch-coordinate form, common half (after the all-gather): fixed-order sum of every rank's rows, the
+        clamped step on P, re-paste of every pair (main.py:581-600)."""
+        L.check(L.lib().ufr_patch_apply(L.ptr(self.rows_all), self.rows_all.shape[0], L.ptr(self.patch),
+                                        L.ptr(self.loss_cur), self.ph, self.pw, self.step, CLAMP_BOUND,
+                                        L.ptr(self.state), L.stream()), "patch apply")
+        self._paste(do_clamp=True, gate=True)
 
     # ------------------------------------------------------------------------------------ windowed encoder
     def _mask_extent(self):
@@ -238,8 +296,9 @@ class PatchAttackStep:
 
     # ------------------------------------------------------------------------------------ one iteration
     def _part_a(self):
-        """forward -> loss (+ d loss/d flow) -> data-gradient backward -> [N>1: local gradient sum]."""
-        self.loss_cur.zero_()
+        """forward -> loss (+ d loss/d flow) -> data-gradient backward -> update (or, patch-coordinate form on
+        several ranks: this rank's cropped gradient rows; the all-gather and `_part_b` follow)."""
+        self.loss_local.zero_()
         if self.cone is not None:
             flow = self._forward_cone()
         else:
@@ -248,27 +307,34 @@ class PatchAttackStep:
             flow = flow.contiguous()
         # shared patch: loss = mean over the GLOBAL batch; private: every sample its own mean
         weight = (1.0 - self.alpha) * ((1.0 / self.world) if self.shared else float(self.B))
-        L.check(L.lib().ufr_flow_loss(L.ptr(flow), L.ptr(self.target), L.ptr(self.g_flow), L.ptr(self.loss_cur),
-                                      self.B, self.H * self.W, self.kind, weight, L.stream()), "flow loss")
+        L.check(L.lib().ufr_flow_loss(L.ptr(flow), L.ptr(self.target), L.ptr(self.g_flow), L.ptr(self.loss_local),
+                                      self.B, self.H * self.W, self.kind, weight, L.ptr(self.loss_ws), L.stream()),
+                "flow loss")
         if not self.shared:
-            self.loss_cur.div_(float(self.B))       # gate on the batch-mean loss
+            self.loss_local.div_(float(self.B))     # gate on the batch-mean loss
         if self.alpha != 0.0:                       # main.py:568-571 (scalar only: no gradient path)
-            reg = torch.nn.functional.l1_loss(self.mask * self.patch, self.mask * self.patch_init)
-            self.loss_cur.add_(self.alpha * reg / self.world)
+            if self.placed:                         # the reference's mean runs over the canvas: same normaliser
+                reg = (self.mask_p * self.patch - self.mask_p * self.patch_init).abs().sum() / float(self.CHW)
+            else:
+                reg = torch.nn.functional.l1_loss(self.mask * self.patch, self.mask * self.patch_init)
+            self.loss_local.add_(self.alpha * reg / self.world)
         if self.cone is not None:
             g_tgt, g_ref = self._backward_cone(flow)
         else:
             g_tgt, g_ref = torch.autograd.grad(flow, (self.adv_tgt, self.adv_ref), self.g_flow)
             g_tgt, g_ref = g_tgt.contiguous(), g_ref.contiguous()
-        if self.world > 1:
-            self._update(g_tgt, g_ref, 1)            # local sum -> packed; the collective follows
-        else:
-            self._update(g_tgt, g_ref, 0)
+        if not self.placed:
+            self._update(g_tgt, g_ref)
+            self._gate()
+            return
+        self._crop(g_tgt, g_ref)
+        if self.world == 1:
+            self._apply()
             self._gate()
 
     def _part_b(self):
-        """N>1 only, after the all-reduce: the identical non-linear update on every rank."""
-        self._update(None, None, 2)
+        """N>1 only, after the all-gather: the identical non-linear update on every rank."""
+        self._apply()
         self._gate()
 
     def _gate(self):
@@ -290,7 +356,7 @@ class PatchAttackStep:
             self._part_a()
         self._first = False
         if self.world > 1:
-            self.exchange(self.packed)               # RCCL all-reduce of [grad sum | loss], eager, same stream
+            self.exchange.gather(self.rows_local, self.rows_all)    # RCCL all-gather of [crop | loss] rows, eager, same stream
             if self.graph_b is not None:
                 self.graph_b.replay()
             else:
@@ -329,15 +395,35 @@ class PatchAttackStep:
         self.graph, self.graph_b = graph, graph_b
 
     # ------------------------------------------------------------------------------------ public API
-    def load(self, tgt, ref, patch, mask, patch_init, target, prefix_features=None):
+    def load(self, tgt, ref, patch, mask, patch_init, target, prefix_features=None, origins=None):
         """Copy one attack() call's operands into the static buffers and do the first, un-clamped
         paste (main.py:537-542).  Must be called after capture (warm-up iterations move the patch).
+        Patch-coordinate steps (`patch_hw`): patch / mask / patch_init are [1,3,ph,pw], `origins` [B,2] holds each
+        pair's (row, column); canvas steps: canvas-sized tensors like the reference's.
         `prefix_features`: see `_cone_refresh` (ignored by the full-frame iteration)."""
         with torch.no_grad():
-            self.tgt.copy_(tgt); self.ref.copy_(ref); self.mask.copy_(mask.expand_as(self.mask))
-            self.patch.copy_(patch); self.patch_init.copy_(patch_init); self.target.copy_(target)
+            self.tgt.copy_(tgt); self.ref.copy_(ref)
+            if self.placed:
+                if origins is None:
+                    raise ValueError("a patch-coordinate step needs origins=[B,2] (row, column of every pair's patch)")
+                if torch.is_tensor(origins):
+                    self.origins.copy_(origins.reshape(self.B, 2))
+                    self.origins_host = None              # device-resident placements: not validated on the host
+                else:
+                    oh = np.ascontiguousarray(np.asarray(origins, dtype=np.int32).reshape(self.B, 2))
+                    if (oh < 0).any() or (oh[:, 0] + self.ph > self.H).any() or (oh[:, 1] + self.pw > self.W).any():
+                        raise ValueError("a patch placement leaves the frame")
+                    self.origins_host = oh
+                    self.origins.copy_(torch.from_numpy(oh))
+                self.mask_p.copy_(mask.reshape(self.mask_p.shape))
+                self.patch.copy_(patch.reshape(self.patch.shape))
+                self.patch_init.copy_(patch_init.reshape(self.patch.shape))
+            else:
+                self.mask.copy_(mask.expand_as(self.mask))
+                self.patch.copy_(patch); self.patch_init.copy_(patch_init)
+            self.target.copy_(target)
             self.state.zero_()
-            self._paste(do_clamp=False)
+            self._paste(do_clamp=False, write_mask=True)
             self._first = True                 # the next iteration sees new frames: full head forward
             if self.cone is not None:
                 self.patch_loaded.copy_(self.patch)
@@ -351,10 +437,12 @@ class PatchAttackStep:
         host read of the device-side gate state."""
         with torch.cuda.device(self.dev):
             if self.graph is None and self._warmup >= 0:
-                saved = [t.clone() for t in (self.tgt, self.ref, self.mask, self.patch, self.patch_init, self.target)]
+                saved = [t.clone() for t in (self.tgt, self.ref, self.patch, self.mask_p if self.placed else self.mask,
+                                             self.patch_init, self.target)]
+                origins = (self.origins_host if self.origins_host is not None else self.origins.clone()) if self.placed else None
                 self._capture()
                 self._warmup = -1
-                self.load(*[saved[i] for i in (0, 1, 3, 2, 4, 5)])
+                self.load(*saved, origins=origins)
             for _ in range(int(max_count)):
                 self._iteration()
             if self.cone is not None and self.world > 1:      # a window overflow anywhere redoes the call everywhere
@@ -384,25 +472,33 @@ _STEP_CACHE_ATTR = "_ufr_patch_steps"
 
 def attack(flow_net, tgt_img_var, ref_past_img_var, ref_future_img_var, patch_var, mask_var,
            patch_init_var, target_var, logger=None, args: Namespace | None = None, use_graph=True,
-           prefix_features=None):
+           prefix_features=None, origins=None):
     """Drop-in for patch_attacks/main.py::attack (:523-613): same positional arguments and return
     tuple `(adv_tgt, None, adv_ref_future, patch_var)`; `patch_var` is updated IN PLACE (:581).
-    The reference reads the module-global `args`; pass it as `args=` (fields flownet, lr, alpha, l2,
-    max_count)."""
+    The reference reads the module-global `args` (main.py:534): when `args=` is not passed, the CALLER's module
+    global `args` is used, so `from understanding_flow_robustness_amd.patch_attack import attack` inside
+    patch_attacks/main.py works with the call at :396 unchanged (fields flownet, lr, alpha, l2, max_count).
+    Extension: `origins=[B,2]` with [1,3,ph,pw] patch / mask tensors = one patch behind B pairs in patch coordinates."""
     if args is None:
-        raise ValueError("attack(): pass the CLI Namespace as args= (the reference reads a module global)")
+        import sys
+        frame = sys._getframe(1)
+        args = frame.f_globals.get("args")
+        if args is None or not hasattr(args, "flownet"):
+            raise ValueError("attack(): no `args` Namespace in the calling module (main.py:534 reads a module global); "
+                             "pass it as args=")
     L.require_hip(tgt_img_var, "tgt_img_var", contiguous=False)
     B, _, H, W = tgt_img_var.shape
     shared = patch_var.shape[0] == 1
-    key = (B, H, W, shared, bool(getattr(args, "l2", False)), float(args.lr), float(getattr(args, "alpha", 0.0)),
+    patch_hw = tuple(patch_var.shape[-2:]) if origins is not None else None
+    key = (B, H, W, shared, patch_hw, bool(getattr(args, "l2", False)), float(args.lr), float(getattr(args, "alpha", 0.0)),
            args.flownet, bool(use_graph))
     cache = flow_net.__dict__.setdefault(_STEP_CACHE_ATTR, {})
     step = cache.get(key)
     if step is None:
         step = cache[key] = PatchAttackStep(flow_net, args, B, H, W, device=tgt_img_var.device,
-                                            shared_patch=shared, use_graph=use_graph)
+                                            shared_patch=shared, use_graph=use_graph, patch_hw=patch_hw)
     step.load(tgt_img_var, ref_future_img_var, patch_var, mask_var, patch_init_var, target_var,
-              prefix_features=prefix_features)
+              prefix_features=prefix_features, origins=origins)
     step.run(getattr(args, "max_count", 2))
     with torch.no_grad():
         patch_var.copy_(step.patch)

@@ -75,6 +75,7 @@ class UniversalPerturbationStep:
         self.packed = torch.zeros(2 * self.CHW + 1, **f32)      # [grad sum frame 0 | frame 1 | loss]
         self.loss_cur = self.packed[2 * self.CHW:]
         self.scale_t = torch.ones(1, **f32)     # 1/normaliser of the loss, device-resident
+        self.loss_ws = torch.zeros(L.LOSS_PARTIALS, **f32)     # workgroup partials of the fixed-order loss reduction
         for p in self.model.parameters():
             p.requires_grad_(False)
         self.model.eval()
@@ -92,7 +93,8 @@ class UniversalPerturbationStep:
         self.loss_cur.zero_()
         flow = predict_flow(self.model, None, self.adv0, self.adv1, self.args).contiguous()
         L.check(L.lib().ufr_flow_loss_ex(L.ptr(flow), L.ptr(self.gt), L.ptr(self.g_flow), L.ptr(self.loss_cur), self.B,
-                                         self.H * self.W, self.Cg, self.kind, 0.0, L.ptr(self.scale_t), L.stream()), "flow loss")
+                                         self.H * self.W, self.Cg, self.kind, 0.0, L.ptr(self.scale_t), L.ptr(self.loss_ws),
+                                         L.stream()), "flow loss")
         g0, g1 = torch.autograd.grad(flow, (self.adv0, self.adv1), self.g_flow, allow_unused=True)
         g0 = torch.zeros_like(self.img0) if g0 is None else g0.contiguous()
         g1 = torch.zeros_like(self.img1) if g1 is None else g1.contiguous()   # :479-483
