@@ -388,6 +388,60 @@ int ufr_kitti_flow_decode(const unsigned short* src, float* dst, int H, int W, u
  * bytes, out = rows x stride, bpp = bytes per complete pixel. */
 int ufr_host_png_unfilter(const unsigned char* data, unsigned char* out, int rows, int stride, int bpp);
 
+/* ---- native FlowNetC head: implicit-GEMM convolutions on bf16 split planes (csrc/igemm.hip) --------------------
+ * replaces, for the attack's frozen networks, the Conv2d / ConvTranspose2d blocks of models/FlowNetC.py:22-50
+ * (models/submodules.py:18-46 `conv`, :75-82 `deconv`) that torch runs on MIOpen -- forward AND data gradient -- without
+ * the activations leaving the device layout between layers.
+ *   activation planes: bf16 [3][chunks][M][32], M = B*H*W pixels, 32 channels per chunk (v = p0 + p1 + p2 exactly);
+ *   weights:           bf16 [3][taps*KC][Npad][32] per phase, pre-split; Npad a multiple of 128;
+ *   gradient sums:     f32 [chunks][M][32].
+ * The tile rows are the cells (b, y, x) of a row grid [B,Hr,Wr] (x offset per sample by row_x0[b*row_x0_stride] /
+ * row_x0_div when row_x0 != NULL: a column band around the patch); tap t of phase z reads input pixel
+ * (y*in_sy + dy[t], x*in_sx + dx[t]) -- zero outside [0,Hi) x [0,Wi), or outside the per-sample input band
+ * [in_x0[b*in_x0_stride]/in_x0_div, + in_xw) when in_x0 != NULL -- and the result lands on output pixel
+ * (y*out_sy + oy0, x*out_sx + ox0) of the [B,Ho,Wo] grid.
+ * Epilogue: act = 1: LeakyReLU(acc + bias) (forward); act = 0: (acc + add) * LeakyReLU'(mask) with `add` an fp32
+ * chunk-major tensor and `mask` plane 0 of the activation this gradient belongs to (either may be NULL).  The result
+ * goes to out_planes (at chunk out_chunk0 of a buffer whose planes are out_plane_stride elements apart) and / or
+ * out_f32.  splitk > 1: fp32 slabs in `ws` ([nphase*splitk][B*Hr*Wr][Npad]), added in a fixed order by a second
+ * kernel (no atomics: bit-reproducible). */
+#define UFR_IGEMM_MAX_TAPS 25
+typedef struct {
+  int ntaps, oy0, ox0;
+  long w_off;                                  /* elements from the start of a weight plane */
+  signed char dy[UFR_IGEMM_MAX_TAPS], dx[UFR_IGEMM_MAX_TAPS];
+} ufr_igemm_phase;
+typedef struct {
+  const void* x; long x_plane_stride; int in_chunk0, KC;
+  int B, Hi, Wi, in_sy, in_sx;
+  const int* in_x0; int in_x0_stride, in_x0_div, in_xw;
+  const void* w; long w_plane_stride; int Npad, N;
+  int Hr, Wr;
+  const int* row_x0; int row_x0_stride, row_x0_div;
+  int Ho, Wo, out_sy, out_sx;
+  int nphase;
+  ufr_igemm_phase phase[4];
+  int act; const float* bias; float slope;
+  const float* add; int add_chunk0;
+  const void* mask; int mask_chunk0;
+  void* out_planes; long out_plane_stride; int out_chunk0;
+  float* out_f32; int out_f32_chunk0;
+  int splitk; float* ws;
+  int products;                                /* 6 (float32-accurate); 3 / 1 for measurements only */
+} ufr_igemm_desc;
+int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream);
+/* Layout passes at the engine's edges.  ufr_nchw_to_planes: planes[chunk0 + c/32] = split(leaky(scale * x[B,C,H,W]))
+ * (scale = 1, slope = 1: a plain conversion).  ufr_chunks_to_nchw: out[B,C,H,W] = scale * leaky'(mask) * v, v from planes
+ * (p0 + p1 + p2) or from an fp32 chunk-major tensor (exactly one of `planes`, `f32`).  ufr_grad_finalize: gradient planes =
+ * split(g * leaky'(mask)) for `chunks` chunks of M pixels. */
+int ufr_nchw_to_planes(const float* x, void* planes, long plane_stride, int chunk0, int B, int C, int H, int W,
+                       float scale, float slope, ufr_stream_t stream);
+int ufr_chunks_to_nchw(const void* planes, long plane_stride, const float* f32, int chunk0, const void* mask,
+                       int mask_chunk0, float* out, int B, int C, int H, int W, float scale, float slope,
+                       ufr_stream_t stream);
+int ufr_grad_finalize(const float* g, int g_chunk0, const void* mask, int mask_chunk0, void* out, long out_plane_stride,
+                      int out_chunk0, long M, int chunks, float slope, ufr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,188 @@
+"""GPU suite: csrc/igemm.hip -- every convolution form of models/FlowNetC.py:22-50 (submodules.py:18-46 `conv`, :75-82
+`deconv`) and their data gradients as ONE implicit-GEMM kernel on bf16 split planes, against torch's float32 operators
+(float64 for the accuracy claim).  Tolerance: 1e-5 of max |result| -- the level at which MIOpen's own fp32 kernels differ
+from float64 (profiles/r1_split_conv_accuracy.jsonl)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-5
+
+
+def _mods():
+    from understanding_flow_robustness_amd import igemm
+    return igemm
+
+
+def _close(got, want, what, tol=TOL):
+    scale = float(want.abs().max())
+    err = float((got.double() - want.double()).abs().max())
+    assert err <= tol * scale, f"{what}: {err / scale:.2e} of max |result|"
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,k,s,p", [
+    (2, 96, 160, 24, 40, 3, 1, 1),        # `conv` block, stride 1, ragged channel counts
+    (3, 70, 130, 13, 21, 3, 2, 1),        # stride 2, odd sizes (M not a multiple of 128)
+    (2, 256, 32, 12, 20, 1, 1, 0),        # conv_redir
+    (1, 64, 128, 20, 36, 5, 2, 2),        # conv2 / conv3 shape (25 taps)
+])
+def test_forward_convolution_with_bias_and_leaky(B, Cin, Cout, H, W, k, s, p):
+    ig = _mods()
+    x, w, b = _rand(B, Cin, H, W, seed=1), _rand(Cout, Cin, k, k, seed=2, scale=0.05), _rand(Cout, seed=3)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    xin = ig.Planes(B, H, W, ig.pad32(Cin) // 32, DEV).load_nchw(x)
+    # output lands at chunk 2 of a wider buffer (a torch.cat of the reference is a chunk offset here)
+    out = ig.Planes(B, Ho, Wo, 2 + ig.pad32(Cout) // 32 + 1, DEV)
+    out.t.fill_(7.0)
+    wi = ig.conv_forward_weights(w, s, p)
+    ig.make_launch(wi, xin, 0, (Ho, Wo), (Ho, Wo), out_planes=out, out_chunk0=2, bias=b)()
+    want = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), s, p), 0.1)
+    _close(out.to_nchw(Cout, 2), want, "forward")
+    # neighbours untouched, padding channels of the last chunk zero
+    assert bool((out.t[:, :2] == 7.0).all()) and bool((out.t[:, 2 + ig.pad32(Cout) // 32:] == 7.0).all())
+    if Cout % 32:
+        assert bool((out.t[:, 2 + Cout // 32, :, Cout % 32:] == 0).all())
+
+
+def test_round_trip_of_the_layout_passes_is_exact():
+    ig = _mods()
+    x = _rand(2, 70, 9, 13, seed=5) * 1e3
+    pl = ig.Planes(2, 9, 13, 4, DEV).load_nchw(x, chunk0=1)
+    assert torch.equal(pl.to_nchw(70, 1), x)                      # three bf16 planes hold a float32 exactly
+    assert bool((pl.t[:, 3, :, 6:] == 0).all())
+    y = ig.Planes(2, 9, 13, 3, DEV).load_nchw(x, scale=0.5, slope=0.1).to_nchw(70)
+    assert torch.equal(y, F.leaky_relu(x * 0.5, 0.1))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 96, 160, 12, 20), (1, 1026, 256, 6, 10)])
+def test_deconv_forward_phases(B, Cin, Cout, H, W):
+    """ConvTranspose2d(Cin, Cout, 4, 2, 1) + bias + LeakyReLU (submodules.py:75-82) as four phase GEMMs."""
+    ig = _mods()
+    x, w, b = _rand(B, Cin, H, W, seed=1), _rand(Cin, Cout, 4, 4, seed=2, scale=0.05), _rand(Cout, seed=3)
+    xin = ig.Planes(B, H, W, ig.pad32(Cin) // 32, DEV).load_nchw(x)
+    out = ig.Planes(B, 2 * H, 2 * W, ig.pad32(Cout) // 32, DEV)
+    wi = ig.deconv_forward_weights(w, 1)
+    ig.make_launch(wi, xin, 0, (H, W), (2 * H, 2 * W), out_planes=out, bias=b)()
+    want = F.leaky_relu(F.conv_transpose2d(x.double(), w.double(), b.double(), 2, 1), 0.1)
+    _close(out.to_nchw(Cout), want, "deconv forward")
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,k,s,p", [(2, 96, 160, 24, 40, 3, 1, 1), (2, 70, 130, 24, 40, 3, 2, 1),
+                                                   (1, 256, 32, 12, 20, 1, 1, 0)])
+def test_data_gradient_with_addend_and_mask(B, Cin, Cout, H, W, k, s, p):
+    """gx = (conv^T(gy) + addend) * LeakyReLU'(activation): planes and fp32 outputs of the gradient epilogue."""
+    ig = _mods()
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    w, gy = _rand(Cout, Cin, k, k, seed=2, scale=0.05), _rand(B, Cout, Ho, Wo, seed=4)
+    act, addend = _rand(B, Cin, H, W, seed=6), _rand(B, Cin, H, W, seed=7)
+    x0 = torch.zeros(B, Cin, H, W, device=DEV, dtype=torch.float64, requires_grad=True)
+    (gx,) = torch.autograd.grad(F.conv2d(x0, w.double(), None, s, p), x0, gy.double())
+    want = (gx + addend.double()) * torch.where(act > 0, 1.0, 0.1).double()
+    gyp = ig.Planes(B, Ho, Wo, ig.pad32(Cout) // 32, DEV).load_nchw(gy)
+    actp = ig.Planes(B, H, W, ig.pad32(Cin) // 32 + 1, DEV).load_nchw(act, chunk0=1)
+    addg = ig.GradSum(B, H, W, ig.pad32(Cin) // 32, DEV)
+    addg.t.copy_(ig.Planes(B, H, W, ig.pad32(Cin) // 32, DEV).load_nchw(addend).t.float().sum(0))
+    outp = ig.Planes(B, H, W, ig.pad32(Cin) // 32, DEV)
+    outf = ig.GradSum(B, H, W, ig.pad32(Cin) // 32, DEV)
+    wi = ig.conv_backward_weights(w, s, p)
+    rows = (Ho, Wo)
+    ig.make_launch(wi, gyp, 0, rows, (H, W), out_planes=outp, out_f32=outf, add=addg, mask=actp, mask_chunk0=1)()
+    _close(outp.to_nchw(Cin), want, "gradient planes")
+    _close(outf.to_nchw(Cin), want, "gradient fp32")
+    # the standalone finalize pass (several sources, last writer not a GEMM): g * leaky'(mask) -> planes
+    from understanding_flow_robustness_amd import _lib as L
+    fin = ig.Planes(B, H, W, ig.pad32(Cin) // 32, DEV)
+    L.check(L.lib().ufr_grad_finalize(L.ptr(addg.t), 0, L.ptr(actp.t), 1, L.ptr(fin.t), fin.plane_stride, 0, fin.M,
+                                      ig.pad32(Cin) // 32, 0.1, L.stream()))
+    assert torch.equal(fin.to_nchw(Cin), addend * torch.where(act > 0, 1.0, 0.1))
+    # and the fp32 -> NCHW pass with mask and scale (what the correlation's adjoint reads)
+    got = outf.to_nchw(Cin, mask=actp, mask_chunk0=1, scale=0.25)
+    _close(got, want * torch.where(act > 0, 1.0, 0.1).double() * 0.25, "gradient sum -> nchw")
+
+
+def test_deconv_data_gradient():
+    ig = _mods()
+    B, Cin, Cout, H, W = 2, 96, 64, 12, 20
+    w, gy = _rand(Cin, Cout, 4, 4, seed=2, scale=0.05), _rand(B, Cout, 2 * H, 2 * W, seed=4)
+    x0 = torch.zeros(B, Cin, H, W, device=DEV, dtype=torch.float64, requires_grad=True)
+    (want,) = torch.autograd.grad(F.conv_transpose2d(x0, w.double(), None, 2, 1), x0, gy.double())
+    gyp = ig.Planes(B, 2 * H, 2 * W, ig.pad32(Cout) // 32, DEV).load_nchw(gy)
+    outf = ig.GradSum(B, H, W, ig.pad32(Cin) // 32, DEV)
+    ig.make_launch(ig.deconv_backward_weights(w, 1), gyp, 0, (H, W), (H, W), out_f32=outf)()
+    _close(outf.to_nchw(Cin), want, "deconv data gradient")
+
+
+def test_split_k_equals_one_pass_and_is_reproducible():
+    """conv6_1's shape class: 6x20 grid, K = 9*1024 -- too few tiles for 256 CUs without splitting the reduction."""
+    ig = _mods()
+    B, Cn, H, W = 2, 512, 6, 20
+    x, w, b = _rand(B, Cn, H, W, seed=1), _rand(Cn, Cn, 3, 3, seed=2, scale=0.02), _rand(Cn, seed=3)
+    xin = ig.Planes(B, H, W, Cn // 32, DEV).load_nchw(x)
+    wi = ig.conv_forward_weights(w, 1, 1)
+    one, many, again = (ig.Planes(B, H, W, Cn // 32, DEV) for _ in range(3))
+    ig.make_launch(wi, xin, 0, (H, W), (H, W), out_planes=one, bias=b)()
+    S = ig.splitk_for(B * H * W, wi.Npad, 9 * wi.KC)
+    assert S >= 4
+    ws = torch.empty(S * B * H * W * wi.Npad, device=DEV)
+    for dst in (many, again):
+        ig.make_launch(wi, xin, 0, (H, W), (H, W), out_planes=dst, bias=b, splitk=S, ws=ws)()
+    want = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), 1, 1), 0.1)
+    _close(one.to_nchw(Cn), want, "one pass")
+    _close(many.to_nchw(Cn), want, "split-K")
+    assert torch.equal(many.t, again.t)                         # fixed-order reduction: no atomics
+
+
+def test_column_band_rows_and_input_band():
+    """Rows restricted to a per-sample column band (origins in device memory): only the band's columns are written, with
+    the full-frame result; an input band makes columns outside it read as zero."""
+    ig = _mods()
+    B, Cin, Cout, H, W, bw = 3, 64, 96, 10, 48, 16
+    x, w, b = _rand(B, Cin, H, W, seed=1), _rand(Cout, Cin, 3, 3, seed=2, scale=0.05), _rand(Cout, seed=3)
+    origins = torch.tensor([[0, 8 * 0, 0, 0], [0, 8 * 32, 0, 0], [0, 8 * 17, 0, 0]], dtype=torch.int32, device=DEV)  # pixels, cell = 8
+    xin = ig.Planes(B, H, W, 2, DEV).load_nchw(x)
+    out = ig.Planes(B, H, W, 3, DEV)
+    out.t.fill_(7.0)
+    wi = ig.conv_forward_weights(w, 1, 1)
+    band = (origins[:, 1], 4, 8)               # tensor view starting at column 1, element stride 4, pixels -> cells
+    ig.make_launch(wi, xin, 0, (H, bw), (H, W), out_planes=out, bias=b, row_band=band)()
+    full = F.leaky_relu(F.conv2d(x, w, b, 1, 1), 0.1)
+    got = out.to_nchw(Cout)
+    for bi, x0 in enumerate((0, 32, 17)):
+        _close(got[bi, :, :, x0:x0 + bw], full[bi, :, :, x0:x0 + bw].double(), f"band of sample {bi}")
+        outside = torch.ones(W, dtype=torch.bool, device=DEV)
+        outside[x0:x0 + bw] = False
+        assert bool((out.t.float().sum(0).view(3, B, H, W, 32)[:, bi][:, :, outside] == 21.0).all())
+    # input band: the same rows, but input columns outside [x0, x0 + bw) count as zero
+    out2 = ig.Planes(B, H, W, 3, DEV)
+    ig.make_launch(wi, xin, 0, (H, bw), (H, W), out_planes=out2, bias=b, row_band=band, in_band=band + (bw,))()
+    got2 = out2.to_nchw(Cout)
+    for bi, x0 in enumerate((0, 32, 17)):
+        xm = torch.zeros_like(x[bi:bi + 1])
+        xm[..., x0:x0 + bw] = x[bi:bi + 1, ..., x0:x0 + bw]
+        ref = F.leaky_relu(F.conv2d(xm, w, b, 1, 1), 0.1)
+        _close(got2[bi:bi + 1, :, :, x0:x0 + bw], ref[..., x0:x0 + bw].double(), f"input band of sample {bi}")
+
+
+def test_accuracy_matches_fp32_against_float64():
+    """The six-product split is an implementation of the float32 product: its error against float64 is at the level of
+    torch's own float32 convolution on this device (conv3_1's reduction length, K = 9*480)."""
+    ig = _mods()
+    B, Cin, Cout, H, W = 1, 473, 256, 24, 40
+    x, w, b = _rand(B, Cin, H, W, seed=1), _rand(Cout, Cin, 3, 3, seed=2, scale=0.03), _rand(Cout, seed=3)
+    xin = ig.Planes(B, H, W, 15, DEV).load_nchw(x)
+    out = ig.Planes(B, H, W, 8, DEV)
+    ig.make_launch(ig.conv_forward_weights(w, 1, 1), xin, 0, (H, W), (H, W), out_planes=out, bias=b)()
+    truth = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), 1, 1), 0.1)
+    fp32 = F.leaky_relu(F.conv2d(x, w, b, 1, 1), 0.1)
+    scale = float(truth.abs().max())
+    e_mine = float((out.to_nchw(Cout).double() - truth).abs().max()) / scale
+    e_fp32 = float((fp32.double() - truth).abs().max()) / scale
+    print(f"six-product split {e_mine:.2e}, torch fp32 {e_fp32:.2e} of max |out|")
+    assert e_mine <= max(3 * e_fp32, 3e-6)

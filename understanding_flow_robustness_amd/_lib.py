@@ -36,6 +36,35 @@ class Pyramid(C.Structure):
                 ("Wl", C.c_int * UFR_MAX_LEVELS)]
 
 
+UFR_IGEMM_MAX_TAPS = 25
+
+
+class IgemmPhase(C.Structure):
+    """ufr_igemm_phase (include/ufr_hip.h)."""
+    _fields_ = [("ntaps", C.c_int), ("oy0", C.c_int), ("ox0", C.c_int), ("w_off", C.c_long),
+                ("dy", C.c_byte * UFR_IGEMM_MAX_TAPS), ("dx", C.c_byte * UFR_IGEMM_MAX_TAPS)]
+
+
+class IgemmDesc(C.Structure):
+    """ufr_igemm_desc (include/ufr_hip.h), field for field."""
+    _fields_ = [("x", C.c_void_p), ("x_plane_stride", C.c_long), ("in_chunk0", C.c_int), ("KC", C.c_int),
+                ("B", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int), ("in_sy", C.c_int), ("in_sx", C.c_int),
+                ("in_x0", C.c_void_p), ("in_x0_stride", C.c_int), ("in_x0_div", C.c_int), ("in_xw", C.c_int),
+                ("w", C.c_void_p), ("w_plane_stride", C.c_long), ("Npad", C.c_int), ("N", C.c_int),
+                ("Hr", C.c_int), ("Wr", C.c_int),
+                ("row_x0", C.c_void_p), ("row_x0_stride", C.c_int), ("row_x0_div", C.c_int),
+                ("Ho", C.c_int), ("Wo", C.c_int), ("out_sy", C.c_int), ("out_sx", C.c_int),
+                ("nphase", C.c_int),
+                ("phase", IgemmPhase * 4),
+                ("act", C.c_int), ("bias", C.c_void_p), ("slope", C.c_float),
+                ("add", C.c_void_p), ("add_chunk0", C.c_int),
+                ("mask", C.c_void_p), ("mask_chunk0", C.c_int),
+                ("out_planes", C.c_void_p), ("out_plane_stride", C.c_long), ("out_chunk0", C.c_int),
+                ("out_f32", C.c_void_p), ("out_f32_chunk0", C.c_int),
+                ("splitk", C.c_int), ("ws", C.c_void_p),
+                ("products", C.c_int)]
+
+
 UFR_MAX_CONE_LAYERS = 8
 
 
@@ -90,6 +119,10 @@ SIGNATURES = {
     "ufr_deconv4x4s2_c2_backward_data": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "ufr_pwc_warp_forward": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_pwc_warp_backward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ufr_igemm": [C.POINTER(IgemmDesc), _vp],
+    "ufr_nchw_to_planes": [_vp, _vp, _l, _i, _i, _i, _i, _i, _f, _f, _vp],
+    "ufr_chunks_to_nchw": [_vp, _l, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _f, _vp],
+    "ufr_grad_finalize": [_vp, _i, _vp, _i, _vp, _l, _i, _l, _i, _f, _vp],
     "ufr_split_bf16x3": [_vp, _vp, _l, _vp],
     "ufr_gemm_split_nt": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ufr_nchw_to_nhwc_split3": [_vp, _vp, _i, _i, _i, _i, _i, _vp],

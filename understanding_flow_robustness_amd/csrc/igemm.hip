@@ -1,0 +1,446 @@
+// igemm.hip -- ONE implicit-GEMM convolution kernel for the native FlowNetC head (flownetc_engine.py): every
+// Conv2d / ConvTranspose2d of models/FlowNetC.py:22-50 (blocks of models/submodules.py:18-46, :75-82) and every one of
+// their data gradients, float32-accurate on the bf16 matrix cores.
+//
+// Arithmetic: a float32 value is held as THREE bf16 planes, v = p0 + p1 + p2 exactly; a product is the
+// six leading bf16 products a0b0 + (a0b1 + a1b0) + (a1b1 + a0b2 + a2b0) accumulated in float32 by
+// `v_mfma_f32_16x16x32_bf16` (2.5 PFLOP/s dense / 6 = 417 TFLOP/s fp32-equivalent against the 157 TFLOP/s fp32 peak).
+// Error against float64 equals a plain fp32 GEMM's (profiles/r1_split_conv_accuracy.jsonl).
+//
+// Layout in HBM -- activations never leave it between layers:
+//   activation planes  bf16 [3][chunks][M][32]   chunk-major NHWC: M = B*H*W pixels, 32 channels per chunk; a K tile
+//                                                of the GEMM (128 pixels x 32 channels of one tap) is one contiguous
+//                                                8 KB run per plane.  A concatenation (torch.cat in FlowNetC.forward)
+//                                                is a chunk offset into a wider buffer.
+//   weights            bf16 [3][taps*KC][Npad][32] per phase, pre-split once (frozen during an attack)
+//   gradient sums      f32  [chunks][M][32]      same pixel / channel order
+//
+// Geometry is data: the tile rows are the cells (b, y, x) of a ROW GRID; tap t reads input pixel
+// (y*in_sy + dy[t], x*in_sx + dx[t]) and the result lands on output pixel (y*out_sy + oy0, x*out_sx + ox0):
+//   Conv2d k, stride s, padding p      rows = output grid, in_s = s, (dy, dx) = (ky - p, kx - p), out_s = 1
+//   its data gradient, s = 1           the same with flipped, transposed weights
+//   ConvTranspose2d(., ., 4, 2, 1)     rows = the COARSE grid, four phases (oy0, ox0) of 4 taps each, out_s = 2
+//   data gradient of a stride-2 conv   the same phase form (1 + 2 + 2 + 4 taps for k = 3)
+//   data gradient of that deconv       rows = coarse grid, in_s = 2, 16 taps
+// A per-sample column origin (device memory) restricts the rows to a band around the patch (band_conv.py's idea
+// without its gather / scatter copies: taps read the full-frame planes directly).
+//
+// Epilogues: forward  = bias + LeakyReLU -> planes;  gradient = (+ fp32 addend) * LeakyReLU'(mask) -> planes and / or
+// fp32.  Split-K (small layers: 6x20 and 12x40 grids cannot fill 256 CUs with 128x128 tiles) writes fp32 slabs that a
+// second kernel adds in a fixed order -- no float atomics anywhere, results are bit-reproducible.
+#include "ufr_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+constexpr int BM = 128, BN = 128, BK = 32;
+__device__ constexpr int PROD_A[6] = {2, 0, 1, 1, 0, 0};   // (a plane, b plane) of each product, smallest first
+__device__ constexpr int PROD_B[6] = {0, 2, 1, 0, 1, 0};
+
+struct RowGeom {            // what the kernels need to turn a tile row into pixels
+  int B, Hr, Wr, M;         // row grid, M = B*Hr*Wr
+  const int* row_x0;        // optional per-sample first column of the band: x = xr + row_x0[b*stride] / div
+  int row_x0_stride, row_x0_div;
+  int Ho, Wo, out_sy, out_sx;
+};
+
+__device__ __forceinline__ void split3(float v, __bf16& a, __bf16& b, __bf16& c) {
+  a = (__bf16)v;
+  const float r1 = v - (float)a;
+  b = (__bf16)r1;
+  c = (__bf16)(r1 - (float)b);
+}
+
+// One output element through the epilogue.  `pout` = output pixel index, `n` = output channel.
+struct Epilogue {
+  const float* bias; float slope; int act;
+  const float* add; int add_chunk0;
+  const __bf16* mask; int mask_chunk0;
+  __bf16* out_planes; long out_plane_stride; int out_chunk0;
+  float* out_f32; int out_f32_chunk0;
+  long Mout; int N, Nchunks32;        // channels < Nchunks32*32 are written (zeros beyond N: the chunk's padding)
+};
+
+__device__ __forceinline__ void epilogue_store(const Epilogue& e, long pout, int n, float v) {
+  if (n >= e.Nchunks32 * 32) return;
+  const long cm = ((long)(n >> 5) * e.Mout + pout) * 32 + (n & 31);          // chunk-major element inside a tensor
+  if (e.act) {
+    v += (n < e.N) ? e.bias[n] : 0.f;
+    v = v > 0.f ? v : v * e.slope;
+  } else {
+    if (e.add) v += e.add[(long)e.add_chunk0 * e.Mout * 32 + cm];
+    if (e.mask) v = ((float)e.mask[(long)e.mask_chunk0 * e.Mout * 32 + cm] > 0.f) ? v : v * e.slope;
+  }
+  if (n >= e.N) v = 0.f;
+  if (e.out_f32) e.out_f32[(long)e.out_f32_chunk0 * e.Mout * 32 + cm] = v;
+  if (e.out_planes) {
+    __bf16 a, b, c;
+    split3(v, a, b, c);
+    __bf16* o = e.out_planes + (long)e.out_chunk0 * e.Mout * 32 + cm;
+    o[0] = a;
+    o[e.out_plane_stride] = b;
+    o[2 * e.out_plane_stride] = c;
+  }
+}
+
+__device__ __forceinline__ long out_pixel(const RowGeom& g, int pm, int oy0, int ox0) {
+  const int hw = g.Hr * g.Wr;
+  const int b = pm / hw, r = pm - b * hw, yr = r / g.Wr, xr = r - yr * g.Wr;
+  const int xg = xr + (g.row_x0 ? g.row_x0[b * g.row_x0_stride] / g.row_x0_div : 0);
+  return ((long)b * g.Ho + (yr * g.out_sy + oy0)) * g.Wo + (xg * g.out_sx + ox0);
+}
+
+struct Phase {
+  int ntaps, oy0, ox0;
+  long w_off;                       // bf16 elements from the weight plane's start
+  signed char dy[UFR_IGEMM_MAX_TAPS], dx[UFR_IGEMM_MAX_TAPS];
+};
+
+struct Args {
+  const __bf16* x; long x_plane_stride; int in_chunk0, KC;
+  int Hi, Wi, in_sy, in_sx;
+  const int* in_x0; int in_x0_stride, in_x0_div, in_xw;   // optional validity band of the INPUT columns (else [0, Wi))
+  const __bf16* w; long w_plane_stride; int Npad;
+  RowGeom g;
+  Epilogue e;
+  int nphase, splitk;
+  float* ws;                         // split-K slabs [nphase*splitk][M][Npad]
+  Phase ph[4];
+};
+
+template <int NPROD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm_kernel(const Args a) {
+  constexpr int NPL = NPROD == 1 ? 1 : (NPROD == 3 ? 2 : 3);
+  constexpr int FIRST = 6 - NPROD;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * NPL][BM * BK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
+  const int z = blockIdx.z, phase = z / a.splitk, ks = z - phase * a.splitk;
+  const Phase& ph = a.ph[phase];
+  const int KC = a.KC, KT = ph.ntaps * KC;
+  const int per = (KT + a.splitk - 1) / a.splitk, kt0 = ks * per, kt1 = min(KT, kt0 + per);
+  const long Min = (long)a.g.B * a.Hi * a.Wi;
+
+  // staging: 512 16-byte pieces per image, two rows per thread
+  const int srow0 = tid >> 2, sch = tid & 3;
+  int yb[2], xb[2], xlo[2], xhi[2];
+  long ibase[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pm = bm + srow0 + 64 * i;
+    const int hw = a.g.Hr * a.g.Wr;
+    const int b = pm / hw, r = pm - b * hw, yr = r / a.g.Wr, xr = r - yr * a.g.Wr;
+    const bool live = pm < a.g.M;
+    const int bb = live ? b : 0;
+    const int xg = xr + (a.g.row_x0 ? a.g.row_x0[bb * a.g.row_x0_stride] / a.g.row_x0_div : 0);
+    yb[i] = live ? yr * a.in_sy : -(1 << 20);        // rows past the end never pass the bounds test
+    xb[i] = xg * a.in_sx;
+    ibase[i] = (long)bb * a.Hi * a.Wi;
+    xlo[i] = a.in_x0 ? a.in_x0[bb * a.in_x0_stride] / a.in_x0_div : 0;
+    xhi[i] = a.in_x0 ? min(a.Wi, xlo[i] + a.in_xw) : a.Wi;
+    xlo[i] = max(xlo[i], 0);
+  }
+  u32x4 sa[NPL][2], sb[NPL][2];
+  const __bf16* gx = a.x + (long)a.in_chunk0 * Min * 32 + sch * 8;
+  const __bf16* gw = a.w + ph.w_off + (long)(bn + srow0) * BK + sch * 8;
+  const int soff0 = srow0 * BK + ((sch ^ ((srow0 >> 1) & 3)) << 3);
+#define UFR_IG_LOAD(kt)                                                                                     \
+  {                                                                                                         \
+    const int tap = (kt) / KC, kc = (kt) - tap * KC, dyo = ph.dy[tap], dxo = ph.dx[tap];                     \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                         \
+      const int yi = yb[i] + dyo, xi = xb[i] + dxo;                                                         \
+      const bool ok = (unsigned)yi < (unsigned)a.Hi && xi >= xlo[i] && xi < xhi[i];                          \
+      const __bf16* src = gx + ((long)kc * Min + (ok ? ibase[i] + (long)yi * a.Wi + xi : 0)) * 32;           \
+      _Pragma("unroll") for (int p = 0; p < NPL; ++p) {                                                     \
+        const u32x4 v = *reinterpret_cast<const u32x4*>(src + p * a.x_plane_stride);                        \
+        sa[p][i] = ok ? v : u32x4{0u, 0u, 0u, 0u};                                                          \
+        sb[p][i] = *reinterpret_cast<const u32x4*>(gw + p * a.w_plane_stride + ((long)(kt) * a.Npad + 64 * i) * BK); \
+      }                                                                                                     \
+    }                                                                                                       \
+  }
+#define UFR_IG_STORE()                                                                              \
+  _Pragma("unroll") for (int p = 0; p < NPL; ++p) _Pragma("unroll") for (int i = 0; i < 2; ++i) {   \
+    *reinterpret_cast<u32x4*>(&lds[p][soff0 + 64 * i * BK]) = sa[p][i];                             \
+    *reinterpret_cast<u32x4*>(&lds[NPL + p][soff0 + 64 * i * BK]) = sb[p][i];                       \
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15;
+  const int foff = frow * BK + ((((lane >> 4)) ^ ((frow >> 1) & 3)) << 3);
+
+  if (kt0 < kt1) UFR_IG_LOAD(kt0)
+  for (int kt = kt0; kt < kt1; ++kt) {
+    __syncthreads();
+    UFR_IG_STORE()
+    __syncthreads();
+    if (kt + 1 < kt1) UFR_IG_LOAD(kt + 1)
+    bf16x8 fa[NPL][4];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        fa[p][m] = *reinterpret_cast<const bf16x8*>(&lds[p][(wr * 64 + m * 16) * BK + foff]);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      bf16x8 fb[NPL];
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) fb[p] = *reinterpret_cast<const bf16x8*>(&lds[NPL + p][(wc * 64 + n * 16) * BK + foff]);
+#pragma unroll
+      for (int t = FIRST; t < 6; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[t]][m], fb[PROD_B[t]], acc[m][n], 0, 0, 0);
+    }
+  }
+#undef UFR_IG_LOAD
+#undef UFR_IG_STORE
+
+  // C/D layout of the 16x16 forms: col = lane & 15, row = (lane >> 4) * 4 + reg
+  if (a.splitk > 1) {
+    float* slab = a.ws + (long)z * a.g.M * a.Npad;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = bm + wr * 64 + m * 16 + (lane >> 4) * 4 + j;
+        if (row < a.g.M) {
+#pragma unroll
+          for (int n = 0; n < 4; ++n) slab[(long)row * a.Npad + bn + wc * 64 + n * 16 + (lane & 15)] = acc[m][n][j];
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = bm + wr * 64 + m * 16 + (lane >> 4) * 4 + j;
+      if (row < a.g.M) {
+        const long pout = out_pixel(a.g, row, ph.oy0, ph.ox0);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) epilogue_store(a.e, pout, bn + wc * 64 + n * 16 + (lane & 15), acc[m][n][j]);
+      }
+    }
+}
+
+// Second stage of split-K: thread = (phase, row, channel); the slabs are added in ascending order.
+__global__ __launch_bounds__(256) void igemm_reduce_kernel(const Args a) {
+  const long total = (long)a.nphase * a.g.M * a.Npad;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % a.Npad);
+    const long rest = i / a.Npad;
+    const int row = (int)(rest % a.g.M), phase = (int)(rest / a.g.M);
+    if (n >= a.e.Nchunks32 * 32) continue;
+    float v = 0.f;
+    for (int s = 0; s < a.splitk; ++s) v += a.ws[((long)(phase * a.splitk + s) * a.g.M + row) * a.Npad + n];
+    epilogue_store(a.e, out_pixel(a.g, row, a.ph[phase].oy0, a.ph[phase].ox0), n, v);
+  }
+}
+
+// ---- layout passes at the engine's edges ---------------------------------------------------------------------------
+// x [B][C][HW] float32 (NCHW) -> planes at a chunk offset, y = leaky(scale * x); channels C..Cpad-1 of the last chunk 0.
+__global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float* __restrict__ x, __bf16* __restrict__ planes,
+                                                             long plane_stride, int chunk0, int B, int C, int HW,
+                                                             float scale, float slope) {
+  __shared__ float tile[32][65];
+  const int c0 = blockIdx.x * 32, p0 = blockIdx.y * 64, b = blockIdx.z, tid = threadIdx.x;
+  {
+    const int p = tid & 63;
+#pragma unroll
+    for (int cc = tid >> 6; cc < 32; cc += 4) {
+      const int c = c0 + cc;
+      float v = (c < C && p0 + p < HW) ? x[((size_t)b * C + c) * HW + p0 + p] * scale : 0.f;
+      tile[cc][p] = v > 0.f ? v : v * slope;
+    }
+  }
+  __syncthreads();
+  const int p = tid >> 2, ch = tid & 3;
+  if (p0 + p >= HW) return;
+  const size_t rows = (size_t)B * HW;
+  __bf16* dst = planes + (((size_t)chunk0 + blockIdx.x) * rows + (size_t)b * HW + p0 + p) * 32 + ch * 8;
+  bf16x8 q0, q1, q2;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    __bf16 a, bq, c;
+    split3(tile[ch * 8 + j][p], a, bq, c);
+    q0[j] = a; q1[j] = bq; q2[j] = c;
+  }
+  *reinterpret_cast<bf16x8*>(dst) = q0;
+  *reinterpret_cast<bf16x8*>(dst + plane_stride) = q1;
+  *reinterpret_cast<bf16x8*>(dst + 2 * plane_stride) = q2;
+}
+
+// chunk-major tensor (planes: p0 + p1 + p2, or fp32) -> out [B][C][HW] float32 (NCHW), optionally
+// out = scale * leaky'(mask) * v with `mask` = plane 0 of an activation in the same chunk-major geometry.
+__global__ __launch_bounds__(256) void chunks_to_nchw_kernel(const __bf16* __restrict__ planes, long plane_stride,
+                                                             const float* __restrict__ f32, int chunk0,
+                                                             const __bf16* __restrict__ mask, int mask_chunk0,
+                                                             float* __restrict__ out, int B, int C, int HW, float scale,
+                                                             float slope) {
+  __shared__ float tile[32][65];
+  const int c0 = blockIdx.x * 32, p0 = blockIdx.y * 64, b = blockIdx.z, tid = threadIdx.x;
+  const size_t rows = (size_t)B * HW;
+  {
+    const int p = tid >> 2, q = tid & 3;
+    if (p0 + p < HW) {
+      const size_t pix = (size_t)b * HW + p0 + p;
+      const size_t o = (((size_t)chunk0 + blockIdx.x) * rows + pix) * 32 + q * 8;
+      float v[8];
+      if (planes) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(planes + o);
+        const bf16x8 bq = *reinterpret_cast<const bf16x8*>(planes + o + plane_stride);
+        const bf16x8 c = *reinterpret_cast<const bf16x8*>(planes + o + 2 * plane_stride);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ((float)a[j] + (float)bq[j]) + (float)c[j];
+      } else {
+        const float4 a = *reinterpret_cast<const float4*>(f32 + o), bq = *reinterpret_cast<const float4*>(f32 + o + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = bq.x; v[5] = bq.y; v[6] = bq.z; v[7] = bq.w;
+      }
+      if (mask) {
+        const bf16x8 m = *reinterpret_cast<const bf16x8*>(mask + (((size_t)mask_chunk0 + blockIdx.x) * rows + pix) * 32 + q * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ((float)m[j] > 0.f) ? v[j] : v[j] * slope;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) tile[q * 8 + j][p] = v[j] * scale;
+    }
+  }
+  __syncthreads();
+  const int p = tid & 63;
+  if (p0 + p >= HW) return;
+#pragma unroll
+  for (int cc = tid >> 6; cc < 32; cc += 4) {
+    const int c = c0 + cc;
+    if (c < C) out[((size_t)b * C + c) * HW + p0 + p] = tile[cc][p];
+  }
+}
+
+// fp32 chunk-major gradient sum -> gradient planes: g * leaky'(mask), chunk by chunk (a gradient with several sources
+// whose last writer is not a GEMM epilogue).
+__global__ __launch_bounds__(256) void grad_finalize_kernel(const float* __restrict__ g, int g_chunk0,
+                                                            const __bf16* __restrict__ mask, int mask_chunk0,
+                                                            __bf16* __restrict__ out, long out_plane_stride, int out_chunk0,
+                                                            long M, int chunks, float slope) {
+  const long total = (long)chunks * M * 4;            // 8 channels per thread
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long e = i * 8;                               // element inside the [chunks][M][32] tensor
+    const float4 a = *reinterpret_cast<const float4*>(g + (long)g_chunk0 * M * 32 + e);
+    const float4 b = *reinterpret_cast<const float4*>(g + (long)g_chunk0 * M * 32 + e + 4);
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    if (mask) {
+      const bf16x8 m = *reinterpret_cast<const bf16x8*>(mask + (long)mask_chunk0 * M * 32 + e);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = ((float)m[j] > 0.f) ? v[j] : v[j] * slope;
+    }
+    bf16x8 q0, q1, q2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      __bf16 x, y, z;
+      split3(v[j], x, y, z);
+      q0[j] = x; q1[j] = y; q2[j] = z;
+    }
+    __bf16* o = out + (long)out_chunk0 * M * 32 + e;
+    *reinterpret_cast<bf16x8*>(o) = q0;
+    *reinterpret_cast<bf16x8*>(o + out_plane_stride) = q1;
+    *reinterpret_cast<bf16x8*>(o + 2 * out_plane_stride) = q2;
+  }
+}
+
+}  // namespace
+
+extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
+  UFR_REQUIRE(d, "igemm: null descriptor");
+  UFR_REQUIRE(d->x && d->w, "igemm: null operand");
+  UFR_REQUIRE(d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Hr > 0 && d->Wr > 0 && d->Ho > 0 && d->Wo > 0, "igemm: bad grid");
+  UFR_REQUIRE(d->KC > 0 && d->in_chunk0 >= 0 && d->N > 0 && d->Npad % BN == 0 && d->Npad >= d->N, "igemm: bad channel counts");
+  UFR_REQUIRE(d->in_sy > 0 && d->in_sx > 0 && d->out_sy > 0 && d->out_sx > 0, "igemm: bad strides");
+  UFR_REQUIRE(d->nphase >= 1 && d->nphase <= 4 && d->splitk >= 1 && d->splitk <= 64, "igemm: bad phase / split count");
+  UFR_REQUIRE(d->products == 6 || d->products == 3 || d->products == 1, "igemm: products must be 6, 3 or 1");
+  UFR_REQUIRE(d->splitk == 1 || d->ws, "igemm: split-K needs a workspace");
+  UFR_REQUIRE(d->out_planes || d->out_f32, "igemm: no output");
+  UFR_REQUIRE(!d->act || d->bias, "igemm: the forward epilogue needs the bias");
+  UFR_REQUIRE(!d->row_x0 || (d->row_x0_div > 0), "igemm: bad band divisor");
+  UFR_REQUIRE(!d->in_x0 || (d->in_x0_div > 0 && d->in_xw > 0), "igemm: bad input band");
+  const long M = (long)d->B * d->Hr * d->Wr;
+  UFR_REQUIRE(M < (1L << 30) && (long)d->B * d->Hi * d->Wi < (1L << 30) && (long)d->B * d->Ho * d->Wo < (1L << 30),
+              "igemm: too many pixels");
+  // every row must land inside the output grid (without a band the check is exact; with one the origins are device
+  // data: the caller guarantees origin + Wr <= the full row-grid width)
+  UFR_REQUIRE((d->Hr - 1) * d->out_sy + 1 <= d->Ho && (d->row_x0 || (d->Wr - 1) * d->out_sx + 1 <= d->Wo),
+              "igemm: the row grid does not fit the output grid");
+  Args a;
+  a.x = static_cast<const __bf16*>(d->x); a.x_plane_stride = d->x_plane_stride; a.in_chunk0 = d->in_chunk0; a.KC = d->KC;
+  a.Hi = d->Hi; a.Wi = d->Wi; a.in_sy = d->in_sy; a.in_sx = d->in_sx;
+  a.in_x0 = d->in_x0; a.in_x0_stride = d->in_x0_stride; a.in_x0_div = d->in_x0_div; a.in_xw = d->in_xw;
+  a.w = static_cast<const __bf16*>(d->w); a.w_plane_stride = d->w_plane_stride; a.Npad = d->Npad;
+  a.g.B = d->B; a.g.Hr = d->Hr; a.g.Wr = d->Wr; a.g.M = (int)M;
+  a.g.row_x0 = d->row_x0; a.g.row_x0_stride = d->row_x0_stride; a.g.row_x0_div = d->row_x0_div;
+  a.g.Ho = d->Ho; a.g.Wo = d->Wo; a.g.out_sy = d->out_sy; a.g.out_sx = d->out_sx;
+  a.e.bias = d->bias; a.e.slope = d->slope; a.e.act = d->act;
+  a.e.add = d->add; a.e.add_chunk0 = d->add_chunk0;
+  a.e.mask = static_cast<const __bf16*>(d->mask); a.e.mask_chunk0 = d->mask_chunk0;
+  a.e.out_planes = static_cast<__bf16*>(d->out_planes); a.e.out_plane_stride = d->out_plane_stride; a.e.out_chunk0 = d->out_chunk0;
+  a.e.out_f32 = d->out_f32; a.e.out_f32_chunk0 = d->out_f32_chunk0;
+  a.e.Mout = (long)d->B * d->Ho * d->Wo; a.e.N = d->N; a.e.Nchunks32 = (d->N + 31) / 32;
+  a.nphase = d->nphase; a.splitk = d->splitk; a.ws = d->ws;
+  for (int z = 0; z < 4; ++z) {
+    const ufr_igemm_phase& p = d->phase[z < d->nphase ? z : 0];
+    UFR_REQUIRE(p.ntaps >= 1 && p.ntaps <= UFR_IGEMM_MAX_TAPS && p.w_off >= 0, "igemm: bad phase %d", z);
+    UFR_REQUIRE(p.oy0 >= 0 && p.oy0 < d->out_sy && p.ox0 >= 0 && p.ox0 < d->out_sx, "igemm: bad phase offset");
+    UFR_REQUIRE(p.w_off + (long)p.ntaps * d->KC * d->Npad * BK <= d->w_plane_stride, "igemm: phase %d weights out of range", z);
+    a.ph[z].ntaps = p.ntaps; a.ph[z].oy0 = p.oy0; a.ph[z].ox0 = p.ox0; a.ph[z].w_off = p.w_off;
+    for (int t = 0; t < UFR_IGEMM_MAX_TAPS; ++t) {
+      a.ph[z].dy[t] = t < p.ntaps ? p.dy[t] : 0;
+      a.ph[z].dx[t] = t < p.ntaps ? p.dx[t] : 0;
+    }
+  }
+  hipStream_t st = ufr::as_stream(stream);
+  const dim3 grid(d->Npad / BN, (unsigned)((M + BM - 1) / BM), d->nphase * d->splitk);
+  if (d->products == 6) igemm_kernel<6><<<grid, 256, 0, st>>>(a);
+  else if (d->products == 3) igemm_kernel<3><<<grid, 256, 0, st>>>(a);
+  else igemm_kernel<1><<<grid, 256, 0, st>>>(a);
+  int rc = ufr::launched("igemm_kernel");
+  if (rc != UFR_OK || d->splitk == 1) return rc;
+  const long total = (long)d->nphase * M * d->Npad;
+  igemm_reduce_kernel<<<ufr::stream_grid(total, 256), 256, 0, st>>>(a);
+  return ufr::launched("igemm_reduce_kernel");
+}
+
+extern "C" int ufr_nchw_to_planes(const float* x, void* planes, long plane_stride, int chunk0, int B, int C, int H, int W,
+                                  float scale, float slope, ufr_stream_t stream) {
+  UFR_REQUIRE(x && planes, "nchw -> planes: null pointer");
+  UFR_REQUIRE(B > 0 && B < 65536 && C > 0 && H > 0 && W > 0 && chunk0 >= 0 && plane_stride > 0, "nchw -> planes: bad shape");
+  const dim3 grid((C + 31) / 32, (H * W + 63) / 64, B);
+  nchw_to_planes_kernel<<<grid, 256, 0, ufr::as_stream(stream)>>>(x, static_cast<__bf16*>(planes), plane_stride, chunk0, B, C,
+                                                                   H * W, scale, slope);
+  return ufr::launched("nchw_to_planes_kernel");
+}
+
+extern "C" int ufr_chunks_to_nchw(const void* planes, long plane_stride, const float* f32, int chunk0, const void* mask,
+                                  int mask_chunk0, float* out, int B, int C, int H, int W, float scale, float slope,
+                                  ufr_stream_t stream) {
+  UFR_REQUIRE((planes != nullptr) != (f32 != nullptr) && out, "chunks -> nchw: exactly one source");
+  UFR_REQUIRE(B > 0 && B < 65536 && C > 0 && H > 0 && W > 0 && chunk0 >= 0 && mask_chunk0 >= 0, "chunks -> nchw: bad shape");
+  const dim3 grid((C + 31) / 32, (H * W + 63) / 64, B);
+  chunks_to_nchw_kernel<<<grid, 256, 0, ufr::as_stream(stream)>>>(static_cast<const __bf16*>(planes), plane_stride, f32, chunk0,
+                                                                   static_cast<const __bf16*>(mask), mask_chunk0, out, B, C,
+                                                                   H * W, scale, slope);
+  return ufr::launched("chunks_to_nchw_kernel");
+}
+
+extern "C" int ufr_grad_finalize(const float* g, int g_chunk0, const void* mask, int mask_chunk0, void* out,
+                                 long out_plane_stride, int out_chunk0, long M, int chunks, float slope, ufr_stream_t stream) {
+  UFR_REQUIRE(g && out, "grad finalize: null pointer");
+  UFR_REQUIRE(M > 0 && chunks > 0 && g_chunk0 >= 0 && mask_chunk0 >= 0 && out_chunk0 >= 0, "grad finalize: bad shape");
+  grad_finalize_kernel<<<ufr::stream_grid((long)chunks * M * 4, 256), 256, 0, ufr::as_stream(stream)>>>(
+      g, g_chunk0, static_cast<const __bf16*>(mask), mask_chunk0, static_cast<__bf16*>(out), out_plane_stride, out_chunk0, M,
+      chunks, slope);
+  return ufr::launched("grad_finalize_kernel");
+}

@@ -1,0 +1,255 @@
+"""Host side of csrc/igemm.hip: plane buffers, pre-split weight images and the geometry descriptors that turn every
+Conv2d / ConvTranspose2d block of models/FlowNetC.py:22-50 (models/submodules.py:18-46, :75-82) -- forward and data
+gradient -- into one launch of `ufr_igemm` (float32-accurate on the bf16 matrix cores: three bf16 planes per operand,
+six products).  No torch arithmetic happens here at run time: weights are packed once (they are frozen
+during an attack), everything else is descriptors over device pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+LEAKY = 0.1                  # models/submodules.py:33, :45, :81
+
+
+def pad32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+def pad128(c: int) -> int:
+    return (c + 127) // 128 * 128
+
+
+class Planes:
+    """An activation in the engine's layout: bf16 [3][chunks][M][32], M = B*H*W pixels in (b, y, x) order, 32 channels
+    per chunk, value = p0 + p1 + p2 exactly.  A torch.cat of the reference is a chunk offset into one wider buffer."""
+
+    def __init__(self, B, H, W, chunks, device):
+        self.B, self.H, self.W, self.chunks = int(B), int(H), int(W), int(chunks)
+        self.M = self.B * self.H * self.W
+        self.t = torch.zeros(3, self.chunks, self.M, 32, dtype=torch.bfloat16, device=device)
+        self.plane_stride = self.chunks * self.M * 32
+
+    def load_nchw(self, x: torch.Tensor, chunk0: int = 0, scale: float = 1.0, slope: float = 1.0):
+        """planes[chunk0 + c/32] = split(leaky(scale * x)); x [B,C,H,W] float32 contiguous."""
+        L.require_hip(x, "x")
+        B, Cn, H, W = x.shape
+        if (B, H, W) != (self.B, self.H, self.W) or chunk0 + pad32(Cn) // 32 > self.chunks or x.dtype != torch.float32:
+            raise RuntimeError("Planes.load_nchw: shape mismatch")
+        L.check(L.lib().ufr_nchw_to_planes(L.ptr(x), L.ptr(self.t), self.plane_stride, int(chunk0), B, Cn, H, W,
+                                           float(scale), float(slope), L.stream()), "nchw -> planes")
+        return self
+
+    def to_nchw(self, Cn: int, chunk0: int = 0, out: torch.Tensor | None = None) -> torch.Tensor:
+        if out is None:
+            out = torch.empty(self.B, Cn, self.H, self.W, dtype=torch.float32, device=self.t.device)
+        L.check(L.lib().ufr_chunks_to_nchw(L.ptr(self.t), self.plane_stride, None, int(chunk0), None, 0, L.ptr(out), self.B, Cn,
+                                           self.H, self.W, 1.0, 1.0, L.stream()), "planes -> nchw")
+        return out
+
+
+class GradSum:
+    """A gradient accumulator: float32 [chunks][M][32] in the same pixel / channel order as `Planes`."""
+
+    def __init__(self, B, H, W, chunks, device):
+        self.B, self.H, self.W, self.chunks = int(B), int(H), int(W), int(chunks)
+        self.M = self.B * self.H * self.W
+        self.t = torch.zeros(self.chunks, self.M, 32, dtype=torch.float32, device=device)
+
+    def to_nchw(self, Cn: int, chunk0: int = 0, mask: Planes | None = None, mask_chunk0: int = 0, scale: float = 1.0,
+                slope: float = LEAKY, out: torch.Tensor | None = None) -> torch.Tensor:
+        if out is None:
+            out = torch.empty(self.B, Cn, self.H, self.W, dtype=torch.float32, device=self.t.device)
+        L.check(L.lib().ufr_chunks_to_nchw(None, 0, L.ptr(self.t), int(chunk0), L.ptr(mask.t) if mask is not None else None,
+                                           int(mask_chunk0), L.ptr(out), self.B, Cn, self.H, self.W, float(scale), float(slope),
+                                           L.stream()), "gradient sum -> nchw")
+        return out
+
+
+# ---------------------------------------------------------------------------------------------------- weights
+class WeightImage:
+    """Pre-split weights of ONE launch: bf16 [3][total] with, per phase, a chunk-major [taps*KC][Npad][32] image at
+    `offsets[z]`; `phases[z]` = (oy0, ox0, [(dy, dx)])."""
+
+    def __init__(self, planes, offsets, phases, N, Npad, KC, geometry):
+        self.planes, self.offsets, self.phases = planes, offsets, phases
+        self.N, self.Npad, self.KC = N, Npad, KC
+        self.geometry = geometry        # dict(in_s, out_s): strides of the row grid -> input / output pixels
+
+
+def _split3(w: torch.Tensor) -> torch.Tensor:
+    """float32 -> [3, n] bf16 planes with w == p0 + p1 + p2 exactly (round to nearest even at every step)."""
+    w = w.reshape(-1).float()
+    p0 = w.to(torch.bfloat16)
+    r1 = w - p0.float()
+    p1 = r1.to(torch.bfloat16)
+    p2 = (r1 - p1.float()).to(torch.bfloat16)
+    return torch.stack((p0, p1, p2)).contiguous()
+
+
+def _pack(mats, device):
+    """mats[z] = float32 [N, taps, C] (output channel, tap, input channel) per phase -> WeightImage arrays."""
+    images, offsets, total = [], [], 0
+    N, _, Cn = mats[0].shape
+    npad, cpad = pad128(N), pad32(Cn)
+    for m in mats:
+        taps = m.shape[1]
+        w = torch.zeros(npad, taps, cpad, dtype=torch.float32, device=device)
+        w[:N, :, :Cn] = m
+        img = w.view(npad, taps * cpad // 32, 32).permute(1, 0, 2).contiguous().view(-1)        # [taps*KC][Npad][32]
+        offsets.append(total)
+        total += img.numel()
+        images.append(img)
+    return _split3(torch.cat(images)), offsets, N, npad, cpad // 32
+
+
+def _deconv_phases(kernel: int, padding: int):
+    """out[2q + o] += w[k] * x[q + d]: the four phases of a stride-2 transposed convolution whose output is exactly twice
+    its input (output_padding = 2 + 2*padding - kernel in {0, 1}); -> [(oy0, ox0, [(ky, kx, dy, dx)])]."""
+    if not 0 <= 2 + 2 * padding - kernel <= 1:
+        raise ValueError("stride-2 transposed convolution: kernel / padding do not double the size")
+    phases = []
+    for oy0 in (0, 1):
+        for ox0 in (0, 1):
+            ry, rx = (oy0 + padding) % 2, (ox0 + padding) % 2
+            cy, cx = (oy0 + padding - ry) // 2, (ox0 + padding - rx) // 2
+            phases.append((oy0, ox0, [(ky, kx, cy - (ky - ry) // 2, cx - (kx - rx) // 2)
+                                      for ky in range(ry, kernel, 2) for kx in range(rx, kernel, 2)]))
+    return phases
+
+
+def conv_forward_weights(weight: torch.Tensor, stride: int, padding: int) -> WeightImage:
+    """Conv2d weight [N,C,k,k] -> the forward launch (rows = output grid)."""
+    N, Cn, k, _ = weight.shape
+    w = weight.detach().float()
+    mat = w.permute(0, 2, 3, 1).reshape(N, k * k, Cn)
+    taps = [(ky - padding, kx - padding) for ky in range(k) for kx in range(k)]
+    planes, offsets, N, npad, KC = _pack([mat], weight.device)
+    return WeightImage(planes, offsets, [(0, 0, taps)], N, npad, KC, dict(in_s=stride, out_s=1))
+
+
+def conv_backward_weights(weight: torch.Tensor, stride: int, padding: int) -> WeightImage:
+    """Data gradient of Conv2d(weight [N,C,k,k], stride, padding): gx[C] from gy[N] (rows = the gy grid)."""
+    N, Cn, k, _ = weight.shape
+    w = weight.detach().float()
+    if stride == 1:
+        # gx[y] = sum_ky gy[y + p - ky] * w[ky]: a convolution of gy with the transposed weights
+        mat = w.permute(1, 2, 3, 0).reshape(Cn, k * k, N)
+        taps = [(padding - ky, padding - kx) for ky in range(k) for kx in range(k)]
+        planes, offsets, n, npad, KC = _pack([mat], weight.device)
+        return WeightImage(planes, offsets, [(0, 0, taps)], n, npad, KC, dict(in_s=1, out_s=1))
+    if stride != 2:
+        raise NotImplementedError("data gradient: stride 1 or 2")
+    phases = _deconv_phases(k, padding)          # gx = conv_transpose(gy, weight): 'input' channels N, output channels C
+    mats = [torch.stack([w[:, :, ky, kx].t() for ky, kx, _, _ in taps], dim=1) for _, _, taps in phases]   # [C, taps, N]
+    planes, offsets, n, npad, KC = _pack(mats, weight.device)
+    return WeightImage(planes, offsets, [(oy, ox, [(dy, dx) for _, _, dy, dx in taps]) for oy, ox, taps in phases], n, npad, KC,
+                       dict(in_s=1, out_s=2))
+
+
+def deconv_forward_weights(weight: torch.Tensor, padding: int) -> WeightImage:
+    """ConvTranspose2d(Cin, Cout, k, 2, padding) weight [Cin,Cout,k,k] -> the forward launch (rows = the coarse grid)."""
+    cin, cout, k, _ = weight.shape
+    w = weight.detach().float()
+    phases = _deconv_phases(k, padding)
+    mats = [torch.stack([w[:, :, ky, kx].t() for ky, kx, _, _ in taps], dim=1) for _, _, taps in phases]   # [Cout, taps, Cin]
+    planes, offsets, n, npad, KC = _pack(mats, weight.device)
+    return WeightImage(planes, offsets, [(oy, ox, [(dy, dx) for _, _, dy, dx in taps]) for oy, ox, taps in phases], n, npad, KC,
+                       dict(in_s=1, out_s=2))
+
+
+def deconv_backward_weights(weight: torch.Tensor, padding: int) -> WeightImage:
+    """Data gradient of that ConvTranspose2d: gx[Cin] on the coarse grid = Conv2d(gy, weight as [Cin,Cout,k,k], stride 2,
+    padding) (rows = the coarse grid, taps read the fine gradient)."""
+    cin, cout, k, _ = weight.shape
+    w = weight.detach().float()
+    mat = w.permute(0, 2, 3, 1).reshape(cin, k * k, cout)
+    taps = [(ky - padding, kx - padding) for ky in range(k) for kx in range(k)]
+    planes, offsets, n, npad, KC = _pack([mat], weight.device)
+    return WeightImage(planes, offsets, [(0, 0, taps)], n, npad, KC, dict(in_s=2, out_s=1))
+
+
+# ---------------------------------------------------------------------------------------------------- launches
+class Launch:
+    """One prepared `ufr_igemm` call: the descriptor plus references that keep its tensors alive."""
+
+    def __init__(self, desc, keep):
+        self.desc, self._keep = desc, keep
+
+    def __call__(self):
+        L.check(L.lib().ufr_igemm(C.byref(self.desc), L.stream()), "igemm")
+
+
+def make_launch(wi: WeightImage, x: Planes, in_chunk0: int, rows_hw, out_hw, *, out_planes: Planes | None = None,
+                out_chunk0: int = 0, out_f32: GradSum | None = None, out_f32_chunk0: int = 0, bias: torch.Tensor | None = None,
+                add: GradSum | None = None, add_chunk0: int = 0, mask: Planes | None = None, mask_chunk0: int = 0,
+                slope: float = LEAKY, splitk: int = 1, ws: torch.Tensor | None = None, row_band=None, in_band=None,
+                products: int = 6) -> Launch:
+    """Descriptor for `wi` applied to the chunks [in_chunk0, in_chunk0 + KC) of `x`.
+    rows_hw = (Hr, Wr) row grid; out_hw = (Ho, Wo) output grid.  row_band = (origins int32 tensor, element stride, divisor):
+    the row grid's columns start at origins[b*stride] // divisor.  in_band = (origins, stride, divisor, width): input
+    columns outside [origin, origin + width) read as zero.  bias given -> forward epilogue (bias + LeakyReLU)."""
+    d = L.IgemmDesc()
+    d.x, d.x_plane_stride, d.in_chunk0, d.KC = x.t.data_ptr(), x.plane_stride, int(in_chunk0), wi.KC
+    if in_chunk0 + wi.KC > x.chunks:
+        raise RuntimeError("igemm: the reduced chunks leave the input buffer")
+    d.B, d.Hi, d.Wi = x.B, x.H, x.W
+    d.in_sy = d.in_sx = int(wi.geometry["in_s"])
+    if in_band is not None:
+        d.in_x0, d.in_x0_stride, d.in_x0_div, d.in_xw = in_band[0].data_ptr(), int(in_band[1]), int(in_band[2]), int(in_band[3])
+    d.w, d.w_plane_stride, d.Npad, d.N = wi.planes.data_ptr(), wi.planes.shape[1], wi.Npad, wi.N
+    d.Hr, d.Wr = int(rows_hw[0]), int(rows_hw[1])
+    if row_band is not None:
+        d.row_x0, d.row_x0_stride, d.row_x0_div = row_band[0].data_ptr(), int(row_band[1]), int(row_band[2])
+    d.Ho, d.Wo = int(out_hw[0]), int(out_hw[1])
+    d.out_sy = d.out_sx = int(wi.geometry["out_s"])
+    d.nphase = len(wi.phases)
+    for z, ((oy0, ox0, taps), off) in enumerate(zip(wi.phases, wi.offsets)):
+        ph = d.phase[z]
+        if len(taps) > L.UFR_IGEMM_MAX_TAPS:
+            raise RuntimeError("igemm: too many taps")
+        ph.ntaps, ph.oy0, ph.ox0, ph.w_off = len(taps), oy0, ox0, off
+        for t, (dy, dx) in enumerate(taps):
+            ph.dy[t], ph.dx[t] = dy, dx
+    Mout = x.B * d.Ho * d.Wo
+    nch = pad32(wi.N) // 32
+    keep = [wi, x, bias, add, mask, out_planes, out_f32, ws, row_band, in_band]
+    if bias is not None:
+        d.act, d.bias = 1, bias.data_ptr()
+    d.slope = float(slope)
+    if add is not None:
+        if add.M != Mout or add_chunk0 + nch > add.chunks:
+            raise RuntimeError("igemm: addend geometry")
+        d.add, d.add_chunk0 = add.t.data_ptr(), int(add_chunk0)
+    if mask is not None:
+        if mask.M != Mout or mask_chunk0 + nch > mask.chunks:
+            raise RuntimeError("igemm: mask geometry")
+        d.mask, d.mask_chunk0 = mask.t.data_ptr(), int(mask_chunk0)
+    if out_planes is not None:
+        if out_planes.M != Mout or out_chunk0 + nch > out_planes.chunks:
+            raise RuntimeError("igemm: output plane geometry")
+        d.out_planes, d.out_plane_stride, d.out_chunk0 = out_planes.t.data_ptr(), out_planes.plane_stride, int(out_chunk0)
+    if out_f32 is not None:
+        if out_f32.M != Mout or out_f32_chunk0 + nch > out_f32.chunks:
+            raise RuntimeError("igemm: fp32 output geometry")
+        d.out_f32, d.out_f32_chunk0 = out_f32.t.data_ptr(), int(out_f32_chunk0)
+    d.splitk = int(splitk)
+    if splitk > 1:
+        need = d.nphase * splitk * x.B * d.Hr * d.Wr * wi.Npad
+        if ws is None or ws.numel() < need or ws.dtype != torch.float32:
+            raise RuntimeError(f"igemm: split-K workspace of {need} floats needed")
+        d.ws = ws.data_ptr()
+    d.products = int(products)
+    return Launch(d, keep)
+
+
+def splitk_for(M: int, Npad: int, ktiles: int, phases: int = 1, target: int = 512) -> int:
+    """Split the reduction until the launch has about `target` workgroups (2 per CU), keeping >= 16 K tiles per slice."""
+    tiles = -(-M // 128) * (Npad // 128) * phases
+    s = 1
+    while tiles * s * 2 <= target and ktiles // (s * 2) >= 16 and s < 32:
+        s *= 2
+    return s
