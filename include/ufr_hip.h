@@ -442,6 +442,21 @@ int ufr_chunks_to_nchw(const void* planes, long plane_stride, const float* f32, 
 int ufr_grad_finalize(const float* g, int g_chunk0, const void* mask, int mask_chunk0, void* out, long out_plane_stride,
                       int out_chunk0, long M, int chunks, float slope, ufr_stream_t stream);
 
+/* The 2-channel layers of the refinement on the engine's layout (csrc/engine_small.hip):
+ * predict_flow* = Conv2d(Cin,2,3,1,1) (models/FlowNetC.py:43-47) reads the chunks [chunk0, chunk0+chunks) of a planes
+ * buffer and writes flow [B,2,H,W] fp32; weights repacked wpk[chunk][tap][out][32].  Its data gradient writes (or adds
+ * to) the fp32 gradient sum G [.. chunks][B*H*W][32].  upsampled_flow* = ConvTranspose2d(2,2,4,2,1) (:48-50) writes its
+ * two channels (+ 30 zeros) into chunk `chunk` of the concatenation at twice the resolution; its data gradient reads
+ * channels 0-1 of that chunk of the fp32 gradient sum. */
+int ufr_flow_head_planes_forward(const void* planes, long plane_stride, int chunk0, int chunks, const float* wpk,
+                                 const float* bias, float* out, int B, int H, int W, ufr_stream_t stream);
+int ufr_flow_head_planes_backward(const float* grad_y, const float* wpk, float* G, int chunk0, int chunks, int B, int H,
+                                  int W, int accumulate, ufr_stream_t stream);
+int ufr_flow_up_planes_forward(const float* x, const float* w, const float* bias, void* planes, long plane_stride,
+                               int chunk, int B, int H, int W, ufr_stream_t stream);
+int ufr_flow_up_planes_backward(const float* G, int chunk, const float* w, float* grad_x, int B, int H, int W,
+                                ufr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -183,16 +183,36 @@ def test_config_c5_flownet2_universal_step_at_448x1024(oracle):
     # where with target = -clean flow the cosine loss sits exactly at its maximum: the gradient is analytically zero
     # and sign() of rounding noise decides -- not a parity case)
     delta0 = (torch.rand(2, 3, H, W, generator=g) * 2 - 1) * 0.01
-    step.load(img0.to(DEV), img1.to(DEV), delta0.to(DEV), (-clean).to(DEV))
-    step.run(n_step)
     with torch.no_grad():
         gpu_clean = net(img0.to(DEV), img1.to(DEV)).cpu()
     assert_close(gpu_clean, clean, rtol=REL, atol_scale=REL, what="FlowNet2 448x1024 clean flow")
+    # step 1 against the oracle's gradient: sign() is index-like, so the update must agree wherever the gradient is
+    # clearly non-zero.  FlowNet2's image gradient runs through four floor() warps (resample2d_kernel.cu:45-52) and is
+    # piecewise: two fp32 evaluations differ by ~1e-2 of its scale (see test_flownet2_vs_reference_wiring), so entries
+    # whose gradient is below that level may take the other sign.
+    adv0 = torch.clamp(img0 + delta0[0], 0, 1).requires_grad_(True)
+    adv1 = torch.clamp(img1 + delta0[1], 0, 1).requires_grad_(True)
+    loss = fo.compute_flow_loss(predict(adv0, adv1), -clean, "cossim")
+    g0, g1 = torch.autograd.grad(loss, (adv0, adv1))
+    grad = torch.stack((g0[0], g1[0]))
+    want1 = torch.clamp(delta0 - 2e-3 * torch.sign(grad), -0.02, 0.02)
+    step.load(img0.to(DEV), img1.to(DEV), delta0.to(DEV), (-clean).to(DEV))
+    step.run(1)
+    flipped = (step.delta.cpu() - want1).abs() > 1e-6
+    scale = float(grad.abs().median())
+    worst = float(grad.abs()[flipped].max()) / scale if bool(flipped.any()) else 0.0
+    frac1 = float(flipped.float().mean())
+    print(f"C5 step 1: {frac1:.2e} of the entries take the other sign; largest |gradient| among them {worst:.2e} of the median")
+    assert frac1 < 1.5e-2 and worst < 0.5, f"C5: {frac1:.2e} flips, up to {worst:.2e} of the median gradient"
+    assert float((step.delta.cpu() - want1).abs().max()) <= 2 * 2e-3 + 1e-6
+    # both steps against the oracle's loop: flips of step 1 move step 2's gradient a little, nothing more
+    step.load(img0.to(DEV), img1.to(DEV), delta0.to(DEV), (-clean).to(DEV))
+    step.run(n_step)
     _, _, d = fo.universal_attack(predict, img0, img1, delta0, -clean, n_step=n_step, lr=2e-3, eps=0.02, shared=True)
     diff = (step.delta.cpu() - d).abs()
     frac = float((diff > 1e-6).float().mean())
-    print(f"C5: {frac:.2e} of the perturbation entries differ, max {float(diff.max()):.2e}")
-    assert frac < 2e-3, f"C5: {frac:.2e} of the perturbation entries differ"
+    print(f"C5: after {n_step} steps {frac:.2e} of the perturbation entries differ, max {float(diff.max()):.2e}")
+    assert frac < 3e-2, f"C5: {frac:.2e} of the perturbation entries differ"
     assert float(diff.max()) <= 2 * 2e-3 * n_step + 1e-6
     assert float((step.delta.cpu() - delta0).abs().max()) > 1e-3          # the steps took effect
 
@@ -238,8 +258,12 @@ def test_raft_gradient_against_float64_truth(alternate, oracle):
         print(f"RAFT alt={alternate} {name}: product {e_mine:.2e}, reference cpu fp32 {e_cpu:.2e}, torch spelling fp32 on "
               f"this device {e_torch:.2e} (float64: {e_64:.1e}), product vs torch spelling {e_same:.2e}")
         assert e_64 <= 1e-10                                  # the formulation itself is exact on this device
-        if not alternate:                                     # same convolutions, same lookups: only the kernels differ
-            assert e_same <= 1e-4, f"{name}: product vs pure-torch spelling on the same device {e_same:.2e}"
+        if not alternate:
+            # same device, same lookups; the convolutions differ in shape (the product stacks the GRU's z | r
+            # convolutions and batches the encoders), so MIOpen's fp32 kernels differ and the conditioning of the
+            # gradient (1e-2 class, above) amplifies that: measured 6e-6 with the find step off, 1e-3 with it on.  A
+            # wrong lookup / GRU / upsampling adjoint would be off by O(1).
+            assert e_same <= 5e-3, f"{name}: product vs pure-torch spelling on the same device {e_same:.2e}"
         if i == 0:
             assert e_mine <= 1e-5
         else:

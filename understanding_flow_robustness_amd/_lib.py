@@ -123,6 +123,10 @@ SIGNATURES = {
     "ufr_nchw_to_planes": [_vp, _vp, _l, _i, _i, _i, _i, _i, _f, _f, _vp],
     "ufr_chunks_to_nchw": [_vp, _l, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _f, _vp],
     "ufr_grad_finalize": [_vp, _i, _vp, _i, _vp, _l, _i, _l, _i, _f, _vp],
+    "ufr_flow_head_planes_forward": [_vp, _l, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "ufr_flow_head_planes_backward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "ufr_flow_up_planes_forward": [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp],
+    "ufr_flow_up_planes_backward": [_vp, _i, _vp, _vp, _i, _i, _i, _vp],
     "ufr_split_bf16x3": [_vp, _vp, _l, _vp],
     "ufr_gemm_split_nt": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ufr_nchw_to_nhwc_split3": [_vp, _vp, _i, _i, _i, _i, _i, _vp],

@@ -1,0 +1,230 @@
+// engine_small.hip -- the 2-channel layers of FlowNetC's refinement on the engine's chunk-major layout (csrc/igemm.hip):
+// predict_flow* = Conv2d(Cin, 2, 3, 1, 1) and upsampled_flow* = ConvTranspose2d(2, 2, 4, 2, 1)
+// (models/FlowNetC.py:43-50, models/submodules.py:85-90).  HBM-bound: one pass over the concatenation buffer.
+//
+//   flow_head_planes_fwd   thread = (pixel, 8-channel group): per chunk and tap one 16-byte read from each of the three
+//                          planes (a wave reads 16 pixels x 64 B = whole lines), v = p0 + p1 + p2 exactly, 16 FMAs against
+//                          weights repacked [chunk][tap][out][32]; the four groups of a pixel are added by two shuffles
+//   flow_head_planes_bwd   thread = (pixel, 8-channel group): the pixel's 3x3x2 gradient neighbourhood in registers,
+//                          per chunk 144 FMAs and one 32-byte store (or read-add-store) into the fp32 gradient sum
+//   flow_up_planes_fwd     ConvTranspose2d(2,2,4,2,1) written straight into the concatenation's last chunk (2 channels
+//                          + 30 zeros, all three planes)
+//   flow_up_planes_bwd     its data gradient from channels 0-1 of that chunk of the fp32 gradient sum
+#include "ufr_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+__device__ __forceinline__ void split3(float v, __bf16& a, __bf16& b, __bf16& c) {
+  a = (__bf16)v;
+  const float r1 = v - (float)a;
+  b = (__bf16)r1;
+  c = (__bf16)(r1 - (float)b);
+}
+
+// wpk [chunks][9][2][32] float32: wpk[ch][k][o][c] = weight[o][32*ch + c][k] (zero for padding channels)
+__global__ __launch_bounds__(256) void flow_head_planes_fwd(const __bf16* __restrict__ x, long plane_stride, int chunk0,
+                                                            int chunks, const float* __restrict__ wpk,
+                                                            const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                            int H, int W) {
+  const long M = (long)B * H * W;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long pix = t >> 2;
+  const int q = (int)(t & 3);
+  const bool live = pix < M;
+  const long pp = live ? pix : 0;
+  const int xx = (int)(pp % W), yy = (int)((pp / W) % H);
+  long off[9];
+  bool ok[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int y2 = yy + k / 3 - 1, x2 = xx + k % 3 - 1;
+    ok[k] = live && y2 >= 0 && y2 < H && x2 >= 0 && x2 < W;
+    off[k] = pp + (long)(k / 3 - 1) * W + (k % 3 - 1);
+  }
+  float a0 = 0.f, a1 = 0.f;
+  for (int ch = 0; ch < chunks; ++ch) {
+    const __bf16* xc = x + ((long)(chunk0 + ch) * M) * 32 + q * 8;
+    const float* wc = wpk + (long)ch * 9 * 2 * 32 + q * 8;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      if (!ok[k]) continue;
+      const __bf16* src = xc + off[k] * 32;
+      const bf16x8 p0 = *reinterpret_cast<const bf16x8*>(src);
+      const bf16x8 p1 = *reinterpret_cast<const bf16x8*>(src + plane_stride);
+      const bf16x8 p2 = *reinterpret_cast<const bf16x8*>(src + 2 * plane_stride);
+      const float4 w0a = *reinterpret_cast<const float4*>(wc + (k * 2 + 0) * 32), w0b = *reinterpret_cast<const float4*>(wc + (k * 2 + 0) * 32 + 4);
+      const float4 w1a = *reinterpret_cast<const float4*>(wc + (k * 2 + 1) * 32), w1b = *reinterpret_cast<const float4*>(wc + (k * 2 + 1) * 32 + 4);
+      const float w0[8] = {w0a.x, w0a.y, w0a.z, w0a.w, w0b.x, w0b.y, w0b.z, w0b.w};
+      const float w1[8] = {w1a.x, w1a.y, w1a.z, w1a.w, w1b.x, w1b.y, w1b.z, w1b.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = ((float)p0[j] + (float)p1[j]) + (float)p2[j];
+        a0 = fmaf(v, w0[j], a0);
+        a1 = fmaf(v, w1[j], a1);
+      }
+    }
+  }
+  a0 += __shfl_xor(a0, 1, 64); a1 += __shfl_xor(a1, 1, 64);
+  a0 += __shfl_xor(a0, 2, 64); a1 += __shfl_xor(a1, 2, 64);
+  if (live && q == 0) {
+    const long HW = (long)H * W, b = pix / HW, p = pix - b * HW;
+    out[(b * 2 + 0) * HW + p] = a0 + bias[0];
+    out[(b * 2 + 1) * HW + p] = a1 + bias[1];
+  }
+}
+
+// G[chunk0 + ch][pix][c] (+)= sum_o sum_k gy[b, o, pix - (k - centre)] * weight[o][32*ch + c][k]
+__global__ __launch_bounds__(256) void flow_head_planes_bwd(const float* __restrict__ gy, const float* __restrict__ wpk,
+                                                            float* __restrict__ G, int chunk0, int chunks, int B, int H, int W,
+                                                            int accumulate) {
+  const long M = (long)B * H * W;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long pix = t >> 2;
+  const int q = (int)(t & 3);
+  if (pix >= M) return;
+  const long HW = (long)H * W, b = pix / HW, p = pix - b * HW;
+  const int yy = (int)(p / W), xx = (int)(p - (long)yy * W);
+  float g0[9], g1[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {                       // the output pixel that used tap k on this input pixel
+    const int y2 = yy - (k / 3 - 1), x2 = xx - (k % 3 - 1);
+    const bool ok = y2 >= 0 && y2 < H && x2 >= 0 && x2 < W;
+    g0[k] = ok ? gy[(b * 2 + 0) * HW + (long)y2 * W + x2] : 0.f;
+    g1[k] = ok ? gy[(b * 2 + 1) * HW + (long)y2 * W + x2] : 0.f;
+  }
+  for (int ch = 0; ch < chunks; ++ch) {
+    const float* wc = wpk + (long)ch * 9 * 2 * 32 + q * 8;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float4 w0a = *reinterpret_cast<const float4*>(wc + (k * 2 + 0) * 32), w0b = *reinterpret_cast<const float4*>(wc + (k * 2 + 0) * 32 + 4);
+      const float w0[8] = {w0a.x, w0a.y, w0a.z, w0a.w, w0b.x, w0b.y, w0b.z, w0b.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = fmaf(g0[k], w0[j], a[j]);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float4 w1a = *reinterpret_cast<const float4*>(wc + (k * 2 + 1) * 32), w1b = *reinterpret_cast<const float4*>(wc + (k * 2 + 1) * 32 + 4);
+      const float w1[8] = {w1a.x, w1a.y, w1a.z, w1a.w, w1b.x, w1b.y, w1b.z, w1b.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = fmaf(g1[k], w1[j], a[j]);
+    }
+    float4* dst = reinterpret_cast<float4*>(G + ((long)(chunk0 + ch) * M + pix) * 32 + q * 8);
+    float4 lo = make_float4(a[0], a[1], a[2], a[3]), hi = make_float4(a[4], a[5], a[6], a[7]);
+    if (accumulate) {
+      const float4 o0 = dst[0], o1 = dst[1];
+      lo.x += o0.x; lo.y += o0.y; lo.z += o0.z; lo.w += o0.w;
+      hi.x += o1.x; hi.y += o1.y; hi.z += o1.z; hi.w += o1.w;
+    }
+    dst[0] = lo;
+    dst[1] = hi;
+  }
+}
+
+// y[b,o,Y,X] = bias[o] + sum_i sum_{ky,kx} x[b,i,(Y+1-ky)/2,(X+1-kx)/2] * w[i,o,ky,kx]  -> chunk `chunk` of `planes`
+// (the same arithmetic, operation for operation, as small_cout.hip's deconv4x4s2_c2_fwd); optionally also NCHW fp32
+__global__ void flow_up_planes_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                   __bf16* __restrict__ planes, long plane_stride, int chunk, int B, int H, int W, int has_bias) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const long total = (long)B * Ho * Wo;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % Wo), Y = (int)((i / Wo) % Ho), b = (int)(i / ((long)Wo * Ho));
+    float a0 = has_bias ? bias[0] : 0.f, a1 = has_bias ? bias[1] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int ky = ((Y + 1) & 1) + 2 * t, yy = (Y + 1 - ky) / 2;
+      if (Y + 1 - ky < 0 || yy >= H) continue;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int kx = ((X + 1) & 1) + 2 * u, xx = (X + 1 - kx) / 2;
+        if (X + 1 - kx < 0 || xx >= W) continue;
+#pragma unroll
+        for (int ic = 0; ic < 2; ++ic) {
+          const float v = x[((size_t)b * 2 + ic) * H * W + (size_t)yy * W + xx];
+          a0 = fmaf(v, w[((ic * 2 + 0) * 4 + ky) * 4 + kx], a0);
+          a1 = fmaf(v, w[((ic * 2 + 1) * 4 + ky) * 4 + kx], a1);
+        }
+      }
+    }
+    __bf16 s0[3], s1[3];
+    split3(a0, s0[0], s0[1], s0[2]);
+    split3(a1, s1[0], s1[1], s1[2]);
+    __bf16* dst = planes + ((long)chunk * total + i) * 32;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      bf16x8 v = {s0[p], s1[p], (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+      const bf16x8 zero = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+      bf16x8* o = reinterpret_cast<bf16x8*>(dst + p * plane_stride);
+      o[0] = v; o[1] = zero; o[2] = zero; o[3] = zero;
+    }
+  }
+}
+
+// gx[b,i,y,x] = sum_o sum_{ky,kx} G[chunk][(b,2y-1+ky,2x-1+kx)][o] * w[i,o,ky,kx]
+__global__ void flow_up_planes_bwd(const float* __restrict__ G, int chunk, const float* __restrict__ w, float* __restrict__ gx,
+                                   int B, int H, int W) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const long total = (long)B * H * W, Mf = (long)B * Ho * Wo;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % W), yy = (int)((i / W) % H), b = (int)(i / ((long)W * H));
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+      const int Y = 2 * yy - 1 + ky;
+      if (Y < 0 || Y >= Ho) continue;
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+        const int X = 2 * xx - 1 + kx;
+        if (X < 0 || X >= Wo) continue;
+        const float2 g = *reinterpret_cast<const float2*>(G + ((long)chunk * Mf + ((long)b * Ho + Y) * Wo + X) * 32);
+        a0 = fmaf(g.x, w[((0 * 2 + 0) * 4 + ky) * 4 + kx], a0);
+        a1 = fmaf(g.x, w[((1 * 2 + 0) * 4 + ky) * 4 + kx], a1);
+        a0 = fmaf(g.y, w[((0 * 2 + 1) * 4 + ky) * 4 + kx], a0);
+        a1 = fmaf(g.y, w[((1 * 2 + 1) * 4 + ky) * 4 + kx], a1);
+      }
+    }
+    gx[((size_t)b * 2 + 0) * H * W + (size_t)yy * W + xx] = a0;
+    gx[((size_t)b * 2 + 1) * H * W + (size_t)yy * W + xx] = a1;
+  }
+}
+
+}  // namespace
+
+extern "C" int ufr_flow_head_planes_forward(const void* planes, long plane_stride, int chunk0, int chunks, const float* wpk,
+                                            const float* bias, float* out, int B, int H, int W, ufr_stream_t stream) {
+  UFR_REQUIRE(planes && wpk && bias && out, "flow head (planes) forward: null pointer");
+  UFR_REQUIRE(B > 0 && H > 0 && W > 0 && chunks > 0 && chunk0 >= 0 && (long)B * H * W < (1L << 29), "flow head (planes) forward: bad shape");
+  const long threads = (long)B * H * W * 4;
+  flow_head_planes_fwd<<<ufr::ceil_div(threads, 256), 256, 0, ufr::as_stream(stream)>>>(
+      static_cast<const __bf16*>(planes), plane_stride, chunk0, chunks, wpk, bias, out, B, H, W);
+  return ufr::launched("flow_head_planes_fwd");
+}
+
+extern "C" int ufr_flow_head_planes_backward(const float* grad_y, const float* wpk, float* G, int chunk0, int chunks, int B,
+                                             int H, int W, int accumulate, ufr_stream_t stream) {
+  UFR_REQUIRE(grad_y && wpk && G, "flow head (planes) backward: null pointer");
+  UFR_REQUIRE(B > 0 && H > 0 && W > 0 && chunks > 0 && chunk0 >= 0 && (long)B * H * W < (1L << 29), "flow head (planes) backward: bad shape");
+  const long threads = (long)B * H * W * 4;
+  flow_head_planes_bwd<<<ufr::ceil_div(threads, 256), 256, 0, ufr::as_stream(stream)>>>(grad_y, wpk, G, chunk0, chunks, B, H, W,
+                                                                                        accumulate);
+  return ufr::launched("flow_head_planes_bwd");
+}
+
+extern "C" int ufr_flow_up_planes_forward(const float* x, const float* w, const float* bias, void* planes, long plane_stride,
+                                          int chunk, int B, int H, int W, ufr_stream_t stream) {
+  UFR_REQUIRE(x && w && planes, "flow upsample (planes) forward: null pointer");
+  UFR_REQUIRE(B > 0 && H > 0 && W > 0 && chunk >= 0, "flow upsample (planes) forward: bad shape");
+  flow_up_planes_fwd<<<ufr::stream_grid((long)B * 4 * H * W, 256), 256, 0, ufr::as_stream(stream)>>>(
+      x, w, bias, static_cast<__bf16*>(planes), plane_stride, chunk, B, H, W, bias != nullptr);
+  return ufr::launched("flow_up_planes_fwd");
+}
+
+extern "C" int ufr_flow_up_planes_backward(const float* G, int chunk, const float* w, float* grad_x, int B, int H, int W,
+                                           ufr_stream_t stream) {
+  UFR_REQUIRE(G && w && grad_x, "flow upsample (planes) backward: null pointer");
+  UFR_REQUIRE(B > 0 && H > 0 && W > 0 && chunk >= 0, "flow upsample (planes) backward: bad shape");
+  flow_up_planes_bwd<<<ufr::stream_grid((long)B * H * W, 256), 256, 0, ufr::as_stream(stream)>>>(G, chunk, w, grad_x, B, H, W);
+  return ufr::launched("flow_up_planes_bwd");
+}
