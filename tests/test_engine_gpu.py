@@ -1,0 +1,130 @@
+"""GPU suite: the native FlowNetC head (flownetc_engine.py: igemm convolutions on split planes + chunk-major 2-channel
+layers) against the torch / MIOpen spelling of the same module (models/FlowNetC.py:121-197) with the same weights."""
+from argparse import Namespace
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def net():
+    from understanding_flow_robustness_amd.flownets.utils_model import fetch_model
+    n = fetch_model(Namespace(flownet="FlowNetC"), synthetic_seed=0).to(DEV)
+    for p in n.parameters():
+        p.requires_grad_(False)
+    return n
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max()) / float(b.double().abs().max())
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 128), (1, 128, 192)])
+def test_engine_head_forward_and_gradients_match_the_torch_head(net, monkeypatch, B, H, W):
+    """Flow and the three feature gradients of the head: engine vs the torch / MIOpen spelling, both judged against a
+    float64 evaluation of the same module (the engine may be no further from it than MIOpen's fp32 path, x3)."""
+    import copy
+    g = torch.Generator().manual_seed(3)
+    feats = []
+    for shape in ((B, 128, H // 4, W // 4), (B, 256, H // 8, W // 8), (B, 256, H // 8, W // 8)):
+        feats.append(torch.randn(*shape, generator=g).mul_(0.5).to(DEV))
+    gflow = torch.randn(B, 2, H, W, generator=g).to(DEV)
+    outs = {}
+    for knob in ("0", "1"):
+        monkeypatch.setenv("UFR_ENGINE", knob)
+        leaves = [f.clone().requires_grad_(True) for f in feats]
+        flow = net.head(*leaves)
+        grads = torch.autograd.grad(flow, leaves, gflow)
+        outs[knob] = (flow.detach(), grads)
+    assert "_ufr_head_engines" in net.__dict__ and len(net.__dict__["_ufr_head_engines"]) >= 1
+    monkeypatch.setenv("UFR_ENGINE", "0")
+    net64 = copy.deepcopy(net).double()
+    net64.__dict__.pop("_ufr_head_engines", None)
+    leaves = [f.double().requires_grad_(True) for f in feats]
+    flow64 = net64.head(*leaves)
+    grads64 = torch.autograd.grad(flow64, leaves, gflow.double())
+    (f0, g0), (f1, g1) = outs["0"], outs["1"]
+    print(f"flow: engine {_rel(f1, flow64):.2e}, torch fp32 {_rel(f0, flow64):.2e} of max |flow| (vs float64)")
+    assert _rel(f1, flow64) <= max(3 * _rel(f0, flow64), 1e-5)
+    for name, a, b, truth in zip(("d/d conv2a", "d/d conv3a", "d/d conv3b"), g1, g0, grads64):
+        e_eng, e_t32 = _rel(a, truth), _rel(b, truth)
+        print(f"{name}: engine {e_eng:.2e}, torch fp32 {e_t32:.2e} of max |gradient| (vs float64)")
+        # a LeakyReLU whose pre-activation sits within rounding of zero takes the other slope in an fp32 evaluation:
+        # isolated entries of a few 1e-4, in either implementation
+        assert e_eng <= max(3 * e_t32, 5e-4), f"{name}: engine {e_eng:.2e} vs torch fp32 {e_t32:.2e}"
+        frac = float(((a.double() - truth).abs() > 1e-4 * float(truth.abs().max())).float().mean())
+        assert frac <= 1e-2, f"{name}: {frac:.2e} of the entries beyond 1e-4"
+
+
+def test_engine_whole_network_vs_reference_golden(net, monkeypatch):
+    """FlowNetC forward + image gradients through the engine against the reference's golden vectors."""
+    import numpy as np
+    from conftest import assert_close, load_golden, t
+    monkeypatch.setenv("UFR_ENGINE", "1")
+    z = load_golden("flownetc_fwd_64x128")
+    x1, x2 = t(z["x1"], DEV).requires_grad_(True), t(z["x2"], DEV).requires_grad_(True)
+    flow = net(x1, x2)
+    assert_close(flow, t(z["flow"]), rtol=1e-4, atol_scale=1e-4, what="flow")
+    loss = (1 - torch.nn.functional.cosine_similarity(flow, t(z["target"], DEV))).mean()
+    g1, g2 = torch.autograd.grad(loss, (x1, x2))
+    assert_close(g1, t(z["g1"]), rtol=1e-3, atol_scale=2e-4, what="d loss / d frame 1")
+    assert_close(g2, t(z["g2"]), rtol=1e-3, atol_scale=2e-4, what="d loss / d frame 2")
+
+
+def test_engine_attack_matches_reference_trace(net, monkeypatch):
+    """The 2-iteration attack() golden (patch_attacks/main.py:523-613 run on the reference) with the engine on."""
+    from conftest import load_golden, t
+    from understanding_flow_robustness_amd.patch_attack import attack
+    monkeypatch.setenv("UFR_ENGINE", "1")
+    from test_flow_oracle_cpu import ATTACK_CASES
+    z = load_golden("attack_flownetc_64x128")
+    for name, l2, lr in ATTACK_CASES:
+        args = Namespace(flownet="FlowNetC", l2=l2, alpha=0.0, lr=lr, max_count=2)
+        patch = t(z["patch0"], DEV).clone()
+        attack(net, t(z["tgt"], DEV), None, t(z["ref"], DEV), patch, t(z["mask"], DEV), t(z["patch0"], DEV),
+               t(z["target"], DEV), None, args=args, use_graph=(name == "cos_lr1000"))
+        ref_patch = t(z[f"{name}_it2_patch"])
+        upd = float((ref_patch - t(z["patch0"])).abs().max())
+        err = float((patch.cpu() - ref_patch).abs().max())
+        assert err <= 1e-4 * max(upd, 1.0), f"{name}: patch err {err:.3e}, update {upd:.3e}"
+
+
+def test_engine_banded_step_equals_full_frame_torch_step(net, monkeypatch):
+    """The whole windowed attack step (prefix window, column band, incremental head forward, windowed correlation adjoint)
+    at the benchmark frame size with the engine on, against the full-frame torch step: 4 pairs behind one patch."""
+    from understanding_flow_robustness_amd.patch_attack import PatchAttackStep
+    B, H, W = 4, 384, 1280
+    g = torch.Generator().manual_seed(11)
+    tgt, ref = torch.rand(B, 3, H, W, generator=g).to(DEV), torch.rand(B, 3, H, W, generator=g).to(DEV)
+    target = torch.randn(B, 2, H, W, generator=g).to(DEV)
+    yy, xx = torch.meshgrid(torch.arange(51), torch.arange(51), indexing="ij")
+    mask_p = (((yy - 25) ** 2 + (xx - 25) ** 2) <= 23 ** 2).float().expand(1, 3, 51, 51).contiguous().to(DEV)
+    patch0 = torch.rand(1, 3, 51, 51, generator=g).to(DEV)
+    placements = ([(0, 0), (333, 1229), (0, 600), (170, 640)], [(333, 0), (160, 640), (7, 1221), (100, 300)])
+
+    def run(engine, cone, lr, iters, graph):
+        monkeypatch.setenv("UFR_ENGINE", "1" if engine else "0")
+        args = Namespace(flownet="FlowNetC", l2=False, alpha=0.0, lr=lr, max_count=iters)
+        step = PatchAttackStep(net, args, B, H, W, device=DEV, patch_hw=(51, 51), use_cone=cone, use_graph=graph)
+        outs = []
+        for origins in placements:
+            step.load(tgt, ref, patch0, mask_p, patch0, target, origins=origins)
+            n, loss = step.run(iters)
+            outs.append((step.patch.clone(), n, loss))
+        return step, outs
+
+    _, probe = run(False, False, 1.0, 1, False)
+    lr = 0.5 / float((probe[0][0] - patch0).abs().max())          # first update peaks at 0.5: the +-2 clamp stays inactive
+    _, full = run(False, False, lr, 3, False)
+    step, eng = run(True, True, lr, 3, True)
+    assert step.cone is not None and step.band is not None and step.band.width == 608 and step.graph_next is not None
+    for (pf, nf, lf), (pe, ne, le) in zip(full, eng):
+        upd = float((pf - patch0).abs().max())
+        err = (pf - pe).abs()
+        off = float((err > 1e-4 * upd).float().mean())
+        print(f"engine windowed step vs full-frame torch step: worst {float(err.max()) / upd:.2e} of the update, {off:.2%} beyond 1e-4")
+        assert nf == ne and abs(lf - le) <= 1e-4 * max(abs(lf), 1.0)
+        assert off <= 0.05 and float(err.max()) <= 5e-3 * upd

@@ -203,7 +203,7 @@ def test_config_c5_flownet2_universal_step_at_448x1024(oracle):
     worst = float(grad.abs()[flipped].max()) / scale if bool(flipped.any()) else 0.0
     frac1 = float(flipped.float().mean())
     print(f"C5 step 1: {frac1:.2e} of the entries take the other sign; largest |gradient| among them {worst:.2e} of the median")
-    assert frac1 < 1.5e-2 and worst < 0.5, f"C5: {frac1:.2e} flips, up to {worst:.2e} of the median gradient"
+    assert frac1 < 2e-3 and worst < 1.0, f"C5: {frac1:.2e} flips, up to {worst:.2e} of the median gradient"
     assert float((step.delta.cpu() - want1).abs().max()) <= 2 * 2e-3 + 1e-6
     # both steps against the oracle's loop: flips of step 1 move step 2's gradient a little, nothing more
     step.load(img0.to(DEV), img1.to(DEV), delta0.to(DEV), (-clean).to(DEV))

@@ -1,0 +1,319 @@
+"""Native FlowNetC head: everything of models/FlowNetC.py:121-197 behind conv1-3 -- correlation, conv_redir, conv3_1 ...
+conv6_1, the coarse-to-fine refinement -- forward AND data gradient as an explicit schedule of hand-written gfx950
+kernels, with no torch operator between the siamese features and flow2.
+
+    convolutions / deconvolutions   csrc/igemm.hip: implicit GEMMs on bf16 split planes (float32-accurate, six products)
+    predict_flow*, upsampled_flow*  csrc/engine_small.hip (HBM-bound passes over the concatenation buffers)
+    correlation                     csrc/correlation*.hip (unchanged), cost volume converted once into conv3_1's input
+
+Activations stay in the chunk-major plane layout between layers (igemm.Planes); a `torch.cat` of the reference
+(FlowNetC.py:142, :167, :172, :177, :182) is a chunk offset into one buffer:
+
+    in31 = [conv_redir 32 | corr 441]            15 chunks @ 1/8     cat3 = [conv3_1 256 | deconv3 128 | flow4_up 2]  13 chunks @ 1/8
+    cat4 = [conv4_1 512 | deconv4 256 | up 2]    25 chunks @ 1/16    cat5 = [conv5_1 512 | deconv5 512 | up 2]        33 chunks @ 1/32
+    cat2 = [conv2 128 | deconv2 64 | up 2]        7 chunks @ 1/4
+
+The backward pass is the reverse schedule; a gradient with several consumers is summed in fp32 (igemm.GradSum) and the last
+contributing GEMM applies LeakyReLU' and writes the gradient planes of the next GEMM directly (no separate passes where a
+GEMM epilogue can do it).  Parameters are frozen: data gradients only (the reference's loss.backward() also computes
+every weight gradient, main.py:573).  All buffers are allocated once; a step is a fixed sequence of launches, so the
+attack's HIP graph captures it as is.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from . import igemm as ig
+
+_HEADS = ((6, 1024), (5, 1026), (4, 770), (3, 386), (2, 194))
+
+
+def _pack_flow_head(weight: torch.Tensor) -> torch.Tensor:
+    """Conv2d(Cin, 2, 3, 1, 1).weight [2,Cin,3,3] -> [chunks][9][2][32] float32 (csrc/engine_small.hip)."""
+    cin = weight.shape[1]
+    chunks = ig.pad32(cin) // 32
+    w = torch.zeros(2, chunks * 32, 9, dtype=torch.float32, device=weight.device)
+    w[:, :cin] = weight.detach().float().reshape(2, cin, 9)
+    return w.view(2, chunks, 32, 9).permute(1, 3, 0, 2).contiguous()
+
+
+class FlowNetCHeadEngine:
+    def __init__(self, net, B: int, H: int, W: int, device):
+        if H % 64 or W % 64:
+            raise ValueError("FlowNetC head engine: frame sides must be multiples of 64")
+        L.lib()
+        self.net, self.B, self.H, self.W, self.dev = net, int(B), int(H), int(W), torch.device(device)
+        g = {s: (H // s, W // s) for s in (4, 8, 16, 32, 64)}
+        self.grid = g
+        P = lambda s, chunks: ig.Planes(B, g[s][0], g[s][1], chunks, self.dev)
+        G = lambda s, chunks: ig.GradSum(B, g[s][0], g[s][1], chunks, self.dev)
+        # ---- activations
+        self.c3a_p = P(8, 8)
+        self.in31, self.cat3, self.cat2 = P(8, 15), P(8, 13), P(4, 7)
+        self.c4a, self.cat4 = P(16, 16), P(16, 25)
+        self.c5a, self.cat5 = P(32, 16), P(32, 33)
+        self.c6a, self.c6 = P(64, 32), P(64, 32)
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.flow = {k: torch.zeros(B, 2, *g[2 ** k], **f32) for k in (6, 5, 4, 3, 2)}
+        self.corr = torch.zeros(B, 21, 21, *g[8], **f32)
+        # ---- gradients
+        self.G_cat2, self.G_cat3, self.G_cat4, self.G_cat5 = G(4, 7), G(8, 13), G(16, 25), G(32, 33)
+        self.G_c6, self.G_in31, self.G_c3a = G(64, 32), G(8, 15), G(8, 8)
+        self.gz_cat2, self.gz_cat3, self.gz_cat4, self.gz_cat5 = P(4, 7), P(8, 13), P(16, 25), P(32, 33)
+        self.gz_c6, self.gz_c6a, self.gz_c5a, self.gz_c4a, self.gz_in31 = P(64, 32), P(64, 32), P(32, 16), P(16, 16), P(8, 15)
+        self.g_flow = {k: torch.zeros(B, 2, *g[2 ** k], **f32) for k in (6, 5, 4, 3)}
+        self.g_corr = torch.zeros(B, 21, 21, *g[8], **f32)
+        self.g_c2a = torch.zeros(B, 128, *g[4], **f32)
+        self.g_c3a, self.g_c3a_redir, self.g_c3b = (torch.zeros(B, 256, *g[8], **f32) for _ in range(3))
+        self._build_launches()
+
+    # ------------------------------------------------------------------------------------------------ set-up
+    def _conv(self, name):
+        return getattr(self.net, name)[0]
+
+    def _build_launches(self):
+        net, g, B = self.net, self.grid, self.B
+        plans = []      # (weights, make_launch kwargs without ws) -> sized together for one split-K workspace
+
+        def plan(wi, x, in_chunk0, rows, out_hw, **kw):
+            M = B * rows[0] * rows[1]
+            ktiles = max(len(t) for _, _, t in wi.phases) * wi.KC
+            S = ig.splitk_for(M, wi.Npad, ktiles, len(wi.phases))
+            plans.append((wi, x, in_chunk0, rows, out_hw, S, kw))
+            return len(plans) - 1
+
+        fwd, bwd = {}, {}
+        cw = lambda n, s, p: ig.conv_forward_weights(self._conv(n).weight, s, p)
+        cb = lambda n, s, p: ig.conv_backward_weights(self._conv(n).weight, s, p)
+        bias = lambda n: self._conv(n).bias.detach().float().contiguous()
+        # forward chain (FlowNetC.py:142-160)
+        fwd["conv_redir"] = plan(cw("conv_redir", 1, 0), self.c3a_p, 0, g[8], g[8], out_planes=self.in31, out_chunk0=0, bias=bias("conv_redir"))
+        fwd["conv3_1"] = plan(cw("conv3_1", 1, 1), self.in31, 0, g[8], g[8], out_planes=self.cat3, out_chunk0=0, bias=bias("conv3_1"))
+        fwd["conv4"] = plan(cw("conv4", 2, 1), self.cat3, 0, g[16], g[16], out_planes=self.c4a, bias=bias("conv4"))
+        fwd["conv4_1"] = plan(cw("conv4_1", 1, 1), self.c4a, 0, g[16], g[16], out_planes=self.cat4, out_chunk0=0, bias=bias("conv4_1"))
+        fwd["conv5"] = plan(cw("conv5", 2, 1), self.cat4, 0, g[32], g[32], out_planes=self.c5a, bias=bias("conv5"))
+        fwd["conv5_1"] = plan(cw("conv5_1", 1, 1), self.c5a, 0, g[32], g[32], out_planes=self.cat5, out_chunk0=0, bias=bias("conv5_1"))
+        fwd["conv6"] = plan(cw("conv6", 2, 1), self.cat5, 0, g[64], g[64], out_planes=self.c6a, bias=bias("conv6"))
+        fwd["conv6_1"] = plan(cw("conv6_1", 1, 1), self.c6a, 0, g[64], g[64], out_planes=self.c6, bias=bias("conv6_1"))
+        # refinement (FlowNetC.py:162-183): deconvK reads the level above, writes the middle segment of catK
+        dec = {5: (self.c6, 64, self.cat5, 16), 4: (self.cat5, 32, self.cat4, 16), 3: (self.cat4, 16, self.cat3, 8),
+               2: (self.cat3, 8, self.cat2, 4)}
+        for k, (src, s_in, dst, chunk0) in dec.items():
+            n = f"deconv{k}"
+            fwd[n] = plan(ig.deconv_forward_weights(self._conv(n).weight, 1), src, 0, g[s_in], g[s_in // 2], out_planes=dst,
+                          out_chunk0=chunk0, bias=bias(n))
+        # backward (reverse order of use; see module docstring)
+        gz = {5: (self.gz_cat5, 16, 16), 4: (self.gz_cat4, 16, 8), 3: (self.gz_cat3, 8, 4), 2: (self.gz_cat2, 4, 2)}
+        Gabove = {2: self.G_cat3, 3: self.G_cat4, 4: self.G_cat5}
+        for k in (2, 3, 4):
+            src, chunk0, _ = gz[k]
+            s_in = {2: 8, 3: 16, 4: 32}[k]
+            bwd[f"deconv{k}"] = plan(ig.deconv_backward_weights(self._conv(f"deconv{k}").weight, 1), src, chunk0, g[s_in], g[s_in],
+                                     out_f32=Gabove[k])
+        bwd["deconv5"] = plan(ig.deconv_backward_weights(self._conv("deconv5").weight, 1), self.gz_cat5, 16, g[64], g[64],
+                              add=self.G_c6, mask=self.c6, out_planes=self.gz_c6)
+        bwd["conv6_1"] = plan(cb("conv6_1", 1, 1), self.gz_c6, 0, g[64], g[64], mask=self.c6a, out_planes=self.gz_c6a)
+        bwd["conv6"] = plan(cb("conv6", 2, 1), self.gz_c6a, 0, g[64], g[32], add=self.G_cat5, mask=self.cat5, out_planes=self.gz_cat5)
+        bwd["conv5_1"] = plan(cb("conv5_1", 1, 1), self.gz_cat5, 0, g[32], g[32], mask=self.c5a, out_planes=self.gz_c5a)
+        bwd["conv5"] = plan(cb("conv5", 2, 1), self.gz_c5a, 0, g[32], g[16], add=self.G_cat4, mask=self.cat4, out_planes=self.gz_cat4)
+        bwd["conv4_1"] = plan(cb("conv4_1", 1, 1), self.gz_cat4, 0, g[16], g[16], mask=self.c4a, out_planes=self.gz_c4a)
+        bwd["conv4"] = plan(cb("conv4", 2, 1), self.gz_c4a, 0, g[16], g[8], add=self.G_cat3, mask=self.cat3, out_planes=self.gz_cat3)
+        bwd["conv3_1"] = plan(cb("conv3_1", 1, 1), self.gz_cat3, 0, g[8], g[8], mask=self.in31, out_planes=self.gz_in31,
+                              out_f32=self.G_in31)
+        bwd["conv_redir"] = plan(cb("conv_redir", 1, 0), self.gz_in31, 0, g[8], g[8], out_f32=self.G_c3a)
+        need = max([len(wi.phases) * S * B * rows[0] * rows[1] * wi.Npad for wi, _, _, rows, _, S, _ in plans if S > 1] + [1])
+        self.ws = torch.empty(need, dtype=torch.float32, device=self.dev)
+        launches = [ig.make_launch(wi, x, c0, rows, out_hw, splitk=S, ws=self.ws if S > 1 else None, **kw)
+                    for wi, x, c0, rows, out_hw, S, kw in plans]
+        self.fwd = {k: launches[i] for k, i in fwd.items()}
+        self.bwd = {k: launches[i] for k, i in bwd.items()}
+        self._plans = {("fwd", k): plans[i] for k, i in fwd.items()}
+        self._plans.update({("bwd", k): plans[i] for k, i in bwd.items()})
+        self._band, self.fwd_band, self.bwd_band = None, {}, {}
+        # 2-channel layers
+        self.pf_w = {k: _pack_flow_head(getattr(net, f"predict_flow{k}").weight) for k, _ in _HEADS}
+        self.pf_b = {k: getattr(net, f"predict_flow{k}").bias.detach().float().contiguous() for k, _ in _HEADS}
+        self.up = {k: getattr(net, f"upsampled_flow{k}_to_{k - 1}") for k in (6, 5, 4, 3)}
+        self.up_w = {k: m.weight.detach().float().contiguous() for k, m in self.up.items()}
+        self.up_b = {k: (m.bias.detach().float().contiguous() if m.bias is not None else None) for k, m in self.up.items()}
+        self.pf_src = {6: (self.c6, 32), 5: (self.cat5, 33), 4: (self.cat4, 25), 3: (self.cat3, 13), 2: (self.cat2, 7)}
+        self.pf_G = {6: self.G_c6, 5: self.G_cat5, 4: self.G_cat4, 3: self.G_cat3, 2: self.G_cat2}
+        # upsampled_flowK_to_K-1 writes the last chunk of cat(K-1)
+        self.up_dst = {6: (self.cat5, 32), 5: (self.cat4, 24), 4: (self.cat3, 12), 3: (self.cat2, 6)}
+        self.up_G = {6: (self.G_cat5, 32), 5: (self.G_cat4, 24), 4: (self.G_cat3, 12), 3: (self.G_cat2, 6)}
+
+    # ------------------------------------------------------------------------------------------------ column band
+    # (level stride of the ROW grid, of the input grid) of the launches that run on the band's columns only
+    _FWD_BAND = {"conv_redir": (8, 8), "conv3_1": (8, 8), "conv4": (16, 8), "conv4_1": (16, 16)}
+    # data gradients on the band (band_conv.py's BAND_LAYERS): rows = the gy grid; the input (a gradient that itself exists
+    # on the band only) reads as zero outside it
+    _BWD_BAND = {"conv5": (32, None), "conv4_1": (16, 16), "conv4": (16, 16), "conv3_1": (8, 8), "conv_redir": (8, 8)}
+
+    def attach_band(self, band):
+        """Derive the banded launches for `band` (band_conv.Band: device-resident first column per pair, static width):
+        the same descriptors with the tile rows restricted to the band -- taps read the full-frame planes, so there is no
+        gather / scatter copy and every computed column is exact."""
+        if self._band is band:
+            return
+        self._band, self.fwd_band, self.bwd_band = band, {}, {}
+        if not band.width:
+            return
+        W = self.W
+        if band.width % 32 or band.width > W:
+            raise ValueError("band width must be a multiple of 32 pixels inside the frame")
+        origin = band.win[:, 1]                                   # int32 view, 8 elements per pair
+
+        def derive(kind, name, ls_rows, ls_in):
+            wi, x, c0, rows, out_hw, S, kw = self._plans[(kind, name)]
+            rows_b = (rows[0], band.width // ls_rows)
+            extra = dict(row_band=(origin, 8, ls_rows))
+            if ls_in is not None:
+                extra["in_band"] = (origin, 8, ls_in, band.width // ls_in)
+            M = self.B * rows_b[0] * rows_b[1]
+            ktiles = max(len(t) for _, _, t in wi.phases) * wi.KC
+            Sb = ig.splitk_for(M, wi.Npad, ktiles, len(wi.phases))
+            if len(wi.phases) * Sb * M * wi.Npad > self.ws.numel():
+                Sb = 1
+            return ig.make_launch(wi, x, c0, rows_b, out_hw, splitk=Sb, ws=self.ws if Sb > 1 else None, **kw, **extra)
+
+        for name, (ls_rows, _) in self._FWD_BAND.items():
+            self.fwd_band[name] = derive("fwd", name, ls_rows, None)       # forward inputs are valid everywhere
+        for name, (ls_rows, ls_in) in self._BWD_BAND.items():
+            self.bwd_band[name] = derive("bwd", name, ls_rows, ls_in)
+
+    # ------------------------------------------------------------------------------------------------ small launches
+    def _pf_forward(self, k):
+        src, chunks = self.pf_src[k]
+        L.check(L.lib().ufr_flow_head_planes_forward(L.ptr(src.t), src.plane_stride, 0, chunks, L.ptr(self.pf_w[k]),
+                                                     L.ptr(self.pf_b[k]), L.ptr(self.flow[k]), self.B, src.H, src.W,
+                                                     L.stream()), "predict_flow forward")
+
+    def _pf_backward(self, k, gy, accumulate):
+        src, chunks = self.pf_src[k]
+        L.check(L.lib().ufr_flow_head_planes_backward(L.ptr(gy), L.ptr(self.pf_w[k]), L.ptr(self.pf_G[k].t), 0, chunks, self.B,
+                                                      src.H, src.W, int(accumulate), L.stream()), "predict_flow backward")
+
+    def _up_forward(self, k):
+        dst, chunk = self.up_dst[k]
+        f = self.flow[k]
+        L.check(L.lib().ufr_flow_up_planes_forward(L.ptr(f), L.ptr(self.up_w[k]), L.ptr(self.up_b[k]) if self.up_b[k] is not None else None,
+                                                   L.ptr(dst.t), dst.plane_stride, chunk, self.B, f.shape[2], f.shape[3],
+                                                   L.stream()), "upsampled_flow forward")
+
+    def _up_backward(self, k):
+        G, chunk = self.up_G[k]
+        f = self.g_flow[k]
+        L.check(L.lib().ufr_flow_up_planes_backward(L.ptr(G.t), chunk, L.ptr(self.up_w[k]), L.ptr(f), self.B, f.shape[2],
+                                                    f.shape[3], L.stream()), "upsampled_flow backward")
+
+    def _finalize(self, Gs, mask, out, chunk0, chunks):
+        L.check(L.lib().ufr_grad_finalize(L.ptr(Gs.t), chunk0, L.ptr(mask.t), chunk0, L.ptr(out.t), out.plane_stride, chunk0,
+                                          Gs.M, chunks, ig.LEAKY, L.stream()), "gradient finalize")
+
+    # ------------------------------------------------------------------------------------------------ the schedule
+    def forward(self, c2a: torch.Tensor, c3a: torch.Tensor, c3b: torch.Tensor, band=None) -> torch.Tensor:
+        """(conv2 of frame 1 [B,128,H/4,W/4], conv3 of both frames [B,256,H/8,W/8]) -> flow2 [B,2,H/4,W/4].
+        `band` (band_conv.Band) with `incremental` set: the features differ from the previous call's only inside the
+        prefix window, so conv_redir / conv3_1 / conv4 / conv4_1 recompute the band's columns only -- the plane buffers
+        still hold the previous iteration's activations everywhere else."""
+        from . import spatial_correlation_sampler_backend as correlation
+        import ctypes as C
+        for t, name in ((c2a, "c2a"), (c3a, "c3a"), (c3b, "c3b")):
+            L.require_hip(t, name)
+        self._c3a, self._c3b = c3a, c3b
+        inc = False
+        if band is not None:
+            self.attach_band(band)
+            inc = bool(band.width and band.incremental and band.inc_layers)
+        self.cat2.load_nchw(c2a, 0)
+        self.c3a_p.load_nchw(c3a, 0)
+        # submodules.py:124-138 (`correlate`: /C) + FlowNetC.py:139 LeakyReLU fused into the correlation's epilogue
+        p = correlation._params(1, 1, 21, 21, 0, 0, 1, 1, 2, 2, 1, 1)
+        L.check(L.lib().ufr_corr_forward_fused(L.ptr(c3a), L.ptr(c3b), L.ptr(self.corr), L.UFR_F32, self.B, 256, *self.grid[8],
+                                               C.byref(p), 1.0 / 256.0, ig.LEAKY, L.stream()), "correlation forward")
+        self.in31.load_nchw(self.corr.view(self.B, 441, *self.grid[8]), 1)
+        for name in ("conv_redir", "conv3_1", "conv4", "conv4_1"):
+            (self.fwd_band if inc else self.fwd)[name]()
+        for name in ("conv5", "conv5_1", "conv6", "conv6_1"):
+            self.fwd[name]()
+        self._pf_forward(6)
+        for k in (5, 4, 3, 2):
+            self._up_forward(k + 1)
+            self.fwd[f"deconv{k}"]()
+            self._pf_forward(k)
+        return self.flow[2]
+
+    def backward(self, g_flow2: torch.Tensor, band=None):
+        """d loss / d flow2 -> (d/d conv2a, d/d conv3a, d/d conv3b), all NCHW float32 (static buffers).
+        With a band: the data gradients of conv5, conv4_1, conv4, conv3_1 and conv_redir run on the band's columns and the
+        correlation's adjoint on the window's cells (only those are read behind a windowed prefix)."""
+        L.require_hip(g_flow2, "g_flow2")
+        B = self.B
+        banded = band is not None and bool(band.width)
+        if band is not None:
+            self.attach_band(band)
+        # level 2: predict_flow2 -> gradient of cat2 = [conv2a | deconv2 | flow3_up]
+        self._pf_backward(2, g_flow2, accumulate=False)
+        self.G_cat2.to_nchw(128, 0, out=self.g_c2a)
+        gz = {2: (self.G_cat2, self.cat2, self.gz_cat2, 4, 2), 3: (self.G_cat3, self.cat3, self.gz_cat3, 8, 4),
+              4: (self.G_cat4, self.cat4, self.gz_cat4, 16, 8), 5: (self.G_cat5, self.cat5, self.gz_cat5, 16, 16)}
+        for k in (2, 3, 4):
+            Gs, act, out, chunk0, chunks = gz[k]
+            self._finalize(Gs, act, out, chunk0, chunks)          # LeakyReLU' of deconvK's output
+            self._up_backward(k + 1)                               # -> d/d flow(K+1)
+            self.bwd[f"deconv{k}"]()                               # writes the gradient sum of cat(K+1)
+            self._pf_backward(k + 1, self.g_flow[k + 1], accumulate=True)
+        Gs, act, out, chunk0, chunks = gz[5]
+        self._finalize(Gs, act, out, chunk0, chunks)
+        self._up_backward(6)
+        self._pf_backward(6, self.g_flow[6], accumulate=False)      # G_c6 = predict_flow6^T; deconv5's adjoint adds to it
+        for name in ("deconv5", "conv6_1", "conv6", "conv5_1"):
+            self.bwd[name]()
+        for name in ("conv5", "conv4_1", "conv4", "conv3_1", "conv_redir"):
+            (self.bwd_band if banded else self.bwd)[name]()
+        # conv_redir's input and the correlation's two inputs
+        self.G_c3a.to_nchw(256, 0, out=self.g_c3a_redir)
+        self.G_in31.to_nchw(441, 1, scale=1.0 / 256.0, out=self.g_corr.view(B, 441, *self.grid[8]))
+        self._corr_backward(self.g_corr, band)
+        return self.g_c2a, self.g_c3a, self.g_c3b
+
+    def _corr_backward(self, g_corr, band):
+        from . import spatial_correlation_sampler_backend as correlation
+        import ctypes as C
+        h8, w8 = self.grid[8]
+        if band is not None and band.cone_win is not None:
+            L.check(L.lib().ufr_corr_backward_window(L.ptr(self._c3a), L.ptr(self._c3b), L.ptr(g_corr), L.ptr(self.g_c3a),
+                                                     L.ptr(self.g_c3b), self.B, 256, h8, w8, 21, 2, L.ptr(band.cone_win), 8,
+                                                     band.cone_hw[0] // 8, band.cone_hw[1] // 8, L.stream()),
+                    "correlation backward (window)")
+        else:
+            p = correlation._params(1, 1, 21, 21, 0, 0, 1, 1, 2, 2, 1, 1)
+            L.check(L.lib().ufr_corr_backward(L.ptr(self._c3a), L.ptr(self._c3b), L.ptr(g_corr), L.ptr(self.g_c3a),
+                                              L.ptr(self.g_c3b), L.UFR_F32, self.B, 256, h8, w8, C.byref(p), L.stream()),
+                    "correlation backward")
+        self.g_c3a.add_(self.g_c3a_redir)
+
+
+class _EngineHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, c2a, c3a, c3b, engine, band):
+        ctx.engine, ctx.band = engine, band
+        # the engine's flow2 is a static buffer: hand autograd its own (2-channel, tiny) tensor
+        return engine.forward(c2a.contiguous(), c3a.contiguous(), c3b.contiguous(), band).clone()
+
+    @staticmethod
+    def backward(ctx, g_flow2):
+        g2a, g3a, g3b = ctx.engine.backward(g_flow2.contiguous(), ctx.band)
+        return g2a, g3a, g3b, None, None
+
+
+def engine_head(net, c2a, c3a, c3b, band=None):
+    """flow2 of FlowNetC's head on the native engine (one engine per batch / frame size, cached on the module)."""
+    B, _, h4, w4 = c2a.shape
+    key = (B, h4 * 4, w4 * 4, str(c2a.device))
+    cache = net.__dict__.setdefault("_ufr_head_engines", {})
+    eng = cache.get(key)
+    if eng is None:
+        eng = cache[key] = FlowNetCHeadEngine(net, B, h4 * 4, w4 * 4, c2a.device)
+    return _EngineHead.apply(c2a, c3a, c3b, eng, band)

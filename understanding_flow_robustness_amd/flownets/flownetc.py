@@ -129,7 +129,21 @@ class FlowNetC(nn.Module):
         feats = [c1[:B], c2a, c3a, c1[B:], c2[B:], c3b] if self.return_feat_maps else None
         return self._rest(c2a, c3a, c3b, feats)
 
+    def _engine_ok(self, c2a, feats, band):
+        """The native head (flownetc_engine.py) serves the attack's configuration: frozen parameters, eval mode, HIP
+        float32 features, frame sides that are multiples of 64."""
+        import os
+        if os.environ.get("UFR_ENGINE", "0") != "1" or feats is not None or self.training:
+            return False
+        frozen = not any(p.requires_grad for p in self.parameters())
+        return (c2a.is_cuda and c2a.dtype == torch.float32 and (frozen or not torch.is_grad_enabled())
+                and c2a.shape[2] % 16 == 0 and c2a.shape[3] % 16 == 0)
+
     def _rest(self, c2a, c3a, c3b, feats, band=None):
+        if self._engine_ok(c2a, feats, band):
+            from ..flownetc_engine import engine_head
+            flow2 = engine_head(self, c2a, c3a, c3b, band)
+            return F.interpolate(flow2 * self.div_flow, scale_factor=4, mode="bilinear", align_corners=False)
         out_corr = correlate(c3a.contiguous(), c3b.contiguous(), band=band)
         if feats is not None:
             feats.append(out_corr.clone())
