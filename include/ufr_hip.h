@@ -393,7 +393,8 @@ int ufr_host_png_unfilter(const unsigned char* data, unsigned char* out, int row
  * (models/submodules.py:18-46 `conv`, :75-82 `deconv`) that torch runs on MIOpen -- forward AND data gradient -- without
  * the activations leaving the device layout between layers.
  *   activation planes: bf16 [3][chunks][M][32], M = B*H*W pixels, 32 channels per chunk (v = p0 + p1 + p2 exactly);
- *   weights:           bf16 [3][taps*KC][Npad][32] per phase, pre-split; Npad a multiple of 128;
+ *   weights:           bf16 [3][taps*KC][Npad][32] per phase, pre-split; Npad a multiple of 64 (128-column tiles when it is
+ *                      a multiple of 128, 64-column tiles otherwise);
  *   gradient sums:     f32 [chunks][M][32].
  * The tile rows are the cells (b, y, x) of a row grid [B,Hr,Wr] (x offset per sample by row_x0[b*row_x0_stride] /
  * row_x0_div when row_x0 != NULL: a column band around the patch); tap t of phase z reads input pixel

@@ -41,8 +41,9 @@ def test_engine_head_forward_and_gradients_match_the_torch_head(net, monkeypatch
         outs[knob] = (flow.detach(), grads)
     assert "_ufr_head_engines" in net.__dict__ and len(net.__dict__["_ufr_head_engines"]) >= 1
     monkeypatch.setenv("UFR_ENGINE", "0")
+    engines = net.__dict__.pop("_ufr_head_engines")              # ctypes descriptors: not copyable
     net64 = copy.deepcopy(net).double()
-    net64.__dict__.pop("_ufr_head_engines", None)
+    net.__dict__["_ufr_head_engines"] = engines
     leaves = [f.double().requires_grad_(True) for f in feats]
     flow64 = net64.head(*leaves)
     grads64 = torch.autograd.grad(flow64, leaves, gflow.double())

@@ -111,20 +111,29 @@ struct Args {
   Phase ph[4];
 };
 
-template <int NPROD>
+// Tile BM x BN_ per workgroup of four waves: BN_ = 128 -> waves 2 x 2, 64 x 64 each (4 x 4 accumulators);
+// BN_ = 64 (layers with <= 64 output channels: deconv2) -> waves 4 x 1, 32 x 64 each (2 x 4 accumulators).
+// K tiles run tap-major; the staging addresses advance incrementally (a pointer bump per tile, the bounds tests and pixel
+// offsets once per tap) so that the loop body is loads, LDS traffic and MFMAs only.
+template <int NPROD, int BN_>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm_kernel(const Args a) {
   constexpr int NPL = NPROD == 1 ? 1 : (NPROD == 3 ? 2 : 3);
   constexpr int FIRST = 6 - NPROD;
-  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * NPL][BM * BK];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
-  const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
+  constexpr int MT = BN_ == 128 ? 4 : 2;             // 16-row accumulator blocks per wave
+  constexpr int BPT = BN_ / 64;                      // weight pieces per thread and plane
+  __shared__ __attribute__((aligned(16))) __bf16 ldsA[NPL][BM * BK];
+  __shared__ __attribute__((aligned(16))) __bf16 ldsB[NPL][BN_ * BK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wrow = BN_ == 128 ? (wave >> 1) * 64 : wave * 32, wcol = BN_ == 128 ? (wave & 1) * 64 : 0;
+  const int bm = blockIdx.y * BM, bn = blockIdx.x * BN_;
   const int z = blockIdx.z, phase = z / a.splitk, ks = z - phase * a.splitk;
   const Phase& ph = a.ph[phase];
   const int KC = a.KC, KT = ph.ntaps * KC;
   const int per = (KT + a.splitk - 1) / a.splitk, kt0 = ks * per, kt1 = min(KT, kt0 + per);
   const long Min = (long)a.g.B * a.Hi * a.Wi;
+  const long cstride = Min * 32;                     // elements between consecutive channel chunks of the input
 
-  // staging: 512 16-byte pieces per image, two rows per thread
+  // staging: 512 16-byte pieces per activation image, two rows per thread
   const int srow0 = tid >> 2, sch = tid & 3;
   int yb[2], xb[2], xlo[2], xhi[2];
   long ibase[2];
@@ -143,89 +152,116 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     xhi[i] = a.in_x0 ? min(a.Wi, xlo[i] + a.in_xw) : a.Wi;
     xlo[i] = max(xlo[i], 0);
   }
-  u32x4 sa[NPL][2], sb[NPL][2];
-  const __bf16* gx = a.x + (long)a.in_chunk0 * Min * 32 + sch * 8;
-  const __bf16* gw = a.w + ph.w_off + (long)(bn + srow0) * BK + sch * 8;
+  u32x4 sa[NPL][2], sb[NPL][BPT];
+  const __bf16* gx = a.x + (long)a.in_chunk0 * cstride + sch * 8;
   const int soff0 = srow0 * BK + ((sch ^ ((srow0 >> 1) & 3)) << 3);
-#define UFR_IG_LOAD(kt)                                                                                     \
-  {                                                                                                         \
-    const int tap = (kt) / KC, kc = (kt) - tap * KC, dyo = ph.dy[tap], dxo = ph.dx[tap];                     \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                         \
-      const int yi = yb[i] + dyo, xi = xb[i] + dxo;                                                         \
-      const bool ok = (unsigned)yi < (unsigned)a.Hi && xi >= xlo[i] && xi < xhi[i];                          \
-      const __bf16* src = gx + ((long)kc * Min + (ok ? ibase[i] + (long)yi * a.Wi + xi : 0)) * 32;           \
-      _Pragma("unroll") for (int p = 0; p < NPL; ++p) {                                                     \
-        const u32x4 v = *reinterpret_cast<const u32x4*>(src + p * a.x_plane_stride);                        \
-        sa[p][i] = ok ? v : u32x4{0u, 0u, 0u, 0u};                                                          \
-        sb[p][i] = *reinterpret_cast<const u32x4*>(gw + p * a.w_plane_stride + ((long)(kt) * a.Npad + 64 * i) * BK); \
-      }                                                                                                     \
-    }                                                                                                       \
-  }
-#define UFR_IG_STORE()                                                                              \
-  _Pragma("unroll") for (int p = 0; p < NPL; ++p) _Pragma("unroll") for (int i = 0; i < 2; ++i) {   \
-    *reinterpret_cast<u32x4*>(&lds[p][soff0 + 64 * i * BK]) = sa[p][i];                             \
-    *reinterpret_cast<u32x4*>(&lds[NPL + p][soff0 + 64 * i * BK]) = sb[p][i];                       \
-  }
-
-  f32x4 acc[4][4];
+  // running state of the K loop
+  int tap = kt0 / KC, kc = kt0 - tap * KC;
+  const __bf16* wp = a.w + ph.w_off + ((long)kt0 * a.Npad + bn + srow0) * BK + sch * 8;
+  const long wstep = (long)a.Npad * BK;
+  const __bf16* xk = gx + (long)kc * cstride;
+  bool ok[2];
+  long aoff[2];
+  auto set_tap = [&](int t) {
+    const int dyo = ph.dy[t], dxo = ph.dx[t];
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+    for (int i = 0; i < 2; ++i) {
+      const int yi = yb[i] + dyo, xi = xb[i] + dxo;
+      ok[i] = (unsigned)yi < (unsigned)a.Hi && xi >= xlo[i] && xi < xhi[i];
+      aoff[i] = ok[i] ? (ibase[i] + (long)yi * a.Wi + xi) * 32 : 0;
+    }
+  };
+  auto load_tile = [&]() {           // loads K tile (tap, kc) into registers and advances the state
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(xk + aoff[i] + p * a.x_plane_stride);
+        sa[p][i] = ok[i] ? v : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BPT; ++i)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) sb[p][i] = *reinterpret_cast<const u32x4*>(wp + p * a.w_plane_stride + (long)(64 * i) * BK);
+    wp += wstep;
+    xk += cstride;
+    if (++kc == KC) {
+      kc = 0;
+      xk = gx;
+      if (++tap < ph.ntaps) set_tap(tap);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(&ldsA[p][soff0 + 64 * i * BK]) = sa[p][i];
+#pragma unroll
+      for (int i = 0; i < BPT; ++i) *reinterpret_cast<u32x4*>(&ldsB[p][soff0 + 64 * i * BK]) = sb[p][i];
+    }
+  };
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int frow = lane & 15;
   const int foff = frow * BK + ((((lane >> 4)) ^ ((frow >> 1) & 3)) << 3);
 
-  if (kt0 < kt1) UFR_IG_LOAD(kt0)
+  if (kt0 < kt1) {
+    set_tap(tap);
+    load_tile();
+  }
   for (int kt = kt0; kt < kt1; ++kt) {
     __syncthreads();
-    UFR_IG_STORE()
+    store_tile();
     __syncthreads();
-    if (kt + 1 < kt1) UFR_IG_LOAD(kt + 1)
-    bf16x8 fa[NPL][4];
+    if (kt + 1 < kt1) load_tile();
+    bf16x8 fa[NPL][MT];
 #pragma unroll
     for (int p = 0; p < NPL; ++p)
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
-        fa[p][m] = *reinterpret_cast<const bf16x8*>(&lds[p][(wr * 64 + m * 16) * BK + foff]);
+      for (int m = 0; m < MT; ++m)
+        fa[p][m] = *reinterpret_cast<const bf16x8*>(&ldsA[p][(wrow + m * 16) * BK + foff]);
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
       bf16x8 fb[NPL];
 #pragma unroll
-      for (int p = 0; p < NPL; ++p) fb[p] = *reinterpret_cast<const bf16x8*>(&lds[NPL + p][(wc * 64 + n * 16) * BK + foff]);
+      for (int p = 0; p < NPL; ++p) fb[p] = *reinterpret_cast<const bf16x8*>(&ldsB[p][(wcol + n * 16) * BK + foff]);
 #pragma unroll
       for (int t = FIRST; t < 6; ++t)
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < MT; ++m)
           acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[t]][m], fb[PROD_B[t]], acc[m][n], 0, 0, 0);
     }
   }
-#undef UFR_IG_LOAD
-#undef UFR_IG_STORE
 
   // C/D layout of the 16x16 forms: col = lane & 15, row = (lane >> 4) * 4 + reg
   if (a.splitk > 1) {
     float* slab = a.ws + (long)z * a.g.M * a.Npad;
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int row = bm + wr * 64 + m * 16 + (lane >> 4) * 4 + j;
+        const int row = bm + wrow + m * 16 + (lane >> 4) * 4 + j;
         if (row < a.g.M) {
 #pragma unroll
-          for (int n = 0; n < 4; ++n) slab[(long)row * a.Npad + bn + wc * 64 + n * 16 + (lane & 15)] = acc[m][n][j];
+          for (int n = 0; n < 4; ++n) slab[(long)row * a.Npad + bn + wcol + n * 16 + (lane & 15)] = acc[m][n][j];
         }
       }
     return;
   }
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int row = bm + wr * 64 + m * 16 + (lane >> 4) * 4 + j;
+      const int row = bm + wrow + m * 16 + (lane >> 4) * 4 + j;
       if (row < a.g.M) {
         const long pout = out_pixel(a.g, row, ph.oy0, ph.ox0);
 #pragma unroll
-        for (int n = 0; n < 4; ++n) epilogue_store(a.e, pout, bn + wc * 64 + n * 16 + (lane & 15), acc[m][n][j]);
+        for (int n = 0; n < 4; ++n) epilogue_store(a.e, pout, bn + wcol + n * 16 + (lane & 15), acc[m][n][j]);
       }
     }
 }
@@ -359,7 +395,7 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   UFR_REQUIRE(d, "igemm: null descriptor");
   UFR_REQUIRE(d->x && d->w, "igemm: null operand");
   UFR_REQUIRE(d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Hr > 0 && d->Wr > 0 && d->Ho > 0 && d->Wo > 0, "igemm: bad grid");
-  UFR_REQUIRE(d->KC > 0 && d->in_chunk0 >= 0 && d->N > 0 && d->Npad % BN == 0 && d->Npad >= d->N, "igemm: bad channel counts");
+  UFR_REQUIRE(d->KC > 0 && d->in_chunk0 >= 0 && d->N > 0 && d->Npad % 64 == 0 && d->Npad >= d->N, "igemm: bad channel counts");
   UFR_REQUIRE(d->in_sy > 0 && d->in_sx > 0 && d->out_sy > 0 && d->out_sx > 0, "igemm: bad strides");
   UFR_REQUIRE(d->nphase >= 1 && d->nphase <= 4 && d->splitk >= 1 && d->splitk <= 64, "igemm: bad phase / split count");
   UFR_REQUIRE(d->products == 6 || d->products == 3 || d->products == 1, "igemm: products must be 6, 3 or 1");
@@ -402,10 +438,16 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
     }
   }
   hipStream_t st = ufr::as_stream(stream);
-  const dim3 grid(d->Npad / BN, (unsigned)((M + BM - 1) / BM), d->nphase * d->splitk);
-  if (d->products == 6) igemm_kernel<6><<<grid, 256, 0, st>>>(a);
-  else if (d->products == 3) igemm_kernel<3><<<grid, 256, 0, st>>>(a);
-  else igemm_kernel<1><<<grid, 256, 0, st>>>(a);
+  const int bn = d->Npad % BN == 0 ? BN : 64;        // 64-column tiles where a 128-column tile would be mostly padding
+  const dim3 grid(d->Npad / bn, (unsigned)((M + BM - 1) / BM), d->nphase * d->splitk);
+  if (bn == BN) {
+    if (d->products == 6) igemm_kernel<6, 128><<<grid, 256, 0, st>>>(a);
+    else if (d->products == 3) igemm_kernel<3, 128><<<grid, 256, 0, st>>>(a);
+    else igemm_kernel<1, 128><<<grid, 256, 0, st>>>(a);
+  } else {
+    UFR_REQUIRE(d->products == 6, "igemm: 64-column tiles are built for six products only");
+    igemm_kernel<6, 64><<<grid, 256, 0, st>>>(a);
+  }
   int rc = ufr::launched("igemm_kernel");
   if (rc != UFR_OK || d->splitk == 1) return rc;
   const long total = (long)d->nphase * M * d->Npad;
