@@ -1,0 +1,3 @@
+"""Top-level name the reference imports (see dropin/README.md): re-export of understanding_flow_robustness_amd.resample2d_cuda."""
+from understanding_flow_robustness_amd.resample2d_cuda import *  # noqa: F401,F403
+from understanding_flow_robustness_amd.resample2d_cuda import backward, forward  # noqa: F401
