@@ -186,35 +186,33 @@ def test_config_c5_flownet2_universal_step_at_448x1024(oracle):
     with torch.no_grad():
         gpu_clean = net(img0.to(DEV), img1.to(DEV)).cpu()
     assert_close(gpu_clean, clean, rtol=REL, atol_scale=REL, what="FlowNet2 448x1024 clean flow")
-    # step 1 against the oracle's gradient: sign() is index-like, so the update must agree wherever the gradient is
-    # clearly non-zero.  FlowNet2's image gradient runs through four floor() warps (resample2d_kernel.cu:45-52) and is
-    # piecewise: two fp32 evaluations differ by ~1e-2 of its scale (see test_flownet2_vs_reference_wiring), so entries
-    # whose gradient is below that level may take the other sign.
-    adv0 = torch.clamp(img0 + delta0[0], 0, 1).requires_grad_(True)
-    adv1 = torch.clamp(img1 + delta0[1], 0, 1).requires_grad_(True)
-    loss = fo.compute_flow_loss(predict(adv0, adv1), -clean, "cossim")
-    g0, g1 = torch.autograd.grad(loss, (adv0, adv1))
-    grad = torch.stack((g0[0], g1[0]))
-    want1 = torch.clamp(delta0 - 2e-3 * torch.sign(grad), -0.02, 0.02)
+    # every step against the oracle's gradient AT THE PRODUCT'S OWN STATE (sign() is index-like, so the update must agree
+    # wherever the gradient is clearly non-zero; the free-running two-step comparison is printed only: a handful of
+    # first-step flips moves the second step's piecewise gradient, see below).  FlowNet2's image gradient runs through
+    # four floor() warps (resample2d_kernel.cu:45-52): two fp32 evaluations differ by ~1e-2 of its scale
+    # (test_flownet2_vs_reference_wiring), so entries whose gradient is below that level may take the other sign.
     step.load(img0.to(DEV), img1.to(DEV), delta0.to(DEV), (-clean).to(DEV))
-    step.run(1)
-    flipped = (step.delta.cpu() - want1).abs() > 1e-6
-    scale = float(grad.abs().median())
-    frac1 = float(flipped.float().mean())
-    strong = float((flipped & (grad.abs() > scale)).float().mean())
-    print(f"C5 step 1: {frac1:.2e} of the entries take the other sign, {strong:.2e} of them with a gradient above the median")
-    assert frac1 < 2e-3 and strong < 2e-4, f"C5: {frac1:.2e} flips, {strong:.2e} on gradients above the median"
-    assert float((step.delta.cpu() - want1).abs().max()) <= 2 * 2e-3 + 1e-6
-    # both steps against the oracle's loop: flips of step 1 move step 2's gradient a little, nothing more
-    step.load(img0.to(DEV), img1.to(DEV), delta0.to(DEV), (-clean).to(DEV))
-    step.run(n_step)
+    state = delta0.clone()
+    for it in range(n_step):
+        adv0 = torch.clamp(img0 + state[0], 0, 1).requires_grad_(True)
+        adv1 = torch.clamp(img1 + state[1], 0, 1).requires_grad_(True)
+        loss = fo.compute_flow_loss(predict(adv0, adv1), -clean, "cossim")
+        g0, g1 = torch.autograd.grad(loss, (adv0, adv1))
+        grad = torch.stack((g0[0], g1[0]))
+        want = torch.clamp(state - 2e-3 * torch.sign(grad), -0.02, 0.02)
+        step.run(1)
+        got = step.delta.cpu().clone()
+        flipped = (got - want).abs() > 1e-6
+        scale = float(grad.abs().median())
+        frac = float(flipped.float().mean())
+        strong = float((flipped & (grad.abs() > scale)).float().mean())
+        print(f"C5 step {it + 1}: {frac:.2e} of the entries take the other sign, {strong:.2e} of them with a gradient above the median")
+        assert frac < 2e-3 and strong < 2e-4, f"C5 step {it + 1}: {frac:.2e} flips, {strong:.2e} on gradients above the median"
+        assert float((got - want).abs().max()) <= 2 * 2e-3 + 1e-6
+        state = got
+    assert float((state - delta0).abs().max()) > 1e-3                     # the steps took effect
     _, _, d = fo.universal_attack(predict, img0, img1, delta0, -clean, n_step=n_step, lr=2e-3, eps=0.02, shared=True)
-    diff = (step.delta.cpu() - d).abs()
-    frac = float((diff > 1e-6).float().mean())
-    print(f"C5: after {n_step} steps {frac:.2e} of the perturbation entries differ, max {float(diff.max()):.2e}")
-    assert frac < 3e-2, f"C5: {frac:.2e} of the perturbation entries differ"
-    assert float(diff.max()) <= 2 * 2e-3 * n_step + 1e-6
-    assert float((step.delta.cpu() - delta0).abs().max()) > 1e-3          # the steps took effect
+    print(f"C5: free-running, after {n_step} steps {float(((state - d).abs() > 1e-6).float().mean()):.2e} of the entries differ")
 
 
 @pytest.mark.parametrize("alternate", [False, True])
