@@ -144,6 +144,11 @@ def _run_step(net, use_cone, masks, B, H, W, lr, shared, iters=3, seed=0, use_gr
     return step, patch, outs
 
 
+def _engine_on():
+    import os
+    return os.environ.get("UFR_ENGINE", "1") == "1"
+
+
 def _sel(mask, shared):
     """Where two implementations of a step must agree: the patch pixels a mask shows."""
     if isinstance(mask, tuple):
@@ -254,7 +259,9 @@ def test_windowed_step_random_placements(net):
     for use_graph in (True, False):          # two captured graphs (first / later iterations) and the eager form
         s_cone, _, cone = _run_step(net, True, masks, B, H, W, lr, False, iters=3 if use_graph else 2, use_graph=use_graph)
         assert s_cone.cone is not None and s_cone.band is not None and s_cone.band.width > 0
-        assert s_cone.band.inc_layers == ("conv3_1", "conv4", "conv4_1") and set(s_cone.band.caches) == set(s_cone.band.inc_layers)
+        assert s_cone.band.inc_layers == ("conv3_1", "conv4", "conv4_1")
+        if not _engine_on():                     # the torch spelling keeps its activation caches on the band object
+            assert set(s_cone.band.caches) == set(s_cone.band.inc_layers)
         if use_graph:
             assert s_cone.graph_next is not None and s_cone.graph_next is not s_cone.graph
             s_ref, _, ref3 = _run_step(net, False, masks, B, H, W, lr, False, iters=3)

@@ -23,34 +23,41 @@ __device__ __forceinline__ void split3(float v, __bf16& a, __bf16& b, __bf16& c)
   c = (__bf16)(r1 - (float)b);
 }
 
-// wpk [chunks][9][2][32] float32: wpk[ch][k][o][c] = weight[o][32*ch + c][k] (zero for padding channels)
-__global__ __launch_bounds__(256) void flow_head_planes_fwd(const __bf16* __restrict__ x, long plane_stride, int chunk0,
-                                                            int chunks, const float* __restrict__ wpk,
-                                                            const float* __restrict__ bias, float* __restrict__ out, int B,
-                                                            int H, int W) {
+// wpk [chunks][9][2][32] float32: wpk[ch][k][o][c] = weight[o][32*ch + c][k] (zero for padding channels).
+// Workgroup = 64 pixels x 4 channel groups x S chunk slices (256*S threads); the layer's weights are staged in LDS once
+// per workgroup (at most 33 chunks x 2304 B); slices are added through LDS in ascending order (deterministic).
+__global__ __launch_bounds__(1024) void flow_head_planes_fwd(const __bf16* __restrict__ x, long plane_stride, int chunk0,
+                                                             int chunks, const float* __restrict__ wpk,
+                                                             const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                             int H, int W, int S) {
+  extern __shared__ __attribute__((aligned(16))) float lds_w[];          // [chunks][9][2][32], then [S][64][2] partials
   const long M = (long)B * H * W;
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long pix = t >> 2;
-  const int q = (int)(t & 3);
+  const int tid = threadIdx.x, slice = tid >> 8, t = tid & 255;
+  for (int i = tid; i < chunks * 576 / 4; i += blockDim.x)
+    reinterpret_cast<float4*>(lds_w)[i] = reinterpret_cast<const float4*>(wpk)[i];
+  __syncthreads();
+  const long pix = (long)blockIdx.x * 64 + (t >> 2);
+  const int q = t & 3;
   const bool live = pix < M;
   const long pp = live ? pix : 0;
   const int xx = (int)(pp % W), yy = (int)((pp / W) % H);
-  long off[9];
-  bool ok[9];
+  int off[9];                                         // neighbour offsets in elements, relative to the pixel's own chunk row
+  float msk[9];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
+  for (int k = 0; k < 9; ++k) {                       // clamped neighbour + validity factor: no branch in the loop
     const int y2 = yy + k / 3 - 1, x2 = xx + k % 3 - 1;
-    ok[k] = live && y2 >= 0 && y2 < H && x2 >= 0 && x2 < W;
-    off[k] = pp + (long)(k / 3 - 1) * W + (k % 3 - 1);
+    const bool ok = y2 >= 0 && y2 < H && x2 >= 0 && x2 < W;
+    off[k] = ok ? ((k / 3 - 1) * W + (k % 3 - 1)) * 32 : 0;
+    msk[k] = ok ? 1.f : 0.f;
   }
   float a0 = 0.f, a1 = 0.f;
-  for (int ch = 0; ch < chunks; ++ch) {
-    const __bf16* xc = x + ((long)(chunk0 + ch) * M) * 32 + q * 8;
-    const float* wc = wpk + (long)ch * 9 * 2 * 32 + q * 8;
-#pragma unroll
+  const int per = (chunks + S - 1) / S, c_lo = slice * per, c_hi = min(chunks, c_lo + per);
+  for (int ch = c_lo; ch < c_hi; ++ch) {
+    const __bf16* xc = x + ((long)(chunk0 + ch) * M + pp) * 32 + q * 8;
+    const float* wc = lds_w + ch * 576 + q * 8;
+#pragma unroll 3
     for (int k = 0; k < 9; ++k) {
-      if (!ok[k]) continue;
-      const __bf16* src = xc + off[k] * 32;
+      const __bf16* src = xc + off[k];
       const bf16x8 p0 = *reinterpret_cast<const bf16x8*>(src);
       const bf16x8 p1 = *reinterpret_cast<const bf16x8*>(src + plane_stride);
       const bf16x8 p2 = *reinterpret_cast<const bf16x8*>(src + 2 * plane_stride);
@@ -58,28 +65,48 @@ __global__ __launch_bounds__(256) void flow_head_planes_fwd(const __bf16* __rest
       const float4 w1a = *reinterpret_cast<const float4*>(wc + (k * 2 + 1) * 32), w1b = *reinterpret_cast<const float4*>(wc + (k * 2 + 1) * 32 + 4);
       const float w0[8] = {w0a.x, w0a.y, w0a.z, w0a.w, w0b.x, w0b.y, w0b.z, w0b.w};
       const float w1[8] = {w1a.x, w1a.y, w1a.z, w1a.w, w1b.x, w1b.y, w1b.z, w1b.w};
+      float s0 = 0.f, s1 = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float v = ((float)p0[j] + (float)p1[j]) + (float)p2[j];
-        a0 = fmaf(v, w0[j], a0);
-        a1 = fmaf(v, w1[j], a1);
+        s0 = fmaf(v, w0[j], s0);
+        s1 = fmaf(v, w1[j], s1);
       }
+      a0 = fmaf(s0, msk[k], a0);
+      a1 = fmaf(s1, msk[k], a1);
     }
   }
   a0 += __shfl_xor(a0, 1, 64); a1 += __shfl_xor(a1, 1, 64);
   a0 += __shfl_xor(a0, 2, 64); a1 += __shfl_xor(a1, 2, 64);
-  if (live && q == 0) {
+  float* part = lds_w + chunks * 576;                   // [S][64][2]
+  if (q == 0) {
+    part[(slice * 64 + (t >> 2)) * 2 + 0] = a0;
+    part[(slice * 64 + (t >> 2)) * 2 + 1] = a1;
+  }
+  __syncthreads();
+  if (slice == 0 && q == 0 && live) {
+    float r0 = 0.f, r1 = 0.f;
+    for (int sl = 0; sl < S; ++sl) {
+      r0 += part[(sl * 64 + (t >> 2)) * 2 + 0];
+      r1 += part[(sl * 64 + (t >> 2)) * 2 + 1];
+    }
     const long HW = (long)H * W, b = pix / HW, p = pix - b * HW;
-    out[(b * 2 + 0) * HW + p] = a0 + bias[0];
-    out[(b * 2 + 1) * HW + p] = a1 + bias[1];
+    out[(b * 2 + 0) * HW + p] = r0 + bias[0];
+    out[(b * 2 + 1) * HW + p] = r1 + bias[1];
   }
 }
 
 // G[chunk0 + ch][pix][c] (+)= sum_o sum_k gy[b, o, pix - (k - centre)] * weight[o][32*ch + c][k]
+// thread = (pixel, 8-channel group), blockIdx.y = slice of the chunks (independent outputs: no reduction)
 __global__ __launch_bounds__(256) void flow_head_planes_bwd(const float* __restrict__ gy, const float* __restrict__ wpk,
                                                             float* __restrict__ G, int chunk0, int chunks, int B, int H, int W,
-                                                            int accumulate) {
+                                                            int accumulate, int per) {
+  extern __shared__ __attribute__((aligned(16))) float lds_w[];          // this slice's [per][9][2][32]
   const long M = (long)B * H * W;
+  const int c_lo = blockIdx.y * per, c_hi = min(chunks, c_lo + per);
+  for (int i = threadIdx.x; i < (c_hi - c_lo) * 576 / 4; i += blockDim.x)
+    reinterpret_cast<float4*>(lds_w)[i] = reinterpret_cast<const float4*>(wpk + (long)c_lo * 576)[i];
+  __syncthreads();
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long pix = t >> 2;
   const int q = (int)(t & 3);
@@ -94,8 +121,8 @@ __global__ __launch_bounds__(256) void flow_head_planes_bwd(const float* __restr
     g0[k] = ok ? gy[(b * 2 + 0) * HW + (long)y2 * W + x2] : 0.f;
     g1[k] = ok ? gy[(b * 2 + 1) * HW + (long)y2 * W + x2] : 0.f;
   }
-  for (int ch = 0; ch < chunks; ++ch) {
-    const float* wc = wpk + (long)ch * 9 * 2 * 32 + q * 8;
+  for (int ch = c_lo; ch < c_hi; ++ch) {
+    const float* wc = lds_w + (ch - c_lo) * 576 + q * 8;
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
@@ -195,20 +222,42 @@ __global__ void flow_up_planes_bwd(const float* __restrict__ G, int chunk, const
 extern "C" int ufr_flow_head_planes_forward(const void* planes, long plane_stride, int chunk0, int chunks, const float* wpk,
                                             const float* bias, float* out, int B, int H, int W, ufr_stream_t stream) {
   UFR_REQUIRE(planes && wpk && bias && out, "flow head (planes) forward: null pointer");
-  UFR_REQUIRE(B > 0 && H > 0 && W > 0 && chunks > 0 && chunk0 >= 0 && (long)B * H * W < (1L << 29), "flow head (planes) forward: bad shape");
-  const long threads = (long)B * H * W * 4;
-  flow_head_planes_fwd<<<ufr::ceil_div(threads, 256), 256, 0, ufr::as_stream(stream)>>>(
-      static_cast<const __bf16*>(planes), plane_stride, chunk0, chunks, wpk, bias, out, B, H, W);
+  UFR_REQUIRE(B > 0 && H > 0 && W > 0 && chunks > 0 && chunks <= 48 && chunk0 >= 0 && (long)B * H * W < (1L << 29),
+              "flow head (planes) forward: bad shape");
+  const long M = (long)B * H * W;
+  const int blocks = ufr::ceil_div(M, 64);
+  int S = 1;                                  // chunk slices per workgroup: more threads on the small grids
+  while (S < 4 && (long)blocks * S * 2 <= 2048 && chunks >= 4 * S) S *= 2;
+  const size_t lds = (size_t)chunks * 576 * 4 + (size_t)S * 64 * 2 * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flow_head_planes_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 576 * 4 + 4 * 64 * 2 * 4);
+    attr_set = true;
+  }
+  flow_head_planes_fwd<<<blocks, 256 * S, lds, ufr::as_stream(stream)>>>(
+      static_cast<const __bf16*>(planes), plane_stride, chunk0, chunks, wpk, bias, out, B, H, W, S);
   return ufr::launched("flow_head_planes_fwd");
 }
 
 extern "C" int ufr_flow_head_planes_backward(const float* grad_y, const float* wpk, float* G, int chunk0, int chunks, int B,
                                              int H, int W, int accumulate, ufr_stream_t stream) {
   UFR_REQUIRE(grad_y && wpk && G, "flow head (planes) backward: null pointer");
-  UFR_REQUIRE(B > 0 && H > 0 && W > 0 && chunks > 0 && chunk0 >= 0 && (long)B * H * W < (1L << 29), "flow head (planes) backward: bad shape");
+  UFR_REQUIRE(B > 0 && H > 0 && W > 0 && chunks > 0 && chunks <= 48 && chunk0 >= 0 && (long)B * H * W < (1L << 29),
+              "flow head (planes) backward: bad shape");
   const long threads = (long)B * H * W * 4;
-  flow_head_planes_bwd<<<ufr::ceil_div(threads, 256), 256, 0, ufr::as_stream(stream)>>>(grad_y, wpk, G, chunk0, chunks, B, H, W,
-                                                                                        accumulate);
+  const int bx = ufr::ceil_div(threads, 256);
+  int slices = 1;                             // chunk slices over blockIdx.y: more workgroups on the small grids
+  while ((long)bx * slices < 1024 && slices < chunks) slices *= 2;
+  if (slices > chunks) slices = chunks;
+  const int per = ufr::ceil_div(chunks, slices);
+  slices = ufr::ceil_div(chunks, per);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flow_head_planes_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 576 * 4);
+    attr_set = true;
+  }
+  flow_head_planes_bwd<<<dim3(bx, slices), 256, (size_t)per * 576 * 4, ufr::as_stream(stream)>>>(grad_y, wpk, G, chunk0, chunks, B,
+                                                                                                H, W, accumulate, per);
   return ufr::launched("flow_head_planes_bwd");
 }
 

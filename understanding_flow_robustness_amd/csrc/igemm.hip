@@ -93,6 +93,51 @@ __device__ __forceinline__ long out_pixel(const RowGeom& g, int pm, int oy0, int
   return ((long)b * g.Ho + (yr * g.out_sy + oy0)) * g.Wo + (xg * g.out_sx + ox0);
 }
 
+// Eight consecutive channels of one output pixel through the epilogue (n0 a multiple of 8): 16-byte accesses.
+__device__ __forceinline__ void epilogue_store8(const Epilogue& e, long pout, int n0, float v[8]) {
+  if (n0 >= e.Nchunks32 * 32) return;
+  const long cm = ((long)(n0 >> 5) * e.Mout + pout) * 32 + (n0 & 31);
+  if (e.act) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v[j] += (n0 + j < e.N) ? e.bias[n0 + j] : 0.f;
+      v[j] = v[j] > 0.f ? v[j] : v[j] * e.slope;
+    }
+  } else {
+    if (e.add) {
+      const float* ap = e.add + (long)e.add_chunk0 * e.Mout * 32 + cm;
+      const float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
+      v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+    }
+    if (e.mask) {
+      const bf16x8 m = *reinterpret_cast<const bf16x8*>(e.mask + (long)e.mask_chunk0 * e.Mout * 32 + cm);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = ((float)m[j] > 0.f) ? v[j] : v[j] * e.slope;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (n0 + j >= e.N) v[j] = 0.f;
+  if (e.out_f32) {
+    float* op = e.out_f32 + (long)e.out_f32_chunk0 * e.Mout * 32 + cm;
+    *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+  if (e.out_planes) {
+    bf16x8 q0, q1, q2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      __bf16 x, y, z;
+      split3(v[j], x, y, z);
+      q0[j] = x; q1[j] = y; q2[j] = z;
+    }
+    __bf16* o = e.out_planes + (long)e.out_chunk0 * e.Mout * 32 + cm;
+    *reinterpret_cast<bf16x8*>(o) = q0;
+    *reinterpret_cast<bf16x8*>(o + e.out_plane_stride) = q1;
+    *reinterpret_cast<bf16x8*>(o + 2 * e.out_plane_stride) = q2;
+  }
+}
+
 struct Phase {
   int ntaps, oy0, ox0;
   long w_off;                       // bf16 elements from the weight plane's start
@@ -121,8 +166,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   constexpr int FIRST = 6 - NPROD;
   constexpr int MT = BN_ == 128 ? 4 : 2;             // 16-row accumulator blocks per wave
   constexpr int BPT = BN_ / 64;                      // weight pieces per thread and plane
-  __shared__ __attribute__((aligned(16))) __bf16 ldsA[NPL][BM * BK];
-  __shared__ __attribute__((aligned(16))) __bf16 ldsB[NPL][BN_ * BK];
+  __shared__ __attribute__((aligned(16))) __bf16 lds_all[NPL * (BM + BN_) * BK];      // one array: the epilogue reuses it
+  __bf16 (*ldsA)[BM * BK] = reinterpret_cast<__bf16 (*)[BM * BK]>(lds_all);
+  __bf16 (*ldsB)[BN_ * BK] = reinterpret_cast<__bf16 (*)[BN_ * BK]>(lds_all + NPL * BM * BK);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wrow = BN_ == 128 ? (wave >> 1) * 64 : wave * 32, wcol = BN_ == 128 ? (wave & 1) * 64 : 0;
   const int bm = blockIdx.y * BM, bn = blockIdx.x * BN_;
@@ -253,30 +299,66 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     return;
   }
+  if constexpr (NPL == 3) {
+    // transpose each wave's 32 x 64 accumulator slabs through LDS so that a lane owns 8 consecutive channels of one
+    // pixel: 16-byte plane / fp32 stores instead of 2-byte ones (row stride 68 floats: conflict-free both ways)
+    constexpr int TS = 68;
+    float* tw = reinterpret_cast<float*>(lds_all) + wave * (32 * TS);
+    static_assert(4 * 32 * TS * 4 <= (int)sizeof(lds_all), "epilogue staging does not fit");
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+    for (int pass = 0; pass < MT / 2; ++pass) {
+      __syncthreads();                                   // the K loop's (or the previous pass's) LDS reads are done
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = bm + wrow + m * 16 + (lane >> 4) * 4 + j;
-      if (row < a.g.M) {
-        const long pout = out_pixel(a.g, row, ph.oy0, ph.ox0);
+      for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) epilogue_store(a.e, pout, bn + wcol + n * 16 + (lane & 15), acc[m][n][j]);
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            tw[(mm * 16 + (lane >> 4) * 4 + j) * TS + n * 16 + (lane & 15)] = acc[pass * 2 + mm][n][j];
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int item = it * 64 + lane, r = item >> 3, g8 = item & 7;
+        const int row = bm + wrow + pass * 32 + r;
+        if (row < a.g.M) {
+          const float4 lo = *reinterpret_cast<const float4*>(tw + r * TS + g8 * 8), hi = *reinterpret_cast<const float4*>(tw + r * TS + g8 * 8 + 4);
+          float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          epilogue_store8(a.e, out_pixel(a.g, row, ph.oy0, ph.ox0), bn + wcol + g8 * 8, v);
+        }
       }
     }
+  } else {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = bm + wrow + m * 16 + (lane >> 4) * 4 + j;
+        if (row < a.g.M) {
+          const long pout = out_pixel(a.g, row, ph.oy0, ph.ox0);
+#pragma unroll
+          for (int n = 0; n < 4; ++n) epilogue_store(a.e, pout, bn + wcol + n * 16 + (lane & 15), acc[m][n][j]);
+        }
+      }
+  }
 }
 
-// Second stage of split-K: thread = (phase, row, channel); the slabs are added in ascending order.
+// Second stage of split-K: thread = (phase, row, 8 channels); the slabs are added in ascending order.
 __global__ __launch_bounds__(256) void igemm_reduce_kernel(const Args a) {
-  const long total = (long)a.nphase * a.g.M * a.Npad;
+  const int n8 = a.Npad / 8;
+  const long total = (long)a.nphase * a.g.M * n8;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int n = (int)(i % a.Npad);
-    const long rest = i / a.Npad;
+    const int n0 = (int)(i % n8) * 8;
+    const long rest = i / n8;
     const int row = (int)(rest % a.g.M), phase = (int)(rest / a.g.M);
-    if (n >= a.e.Nchunks32 * 32) continue;
-    float v = 0.f;
-    for (int s = 0; s < a.splitk; ++s) v += a.ws[((long)(phase * a.splitk + s) * a.g.M + row) * a.Npad + n];
-    epilogue_store(a.e, out_pixel(a.g, row, a.ph[phase].oy0, a.ph[phase].ox0), n, v);
+    if (n0 >= a.e.Nchunks32 * 32) continue;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* src = a.ws + ((long)(phase * a.splitk) * a.g.M + row) * a.Npad + n0;
+    const long sstride = (long)a.g.M * a.Npad;
+    for (int s = 0; s < a.splitk; ++s) {
+      const float4 lo = *reinterpret_cast<const float4*>(src + s * sstride), hi = *reinterpret_cast<const float4*>(src + s * sstride + 4);
+      v[0] += lo.x; v[1] += lo.y; v[2] += lo.z; v[3] += lo.w; v[4] += hi.x; v[5] += hi.y; v[6] += hi.z; v[7] += hi.w;
+    }
+    epilogue_store8(a.e, out_pixel(a.g, row, a.ph[phase].oy0, a.ph[phase].ox0), n0, v);
   }
 }
 
@@ -450,7 +532,7 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   }
   int rc = ufr::launched("igemm_kernel");
   if (rc != UFR_OK || d->splitk == 1) return rc;
-  const long total = (long)d->nphase * M * d->Npad;
+  const long total = (long)d->nphase * M * (d->Npad / 8);
   igemm_reduce_kernel<<<ufr::stream_grid(total, 256), 256, 0, st>>>(a);
   return ufr::launched("igemm_reduce_kernel");
 }

@@ -133,7 +133,7 @@ class FlowNetC(nn.Module):
         """The native head (flownetc_engine.py) serves the attack's configuration: frozen parameters, eval mode, HIP
         float32 features, frame sides that are multiples of 64."""
         import os
-        if os.environ.get("UFR_ENGINE", "0") != "1" or feats is not None or self.training:
+        if os.environ.get("UFR_ENGINE", "1") != "1" or feats is not None or self.training:
             return False
         frozen = not any(p.requires_grad for p in self.parameters())
         return (c2a.is_cuda and c2a.dtype == torch.float32 and (frozen or not torch.is_grad_enabled())
