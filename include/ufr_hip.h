@@ -429,6 +429,7 @@ typedef struct {
   float* out_f32; int out_f32_chunk0;
   int splitk; float* ws;
   int products;                                /* 6 (float32-accurate); 3 / 1 for measurements only */
+  int variant;                                 /* 0 = default (LDS-DMA staging; UFR_IGEMM=reg selects 1), 1 = register-staged, 2 = LDS-DMA */
 } ufr_igemm_desc;
 int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream);
 /* Layout passes at the engine's edges.  ufr_nchw_to_planes: planes[chunk0 + c/32] = split(leaky(scale * x[B,C,H,W]))

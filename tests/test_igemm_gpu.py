@@ -11,9 +11,28 @@ DEV = "cuda:0"
 TOL = 1e-5
 
 
+VARIANT = {"v": 0}
+
+
+class _Ig:
+    """The igemm host module with `make_launch` pinned to one kernel variant (1 = register-staged, 2 = LDS-DMA)."""
+
+    def __getattr__(self, name):
+        from understanding_flow_robustness_amd import igemm
+        if name == "make_launch":
+            return lambda *a, **k: igemm.make_launch(*a, variant=VARIANT["v"], **k)
+        return getattr(igemm, name)
+
+
+@pytest.fixture(autouse=True, params=[1, 2], ids=["register-staged", "lds-dma"])
+def _variant(request):
+    VARIANT["v"] = request.param
+    yield
+    VARIANT["v"] = 0
+
+
 def _mods():
-    from understanding_flow_robustness_amd import igemm
-    return igemm
+    return _Ig()
 
 
 def _close(got, want, what, tol=TOL):

@@ -29,7 +29,8 @@ def timed(fn, iters=20):
 
 
 def main():
-    only = set(sys.argv[1:])
+    only = set(a for a in sys.argv[1:] if not a.startswith("--"))
+    variants = (1, 2) if "--both" in sys.argv else (0,)
     layers = [  # name, kind, Cin, Cout, k, stride, input grid (of the forward)
         ("conv3_1", "conv", 473, 256, 3, 1, (H8, W8)), ("conv4", "conv", 256, 512, 3, 2, (H8, W8)),
         ("conv4_1", "conv", 512, 512, 3, 1, (H8 // 2, W8 // 2)), ("conv5", "conv", 512, 512, 3, 2, (H8 // 2, W8 // 2)),
@@ -63,12 +64,12 @@ def main():
                                                      ("bwd", bwd_w, gy, bwd_rows, (hi, wi), gx, dict(mask=x))):
             M = B * rows[0] * rows[1]
             ktiles = max(len(t) for _, _, t in wimg.phases) * wimg.KC
-            for S in sorted({1, ig.splitk_for(M, wimg.Npad, ktiles, len(wimg.phases))}):
+            for S, variant in [(S, v) for S in sorted({1, ig.splitk_for(M, wimg.Npad, ktiles, len(wimg.phases))}) for v in variants]:
                 ws = torch.empty(len(wimg.phases) * S * M * wimg.Npad, device=DEV) if S > 1 else None
-                launch = ig.make_launch(wimg, src, 0, rows, out_hw, out_planes=dst, splitk=S, ws=ws, **kw)
+                launch = ig.make_launch(wimg, src, 0, rows, out_hw, out_planes=dst, splitk=S, ws=ws, variant=variant, **kw)
                 ms = timed(launch)
                 tf = flop / ms / 1e9
-                print(json.dumps(dict(layer=name, dir=tag, splitk=S, M=M, Npad=wimg.Npad, ktiles=ktiles, phases=len(wimg.phases),
+                print(json.dumps(dict(layer=name, dir=tag, variant=variant, splitk=S, M=M, Npad=wimg.Npad, ktiles=ktiles, phases=len(wimg.phases),
                                       gflop=round(flop / 1e9, 1), ms=round(ms, 4), tflops=round(tf, 1), frac_of_417=round(tf / CEIL, 3))),
                       flush=True)
 

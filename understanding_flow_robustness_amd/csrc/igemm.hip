@@ -156,6 +156,68 @@ struct Args {
   Phase ph[4];
 };
 
+// Accumulators -> memory: split-K slabs, or the fused epilogue through an LDS transpose (a lane owns 8 consecutive
+// channels of one pixel: 16-byte plane / fp32 stores; row stride 68 floats is conflict-free both ways).
+template <int NPL, int MT>
+__device__ __forceinline__ void igemm_write_out(const Args& a, const Phase& ph, f32x4 (&acc)[MT][4], float* lds_f32, int z, int bm,
+                                                int bn, int wrow, int wcol, int lane, int wave) {
+  // C/D layout of the 16x16 forms: col = lane & 15, row = (lane >> 4) * 4 + reg
+  if (a.splitk > 1) {
+    float* slab = a.ws + (long)z * a.g.M * a.Npad;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = bm + wrow + m * 16 + (lane >> 4) * 4 + j;
+        if (row < a.g.M) {
+#pragma unroll
+          for (int n = 0; n < 4; ++n) slab[(long)row * a.Npad + bn + wcol + n * 16 + (lane & 15)] = acc[m][n][j];
+        }
+      }
+    return;
+  }
+  if constexpr (NPL == 3) {
+    // transpose each wave's 32 x 64 accumulator slabs through LDS so that a lane owns 8 consecutive channels of one
+    // pixel: 16-byte plane / fp32 stores instead of 2-byte ones (row stride 68 floats: conflict-free both ways)
+    constexpr int TS = 68;
+    float* tw = lds_f32 + wave * (32 * TS);
+#pragma unroll
+    for (int pass = 0; pass < MT / 2; ++pass) {
+      __syncthreads();                                   // the K loop's (or the previous pass's) LDS reads are done
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            tw[(mm * 16 + (lane >> 4) * 4 + j) * TS + n * 16 + (lane & 15)] = acc[pass * 2 + mm][n][j];
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int item = it * 64 + lane, r = item >> 3, g8 = item & 7;
+        const int row = bm + wrow + pass * 32 + r;
+        if (row < a.g.M) {
+          const float4 lo = *reinterpret_cast<const float4*>(tw + r * TS + g8 * 8), hi = *reinterpret_cast<const float4*>(tw + r * TS + g8 * 8 + 4);
+          float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          epilogue_store8(a.e, out_pixel(a.g, row, ph.oy0, ph.ox0), bn + wcol + g8 * 8, v);
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = bm + wrow + m * 16 + (lane >> 4) * 4 + j;
+        if (row < a.g.M) {
+          const long pout = out_pixel(a.g, row, ph.oy0, ph.ox0);
+#pragma unroll
+          for (int n = 0; n < 4; ++n) epilogue_store(a.e, pout, bn + wcol + n * 16 + (lane & 15), acc[m][n][j]);
+        }
+      }
+  }
+}
+
 // Tile BM x BN_ per workgroup of four waves: BN_ = 128 -> waves 2 x 2, 64 x 64 each (4 x 4 accumulators);
 // BN_ = 64 (layers with <= 64 output channels: deconv2) -> waves 4 x 1, 32 x 64 each (2 x 4 accumulators).
 // K tiles run tap-major; the staging addresses advance incrementally (a pointer bump per tile, the bounds tests and pixel
@@ -284,62 +346,128 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
 
-  // C/D layout of the 16x16 forms: col = lane & 15, row = (lane >> 4) * 4 + reg
-  if (a.splitk > 1) {
-    float* slab = a.ws + (long)z * a.g.M * a.Npad;
+  static_assert(NPL != 3 || 4 * 32 * 68 * 4 <= (int)sizeof(lds_all), "epilogue staging does not fit");
+  igemm_write_out<NPL, MT>(a, ph, acc, reinterpret_cast<float*>(lds_all), z, bm, bn, wrow, wcol, lane, wave);
+}
+
+// The same tile with LDS-DMA staging (`global_load_lds_dwordx4`: HBM/L2 -> LDS without passing through registers).
+// No staging registers and no ds_write pass: 3 workgroups per CU instead of 2 (<= 168 VGPRs, 3 x 48 KB of LDS), so that
+// while one workgroup waits for its tile two others have MFMA work -- the register-staged kernel's matrix pipe sits idle
+// half of the time (profiles/r2_igemm_v1_pmc1.txt: SQ_VALU_MFMA_BUSY 50 %).  The LDS image is the same XOR-swizzled one;
+// an LDS-DMA writes lane-linearly (wave base + lane * 16 B), so the swizzle moves to the SOURCE address (lane (row, slot)
+// fetches 16-byte piece slot ^ ((row >> 1) & 3) of its row).  Rows outside the frame fetch a zero page.
+__device__ __attribute__((aligned(64))) unsigned ufr_zero_page[16];
+
+template <int BN_>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void igemm_glds_kernel(const Args a) {
+  constexpr int NPL = 3, FIRST = 0;
+  constexpr int MT = BN_ == 128 ? 4 : 2;
+  constexpr int BPT = BN_ / 64;
+  __shared__ __attribute__((aligned(16))) __bf16 lds_all[NPL * (BM + BN_) * BK];
+  __bf16 (*ldsA)[BM * BK] = reinterpret_cast<__bf16 (*)[BM * BK]>(lds_all);
+  __bf16 (*ldsB)[BN_ * BK] = reinterpret_cast<__bf16 (*)[BN_ * BK]>(lds_all + NPL * BM * BK);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wrow = BN_ == 128 ? (wave >> 1) * 64 : wave * 32, wcol = BN_ == 128 ? (wave & 1) * 64 : 0;
+  const int bm = blockIdx.y * BM, bn = blockIdx.x * BN_;
+  const int z = blockIdx.z, phase = z / a.splitk, ks = z - phase * a.splitk;
+  const Phase& ph = a.ph[phase];
+  const int KC = a.KC, KT = ph.ntaps * KC;
+  const int per = (KT + a.splitk - 1) / a.splitk, kt0 = ks * per, kt1 = min(KT, kt0 + per);
+  const long Min = (long)a.g.B * a.Hi * a.Wi;
+  const long cstride = Min * 32;
+
+  const int srow0 = tid >> 2, sch = tid & 3;
+  const int csw = sch ^ ((srow0 >> 1) & 3);             // the piece this lane fetches (64 more rows keep (row >> 1) & 3)
+  int yb[2], xb[2], xlo[2], xhi[2];
+  long ibase[2];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = bm + wrow + m * 16 + (lane >> 4) * 4 + j;
-        if (row < a.g.M) {
-#pragma unroll
-          for (int n = 0; n < 4; ++n) slab[(long)row * a.Npad + bn + wcol + n * 16 + (lane & 15)] = acc[m][n][j];
-        }
-      }
-    return;
+  for (int i = 0; i < 2; ++i) {
+    const int pm = bm + srow0 + 64 * i;
+    const int hw = a.g.Hr * a.g.Wr;
+    const int b = pm / hw, r = pm - b * hw, yr = r / a.g.Wr, xr = r - yr * a.g.Wr;
+    const bool live = pm < a.g.M;
+    const int bb = live ? b : 0;
+    const int xg = xr + (a.g.row_x0 ? a.g.row_x0[bb * a.g.row_x0_stride] / a.g.row_x0_div : 0);
+    yb[i] = live ? yr * a.in_sy : -(1 << 20);
+    xb[i] = xg * a.in_sx;
+    ibase[i] = (long)bb * a.Hi * a.Wi;
+    xlo[i] = a.in_x0 ? a.in_x0[bb * a.in_x0_stride] / a.in_x0_div : 0;
+    xhi[i] = a.in_x0 ? min(a.Wi, xlo[i] + a.in_xw) : a.Wi;
+    xlo[i] = max(xlo[i], 0);
   }
-  if constexpr (NPL == 3) {
-    // transpose each wave's 32 x 64 accumulator slabs through LDS so that a lane owns 8 consecutive channels of one
-    // pixel: 16-byte plane / fp32 stores instead of 2-byte ones (row stride 68 floats: conflict-free both ways)
-    constexpr int TS = 68;
-    float* tw = reinterpret_cast<float*>(lds_all) + wave * (32 * TS);
-    static_assert(4 * 32 * TS * 4 <= (int)sizeof(lds_all), "epilogue staging does not fit");
+  const __bf16* gx = a.x + (long)a.in_chunk0 * cstride + csw * 8;
+  const __bf16* zero = reinterpret_cast<const __bf16*>(ufr_zero_page);
+  int tap = kt0 / KC, kc = kt0 - tap * KC;
+  const __bf16* wp = a.w + ph.w_off + ((long)kt0 * a.Npad + bn + srow0) * BK + csw * 8;
+  const long wstep = (long)a.Npad * BK;
+  const __bf16* xk = gx + (long)kc * cstride;
+  bool ok[2];
+  long aoff[2];
+  auto set_tap = [&](int t) {
+    const int dyo = ph.dy[t], dxo = ph.dx[t];
 #pragma unroll
-    for (int pass = 0; pass < MT / 2; ++pass) {
-      __syncthreads();                                   // the K loop's (or the previous pass's) LDS reads are done
-#pragma unroll
-      for (int mm = 0; mm < 2; ++mm)
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            tw[(mm * 16 + (lane >> 4) * 4 + j) * TS + n * 16 + (lane & 15)] = acc[pass * 2 + mm][n][j];
-      __syncthreads();
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int item = it * 64 + lane, r = item >> 3, g8 = item & 7;
-        const int row = bm + wrow + pass * 32 + r;
-        if (row < a.g.M) {
-          const float4 lo = *reinterpret_cast<const float4*>(tw + r * TS + g8 * 8), hi = *reinterpret_cast<const float4*>(tw + r * TS + g8 * 8 + 4);
-          float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-          epilogue_store8(a.e, out_pixel(a.g, row, ph.oy0, ph.ox0), bn + wcol + g8 * 8, v);
-        }
-      }
+    for (int i = 0; i < 2; ++i) {
+      const int yi = yb[i] + dyo, xi = xb[i] + dxo;
+      ok[i] = (unsigned)yi < (unsigned)a.Hi && xi >= xlo[i] && xi < xhi[i];
+      aoff[i] = ok[i] ? (ibase[i] + (long)yi * a.Wi + xi) * 32 : 0;
     }
-  } else {
+  };
+  // wave-uniform LDS destinations: the wave's 16 rows of each image (lane l lands at base + 16 l bytes)
+  auto stage_tile = [&]() {
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = bm + wrow + m * 16 + (lane >> 4) * 4 + j;
-        if (row < a.g.M) {
-          const long pout = out_pixel(a.g, row, ph.oy0, ph.ox0);
-#pragma unroll
-          for (int n = 0; n < 4; ++n) epilogue_store(a.e, pout, bn + wcol + n * 16 + (lane & 15), acc[m][n][j]);
-        }
+      for (int p = 0; p < NPL; ++p) {
+        const __bf16* src = ok[i] ? xk + aoff[i] + p * a.x_plane_stride : zero;
+        __builtin_amdgcn_global_load_lds(src, &ldsA[p][(64 * i + wave * 16) * BK], 16, 0, 0);
       }
+#pragma unroll
+    for (int i = 0; i < BPT; ++i)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p)
+        __builtin_amdgcn_global_load_lds(wp + p * a.w_plane_stride + (long)(64 * i) * BK, &ldsB[p][(64 * i + wave * 16) * BK], 16, 0, 0);
+    wp += wstep;
+    xk += cstride;
+    if (++kc == KC) {
+      kc = 0;
+      xk = gx;
+      if (++tap < ph.ntaps) set_tap(tap);
+    }
+  };
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15;
+  const int foff = frow * BK + ((((lane >> 4)) ^ ((frow >> 1) & 3)) << 3);
+
+  if (kt0 < kt1) set_tap(tap);
+  for (int kt = kt0; kt < kt1; ++kt) {
+    __syncthreads();                 // every wave has read the previous tile's fragments
+    stage_tile();
+    __syncthreads();                 // hipcc waits vmcnt(0) here: the DMA writes have landed for every wave
+    bf16x8 fa[NPL][MT];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        fa[p][m] = *reinterpret_cast<const bf16x8*>(&ldsA[p][(wrow + m * 16) * BK + foff]);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      bf16x8 fb[NPL];
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) fb[p] = *reinterpret_cast<const bf16x8*>(&ldsB[p][(wcol + n * 16) * BK + foff]);
+#pragma unroll
+      for (int t = FIRST; t < 6; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[t]][m], fb[PROD_B[t]], acc[m][n], 0, 0, 0);
+    }
   }
+  static_assert(4 * 32 * 68 * 4 <= (int)sizeof(lds_all), "epilogue staging does not fit");
+  igemm_write_out<NPL, MT>(a, ph, acc, reinterpret_cast<float*>(lds_all), z, bm, bn, wrow, wcol, lane, wave);
 }
 
 // Second stage of split-K: thread = (phase, row, 8 channels); the slabs are added in ascending order.
@@ -522,7 +650,13 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   hipStream_t st = ufr::as_stream(stream);
   const int bn = d->Npad % BN == 0 ? BN : 64;        // 64-column tiles where a 128-column tile would be mostly padding
   const dim3 grid(d->Npad / bn, (unsigned)((M + BM - 1) / BM), d->nphase * d->splitk);
-  if (bn == BN) {
+  static const int default_variant = [] { const char* e = getenv("UFR_IGEMM"); return e && e[0] == 'r' ? 1 : 2; }();
+  const int variant = d->variant ? d->variant : default_variant;        // 1 = register-staged, 2 = LDS-DMA staging
+  UFR_REQUIRE(variant == 1 || variant == 2, "igemm: unknown kernel variant %d", variant);
+  if (variant == 2 && d->products == 6) {
+    if (bn == BN) igemm_glds_kernel<128><<<grid, 256, 0, st>>>(a);
+    else igemm_glds_kernel<64><<<grid, 256, 0, st>>>(a);
+  } else if (bn == BN) {
     if (d->products == 6) igemm_kernel<6, 128><<<grid, 256, 0, st>>>(a);
     else if (d->products == 3) igemm_kernel<3, 128><<<grid, 256, 0, st>>>(a);
     else igemm_kernel<1, 128><<<grid, 256, 0, st>>>(a);

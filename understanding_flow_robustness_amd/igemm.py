@@ -193,7 +193,7 @@ def make_launch(wi: WeightImage, x: Planes, in_chunk0: int, rows_hw, out_hw, *, 
                 out_chunk0: int = 0, out_f32: GradSum | None = None, out_f32_chunk0: int = 0, bias: torch.Tensor | None = None,
                 add: GradSum | None = None, add_chunk0: int = 0, mask: Planes | None = None, mask_chunk0: int = 0,
                 slope: float = LEAKY, splitk: int = 1, ws: torch.Tensor | None = None, row_band=None, in_band=None,
-                products: int = 6) -> Launch:
+                products: int = 6, variant: int = 0) -> Launch:
     """Descriptor for `wi` applied to the chunks [in_chunk0, in_chunk0 + KC) of `x`.
     rows_hw = (Hr, Wr) row grid; out_hw = (Ho, Wo) output grid.  row_band = (origins int32 tensor, element stride, divisor):
     the row grid's columns start at origins[b*stride] // divisor.  in_band = (origins, stride, divisor, width): input
@@ -249,6 +249,7 @@ def make_launch(wi: WeightImage, x: Planes, in_chunk0: int, rows_hw, out_hw, *, 
             raise RuntimeError(f"igemm: split-K workspace of {need} floats needed")
         d.ws = ws.data_ptr()
     d.products = int(products)
+    d.variant = int(variant)               # 0 = library default, 1 = register-staged kernel, 2 = LDS-DMA kernel
     return Launch(d, keep)
 
 
