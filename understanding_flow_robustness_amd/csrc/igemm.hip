@@ -358,6 +358,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // fetches 16-byte piece slot ^ ((row >> 1) & 3) of its row).  Rows outside the frame fetch a zero page.
 __device__ __attribute__((aligned(64))) unsigned ufr_zero_page[16];
 
+// one LDS-DMA: 16 bytes per lane from `src` (per lane) to `lds_wave_base + 16 * lane` (the base must be wave-uniform)
+__device__ __forceinline__ void glds16(const __bf16* src, __bf16* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(src, lds_wave_base, 16, 0, 0);
+}
+
 template <int BN_>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void igemm_glds_kernel(const Args a) {
   constexpr int NPL = 3, FIRST = 0;
@@ -419,13 +424,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
       for (int p = 0; p < NPL; ++p) {
         const __bf16* src = ok[i] ? xk + aoff[i] + p * a.x_plane_stride : zero;
-        __builtin_amdgcn_global_load_lds(src, &ldsA[p][(64 * i + wave * 16) * BK], 16, 0, 0);
+        glds16(src, &ldsA[p][(64 * i + wave * 16) * BK]);
       }
 #pragma unroll
     for (int i = 0; i < BPT; ++i)
 #pragma unroll
       for (int p = 0; p < NPL; ++p)
-        __builtin_amdgcn_global_load_lds(wp + p * a.w_plane_stride + (long)(64 * i) * BK, &ldsB[p][(64 * i + wave * 16) * BK], 16, 0, 0);
+        glds16(wp + p * a.w_plane_stride + (long)(64 * i) * BK, &ldsB[p][(64 * i + wave * 16) * BK]);
     wp += wstep;
     xk += cstride;
     if (++kc == KC) {

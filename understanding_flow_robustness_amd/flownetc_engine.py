@@ -182,6 +182,18 @@ class FlowNetCHeadEngine:
         for name, (ls_rows, ls_in) in self._BWD_BAND.items():
             self.bwd_band[name] = derive("bwd", name, ls_rows, ls_in)
 
+    def launch_table(self):
+        """Every prepared igemm launch with its algorithmic work, for bench.py's per-kernel rooflines:
+        [(name, 'fwd' | 'bwd', 'full' | 'band', launch, GFLOP)]."""
+        rows = []
+        for kind, table, tag in (("fwd", self.fwd, "full"), ("bwd", self.bwd, "full"), ("fwd", self.fwd_band, "band"),
+                                 ("bwd", self.bwd_band, "band")):
+            for name, launch in table.items():
+                wi = self._plans[(kind, name)][0]
+                d = launch.desc
+                rows.append((name, kind, tag, launch, wi.flops(d.B * d.Hr * d.Wr) / 1e9))
+        return rows
+
     # ------------------------------------------------------------------------------------------------ small launches
     def _pf_forward(self, k):
         src, chunks = self.pf_src[k]

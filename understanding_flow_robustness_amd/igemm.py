@@ -80,10 +80,15 @@ class WeightImage:
     """Pre-split weights of ONE launch: bf16 [3][total] with, per phase, a chunk-major [taps*KC][Npad][32] image at
     `offsets[z]`; `phases[z]` = (oy0, ox0, [(dy, dx)])."""
 
-    def __init__(self, planes, offsets, phases, N, Npad, KC, geometry):
+    def __init__(self, planes, offsets, phases, N, Npad, KC, geometry, C=None):
         self.planes, self.offsets, self.phases = planes, offsets, phases
         self.N, self.Npad, self.KC = N, Npad, KC
+        self.C = C if C is not None else KC * 32          # real input channels (KC*32 includes the chunk padding)
         self.geometry = geometry        # dict(in_s, out_s): strides of the row grid -> input / output pixels
+
+    def flops(self, rows: int) -> float:
+        """Algorithmic FLOPs of one launch over `rows` tile rows: 2 * rows * taps * Cin * Cout, real channel counts."""
+        return 2.0 * rows * sum(len(t) for _, _, t in self.phases) * self.C * self.N
 
 
 def _split3(w: torch.Tensor) -> torch.Tensor:
@@ -109,7 +114,7 @@ def _pack(mats, device):
         offsets.append(total)
         total += img.numel()
         images.append(img)
-    return _split3(torch.cat(images)), offsets, N, npad, cpad // 32
+    return _split3(torch.cat(images)), offsets, N, npad, cpad // 32, Cn
 
 
 def _deconv_phases(kernel: int, padding: int):
@@ -133,8 +138,8 @@ def conv_forward_weights(weight: torch.Tensor, stride: int, padding: int) -> Wei
     w = weight.detach().float()
     mat = w.permute(0, 2, 3, 1).reshape(N, k * k, Cn)
     taps = [(ky - padding, kx - padding) for ky in range(k) for kx in range(k)]
-    planes, offsets, N, npad, KC = _pack([mat], weight.device)
-    return WeightImage(planes, offsets, [(0, 0, taps)], N, npad, KC, dict(in_s=stride, out_s=1))
+    planes, offsets, N, npad, KC, cr = _pack([mat], weight.device)
+    return WeightImage(planes, offsets, [(0, 0, taps)], N, npad, KC, dict(in_s=stride, out_s=1), cr)
 
 
 def conv_backward_weights(weight: torch.Tensor, stride: int, padding: int) -> WeightImage:
@@ -145,15 +150,15 @@ def conv_backward_weights(weight: torch.Tensor, stride: int, padding: int) -> We
         # gx[y] = sum_ky gy[y + p - ky] * w[ky]: a convolution of gy with the transposed weights
         mat = w.permute(1, 2, 3, 0).reshape(Cn, k * k, N)
         taps = [(padding - ky, padding - kx) for ky in range(k) for kx in range(k)]
-        planes, offsets, n, npad, KC = _pack([mat], weight.device)
-        return WeightImage(planes, offsets, [(0, 0, taps)], n, npad, KC, dict(in_s=1, out_s=1))
+        planes, offsets, n, npad, KC, cr = _pack([mat], weight.device)
+        return WeightImage(planes, offsets, [(0, 0, taps)], n, npad, KC, dict(in_s=1, out_s=1), cr)
     if stride != 2:
         raise NotImplementedError("data gradient: stride 1 or 2")
     phases = _deconv_phases(k, padding)          # gx = conv_transpose(gy, weight): 'input' channels N, output channels C
     mats = [torch.stack([w[:, :, ky, kx].t() for ky, kx, _, _ in taps], dim=1) for _, _, taps in phases]   # [C, taps, N]
-    planes, offsets, n, npad, KC = _pack(mats, weight.device)
+    planes, offsets, n, npad, KC, cr = _pack(mats, weight.device)
     return WeightImage(planes, offsets, [(oy, ox, [(dy, dx) for _, _, dy, dx in taps]) for oy, ox, taps in phases], n, npad, KC,
-                       dict(in_s=1, out_s=2))
+                       dict(in_s=1, out_s=2), cr)
 
 
 def deconv_forward_weights(weight: torch.Tensor, padding: int) -> WeightImage:
@@ -162,9 +167,9 @@ def deconv_forward_weights(weight: torch.Tensor, padding: int) -> WeightImage:
     w = weight.detach().float()
     phases = _deconv_phases(k, padding)
     mats = [torch.stack([w[:, :, ky, kx].t() for ky, kx, _, _ in taps], dim=1) for _, _, taps in phases]   # [Cout, taps, Cin]
-    planes, offsets, n, npad, KC = _pack(mats, weight.device)
+    planes, offsets, n, npad, KC, cr = _pack(mats, weight.device)
     return WeightImage(planes, offsets, [(oy, ox, [(dy, dx) for _, _, dy, dx in taps]) for oy, ox, taps in phases], n, npad, KC,
-                       dict(in_s=1, out_s=2))
+                       dict(in_s=1, out_s=2), cr)
 
 
 def deconv_backward_weights(weight: torch.Tensor, padding: int) -> WeightImage:
@@ -174,8 +179,8 @@ def deconv_backward_weights(weight: torch.Tensor, padding: int) -> WeightImage:
     w = weight.detach().float()
     mat = w.permute(0, 2, 3, 1).reshape(cin, k * k, cout)
     taps = [(ky - padding, kx - padding) for ky in range(k) for kx in range(k)]
-    planes, offsets, n, npad, KC = _pack([mat], weight.device)
-    return WeightImage(planes, offsets, [(0, 0, taps)], n, npad, KC, dict(in_s=2, out_s=1))
+    planes, offsets, n, npad, KC, cr = _pack([mat], weight.device)
+    return WeightImage(planes, offsets, [(0, 0, taps)], n, npad, KC, dict(in_s=2, out_s=1), cr)
 
 
 # ---------------------------------------------------------------------------------------------------- launches
