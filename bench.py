@@ -12,8 +12,10 @@ step     : ONE inner-loop iteration of attack() (main.py:546-611) over the rank'
            replayed as one HIP graph (N>1: two graphs around one RCCL all-gather of the 31 KB [crop | loss] rows).
 scaling  : weak (8 pairs per GPU); value = N*8*K / max-over-ranks time.
 Inputs are resident in HBM before the timed region.  The JSON line also carries
-  roofline     -- the step against the fp32 MFMA peak (convs are ~98% of the FLOPs) and, under
-                  "kernels", every hand-written kernel against its own bound, timed with HIP events;
+  roofline     -- the dominant kernel (csrc/igemm.hip: the head's convolutions, float32-accurate on the bf16 matrix cores
+                  with six products -> ceiling 2.5 PFLOP/s / 6 = 417 TFLOP/s fp32-equivalent) over the launches of one
+                  iteration, each timed live with HIP events; under "kernels" every launch of the step's own kernels and
+                  the MIOpen prefix against its own bound; under "step" the whole iteration's executed FLOPs;
   cpu_baseline -- the CPU oracle (torch-CPU convs + C correlation) on a bounded sample, rank 0, N=1.
 """
 from __future__ import annotations
@@ -35,7 +37,9 @@ PATCH = 51                      # --patch-size 0.1329 * 384 (utils_patch.py:760-
 # algorithmic work per frame pair per iteration, forward + data gradient (SURVEY.md 8d / BASELINE.md)
 GFLOP_NET_FWD = 111.9           # FlowNetC convolutions, one pair, forward
 GFLOP_PREFIX_FWD = 2 * (2.312 + 12.583 + 12.583)   # conv1-3 on both frames (2*Cin*Cout*k*k*Hout*Wout)
-GFLOP_CORR = 1.734 + 3.468
+GFLOP_CORR_FWD, GFLOP_CORR_BWD = 1.734, 3.468
+GFLOP_CORR = GFLOP_CORR_FWD + GFLOP_CORR_BWD
+GFLOP_CORR_BWD_WINDOW = 2 * 2 * 256 * 441 * 16 * 16 / 1e9       # both adjoints on the window's 16x16 cells (0.116 per pair)
 
 
 GFLOP_BAND_LAYERS = 16.74 + 4.53 + 9.06 + 2.26     # data gradients of conv3_1, conv4, conv4_1, conv5 (one pair)
@@ -47,13 +51,13 @@ GFLOP_INC_LAYERS = 16.74 + 4.53 + 9.06            # forward of conv3_1, conv4, c
 def gflop_per_pair_step(window_hw, max_count, band_width=None, incremental=False):
     """FLOPs the step EXECUTES per pair and iteration.  Full-frame: whole network forward + data gradient.
     Windowed prefix (patch_attack.py): head forward + adjoint at full size, conv1-3 forward + adjoint on
-    the window, plus the one full-frame conv1-3 forward per attack() call spread over its iterations;
-    with a column band (band_conv.py) four head data gradients shrink to band_width / W."""
+    the window, the correlation's adjoint on the window's cells, plus the one full-frame conv1-3 forward per attack()
+    call spread over its iterations; with a column band four head data gradients shrink to band_width / W."""
     if window_hw is None:
         return 2 * GFLOP_NET_FWD + GFLOP_CORR
     frac = window_hw[0] * window_hw[1] / float(H * W)
     head = GFLOP_NET_FWD - GFLOP_PREFIX_FWD
-    total = 2 * head + GFLOP_CORR + 2 * GFLOP_PREFIX_FWD * frac + GFLOP_PREFIX_FWD / max_count
+    total = 2 * head + GFLOP_CORR_FWD + GFLOP_CORR_BWD_WINDOW + 2 * GFLOP_PREFIX_FWD * frac + GFLOP_PREFIX_FWD / max_count
     if band_width is not None:
         total -= GFLOP_BAND_LAYERS * (1.0 - band_width / float(W))
         if incremental:    # conv3_1 / conv4 / conv4_1 forward on the band only, from the 2nd iteration of a call on
@@ -63,6 +67,7 @@ def gflop_per_pair_step(window_hw, max_count, band_width=None, incremental=False
 
 GFLOP_PER_PAIR_STEP = gflop_per_pair_step(None, 2)
 PEAK_FP32_TFLOPS = 157.3        # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
+PEAK_SPLIT6_TFLOPS = 2500.0 / 6   # bf16 dense MFMA peak / six products per float32 product (csrc/igemm.hip)
 PEAK_HBM_GBS = 8000.0
 CORR_FWD = dict(gflop=1.734, mbytes=29.3)   # per [1,256,48,160] pair
 CORR_BWD = dict(gflop=3.468, mbytes=44.9)
@@ -97,36 +102,65 @@ def event_time(fn, iters, warm=2):
     return s.elapsed_time(e) / iters
 
 
-def kernel_rooflines(device):
-    """Live per-kernel timings of the hand-written kernels on the step's shapes."""
+def _pmc(name):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def kernel_rooflines(step, device, max_count):
+    """Live timings (HIP events on the launch stream) of every kernel class of the step on the step's own shapes.
+    Returns (entries, igemm aggregate over one average iteration)."""
+    from understanding_flow_robustness_amd import _lib as L
     from understanding_flow_robustness_amd import spatial_correlation_sampler_backend as be
     B = B_PER_GPU
+    ks = []
+    traffic = _pmc("r2_igemm_traffic.json")           # HBM-side bytes per launch from the PMC passes (rocprofv3 only)
+    # ---- the head's convolutions: every prepared igemm launch of the engine the step runs
+    eng = None
+    for e in getattr(step.net, "__dict__", {}).get("_ufr_head_engines", {}).values():
+        if e.B == B and e.H == H and e.W == W:
+            eng = e
+    agg = None
+    if eng is not None:
+        per = {}
+        for name, kind, tag, launch, gflop in eng.launch_table():
+            t = event_time(launch, 10)
+            tf = gflop / t
+            key = f"igemm {name} {kind} ({tag})"
+            per[(name, kind, tag)] = (t, gflop)
+            ks.append(dict(kernel=key, ms=round(t, 4), bound="mfma", achieved=round(tf, 1), peak=round(PEAK_SPLIT6_TFLOPS, 1),
+                           unit="TFLOP/s", frac=round(tf / PEAK_SPLIT6_TFLOPS, 3), gflop=round(gflop, 2),
+                           traffic=traffic.get(key)))
+        # one average iteration of an attack() call of `max_count` iterations: the first runs the full forward, later
+        # ones the band's columns of conv_redir / conv3_1 / conv4 / conv4_1; five data gradients always run on the band
+        banded = bool(eng.bwd_band)
+        t_sum = g_sum = 0.0
+        for (name, kind, tag), (t, gflop) in per.items():
+            if kind == "fwd":
+                has_band = (name, "fwd", "band") in per
+                w = (1.0 / max_count if has_band else 1.0) if tag == "full" else (max_count - 1.0) / max_count
+            else:
+                has_band = banded and (name, "bwd", "band") in per
+                w = (0.0 if has_band else 1.0) if tag == "full" else 1.0
+            t_sum += w * t
+            g_sum += w * gflop
+        agg = dict(ms=t_sum, gflop=g_sum)
+    # ---- correlation
     a = torch.randn(B, 256, H // 8, W // 8, device=device)
     b = torch.randn(B, 256, H // 8, W // 8, device=device)
     prm = (1, 1, 21, 21, 0, 0, 1, 1, 2, 2, 1, 1)
     out = be.forward(a, b, *prm)
     go = torch.randn_like(out)
     t_f = event_time(lambda: be.forward(a, b, *prm), 10)
-    t_b = event_time(lambda: be.backward(a, b, go, *prm), 10)
-    ks = []
-    # HBM-side bytes per launch from the PMC passes of this round (never measured live: rocprofv3 only)
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_corr_traffic.json")) as f:
-            pmc = json.load(f)
-    except OSError:
-        pmc = {}
-    for name, t, w in (("corr_fwd_vec<21,2>", t_f, CORR_FWD), ("corr_bwd_mfma<21,2> (both adjoints)", t_b, CORR_BWD)):
-        tf = w["gflop"] * B / t            # GFLOP/ms == TFLOP/s
-        gbs = w["mbytes"] * B / t          # MB/ms == GB/s
-        # arithmetic intensity 59-77 FLOP/B is above the fp32 ridge (~20): the bound is the fp32 VALU/MFMA rate
-        ks.append(dict(kernel=name, ms=round(t, 4), bound="mfma", achieved=round(tf, 2), peak=PEAK_FP32_TFLOPS,
-                       unit="TFLOP/s", frac=round(tf / PEAK_FP32_TFLOPS, 4), hbm_gbs=round(gbs, 1),
-                       hbm_frac=round(gbs / PEAK_HBM_GBS, 4),
-                       traffic=(pmc[name]["fetch_bytes"] + pmc[name]["write_bytes"]) if name in pmc else None,
-                       algorithmic_bytes=int(w["mbytes"] * 1e6 * B)))
-    ks[-1]["note"] = "full-frame iteration only (UFR_CONE=0); the windowed step runs corr_bwd_window"
-    # the adjoint the windowed step actually runs: 16x16 cells per pair, both inputs
-    from understanding_flow_robustness_amd import _lib as L
+    pmc = _pmc("r1_corr_traffic.json")
+    tf = CORR_FWD["gflop"] * B / t_f
+    ks.append(dict(kernel="corr_fwd_vec<21,2>", ms=round(t_f, 4), bound="mfma", achieved=round(tf, 2), peak=PEAK_FP32_TFLOPS,
+                   unit="TFLOP/s", frac=round(tf / PEAK_FP32_TFLOPS, 4), hbm_gbs=round(CORR_FWD["mbytes"] * B / t_f, 1),
+                   traffic=(pmc["corr_fwd_vec<21,2>"]["fetch_bytes"] + pmc["corr_fwd_vec<21,2>"]["write_bytes"]) if "corr_fwd_vec<21,2>" in pmc else None,
+                   algorithmic_bytes=int(CORR_FWD["mbytes"] * 1e6 * B)))
     win = torch.zeros(B, 8, dtype=torch.int32, device=device)
     win[:, 0], win[:, 1] = 128, 512
     g1, g2 = torch.empty_like(a), torch.empty_like(b)
@@ -134,23 +168,40 @@ def kernel_rooflines(device):
         L.ptr(a), L.ptr(b), L.ptr(go), L.ptr(g1), L.ptr(g2), B, 256, H // 8, W // 8, 21, 2, L.ptr(win), 8, 16, 16,
         L.stream())), 10)
     cells = 16 * 16
-    gflop_w = 2 * 2 * 256 * 441 * cells * B / 1e9                       # both adjoints
     bytes_w = B * (2 * 441 * cells * 4 + 2 * 256 * 56 * 56 * 4 + 2 * 256 * (H // 8) * (W // 8) * 4)   # gout, regions, zero-filled outputs
     ks.append(dict(kernel="corr_bwd_window<8,21,2> (both adjoints, 16x16 cells per pair)", ms=round(t_w, 4), bound="hbm",
                    achieved=round(bytes_w / t_w / 1e6, 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                   frac=round(bytes_w / t_w / 1e6 / PEAK_HBM_GBS, 4), tflops=round(gflop_w / t_w, 2), traffic=None,
-                   algorithmic_bytes=int(bytes_w),
-                   note="bound in practice by L2->L1 traffic: 32 channel groups re-read the window's grad_output"))
-    return ks
+                   frac=round(bytes_w / t_w / 1e6 / PEAK_HBM_GBS, 4), tflops=round(GFLOP_CORR_BWD_WINDOW * B / t_w, 2),
+                   traffic=_pmc("r2_corr_window_traffic.json").get("traffic_bytes"), algorithmic_bytes=int(bytes_w)))
+    # ---- the 2-channel layers of the refinement (HBM-bound: one pass over the concatenation's planes)
+    if eng is not None:
+        for k in (6, 5, 4, 3, 2):
+            src, chunks = eng.pf_src[k]
+            nbytes = chunks * src.M * 32 * 6 + B * 2 * src.H * src.W * 4
+            t = event_time(lambda: eng._pf_forward(k), 10)
+            ks.append(dict(kernel=f"flow_head_planes_fwd predict_flow{k}", ms=round(t, 4), bound="hbm", achieved=round(nbytes / t / 1e6, 1),
+                           peak=PEAK_HBM_GBS, unit="GB/s", frac=round(nbytes / t / 1e6 / PEAK_HBM_GBS, 4), algorithmic_bytes=int(nbytes), traffic=None))
+            gsrc = eng.g_flow[k] if k != 2 else torch.zeros_like(eng.flow[2])
+            nbytes_b = chunks * src.M * 32 * 4 * (1 if k in (2, 6) else 2) + B * 2 * src.H * src.W * 4
+            t = event_time(lambda: eng._pf_backward(k, gsrc, accumulate=k not in (2, 6)), 10)
+            ks.append(dict(kernel=f"flow_head_planes_bwd predict_flow{k}", ms=round(t, 4), bound="hbm", achieved=round(nbytes_b / t / 1e6, 1),
+                           peak=PEAK_HBM_GBS, unit="GB/s", frac=round(nbytes_b / t / 1e6 / PEAK_HBM_GBS, 4), algorithmic_bytes=int(nbytes_b), traffic=None))
+    # ---- the full-frame prefix of load() (conv1-3 on both frames of every pair: MIOpen fp32)
+    x = torch.rand(2 * B, 3, H, W, device=device)
+    with torch.no_grad():
+        t_p = event_time(lambda: step.net.encode(x), 5)
+    tf = GFLOP_PREFIX_FWD * B / t_p
+    ks.append(dict(kernel="MIOpen fp32 conv1-3, full frame, once per attack() call", ms=round(t_p, 4), bound="mfma", achieved=round(tf, 1),
+                   peak=PEAK_FP32_TFLOPS, unit="TFLOP/s", frac=round(tf / PEAK_FP32_TFLOPS, 3), gflop=round(GFLOP_PREFIX_FWD * B, 1), traffic=None))
+    return ks, agg
 
 
 def step_traffic():
     """HBM-side bytes of one iteration of the windowed step from this round's PMC passes
-    (tools/pmc_step_traffic.py -> profiles/r1_step_traffic.json); counters cannot be read live."""
+    (tools/pmc_step_traffic.py -> profiles/r2_step_traffic.json); counters cannot be read live."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_step_traffic.json")) as f:
-            return int(json.load(f)["traffic_bytes_per_iteration"])
-    except (OSError, KeyError, ValueError):
+        return int(_pmc("r2_step_traffic.json")["traffic_bytes_per_iteration"])
+    except (KeyError, ValueError):
         return None
 
 
@@ -178,12 +229,15 @@ def cpu_baseline():
     predict = lambda x, y: fo.flownetc_forward(sd, x, y)
     with torch.no_grad():
         target = -predict(tgt, ref)           # clean forward doubles as the warm-up (main.py:371,395)
+        t1 = time.time()
+        predict(tgt, ref)                     # configs[0] (C1): FlowNetC forward on one 384x1280 pair, CPU only
+        c1 = time.time() - t1
     t0, n, calls = time.time(), 0, 0
     while time.time() - t0 < 12.0:            # bounded sample: ~12 s of CPU work
         _, _, _, k, _ = fo.patch_attack(predict, tgt, ref, patch0.clone(), mask, patch0, target, lr=1e3, max_count=2)
         n, calls = n + k, calls + 1
     dt = time.time() - t0
-    return dict(value=round(n / dt, 4), unit="frame-pairs*steps/s", cores=cores, kind="port",
+    return dict(value=round(n / dt, 4), unit="frame-pairs*steps/s", cores=cores, kind="port", c1_cpu_forward_s=round(c1, 3),
                 sample=f"{calls} attack() calls of 2 iterations ({n} iterations), 1 pair 384x1280 (the reference's "
                        f"batch size), FlowNetC fp32, torch-CPU convs + C oracle correlation (OpenMP over "
                        f"batch*channels; the reference's CPU backward is single-threaded at batch 1), {dt:.1f} s")
@@ -308,14 +362,32 @@ def main():
                        "graph": not opt.no_graph,
                        "parallelism": (f"dp{world}: pairs sharded, per-rank crop of the pre-clamp gradient to [3,51,51], "
                                        f"all-gather of {world} x 31 KB rows + fixed-order sum before the clamp")},
-            "roofline": {"bound": "mfma", "kernel": "attack step = 1 hipGraph launch (MIOpen fp32 convs + ufr_* kernels)",
-                         "achieved": round(tf, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(tf / PEAK_FP32_TFLOPS, 4), "traffic": step_traffic(),
-                         "algorithmic_gflop_per_launch": round(gflop * B_PER_GPU, 1),
+            "roofline": {"bound": "mfma", "kernel": "attack step = 1 hipGraph launch", "achieved": round(tf, 2),
+                         "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_TFLOPS, 4),
+                         "traffic": step_traffic(), "algorithmic_gflop_per_launch": round(gflop * B_PER_GPU, 1),
                          "full_frame_gflop_per_launch": round(GFLOP_PER_PAIR_STEP * B_PER_GPU, 1)},
         }
+        engine_on = bool(getattr(net, "__dict__", {}).get("_ufr_head_engines"))
+        line["config"]["arithmetic"] = (
+            "float32 end to end; the head's convolutions compute each float32 product on the bf16 matrix cores as three bf16 "
+            "planes per operand and the six leading products, float32 accumulation (csrc/igemm.hip: error vs float64 at "
+            "MIOpen's own fp32 level, tests/test_igemm_gpu.py); conv1-3 on MIOpen fp32" if engine_on else
+            "float32 end to end on MIOpen (UFR_ENGINE=0)")
         if world == 1:
-            line["roofline"]["kernels"] = kernel_rooflines(device)
+            kernels, agg = kernel_rooflines(step, device, mc)
+            step_line = line["roofline"]
+            if agg is not None:
+                # the dominant kernel: csrc/igemm.hip over the launches of one average iteration (live HIP-event timings)
+                tf_i = agg["gflop"] / agg["ms"]
+                line["roofline"] = {"bound": "mfma", "kernel": "igemm (csrc/igemm.hip), all launches of one iteration",
+                                    "achieved": round(tf_i, 1), "peak": round(PEAK_SPLIT6_TFLOPS, 1), "unit": "TFLOP/s",
+                                    "frac": round(tf_i / PEAK_SPLIT6_TFLOPS, 3),
+                                    "traffic": _pmc("r2_igemm_traffic.json").get("per_iteration_bytes"),
+                                    "ms_per_iteration": round(agg["ms"], 3), "algorithmic_gflop_per_iteration": round(agg["gflop"], 1),
+                                    "peak_note": "fp32-equivalent: 2.5 PFLOP/s dense bf16 MFMA / 6 products per float32 product",
+                                    "step": step_line}
+            line["roofline"]["kernels"] = kernels
+            line["config"]["other_configs"] = _pmc("r2_configs.json") or None
             if step.cone is not None and not opt.no_full_frame:
                 # the same protocol with every frame-sized shortcut off (UFR_CONE=0): what the windowed prefix,
                 # band and incremental forward are worth, measured in this very process
@@ -336,6 +408,7 @@ def main():
                 line["config"]["full_frame_attack_iters_per_s"] = round(B_PER_GPU * k / (time.perf_counter() - t1), 2)
             if not opt.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline()
+                line["config"]["c1_cpu_forward_s"] = line["cpu_baseline"].get("c1_cpu_forward_s")
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -26,13 +26,22 @@ def per_iteration(path, counter, iters):
     lo, hi = marks[-iters - 1] + 1, marks[-1] + 1
     per_kernel = defaultdict(float)
     for n, v in zip(names[lo:hi], vals[lo:hi]):
-        per_kernel[n.split("(")[0][-60:]] += v / iters
+        per_kernel[n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:60]] += v / iters
     return sum(vals[lo:hi]) / iters, per_kernel
 
 
-def main(fetch_csv, write_csv, iters):
+def main(fetch_csv, write_csv, iters, igemm_out=None):
     f_kb, f_k = per_iteration(fetch_csv, "FETCH_SIZE", iters)
     w_kb, w_k = per_iteration(write_csv, "WRITE_SIZE", iters)
+    if igemm_out:
+        # the dominant kernel class alone (csrc/igemm.hip, both staging variants, + its split-K reduce)
+        fi = sum(v for k, v in f_k.items() if "igemm" in k)
+        wi = sum(v for k, v in w_k.items() if "igemm" in k)
+        with open(igemm_out, "w") as f:
+            json.dump({"_provenance": "igemm_* dispatches of the same two rocprofv3 --pmc passes as r2_step_traffic.json, per "
+                                      "iteration; KB -> bytes, FETCH_SIZE x2 per MI355X_MICROARCH.md",
+                       "fetch_bytes": round(2.0 * fi * 1024), "write_bytes": round(wi * 1024),
+                       "per_iteration_bytes": round(2.0 * fi * 1024 + wi * 1024)}, f, indent=1)
     fetch_b, write_b = 2.0 * f_kb * 1024.0, w_kb * 1024.0              # FETCH_SIZE doubled on gfx950
     out = {"_provenance": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes with --kernel-trace only, over "
                           "bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-full-frame; mean over the last %d iterations "
@@ -46,4 +55,4 @@ def main(fetch_csv, write_csv, iters):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 4)
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 4, sys.argv[4] if len(sys.argv) > 4 else None)
