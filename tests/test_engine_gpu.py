@@ -129,3 +129,36 @@ def test_engine_banded_step_equals_full_frame_torch_step(net, monkeypatch):
         print(f"engine windowed step vs full-frame torch step: worst {float(err.max()) / upd:.2e} of the update, {off:.2%} beyond 1e-4")
         assert nf == ne and abs(lf - le) <= 1e-4 * max(abs(lf), 1.0)
         assert off <= 0.05 and float(err.max()) <= 5e-3 * upd
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 194, 96, 320), (16, 70, 20, 100), (1, 386, 48, 160), (2, 1026, 12, 40), (3, 37, 7, 9)])
+def test_flow_head_planes_kernels_vs_torch(B, C, H, W):
+    """csrc/engine_small.hip: predict_flow (Conv2d(C,2,3,1,1)) on the chunk-major planes -- the LDS-tiled kernel of the big
+    grids, the per-pixel kernel of the small ones, ragged tiles -- and its data gradient (write and accumulate), against
+    torch in float64."""
+    import torch.nn.functional as F
+    from understanding_flow_robustness_amd import _lib as L
+    from understanding_flow_robustness_amd import igemm as ig
+    from understanding_flow_robustness_amd.flownetc_engine import _pack_flow_head
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C, H, W, generator=g).to(DEV)
+    w = (torch.randn(2, C, 3, 3, generator=g) * 0.1).to(DEV)
+    b = torch.randn(2, generator=g).to(DEV)
+    chunks = ig.pad32(C) // 32
+    pl = ig.Planes(B, H, W, chunks + 1, DEV).load_nchw(x, chunk0=1)
+    wpk = _pack_flow_head(w)
+    out = torch.empty(B, 2, H, W, device=DEV)
+    L.check(L.lib().ufr_flow_head_planes_forward(L.ptr(pl.t), pl.plane_stride, 1, chunks, L.ptr(wpk), L.ptr(b), L.ptr(out), B, H, W,
+                                                 L.stream()))
+    want = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    assert _rel(out, want) <= 1e-5, f"forward {_rel(out, want):.2e}"
+    gy = torch.randn(B, 2, H, W, generator=g).to(DEV)
+    x0 = torch.zeros(B, C, H, W, device=DEV, dtype=torch.float64, requires_grad=True)
+    (gx,) = torch.autograd.grad(F.conv2d(x0, w.double(), None, 1, 1), x0, gy.double())
+    G = ig.GradSum(B, H, W, chunks + 1, DEV)
+    G.t.fill_(0.5)
+    L.check(L.lib().ufr_flow_head_planes_backward(L.ptr(gy), L.ptr(wpk), L.ptr(G.t), 1, chunks, B, H, W, 0, L.stream()))
+    assert _rel(G.to_nchw(C, 1), gx) <= 1e-5
+    assert bool((G.t[0] == 0.5).all())                                   # the neighbouring chunk is untouched
+    L.check(L.lib().ufr_flow_head_planes_backward(L.ptr(gy), L.ptr(wpk), L.ptr(G.t), 1, chunks, B, H, W, 1, L.stream()))
+    assert _rel(G.to_nchw(C, 1), 2 * gx) <= 1e-5

@@ -24,9 +24,86 @@ __device__ __forceinline__ void split3(float v, __bf16& a, __bf16& b, __bf16& c)
 }
 
 // wpk [chunks][9][2][32] float32: wpk[ch][k][o][c] = weight[o][32*ch + c][k] (zero for padding channels).
-// Workgroup = 64 pixels x 4 channel groups x S chunk slices (256*S threads); the layer's weights are staged in LDS once
-// per workgroup (at most 33 chunks x 2304 B); slices are added through LDS in ascending order (deterministic).
+// Workgroup = an 8 x 32 pixel tile of one image (thread = pixel, all 32 channels of a chunk) x S chunk slices.  Per chunk
+// the tile + its 1-pixel halo (10 x 34 pixels, zero outside the frame) is fetched ONCE -- three 16-byte plane reads per
+// 8 channels -- summed to float32 and kept in LDS; the nine taps then read LDS.  Global traffic = the planes once
+// (x 1.33 for the halo) instead of nine times through L1/L2.  Slices are added through LDS in ascending order.
+constexpr int PF_TH = 8, PF_TW = 32, PF_HH = PF_TH + 2, PF_HW = PF_TW + 2, PF_CS = 36;   // channel stride 36 floats: conflict-free taps
 __global__ __launch_bounds__(1024) void flow_head_planes_fwd(const __bf16* __restrict__ x, long plane_stride, int chunk0,
+                                                             int chunks, const float* __restrict__ wpk,
+                                                             const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                             int H, int W, int S) {
+  extern __shared__ __attribute__((aligned(16))) float lds_pf[];   // [S][PF_HH*PF_HW][PF_CS] tiles | [S][576] weights | [S][256][2]
+  const long M = (long)B * H * W;
+  const int tid = threadIdx.x, slice = tid >> 8, t = tid & 255;
+  float* tile = lds_pf + (long)slice * (PF_HH * PF_HW * PF_CS);
+  float* wl = lds_pf + (long)S * (PF_HH * PF_HW * PF_CS) + slice * 576;
+  float* part = lds_pf + (long)S * (PF_HH * PF_HW * PF_CS + 576);
+  const int tiles_x = (W + PF_TW - 1) / PF_TW, tiles_y = (H + PF_TH - 1) / PF_TH;
+  const int b = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x - b * tiles_x * tiles_y;
+  const int y0 = (tr / tiles_x) * PF_TH, x0 = (tr % tiles_x) * PF_TW;
+  const int ly = t / PF_TW, lx = t - ly * PF_TW;                     // this thread's pixel inside the tile
+  const int per = (chunks + S - 1) / S, c_lo = slice * per, c_hi = min(chunks, c_lo + per);
+  float a0 = 0.f, a1 = 0.f;
+  for (int ch = c_lo; ch < c_lo + per; ++ch) {                       // uniform trip count: the barriers stay aligned
+    const bool work = ch < c_hi;
+    __syncthreads();                                                  // previous chunk's taps are done
+    if (work) {
+      // stage: 340 halo pixels x 4 pieces of 8 channels = 1360 items over 256 threads
+      for (int it = t; it < PF_HH * PF_HW * 4; it += 256) {
+        const int hp = it >> 2, q = it & 3, hy = hp / PF_HW, hx = hp - hy * PF_HW;
+        const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+          const __bf16* src = x + (((long)(chunk0 + ch) * M) + ((long)b * H + yy) * W + xx) * 32 + q * 8;
+          const bf16x8 p0 = *reinterpret_cast<const bf16x8*>(src);
+          const bf16x8 p1 = *reinterpret_cast<const bf16x8*>(src + plane_stride);
+          const bf16x8 p2 = *reinterpret_cast<const bf16x8*>(src + 2 * plane_stride);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = ((float)p0[j] + (float)p1[j]) + (float)p2[j];
+        }
+        float4* dst = reinterpret_cast<float4*>(tile + hp * PF_CS + q * 8);
+        dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+        dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+      }
+      for (int i = t; i < 576 / 4; i += 256) reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(wpk + (long)ch * 576)[i];
+    }
+    __syncthreads();
+    if (work) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const float* px = tile + ((ly + k / 3) * PF_HW + lx + k % 3) * PF_CS;
+        const float* w0 = wl + (k * 2 + 0) * 32;
+        const float* w1 = wl + (k * 2 + 1) * 32;
+#pragma unroll
+        for (int c4 = 0; c4 < 8; ++c4) {
+          const float4 v = *reinterpret_cast<const float4*>(px + c4 * 4);
+          const float4 u0 = *reinterpret_cast<const float4*>(w0 + c4 * 4), u1 = *reinterpret_cast<const float4*>(w1 + c4 * 4);
+          a0 = fmaf(v.x, u0.x, a0); a0 = fmaf(v.y, u0.y, a0); a0 = fmaf(v.z, u0.z, a0); a0 = fmaf(v.w, u0.w, a0);
+          a1 = fmaf(v.x, u1.x, a1); a1 = fmaf(v.y, u1.y, a1); a1 = fmaf(v.z, u1.z, a1); a1 = fmaf(v.w, u1.w, a1);
+        }
+      }
+    }
+  }
+  part[(slice * 256 + t) * 2 + 0] = a0;
+  part[(slice * 256 + t) * 2 + 1] = a1;
+  __syncthreads();
+  const int yy = y0 + ly, xx = x0 + lx;
+  if (slice == 0 && yy < H && xx < W) {
+    float r0 = 0.f, r1 = 0.f;
+    for (int sl = 0; sl < S; ++sl) {
+      r0 += part[(sl * 256 + t) * 2 + 0];
+      r1 += part[(sl * 256 + t) * 2 + 1];
+    }
+    const long HW = (long)H * W, p = (long)yy * W + xx;
+    out[((long)b * 2 + 0) * HW + p] = r0 + bias[0];
+    out[((long)b * 2 + 1) * HW + p] = r1 + bias[1];
+  }
+}
+
+// Small grids (1/16 resolution and coarser): thread = (pixel, 8-channel group) x S chunk slices, taps straight from L1 / L2,
+// the layer's weights in LDS; slices added through LDS in ascending order.
+__global__ __launch_bounds__(1024) void flow_head_planes_fwd_small(const __bf16* __restrict__ x, long plane_stride, int chunk0,
                                                              int chunks, const float* __restrict__ wpk,
                                                              const float* __restrict__ bias, float* __restrict__ out, int B,
                                                              int H, int W, int S) {
@@ -224,19 +301,31 @@ extern "C" int ufr_flow_head_planes_forward(const void* planes, long plane_strid
   UFR_REQUIRE(planes && wpk && bias && out, "flow head (planes) forward: null pointer");
   UFR_REQUIRE(B > 0 && H > 0 && W > 0 && chunks > 0 && chunks <= 48 && chunk0 >= 0 && (long)B * H * W < (1L << 29),
               "flow head (planes) forward: bad shape");
-  const long M = (long)B * H * W;
-  const int blocks = ufr::ceil_div(M, 64);
-  int S = 1;                                  // chunk slices per workgroup: more threads on the small grids
-  while (S < 4 && (long)blocks * S * 2 <= 2048 && chunks >= 4 * S) S *= 2;
-  const size_t lds = (size_t)chunks * 576 * 4 + (size_t)S * 64 * 2 * 4;
+  const int blocks = B * ufr::ceil_div(H, PF_TH) * ufr::ceil_div(W, PF_TW);
+  hipStream_t st = ufr::as_stream(stream);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flow_head_planes_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 576 * 4 + 4 * 64 * 2 * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flow_head_planes_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (2 * (PF_HH * PF_HW * PF_CS + 576) + 2 * 256 * 2) * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flow_head_planes_fwd_small), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              48 * 576 * 4 + 4 * 64 * 2 * 4);
     attr_set = true;
   }
-  flow_head_planes_fwd<<<blocks, 256 * S, lds, ufr::as_stream(stream)>>>(
-      static_cast<const __bf16*>(planes), plane_stride, chunk0, chunks, wpk, bias, out, B, H, W, S);
-  return ufr::launched("flow_head_planes_fwd");
+  if (blocks >= 192) {                        // big grids: LDS-tiled kernel, the planes are fetched once
+    const int S = (blocks < 512 && chunks >= 8) ? 2 : 1;
+    const size_t lds = ((size_t)S * (PF_HH * PF_HW * PF_CS + 576) + (size_t)S * 256 * 2) * 4;
+    flow_head_planes_fwd<<<blocks, 256 * S, lds, st>>>(static_cast<const __bf16*>(planes), plane_stride, chunk0, chunks, wpk, bias,
+                                                       out, B, H, W, S);
+    return ufr::launched("flow_head_planes_fwd");
+  }
+  const long M = (long)B * H * W;
+  const int sblocks = ufr::ceil_div(M, 64);
+  int S = 1;                                  // chunk slices per workgroup: more threads on the small grids
+  while (S < 4 && (long)sblocks * S * 2 <= 2048 && chunks >= 4 * S) S *= 2;
+  const size_t lds = (size_t)chunks * 576 * 4 + (size_t)S * 64 * 2 * 4;
+  flow_head_planes_fwd_small<<<sblocks, 256 * S, lds, st>>>(static_cast<const __bf16*>(planes), plane_stride, chunk0, chunks, wpk,
+                                                           bias, out, B, H, W, S);
+  return ufr::launched("flow_head_planes_fwd_small");
 }
 
 extern "C" int ufr_flow_head_planes_backward(const float* grad_y, const float* wpk, float* G, int chunk0, int chunks, int B,
