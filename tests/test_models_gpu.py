@@ -238,12 +238,20 @@ def test_raft_gradient_against_float64_truth(alternate, oracle):
         return flow.detach().double().cpu(), g1.double().cpu(), g2.double().cpu()
 
     truth = oracle_run("cpu", torch.float64)
-    same_dev = oracle_run(DEV, torch.float32)
-    gpu64 = oracle_run(DEV, torch.float64)
-    x1, x2 = t(z["x1"], DEV).requires_grad_(True), t(z["x2"], DEV).requires_grad_(True)
-    flow = predict_flow(net, None, x1, x2, args)
-    loss = (1 - torch.nn.functional.cosine_similarity(flow, t(z["target"], DEV))).mean()
-    g1, g2 = torch.autograd.grad(loss, (x1, x2))
+    # MIOpen's find step (cudnn.benchmark, switched on by earlier tests of this process) picks different fp32 kernels for
+    # differently shaped calls; with it off the product and the pure-torch spelling run the same convolution kernels and
+    # differ only by the hand-written lookup / GRU / upsampling kernels
+    bench_mode = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = False
+    try:
+        same_dev = oracle_run(DEV, torch.float32)
+        gpu64 = oracle_run(DEV, torch.float64)
+        x1, x2 = t(z["x1"], DEV).requires_grad_(True), t(z["x2"], DEV).requires_grad_(True)
+        flow = predict_flow(net, None, x1, x2, args)
+        loss = (1 - torch.nn.functional.cosine_similarity(flow, t(z["target"], DEV))).mean()
+        g1, g2 = torch.autograd.grad(loss, (x1, x2))
+    finally:
+        torch.backends.cudnn.benchmark = bench_mode
     mine = (flow.detach().double().cpu(), g1.double().cpu(), g2.double().cpu())
     cpu32 = (t(z["flow"]).double(), t(z["g1"]).double(), t(z["g2"]).double())
     rel = lambda a, b, i: float((a[i] - b[i]).abs().max()) / float(truth[i].abs().max())
@@ -261,7 +269,8 @@ def test_raft_gradient_against_float64_truth(alternate, oracle):
             # convolutions and batches the encoders), so MIOpen's fp32 kernels differ and the conditioning of the
             # gradient (1e-2 class, above) amplifies that: measured 6e-6 with the find step off, 1e-3 with it on.  A
             # wrong lookup / GRU / upsampling adjoint would be off by O(1).
-            assert e_same <= 5e-3, f"{name}: product vs pure-torch spelling on the same device {e_same:.2e}"
+            assert e_same <= max(5e-3, RAFT_F64_FACTOR * max(noise, e_torch)) if i else e_same <= 1e-5, \
+                f"{name}: product vs pure-torch spelling on the same device {e_same:.2e}"
         if i == 0:
             assert e_mine <= 1e-5
         else:
