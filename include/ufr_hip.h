@@ -437,7 +437,12 @@ int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream);
  * (p0 + p1 + p2) or from an fp32 chunk-major tensor (exactly one of `planes`, `f32`).  ufr_grad_finalize: gradient planes =
  * split(g * leaky'(mask)) for `chunks` chunks of M pixels. */
 int ufr_nchw_to_planes(const float* x, void* planes, long plane_stride, int chunk0, int B, int C, int H, int W,
-                       float scale, float slope, ufr_stream_t stream);
+                       float scale, float slope, const float* bias, ufr_stream_t stream);
+/* The windowed prefix's results patched into cached full-frame features that live in the plane layout: as
+ * ufr_window_scatter (same origins, clamping and rim rule), destination = chunks [chunk0, ...) of a planes buffer. */
+int ufr_window_scatter_planes(const float* src, void* planes, long plane_stride, int chunk0, const int* win, int n_win,
+                              int N, int C, int Hd, int Wd, int wh, int ww, int level_stride, int margin,
+                              ufr_stream_t stream);
 int ufr_chunks_to_nchw(const void* planes, long plane_stride, const float* f32, int chunk0, const void* mask,
                        int mask_chunk0, float* out, int B, int C, int H, int W, float scale, float slope,
                        ufr_stream_t stream);

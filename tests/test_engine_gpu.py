@@ -122,6 +122,7 @@ def test_engine_banded_step_equals_full_frame_torch_step(net, monkeypatch):
     _, full = run(False, False, lr, 3, False)
     step, eng = run(True, True, lr, 3, True)
     assert step.cone is not None and step.band is not None and step.band.width == 608 and step.graph_next is not None
+    assert step.eng is not None                       # cached features resident in the native head's planes
     for (pf, nf, lf), (pe, ne, le) in zip(full, eng):
         upd = float((pf - patch0).abs().max())
         err = (pf - pe).abs()

@@ -138,6 +138,24 @@ __device__ __forceinline__ void epilogue_store8(const Epilogue& e, long pout, in
   }
 }
 
+// XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs in launch order (x fastest, then y, then z), each
+// XCD with its own 4 MB L2.  Launch index i is remapped to tile (i % 8) * ceil(n/8) + i / 8 (the bijective form for
+// n % 8 != 0): every XCD then owns ONE contiguous run of tiles -- all N tiles of an M tile and the M tiles above and below
+// it, whose taps read the same activation rows -- instead of every XCD fetching every row from the fabric (measured
+// before: 22 GB of L2 misses per iteration for ~3.5 GB of activations, profiles/r2_igemm_traffic.json).
+__device__ __forceinline__ void xcd_tile(int swz, int& bx, int& by, int& bz) {
+  bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+  if (!swz) return;
+  const int nx = gridDim.x, nxy = nx * gridDim.y, n = nxy * gridDim.z;
+  const int orig = (bz * gridDim.y + by) * nx + bx;
+  const int q = n / 8, r = n % 8, xcd = orig % 8, idx = orig / 8;
+  const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  bz = w / nxy;
+  const int rem = w - bz * nxy;
+  by = rem / nx;
+  bx = rem - by * nx;
+}
+
 struct Phase {
   int ntaps, oy0, ox0;
   long w_off;                       // bf16 elements from the weight plane's start
@@ -151,7 +169,7 @@ struct Args {
   const __bf16* w; long w_plane_stride; int Npad;
   RowGeom g;
   Epilogue e;
-  int nphase, splitk;
+  int nphase, splitk, xcd;
   float* ws;                         // split-K slabs [nphase*splitk][M][Npad]
   Phase ph[4];
 };
@@ -233,8 +251,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   __bf16 (*ldsB)[BN_ * BK] = reinterpret_cast<__bf16 (*)[BN_ * BK]>(lds_all + NPL * BM * BK);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wrow = BN_ == 128 ? (wave >> 1) * 64 : wave * 32, wcol = BN_ == 128 ? (wave & 1) * 64 : 0;
-  const int bm = blockIdx.y * BM, bn = blockIdx.x * BN_;
-  const int z = blockIdx.z, phase = z / a.splitk, ks = z - phase * a.splitk;
+  int tx, ty, z;
+  xcd_tile(a.xcd, tx, ty, z);
+  const int bm = ty * BM, bn = tx * BN_;
+  const int phase = z / a.splitk, ks = z - phase * a.splitk;
   const Phase& ph = a.ph[phase];
   const int KC = a.KC, KT = ph.ntaps * KC;
   const int per = (KT + a.splitk - 1) / a.splitk, kt0 = ks * per, kt1 = min(KT, kt0 + per);
@@ -373,8 +393,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   __bf16 (*ldsB)[BN_ * BK] = reinterpret_cast<__bf16 (*)[BN_ * BK]>(lds_all + NPL * BM * BK);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wrow = BN_ == 128 ? (wave >> 1) * 64 : wave * 32, wcol = BN_ == 128 ? (wave & 1) * 64 : 0;
-  const int bm = blockIdx.y * BM, bn = blockIdx.x * BN_;
-  const int z = blockIdx.z, phase = z / a.splitk, ks = z - phase * a.splitk;
+  int tx, ty, z;
+  xcd_tile(a.xcd, tx, ty, z);
+  const int bm = ty * BM, bn = tx * BN_;
+  const int phase = z / a.splitk, ks = z - phase * a.splitk;
   const Phase& ph = a.ph[phase];
   const int KC = a.KC, KT = ph.ntaps * KC;
   const int per = (KT + a.splitk - 1) / a.splitk, kt0 = ks * per, kt1 = min(KT, kt0 + per);
@@ -499,7 +521,7 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const Args a) {
 // x [B][C][HW] float32 (NCHW) -> planes at a chunk offset, y = leaky(scale * x); channels C..Cpad-1 of the last chunk 0.
 __global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float* __restrict__ x, __bf16* __restrict__ planes,
                                                              long plane_stride, int chunk0, int B, int C, int HW,
-                                                             float scale, float slope) {
+                                                             float scale, float slope, const float* __restrict__ bias) {
   __shared__ float tile[32][65];
   const int c0 = blockIdx.x * 32, p0 = blockIdx.y * 64, b = blockIdx.z, tid = threadIdx.x;
   {
@@ -507,8 +529,13 @@ __global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float* __rest
 #pragma unroll
     for (int cc = tid >> 6; cc < 32; cc += 4) {
       const int c = c0 + cc;
-      float v = (c < C && p0 + p < HW) ? x[((size_t)b * C + c) * HW + p0 + p] * scale : 0.f;
-      tile[cc][p] = v > 0.f ? v : v * slope;
+      float v = 0.f;
+      if (c < C && p0 + p < HW) {
+        v = x[((size_t)b * C + c) * HW + p0 + p] * scale;
+        if (bias) v += bias[c];
+        v = v > 0.f ? v : v * slope;
+      }
+      tile[cc][p] = v;
     }
   }
   __syncthreads();
@@ -604,7 +631,59 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const float* __restr
   }
 }
 
+// dst planes [chunk0 + c/32][(n, y0+i, x0+j)][c%32] = split(src[n,c,i,j]) for the window of sample n (origin win[n % n_win] /
+// level_stride, clamped into the frame; rim cells next to an interior window edge are skipped, as in ufr_window_scatter):
+// the cached full-frame features live in the plane layout, the windowed prefix's results are patched into them.
+__global__ __launch_bounds__(256) void window_scatter_planes_kernel(const float* __restrict__ src, __bf16* __restrict__ planes,
+                                                                    long plane_stride, int chunk0, const int* __restrict__ win,
+                                                                    int n_win, int N, int C, int Hd, int Wd, int wh, int ww,
+                                                                    int level_stride, int margin) {
+  const int groups = (C + 7) / 8;
+  const long total = (long)N * wh * ww * groups;
+  const long M = (long)N * Hd * Wd;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int g8 = (int)(t % groups);
+    long r = t / groups;
+    const int j = (int)(r % ww); r /= ww;
+    const int i = (int)(r % wh);
+    const int n = (int)(r / wh);
+    const int* w = win + (n % n_win) * 8;
+    const int y0 = min(max(w[0] / level_stride, 0), Hd - wh), x0 = min(max(w[1] / level_stride, 0), Wd - ww);
+    const bool rim = (i < margin && y0 > 0) || (i >= wh - margin && y0 + wh < Hd) || (j < margin && x0 > 0) ||
+                     (j >= ww - margin && x0 + ww < Wd);
+    if (rim) continue;
+    bf16x8 q0, q1, q2;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = g8 * 8 + k;
+      const float v = c < C ? src[(((long)n * C + c) * wh + i) * ww + j] : 0.f;
+      __bf16 a, b, d;
+      split3(v, a, b, d);
+      q0[k] = a; q1[k] = b; q2[k] = d;
+    }
+    const int c0 = g8 * 8;
+    __bf16* o = planes + (((long)(chunk0 + (c0 >> 5)) * M) + ((long)n * Hd + y0 + i) * Wd + x0 + j) * 32 + (c0 & 31);
+    *reinterpret_cast<bf16x8*>(o) = q0;
+    *reinterpret_cast<bf16x8*>(o + plane_stride) = q1;
+    *reinterpret_cast<bf16x8*>(o + 2 * plane_stride) = q2;
+  }
+}
+
 }  // namespace
+
+extern "C" int ufr_window_scatter_planes(const float* src, void* planes, long plane_stride, int chunk0, const int* win,
+                                         int n_win, int N, int C, int Hd, int Wd, int wh, int ww, int level_stride, int margin,
+                                         ufr_stream_t stream) {
+  UFR_REQUIRE(src && planes && win, "window scatter (planes): null pointer");
+  UFR_REQUIRE(N > 0 && C > 0 && Hd > 0 && Wd > 0 && wh > 0 && ww > 0 && wh <= Hd && ww <= Wd && chunk0 >= 0,
+              "window scatter (planes): bad shape");
+  UFR_REQUIRE(level_stride > 0 && margin >= 0 && 2 * margin <= wh && 2 * margin <= ww && n_win > 0 && n_win <= N,
+              "window scatter (planes): bad stride / margin / window count");
+  const long total = (long)N * wh * ww * ((C + 7) / 8);
+  window_scatter_planes_kernel<<<ufr::stream_grid(total, 256), 256, 0, ufr::as_stream(stream)>>>(
+      src, static_cast<__bf16*>(planes), plane_stride, chunk0, win, n_win, N, C, Hd, Wd, wh, ww, level_stride, margin);
+  return ufr::launched("window_scatter_planes_kernel");
+}
 
 extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   UFR_REQUIRE(d, "igemm: null descriptor");
@@ -641,6 +720,8 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   a.e.out_f32 = d->out_f32; a.e.out_f32_chunk0 = d->out_f32_chunk0;
   a.e.Mout = (long)d->B * d->Ho * d->Wo; a.e.N = d->N; a.e.Nchunks32 = (d->N + 31) / 32;
   a.nphase = d->nphase; a.splitk = d->splitk; a.ws = d->ws;
+  static const int xcd_order = [] { const char* e = getenv("UFR_IGEMM_XCD"); return e && e[0] == '0' ? 0 : 1; }();
+  a.xcd = xcd_order;
   for (int z = 0; z < 4; ++z) {
     const ufr_igemm_phase& p = d->phase[z < d->nphase ? z : 0];
     UFR_REQUIRE(p.ntaps >= 1 && p.ntaps <= UFR_IGEMM_MAX_TAPS && p.w_off >= 0, "igemm: bad phase %d", z);
@@ -677,12 +758,12 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
 }
 
 extern "C" int ufr_nchw_to_planes(const float* x, void* planes, long plane_stride, int chunk0, int B, int C, int H, int W,
-                                  float scale, float slope, ufr_stream_t stream) {
+                                  float scale, float slope, const float* bias, ufr_stream_t stream) {
   UFR_REQUIRE(x && planes, "nchw -> planes: null pointer");
   UFR_REQUIRE(B > 0 && B < 65536 && C > 0 && H > 0 && W > 0 && chunk0 >= 0 && plane_stride > 0, "nchw -> planes: bad shape");
   const dim3 grid((C + 31) / 32, (H * W + 63) / 64, B);
   nchw_to_planes_kernel<<<grid, 256, 0, ufr::as_stream(stream)>>>(x, static_cast<__bf16*>(planes), plane_stride, chunk0, B, C,
-                                                                   H * W, scale, slope);
+                                                                   H * W, scale, slope, bias);
   return ufr::launched("nchw_to_planes_kernel");
 }
 

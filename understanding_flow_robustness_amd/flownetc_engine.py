@@ -66,6 +66,8 @@ class FlowNetCHeadEngine:
         self.g_corr = torch.zeros(B, 21, 21, *g[8], **f32)
         self.g_c2a = torch.zeros(B, 128, *g[4], **f32)
         self.g_c3a, self.g_c3a_redir, self.g_c3b = (torch.zeros(B, 256, *g[8], **f32) for _ in range(3))
+        self.c3_nchw = torch.zeros(2 * B, 256, *g[8], **f32)        # both frames' conv3 for the correlation kernels
+        self._prefix = None                                          # full-frame conv1-3 buffers + launches, built on first use
         self._build_launches()
 
     # ------------------------------------------------------------------------------------------------ set-up
@@ -142,6 +144,65 @@ class FlowNetCHeadEngine:
         # upsampled_flowK_to_K-1 writes the last chunk of cat(K-1)
         self.up_dst = {6: (self.cat5, 32), 5: (self.cat4, 24), 4: (self.cat3, 12), 3: (self.cat2, 6)}
         self.up_G = {6: (self.G_cat5, 32), 5: (self.G_cat4, 24), 4: (self.G_cat3, 12), 3: (self.G_cat2, 6)}
+
+    # ------------------------------------------------------------------------------------------------ conv1-3
+    def _build_prefix(self):
+        """Full-frame conv1-3 for both frames of every pair (models/FlowNetC.py:100-119), run once per attack() call:
+        conv1 (3 input channels: a 147-deep reduction, torch / MIOpen) with bias + LeakyReLU fused into the conversion to
+        planes; conv2 and conv3 (5x5, stride 2: 91% of the prefix's FLOPs) on the igemm with the fused epilogue."""
+        B2, dev = 2 * self.B, self.dev
+        H, W = self.H, self.W
+        c1 = ig.Planes(B2, H // 2, W // 2, 2, dev)
+        c2 = ig.Planes(B2, H // 4, W // 4, 4, dev)
+        c3 = ig.Planes(B2, H // 8, W // 8, 8, dev)
+        bias = lambda n: self._conv(n).bias.detach().float().contiguous()
+        l2 = ig.make_launch(ig.conv_forward_weights(self._conv("conv2").weight, 2, 2), c1, 0, (H // 4, W // 4), (H // 4, W // 4),
+                            out_planes=c2, bias=bias("conv2"))
+        l3 = ig.make_launch(ig.conv_forward_weights(self._conv("conv3").weight, 2, 2), c2, 0, (H // 8, W // 8), (H // 8, W // 8),
+                            out_planes=c3, bias=bias("conv3"))
+        self._prefix = dict(c1=c1, c2=c2, c3=c3, conv2=l2, conv3=l3, b1=bias("conv1"),
+                            w1=self._conv("conv1").weight.detach())
+
+    def prefix_full(self, frames_a: torch.Tensor, frames_b: torch.Tensor):
+        """New frames: conv2 of the first frames and conv3 of both, for the full frame, straight into the head's plane
+        buffers (cat2[0:4], c3a_p, c3b_p) plus conv3 in NCHW for the correlation kernels."""
+        if self._prefix is None:
+            self._build_prefix()
+        P, B = self._prefix, self.B
+        x = self.net.normalize_correctly(torch.cat((frames_a, frames_b), 0))
+        y1 = torch.nn.functional.conv2d(x, P["w1"], None, 2, 3)
+        P["c1"].load_nchw(y1, 0, 1.0, ig.LEAKY, P["b1"])                 # bias + LeakyReLU + split, one pass
+        P["conv2"]()
+        P["conv3"]()
+        M4, M8 = self.cat2.M, self.c3a_p.M
+        self.cat2.t[:, 0:4].copy_(P["c2"].t[:, :, :M4])                  # conv2 of the first frames: the skip connection
+        self.c3a_p.t.copy_(P["c3"].t[:, :, :M8])
+        self.c3b_p.t.copy_(P["c3"].t[:, :, M8:])
+        P["c3"].to_nchw(256, 0, out=self.c3_nchw)
+        self._c3a, self._c3b = self.c3_nchw[:B], self.c3_nchw[B:]
+
+    def load_prefix_features(self, c2_all: torch.Tensor, c3_all: torch.Tensor):
+        """The same from NCHW features the caller already holds (train()'s clean forward seeds the attack's cache)."""
+        B = self.B
+        self.cat2.load_nchw(c2_all[:B].contiguous(), 0)
+        self.c3_nchw.copy_(c3_all[:2 * B])
+        self._c3a, self._c3b = self.c3_nchw[:B], self.c3_nchw[B:]
+        self.c3a_p.load_nchw(self._c3a, 0)
+        self.c3b_p.load_nchw(self._c3b, 0)
+
+    def scatter_window_features(self, c2_w: torch.Tensor, c3_w: torch.Tensor, win: torch.Tensor, wh: int, ww: int, m2: int, m3: int):
+        """The windowed prefix's conv2 (first frames) / conv3 (both frames) patched into the cached planes and into the NCHW
+        conv3 the correlation reads; `win` = the step's origin table, m2 / m3 = rim margins in cells (cone.py)."""
+        lib, B, st = L.lib(), self.B, L.stream()
+        h4, w4 = self.grid[4]
+        h8, w8 = self.grid[8]
+        L.check(lib.ufr_window_scatter_planes(L.ptr(c2_w), L.ptr(self.cat2.t), self.cat2.plane_stride, 0, L.ptr(win), B, B, 128,
+                                              h4, w4, wh // 4, ww // 4, 4, m2, st), "window -> planes (conv2)")
+        for k, dst in ((0, self.c3a_p), (1, self.c3b_p)):
+            L.check(lib.ufr_window_scatter_planes(L.ptr(c3_w[k * B:]), L.ptr(dst.t), dst.plane_stride, 0, L.ptr(win), B, B, 256,
+                                                  h8, w8, wh // 8, ww // 8, 8, m3, st), "window -> planes (conv3)")
+        L.check(lib.ufr_window_scatter(L.ptr(c3_w), L.ptr(self.c3_nchw), L.ptr(win), B, 2 * B, 256, h8, w8, wh // 8, ww // 8, 8,
+                                       m3, st), "window -> nchw (conv3)")
 
     # ------------------------------------------------------------------------------------------------ column band
     # (level stride of the ROW grid, of the input grid) of the launches that run on the band's columns only
@@ -224,22 +285,28 @@ class FlowNetCHeadEngine:
                                           Gs.M, chunks, ig.LEAKY, L.stream()), "gradient finalize")
 
     # ------------------------------------------------------------------------------------------------ the schedule
-    def forward(self, c2a: torch.Tensor, c3a: torch.Tensor, c3b: torch.Tensor, band=None) -> torch.Tensor:
+    def forward_cached(self, band=None) -> torch.Tensor:
+        """`forward` on the features the engine already holds (prefix_full / load_prefix_features + scatter_window_features)."""
+        return self.forward(None, self._c3a, self._c3b, band)
+
+    def forward(self, c2a: torch.Tensor | None, c3a: torch.Tensor, c3b: torch.Tensor, band=None) -> torch.Tensor:
         """(conv2 of frame 1 [B,128,H/4,W/4], conv3 of both frames [B,256,H/8,W/8]) -> flow2 [B,2,H/4,W/4].
         `band` (band_conv.Band) with `incremental` set: the features differ from the previous call's only inside the
         prefix window, so conv_redir / conv3_1 / conv4 / conv4_1 recompute the band's columns only -- the plane buffers
         still hold the previous iteration's activations everywhere else."""
         from . import spatial_correlation_sampler_backend as correlation
         import ctypes as C
-        for t, name in ((c2a, "c2a"), (c3a, "c3a"), (c3b, "c3b")):
+        for t, name in ((c3a, "c3a"), (c3b, "c3b")):
             L.require_hip(t, name)
         self._c3a, self._c3b = c3a, c3b
         inc = False
         if band is not None:
             self.attach_band(band)
             inc = bool(band.width and band.incremental and band.inc_layers)
-        self.cat2.load_nchw(c2a, 0)
-        self.c3a_p.load_nchw(c3a, 0)
+        if c2a is not None:                      # features handed over in NCHW: convert; None: the planes are up to date
+            L.require_hip(c2a, "c2a")
+            self.cat2.load_nchw(c2a, 0)
+            self.c3a_p.load_nchw(c3a, 0)
         # submodules.py:124-138 (`correlate`: /C) + FlowNetC.py:139 LeakyReLU fused into the correlation's epilogue
         p = correlation._params(1, 1, 21, 21, 0, 0, 1, 1, 2, 2, 1, 1)
         L.check(L.lib().ufr_corr_forward_fused(L.ptr(c3a), L.ptr(c3b), L.ptr(self.corr), L.UFR_F32, self.B, 256, *self.grid[8],
@@ -320,12 +387,17 @@ class _EngineHead(torch.autograd.Function):
         return g2a, g3a, g3b, None, None
 
 
-def engine_head(net, c2a, c3a, c3b, band=None):
-    """flow2 of FlowNetC's head on the native engine (one engine per batch / frame size, cached on the module)."""
-    B, _, h4, w4 = c2a.shape
-    key = (B, h4 * 4, w4 * 4, str(c2a.device))
+def get_engine(net, B: int, H: int, W: int, device) -> FlowNetCHeadEngine:
+    """One engine per batch / frame size, cached on the module."""
+    key = (int(B), int(H), int(W), str(torch.device(device)))
     cache = net.__dict__.setdefault("_ufr_head_engines", {})
     eng = cache.get(key)
     if eng is None:
-        eng = cache[key] = FlowNetCHeadEngine(net, B, h4 * 4, w4 * 4, c2a.device)
-    return _EngineHead.apply(c2a, c3a, c3b, eng, band)
+        eng = cache[key] = FlowNetCHeadEngine(net, B, H, W, device)
+    return eng
+
+
+def engine_head(net, c2a, c3a, c3b, band=None):
+    """flow2 of FlowNetC's head on the native engine, as an autograd Function of the NCHW features."""
+    B, _, h4, w4 = c2a.shape
+    return _EngineHead.apply(c2a, c3a, c3b, get_engine(net, B, h4 * 4, w4 * 4, c2a.device), band)

@@ -129,6 +129,14 @@ class FlowNetC(nn.Module):
         feats = [c1[:B], c2a, c3a, c1[B:], c2[B:], c3b] if self.return_feat_maps else None
         return self._rest(c2a, c3a, c3b, feats)
 
+    def engine_available(self, H, W, device) -> bool:
+        """Can the attack step keep this network's cached features inside the native head (patch_attack.py's windowed
+        iteration)?  Same conditions as `_engine_ok`, asked before any feature exists."""
+        import os
+        frozen = not any(p.requires_grad for p in self.parameters())
+        return (os.environ.get("UFR_ENGINE", "1") == "1" and os.environ.get("UFR_ENGINE_PREFIX", "1") == "1" and not self.training
+                and not self.return_feat_maps and frozen and torch.device(device).type == "cuda" and H % 64 == 0 and W % 64 == 0)
+
     def _engine_ok(self, c2a, feats, band):
         """The native head (flownetc_engine.py) serves the attack's configuration: frozen parameters, eval mode, HIP
         float32 features, frame sides that are multiples of 64."""

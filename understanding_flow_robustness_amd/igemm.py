@@ -39,14 +39,15 @@ class Planes:
         self.t = torch.zeros(3, self.chunks, self.M, 32, dtype=torch.bfloat16, device=device)
         self.plane_stride = self.chunks * self.M * 32
 
-    def load_nchw(self, x: torch.Tensor, chunk0: int = 0, scale: float = 1.0, slope: float = 1.0):
-        """planes[chunk0 + c/32] = split(leaky(scale * x)); x [B,C,H,W] float32 contiguous."""
+    def load_nchw(self, x: torch.Tensor, chunk0: int = 0, scale: float = 1.0, slope: float = 1.0, bias: torch.Tensor | None = None):
+        """planes[chunk0 + c/32] = split(leaky(scale * x + bias[c])); x [B,C,H,W] float32 contiguous."""
         L.require_hip(x, "x")
         B, Cn, H, W = x.shape
         if (B, H, W) != (self.B, self.H, self.W) or chunk0 + pad32(Cn) // 32 > self.chunks or x.dtype != torch.float32:
             raise RuntimeError("Planes.load_nchw: shape mismatch")
         L.check(L.lib().ufr_nchw_to_planes(L.ptr(x), L.ptr(self.t), self.plane_stride, int(chunk0), B, Cn, H, W,
-                                           float(scale), float(slope), L.stream()), "nchw -> planes")
+                                           float(scale), float(slope), L.ptr(bias) if bias is not None else None, L.stream()),
+                "nchw -> planes")
         return self
 
     def to_nchw(self, Cn: int, chunk0: int = 0, out: torch.Tensor | None = None) -> torch.Tensor:

@@ -217,13 +217,20 @@ class PatchAttackStep:
         self.win_hw = (wh, ww)
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.xw = torch.zeros(2 * B, 3, wh, ww, **f32).requires_grad_(True)
+        # native head (flownetc_engine.py): the cached full-frame features live in its plane buffers, the head and its
+        # adjoint are explicit launch schedules (no torch operator, no autograd between the features and flow2)
+        self.eng = None
+        if getattr(self.net, "engine_available", None) is not None and self.net.engine_available(H, W, self.dev):
+            from .flownetc_engine import get_engine
+            self.eng = get_engine(self.net, B, H, W, self.dev)
+            self.eng.flow[2].requires_grad_(True)
         self.taps = []                         # (level stride, margin, frames, full leaf, window gradient)
         with torch.no_grad():
             feats = self.net.encode(torch.zeros(2, 3, spec.total_stride * 2, spec.total_stride * 2, **f32))
         for t, m, fr, f in zip(spec.taps, spec.tap_margins(), spec.frames, feats):
             ls = spec.level_stride(t)
             n = B * fr                         # frames = 1: the head reads this tap for the first frame only
-            full = torch.zeros(n, f.shape[1], H // ls, W // ls, **f32).requires_grad_(True)
+            full = None if self.eng is not None else torch.zeros(n, f.shape[1], H // ls, W // ls, **f32).requires_grad_(True)
             gwin = torch.zeros(n, f.shape[1], wh // ls, ww // ls, **f32)
             self.taps.append((ls, m, n, full, gwin))
         self.g_tgt_full = torch.zeros_like(self.tgt)
@@ -261,6 +268,12 @@ class PatchAttackStep:
         if self.band is not None and self.band.width:   # band start: 32-pixel aligned, `reach` left of the window, inside the frame
             start = torch.div(self.win[:, 1] - self._band_reach, 32, rounding_mode="floor") * 32
             self.band.win[:, 1] = start.clamp(0, self.W - self.band.width)
+        if self.eng is not None:
+            if prefix_features is not None:
+                self.eng.load_prefix_features(prefix_features[0], prefix_features[1])
+            else:
+                self.eng.prefix_full(self.adv_tgt.detach(), self.adv_ref.detach())
+            return
         feats = prefix_features if prefix_features is not None else \
             self.net.encode(torch.cat((self.adv_tgt.detach(), self.adv_ref.detach()), 0))
         for (ls, m, n, full, _), f in zip(self.taps, feats):
@@ -274,6 +287,13 @@ class PatchAttackStep:
         self._win_copy(lib.ufr_window_gather, self.adv_tgt, self.xw, B, 3, H, W, 1, 0)
         self._win_copy(lib.ufr_window_gather, self.adv_ref, self.xw[B:], B, 3, H, W, 1, 0)
         self._feats_w = [f[:n] for f, (_, _, n, _, _) in zip(self.net.encode(self.xw), self.taps)]
+        if self.eng is not None:
+            (_, m2, _, _, _), (_, m3, _, _, _) = self.taps
+            wh, ww = self.win_hw
+            self.eng.scatter_window_features(self._feats_w[0], self._feats_w[1], self.win, wh, ww, m2, m3)
+            self.eng.forward_cached(self.band)             # writes eng.flow[2], the leaf of the remaining torch ops
+            return torch.nn.functional.interpolate(self.eng.flow[2] * self.net.div_flow, scale_factor=4, mode="bilinear",
+                                                   align_corners=False)
         for f, (ls, m, n, full, _) in zip(self._feats_w, self.taps):
             self._win_copy(lib.ufr_window_scatter, f, full, n, f.shape[1], H // ls, W // ls, ls, m)
         full = [t[3] for t in self.taps]
@@ -284,9 +304,17 @@ class PatchAttackStep:
         """Adjoint of the head at full size, of the prefix on the window; canvas-sized gradients that are
         zero outside the window (only mask * gradient is ever used, main.py:575-583)."""
         lib, B, H, W = L.lib(), self.B, self.H, self.W
-        g_full = torch.autograd.grad(flow, [t[3] for t in self.taps], self.g_flow)
-        for g, (ls, m, n, _, gwin) in zip(g_full, self.taps):
-            self._win_copy(lib.ufr_window_gather, g.contiguous(), gwin, n, g.shape[1], H // ls, W // ls, ls, m)
+        if self.eng is not None:
+            (g_flow2,) = torch.autograd.grad(flow, (self.eng.flow[2],), self.g_flow)
+            g2a, g3a, g3b = self.eng.backward(g_flow2.contiguous(), self.band)
+            (ls2, m2, _, _, gw2), (ls3, m3, _, _, gw3) = self.taps
+            self._win_copy(lib.ufr_window_gather, g2a, gw2, B, 128, H // ls2, W // ls2, ls2, m2)
+            self._win_copy(lib.ufr_window_gather, g3a, gw3, B, 256, H // ls3, W // ls3, ls3, m3)
+            self._win_copy(lib.ufr_window_gather, g3b, gw3[B:], B, 256, H // ls3, W // ls3, ls3, m3)
+        else:
+            g_full = torch.autograd.grad(flow, [t[3] for t in self.taps], self.g_flow)
+            for g, (ls, m, n, _, gwin) in zip(g_full, self.taps):
+                self._win_copy(lib.ufr_window_gather, g.contiguous(), gwin, n, g.shape[1], H // ls, W // ls, ls, m)
         gxw, = torch.autograd.grad(self._feats_w, (self.xw,), [t[4] for t in self.taps])
         self._feats_w = None
         gxw = gxw.contiguous()
