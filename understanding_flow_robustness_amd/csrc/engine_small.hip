@@ -66,21 +66,21 @@ __global__ __launch_bounds__(1024) void flow_head_planes_fwd(const __bf16* __res
         dst[0] = make_float4(v[0], v[1], v[2], v[3]);
         dst[1] = make_float4(v[4], v[5], v[6], v[7]);
       }
-      for (int i = t; i < 576 / 4; i += 256) reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(wpk + (long)ch * 576)[i];
     }
     __syncthreads();
     if (work) {
+      // the chunk's weights are wave-uniform (thread = pixel): read through the scalar unit, FMAs take them as SGPR operands
+      const float* wg = wpk + (long)ch * 576;
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
         const float* px = tile + ((ly + k / 3) * PF_HW + lx + k % 3) * PF_CS;
-        const float* w0 = wl + (k * 2 + 0) * 32;
-        const float* w1 = wl + (k * 2 + 1) * 32;
+        const float* w0 = wg + (k * 2 + 0) * 32;
+        const float* w1 = wg + (k * 2 + 1) * 32;
 #pragma unroll
         for (int c4 = 0; c4 < 8; ++c4) {
           const float4 v = *reinterpret_cast<const float4*>(px + c4 * 4);
-          const float4 u0 = *reinterpret_cast<const float4*>(w0 + c4 * 4), u1 = *reinterpret_cast<const float4*>(w1 + c4 * 4);
-          a0 = fmaf(v.x, u0.x, a0); a0 = fmaf(v.y, u0.y, a0); a0 = fmaf(v.z, u0.z, a0); a0 = fmaf(v.w, u0.w, a0);
-          a1 = fmaf(v.x, u1.x, a1); a1 = fmaf(v.y, u1.y, a1); a1 = fmaf(v.z, u1.z, a1); a1 = fmaf(v.w, u1.w, a1);
+          a0 = fmaf(v.x, w0[c4 * 4 + 0], a0); a0 = fmaf(v.y, w0[c4 * 4 + 1], a0); a0 = fmaf(v.z, w0[c4 * 4 + 2], a0); a0 = fmaf(v.w, w0[c4 * 4 + 3], a0);
+          a1 = fmaf(v.x, w1[c4 * 4 + 0], a1); a1 = fmaf(v.y, w1[c4 * 4 + 1], a1); a1 = fmaf(v.z, w1[c4 * 4 + 2], a1); a1 = fmaf(v.w, w1[c4 * 4 + 3], a1);
         }
       }
     }

@@ -49,7 +49,7 @@ class FlowNetCHeadEngine:
         P = lambda s, chunks: ig.Planes(B, g[s][0], g[s][1], chunks, self.dev)
         G = lambda s, chunks: ig.GradSum(B, g[s][0], g[s][1], chunks, self.dev)
         # ---- activations
-        self.c3a_p = P(8, 8)
+        self.c3a_p, self.c3b_p = P(8, 8), P(8, 8)
         self.in31, self.cat3, self.cat2 = P(8, 15), P(8, 13), P(4, 7)
         self.c4a, self.cat4 = P(16, 16), P(16, 25)
         self.c5a, self.cat5 = P(32, 16), P(32, 33)
