@@ -37,7 +37,6 @@ __global__ __launch_bounds__(1024) void flow_head_planes_fwd(const __bf16* __res
   const long M = (long)B * H * W;
   const int tid = threadIdx.x, slice = tid >> 8, t = tid & 255;
   float* tile = lds_pf + (long)slice * (PF_HH * PF_HW * PF_CS);
-  float* wl = lds_pf + (long)S * (PF_HH * PF_HW * PF_CS) + slice * 576;
   float* part = lds_pf + (long)S * (PF_HH * PF_HW * PF_CS + 576);
   const int tiles_x = (W + PF_TW - 1) / PF_TW, tiles_y = (H + PF_TH - 1) / PF_TH;
   const int b = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x - b * tiles_x * tiles_y;
