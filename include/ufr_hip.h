@@ -449,6 +449,14 @@ int ufr_chunks_to_nchw(const void* planes, long plane_stride, const float* f32, 
 int ufr_grad_finalize(const float* g, int g_chunk0, const void* mask, int mask_chunk0, void* out, long out_plane_stride,
                       int out_chunk0, long M, int chunks, float slope, ufr_stream_t stream);
 
+/* FlowNetC's cost volume on the matrix cores, planes in, planes out (csrc/correlation_planes.hip): replaces
+ * correlation_cuda_forward_kernel (correlation_cuda_kernel.cu:21-83) + `correlate`'s / C (models/submodules.py:124-138) +
+ * LeakyReLU (FlowNetC.py:139) for kernel 1, patch 21, dilation_patch 2, 256 channels.  f1 / f2: planes [3][8][B*H*W][32];
+ * out channel d = dy*21 + dx of pixel (b, y, x) = leaky(scale * sum_c f1[c,y,x] * f2[c, y + 2(dy-10), x + 2(dx-10)]) lands in
+ * chunk out_chunk0 + d/32 of `out_planes`.  Other configurations: UFR_EUNSUPPORTED (use ufr_corr_forward). */
+int ufr_corr_forward_planes(const void* f1_planes, const void* f2_planes, long in_plane_stride, void* out_planes,
+                            long out_plane_stride, int out_chunk0, int B, int C, int H, int W, int patch,
+                            int dilation_patch, float scale, float slope, ufr_stream_t stream);
 /* The 2-channel layers of the refinement on the engine's layout (csrc/engine_small.hip):
  * predict_flow* = Conv2d(Cin,2,3,1,1) (models/FlowNetC.py:43-47) reads the chunks [chunk0, chunk0+chunks) of a planes
  * buffer and writes flow [B,2,H,W] fp32; weights repacked wpk[chunk][tap][out][32].  Its data gradient writes (or adds

@@ -163,3 +163,27 @@ def test_flow_head_planes_kernels_vs_torch(B, C, H, W):
     assert bool((G.t[0] == 0.5).all())                                   # the neighbouring chunk is untouched
     L.check(L.lib().ufr_flow_head_planes_backward(L.ptr(gy), L.ptr(wpk), L.ptr(G.t), 1, chunks, B, H, W, 1, L.stream()))
     assert _rel(G.to_nchw(C, 1), 2 * gx) <= 1e-5
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 24, 40), (1, 48, 160), (3, 13, 37), (1, 20, 200)])
+def test_correlation_on_planes_equals_the_reference_cost_volume(B, H, W):
+    """csrc/correlation_planes.hip (banded GEMM on the matrix cores, planes in / planes out, / C and LeakyReLU fused) against
+    the cost volume of the spatial correlation sampler (pinned bit for bit to the reference's CPU implementation) in
+    float64: row widths of 2, 4 and 5 waves per block, several column blocks, odd sizes."""
+    import torch.nn.functional as F
+    from understanding_flow_robustness_amd import _lib as L
+    from understanding_flow_robustness_amd import igemm as ig
+    from understanding_flow_robustness_amd import spatial_correlation_sampler_backend as be
+    g = torch.Generator().manual_seed(9)
+    f1, f2 = torch.randn(B, 256, H, W, generator=g).to(DEV), torch.randn(B, 256, H, W, generator=g).to(DEV)
+    a = ig.Planes(B, H, W, 8, DEV).load_nchw(f1)
+    b = ig.Planes(B, H, W, 8, DEV).load_nchw(f2)
+    out = ig.Planes(B, H, W, 15, DEV)
+    out.t.fill_(3.0)
+    L.check(L.lib().ufr_corr_forward_planes(L.ptr(a.t), L.ptr(b.t), a.plane_stride, L.ptr(out.t), out.plane_stride, 1, B, 256, H, W,
+                                            21, 2, 1.0 / 256.0, 0.1, L.stream()))
+    want = F.leaky_relu(be.forward(f1.double(), f2.double(), 1, 1, 21, 21, 0, 0, 1, 1, 2, 2, 1, 1).view(B, 441, H, W) / 256.0, 0.1)
+    got = out.to_nchw(441, 1)
+    assert _rel(got, want) <= 1e-5, f"cost volume {_rel(got, want):.2e}"
+    assert bool((out.t[:, 0] == 3.0).all())                              # conv_redir's chunk is untouched
+    assert bool((out.t[:, 14, :, 25:] == 3.0).all())                     # channels 441..447: never written (the engine keeps them zero)

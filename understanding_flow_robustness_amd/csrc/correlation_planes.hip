@@ -1,0 +1,158 @@
+// correlation_planes.hip -- FlowNetC's cost volume (21 x 21 displacements, stride 2: correlation_cuda_kernel.cu:21-83 with
+// models/submodules.py:124-138 `correlate` = / C and FlowNetC.py:139 LeakyReLU fused) on the bf16 matrix cores, reading the
+// engine's chunk-major planes of both feature maps and writing conv3_1's input planes directly (flownetc_engine.py: `in31`
+// chunks 1..14) -- no NCHW cost volume, no conversion pass.
+//
+// For one output row y and displacement row dy (source row y2 = y + 2(dy - 10)) the volume is a BANDED GEMM:
+//     R[x, x'] = sum_c f1[c, y, x] * f2[c, y2, x'],      needed for x' - x in {-20, -18, ..., 20}
+// Only same-parity columns meet, so a workgroup owns (sample, row, column parity): with i = x / 2, j = x' / 2 the band is
+// |j - i| <= 10.  A wave owns 16 columns i and keeps its f1 fragments (256 channels x 3 planes = 96 VGPRs) for its whole
+// life; per dy the source row's same-parity columns are streamed through LDS by LDS-DMA, a quarter of the channels at a time
+// (XOR-swizzled images like csrc/igemm.hip), and each wave multiplies its 16 columns against 3 tiles of 16 source columns
+// (j in [i0 - 16, i0 + 32): 44 % of the MFMA work lands inside the band), float32 = six bf16 products.
+// out channel d = dy * 21 + (j - i + 10); value = leaky(R / C).
+#include "ufr_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ constexpr int PROD_A[6] = {2, 0, 1, 1, 0, 0};
+__device__ constexpr int PROD_B[6] = {0, 2, 1, 0, 1, 0};
+__device__ __attribute__((aligned(64))) unsigned corr_zero_page[16];
+
+__device__ __forceinline__ void glds16(const __bf16* src, __bf16* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(src, lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void split3(float v, __bf16& a, __bf16& b, __bf16& c) {
+  a = (__bf16)v;
+  const float r1 = v - (float)a;
+  b = (__bf16)r1;
+  c = (__bf16)(r1 - (float)b);
+}
+
+constexpr int P = 21, R = 10, KCH = 8;           // 21 displacements per axis, reach 10 same-parity columns, 8 chunks of 32 channels
+constexpr int KS = 2;                            // channel chunks per LDS stage
+
+// f1, f2: planes [3][KCH][M][32] (M = B*H*W); out: planes [3][out_chunks][M][32], channels written at chunk out_chunk0 + d / 32.
+// grid = (column blocks, 2 parities, B*H); block = NW waves.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void corr_fwd_planes_kernel(const __bf16* __restrict__ f1, const __bf16* __restrict__ f2,
+                                                                  long in_plane_stride, __bf16* __restrict__ out,
+                                                                  long out_plane_stride, int out_chunk0, int B, int H, int W,
+                                                                  float scale, float slope) {
+  constexpr int NJ = 16 * NW + 32;               // staged source columns: [i0 - 16, i0 + 16 NW + 16)
+  __shared__ __attribute__((aligned(16))) __bf16 lds[3][KS][NJ * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int par = blockIdx.y, by = blockIdx.z, b = by / H, y = by - b * H;
+  const int i0 = blockIdx.x * 16 * NW;
+  const long M = (long)B * H * W;
+  const long rowbase = ((long)b * H + y) * W;
+  // ---- this wave's f1 fragments: row = column i0 + 16 wave + (lane & 15), k group lane >> 4
+  const int ai = i0 + 16 * wave + (lane & 15), ax = 2 * ai + par;
+  const bool a_ok = ax < W;
+  bf16x8 fa[KCH][3];
+#pragma unroll
+  for (int kc = 0; kc < KCH; ++kc)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const __bf16* src = a_ok ? f1 + p * in_plane_stride + ((long)kc * M + rowbase + ax) * 32 + (lane >> 4) * 8
+                               : reinterpret_cast<const __bf16*>(corr_zero_page);
+      fa[kc][p] = *reinterpret_cast<const bf16x8*>(src);
+    }
+  // staging pieces: NJ rows x 4 pieces per image, 16 rows per wave-instruction; wave `wave` takes row blocks wave, wave + NW, ...
+  constexpr int NRB = NJ / 16;                   // row blocks per image
+  const int srow_in = lane >> 2, spiece = lane & 3;
+  const int frow = lane & 15;
+  const int foff = frow * 32 + (((lane >> 4) ^ ((frow >> 1) & 3)) << 3);
+  const __bf16* zero = reinterpret_cast<const __bf16*>(corr_zero_page);
+
+  for (int dy = 0; dy < P; ++dy) {
+    const int y2 = y + 2 * (dy - R);
+    const bool row_ok = y2 >= 0 && y2 < H;       // uniform
+    f32x4 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (row_ok) {
+      const long srcrow = ((long)b * H + y2) * W;
+#pragma unroll
+      for (int s = 0; s < KCH / KS; ++s) {      // unrolled: fa[] must be indexed statically (registers, not scratch)
+        __syncthreads();                          // the previous stage's fragment reads are done
+        for (int rb = wave; rb < NRB; rb += NW) {
+          const int r = rb * 16 + srow_in;        // staged row -> same-parity column j
+          const int j = i0 - 16 + r, xs = 2 * j + par;
+          const bool ok = j >= 0 && xs < W;
+          const int csw = spiece ^ ((r >> 1) & 3);
+#pragma unroll
+          for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+              const __bf16* src = ok ? f2 + p * in_plane_stride + ((long)(s * KS + kk) * M + srcrow + xs) * 32 + csw * 8 : zero;
+              glds16(src, &lds[p][kk][rb * 16 * 32]);
+            }
+        }
+        __syncthreads();                          // hipcc waits vmcnt(0) before the barrier: every DMA has landed
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            bf16x8 fb[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fb[p] = *reinterpret_cast<const bf16x8*>(&lds[p][kk][(wave + t) * 16 * 32 + foff]);
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+              acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s * KS + kk][PROD_A[q]], fb[PROD_B[q]], acc[t], 0, 0, 0);
+          }
+      }
+    }
+    // ---- this displacement row's 21 channels of the wave's 16 columns.  C/D layout: col = lane & 15 (source column j of
+    // the tile), row = (lane >> 4) * 4 + reg (output column i)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int il = (lane >> 4) * 4 + rg;                      // output column inside the wave
+        const int dx = 16 * t - 16 + (lane & 15) - il + R;         // j - i + 10
+        const int x = 2 * (i0 + 16 * wave + il) + par;
+        if (dx >= 0 && dx < P && x < W) {
+          float v = acc[t][rg] * scale;
+          v = v > 0.f ? v : v * slope;
+          __bf16 p0, p1, p2;
+          split3(v, p0, p1, p2);
+          const int d = dy * P + dx;
+          __bf16* o = out + ((long)(out_chunk0 + (d >> 5)) * M + rowbase + x) * 32 + (d & 31);
+          o[0] = p0;
+          o[out_plane_stride] = p1;
+          o[2 * out_plane_stride] = p2;
+        }
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int ufr_corr_forward_planes(const void* f1_planes, const void* f2_planes, long in_plane_stride, void* out_planes,
+                                       long out_plane_stride, int out_chunk0, int B, int C, int H, int W, int patch,
+                                       int dilation_patch, float scale, float slope, ufr_stream_t stream) {
+  UFR_REQUIRE(f1_planes && f2_planes && out_planes, "correlation (planes): null pointer");
+  UFR_REQUIRE(B > 0 && H > 0 && W > 0 && (long)B * H < 65536 && out_chunk0 >= 0, "correlation (planes): bad shape");
+  if (C != 32 * KCH || patch != P || dilation_patch != 2)
+    return ufr::fail(UFR_EUNSUPPORTED, "correlation (planes): built for FlowNetC's configuration (256 channels, patch 21, "
+                                       "dilation_patch 2); got C=%d patch=%d dilation_patch=%d", C, patch, dilation_patch);
+  const int ni = (W + 1) / 2;                    // same-parity columns of a row (parity 0; parity 1 has W / 2)
+  hipStream_t st = ufr::as_stream(stream);
+  const __bf16* a = static_cast<const __bf16*>(f1_planes);
+  const __bf16* b = static_cast<const __bf16*>(f2_planes);
+  __bf16* o = static_cast<__bf16*>(out_planes);
+#define UFR_CP_LAUNCH(NW)                                                                                         \
+  corr_fwd_planes_kernel<NW><<<dim3(ufr::ceil_div(ni, 16 * NW), 2, B * H), 64 * NW, 0, st>>>(a, b, in_plane_stride, o, \
+                                                                                             out_plane_stride, out_chunk0, B, H, W, scale, slope)
+  const int waves = ufr::ceil_div(ni, 16);
+  if (waves <= 2) UFR_CP_LAUNCH(2);
+  else if (waves <= 4 || waves > 5 * 2) UFR_CP_LAUNCH(4);      // 4-wave blocks also tile rows wider than one block
+  else UFR_CP_LAUNCH(5);                                         // 160 columns (FlowNetC @1280): one block per row and parity
+#undef UFR_CP_LAUNCH
+  return ufr::launched("corr_fwd_planes_kernel");
+}

@@ -114,6 +114,167 @@ __global__ void resample2d_bwd(const float* __restrict__ img, const float* __res
   }
 }
 
+// ---- LDS-staged forms (kernel_size 1, bilinear, image and flow of one size: FlowNet2's only use) -----------------------
+// Workgroup = an 8 x 32 tile of output pixels.  The tile's source pixels lie in the bounding box of its (clamped) sampling
+// corners; when that box fits the LDS budget (smooth flow: tile + |flow| spread) the box of every channel is fetched ONCE
+// with coalesced row reads and the 4*C bilinear taps of every pixel come from LDS -- instead of 4*C scattered global reads
+// per pixel.  The adjoint with respect to the image is PRIVATISED: the tile's 4*C contributions per pixel are accumulated
+// in an LDS copy of the box (ds_add_f32) and flushed with one global atomic per touched cell (the boxes of neighbouring
+// tiles overlap), instead of 4*C global float atomics per pixel (resample2d_kernel.cu:118-121's scheme).  A box that does
+// not fit (wild flow) falls back to the direct form, tile by tile; the arithmetic is identical either way.
+constexpr int RS_TH = 8, RS_TW = 32;
+
+struct RsBox { int x0, y0, bw, bh; };
+
+__device__ __forceinline__ RsBox rs_tile_box(int xL, int xR, int yT, int yB, bool live, int* red) {
+  // red: 4 ints in LDS, initialised by the caller pattern below
+  int mnx = live ? xL : (1 << 30), mxx = live ? xR : -(1 << 30), mny = live ? yT : (1 << 30), mxy = live ? yB : -(1 << 30);
+  for (int off = 32; off > 0; off >>= 1) {
+    mnx = min(mnx, __shfl_xor(mnx, off, 64)); mxx = max(mxx, __shfl_xor(mxx, off, 64));
+    mny = min(mny, __shfl_xor(mny, off, 64)); mxy = max(mxy, __shfl_xor(mxy, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&red[0], mnx); atomicMax(&red[1], mxx); atomicMin(&red[2], mny); atomicMax(&red[3], mxy);
+  }
+  __syncthreads();
+  RsBox bx;
+  bx.x0 = red[0]; bx.y0 = red[2]; bx.bw = red[1] - red[0] + 1; bx.bh = red[3] - red[2] + 1;
+  return bx;
+}
+
+__global__ __launch_bounds__(256) void resample2d_fwd_lds(const float* __restrict__ img, const float* __restrict__ flow,
+                                                          float* __restrict__ out, int B, int C, int H, int W, int lds_floats) {
+  extern __shared__ __attribute__((aligned(16))) float rs_lds[];
+  __shared__ int red[4];
+  const int tid = threadIdx.x;
+  if (tid == 0) { red[0] = 1 << 30; red[1] = -(1 << 30); red[2] = 1 << 30; red[3] = -(1 << 30); }
+  __syncthreads();
+  const int tiles_x = (W + RS_TW - 1) / RS_TW, tiles_y = (H + RS_TH - 1) / RS_TH;
+  const int b = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x - b * tiles_x * tiles_y;
+  const int x = (tr % tiles_x) * RS_TW + (tid & (RS_TW - 1)), y = (tr / tiles_x) * RS_TH + tid / RS_TW;
+  const bool live = x < W && y < H;
+  const size_t plane = (size_t)H * W, pix = (size_t)(live ? y : 0) * W + (live ? x : 0);
+  const float dx = live ? flow[((size_t)b * 2 + 0) * plane + pix] : 0.f;
+  const float dy = live ? flow[((size_t)b * 2 + 1) * plane + pix] : 0.f;
+  const float xf = (float)x + dx, yf = (float)y + dy;
+  const float alpha = xf - floorf(xf), beta = yf - floorf(yf);
+  const int xL = clampi((int)floorf(xf), 0, W - 1), xR = clampi((int)floorf(xf) + 1, 0, W - 1);
+  const int yT = clampi((int)floorf(yf), 0, H - 1), yB = clampi((int)floorf(yf) + 1, 0, H - 1);
+  const double wTL = (1. - alpha) * (1. - beta), wTR = (double)alpha * (1. - beta);
+  const double wBL = (1. - alpha) * (double)beta, wBR = (double)alpha * (double)beta;
+  const RsBox bx = rs_tile_box(xL, xR, yT, yB, live, red);
+  const bool staged = (long)C * bx.bw * bx.bh <= lds_floats;          // uniform
+  if (staged) {
+    const int area = bx.bw * bx.bh;
+    for (int i = tid; i < C * area; i += 256) {
+      const int c = i / area, r = i - c * area, ry = r / bx.bw, rx = r - ry * bx.bw;
+      rs_lds[i] = img[((size_t)b * C + c) * plane + (size_t)(bx.y0 + ry) * W + bx.x0 + rx];
+    }
+    __syncthreads();
+    if (live) {
+      const int oTL = (yT - bx.y0) * bx.bw + xL - bx.x0, oTR = (yT - bx.y0) * bx.bw + xR - bx.x0;
+      const int oBL = (yB - bx.y0) * bx.bw + xL - bx.x0, oBR = (yB - bx.y0) * bx.bw + xR - bx.x0;
+      for (int c = 0; c < C; ++c) {
+        const float* im = rs_lds + c * area;
+        float val = 0.f;
+        val += (float)(wTL * im[oTL]);
+        val += (float)(wTR * im[oTR]);
+        val += (float)(wBL * im[oBL]);
+        val += (float)(wBR * im[oBR]);
+        out[((size_t)b * C + c) * plane + pix] = val;
+      }
+    }
+  } else if (live) {
+    for (int c = 0; c < C; ++c) {
+      const float* im = img + ((size_t)b * C + c) * plane;
+      float val = 0.f;
+      val += (float)(wTL * im[(size_t)yT * W + xL]);
+      val += (float)(wTR * im[(size_t)yT * W + xR]);
+      val += (float)(wBL * im[(size_t)yB * W + xL]);
+      val += (float)(wBR * im[(size_t)yB * W + xR]);
+      out[((size_t)b * C + c) * plane + pix] = val;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void resample2d_bwd_lds(const float* __restrict__ img, const float* __restrict__ flow,
+                                                          const float* __restrict__ gout, float* __restrict__ gimg,
+                                                          float* __restrict__ gflow, int B, int C, int H, int W, int lds_floats) {
+  extern __shared__ __attribute__((aligned(16))) float rs_lds[];      // [C*area] image box | [C*area] gradient box
+  __shared__ int red[4];
+  const int tid = threadIdx.x;
+  if (tid == 0) { red[0] = 1 << 30; red[1] = -(1 << 30); red[2] = 1 << 30; red[3] = -(1 << 30); }
+  __syncthreads();
+  const int tiles_x = (W + RS_TW - 1) / RS_TW, tiles_y = (H + RS_TH - 1) / RS_TH;
+  const int b = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x - b * tiles_x * tiles_y;
+  const int x = (tr % tiles_x) * RS_TW + (tid & (RS_TW - 1)), y = (tr / tiles_x) * RS_TH + tid / RS_TW;
+  const bool live = x < W && y < H;
+  const size_t plane = (size_t)H * W, pix = (size_t)(live ? y : 0) * W + (live ? x : 0);
+  const float dx = live ? flow[((size_t)b * 2 + 0) * plane + pix] : 0.f;
+  const float dy = live ? flow[((size_t)b * 2 + 1) * plane + pix] : 0.f;
+  const float xf = (float)x + dx, yf = (float)y + dy;
+  const int xL = clampi((int)floorf(xf), 0, W - 1), xR = clampi((int)floorf(xf) + 1, 0, W - 1);
+  const int yT = clampi((int)floorf(yf), 0, H - 1), yB = clampi((int)floorf(yf) + 1, 0, H - 1);
+  // image adjoint: weights with int() truncation (resample2d_kernel.cu:105-106); flow adjoint: floor()
+  const float alpha = xf - (float)(int)xf, beta = yf - (float)(int)yf;
+  const float gx = 1 - (yf - floorf(yf)), gy = 1 - (xf - floorf(xf));
+  const RsBox bx = rs_tile_box(xL, xR, yT, yB, live, red);
+  const int area = bx.bw * bx.bh;
+  const bool staged = 2L * C * area <= lds_floats;                     // uniform
+  float o0 = 0.f, o1 = 0.f;
+  if (staged) {
+    float* gbox = rs_lds + C * area;
+    for (int i = tid; i < C * area; i += 256) {
+      const int c = i / area, r = i - c * area, ry = r / bx.bw, rx = r - ry * bx.bw;
+      rs_lds[i] = img[((size_t)b * C + c) * plane + (size_t)(bx.y0 + ry) * W + bx.x0 + rx];
+      gbox[i] = 0.f;
+    }
+    __syncthreads();
+    if (live) {
+      const int oTL = (yT - bx.y0) * bx.bw + xL - bx.x0, oTR = (yT - bx.y0) * bx.bw + xR - bx.x0;
+      const int oBL = (yB - bx.y0) * bx.bw + xL - bx.x0, oBR = (yB - bx.y0) * bx.bw + xR - bx.x0;
+      for (int c = 0; c < C; ++c) {
+        const float g = gout[((size_t)b * C + c) * plane + pix];
+        float* gi = gbox + c * area;
+        atomicAdd(&gi[oTL], (1 - alpha) * (1 - beta) * g);
+        atomicAdd(&gi[oTR], (alpha) * (1 - beta) * g);
+        atomicAdd(&gi[oBL], (1 - alpha) * (beta)*g);
+        atomicAdd(&gi[oBR], (alpha) * (beta)*g);
+        const float* im = rs_lds + c * area;
+        const float tl = im[oTL], trv = im[oTR], bl = im[oBL], br = im[oBR];
+        o0 += (gx)*g * trv; o0 -= (gx)*g * tl; o0 += (1 - gx) * g * br; o0 -= (1 - gx) * g * bl;
+        o1 += (gy)*g * bl;  o1 -= (gy)*g * tl; o1 += (1 - gy) * g * br; o1 -= (1 - gy) * g * trv;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < C * area; i += 256) {
+      const float v = gbox[i];
+      if (v != 0.f) {
+        const int c = i / area, r = i - c * area, ry = r / bx.bw, rx = r - ry * bx.bw;
+        atomicAdd(&gimg[((size_t)b * C + c) * plane + (size_t)(bx.y0 + ry) * W + bx.x0 + rx], v);
+      }
+    }
+  } else if (live) {
+    for (int c = 0; c < C; ++c) {
+      const float g = gout[((size_t)b * C + c) * plane + pix];
+      float* gi = gimg + ((size_t)b * C + c) * plane;
+      atomicAdd(&gi[(size_t)yT * W + xL], (1 - alpha) * (1 - beta) * g);
+      atomicAdd(&gi[(size_t)yT * W + xR], (alpha) * (1 - beta) * g);
+      atomicAdd(&gi[(size_t)yB * W + xL], (1 - alpha) * (beta)*g);
+      atomicAdd(&gi[(size_t)yB * W + xR], (alpha) * (beta)*g);
+      const float* im = img + ((size_t)b * C + c) * plane;
+      const float tl = im[(size_t)yT * W + xL], trv = im[(size_t)yT * W + xR];
+      const float bl = im[(size_t)yB * W + xL], br = im[(size_t)yB * W + xR];
+      o0 += (gx)*g * trv; o0 -= (gx)*g * tl; o0 += (1 - gx) * g * br; o0 -= (1 - gx) * g * bl;
+      o1 += (gy)*g * bl;  o1 -= (gy)*g * tl; o1 += (1 - gy) * g * br; o1 -= (1 - gy) * g * trv;
+    }
+  }
+  if (live) {
+    gflow[((size_t)b * 2 + 0) * plane + pix] = o0;
+    gflow[((size_t)b * 2 + 1) * plane + pix] = o1;
+  }
+}
+
 // channelnorm_kernel.cu:18-60
 __global__ void channelnorm_fwd(const float* __restrict__ in, float* __restrict__ out, int B, int C,
                                 long HW) {
@@ -149,6 +310,22 @@ __global__ void channelnorm_bwd(const float* __restrict__ in, const float* __res
   }
 }
 
+constexpr int RS_LDS_BYTES = 48 * 1024;         // per workgroup: three workgroups per CU
+
+bool rs_use_lds() {
+  static const bool v = [] { const char* e = getenv("UFR_RESAMPLE_LDS"); return !(e && e[0] == '0'); }();
+  return v;
+}
+
+void rs_raise_lds() {
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resample2d_fwd_lds), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resample2d_bwd_lds), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS_BYTES);
+    done = true;
+  }
+}
+
 }  // namespace
 
 extern "C" int ufr_resample2d_forward(const float* input1, const float* input2, float* output,
@@ -158,6 +335,12 @@ extern "C" int ufr_resample2d_forward(const float* input1, const float* input2, 
   UFR_REQUIRE(B > 0 && C > 0 && Hi > 0 && Wi > 0 && H > 0 && W > 0 && kernel_size >= 1,
               "resample2d forward: bad shape");
   const long npix = (long)B * H * W;
+  if (kernel_size == 1 && bilinear && Hi == H && Wi == W && rs_use_lds()) {       // FlowNet2's configuration: LDS-staged form
+    const int tiles = B * ufr::ceil_div(H, RS_TH) * ufr::ceil_div(W, RS_TW);
+    rs_raise_lds();
+    resample2d_fwd_lds<<<tiles, 256, RS_LDS_BYTES, ufr::as_stream(stream)>>>(input1, input2, output, B, C, H, W, RS_LDS_BYTES / 4);
+    return ufr::launched("resample2d_fwd_lds");
+  }
   hipLaunchKernelGGL(resample2d_fwd, dim3(ufr::stream_grid(npix, 256)), dim3(256), 0,
                      ufr::as_stream(stream), input1, input2, output, B, C, Hi, Wi, H, W,
                      kernel_size, bilinear);
@@ -177,6 +360,13 @@ extern "C" int ufr_resample2d_backward(const float* input1, const float* input2,
   hipError_t e = hipMemsetAsync(grad_input1, 0, sizeof(float) * (size_t)B * C * Hi * Wi, st);
   if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "resample2d backward: memset: %s", hipGetErrorString(e));
   const long npix = (long)B * H * W;
+  if (kernel_size == 1 && Hi == H && Wi == W && rs_use_lds()) {
+    const int tiles = B * ufr::ceil_div(H, RS_TH) * ufr::ceil_div(W, RS_TW);
+    rs_raise_lds();
+    resample2d_bwd_lds<<<tiles, 256, RS_LDS_BYTES, st>>>(input1, input2, grad_output, grad_input1, grad_input2, B, C, H, W,
+                                                         RS_LDS_BYTES / 4);
+    return ufr::launched("resample2d_bwd_lds");
+  }
   hipLaunchKernelGGL(resample2d_bwd, dim3(ufr::stream_grid(npix, 256)), dim3(256), 0, st, input1,
                      input2, grad_output, grad_input1, grad_input2, B, C, Hi, Wi, H, W, kernel_size);
   return ufr::launched("resample2d_bwd");

@@ -303,15 +303,24 @@ class FlowNetCHeadEngine:
         if band is not None:
             self.attach_band(band)
             inc = bool(band.width and band.incremental and band.inc_layers)
+        import os
+        planes_corr = os.environ.get("UFR_CORR_PLANES", "1") == "1"
         if c2a is not None:                      # features handed over in NCHW: convert; None: the planes are up to date
             L.require_hip(c2a, "c2a")
             self.cat2.load_nchw(c2a, 0)
             self.c3a_p.load_nchw(c3a, 0)
+            if planes_corr:
+                self.c3b_p.load_nchw(c3b, 0)
         # submodules.py:124-138 (`correlate`: /C) + FlowNetC.py:139 LeakyReLU fused into the correlation's epilogue
-        p = correlation._params(1, 1, 21, 21, 0, 0, 1, 1, 2, 2, 1, 1)
-        L.check(L.lib().ufr_corr_forward_fused(L.ptr(c3a), L.ptr(c3b), L.ptr(self.corr), L.UFR_F32, self.B, 256, *self.grid[8],
-                                               C.byref(p), 1.0 / 256.0, ig.LEAKY, L.stream()), "correlation forward")
-        self.in31.load_nchw(self.corr.view(self.B, 441, *self.grid[8]), 1)
+        if planes_corr:                          # matrix cores, planes in, conv3_1's input planes out (correlation_planes.hip)
+            L.check(L.lib().ufr_corr_forward_planes(L.ptr(self.c3a_p.t), L.ptr(self.c3b_p.t), self.c3a_p.plane_stride,
+                                                    L.ptr(self.in31.t), self.in31.plane_stride, 1, self.B, 256, *self.grid[8], 21, 2,
+                                                    1.0 / 256.0, ig.LEAKY, L.stream()), "correlation forward (planes)")
+        else:
+            p = correlation._params(1, 1, 21, 21, 0, 0, 1, 1, 2, 2, 1, 1)
+            L.check(L.lib().ufr_corr_forward_fused(L.ptr(c3a), L.ptr(c3b), L.ptr(self.corr), L.UFR_F32, self.B, 256, *self.grid[8],
+                                                   C.byref(p), 1.0 / 256.0, ig.LEAKY, L.stream()), "correlation forward")
+            self.in31.load_nchw(self.corr.view(self.B, 441, *self.grid[8]), 1)
         for name in ("conv_redir", "conv3_1", "conv4", "conv4_1"):
             (self.fwd_band if inc else self.fwd)[name]()
         for name in ("conv5", "conv5_1", "conv6", "conv6_1"):
