@@ -7,8 +7,8 @@
 //     R[x, x'] = sum_c f1[c, y, x] * f2[c, y2, x'],      needed for x' - x in {-20, -18, ..., 20}
 // Only same-parity columns meet, so a workgroup owns (sample, row, column parity): with i = x / 2, j = x' / 2 the band is
 // |j - i| <= 10.  A wave owns 16 columns i and keeps its f1 fragments (256 channels x 3 planes = 96 VGPRs) for its whole
-// life; per dy the source row's same-parity columns are streamed through LDS by LDS-DMA, a quarter of the channels at a time
-// (XOR-swizzled images like csrc/igemm.hip), and each wave multiplies its 16 columns against 3 tiles of 16 source columns
+// life; per dy the source row's same-parity columns are streamed through LDS by LDS-DMA, one 32-channel chunk per stage,
+// double-buffered (XOR-swizzled images like csrc/igemm.hip), and each wave multiplies its 16 columns against 3 tiles of 16 source columns
 // (j in [i0 - 16, i0 + 32): 44 % of the MFMA work lands inside the band), float32 = six bf16 products.
 // out channel d = dy * 21 + (j - i + 10); value = leaky(R / C).
 #include "ufr_common.h"
@@ -34,17 +34,19 @@ __device__ __forceinline__ void split3(float v, __bf16& a, __bf16& b, __bf16& c)
 }
 
 constexpr int P = 21, R = 10, KCH = 8;           // 21 displacements per axis, reach 10 same-parity columns, 8 chunks of 32 channels
-constexpr int KS = 2;                            // channel chunks per LDS stage
 
 // f1, f2: planes [3][KCH][M][32] (M = B*H*W); out: planes [3][out_chunks][M][32], channels written at chunk out_chunk0 + d / 32.
 // grid = (column blocks, 2 parities, B*H); block = NW waves.
+// Pipeline: a STAGE = one 32-channel chunk of one source row (3 planes x NJ columns x 64 B).  Two LDS buffers; the DMA of
+// stage s+1 is issued before the MFMAs of stage s and waited for (hipcc's vmcnt(0) in front of the barrier) after them: one
+// barrier per stage, loads overlap the matrix work, 43 KB of LDS per workgroup (three workgroups per CU).
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void corr_fwd_planes_kernel(const __bf16* __restrict__ f1, const __bf16* __restrict__ f2,
                                                                   long in_plane_stride, __bf16* __restrict__ out,
                                                                   long out_plane_stride, int out_chunk0, int B, int H, int W,
                                                                   float scale, float slope) {
   constexpr int NJ = 16 * NW + 32;               // staged source columns: [i0 - 16, i0 + 16 NW + 16)
-  __shared__ __attribute__((aligned(16))) __bf16 lds[3][KS][NJ * 32];
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2][3][NJ * 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int par = blockIdx.y, by = blockIdx.z, b = by / H, y = by - b * H;
   const int i0 = blockIdx.x * 16 * NW;
@@ -68,47 +70,25 @@ __global__ __launch_bounds__(64 * NW) void corr_fwd_planes_kernel(const __bf16* 
   const int frow = lane & 15;
   const int foff = frow * 32 + (((lane >> 4) ^ ((frow >> 1) & 3)) << 3);
   const __bf16* zero = reinterpret_cast<const __bf16*>(corr_zero_page);
-
-  for (int dy = 0; dy < P; ++dy) {
-    const int y2 = y + 2 * (dy - R);
-    const bool row_ok = y2 >= 0 && y2 < H;       // uniform
-    f32x4 acc[3];
+  auto stage = [&](int dy, int kc, int buf) {    // LDS-DMA of chunk kc of source row y + 2 (dy - R) into buffer `buf`
+    const long srcrow = ((long)b * H + (y + 2 * (dy - R))) * W;
+    for (int rb = wave; rb < NRB; rb += NW) {
+      const int r = rb * 16 + srow_in;            // staged row -> same-parity column j
+      const int j = i0 - 16 + r, xs = 2 * j + par;
+      const bool ok = j >= 0 && xs < W;
+      const int csw = spiece ^ ((r >> 1) & 3);
 #pragma unroll
-    for (int t = 0; t < 3; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (row_ok) {
-      const long srcrow = ((long)b * H + y2) * W;
-#pragma unroll
-      for (int s = 0; s < KCH / KS; ++s) {      // unrolled: fa[] must be indexed statically (registers, not scratch)
-        __syncthreads();                          // the previous stage's fragment reads are done
-        for (int rb = wave; rb < NRB; rb += NW) {
-          const int r = rb * 16 + srow_in;        // staged row -> same-parity column j
-          const int j = i0 - 16 + r, xs = 2 * j + par;
-          const bool ok = j >= 0 && xs < W;
-          const int csw = spiece ^ ((r >> 1) & 3);
-#pragma unroll
-          for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-              const __bf16* src = ok ? f2 + p * in_plane_stride + ((long)(s * KS + kk) * M + srcrow + xs) * 32 + csw * 8 : zero;
-              glds16(src, &lds[p][kk][rb * 16 * 32]);
-            }
-        }
-        __syncthreads();                          // hipcc waits vmcnt(0) before the barrier: every DMA has landed
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-          for (int t = 0; t < 3; ++t) {
-            bf16x8 fb[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) fb[p] = *reinterpret_cast<const bf16x8*>(&lds[p][kk][(wave + t) * 16 * 32 + foff]);
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-              acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s * KS + kk][PROD_A[q]], fb[PROD_B[q]], acc[t], 0, 0, 0);
-          }
+      for (int p = 0; p < 3; ++p) {
+        const __bf16* src = ok ? f2 + p * in_plane_stride + ((long)kc * M + srcrow + xs) * 32 + csw * 8 : zero;
+        glds16(src, &lds[buf][p][rb * 16 * 32]);
       }
     }
-    // ---- this displacement row's 21 channels of the wave's 16 columns.  C/D layout: col = lane & 15 (source column j of
-    // the tile), row = (lane >> 4) * 4 + reg (output column i)
+  };
+  auto row_ok = [&](int dy) { const int y2 = y + 2 * (dy - R); return dy < P && y2 >= 0 && y2 < H; };
+  int dy = 0;
+  while (dy < P && !row_ok(dy)) ++dy;            // rows above the frame: their channels are written as zeros below
+  // zero channels of the skipped displacement rows (top), then the pipelined rows, then the skipped bottom rows
+  auto write_row = [&](int d_row, const f32x4 (&acc)[3]) {
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -121,14 +101,43 @@ __global__ __launch_bounds__(64 * NW) void corr_fwd_planes_kernel(const __bf16* 
           v = v > 0.f ? v : v * slope;
           __bf16 p0, p1, p2;
           split3(v, p0, p1, p2);
-          const int d = dy * P + dx;
+          const int d = d_row * P + dx;
           __bf16* o = out + ((long)(out_chunk0 + (d >> 5)) * M + rowbase + x) * 32 + (d & 31);
           o[0] = p0;
           o[out_plane_stride] = p1;
           o[2 * out_plane_stride] = p2;
         }
       }
+  };
+  const f32x4 zacc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  for (int d0 = 0; d0 < dy; ++d0) write_row(d0, zacc);
+  if (dy < P) {
+    stage(dy, 0, 0);
+    __syncthreads();
   }
+  for (; dy < P && row_ok(dy); ++dy) {           // the valid rows are contiguous in dy
+    f32x4 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool more_rows = row_ok(dy + 1);
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc) {           // unrolled: fa[] indexed statically; buffer = kc & 1 (KCH is even)
+      if (kc + 1 < KCH) stage(dy, kc + 1, (kc + 1) & 1);
+      else if (more_rows) stage(dy + 1, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        bf16x8 fb[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) fb[p] = *reinterpret_cast<const bf16x8*>(&lds[kc & 1][p][(wave + t) * 16 * 32 + foff]);
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kc][PROD_A[q]], fb[PROD_B[q]], acc[t], 0, 0, 0);
+      }
+      __syncthreads();                            // own DMA landed (vmcnt(0)), every wave done with this buffer
+    }
+    write_row(dy, acc);
+  }
+  for (; dy < P; ++dy) write_row(dy, zacc);
 }
 
 }  // namespace
