@@ -154,13 +154,29 @@ def kernel_rooflines(step, device, max_count):
     prm = (1, 1, 21, 21, 0, 0, 1, 1, 2, 2, 1, 1)
     out = be.forward(a, b, *prm)
     go = torch.randn_like(out)
-    t_f = event_time(lambda: be.forward(a, b, *prm), 10)
-    pmc = _pmc("r1_corr_traffic.json")
-    tf = CORR_FWD["gflop"] * B / t_f
-    ks.append(dict(kernel="corr_fwd_vec<21,2>", ms=round(t_f, 4), bound="mfma", achieved=round(tf, 2), peak=PEAK_FP32_TFLOPS,
-                   unit="TFLOP/s", frac=round(tf / PEAK_FP32_TFLOPS, 4), hbm_gbs=round(CORR_FWD["mbytes"] * B / t_f, 1),
-                   traffic=(pmc["corr_fwd_vec<21,2>"]["fetch_bytes"] + pmc["corr_fwd_vec<21,2>"]["write_bytes"]) if "corr_fwd_vec<21,2>" in pmc else None,
-                   algorithmic_bytes=int(CORR_FWD["mbytes"] * 1e6 * B)))
+    if eng is not None:
+        # the step's cost volume: banded GEMM on the matrix cores, planes in / planes out (csrc/correlation_planes.hip).
+        # Algorithmic bytes: both feature maps' planes in (3 x bf16) + the 441 channels' planes out; flops as fp32 MACs.
+        from understanding_flow_robustness_amd import igemm as ig
+        h8, w8 = H // 8, W // 8
+        t_f = event_time(lambda: L.check(L.lib().ufr_corr_forward_planes(
+            L.ptr(eng.c3a_p.t), L.ptr(eng.c3b_p.t), eng.c3a_p.plane_stride, L.ptr(eng.in31.t), eng.in31.plane_stride, 1, B, 256,
+            h8, w8, 21, 2, 1.0 / 256.0, ig.LEAKY, L.stream())), 10)
+        tf = CORR_FWD["gflop"] * B / t_f
+        nbytes = B * h8 * w8 * (2 * 256 + 441) * 6
+        ks.append(dict(kernel="corr_fwd_planes_kernel<5> (21x21 cost volume, / C, LeakyReLU, planes in / out)", ms=round(t_f, 4), bound="mfma",
+                       achieved=round(tf, 2), peak=PEAK_FP32_TFLOPS, unit="TFLOP/s", frac=round(tf / PEAK_FP32_TFLOPS, 4),
+                       hbm_gbs=round(nbytes / t_f / 1e6, 1), traffic=_pmc("r2_corr_planes_traffic.json").get("traffic_bytes"),
+                       algorithmic_bytes=int(nbytes),
+                       note="useful fp32 flops against the fp32 vector peak; on the matrix cores 44 % of the six-product MFMA work lies in the band"))
+    else:
+        t_f = event_time(lambda: be.forward(a, b, *prm), 10)
+        pmc = _pmc("r1_corr_traffic.json")
+        tf = CORR_FWD["gflop"] * B / t_f
+        ks.append(dict(kernel="corr_fwd_vec<21,2>", ms=round(t_f, 4), bound="mfma", achieved=round(tf, 2), peak=PEAK_FP32_TFLOPS,
+                       unit="TFLOP/s", frac=round(tf / PEAK_FP32_TFLOPS, 4), hbm_gbs=round(CORR_FWD["mbytes"] * B / t_f, 1),
+                       traffic=(pmc["corr_fwd_vec<21,2>"]["fetch_bytes"] + pmc["corr_fwd_vec<21,2>"]["write_bytes"]) if "corr_fwd_vec<21,2>" in pmc else None,
+                       algorithmic_bytes=int(CORR_FWD["mbytes"] * 1e6 * B)))
     win = torch.zeros(B, 8, dtype=torch.int32, device=device)
     win[:, 0], win[:, 1] = 128, 512
     g1, g2 = torch.empty_like(a), torch.empty_like(b)

@@ -449,6 +449,17 @@ int ufr_chunks_to_nchw(const void* planes, long plane_stride, const float* f32, 
 int ufr_grad_finalize(const float* g, int g_chunk0, const void* mask, int mask_chunk0, void* out, long out_plane_stride,
                       int out_chunk0, long M, int chunks, float slope, ufr_stream_t stream);
 
+/* Both adjoints of FlowNetC's cost volume (correlation_cuda_kernel.cu:86-233; patch 21, dilation_patch 2, 256 channels) on
+ * the cells of the prefix window, on the matrix cores (csrc/correlation_window_mfma.hip), fused with everything around it:
+ * G = the engine's chunk-major float32 gradient sum of conv3_1's input (the cost volume's channels start at chunk
+ * g_chunk0; g_scale = 1 / C of models/submodules.py:124-138), G_redir (nullable) = conv_redir's input gradient, added to
+ * the first frames' rows; grad_window [2B, C, wh, ww] = d/d conv3a (rows 0..B-1) and d/d conv3b, window-sized, with the
+ * inexact rim of `margin` cells zeroed exactly as ufr_window_gather does.  win / level_stride as ufr_corr_backward_window. */
+int ufr_corr_backward_window_fused(const float* f1, const float* f2, const float* G, int g_chunk0, float g_scale,
+                                   const float* G_redir, float* grad_window, int B, int C, int H, int W, int patch,
+                                   int dilation_patch, const int* win, int level_stride, int wh, int ww, int margin,
+                                   ufr_stream_t stream);
+
 /* FlowNetC's cost volume on the matrix cores, planes in, planes out (csrc/correlation_planes.hip): replaces
  * correlation_cuda_forward_kernel (correlation_cuda_kernel.cu:21-83) + `correlate`'s / C (models/submodules.py:124-138) +
  * LeakyReLU (FlowNetC.py:139) for kernel 1, patch 21, dilation_patch 2, 256 channels.  f1 / f2: planes [3][8][B*H*W][32];
@@ -465,6 +476,11 @@ int ufr_corr_forward_planes(const void* f1_planes, const void* f2_planes, long i
  * channels 0-1 of that chunk of the fp32 gradient sum. */
 int ufr_flow_head_planes_forward(const void* planes, long plane_stride, int chunk0, int chunks, const float* wpk,
                                  const float* bias, float* out, int B, int H, int W, ufr_stream_t stream);
+/* The same convolution on the matrix cores: a per-pixel GEMM T[p, 2k + o] = sum_c x[p, c] w[o, c, k] (float32 = six bf16
+ * products, as ufr_igemm) whose A operand is the plane layout as it lies in HBM, then the 9-tap gather through LDS.
+ * wmf: bf16 [chunks][3][2][16][32] (plane p of w[o][32 ch + c][k] at n = 2k + o, zeros for n >= 18). */
+int ufr_flow_head_planes_forward_mfma(const void* planes, long plane_stride, int chunk0, int chunks, const void* wmf,
+                                      const float* bias, float* out, int B, int H, int W, ufr_stream_t stream);
 int ufr_flow_head_planes_backward(const float* grad_y, const float* wpk, float* G, int chunk0, int chunks, int B, int H,
                                   int W, int accumulate, ufr_stream_t stream);
 int ufr_flow_up_planes_forward(const float* x, const float* w, const float* bias, void* planes, long plane_stride,

@@ -132,7 +132,8 @@ def test_engine_banded_step_equals_full_frame_torch_step(net, monkeypatch):
         assert off <= 0.05 and float(err.max()) <= 5e-3 * upd
 
 
-@pytest.mark.parametrize("B,C,H,W", [(2, 194, 96, 320), (16, 70, 20, 100), (1, 386, 48, 160), (2, 1026, 12, 40), (3, 37, 7, 9)])
+@pytest.mark.parametrize("B,C,H,W", [(2, 194, 96, 320), (16, 70, 20, 100), (1, 386, 48, 160), (2, 1026, 12, 40), (3, 37, 7, 9),
+                                     (8, 194, 96, 320), (8, 386, 48, 160)])
 def test_flow_head_planes_kernels_vs_torch(B, C, H, W):
     """csrc/engine_small.hip: predict_flow (Conv2d(C,2,3,1,1)) on the chunk-major planes -- the LDS-tiled kernel of the big
     grids, the per-pixel kernel of the small ones, ragged tiles -- and its data gradient (write and accumulate), against
@@ -140,7 +141,7 @@ def test_flow_head_planes_kernels_vs_torch(B, C, H, W):
     import torch.nn.functional as F
     from understanding_flow_robustness_amd import _lib as L
     from understanding_flow_robustness_amd import igemm as ig
-    from understanding_flow_robustness_amd.flownetc_engine import _pack_flow_head
+    from understanding_flow_robustness_amd.flownetc_engine import _pack_flow_head, _pack_flow_head_mfma
     g = torch.Generator().manual_seed(5)
     x = torch.randn(B, C, H, W, generator=g).to(DEV)
     w = (torch.randn(2, C, 3, 3, generator=g) * 0.1).to(DEV)
@@ -153,6 +154,11 @@ def test_flow_head_planes_kernels_vs_torch(B, C, H, W):
                                                  L.stream()))
     want = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
     assert _rel(out, want) <= 1e-5, f"forward {_rel(out, want):.2e}"
+    # the matrix-core form (per-pixel GEMM + 9-tap gather): tile heights 8 / 4 / 2, one and two chunk slices
+    out_m = torch.full((B, 2, H, W), float("nan"), device=DEV)
+    L.check(L.lib().ufr_flow_head_planes_forward_mfma(L.ptr(pl.t), pl.plane_stride, 1, chunks, L.ptr(_pack_flow_head_mfma(w)), L.ptr(b),
+                                                      L.ptr(out_m), B, H, W, L.stream()))
+    assert _rel(out_m, want) <= 1e-5, f"forward (mfma) {_rel(out_m, want):.2e}"
     gy = torch.randn(B, 2, H, W, generator=g).to(DEV)
     x0 = torch.zeros(B, C, H, W, device=DEV, dtype=torch.float64, requires_grad=True)
     (gx,) = torch.autograd.grad(F.conv2d(x0, w.double(), None, 1, 1), x0, gy.double())
@@ -187,3 +193,48 @@ def test_correlation_on_planes_equals_the_reference_cost_volume(B, H, W):
     assert _rel(got, want) <= 1e-5, f"cost volume {_rel(got, want):.2e}"
     assert bool((out.t[:, 0] == 3.0).all())                              # conv_redir's chunk is untouched
     assert bool((out.t[:, 14, :, 25:] == 3.0).all())                     # channels 441..447: never written (the engine keeps them zero)
+
+
+@pytest.mark.parametrize("B,H,W,wh,ww,margin,origins", [
+    (2, 48, 160, 16, 16, 2, [(128, 512), (0, 0)]),            # interior window; window on the frame's corner (no rim there)
+    (3, 24, 40, 16, 16, 1, [(64, 192), (8, 8), (40, 100)]),    # clamped origins, window reaching the right / bottom edge
+    (1, 20, 36, 10, 12, 0, [(24, 56)]),                        # ragged window (fewer than 16 cells), no rim
+])
+def test_corr_backward_window_fused_equals_the_unfused_chain(B, H, W, wh, ww, margin, origins):
+    """csrc/correlation_window_mfma.hip (both adjoints of the cost volume on the window's cells, on the matrix cores, read
+    from the chunk-major gradient sums, + conv_redir's gradient, written window-sized with the rim zeroed) against the
+    chain it replaces: gradient sum -> NCHW, the full correlation backward (pinned to the reference's CPU implementation
+    in tests/test_ops_gpu.py), + conv_redir's gradient, ufr_window_gather."""
+    import ctypes as C
+    from understanding_flow_robustness_amd import _lib as L
+    from understanding_flow_robustness_amd import igemm as ig
+    from understanding_flow_robustness_amd import spatial_correlation_sampler_backend as correlation
+    g = torch.Generator().manual_seed(11)
+    f1, f2 = torch.randn(B, 256, H, W, generator=g).to(DEV), torch.randn(B, 256, H, W, generator=g).to(DEV)
+    gc = torch.randn(B, 441, H, W, generator=g).to(DEV)                  # d loss / d (cost volume / C ... before the 1/C)
+    gr = torch.randn(B, 256, H, W, generator=g).to(DEV)                  # conv_redir's input gradient
+    M = B * H * W
+
+    def chunked(x, chunks, chunk0):                                       # NCHW -> float32 [chunks][M][32]
+        full = torch.zeros(B, chunks * 32, H, W, device=DEV)
+        full[:, chunk0 * 32:chunk0 * 32 + x.shape[1]] = x
+        return full.view(B, chunks, 32, H, W).permute(1, 0, 3, 4, 2).reshape(chunks, M, 32).contiguous()
+    G, Gr = chunked(gc, 15, 1), chunked(gr, 8, 0)
+    win = torch.zeros(B, 8, dtype=torch.int32, device=DEV)
+    for n, (oy, ox) in enumerate(origins):
+        win[n, 0], win[n, 1] = oy, ox
+    got = torch.full((2 * B, 256, wh, ww), float("nan"), device=DEV)
+    L.check(L.lib().ufr_corr_backward_window_fused(L.ptr(f1), L.ptr(f2), L.ptr(G), 1, 1.0 / 256.0, L.ptr(Gr), L.ptr(got), B, 256, H, W,
+                                                   21, 2, L.ptr(win), 8, wh, ww, margin, L.stream()))
+    p = correlation._params(1, 1, 21, 21, 0, 0, 1, 1, 2, 2, 1, 1)
+    g1, g2 = torch.empty_like(f1), torch.empty_like(f2)
+    gcs = (gc / 256.0).contiguous()
+    L.check(L.lib().ufr_corr_backward(L.ptr(f1), L.ptr(f2), L.ptr(gcs), L.ptr(g1), L.ptr(g2), L.UFR_F32, B, 256, H, W, C.byref(p),
+                                      L.stream()))
+    g1 += gr
+    want = torch.empty(2 * B, 256, wh, ww, device=DEV)
+    for src, dst in ((g1, want[:B]), (g2, want[B:])):
+        L.check(L.lib().ufr_window_gather(L.ptr(src), L.ptr(dst), L.ptr(win), B, B, 256, H, W, wh, ww, 8, margin, L.stream()))
+    assert bool(torch.isfinite(got).all())
+    assert bool(((want == 0) == (got == 0)).all()) or margin == 0        # the rim is zero in both
+    assert _rel(got[:B], want[:B]) <= 1e-5 and _rel(got[B:], want[B:]) <= 1e-5, (_rel(got[:B], want[:B]), _rel(got[B:], want[B:]))

@@ -35,6 +35,7 @@ def emit(kernel, config, ms, nbytes, note=""):
 
 
 def main():
+    only_resample = "--resample-only" in sys.argv
     lib = L.lib()
     g = torch.Generator().manual_seed(0)
     rnd = lambda *s: torch.randn(*s, generator=g).to(DEV)
@@ -42,15 +43,21 @@ def main():
     # ---- FlowNet2 @448x1024 (C5: one pair per GPU, and 8 pairs)
     for B in (1, 8):
         H, W = 448, 1024
-        img, flow = torch.rand(B, 3, H, W, generator=g).to(DEV), (4 * torch.randn(B, 2, H, W, generator=g)).to(DEV)
+        img = torch.rand(B, 3, H, W, generator=g).to(DEV)
         out, gout = torch.empty_like(img), rnd(B, 3, H, W)
-        gimg, gflow = torch.empty_like(img), torch.empty_like(flow)
         cfg = f"FlowNet2 448x1024, {B} pair(s)"
-        ms = timed(lambda: L.check(lib.ufr_resample2d_forward(L.ptr(img), L.ptr(flow), L.ptr(out), B, 3, H, W, H, W, 1, 1, st())))
-        emit("resample2d_fwd", cfg, ms, (img.numel() + flow.numel() + out.numel()) * 4)
-        ms = timed(lambda: L.check(lib.ufr_resample2d_backward(L.ptr(img), L.ptr(flow), L.ptr(gout), L.ptr(gimg), L.ptr(gflow), B, 3, H, W,
-                                                               H, W, 1, 1, st())))
-        emit("resample2d_bwd (image + flow gradients)", cfg, ms, (img.numel() + flow.numel() + gout.numel() + gimg.numel() + gflow.numel()) * 4)
+        # two flow fields: 'smooth' = what a flow network emits (a 1/16-resolution field of +-16 px, bilinearly upsampled, plus
+        # 0.25 px of noise); 'rough' = independent 4 px noise per pixel (worst case for locality)
+        coarse = 16 * torch.randn(B, 2, H // 16, W // 16, generator=g)
+        smooth = torch.nn.functional.interpolate(coarse, size=(H, W), mode="bilinear", align_corners=False) + 0.25 * torch.randn(B, 2, H, W, generator=g)
+        for kind, flow in (("smooth", smooth.to(DEV)), ("rough", (4 * torch.randn(B, 2, H, W, generator=g)).to(DEV))):
+            gimg, gflow = torch.empty_like(img), torch.empty_like(flow)
+            ms = timed(lambda: L.check(lib.ufr_resample2d_forward(L.ptr(img), L.ptr(flow), L.ptr(out), B, 3, H, W, H, W, 1, 1, st())))
+            emit(f"resample2d_fwd ({kind} flow)", cfg, ms, (img.numel() + flow.numel() + out.numel()) * 4)
+            ms = timed(lambda: L.check(lib.ufr_resample2d_backward(L.ptr(img), L.ptr(flow), L.ptr(gout), L.ptr(gimg), L.ptr(gflow), B, 3, H, W,
+                                                                   H, W, 1, 1, st())))
+            emit(f"resample2d_bwd (image + flow gradients, {kind} flow)", cfg, ms,
+                 (img.numel() + flow.numel() + gout.numel() + gimg.numel() + gflow.numel()) * 4)
         for C in (3, 2):
             x = rnd(B, C, H, W)
             nrm, gn, gx = torch.empty(B, 1, H, W, device=DEV), rnd(B, 1, H, W), torch.empty_like(x)
@@ -58,6 +65,8 @@ def main():
             emit(f"channelnorm_fwd C={C}", cfg, ms, (x.numel() + nrm.numel()) * 4)
             ms = timed(lambda: L.check(lib.ufr_channelnorm_backward(L.ptr(x), L.ptr(nrm), L.ptr(gn), L.ptr(gx), B, C, H, W, 2, st())))
             emit(f"channelnorm_bwd C={C}", cfg, ms, (2 * x.numel() + 2 * nrm.numel()) * 4)
+    if only_resample:
+        return
     # ---- RAFT @384x1280 (C3): 48x160 cells, 4 pyramid levels, radius 4
     from understanding_flow_robustness_amd import alt_cuda_corr
     from understanding_flow_robustness_amd.flownets import raft as R

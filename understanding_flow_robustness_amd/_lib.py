@@ -110,6 +110,7 @@ SIGNATURES = {
     "ufr_cone_window": [_vp, _i, _l, _i, _i, _i, C.POINTER(ConeChain), _i, _i, _vp, _vp, _vp],
     "ufr_window_gather": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ufr_window_scatter": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ufr_corr_backward_window_fused": [_vp, _vp, _vp, _i, _f, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp],
     "ufr_corr_backward_window": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp],
     "ufr_bias_leaky_forward": [_vp, _vp, _i, _i, _l, _f, _vp],
     "ufr_leaky_backward": [_vp, _vp, _vp, _l, _f, _vp],
@@ -125,6 +126,7 @@ SIGNATURES = {
     "ufr_chunks_to_nchw": [_vp, _l, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _f, _vp],
     "ufr_grad_finalize": [_vp, _i, _vp, _i, _vp, _l, _i, _l, _i, _f, _vp],
     "ufr_flow_head_planes_forward": [_vp, _l, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "ufr_flow_head_planes_forward_mfma": [_vp, _l, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ufr_flow_head_planes_backward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "ufr_flow_up_planes_forward": [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp],
     "ufr_flow_up_planes_backward": [_vp, _i, _vp, _vp, _i, _i, _i, _vp],

@@ -172,6 +172,109 @@ __global__ __launch_bounds__(1024) void flow_head_planes_fwd_small(const __bf16*
   }
 }
 
+// ---- predict_flow* on the matrix cores ------------------------------------------------------------------------------
+// out[o, y, x] = bias[o] + sum_k sum_c x[c, y + ky, x + kx] w[o, c, k] is computed as a GEMM per PIXEL followed by a
+// 9-tap gather:  T[p, n = 2k + o] = sum_c x[p, c] w[o, c, k]   (M = pixels of the tile + halo, N = 18 padded to 32, K = C)
+//                out[o, p]      = bias[o] + sum_k T[p + tap k, 2k + o]
+// The A operand is the engine's plane layout as it lies in HBM (a lane's fragment = 8 channels of one pixel = one 16-byte
+// load per plane, no LDS staging); float32 = six bf16 products (csrc/igemm.hip); T goes through LDS once.  Workgroup =
+// TH x 32 pixels (+ halo) x S chunk slices; wave = (slice, tile lane): m-tiles tw, tw + 4, ... of 16 halo pixels.
+// wmf: bf16 [chunks][3 planes][2 n-tiles][16][32]: plane p of w[o][32 ch + c][k] at n = 2k + o, zero for n >= 18.
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+__device__ constexpr int PFM_A[6] = {2, 0, 1, 1, 0, 0};
+__device__ constexpr int PFM_B[6] = {0, 2, 1, 0, 1, 0};
+__device__ __attribute__((aligned(64))) unsigned pf_zero_page[16];
+constexpr int PFM_TW = 32, PFM_HW = PFM_TW + 2, PFM_MAXT = 6, PFM_TS = 20;   // T row stride (floats): 18 used
+
+__global__ __launch_bounds__(512) void flow_head_planes_fwd_mfma(const __bf16* __restrict__ x, long plane_stride, int chunk0,
+                                                                  int chunks, const __bf16* __restrict__ wmf,
+                                                                  const float* __restrict__ bias, float* __restrict__ out,
+                                                                  int B, int H, int W, int TH, int S) {
+  extern __shared__ __attribute__((aligned(16))) float pfm_T[];            // [S][mt * 16][PFM_TS]
+  const long M = (long)B * H * W;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, slice = wave >> 2, tw = wave & 3;
+  const int tiles_x = (W + PFM_TW - 1) / PFM_TW, tiles_y = (H + TH - 1) / TH;
+  const int b = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x - b * tiles_x * tiles_y;
+  const int y0 = (tr / tiles_x) * TH, x0 = (tr % tiles_x) * PFM_TW;
+  const int nh = (TH + 2) * PFM_HW, mt = (nh + 15) >> 4;
+  const __bf16* zero = reinterpret_cast<const __bf16*>(pf_zero_page);
+  // this lane's halo pixel in each of its m-tiles
+  const __bf16* abase[PFM_MAXT];
+  unsigned okmask = 0;
+#pragma unroll
+  for (int s = 0; s < PFM_MAXT; ++s) {
+    const int hp = (tw + 4 * s) * 16 + (lane & 15);
+    const int hy = hp / PFM_HW, hx = hp - hy * PFM_HW;
+    const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+    const bool ok = tw + 4 * s < mt && hp < nh && yy >= 0 && yy < H && xx >= 0 && xx < W;
+    abase[s] = ok ? x + ((long)chunk0 * M + ((long)b * H + yy) * W + xx) * 32 + (lane >> 4) * 8 : zero;
+    okmask |= ok ? 1u << s : 0u;
+  }
+  f32x4 acc[PFM_MAXT][2];
+#pragma unroll
+  for (int s = 0; s < PFM_MAXT; ++s) acc[s][0] = acc[s][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int per = (chunks + S - 1) / S, c_lo = slice * per, c_hi = min(chunks, c_lo + per);
+  const __bf16* wl = wmf + (lane & 15) * 32 + (lane >> 4) * 8;
+  for (int ch = c_lo; ch < c_hi; ++ch) {
+    bf16x8 fb[2][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) fb[nt][p] = *reinterpret_cast<const bf16x8*>(wl + (((long)ch * 3 + p) * 2 + nt) * 512);
+    bf16x8 fa[PFM_MAXT][3];
+#pragma unroll
+    for (int s = 0; s < PFM_MAXT; ++s)
+      if (tw + 4 * s < mt) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const long off = (okmask >> s & 1u) ? (long)ch * M * 32 + p * plane_stride : 0;   // the zero page does not move
+          fa[s][p] = *reinterpret_cast<const bf16x8*>(abase[s] + off);
+        }
+      }
+#pragma unroll
+    for (int s = 0; s < PFM_MAXT; ++s)
+      if (tw + 4 * s < mt) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int q = 0; q < 6; ++q)
+            acc[s][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s][PFM_A[q]], fb[nt][PFM_B[q]], acc[s][nt], 0, 0, 0);
+      }
+  }
+  // T: lane holds D[m = 4 (lane >> 4) + r][n = lane & 15]
+  float* T = pfm_T + (long)slice * mt * 16 * PFM_TS;
+#pragma unroll
+  for (int s = 0; s < PFM_MAXT; ++s)
+    if (tw + 4 * s < mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* row = T + ((tw + 4 * s) * 16 + (lane >> 4) * 4 + r) * PFM_TS;
+        row[lane & 15] = acc[s][0][r];
+        if ((lane & 15) < 2) row[16 + (lane & 15)] = acc[s][1][r];
+      }
+    }
+  __syncthreads();
+  if (tid < TH * PFM_TW) {
+    const int ly = tid / PFM_TW, lx = tid - ly * PFM_TW;
+    const int yy = y0 + ly, xx = x0 + lx;
+    if (yy < H && xx < W) {
+      float r0 = 0.f, r1 = 0.f;
+      for (int sl = 0; sl < S; ++sl) {               // slices, then taps, in ascending order
+        const float* Ts = pfm_T + (long)sl * mt * 16 * PFM_TS;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const float* e = Ts + ((ly + k / 3) * PFM_HW + lx + k % 3) * PFM_TS + 2 * k;
+          r0 += e[0];
+          r1 += e[1];
+        }
+      }
+      const long HW = (long)H * W, p = (long)yy * W + xx;
+      out[((long)b * 2 + 0) * HW + p] = r0 + bias[0];
+      out[((long)b * 2 + 1) * HW + p] = r1 + bias[1];
+    }
+  }
+}
+
 // G[chunk0 + ch][pix][c] (+)= sum_o sum_k gy[b, o, pix - (k - centre)] * weight[o][32*ch + c][k]
 // thread = (pixel, 8-channel group), blockIdx.y = slice of the chunks (independent outputs: no reduction)
 __global__ __launch_bounds__(256) void flow_head_planes_bwd(const float* __restrict__ gy, const float* __restrict__ wpk,
@@ -325,6 +428,30 @@ extern "C" int ufr_flow_head_planes_forward(const void* planes, long plane_strid
   flow_head_planes_fwd_small<<<sblocks, 256 * S, lds, st>>>(static_cast<const __bf16*>(planes), plane_stride, chunk0, chunks, wpk,
                                                            bias, out, B, H, W, S);
   return ufr::launched("flow_head_planes_fwd_small");
+}
+
+extern "C" int ufr_flow_head_planes_forward_mfma(const void* planes, long plane_stride, int chunk0, int chunks, const void* wmf,
+                                                 const float* bias, float* out, int B, int H, int W, ufr_stream_t stream) {
+  UFR_REQUIRE(planes && wmf && bias && out, "flow head (planes, mfma) forward: null pointer");
+  UFR_REQUIRE(B > 0 && H > 0 && W > 0 && chunks > 0 && chunks <= 48 && chunk0 >= 0 && (long)B * H * W < (1L << 29),
+              "flow head (planes, mfma) forward: bad shape");
+  auto blocks_of = [&](int th) { return B * ufr::ceil_div(H, th) * ufr::ceil_div(W, PFM_TW); };
+  const int TH = blocks_of(8) >= 512 ? 8 : (blocks_of(4) >= 256 ? 4 : 2);
+  const int blocks = blocks_of(TH);
+  const int S = (blocks >= 512 || chunks < 4) ? 1 : 2;
+  const int mt = ((TH + 2) * PFM_HW + 15) / 16;
+  const size_t lds = (size_t)S * mt * 16 * PFM_TS * sizeof(float);
+  static size_t lds_allowed = 64 * 1024;
+  if (lds > lds_allowed) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flow_head_planes_fwd_mfma),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "flow head (planes, mfma) forward: %s", hipGetErrorString(e));
+    lds_allowed = lds;
+  }
+  flow_head_planes_fwd_mfma<<<blocks, 256 * S, lds, ufr::as_stream(stream)>>>(static_cast<const __bf16*>(planes), plane_stride, chunk0,
+                                                                              chunks, static_cast<const __bf16*>(wmf), bias, out, B, H,
+                                                                              W, TH, S);
+  return ufr::launched("flow_head_planes_fwd_mfma");
 }
 
 extern "C" int ufr_flow_head_planes_backward(const float* grad_y, const float* wpk, float* G, int chunk0, int chunks, int B,

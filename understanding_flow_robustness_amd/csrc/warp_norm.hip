@@ -123,6 +123,7 @@ __global__ void resample2d_bwd(const float* __restrict__ img, const float* __res
 // tiles overlap), instead of 4*C global float atomics per pixel (resample2d_kernel.cu:118-121's scheme).  A box that does
 // not fit (wild flow) falls back to the direct form, tile by tile; the arithmetic is identical either way.
 constexpr int RS_TH = 8, RS_TW = 32;
+constexpr int RS_FWD_MAX_AREA = 3 * RS_TH * RS_TW;
 
 struct RsBox { int x0, y0, bw, bh; };
 
@@ -163,12 +164,15 @@ __global__ __launch_bounds__(256) void resample2d_fwd_lds(const float* __restric
   const double wTL = (1. - alpha) * (1. - beta), wTR = (double)alpha * (1. - beta);
   const double wBL = (1. - alpha) * (double)beta, wBR = (double)alpha * (double)beta;
   const RsBox bx = rs_tile_box(xL, xR, yT, yB, live, red);
-  const bool staged = (long)C * bx.bw * bx.bh <= lds_floats;          // uniform
+  // uniform.  Staging pays only while the box is not much larger than the tile (smooth flow): a box of more than
+  // RS_FWD_MAX_AREA cells costs more coalesced reads than the 4 taps per pixel it saves (measured: profiles/r2_hbm_ops*).
+  const bool staged = (long)C * bx.bw * bx.bh <= lds_floats && bx.bw * bx.bh <= RS_FWD_MAX_AREA;
   if (staged) {
     const int area = bx.bw * bx.bh;
-    for (int i = tid; i < C * area; i += 256) {
-      const int c = i / area, r = i - c * area, ry = r / bx.bw, rx = r - ry * bx.bw;
-      rs_lds[i] = img[((size_t)b * C + c) * plane + (size_t)(bx.y0 + ry) * W + bx.x0 + rx];
+    for (int r = tid >> 6; r < C * bx.bh; r += 4) {                   // one wave per box row: coalesced, no per-cell division
+      const int c = r / bx.bh, ry = r - c * bx.bh;
+      const float* src = img + ((size_t)b * C + c) * plane + (size_t)(bx.y0 + ry) * W + bx.x0;
+      for (int rx = tid & 63; rx < bx.bw; rx += 64) rs_lds[c * area + ry * bx.bw + rx] = src[rx];
     }
     __syncthreads();
     if (live) {
@@ -224,10 +228,13 @@ __global__ __launch_bounds__(256) void resample2d_bwd_lds(const float* __restric
   float o0 = 0.f, o1 = 0.f;
   if (staged) {
     float* gbox = rs_lds + C * area;
-    for (int i = tid; i < C * area; i += 256) {
-      const int c = i / area, r = i - c * area, ry = r / bx.bw, rx = r - ry * bx.bw;
-      rs_lds[i] = img[((size_t)b * C + c) * plane + (size_t)(bx.y0 + ry) * W + bx.x0 + rx];
-      gbox[i] = 0.f;
+    for (int r = tid >> 6; r < C * bx.bh; r += 4) {                   // one wave per box row
+      const int c = r / bx.bh, ry = r - c * bx.bh;
+      const float* src = img + ((size_t)b * C + c) * plane + (size_t)(bx.y0 + ry) * W + bx.x0;
+      for (int rx = tid & 63; rx < bx.bw; rx += 64) {
+        rs_lds[c * area + ry * bx.bw + rx] = src[rx];
+        gbox[c * area + ry * bx.bw + rx] = 0.f;
+      }
     }
     __syncthreads();
     if (live) {
@@ -247,11 +254,12 @@ __global__ __launch_bounds__(256) void resample2d_bwd_lds(const float* __restric
       }
     }
     __syncthreads();
-    for (int i = tid; i < C * area; i += 256) {
-      const float v = gbox[i];
-      if (v != 0.f) {
-        const int c = i / area, r = i - c * area, ry = r / bx.bw, rx = r - ry * bx.bw;
-        atomicAdd(&gimg[((size_t)b * C + c) * plane + (size_t)(bx.y0 + ry) * W + bx.x0 + rx], v);
+    for (int r = tid >> 6; r < C * bx.bh; r += 4) {
+      const int c = r / bx.bh, ry = r - c * bx.bh;
+      float* dst = gimg + ((size_t)b * C + c) * plane + (size_t)(bx.y0 + ry) * W + bx.x0;
+      for (int rx = tid & 63; rx < bx.bw; rx += 64) {
+        const float v = gbox[c * area + ry * bx.bw + rx];
+        if (v != 0.f) atomicAdd(&dst[rx], v);
       }
     }
   } else if (live) {
@@ -312,9 +320,12 @@ __global__ void channelnorm_bwd(const float* __restrict__ in, const float* __res
 
 constexpr int RS_LDS_BYTES = 48 * 1024;         // per workgroup: three workgroups per CU
 
-bool rs_use_lds() {
-  static const bool v = [] { const char* e = getenv("UFR_RESAMPLE_LDS"); return !(e && e[0] == '0'); }();
-  return v;
+// UFR_RESAMPLE_LDS: unset / 1 = LDS-privatised adjoint, direct forward (the measured optimum: profiles/r2_hbm_ops_*: the
+// forward's 12 taps per pixel are already served by L1 / L2, staging the box costs more than it saves -- 0.112 vs 0.071 ms
+// at 8 x 448x1024 with a smooth flow -- while the adjoint's atomics drop 3x: 1.56 -> 0.50 ms); 0 = both direct; 2 = both LDS.
+int rs_lds_mode() {
+  const char* e = getenv("UFR_RESAMPLE_LDS");      // read per call: the tests switch it
+  return e ? (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)) : 1;
 }
 
 void rs_raise_lds() {
@@ -335,7 +346,7 @@ extern "C" int ufr_resample2d_forward(const float* input1, const float* input2, 
   UFR_REQUIRE(B > 0 && C > 0 && Hi > 0 && Wi > 0 && H > 0 && W > 0 && kernel_size >= 1,
               "resample2d forward: bad shape");
   const long npix = (long)B * H * W;
-  if (kernel_size == 1 && bilinear && Hi == H && Wi == W && rs_use_lds()) {       // FlowNet2's configuration: LDS-staged form
+  if (kernel_size == 1 && bilinear && Hi == H && Wi == W && rs_lds_mode() == 2) {   // LDS-staged form (opt-in: see rs_lds_mode)
     const int tiles = B * ufr::ceil_div(H, RS_TH) * ufr::ceil_div(W, RS_TW);
     rs_raise_lds();
     resample2d_fwd_lds<<<tiles, 256, RS_LDS_BYTES, ufr::as_stream(stream)>>>(input1, input2, output, B, C, H, W, RS_LDS_BYTES / 4);
@@ -360,7 +371,7 @@ extern "C" int ufr_resample2d_backward(const float* input1, const float* input2,
   hipError_t e = hipMemsetAsync(grad_input1, 0, sizeof(float) * (size_t)B * C * Hi * Wi, st);
   if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "resample2d backward: memset: %s", hipGetErrorString(e));
   const long npix = (long)B * H * W;
-  if (kernel_size == 1 && Hi == H && Wi == W && rs_use_lds()) {
+  if (kernel_size == 1 && Hi == H && Wi == W && rs_lds_mode() >= 1) {
     const int tiles = B * ufr::ceil_div(H, RS_TH) * ufr::ceil_div(W, RS_TW);
     rs_raise_lds();
     resample2d_bwd_lds<<<tiles, 256, RS_LDS_BYTES, st>>>(input1, input2, grad_output, grad_input1, grad_input2, B, C, H, W,

@@ -21,6 +21,8 @@ attack's HIP graph captures it as is.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -36,6 +38,18 @@ def _pack_flow_head(weight: torch.Tensor) -> torch.Tensor:
     w = torch.zeros(2, chunks * 32, 9, dtype=torch.float32, device=weight.device)
     w[:, :cin] = weight.detach().float().reshape(2, cin, 9)
     return w.view(2, chunks, 32, 9).permute(1, 3, 0, 2).contiguous()
+
+
+def _pack_flow_head_mfma(weight: torch.Tensor) -> torch.Tensor:
+    """Conv2d(Cin, 2, 3, 1, 1).weight -> bf16 [chunks][3 planes][2][16][32]: plane p of w[o][32 ch + c][k] at n = 2 k + o
+    (the B operand of csrc/engine_small.hip `flow_head_planes_fwd_mfma`; columns 18..31 are zero)."""
+    cin = weight.shape[1]
+    chunks = ig.pad32(cin) // 32
+    w = torch.zeros(chunks * 32, 32, dtype=torch.float32, device=weight.device)          # [c][n]
+    w[:cin, :18] = weight.detach().float().reshape(2, cin, 9).permute(1, 2, 0).reshape(cin, 18)
+    wn = w.view(chunks, 32, 32).permute(0, 2, 1).contiguous()                              # [chunk][n][c]
+    planes = ig._split3(wn).view(3, chunks, 32, 32).permute(1, 0, 2, 3).contiguous()      # [chunk][plane][n][c]
+    return planes
 
 
 class FlowNetCHeadEngine:
@@ -135,6 +149,8 @@ class FlowNetCHeadEngine:
         self._band, self.fwd_band, self.bwd_band = None, {}, {}
         # 2-channel layers
         self.pf_w = {k: _pack_flow_head(getattr(net, f"predict_flow{k}").weight) for k, _ in _HEADS}
+        self.pf_wm = {k: _pack_flow_head_mfma(getattr(net, f"predict_flow{k}").weight) for k, _ in _HEADS}
+        self.pf_mfma = os.environ.get("UFR_PF_MFMA", "1") != "0"
         self.pf_b = {k: getattr(net, f"predict_flow{k}").bias.detach().float().contiguous() for k, _ in _HEADS}
         self.up = {k: getattr(net, f"upsampled_flow{k}_to_{k - 1}") for k in (6, 5, 4, 3)}
         self.up_w = {k: m.weight.detach().float().contiguous() for k, m in self.up.items()}
@@ -258,6 +274,11 @@ class FlowNetCHeadEngine:
     # ------------------------------------------------------------------------------------------------ small launches
     def _pf_forward(self, k):
         src, chunks = self.pf_src[k]
+        if self.pf_mfma:
+            L.check(L.lib().ufr_flow_head_planes_forward_mfma(L.ptr(src.t), src.plane_stride, 0, chunks, L.ptr(self.pf_wm[k]),
+                                                              L.ptr(self.pf_b[k]), L.ptr(self.flow[k]), self.B, src.H, src.W,
+                                                              L.stream()), "predict_flow forward (mfma)")
+            return
         L.check(L.lib().ufr_flow_head_planes_forward(L.ptr(src.t), src.plane_stride, 0, chunks, L.ptr(self.pf_w[k]),
                                                      L.ptr(self.pf_b[k]), L.ptr(self.flow[k]), self.B, src.H, src.W,
                                                      L.stream()), "predict_flow forward")
@@ -332,10 +353,12 @@ class FlowNetCHeadEngine:
             self._pf_forward(k)
         return self.flow[2]
 
-    def backward(self, g_flow2: torch.Tensor, band=None):
+    def backward(self, g_flow2: torch.Tensor, band=None, fused_window: bool = True):
         """d loss / d flow2 -> (d/d conv2a, d/d conv3a, d/d conv3b), all NCHW float32 (static buffers).
         With a band: the data gradients of conv5, conv4_1, conv4, conv3_1 and conv_redir run on the band's columns and the
-        correlation's adjoint on the window's cells (only those are read behind a windowed prefix)."""
+        correlation's adjoint on the window's cells (only those are read behind a windowed prefix).  When the band carries
+        `g3_window` (the window-sized gradient of conv3, both frames: patch_attack.py) and `fused_window`, the correlation's
+        adjoints are written there directly and the last two results are None."""
         L.require_hip(g_flow2, "g_flow2")
         B = self.B
         banded = band is not None and bool(band.width)
@@ -361,6 +384,17 @@ class FlowNetCHeadEngine:
         for name in ("conv5", "conv4_1", "conv4", "conv3_1", "conv_redir"):
             (self.bwd_band if banded else self.bwd)[name]()
         # conv_redir's input and the correlation's two inputs
+        gw = getattr(band, "g3_window", None) if (band is not None and fused_window) else None
+        h8, w8 = self.grid[8]
+        if (gw is not None and band.cone_win is not None and band.cone_hw[1] // 8 <= 16 and w8 % 4 == 0
+                and os.environ.get("UFR_CORR_BWD_MFMA", "1") != "0"):
+            # windowed prefix behind the head: the cost volume's adjoints on the window's cells, on the matrix cores, straight
+            # from the gradient sums into the window-sized gradient (correlation_window_mfma.hip)
+            L.check(L.lib().ufr_corr_backward_window_fused(L.ptr(self._c3a), L.ptr(self._c3b), L.ptr(self.G_in31.t), 1, 1.0 / 256.0,
+                                                           L.ptr(self.G_c3a.t), L.ptr(gw), B, 256, h8, w8, 21, 2,
+                                                           L.ptr(band.cone_win), 8, band.cone_hw[0] // 8, band.cone_hw[1] // 8,
+                                                           int(band.g3_margin), L.stream()), "correlation backward (window, fused)")
+            return self.g_c2a, None, None
         self.G_c3a.to_nchw(256, 0, out=self.g_c3a_redir)
         self.G_in31.to_nchw(441, 1, scale=1.0 / 256.0, out=self.g_corr.view(B, 441, *self.grid[8]))
         self._corr_backward(self.g_corr, band)
@@ -392,7 +426,7 @@ class _EngineHead(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_flow2):
-        g2a, g3a, g3b = ctx.engine.backward(g_flow2.contiguous(), ctx.band)
+        g2a, g3a, g3b = ctx.engine.backward(g_flow2.contiguous(), ctx.band, fused_window=False)
         return g2a, g3a, g3b, None, None
 
 

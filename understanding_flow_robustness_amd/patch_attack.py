@@ -306,11 +306,14 @@ class PatchAttackStep:
         lib, B, H, W = L.lib(), self.B, self.H, self.W
         if self.eng is not None:
             (g_flow2,) = torch.autograd.grad(flow, (self.eng.flow[2],), self.g_flow)
-            g2a, g3a, g3b = self.eng.backward(g_flow2.contiguous(), self.band)
             (ls2, m2, _, _, gw2), (ls3, m3, _, _, gw3) = self.taps
+            if self.band is not None:            # the engine writes conv3's window gradient itself (fused correlation adjoint)
+                self.band.g3_window, self.band.g3_margin = gw3, m3
+            g2a, g3a, g3b = self.eng.backward(g_flow2.contiguous(), self.band)
             self._win_copy(lib.ufr_window_gather, g2a, gw2, B, 128, H // ls2, W // ls2, ls2, m2)
-            self._win_copy(lib.ufr_window_gather, g3a, gw3, B, 256, H // ls3, W // ls3, ls3, m3)
-            self._win_copy(lib.ufr_window_gather, g3b, gw3[B:], B, 256, H // ls3, W // ls3, ls3, m3)
+            if g3a is not None:
+                self._win_copy(lib.ufr_window_gather, g3a, gw3, B, 256, H // ls3, W // ls3, ls3, m3)
+                self._win_copy(lib.ufr_window_gather, g3b, gw3[B:], B, 256, H // ls3, W // ls3, ls3, m3)
         else:
             g_full = torch.autograd.grad(flow, [t[3] for t in self.taps], self.g_flow)
             for g, (ls, m, n, _, gwin) in zip(g_full, self.taps):
