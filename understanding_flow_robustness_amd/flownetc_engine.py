@@ -220,6 +220,74 @@ class FlowNetCHeadEngine:
         L.check(lib.ufr_window_scatter(L.ptr(c3_w), L.ptr(self.c3_nchw), L.ptr(win), B, 2 * B, 256, h8, w8, wh // 8, ww // 8, 8,
                                        m3, st), "window -> nchw (conv3)")
 
+    # ------------------------------------------------------------------------------------------------ windowed conv1-3
+    def _build_window_prefix(self, wh: int, ww: int):
+        """conv1-3 of both frames on the patch attack's prefix window (patch_attack.py `_forward_cone`: [2B, 3, wh, ww]) and
+        their data gradients.  conv2 / conv3 (5x5, stride 2: 92% of the window's FLOPs) and both of their data gradients run
+        on the igemm; conv1 (3 input channels) and its data gradient stay on torch / MIOpen, as in `prefix_full`."""
+        B2, dev = 2 * self.B, self.dev
+        f32 = dict(dtype=torch.float32, device=dev)
+        h2, w2, h4, w4, h8, w8 = wh // 2, ww // 2, wh // 4, ww // 4, wh // 8, ww // 8
+        c1, c2, c3 = ig.Planes(B2, h2, w2, 2, dev), ig.Planes(B2, h4, w4, 4, dev), ig.Planes(B2, h8, w8, 8, dev)
+        gz_c3, gz_c2 = ig.Planes(B2, h8, w8, 8, dev), ig.Planes(B2, h4, w4, 4, dev)
+        G_c2, G_c1 = ig.GradSum(B2, h4, w4, 4, dev), ig.GradSum(B2, h2, w2, 2, dev)
+        bias = lambda n: self._conv(n).bias.detach().float().contiguous()
+        plans = [
+            (ig.conv_forward_weights(self._conv("conv2").weight, 2, 2), c1, (h4, w4), (h4, w4), dict(out_planes=c2, bias=bias("conv2"))),
+            (ig.conv_forward_weights(self._conv("conv3").weight, 2, 2), c2, (h8, w8), (h8, w8), dict(out_planes=c3, bias=bias("conv3"))),
+            (ig.conv_backward_weights(self._conv("conv3").weight, 2, 2), gz_c3, (h8, w8), (h4, w4), dict(out_f32=G_c2)),
+            (ig.conv_backward_weights(self._conv("conv2").weight, 2, 2), gz_c2, (h4, w4), (h2, w2), dict(out_f32=G_c1)),
+        ]
+        sized = []
+        for wi, x, rows, out_hw, kw in plans:
+            ktiles = max(len(t) for _, _, t in wi.phases) * wi.KC
+            sized.append(ig.splitk_for(B2 * rows[0] * rows[1], wi.Npad, ktiles, len(wi.phases)))
+        need = max([len(wi.phases) * S * B2 * rows[0] * rows[1] * wi.Npad for (wi, _, rows, _, _), S in zip(plans, sized) if S > 1] + [1])
+        ws = torch.empty(need, **f32)
+        launches = [ig.make_launch(wi, x, 0, rows, out_hw, splitk=S, ws=ws if S > 1 else None, **kw)
+                    for (wi, x, rows, out_hw, kw), S in zip(plans, sized)]
+        self._wprefix = dict(hw=(wh, ww), c1=c1, c2=c2, c3=c3, gz_c3=gz_c3, gz_c2=gz_c2, G_c2=G_c2, G_c1=G_c1, ws=ws,
+                             conv2=launches[0], conv3=launches[1], conv3_bwd=launches[2], conv2_bwd=launches[3],
+                             b1=bias("conv1"), w1=self._conv("conv1").weight.detach(),
+                             c2_nchw=torch.zeros(B2, 128, h4, w4, **f32), c3_nchw=torch.zeros(B2, 256, h8, w8, **f32),
+                             g_c2=torch.zeros(B2, 128, h4, w4, **f32), g_c1=torch.zeros(B2, 64, h2, w2, **f32))
+
+    def window_prefix_forward(self, xw: torch.Tensor, win: torch.Tensor, m2: int, m3: int):
+        """conv1-3 of the window stack `xw` [2B, 3, wh, ww] (raw frames; first frames, then second frames), patched into the
+        cached full-frame features.  The window's convolutions zero-pad at the window's edges exactly like the torch
+        prefix they replace; the inexact rim (m2 / m3 cells) is skipped by the scatter."""
+        wh, ww = int(xw.shape[2]), int(xw.shape[3])
+        P = getattr(self, "_wprefix", None)
+        if P is None or P["hw"] != (wh, ww):
+            self._build_window_prefix(wh, ww)
+            P = self._wprefix
+        x = self.net.normalize_correctly(xw.detach())
+        y1 = torch.nn.functional.conv2d(x, P["w1"], None, 2, 3)
+        P["c1"].load_nchw(y1, 0, 1.0, ig.LEAKY, P["b1"])
+        P["conv2"]()
+        P["conv3"]()
+        P["c2"].to_nchw(128, 0, out=P["c2_nchw"])
+        P["c3"].to_nchw(256, 0, out=P["c3_nchw"])
+        self.scatter_window_features(P["c2_nchw"], P["c3_nchw"], win, wh, ww, m2, m3)
+
+    def window_prefix_backward(self, gw2: torch.Tensor, gw3: torch.Tensor) -> torch.Tensor:
+        """d loss / d xw from the window gradients of the two taps: gw2 [B, 128, wh/4, ww/4] (conv2 of the first frames),
+        gw3 [2B, 256, wh/8, ww/8] (conv3 of both), rims already zeroed."""
+        P, B = self._wprefix, self.B
+        wh, ww = P["hw"]
+        slope = ig.LEAKY
+        # LeakyReLU' of conv3's output, split into the gradient planes conv3's data gradient reads
+        g3 = gw3 * torch.where(P["c3_nchw"] > 0, 1.0, slope)
+        P["gz_c3"].load_nchw(g3, 0)
+        P["conv3_bwd"]()
+        g2 = P["G_c2"].to_nchw(128, 0, out=P["g_c2"])
+        g2[:B] += gw2
+        g2 *= torch.where(P["c2_nchw"] > 0, 1.0, slope)
+        P["gz_c2"].load_nchw(g2, 0)
+        P["conv2_bwd"]()
+        g1 = P["G_c1"].to_nchw(64, 0, mask=P["c1"], out=P["g_c1"])       # LeakyReLU' of conv1's output fused
+        return torch.nn.grad.conv2d_input((2 * B, 3, wh, ww), P["w1"], g1, stride=2, padding=3)
+
     # ------------------------------------------------------------------------------------------------ column band
     # (level stride of the ROW grid, of the input grid) of the launches that run on the band's columns only
     _FWD_BAND = {"conv_redir": (8, 8), "conv3_1": (8, 8), "conv4": (16, 8), "conv4_1": (16, 16)}

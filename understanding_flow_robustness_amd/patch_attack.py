@@ -224,6 +224,8 @@ class PatchAttackStep:
             from .flownetc_engine import get_engine
             self.eng = get_engine(self.net, B, H, W, self.dev)
             self.eng.flow[2].requires_grad_(True)
+        # the window's conv2 / conv3 and their data gradients on the engine's igemm instead of torch / MIOpen
+        self._eng_window = self.eng is not None and os.environ.get("UFR_ENGINE_WINDOW", "1") != "0"
         self.taps = []                         # (level stride, margin, frames, full leaf, window gradient)
         with torch.no_grad():
             feats = self.net.encode(torch.zeros(2, 3, spec.total_stride * 2, spec.total_stride * 2, **f32))
@@ -286,6 +288,13 @@ class PatchAttackStep:
         lib, B, H, W = L.lib(), self.B, self.H, self.W
         self._win_copy(lib.ufr_window_gather, self.adv_tgt, self.xw, B, 3, H, W, 1, 0)
         self._win_copy(lib.ufr_window_gather, self.adv_ref, self.xw[B:], B, 3, H, W, 1, 0)
+        if self.eng is not None and self._eng_window:      # conv1-3 of the window on the engine too (no autograd graph)
+            (_, m2, _, _, _), (_, m3, _, _, _) = self.taps
+            self._feats_w = None
+            self.eng.window_prefix_forward(self.xw, self.win, m2, m3)
+            self.eng.forward_cached(self.band)
+            return torch.nn.functional.interpolate(self.eng.flow[2] * self.net.div_flow, scale_factor=4, mode="bilinear",
+                                                   align_corners=False)
         self._feats_w = [f[:n] for f, (_, _, n, _, _) in zip(self.net.encode(self.xw), self.taps)]
         if self.eng is not None:
             (_, m2, _, _, _), (_, m3, _, _, _) = self.taps
@@ -318,7 +327,10 @@ class PatchAttackStep:
             g_full = torch.autograd.grad(flow, [t[3] for t in self.taps], self.g_flow)
             for g, (ls, m, n, _, gwin) in zip(g_full, self.taps):
                 self._win_copy(lib.ufr_window_gather, g.contiguous(), gwin, n, g.shape[1], H // ls, W // ls, ls, m)
-        gxw, = torch.autograd.grad(self._feats_w, (self.xw,), [t[4] for t in self.taps])
+        if self.eng is not None and self._eng_window:
+            gxw = self.eng.window_prefix_backward(self.taps[0][4], self.taps[1][4])
+        else:
+            gxw, = torch.autograd.grad(self._feats_w, (self.xw,), [t[4] for t in self.taps])
         self._feats_w = None
         gxw = gxw.contiguous()
         self._win_copy(lib.ufr_window_scatter, gxw, self.g_tgt_full, B, 3, H, W, 1, 0)
