@@ -139,7 +139,9 @@ def kernel_rooflines(step, device, max_count):
         banded = bool(eng.bwd_band)
         t_sum = g_sum = 0.0
         for (name, kind, tag), (t, gflop) in per.items():
-            if kind == "fwd":
+            if tag == "window":
+                w = 1.0
+            elif kind == "fwd":
                 has_band = (name, "fwd", "band") in per
                 w = (1.0 / max_count if has_band else 1.0) if tag == "full" else (max_count - 1.0) / max_count
             else:

@@ -481,6 +481,12 @@ int ufr_flow_head_planes_forward(const void* planes, long plane_stride, int chun
  * wmf: bf16 [chunks][3][2][16][32] (plane p of w[o][32 ch + c][k] at n = 2k + o, zeros for n >= 18). */
 int ufr_flow_head_planes_forward_mfma(const void* planes, long plane_stride, int chunk0, int chunks, const void* wmf,
                                       const float* bias, float* out, int B, int H, int W, ufr_stream_t stream);
+/* The two flow channels of a ConvTranspose2d(Cin, Cout, 4, 2, 1) data gradient (models/FlowNetC.py:162-183: the last two
+ * input channels of deconvK are the upsampled flow), same per-pixel GEMM + gather: grad_planes = the masked output gradient
+ * on the fine grid [2H, 2W] (chunks chunk0 .. chunk0 + chunks), wmf as above with n = 2 (4 ky + kx) + o for the weights
+ * w[Cin - 2 + o][c][ky][kx]; writes lanes 0-1 of chunk `out_chunk` of the coarse grid's [H, W] float32 gradient sum G. */
+int ufr_deconv_flow_tail_backward_mfma(const void* grad_planes, long plane_stride, int chunk0, int chunks, const void* wmf,
+                                       float* G, int out_chunk, int B, int H, int W, ufr_stream_t stream);
 int ufr_flow_head_planes_backward(const float* grad_y, const float* wpk, float* G, int chunk0, int chunks, int B, int H,
                                   int W, int accumulate, ufr_stream_t stream);
 int ufr_flow_up_planes_forward(const float* x, const float* w, const float* bias, void* planes, long plane_stride,

@@ -167,12 +167,13 @@ def _same_update(pf, pc, p0, sel, what):
     """Two implementations of the same multi-iteration attack.  From the second iteration on a one-ulp
     difference (MIOpen's split-K data gradients are not bit-reproducible) can flip a LeakyReLU somewhere and
     move the gradient entries behind it by a few 1e-4 of the largest update, so: at least 95% of the patch
-    pixels agree to 1e-4 of the update and every pixel to 5e-3 (a misplaced window or band is off by O(1))."""
+    pixels agree to 1e-4 of the update and every pixel to 1e-2 (a misplaced window or band is off by O(1); three
+    iterations of two different fp32 summation orders were seen at 8e-3 once, 6e-7 typically)."""
     upd = float(((pf - p0) * sel).abs().max())
     err = ((pf - pc) * sel).abs()
     assert 1e-3 < upd < 1.9, f"{what}: test lr leaves the update degenerate ({upd})"
     off = float((err > 1e-4 * upd + 1e-6).sum()) / max(float((sel != 0).sum()), 1.0)
-    assert off <= 0.05 and float(err.max()) <= 5e-3 * upd, \
+    assert off <= 0.05 and float(err.max()) <= 1e-2 * upd, \
         f"{what}: {off:.2%} of the patch pixels differ by more than 1e-4, worst {float(err.max()) / upd:.2e} of the update"
     return upd
 

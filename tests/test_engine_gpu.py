@@ -238,3 +238,73 @@ def test_corr_backward_window_fused_equals_the_unfused_chain(B, H, W, wh, ww, ma
     assert bool(torch.isfinite(got).all())
     assert bool(((want == 0) == (got == 0)).all()) or margin == 0        # the rim is zero in both
     assert _rel(got[:B], want[:B]) <= 1e-5 and _rel(got[B:], want[B:]) <= 1e-5, (_rel(got[:B], want[:B]), _rel(got[B:], want[B:]))
+
+
+def test_window_prefix_on_the_engine_equals_the_torch_prefix(net):
+    """flownetc_engine.py `window_prefix_forward` / `window_prefix_backward` (conv2 / conv3 of the attack's 128 x 128
+    window and their data gradients on the igemm, conv1 on torch) against torch autograd through `net.encode` on the
+    same window stack, judged against a float64 evaluation."""
+    from understanding_flow_robustness_amd.flownetc_engine import get_engine
+    B, H, W, wh, ww = 2, 128, 256, 128, 128
+    g = torch.Generator().manual_seed(21)
+    eng = get_engine(net, B, H, W, DEV)
+    xw = torch.rand(2 * B, 3, wh, ww, generator=g).mul_(255.0).to(DEV)
+    win = torch.zeros(B, 8, dtype=torch.int32, device=DEV)
+    win[:, 1] = 64
+    eng.window_prefix_forward(xw, win, 0, 0)
+    P = eng._wprefix
+    x32 = xw.clone().requires_grad_(True)
+    c2, c3 = net.encode(x32)
+    import torch.nn.functional as F
+
+    def encode64(x):                                                       # models/FlowNetC.py:100-119 in float64
+        y = x - net._mean64.double()
+        outs = []
+        for name, k in (("conv1", 7), ("conv2", 5), ("conv3", 5)):
+            conv = getattr(net, name)[0]
+            y = F.leaky_relu(F.conv2d(y, conv.weight.double(), conv.bias.double(), 2, (k - 1) // 2), 0.1)
+            outs.append(y)
+        return outs[1], outs[2]
+    x64 = xw.double().requires_grad_(True)
+    c2_64, c3_64 = encode64(x64)
+    for name, got, t32, t64 in (("conv2", P["c2_nchw"], c2, c2_64), ("conv3", P["c3_nchw"], c3, c3_64)):
+        e_eng, e_t = _rel(got, t64), _rel(t32.detach(), t64)
+        print(f"{name}: engine {e_eng:.2e}, torch fp32 {e_t:.2e} (vs float64)")
+        assert e_eng <= max(3 * e_t, 2e-6), name
+    gw2 = torch.randn(B, 128, wh // 4, ww // 4, generator=g).to(DEV)
+    gw3 = torch.randn(2 * B, 256, wh // 8, ww // 8, generator=g).to(DEV)
+    gw2_all = torch.cat((gw2, torch.zeros_like(gw2)), 0)
+    gx = eng.window_prefix_backward(gw2, gw3)
+    (gx32,) = torch.autograd.grad((c2, c3), x32, (gw2_all, gw3))
+    (gx64,) = torch.autograd.grad((c2_64, c3_64), x64, (gw2_all.double(), gw3.double()))
+    e_eng, e_t = _rel(gx, gx64), _rel(gx32, gx64)
+    print(f"d/d window: engine {e_eng:.2e}, torch fp32 {e_t:.2e} (vs float64)")
+    # LeakyReLU slope flips at pre-activations within rounding of zero: isolated entries, in either implementation
+    assert e_eng <= max(3 * e_t, 5e-4)
+    frac = float(((gx.double() - gx64).abs() > 1e-4 * float(gx64.abs().max())).float().mean())
+    assert frac <= 1e-2, frac
+
+
+@pytest.mark.parametrize("B,Cout,H,W", [(8, 64, 48, 160), (2, 256, 12, 40), (3, 96, 5, 7), (1, 128, 24, 80)])
+def test_deconv_flow_tail_kernel_vs_torch(B, Cout, H, W):
+    """csrc/engine_small.hip `flow_head_planes_fwd_mfma<1>`: the data gradient of ConvTranspose2d(Cin, Cout, 4, 2, 1) with
+    respect to its last two input channels (the upsampled flow) from the masked output gradient's planes, against torch in
+    float64; lanes 2.. of the written chunk and the neighbouring chunk stay untouched."""
+    import torch.nn.functional as F
+    from understanding_flow_robustness_amd import _lib as L
+    from understanding_flow_robustness_amd import igemm as ig
+    from understanding_flow_robustness_amd.flownetc_engine import _pack_flow_tail_mfma
+    g = torch.Generator().manual_seed(9)
+    w2 = (torch.randn(2, Cout, 4, 4, generator=g) * 0.1).to(DEV)
+    gy = torch.randn(B, Cout, 2 * H, 2 * W, generator=g).to(DEV)
+    chunks = ig.pad32(Cout) // 32
+    pl = ig.Planes(B, 2 * H, 2 * W, chunks + 1, DEV).load_nchw(gy, chunk0=1)
+    G = ig.GradSum(B, H, W, 3, DEV)
+    G.t.fill_(0.25)
+    L.check(L.lib().ufr_deconv_flow_tail_backward_mfma(L.ptr(pl.t), pl.plane_stride, 1, chunks, L.ptr(_pack_flow_tail_mfma(w2)),
+                                                       L.ptr(G.t), 1, B, H, W, L.stream()))
+    x0 = torch.zeros(B, 2, H, W, device=DEV, dtype=torch.float64, requires_grad=True)
+    (want,) = torch.autograd.grad(F.conv_transpose2d(x0, w2.double(), None, 2, 1), x0, gy.double())
+    got = G.t[1].view(B, H, W, 32)
+    assert _rel(got[..., :2].permute(0, 3, 1, 2), want) <= 1e-5
+    assert bool((got[..., 2:] == 0.25).all()) and bool((G.t[0] == 0.25).all()) and bool((G.t[2] == 0.25).all())

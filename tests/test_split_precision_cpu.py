@@ -63,3 +63,29 @@ def test_xcd_tile_order_is_a_bijection_with_contiguous_runs():
         assert len(seen) == gx * gy, (gx, gy)                       # every tile computed exactly once
         for tiles in runs.values():                                 # one XCD = one contiguous run of tiles
             assert tiles == list(range(tiles[0], tiles[0] + len(tiles))), (gx, gy)
+
+
+def _igemm_tile(bx, by, bz, gx, gy, gz):
+    """Python mirror of csrc/igemm.hip::xcd_tile: XCD-contiguous runs, phase / split-K slice (z) fastest inside a run."""
+    n, orig = gx * gy * gz, (bz * gy + by) * gx + bx
+    q, r, xcd, idx = n // 8, n % 8, orig % 8, orig // 8
+    w = (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + idx
+    rem = w // gz
+    return rem % gx, rem // gx, w % gz
+
+
+def test_igemm_tile_order_is_a_bijection_that_spreads_the_phases_over_the_xcds():
+    """A stride-2 data gradient's four phases reduce over 1, 2, 2 and 4 taps: every XCD must get its share of each."""
+    for gx, gy, gz in ((2, 120, 4), (4, 30, 4), (1, 480, 1), (7, 30, 2), (3, 5, 4), (9, 30, 1), (1, 1, 4), (4, 8, 16)):
+        seen, per_xcd = set(), {}
+        for bz in range(gz):
+            for by in range(gy):
+                for bx in range(gx):
+                    t = _igemm_tile(bx, by, bz, gx, gy, gz)
+                    assert 0 <= t[0] < gx and 0 <= t[1] < gy and 0 <= t[2] < gz
+                    seen.add(t)
+                    per_xcd.setdefault(((bz * gy + by) * gx + bx) % 8, []).append(t[2])
+        assert len(seen) == gx * gy * gz, (gx, gy, gz)
+        for zs in per_xcd.values():
+            counts = [zs.count(z) for z in range(gz)]
+            assert max(counts) - min(counts) <= 1, (gx, gy, gz, counts)

@@ -127,6 +127,7 @@ SIGNATURES = {
     "ufr_grad_finalize": [_vp, _i, _vp, _i, _vp, _l, _i, _l, _i, _f, _vp],
     "ufr_flow_head_planes_forward": [_vp, _l, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ufr_flow_head_planes_forward_mfma": [_vp, _l, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "ufr_deconv_flow_tail_backward_mfma": [_vp, _l, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_flow_head_planes_backward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "ufr_flow_up_planes_forward": [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp],
     "ufr_flow_up_planes_backward": [_vp, _i, _vp, _vp, _i, _i, _i, _vp],

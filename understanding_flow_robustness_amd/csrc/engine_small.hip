@@ -184,30 +184,41 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 __device__ constexpr int PFM_A[6] = {2, 0, 1, 1, 0, 0};
 __device__ constexpr int PFM_B[6] = {0, 2, 1, 0, 1, 0};
 __device__ __attribute__((aligned(64))) unsigned pf_zero_page[16];
-constexpr int PFM_TW = 32, PFM_HW = PFM_TW + 2, PFM_MAXT = 6, PFM_TS = 20;   // T row stride (floats): 18 used
+constexpr int PFM_HW = 34, PFM_MAXT = 6;          // pixels across a staged tile (32 + halo, or 2 x 16 + 2); m-tiles per wave
 
+// MODE 0: predict_flow (3 x 3, stride 1, pad 1): tile = TH x 32 outputs, staged pixels = the tile + halo; N = 18 of 32;
+//         out = NCHW [B, 2, H, W] + bias.
+// MODE 1: the two flow channels of a ConvTranspose2d(4, 2, 1) data gradient (the last two input channels of deconvK --
+//         the upsampled flow; the other channels go through ufr_igemm with an N that is a multiple of 128):
+//         g[o, y, x] = sum_{ky,kx} sum_c gz[c, 2y - 1 + ky, 2x - 1 + kx] w[o, c, ky, kx];  tile = TH x 16 coarse outputs,
+//         staged pixels = the (2 TH + 2) x 34 fine pixels under it; N = 32; out = lanes 0-1 of chunk `out_chunk` of the
+//         coarse grid's float32 gradient sum.  H, W = the OUTPUT grid in both modes.
+template <int MODE>
 __global__ __launch_bounds__(512) void flow_head_planes_fwd_mfma(const __bf16* __restrict__ x, long plane_stride, int chunk0,
-                                                                  int chunks, const __bf16* __restrict__ wmf,
-                                                                  const float* __restrict__ bias, float* __restrict__ out,
-                                                                  int B, int H, int W, int TH, int S) {
-  extern __shared__ __attribute__((aligned(16))) float pfm_T[];            // [S][mt * 16][PFM_TS]
-  const long M = (long)B * H * W;
+                                                                 int chunks, const __bf16* __restrict__ wmf,
+                                                                 const float* __restrict__ bias, float* __restrict__ out,
+                                                                 int out_chunk, int B, int H, int W, int TH, int S) {
+  constexpr int TW = MODE == 0 ? 32 : 16, TS = MODE == 0 ? 20 : 36;        // T row stride (floats): 18 / 32 used
+  extern __shared__ __attribute__((aligned(16))) float pfm_T[];            // [S][mt * 16][TS]
+  const int Hs = MODE == 0 ? H : 2 * H, Ws = MODE == 0 ? W : 2 * W;        // the staged (input) grid
+  const long M = (long)B * Hs * Ws;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, slice = wave >> 2, tw = wave & 3;
-  const int tiles_x = (W + PFM_TW - 1) / PFM_TW, tiles_y = (H + TH - 1) / TH;
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
   const int b = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x - b * tiles_x * tiles_y;
-  const int y0 = (tr / tiles_x) * TH, x0 = (tr % tiles_x) * PFM_TW;
-  const int nh = (TH + 2) * PFM_HW, mt = (nh + 15) >> 4;
+  const int y0 = (tr / tiles_x) * TH, x0 = (tr % tiles_x) * TW;
+  const int sy0 = MODE == 0 ? y0 - 1 : 2 * y0 - 1, sx0 = MODE == 0 ? x0 - 1 : 2 * x0 - 1;   // first staged pixel
+  const int nh = (MODE == 0 ? TH + 2 : 2 * TH + 2) * PFM_HW, mt = (nh + 15) >> 4;
   const __bf16* zero = reinterpret_cast<const __bf16*>(pf_zero_page);
-  // this lane's halo pixel in each of its m-tiles
+  // this lane's staged pixel in each of its m-tiles
   const __bf16* abase[PFM_MAXT];
   unsigned okmask = 0;
 #pragma unroll
   for (int s = 0; s < PFM_MAXT; ++s) {
     const int hp = (tw + 4 * s) * 16 + (lane & 15);
     const int hy = hp / PFM_HW, hx = hp - hy * PFM_HW;
-    const int yy = y0 + hy - 1, xx = x0 + hx - 1;
-    const bool ok = tw + 4 * s < mt && hp < nh && yy >= 0 && yy < H && xx >= 0 && xx < W;
-    abase[s] = ok ? x + ((long)chunk0 * M + ((long)b * H + yy) * W + xx) * 32 + (lane >> 4) * 8 : zero;
+    const int yy = sy0 + hy, xx = sx0 + hx;
+    const bool ok = tw + 4 * s < mt && hp < nh && yy >= 0 && yy < Hs && xx >= 0 && xx < Ws;
+    abase[s] = ok ? x + ((long)chunk0 * M + ((long)b * Hs + yy) * Ws + xx) * 32 + (lane >> 4) * 8 : zero;
     okmask |= ok ? 1u << s : 0u;
   }
   f32x4 acc[PFM_MAXT][2];
@@ -242,35 +253,50 @@ __global__ __launch_bounds__(512) void flow_head_planes_fwd_mfma(const __bf16* _
       }
   }
   // T: lane holds D[m = 4 (lane >> 4) + r][n = lane & 15]
-  float* T = pfm_T + (long)slice * mt * 16 * PFM_TS;
+  float* T = pfm_T + (long)slice * mt * 16 * TS;
 #pragma unroll
   for (int s = 0; s < PFM_MAXT; ++s)
     if (tw + 4 * s < mt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float* row = T + ((tw + 4 * s) * 16 + (lane >> 4) * 4 + r) * PFM_TS;
+        float* row = T + ((tw + 4 * s) * 16 + (lane >> 4) * 4 + r) * TS;
         row[lane & 15] = acc[s][0][r];
-        if ((lane & 15) < 2) row[16 + (lane & 15)] = acc[s][1][r];
+        if (MODE == 1 || (lane & 15) < 2) row[16 + (lane & 15)] = acc[s][1][r];
       }
     }
   __syncthreads();
-  if (tid < TH * PFM_TW) {
-    const int ly = tid / PFM_TW, lx = tid - ly * PFM_TW;
+  if (tid < TH * TW) {
+    const int ly = tid / TW, lx = tid - ly * TW;
     const int yy = y0 + ly, xx = x0 + lx;
     if (yy < H && xx < W) {
       float r0 = 0.f, r1 = 0.f;
       for (int sl = 0; sl < S; ++sl) {               // slices, then taps, in ascending order
-        const float* Ts = pfm_T + (long)sl * mt * 16 * PFM_TS;
+        const float* Ts = pfm_T + (long)sl * mt * 16 * TS;
+        if (MODE == 0) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          const float* e = Ts + ((ly + k / 3) * PFM_HW + lx + k % 3) * PFM_TS + 2 * k;
-          r0 += e[0];
-          r1 += e[1];
+          for (int k = 0; k < 9; ++k) {
+            const float* e = Ts + ((ly + k / 3) * PFM_HW + lx + k % 3) * TS + 2 * k;
+            r0 += e[0];
+            r1 += e[1];
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const float* e = Ts + ((2 * ly + k / 4) * PFM_HW + 2 * lx + k % 4) * TS + 2 * k;
+            r0 += e[0];
+            r1 += e[1];
+          }
         }
       }
-      const long HW = (long)H * W, p = (long)yy * W + xx;
-      out[((long)b * 2 + 0) * HW + p] = r0 + bias[0];
-      out[((long)b * 2 + 1) * HW + p] = r1 + bias[1];
+      if (MODE == 0) {
+        const long HW = (long)H * W, p = (long)yy * W + xx;
+        out[((long)b * 2 + 0) * HW + p] = r0 + bias[0];
+        out[((long)b * 2 + 1) * HW + p] = r1 + bias[1];
+      } else {
+        float* o = out + ((long)out_chunk * B * H * W + ((long)b * H + yy) * W + xx) * 32;
+        o[0] = r0;
+        o[1] = r1;
+      }
     }
   }
 }
@@ -430,28 +456,48 @@ extern "C" int ufr_flow_head_planes_forward(const void* planes, long plane_strid
   return ufr::launched("flow_head_planes_fwd_small");
 }
 
+namespace {
+template <int MODE>
+int launch_pf_mfma(const void* planes, long plane_stride, int chunk0, int chunks, const void* wmf, const float* bias, float* out,
+                   int out_chunk, int B, int H, int W, hipStream_t st, const char* what) {
+  constexpr int TW = MODE == 0 ? 32 : 16, TS = MODE == 0 ? 20 : 36;
+  auto blocks_of = [&](int th) { return B * ufr::ceil_div(H, th) * ufr::ceil_div(W, TW); };
+  int TH;                                       // MODE 0: 10 / 6 / 4 staged rows; MODE 1: 2 TH + 2 <= 10
+  if (MODE == 0) TH = blocks_of(8) >= 512 ? 8 : (blocks_of(4) >= 256 ? 4 : 2);
+  else TH = blocks_of(4) >= 256 ? 4 : 2;
+  const int blocks = blocks_of(TH);
+  const int S = (blocks >= 512 || chunks < 4) ? 1 : 2;
+  const int mt = ((MODE == 0 ? TH + 2 : 2 * TH + 2) * PFM_HW + 15) / 16;
+  const size_t lds = (size_t)S * mt * 16 * TS * sizeof(float);
+  static size_t lds_allowed = 64 * 1024;
+  if (lds > lds_allowed) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flow_head_planes_fwd_mfma<MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+    lds_allowed = lds;
+  }
+  flow_head_planes_fwd_mfma<MODE><<<blocks, 256 * S, lds, st>>>(static_cast<const __bf16*>(planes), plane_stride, chunk0, chunks,
+                                                                static_cast<const __bf16*>(wmf), bias, out, out_chunk, B, H, W, TH, S);
+  return ufr::launched(what);
+}
+}  // namespace
+
 extern "C" int ufr_flow_head_planes_forward_mfma(const void* planes, long plane_stride, int chunk0, int chunks, const void* wmf,
                                                  const float* bias, float* out, int B, int H, int W, ufr_stream_t stream) {
   UFR_REQUIRE(planes && wmf && bias && out, "flow head (planes, mfma) forward: null pointer");
   UFR_REQUIRE(B > 0 && H > 0 && W > 0 && chunks > 0 && chunks <= 48 && chunk0 >= 0 && (long)B * H * W < (1L << 29),
               "flow head (planes, mfma) forward: bad shape");
-  auto blocks_of = [&](int th) { return B * ufr::ceil_div(H, th) * ufr::ceil_div(W, PFM_TW); };
-  const int TH = blocks_of(8) >= 512 ? 8 : (blocks_of(4) >= 256 ? 4 : 2);
-  const int blocks = blocks_of(TH);
-  const int S = (blocks >= 512 || chunks < 4) ? 1 : 2;
-  const int mt = ((TH + 2) * PFM_HW + 15) / 16;
-  const size_t lds = (size_t)S * mt * 16 * PFM_TS * sizeof(float);
-  static size_t lds_allowed = 64 * 1024;
-  if (lds > lds_allowed) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flow_head_planes_fwd_mfma),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "flow head (planes, mfma) forward: %s", hipGetErrorString(e));
-    lds_allowed = lds;
-  }
-  flow_head_planes_fwd_mfma<<<blocks, 256 * S, lds, ufr::as_stream(stream)>>>(static_cast<const __bf16*>(planes), plane_stride, chunk0,
-                                                                              chunks, static_cast<const __bf16*>(wmf), bias, out, B, H,
-                                                                              W, TH, S);
-  return ufr::launched("flow_head_planes_fwd_mfma");
+  return launch_pf_mfma<0>(planes, plane_stride, chunk0, chunks, wmf, bias, out, 0, B, H, W, ufr::as_stream(stream),
+                           "flow_head_planes_fwd_mfma");
+}
+
+extern "C" int ufr_deconv_flow_tail_backward_mfma(const void* grad_planes, long plane_stride, int chunk0, int chunks, const void* wmf,
+                                                  float* G, int out_chunk, int B, int H, int W, ufr_stream_t stream) {
+  UFR_REQUIRE(grad_planes && wmf && G, "deconv flow tail backward: null pointer");
+  UFR_REQUIRE(B > 0 && H > 0 && W > 0 && chunks > 0 && chunks <= 48 && chunk0 >= 0 && out_chunk >= 0 &&
+                  (long)B * H * W < (1L << 27), "deconv flow tail backward: bad shape");
+  return launch_pf_mfma<1>(grad_planes, plane_stride, chunk0, chunks, wmf, nullptr, G, out_chunk, B, H, W, ufr::as_stream(stream),
+                           "deconv_flow_tail_bwd_mfma");
 }
 
 extern "C" int ufr_flow_head_planes_backward(const float* grad_y, const float* wpk, float* G, int chunk0, int chunks, int B,

@@ -150,8 +150,12 @@ __device__ __forceinline__ void xcd_tile(int swz, int& bx, int& by, int& bz) {
   const int orig = (bz * gridDim.y + by) * nx + bx;
   const int q = n / 8, r = n % 8, xcd = orig % 8, idx = orig / 8;
   const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  bz = w / nxy;
-  const int rem = w - bz * nxy;
+  // z (phase x split-K slice) varies FASTEST inside an XCD's run: the phases of a stride-2 data gradient reduce over 1, 2,
+  // 2 and 4 taps, so a phase-major list would hand two XCDs only the shortest workgroups and two only the longest (measured:
+  // conv4 / conv5 / conv6 backward at half the rate of their stride-1 neighbours); the phases of one tile also read the same
+  // activation rows.
+  bz = w % gridDim.z;
+  const int rem = w / gridDim.z;
   by = rem / nx;
   bx = rem - by * nx;
 }

@@ -52,6 +52,17 @@ def _pack_flow_head_mfma(weight: torch.Tensor) -> torch.Tensor:
     return planes
 
 
+def _pack_flow_tail_mfma(weight2: torch.Tensor) -> torch.Tensor:
+    """The two flow rows of a ConvTranspose2d(Cin, Cout, 4, 2, 1) weight, [2, Cout, 4, 4] -> bf16 [chunks][3][2][16][32] with
+    n = 2 (4 ky + kx) + o (csrc/engine_small.hip `flow_head_planes_fwd_mfma<1>`)."""
+    cout = weight2.shape[1]
+    chunks = ig.pad32(cout) // 32
+    w = torch.zeros(chunks * 32, 32, dtype=torch.float32, device=weight2.device)          # [c][n]
+    w[:cout] = weight2.detach().float().reshape(2, cout, 16).permute(1, 2, 0).reshape(cout, 32)
+    wn = w.view(chunks, 32, 32).permute(0, 2, 1).contiguous()                               # [chunk][n][c]
+    return ig._split3(wn).view(3, chunks, 32, 32).permute(1, 0, 2, 3).contiguous()
+
+
 class FlowNetCHeadEngine:
     def __init__(self, net, B: int, H: int, W: int, device):
         if H % 64 or W % 64:
@@ -122,11 +133,20 @@ class FlowNetCHeadEngine:
         # backward (reverse order of use; see module docstring)
         gz = {5: (self.gz_cat5, 16, 16), 4: (self.gz_cat4, 16, 8), 3: (self.gz_cat3, 8, 4), 2: (self.gz_cat2, 4, 2)}
         Gabove = {2: self.G_cat3, 3: self.G_cat4, 4: self.G_cat5}
+        # deconvK's input ends with the two channels of the upsampled flow: 386 / 770 / 1026 columns would pad the GEMM to
+        # 512 / 896 / 1152 (and deconv3 / deconv4 to a second round of workgroups); the 384 / 768 / 1024 feature channels go
+        # through the igemm and the two flow columns through the 2-channel kernel (`_deconv_tail`)
+        self.tail = os.environ.get("UFR_DECONV_TAIL", "1") != "0"
+        self.tail_w, self.tail_args = {}, {}
         for k in (2, 3, 4):
             src, chunk0, _ = gz[k]
             s_in = {2: 8, 3: 16, 4: 32}[k]
-            bwd[f"deconv{k}"] = plan(ig.deconv_backward_weights(self._conv(f"deconv{k}").weight, 1), src, chunk0, g[s_in], g[s_in],
-                                     out_f32=Gabove[k])
+            w = self._conv(f"deconv{k}").weight
+            main = w.shape[0] - 2 if self.tail else w.shape[0]
+            bwd[f"deconv{k}"] = plan(ig.deconv_backward_weights(w[:main], 1), src, chunk0, g[s_in], g[s_in], out_f32=Gabove[k])
+            if self.tail:
+                self.tail_w[k] = _pack_flow_tail_mfma(w[main:])
+                self.tail_args[k] = (src, chunk0, ig.pad32(w.shape[1]) // 32, Gabove[k], main // 32, g[s_in])
         bwd["deconv5"] = plan(ig.deconv_backward_weights(self._conv("deconv5").weight, 1), self.gz_cat5, 16, g[64], g[64],
                               add=self.G_c6, mask=self.c6, out_planes=self.gz_c6)
         bwd["conv6_1"] = plan(cb("conv6_1", 1, 1), self.gz_c6, 0, g[64], g[64], mask=self.c6a, out_planes=self.gz_c6a)
@@ -246,7 +266,8 @@ class FlowNetCHeadEngine:
         ws = torch.empty(need, **f32)
         launches = [ig.make_launch(wi, x, 0, rows, out_hw, splitk=S, ws=ws if S > 1 else None, **kw)
                     for (wi, x, rows, out_hw, kw), S in zip(plans, sized)]
-        self._wprefix = dict(hw=(wh, ww), c1=c1, c2=c2, c3=c3, gz_c3=gz_c3, gz_c2=gz_c2, G_c2=G_c2, G_c1=G_c1, ws=ws,
+        wis = {k + "_wi": p[0] for k, p in zip(("conv2", "conv3", "conv3_bwd", "conv2_bwd"), plans)}
+        self._wprefix = dict(**wis, hw=(wh, ww), c1=c1, c2=c2, c3=c3, gz_c3=gz_c3, gz_c2=gz_c2, G_c2=G_c2, G_c1=G_c1, ws=ws,
                              conv2=launches[0], conv3=launches[1], conv3_bwd=launches[2], conv2_bwd=launches[3],
                              b1=bias("conv1"), w1=self._conv("conv1").weight.detach(),
                              c2_nchw=torch.zeros(B2, 128, h4, w4, **f32), c3_nchw=torch.zeros(B2, 256, h8, w8, **f32),
@@ -337,6 +358,12 @@ class FlowNetCHeadEngine:
                 wi = self._plans[(kind, name)][0]
                 d = launch.desc
                 rows.append((name, kind, tag, launch, wi.flops(d.B * d.Hr * d.Wr) / 1e9))
+        P = getattr(self, "_wprefix", None)
+        if P is not None:                      # conv2 / conv3 of the attack's prefix window (every iteration)
+            for name, kind, key in (("conv2", "fwd", "conv2"), ("conv3", "fwd", "conv3"), ("conv3", "bwd", "conv3_bwd"),
+                                    ("conv2", "bwd", "conv2_bwd")):
+                d = P[key].desc
+                rows.append((name, kind, "window", P[key], P[key + "_wi"].flops(d.B * d.Hr * d.Wr) / 1e9))
         return rows
 
     # ------------------------------------------------------------------------------------------------ small launches
@@ -362,6 +389,12 @@ class FlowNetCHeadEngine:
         L.check(L.lib().ufr_flow_up_planes_forward(L.ptr(f), L.ptr(self.up_w[k]), L.ptr(self.up_b[k]) if self.up_b[k] is not None else None,
                                                    L.ptr(dst.t), dst.plane_stride, chunk, self.B, f.shape[2], f.shape[3],
                                                    L.stream()), "upsampled_flow forward")
+
+    def _deconv_tail(self, k):
+        src, chunk0, chunks, Gd, out_chunk, (h, w) = self.tail_args[k]
+        L.check(L.lib().ufr_deconv_flow_tail_backward_mfma(L.ptr(src.t), src.plane_stride, chunk0, chunks, L.ptr(self.tail_w[k]),
+                                                           L.ptr(Gd.t), out_chunk, self.B, h, w, L.stream()),
+                "deconv data gradient, flow channels")
 
     def _up_backward(self, k):
         G, chunk = self.up_G[k]
@@ -442,6 +475,8 @@ class FlowNetCHeadEngine:
             self._finalize(Gs, act, out, chunk0, chunks)          # LeakyReLU' of deconvK's output
             self._up_backward(k + 1)                               # -> d/d flow(K+1)
             self.bwd[f"deconv{k}"]()                               # writes the gradient sum of cat(K+1)
+            if self.tail:
+                self._deconv_tail(k)
             self._pf_backward(k + 1, self.g_flow[k + 1], accumulate=True)
         Gs, act, out, chunk0, chunks = gz[5]
         self._finalize(Gs, act, out, chunk0, chunks)

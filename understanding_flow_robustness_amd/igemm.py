@@ -259,8 +259,9 @@ def make_launch(wi: WeightImage, x: Planes, in_chunk0: int, rows_hw, out_hw, *, 
     return Launch(d, keep)
 
 
-def splitk_for(M: int, Npad: int, ktiles: int, phases: int = 1, target: int = 512) -> int:
-    """Split the reduction until the launch has about `target` workgroups (2 per CU), keeping >= 16 K tiles per slice."""
+def splitk_for(M: int, Npad: int, ktiles: int, phases: int = 1, target: int = 768) -> int:
+    """Split the reduction until the launch has about `target` workgroups (3 per CU: the LDS-DMA kernel's occupancy),
+    keeping >= 16 K tiles per slice."""
     tiles = -(-M // 128) * (Npad // (128 if Npad % 128 == 0 else 64)) * phases
     s = 1
     while tiles * s * 2 <= target and ktiles // (s * 2) >= 16 and s < 32:
