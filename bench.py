@@ -181,13 +181,25 @@ def kernel_rooflines(step, device, max_count):
                        algorithmic_bytes=int(CORR_FWD["mbytes"] * 1e6 * B)))
     win = torch.zeros(B, 8, dtype=torch.int32, device=device)
     win[:, 0], win[:, 1] = 128, 512
-    g1, g2 = torch.empty_like(a), torch.empty_like(b)
-    t_w = event_time(lambda: L.check(L.lib().ufr_corr_backward_window(
-        L.ptr(a), L.ptr(b), L.ptr(go), L.ptr(g1), L.ptr(g2), B, 256, H // 8, W // 8, 21, 2, L.ptr(win), 8, 16, 16,
-        L.stream())), 10)
     cells = 16 * 16
-    bytes_w = B * (2 * 441 * cells * 4 + 2 * 256 * 56 * 56 * 4 + 2 * 256 * (H // 8) * (W // 8) * 4)   # gout, regions, zero-filled outputs
-    ks.append(dict(kernel="corr_bwd_window<8,21,2> (both adjoints, 16x16 cells per pair)", ms=round(t_w, 4), bound="hbm",
+    if eng is not None:
+        # the step's form: both adjoints on the window's cells on the matrix cores, gradient sums in, window gradient out
+        # (csrc/correlation_window_mfma.hip).  Algorithmic bytes per pair: the band of cost-volume gradients of the window's
+        # cells (both adjoints), the two 56 x 64-cell feature regions, conv_redir's window gradient, the window-sized output.
+        gw = torch.empty(2 * B, 256, 16, 16, device=device)
+        t_w = event_time(lambda: L.check(L.lib().ufr_corr_backward_window_fused(
+            L.ptr(a), L.ptr(b), L.ptr(eng.G_in31.t), 1, 1.0 / 256.0, L.ptr(eng.G_c3a.t), L.ptr(gw), B, 256, H // 8, W // 8, 21, 2,
+            L.ptr(win), 8, 16, 16, 1, L.stream())), 10)
+        bytes_w = B * (2 * 441 * cells * 4 + 2 * 256 * 56 * 64 * 4 + 256 * cells * 4 + 2 * 256 * cells * 4)
+        name = "corr_bwd_window_mfma_kernel<2,2> (both adjoints + conv_redir's gradient, 16x16 cells per pair, window-sized output)"
+    else:
+        g1, g2 = torch.empty_like(a), torch.empty_like(b)
+        t_w = event_time(lambda: L.check(L.lib().ufr_corr_backward_window(
+            L.ptr(a), L.ptr(b), L.ptr(go), L.ptr(g1), L.ptr(g2), B, 256, H // 8, W // 8, 21, 2, L.ptr(win), 8, 16, 16,
+            L.stream())), 10)
+        bytes_w = B * (2 * 441 * cells * 4 + 2 * 256 * 56 * 56 * 4 + 2 * 256 * (H // 8) * (W // 8) * 4)   # gout, regions, zero-filled outputs
+        name = "corr_bwd_window<8,21,2> (both adjoints, 16x16 cells per pair)"
+    ks.append(dict(kernel=name, ms=round(t_w, 4), bound="hbm",
                    achieved=round(bytes_w / t_w / 1e6, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                    frac=round(bytes_w / t_w / 1e6 / PEAK_HBM_GBS, 4), tflops=round(GFLOP_CORR_BWD_WINDOW * B / t_w, 2),
                    traffic=_pmc("r2_corr_window_traffic.json").get("traffic_bytes"), algorithmic_bytes=int(bytes_w)))

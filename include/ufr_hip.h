@@ -449,6 +449,18 @@ int ufr_chunks_to_nchw(const void* planes, long plane_stride, const float* f32, 
 int ufr_grad_finalize(const float* g, int g_chunk0, const void* mask, int mask_chunk0, void* out, long out_plane_stride,
                       int out_chunk0, long M, int chunks, float slope, ufr_stream_t stream);
 
+/* NCHW float32 gradient x LeakyReLU'(NCHW activation) -> the engine's gradient planes (three bf16 planes, chunk-major), one pass. */
+int ufr_nchw_grad_to_planes(const float* grad, const float* act, void* planes, long plane_stride, int chunk0, int B, int C, int H,
+                            int W, float slope, ufr_stream_t stream);
+/* ufr_window_gather for a chunk-major float32 tensor [chunks][N*Hs*Ws][32] -> [chunks][N_dst*wh*ww][32] (images >= N untouched). */
+int ufr_window_gather_chunks(const float* src, float* dst, const int* win, int n_win, int N, int N_dst, int chunks, int Hs, int Ws,
+                             int wh, int ww, int level_stride, int margin, ufr_stream_t stream);
+
+/* models/FlowNetC.py:73-79, :93-94 (normalize_correctly): out[n] = (float)((double)frame - mean[c]) for the Ba first frames and
+ * the Bb second frames (frames_b may be NULL when Bb == 0) as one stack [Ba + Bb, C, H, W]; mean = C float64 values on the device. */
+int ufr_normalize_frames(const float* frames_a, const float* frames_b, float* out, int Ba, int Bb, int C, int H, int W,
+                         const double* mean, ufr_stream_t stream);
+
 /* Both adjoints of FlowNetC's cost volume (correlation_cuda_kernel.cu:86-233; patch 21, dilation_patch 2, 256 channels) on
  * the cells of the prefix window, on the matrix cores (csrc/correlation_window_mfma.hip), fused with everything around it:
  * G = the engine's chunk-major float32 gradient sum of conv3_1's input (the cost volume's channels start at chunk

@@ -274,7 +274,7 @@ def test_window_prefix_on_the_engine_equals_the_torch_prefix(net):
     gw2 = torch.randn(B, 128, wh // 4, ww // 4, generator=g).to(DEV)
     gw3 = torch.randn(2 * B, 256, wh // 8, ww // 8, generator=g).to(DEV)
     gw2_all = torch.cat((gw2, torch.zeros_like(gw2)), 0)
-    gx = eng.window_prefix_backward(gw2, gw3)
+    gx = eng.window_prefix_backward(gw3, gw2)
     (gx32,) = torch.autograd.grad((c2, c3), x32, (gw2_all, gw3))
     (gx64,) = torch.autograd.grad((c2_64, c3_64), x64, (gw2_all.double(), gw3.double()))
     e_eng, e_t = _rel(gx, gx64), _rel(gx32, gx64)
@@ -308,3 +308,43 @@ def test_deconv_flow_tail_kernel_vs_torch(B, Cout, H, W):
     got = G.t[1].view(B, H, W, 32)
     assert _rel(got[..., :2].permute(0, 3, 1, 2), want) <= 1e-5
     assert bool((got[..., 2:] == 0.25).all()) and bool((G.t[0] == 0.25).all()) and bool((G.t[2] == 0.25).all())
+
+
+def test_normalize_frames_kernel_is_bit_exact(net):
+    """csrc/attack.hip `normalize_frames_kernel` = torch.cat + `normalize_correctly` (float64 mean subtraction,
+    FlowNetC.py:73-79, :93-94), bit for bit, for two stacks and for one."""
+    from understanding_flow_robustness_amd import _lib as L
+    g = torch.Generator().manual_seed(4)
+    a, b = torch.rand(3, 3, 40, 72, generator=g).to(DEV), torch.rand(2, 3, 40, 72, generator=g).mul_(255.0).to(DEV)
+    mean = net._mean64.reshape(-1).contiguous()
+    out = torch.empty(5, 3, 40, 72, device=DEV)
+    L.check(L.lib().ufr_normalize_frames(L.ptr(a), L.ptr(b), L.ptr(out), 3, 2, 3, 40, 72, L.ptr(mean), L.stream()))
+    assert torch.equal(out, net.normalize_correctly(torch.cat((a, b), 0)))
+    out1 = torch.empty(3, 3, 40, 72, device=DEV)
+    L.check(L.lib().ufr_normalize_frames(L.ptr(a), None, L.ptr(out1), 3, 0, 3, 40, 72, L.ptr(mean), L.stream()))
+    assert torch.equal(out1, net.normalize_correctly(a))
+
+
+def test_window_gather_chunks_and_gradient_planes_kernels():
+    """csrc/window.hip `window_gather_chunks_kernel` == ufr_window_gather on the NCHW form of the same chunk-major tensor;
+    csrc/igemm.hip `ufr_nchw_grad_to_planes` == gradient x LeakyReLU'(activation), split exactly."""
+    from understanding_flow_robustness_amd import _lib as L
+    from understanding_flow_robustness_amd import igemm as ig
+    g = torch.Generator().manual_seed(6)
+    B, H, W, wh, ww, m = 3, 24, 40, 8, 12, 2
+    G = ig.GradSum(B, H, W, 4, DEV)
+    G.t.copy_(torch.randn(4, B * H * W, 32, generator=g))
+    win = torch.zeros(B, 8, dtype=torch.int32, device=DEV)
+    win[:, 0] = torch.tensor([0, 16, 64], dtype=torch.int32)
+    win[:, 1] = torch.tensor([112, 8, 48], dtype=torch.int32)
+    dst = ig.GradSum(2 * B, wh, ww, 4, DEV)
+    dst.t.fill_(7.0)
+    L.check(L.lib().ufr_window_gather_chunks(L.ptr(G.t), L.ptr(dst.t), L.ptr(win), B, B, 2 * B, 4, H, W, wh, ww, 4, m, L.stream()))
+    want = torch.empty(B, 128, wh, ww, device=DEV)
+    L.check(L.lib().ufr_window_gather(L.ptr(G.to_nchw(128, 0)), L.ptr(want), L.ptr(win), B, B, 128, H, W, wh, ww, 4, m, L.stream()))
+    got = dst.to_nchw(128, 0)
+    assert torch.equal(got[:B], want) and bool((got[B:] == 7.0).all())
+    grad, act = torch.randn(2, 70, 9, 13, generator=g).to(DEV), torch.randn(2, 70, 9, 13, generator=g).to(DEV)
+    pl = ig.Planes(2, 9, 13, 4, DEV)
+    L.check(L.lib().ufr_nchw_grad_to_planes(L.ptr(grad), L.ptr(act), L.ptr(pl.t), pl.plane_stride, 1, 2, 70, 9, 13, 0.1, L.stream()))
+    assert torch.equal(pl.to_nchw(70, 1), grad * torch.where(act > 0, 1.0, 0.1))

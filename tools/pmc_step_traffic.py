@@ -30,9 +30,23 @@ def per_iteration(path, counter, iters):
     return sum(vals[lo:hi]) / iters, per_kernel
 
 
-def main(fetch_csv, write_csv, iters, igemm_out=None):
+# kernels launched once per iteration whose per-launch traffic bench.py quotes beside its live timing
+SINGLE = {"corr_fwd_planes_kernel": "r2_corr_planes_traffic.json", "corr_bwd_window_mfma_kernel": "r2_corr_window_traffic.json"}
+
+
+def main(fetch_csv, write_csv, iters, igemm_out=None, single_dir=None):
     f_kb, f_k = per_iteration(fetch_csv, "FETCH_SIZE", iters)
     w_kb, w_k = per_iteration(write_csv, "WRITE_SIZE", iters)
+    if single_dir:
+        for pat, name in SINGLE.items():
+            fk = sum(v for k, v in f_k.items() if pat in k)
+            wk = sum(v for k, v in w_k.items() if pat in k)
+            if fk or wk:
+                with open(f"{single_dir}/{name}", "w") as f:
+                    json.dump({"_provenance": f"{pat}: the same two rocprofv3 --pmc passes as r2_step_traffic.json, one launch per "
+                                              "iteration; KB -> bytes, FETCH_SIZE x2 per MI355X_MICROARCH.md",
+                               "fetch_bytes": round(2.0 * fk * 1024), "write_bytes": round(wk * 1024),
+                               "traffic_bytes": round(2.0 * fk * 1024 + wk * 1024)}, f, indent=1)
     if igemm_out:
         # the dominant kernel class alone (csrc/igemm.hip, both staging variants, + its split-K reduce)
         fi = sum(v for k, v in f_k.items() if "igemm" in k)
@@ -55,4 +69,5 @@ def main(fetch_csv, write_csv, iters, igemm_out=None):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 4, sys.argv[4] if len(sys.argv) > 4 else None)
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 4, sys.argv[4] if len(sys.argv) > 4 else None,
+         sys.argv[5] if len(sys.argv) > 5 else None)

@@ -185,6 +185,17 @@ __global__ void paste_placed_kernel(const float* __restrict__ tgt, const float* 
   }
 }
 
+// models/FlowNetC.py:73-79, :93-94 (`normalize_correctly`): the float64 mean subtraction of both frame stacks, written as
+// ONE float32 stack [Ba + Bb, C, H, W] (first frames, then second frames) -- replaces torch.cat + .double() + sub + .float().
+__global__ void normalize_frames_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                        long na, long total, int C, long HW, const double* __restrict__ mean) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)((i / HW) % C);
+    const float v = i < na ? a[i] : b[i - na];
+    out[i] = (float)((double)v - mean[c]);
+  }
+}
+
 __global__ void gate_kernel(const float* __restrict__ loss_cur, float* __restrict__ state, float thr) {
   if (threadIdx.x == 0 && blockIdx.x == 0 && state[0] == 0.f) {
     const float l = *loss_cur;
@@ -296,4 +307,14 @@ extern "C" int ufr_patch_paste_placed(const float* tgt, const float* ref, const 
                      ref, patch_p, mask_p, origins, adv_tgt, adv_ref, mask_out, total, H, W, ph, pw, do_clamp, lo, hi,
                      gate_state);
   return ufr::launched("paste_placed_kernel");
+}
+
+extern "C" int ufr_normalize_frames(const float* frames_a, const float* frames_b, float* out, int Ba, int Bb, int C, int H, int W,
+                                    const double* mean, ufr_stream_t stream) {
+  UFR_REQUIRE(frames_a && out && mean && (frames_b || Bb == 0), "normalize frames: null pointer argument");
+  UFR_REQUIRE(Ba > 0 && Bb >= 0 && C > 0 && H > 0 && W > 0, "normalize frames: bad shape");
+  const long HW = (long)H * W, na = (long)Ba * C * HW, total = na + (long)Bb * C * HW;
+  normalize_frames_kernel<<<ufr::stream_grid(total, 256), 256, 0, ufr::as_stream(stream)>>>(frames_a, frames_b, out, na, total, C, HW,
+                                                                                             mean);
+  return ufr::launched("normalize_frames_kernel");
 }

@@ -525,7 +525,9 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const Args a) {
 // x [B][C][HW] float32 (NCHW) -> planes at a chunk offset, y = leaky(scale * x); channels C..Cpad-1 of the last chunk 0.
 __global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float* __restrict__ x, __bf16* __restrict__ planes,
                                                              long plane_stride, int chunk0, int B, int C, int HW,
-                                                             float scale, float slope, const float* __restrict__ bias) {
+                                                             float scale, float slope, const float* __restrict__ bias,
+                                                             const float* __restrict__ act) {
+  // act != nullptr: x is a GRADIENT and act the activation it passes through: y = x * LeakyReLU'(act) (no scale / bias)
   __shared__ float tile[32][65];
   const int c0 = blockIdx.x * 32, p0 = blockIdx.y * 64, b = blockIdx.z, tid = threadIdx.x;
   {
@@ -535,9 +537,14 @@ __global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float* __rest
       const int c = c0 + cc;
       float v = 0.f;
       if (c < C && p0 + p < HW) {
-        v = x[((size_t)b * C + c) * HW + p0 + p] * scale;
-        if (bias) v += bias[c];
-        v = v > 0.f ? v : v * slope;
+        const size_t e = ((size_t)b * C + c) * HW + p0 + p;
+        v = x[e] * scale;
+        if (act) {
+          v = act[e] > 0.f ? v : v * slope;
+        } else {
+          if (bias) v += bias[c];
+          v = v > 0.f ? v : v * slope;
+        }
       }
       tile[cc][p] = v;
     }
@@ -767,7 +774,17 @@ extern "C" int ufr_nchw_to_planes(const float* x, void* planes, long plane_strid
   UFR_REQUIRE(B > 0 && B < 65536 && C > 0 && H > 0 && W > 0 && chunk0 >= 0 && plane_stride > 0, "nchw -> planes: bad shape");
   const dim3 grid((C + 31) / 32, (H * W + 63) / 64, B);
   nchw_to_planes_kernel<<<grid, 256, 0, ufr::as_stream(stream)>>>(x, static_cast<__bf16*>(planes), plane_stride, chunk0, B, C,
-                                                                   H * W, scale, slope, bias);
+                                                                   H * W, scale, slope, bias, nullptr);
+  return ufr::launched("nchw_to_planes_kernel");
+}
+
+extern "C" int ufr_nchw_grad_to_planes(const float* grad, const float* act, void* planes, long plane_stride, int chunk0, int B, int C,
+                                       int H, int W, float slope, ufr_stream_t stream) {
+  UFR_REQUIRE(grad && act && planes, "nchw gradient -> planes: null pointer");
+  UFR_REQUIRE(B > 0 && B < 65536 && C > 0 && H > 0 && W > 0 && chunk0 >= 0 && plane_stride > 0, "nchw gradient -> planes: bad shape");
+  const dim3 grid((C + 31) / 32, (H * W + 63) / 64, B);
+  nchw_to_planes_kernel<<<grid, 256, 0, ufr::as_stream(stream)>>>(grad, static_cast<__bf16*>(planes), plane_stride, chunk0, B, C,
+                                                                   H * W, 1.0f, slope, nullptr, act);
   return ufr::launched("nchw_to_planes_kernel");
 }
 

@@ -119,6 +119,28 @@ __global__ void window_copy_kernel(const float* __restrict__ src, float* __restr
   }
 }
 
+// The window of a chunk-major float32 tensor [chunks][N * Hf * Wf][32] (the engine's gradient sums) as a chunk-major
+// window tensor [chunks][N_dst * wh * ww][32], rim zeroed like window_copy_kernel<true>; images n >= N of dst are not touched.
+__global__ void window_gather_chunks_kernel(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ win,
+                                            int n_win, int N, int N_dst, int chunks, int Hf, int Wf, int wh, int ww, int level_stride,
+                                            int margin, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i & 7);                      // float4 of the pixel's 32 channels
+    long r = i >> 3;
+    const int j = (int)(r % ww); r /= ww;
+    const int ii = (int)(r % wh); r /= wh;
+    const int n = (int)(r % N);
+    const int ch = (int)(r / N);
+    const int* w = win + (n % n_win) * kWinInts;
+    const int y0 = min(max(w[0] / level_stride, 0), Hf - wh), x0 = min(max(w[1] / level_stride, 0), Wf - ww);
+    const bool rim = (ii < margin && y0 > 0) || (ii >= wh - margin && y0 + wh < Hf) ||
+                     (j < margin && x0 > 0) || (j >= ww - margin && x0 + ww < Wf);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!rim) v = *reinterpret_cast<const float4*>(src + (((long)ch * N * Hf + (long)n * Hf + y0 + ii) * Wf + x0 + j) * 32 + q * 4);
+    *reinterpret_cast<float4*>(dst + (((long)ch * N_dst * wh + (long)n * wh + ii) * ww + j) * 32 + q * 4) = v;
+  }
+}
+
 int check_window(const char* what, int N, int C, int Hf, int Wf, int wh, int ww, int level_stride, int margin,
                  int n_win) {
   UFR_REQUIRE(N > 0 && C > 0 && Hf > 0 && Wf > 0, "%s: bad shape N=%d C=%d H=%d W=%d", what, N, C, Hf, Wf);
@@ -176,4 +198,15 @@ extern "C" int ufr_window_scatter(const float* src, float* dst, const int* win, 
   window_copy_kernel<false><<<ufr::stream_grid(total, 256), 256, 0, ufr::as_stream(stream)>>>(
       src, dst, win, n_win, C, Hd, Wd, wh, ww, level_stride, margin, total);
   return ufr::launched("window_scatter");
+}
+
+extern "C" int ufr_window_gather_chunks(const float* src, float* dst, const int* win, int n_win, int N, int N_dst, int chunks,
+                                        int Hs, int Ws, int wh, int ww, int level_stride, int margin, ufr_stream_t stream) {
+  UFR_REQUIRE(src && dst && win, "window_gather_chunks: null pointer");
+  if (int rc = check_window("window_gather_chunks", N, chunks, Hs, Ws, wh, ww, level_stride, margin, n_win)) return rc;
+  UFR_REQUIRE(N_dst >= N, "window_gather_chunks: destination holds %d images, source %d", N_dst, N);
+  const long total = (long)chunks * N * wh * ww * 8;
+  window_gather_chunks_kernel<<<ufr::stream_grid(total, 256), 256, 0, ufr::as_stream(stream)>>>(
+      src, dst, win, n_win, N, N_dst, chunks, Hs, Ws, wh, ww, level_stride, margin, total);
+  return ufr::launched("window_gather_chunks");
 }

@@ -199,13 +199,27 @@ class FlowNetCHeadEngine:
         self._prefix = dict(c1=c1, c2=c2, c3=c3, conv2=l2, conv3=l3, b1=bias("conv1"),
                             w1=self._conv("conv1").weight.detach())
 
+    def _normalized(self, a: torch.Tensor, b: torch.Tensor | None, P: dict) -> torch.Tensor:
+        """`normalize_correctly` (float64 mean subtraction, FlowNetC.py:73-79) of one or two frame stacks as one float32 stack."""
+        a = a.contiguous()
+        L.require_hip(a, "frames")
+        nb = 0 if b is None else int(b.shape[0])
+        shape = (int(a.shape[0]) + nb, 3, int(a.shape[2]), int(a.shape[3]))
+        x = P.get("x")
+        if x is None or tuple(x.shape) != shape:
+            x = P["x"] = torch.empty(shape, dtype=torch.float32, device=self.dev)
+        mean = self.net._mean64.reshape(-1).contiguous()
+        L.check(L.lib().ufr_normalize_frames(L.ptr(a), L.ptr(b.contiguous()) if b is not None else None, L.ptr(x), int(a.shape[0]), nb,
+                                             3, shape[2], shape[3], L.ptr(mean), L.stream()), "normalize frames")
+        return x
+
     def prefix_full(self, frames_a: torch.Tensor, frames_b: torch.Tensor):
         """New frames: conv2 of the first frames and conv3 of both, for the full frame, straight into the head's plane
         buffers (cat2[0:4], c3a_p, c3b_p) plus conv3 in NCHW for the correlation kernels."""
         if self._prefix is None:
             self._build_prefix()
         P, B = self._prefix, self.B
-        x = self.net.normalize_correctly(torch.cat((frames_a, frames_b), 0))
+        x = self._normalized(frames_a, frames_b, P)
         y1 = torch.nn.functional.conv2d(x, P["w1"], None, 2, 3)
         P["c1"].load_nchw(y1, 0, 1.0, ig.LEAKY, P["b1"])                 # bias + LeakyReLU + split, one pass
         P["conv2"]()
@@ -250,12 +264,15 @@ class FlowNetCHeadEngine:
         h2, w2, h4, w4, h8, w8 = wh // 2, ww // 2, wh // 4, ww // 4, wh // 8, ww // 8
         c1, c2, c3 = ig.Planes(B2, h2, w2, 2, dev), ig.Planes(B2, h4, w4, 4, dev), ig.Planes(B2, h8, w8, 8, dev)
         gz_c3, gz_c2 = ig.Planes(B2, h8, w8, 8, dev), ig.Planes(B2, h4, w4, 4, dev)
-        G_c2, G_c1 = ig.GradSum(B2, h4, w4, 4, dev), ig.GradSum(B2, h2, w2, 2, dev)
+        G_gw2, G_c1 = ig.GradSum(B2, h4, w4, 4, dev), ig.GradSum(B2, h2, w2, 2, dev)   # G_gw2: the conv2 tap's window gradient
+                                                                                       # (first frames; second frames stay 0)
         bias = lambda n: self._conv(n).bias.detach().float().contiguous()
         plans = [
             (ig.conv_forward_weights(self._conv("conv2").weight, 2, 2), c1, (h4, w4), (h4, w4), dict(out_planes=c2, bias=bias("conv2"))),
             (ig.conv_forward_weights(self._conv("conv3").weight, 2, 2), c2, (h8, w8), (h8, w8), dict(out_planes=c3, bias=bias("conv3"))),
-            (ig.conv_backward_weights(self._conv("conv3").weight, 2, 2), gz_c3, (h8, w8), (h4, w4), dict(out_f32=G_c2)),
+            # conv3's data gradient + the skip connection's gradient, x LeakyReLU'(conv2) -> conv2's gradient planes
+            (ig.conv_backward_weights(self._conv("conv3").weight, 2, 2), gz_c3, (h8, w8), (h4, w4),
+             dict(add=G_gw2, mask=c2, out_planes=gz_c2)),
             (ig.conv_backward_weights(self._conv("conv2").weight, 2, 2), gz_c2, (h4, w4), (h2, w2), dict(out_f32=G_c1)),
         ]
         sized = []
@@ -267,11 +284,11 @@ class FlowNetCHeadEngine:
         launches = [ig.make_launch(wi, x, 0, rows, out_hw, splitk=S, ws=ws if S > 1 else None, **kw)
                     for (wi, x, rows, out_hw, kw), S in zip(plans, sized)]
         wis = {k + "_wi": p[0] for k, p in zip(("conv2", "conv3", "conv3_bwd", "conv2_bwd"), plans)}
-        self._wprefix = dict(**wis, hw=(wh, ww), c1=c1, c2=c2, c3=c3, gz_c3=gz_c3, gz_c2=gz_c2, G_c2=G_c2, G_c1=G_c1, ws=ws,
+        self._wprefix = dict(**wis, hw=(wh, ww), c1=c1, c2=c2, c3=c3, gz_c3=gz_c3, gz_c2=gz_c2, G_gw2=G_gw2, G_c1=G_c1, ws=ws,
                              conv2=launches[0], conv3=launches[1], conv3_bwd=launches[2], conv2_bwd=launches[3],
                              b1=bias("conv1"), w1=self._conv("conv1").weight.detach(),
                              c2_nchw=torch.zeros(B2, 128, h4, w4, **f32), c3_nchw=torch.zeros(B2, 256, h8, w8, **f32),
-                             g_c2=torch.zeros(B2, 128, h4, w4, **f32), g_c1=torch.zeros(B2, 64, h2, w2, **f32))
+                             g_c1=torch.zeros(B2, 64, h2, w2, **f32))
 
     def window_prefix_forward(self, xw: torch.Tensor, win: torch.Tensor, m2: int, m3: int):
         """conv1-3 of the window stack `xw` [2B, 3, wh, ww] (raw frames; first frames, then second frames), patched into the
@@ -282,29 +299,38 @@ class FlowNetCHeadEngine:
         if P is None or P["hw"] != (wh, ww):
             self._build_window_prefix(wh, ww)
             P = self._wprefix
-        x = self.net.normalize_correctly(xw.detach())
+        x = self._normalized(xw.detach(), None, P)
         y1 = torch.nn.functional.conv2d(x, P["w1"], None, 2, 3)
         P["c1"].load_nchw(y1, 0, 1.0, ig.LEAKY, P["b1"])
         P["conv2"]()
         P["conv3"]()
-        P["c2"].to_nchw(128, 0, out=P["c2_nchw"])
+        P["c2"].to_nchw(128, 0, out=P["c2_nchw"])                         # (the scatter kernels take NCHW windows)
         P["c3"].to_nchw(256, 0, out=P["c3_nchw"])
         self.scatter_window_features(P["c2_nchw"], P["c3_nchw"], win, wh, ww, m2, m3)
 
-    def window_prefix_backward(self, gw2: torch.Tensor, gw3: torch.Tensor) -> torch.Tensor:
-        """d loss / d xw from the window gradients of the two taps: gw2 [B, 128, wh/4, ww/4] (conv2 of the first frames),
-        gw3 [2B, 256, wh/8, ww/8] (conv3 of both), rims already zeroed."""
+    def window_gather_conv2_gradient(self, win: torch.Tensor, m2: int):
+        """The conv2 tap's window gradient straight from the head's chunk-major sum of cat2 (chunks 0-3 = conv2 of the
+        first frames) into the addend of conv3's data gradient: no full-frame NCHW conversion, no NCHW window."""
+        P = self._wprefix
+        wh, ww = P["hw"]
+        h4, w4 = self.grid[4]
+        L.check(L.lib().ufr_window_gather_chunks(L.ptr(self.G_cat2.t), L.ptr(P["G_gw2"].t), L.ptr(win), self.B, self.B, 2 * self.B, 4,
+                                                 h4, w4, wh // 4, ww // 4, 4, int(m2), L.stream()), "window gather (chunks)")
+
+    def window_prefix_backward(self, gw3: torch.Tensor, gw2: torch.Tensor | None = None) -> torch.Tensor:
+        """d loss / d xw from the window gradients of the two taps: gw3 [2B, 256, wh/8, ww/8] (conv3 of both frames, rim
+        zeroed); the conv2 tap's (first frames) was put into `G_gw2` by `window_gather_conv2_gradient`, or is handed over
+        here as NCHW [B, 128, wh/4, ww/4]."""
         P, B = self._wprefix, self.B
         wh, ww = P["hw"]
-        slope = ig.LEAKY
-        # LeakyReLU' of conv3's output, split into the gradient planes conv3's data gradient reads
-        g3 = gw3 * torch.where(P["c3_nchw"] > 0, 1.0, slope)
-        P["gz_c3"].load_nchw(g3, 0)
-        P["conv3_bwd"]()
-        g2 = P["G_c2"].to_nchw(128, 0, out=P["g_c2"])
-        g2[:B] += gw2
-        g2 *= torch.where(P["c2_nchw"] > 0, 1.0, slope)
-        P["gz_c2"].load_nchw(g2, 0)
+        if gw2 is not None:                      # NCHW -> chunk-major addend (tests, callers without the engine's sums)
+            full = torch.zeros(2 * B, 128, wh // 4, ww // 4, dtype=torch.float32, device=self.dev)
+            full[:B] = gw2
+            P["G_gw2"].t.copy_(full.view(2 * B, 4, 32, wh // 4, ww // 4).permute(1, 0, 3, 4, 2).reshape(4, -1, 32))
+        gz = P["gz_c3"]                          # x LeakyReLU'(conv3), split into the planes conv3's data gradient reads
+        L.check(L.lib().ufr_nchw_grad_to_planes(L.ptr(gw3), L.ptr(P["c3_nchw"]), L.ptr(gz.t), gz.plane_stride, 0, 2 * B, 256, wh // 8,
+                                                ww // 8, ig.LEAKY, L.stream()), "window gradient -> planes")
+        P["conv3_bwd"]()                         # + G_gw2, x LeakyReLU'(conv2) -> gz_c2 (epilogue)
         P["conv2_bwd"]()
         g1 = P["G_c1"].to_nchw(64, 0, mask=P["c1"], out=P["g_c1"])       # LeakyReLU' of conv1's output fused
         return torch.nn.grad.conv2d_input((2 * B, 3, wh, ww), P["w1"], g1, stride=2, padding=3)
@@ -467,7 +493,12 @@ class FlowNetCHeadEngine:
             self.attach_band(band)
         # level 2: predict_flow2 -> gradient of cat2 = [conv2a | deconv2 | flow3_up]
         self._pf_backward(2, g_flow2, accumulate=False)
-        self.G_cat2.to_nchw(128, 0, out=self.g_c2a)
+        eng_window = bool(fused_window and band is not None and getattr(band, "eng_window", False)
+                          and getattr(self, "_wprefix", None) is not None)
+        if eng_window:                           # the window prefix runs on the engine: its conv2 gradient stays chunk-major
+            self.window_gather_conv2_gradient(band.cone_win, band.g2_margin)
+        else:
+            self.G_cat2.to_nchw(128, 0, out=self.g_c2a)
         gz = {2: (self.G_cat2, self.cat2, self.gz_cat2, 4, 2), 3: (self.G_cat3, self.cat3, self.gz_cat3, 8, 4),
               4: (self.G_cat4, self.cat4, self.gz_cat4, 16, 8), 5: (self.G_cat5, self.cat5, self.gz_cat5, 16, 16)}
         for k in (2, 3, 4):
@@ -497,11 +528,11 @@ class FlowNetCHeadEngine:
                                                            L.ptr(self.G_c3a.t), L.ptr(gw), B, 256, h8, w8, 21, 2,
                                                            L.ptr(band.cone_win), 8, band.cone_hw[0] // 8, band.cone_hw[1] // 8,
                                                            int(band.g3_margin), L.stream()), "correlation backward (window, fused)")
-            return self.g_c2a, None, None
+            return (None if eng_window else self.g_c2a), None, None
         self.G_c3a.to_nchw(256, 0, out=self.g_c3a_redir)
         self.G_in31.to_nchw(441, 1, scale=1.0 / 256.0, out=self.g_corr.view(B, 441, *self.grid[8]))
         self._corr_backward(self.g_corr, band)
-        return self.g_c2a, self.g_c3a, self.g_c3b
+        return (None if eng_window else self.g_c2a), self.g_c3a, self.g_c3b
 
     def _corr_backward(self, g_corr, band):
         from . import spatial_correlation_sampler_backend as correlation

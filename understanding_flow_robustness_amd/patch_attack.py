@@ -318,8 +318,10 @@ class PatchAttackStep:
             (ls2, m2, _, _, gw2), (ls3, m3, _, _, gw3) = self.taps
             if self.band is not None:            # the engine writes conv3's window gradient itself (fused correlation adjoint)
                 self.band.g3_window, self.band.g3_margin = gw3, m3
+                self.band.eng_window, self.band.g2_margin = self._eng_window, m2
             g2a, g3a, g3b = self.eng.backward(g_flow2.contiguous(), self.band)
-            self._win_copy(lib.ufr_window_gather, g2a, gw2, B, 128, H // ls2, W // ls2, ls2, m2)
+            if g2a is not None:
+                self._win_copy(lib.ufr_window_gather, g2a, gw2, B, 128, H // ls2, W // ls2, ls2, m2)
             if g3a is not None:
                 self._win_copy(lib.ufr_window_gather, g3a, gw3, B, 256, H // ls3, W // ls3, ls3, m3)
                 self._win_copy(lib.ufr_window_gather, g3b, gw3[B:], B, 256, H // ls3, W // ls3, ls3, m3)
@@ -328,7 +330,7 @@ class PatchAttackStep:
             for g, (ls, m, n, _, gwin) in zip(g_full, self.taps):
                 self._win_copy(lib.ufr_window_gather, g.contiguous(), gwin, n, g.shape[1], H // ls, W // ls, ls, m)
         if self.eng is not None and self._eng_window:
-            gxw = self.eng.window_prefix_backward(self.taps[0][4], self.taps[1][4])
+            gxw = self.eng.window_prefix_backward(self.taps[1][4], None if g2a is None else self.taps[0][4])
         else:
             gxw, = torch.autograd.grad(self._feats_w, (self.xw,), [t[4] for t in self.taps])
         self._feats_w = None
