@@ -141,6 +141,8 @@ def kernel_rooflines(step, device, max_count):
         for (name, kind, tag), (t, gflop) in per.items():
             if tag == "window":
                 w = 1.0
+            elif tag == "prefix":              # full-frame conv2 / conv3 of load(): once per attack() call
+                w = 1.0 / max_count
             elif kind == "fwd":
                 has_band = (name, "fwd", "band") in per
                 w = (1.0 / max_count if has_band else 1.0) if tag == "full" else (max_count - 1.0) / max_count
@@ -401,7 +403,9 @@ def main():
         line["config"]["arithmetic"] = (
             "float32 end to end; the head's convolutions compute each float32 product on the bf16 matrix cores as three bf16 "
             "planes per operand and the six leading products, float32 accumulation (csrc/igemm.hip: error vs float64 at "
-            "MIOpen's own fp32 level, tests/test_igemm_gpu.py); conv1-3 on MIOpen fp32" if engine_on else
+            "MIOpen's own fp32 level, tests/test_igemm_gpu.py) -- the head, conv2 / conv3 of the full-frame prefix and of the "
+            "window and their data gradients, the cost volume and both of its adjoints, predict_flow; conv1 (3 input channels) "
+            "and its data gradient on MIOpen fp32" if engine_on else
             "float32 end to end on MIOpen (UFR_ENGINE=0)")
         if world == 1:
             kernels, agg = kernel_rooflines(step, device, mc)

@@ -175,9 +175,9 @@ __global__ __launch_bounds__(64 * NW) void corr_fwd_planes_kernel(const __bf16* 
 #pragma unroll
         for (int p = 0; p < 3; ++p) fb[tt][p] = *reinterpret_cast<const bf16x8*>(bsrc + p * PLANE + tt * 16 * 32);
 #pragma unroll
-      for (int tt = 0; tt < 3; ++tt)
+      for (int q = 0; q < 6; ++q)                // the three tiles' accumulation chains interleaved: no back-to-back dependence
 #pragma unroll
-        for (int q = 0; q < 6; ++q)
+        for (int tt = 0; tt < 3; ++tt)
           acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kc][PROD_A[q]], fb[tt][PROD_B[q]], acc[tt], 0, 0, 0);
       if (kc == KCH - 1) {                        // the row is complete: its stores go out BEFORE the next DMA is issued,
         write_row(dy, acc, false);                // so the youngest `n` memory operations below are exactly that DMA

@@ -192,11 +192,11 @@ class FlowNetCHeadEngine:
         c2 = ig.Planes(B2, H // 4, W // 4, 4, dev)
         c3 = ig.Planes(B2, H // 8, W // 8, 8, dev)
         bias = lambda n: self._conv(n).bias.detach().float().contiguous()
-        l2 = ig.make_launch(ig.conv_forward_weights(self._conv("conv2").weight, 2, 2), c1, 0, (H // 4, W // 4), (H // 4, W // 4),
-                            out_planes=c2, bias=bias("conv2"))
-        l3 = ig.make_launch(ig.conv_forward_weights(self._conv("conv3").weight, 2, 2), c2, 0, (H // 8, W // 8), (H // 8, W // 8),
-                            out_planes=c3, bias=bias("conv3"))
-        self._prefix = dict(c1=c1, c2=c2, c3=c3, conv2=l2, conv3=l3, b1=bias("conv1"),
+        w2 = ig.conv_forward_weights(self._conv("conv2").weight, 2, 2)
+        w3 = ig.conv_forward_weights(self._conv("conv3").weight, 2, 2)
+        l2 = ig.make_launch(w2, c1, 0, (H // 4, W // 4), (H // 4, W // 4), out_planes=c2, bias=bias("conv2"))
+        l3 = ig.make_launch(w3, c2, 0, (H // 8, W // 8), (H // 8, W // 8), out_planes=c3, bias=bias("conv3"))
+        self._prefix = dict(c1=c1, c2=c2, c3=c3, conv2=l2, conv3=l3, conv2_wi=w2, conv3_wi=w3, b1=bias("conv1"),
                             w1=self._conv("conv1").weight.detach())
 
     def _normalized(self, a: torch.Tensor, b: torch.Tensor | None, P: dict) -> torch.Tensor:
@@ -384,6 +384,11 @@ class FlowNetCHeadEngine:
                 wi = self._plans[(kind, name)][0]
                 d = launch.desc
                 rows.append((name, kind, tag, launch, wi.flops(d.B * d.Hr * d.Wr) / 1e9))
+        F = self._prefix
+        if F is not None:                      # full-frame conv2 / conv3 of both frames, once per attack() call
+            for name, key in (("conv2", "conv2"), ("conv3", "conv3")):
+                d = F[key].desc
+                rows.append((name, "fwd", "prefix", F[key], F[key + "_wi"].flops(d.B * d.Hr * d.Wr) / 1e9))
         P = getattr(self, "_wprefix", None)
         if P is not None:                      # conv2 / conv3 of the attack's prefix window (every iteration)
             for name, kind, key in (("conv2", "fwd", "conv2"), ("conv3", "fwd", "conv3"), ("conv3", "bwd", "conv3_bwd"),
