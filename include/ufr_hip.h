@@ -449,6 +449,15 @@ int ufr_chunks_to_nchw(const void* planes, long plane_stride, const float* f32, 
 int ufr_grad_finalize(const float* g, int g_chunk0, const void* mask, int mask_chunk0, void* out, long out_plane_stride,
                       int out_chunk0, long M, int chunks, float slope, ufr_stream_t stream);
 
+/* Raw frames [Ba(+Bb), 3, H, W] -> the PACKED planes conv1 = Conv2d(3, 64, 7, 2, 3) (models/FlowNetC.py:22) reads as an
+ * 8-tap ufr_igemm launch: planes [3][1][(Ba + Bb) * (H/2 + 3) * (W/2 + 2)][32], channel j*12 + (c*2 + p)*2 + q of packed
+ * pixel (yp, xp) = frame[c, 2 (yp - 2) + p, 2 (xp - 2 + j) + q] - mean[c] in float64 (normalize_correctly, FlowNetC.py:73-79),
+ * zero outside the frame and for channels 24..31. */
+int ufr_conv1_pack_planes(const float* frames_a, const float* frames_b, void* planes, long plane_stride, int Ba, int Bb, int H,
+                          int W, const double* mean, ufr_stream_t stream);
+/* Adjoint of the packing: d loss / d frames [N, 3, H, W] from the float32 gradient sum of the packed planes
+ * [1][N * (H/2 + 3) * (W/2 + 2)][32] (the output of conv1's data-gradient launch). */
+int ufr_conv1_unpack_grad(const float* G, float* grad_frames, int N, int H, int W, ufr_stream_t stream);
 /* NCHW float32 gradient x LeakyReLU'(NCHW activation) -> the engine's gradient planes (three bf16 planes, chunk-major), one pass. */
 int ufr_nchw_grad_to_planes(const float* grad, const float* act, void* planes, long plane_stride, int chunk0, int B, int C, int H,
                             int W, float slope, ufr_stream_t stream);

@@ -267,6 +267,12 @@ def test_window_prefix_on_the_engine_equals_the_torch_prefix(net):
         return outs[1], outs[2]
     x64 = xw.double().requires_grad_(True)
     c2_64, c3_64 = encode64(x64)
+    # conv1 on the igemm over the packed planes (pixel-unshuffle, two columns per chunk, padding inside the buffer)
+    c1_64 = F.leaky_relu(F.conv2d(x64 - net._mean64.double(), net.conv1[0].weight.double(), net.conv1[0].bias.double(), 2, 3), 0.1)
+    c1_32 = F.leaky_relu(F.conv2d(net.normalize_correctly(xw), net.conv1[0].weight, net.conv1[0].bias, 2, 3), 0.1)
+    e_eng, e_t = _rel(P["c1"].to_nchw(64, 0), c1_64.detach()), _rel(c1_32, c1_64.detach())
+    print(f"conv1: engine {e_eng:.2e}, torch fp32 {e_t:.2e} (vs float64)")
+    assert "conv1" in P and e_eng <= max(3 * e_t, 2e-6)
     for name, got, t32, t64 in (("conv2", P["c2_nchw"], c2, c2_64), ("conv3", P["c3_nchw"], c3, c3_64)):
         e_eng, e_t = _rel(got, t64), _rel(t32.detach(), t64)
         print(f"{name}: engine {e_eng:.2e}, torch fp32 {e_t:.2e} (vs float64)")

@@ -110,6 +110,8 @@ SIGNATURES = {
     "ufr_cone_window": [_vp, _i, _l, _i, _i, _i, C.POINTER(ConeChain), _i, _i, _vp, _vp, _vp],
     "ufr_window_gather": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ufr_window_scatter": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ufr_conv1_pack_planes": [_vp, _vp, _vp, _l, _i, _i, _i, _i, _vp, _vp],
+    "ufr_conv1_unpack_grad": [_vp, _vp, _i, _i, _i, _vp],
     "ufr_nchw_grad_to_planes": [_vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _f, _vp],
     "ufr_window_gather_chunks": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ufr_normalize_frames": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],

@@ -566,6 +566,59 @@ __global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float* __rest
   *reinterpret_cast<bf16x8*>(dst + 2 * plane_stride) = q2;
 }
 
+// ---- conv1 (Conv2d(3, 64, 7, 2, 3), models/FlowNetC.py:22) as an igemm launch --------------------------------------------
+// A 3-channel pixel would leave 29 of a chunk's 32 channels empty.  The frames are therefore written as PACKED planes: the
+// 2 x 2 pixel-unshuffle turns the stride-2 7 x 7 convolution into a stride-1 4 x 4 one over 12 channels on the half grid,
+// and two horizontally adjacent half-grid pixels share one chunk (24 of 32 channels), so the convolution is 4 x 2 = 8 taps
+// of ONE chunk.  The buffer carries the zero padding physically (2 rows above, 1 below, 2 columns to the left, the j = 1 half of the last column): every tap
+// is in range.  channel j*12 + (c*2 + p)*2 + q of packed pixel (yp, xp) = frame[c, 2 (yp - 2) + p, 2 (xp - 2 + j) + q] - mean[c]
+// (the float64 mean subtraction of normalize_correctly, FlowNetC.py:73-79, fused), zero outside the frame.
+__global__ __launch_bounds__(256) void conv1_pack_kernel(const float* __restrict__ fa, const float* __restrict__ fb, int Ba,
+                                                         __bf16* __restrict__ planes, long plane_stride, int N, int H, int W,
+                                                         const double* __restrict__ mean) {
+  const int Hh = H >> 1, Wh = W >> 1, Hp = Hh + 3, Wp = Wh + 2;
+  const long total = (long)N * Hp * Wp * 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i & 3);
+    const long pix = i >> 2;
+    const int xp = (int)(pix % Wp), yp = (int)((pix / Wp) % Hp), n = (int)(pix / ((long)Wp * Hp));
+    const float* img = n < Ba ? fa + (long)n * 3 * H * W : fb + (long)(n - Ba) * 3 * H * W;
+    bf16x8 q0, q1, q2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ch = k * 8 + e;
+      float v = 0.f;
+      if (ch < 24) {
+        const int j = ch / 12, r = ch - 12 * j, c = r >> 2, p = (r >> 1) & 1, q = r & 1;
+        const int yh = yp - 2, xh = xp - 2 + j;
+        if (yh >= 0 && yh < Hh && xh >= 0 && xh < Wh)
+          v = (float)((double)img[((long)c * H + 2 * yh + p) * W + 2 * xh + q] - mean[c]);
+      }
+      __bf16 a, b2, c2;
+      split3(v, a, b2, c2);
+      q0[e] = a; q1[e] = b2; q2[e] = c2;
+    }
+    __bf16* dst = planes + pix * 32 + k * 8;
+    *reinterpret_cast<bf16x8*>(dst) = q0;
+    *reinterpret_cast<bf16x8*>(dst + plane_stride) = q1;
+    *reinterpret_cast<bf16x8*>(dst + 2 * plane_stride) = q2;
+  }
+}
+
+// Adjoint of conv1_pack_kernel: the gradient with respect to the raw frames from the float32 gradient sum of the packed
+// planes G [1][N * Hp * Wp][32]: a frame pixel sits in two packed pixels (j = 0 and j = 1 of the column pair).
+__global__ __launch_bounds__(256) void conv1_unpack_grad_kernel(const float* __restrict__ G, float* __restrict__ gx, int N, int H,
+                                                                int W) {
+  const int Hh = H >> 1, Wh = W >> 1, Hp = Hh + 3, Wp = Wh + 2;
+  const long total = (long)N * 3 * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H), c = (int)((i / ((long)W * H)) % 3), n = (int)(i / ((long)3 * W * H));
+    const int r = (c * 2 + (y & 1)) * 2 + (x & 1);
+    const long row = ((long)n * Hp + (y >> 1) + 2) * Wp + (x >> 1);
+    gx[i] = G[(row + 2) * 32 + r] + G[(row + 1) * 32 + 12 + r];
+  }
+}
+
 // chunk-major tensor (planes: p0 + p1 + p2, or fp32) -> out [B][C][HW] float32 (NCHW), optionally
 // out = scale * leaky'(mask) * v with `mask` = plane 0 of an activation in the same chunk-major geometry.
 __global__ __launch_bounds__(256) void chunks_to_nchw_kernel(const __bf16* __restrict__ planes, long plane_stride,
@@ -786,6 +839,25 @@ extern "C" int ufr_nchw_grad_to_planes(const float* grad, const float* act, void
   nchw_to_planes_kernel<<<grid, 256, 0, ufr::as_stream(stream)>>>(grad, static_cast<__bf16*>(planes), plane_stride, chunk0, B, C,
                                                                    H * W, 1.0f, slope, nullptr, act);
   return ufr::launched("nchw_to_planes_kernel");
+}
+
+extern "C" int ufr_conv1_pack_planes(const float* frames_a, const float* frames_b, void* planes, long plane_stride, int Ba, int Bb,
+                                     int H, int W, const double* mean, ufr_stream_t stream) {
+  UFR_REQUIRE(frames_a && planes && mean && (frames_b || Bb == 0), "conv1 pack: null pointer");
+  UFR_REQUIRE(Ba > 0 && Bb >= 0 && H > 0 && W > 0 && !(H & 1) && !(W & 1) && plane_stride > 0, "conv1 pack: bad shape");
+  const long total = (long)(Ba + Bb) * ((H >> 1) + 3) * ((W >> 1) + 2) * 4;
+  conv1_pack_kernel<<<ufr::stream_grid(total, 256), 256, 0, ufr::as_stream(stream)>>>(frames_a, frames_b, Ba,
+                                                                                      static_cast<__bf16*>(planes), plane_stride,
+                                                                                      Ba + Bb, H, W, mean);
+  return ufr::launched("conv1_pack_kernel");
+}
+
+extern "C" int ufr_conv1_unpack_grad(const float* G, float* grad_frames, int N, int H, int W, ufr_stream_t stream) {
+  UFR_REQUIRE(G && grad_frames, "conv1 unpack: null pointer");
+  UFR_REQUIRE(N > 0 && H > 0 && W > 0 && !(H & 1) && !(W & 1), "conv1 unpack: bad shape");
+  const long total = (long)N * 3 * H * W;
+  conv1_unpack_grad_kernel<<<ufr::stream_grid(total, 256), 256, 0, ufr::as_stream(stream)>>>(G, grad_frames, N, H, W);
+  return ufr::launched("conv1_unpack_grad_kernel");
 }
 
 extern "C" int ufr_chunks_to_nchw(const void* planes, long plane_stride, const float* f32, int chunk0, const void* mask,

@@ -51,55 +51,6 @@ __global__ void resample2d_fwd(const float* __restrict__ img, const float* __res
   }
 }
 
-// The same forward specialised for FlowNet2's only use (kernel_size 1, bilinear, image and flow of one size, W % 4 == 0,
-// C <= 4): a thread owns FOUR consecutive pixels of a row -- flow read and result written as float4, the 16 C taps issued
-// back to back (the generic form: one pixel, C x 4 dependent trips through runtime loops).  Same arithmetic, same order.
-template <int C>
-__global__ __launch_bounds__(256) void resample2d_fwd_k1x4(const float* __restrict__ img, const float* __restrict__ flow,
-                                                           float* __restrict__ out, int B, int H, int W) {
-  const long nquad = (long)B * H * (W >> 2);
-  const size_t plane = (size_t)H * W;
-  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += (long)gridDim.x * blockDim.x) {
-    const int wq = W >> 2;
-    const int x0 = (int)(q % wq) << 2, y = (int)((q / wq) % H), b = (int)(q / ((long)wq * H));
-    const size_t pix = (size_t)y * W + x0;
-    const float4 fdx = *reinterpret_cast<const float4*>(flow + ((size_t)b * 2 + 0) * plane + pix);
-    const float4 fdy = *reinterpret_cast<const float4*>(flow + ((size_t)b * 2 + 1) * plane + pix);
-    const float dxs[4] = {fdx.x, fdx.y, fdx.z, fdx.w}, dys[4] = {fdy.x, fdy.y, fdy.z, fdy.w};
-    float tap[C][4][4];
-    double wgt[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float xf = (float)(x0 + i) + dxs[i], yf = (float)y + dys[i];
-      const float alpha = xf - floorf(xf), beta = yf - floorf(yf);
-      const int xL = clampi((int)floorf(xf), 0, W - 1), xR = clampi((int)floorf(xf) + 1, 0, W - 1);
-      const int yT = clampi((int)floorf(yf), 0, H - 1), yB = clampi((int)floorf(yf) + 1, 0, H - 1);
-      wgt[i][0] = (1. - alpha) * (1. - beta); wgt[i][1] = (double)alpha * (1. - beta);
-      wgt[i][2] = (1. - alpha) * (double)beta; wgt[i][3] = (double)alpha * (double)beta;
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        const float* im = img + ((size_t)b * C + c) * plane;
-        tap[c][i][0] = im[(size_t)yT * W + xL]; tap[c][i][1] = im[(size_t)yT * W + xR];
-        tap[c][i][2] = im[(size_t)yB * W + xL]; tap[c][i][3] = im[(size_t)yB * W + xR];
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      float v[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float val = 0.f;
-        val += (float)(wgt[i][0] * tap[c][i][0]);
-        val += (float)(wgt[i][1] * tap[c][i][1]);
-        val += (float)(wgt[i][2] * tap[c][i][2]);
-        val += (float)(wgt[i][3] * tap[c][i][3]);
-        v[i] = val;
-      }
-      *reinterpret_cast<float4*>(out + ((size_t)b * C + c) * plane + pix) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-  }
-}
-
 // resample2d_kernel.cu:75-125 (scatter to the image; weights use int() truncation, :105-106)
 // fused with :127-198 (gradient wrt the flow; clamps with the flow's dims; channel 0 uses
 // gamma = 1-frac(y), channel 1 gamma = 1-frac(x)).  gimg must be zero on entry.
@@ -369,7 +320,8 @@ __global__ void channelnorm_bwd(const float* __restrict__ in, const float* __res
 
 constexpr int RS_LDS_BYTES = 48 * 1024;         // per workgroup: three workgroups per CU
 
-// UFR_RESAMPLE_LDS: unset / 1 = LDS-privatised adjoint, direct forward (four pixels per thread when the shape allows) (the measured optimum: profiles/r2_hbm_ops_*: the
+// UFR_RESAMPLE_LDS: unset / 1 = LDS-privatised adjoint, direct forward (one pixel per thread: a four-pixel-per-thread
+// form with float4 flow / output accesses measured 0.136 vs 0.071 ms -- fewer, wider threads lose the gathers' locality) (the measured optimum: profiles/r2_hbm_ops_*: the
 // forward's 12 taps per pixel are already served by L1 / L2, staging the box costs more than it saves -- 0.112 vs 0.071 ms
 // at 8 x 448x1024 with a smooth flow -- while the adjoint's atomics drop 3x: 1.56 -> 0.50 ms); 0 = both direct; 2 = both LDS.
 int rs_lds_mode() {
@@ -400,18 +352,6 @@ extern "C" int ufr_resample2d_forward(const float* input1, const float* input2, 
     rs_raise_lds();
     resample2d_fwd_lds<<<tiles, 256, RS_LDS_BYTES, ufr::as_stream(stream)>>>(input1, input2, output, B, C, H, W, RS_LDS_BYTES / 4);
     return ufr::launched("resample2d_fwd_lds");
-  }
-  if (kernel_size == 1 && bilinear && Hi == H && Wi == W && (W & 3) == 0 && C >= 1 && C <= 4 && rs_lds_mode() != 0) {
-    const long nquad = npix >> 2;                 // FlowNet2's configuration: four pixels per thread, taps in flight together
-    const dim3 grid(ufr::stream_grid(nquad, 256));
-    hipStream_t st = ufr::as_stream(stream);
-    switch (C) {
-      case 1: resample2d_fwd_k1x4<1><<<grid, 256, 0, st>>>(input1, input2, output, B, H, W); break;
-      case 2: resample2d_fwd_k1x4<2><<<grid, 256, 0, st>>>(input1, input2, output, B, H, W); break;
-      case 3: resample2d_fwd_k1x4<3><<<grid, 256, 0, st>>>(input1, input2, output, B, H, W); break;
-      default: resample2d_fwd_k1x4<4><<<grid, 256, 0, st>>>(input1, input2, output, B, H, W); break;
-    }
-    return ufr::launched("resample2d_fwd_k1x4");
   }
   hipLaunchKernelGGL(resample2d_fwd, dim3(ufr::stream_grid(npix, 256)), dim3(256), 0,
                      ufr::as_stream(stream), input1, input2, output, B, C, Hi, Wi, H, W,

@@ -198,6 +198,36 @@ class FlowNetCHeadEngine:
         l3 = ig.make_launch(w3, c2, 0, (H // 8, W // 8), (H // 8, W // 8), out_planes=c3, bias=bias("conv3"))
         self._prefix = dict(c1=c1, c2=c2, c3=c3, conv2=l2, conv3=l3, conv2_wi=w2, conv3_wi=w3, b1=bias("conv1"),
                             w1=self._conv("conv1").weight.detach())
+        self._prefix.update(self._conv1_launch(B2, H, W, c1))
+
+    def _conv1_launch(self, n: int, H: int, W: int, c1: ig.Planes) -> dict:
+        """conv1 = Conv2d(3, 64, 7, 2, 3) + bias + LeakyReLU as an igemm launch over the packed planes of the raw frames
+        (csrc/igemm.hip `conv1_pack_kernel`: pixel-unshuffle + two columns per chunk -> 8 taps of one chunk, the mean
+        subtraction and the zero padding inside the buffer), writing conv1's planes directly."""
+        if os.environ.get("UFR_CONV1_IGEMM", "1") == "0":
+            return {}
+        packed = ig.Planes(n, H // 2 + 3, W // 2 + 2, 1, self.dev)
+        wi = ig.conv1_packed_weights(self._conv("conv1").weight)
+        launch = ig.make_launch(wi, packed, 0, (H // 2, W // 2), (H // 2, W // 2), out_planes=c1,
+                                bias=self._conv("conv1").bias.detach().float().contiguous())
+        return dict(packed=packed, conv1=launch, conv1_wi=wi)
+
+    def _conv1(self, P: dict, a: torch.Tensor, b: torch.Tensor | None):
+        """conv1 + bias + LeakyReLU of one or two raw frame stacks into P['c1']."""
+        if "conv1" in P:
+            a = a.contiguous()
+            L.require_hip(a, "frames")
+            nb = 0 if b is None else int(b.shape[0])
+            mean = self.net._mean64.reshape(-1).contiguous()
+            pk = P["packed"]
+            L.check(L.lib().ufr_conv1_pack_planes(L.ptr(a), L.ptr(b.contiguous()) if b is not None else None, L.ptr(pk.t),
+                                                  pk.plane_stride, int(a.shape[0]), nb, int(a.shape[2]), int(a.shape[3]),
+                                                  L.ptr(mean), L.stream()), "conv1 pack")
+            P["conv1"]()
+            return
+        x = self._normalized(a, b, P)
+        y1 = torch.nn.functional.conv2d(x, P["w1"], None, 2, 3)
+        P["c1"].load_nchw(y1, 0, 1.0, ig.LEAKY, P["b1"])                 # bias + LeakyReLU + split, one pass
 
     def _normalized(self, a: torch.Tensor, b: torch.Tensor | None, P: dict) -> torch.Tensor:
         """`normalize_correctly` (float64 mean subtraction, FlowNetC.py:73-79) of one or two frame stacks as one float32 stack."""
@@ -219,9 +249,7 @@ class FlowNetCHeadEngine:
         if self._prefix is None:
             self._build_prefix()
         P, B = self._prefix, self.B
-        x = self._normalized(frames_a, frames_b, P)
-        y1 = torch.nn.functional.conv2d(x, P["w1"], None, 2, 3)
-        P["c1"].load_nchw(y1, 0, 1.0, ig.LEAKY, P["b1"])                 # bias + LeakyReLU + split, one pass
+        self._conv1(P, frames_a, frames_b)
         P["conv2"]()
         P["conv3"]()
         M4, M8 = self.cat2.M, self.c3a_p.M
@@ -257,13 +285,16 @@ class FlowNetCHeadEngine:
     # ------------------------------------------------------------------------------------------------ windowed conv1-3
     def _build_window_prefix(self, wh: int, ww: int):
         """conv1-3 of both frames on the patch attack's prefix window (patch_attack.py `_forward_cone`: [2B, 3, wh, ww]) and
-        their data gradients.  conv2 / conv3 (5x5, stride 2: 92% of the window's FLOPs) and both of their data gradients run
-        on the igemm; conv1 (3 input channels) and its data gradient stay on torch / MIOpen, as in `prefix_full`."""
+        their data gradients, all on the igemm: conv2 / conv3 (5x5, stride 2: 92% of the window's FLOPs) as they are, conv1
+        (3 input channels) over the packed planes of the raw window stack (`_conv1_launch`), its data gradient with respect
+        to those planes followed by the unpacking.  `UFR_CONV1_IGEMM=0` keeps conv1 and its gradient on torch / MIOpen."""
         B2, dev = 2 * self.B, self.dev
         f32 = dict(dtype=torch.float32, device=dev)
         h2, w2, h4, w4, h8, w8 = wh // 2, ww // 2, wh // 4, ww // 4, wh // 8, ww // 8
         c1, c2, c3 = ig.Planes(B2, h2, w2, 2, dev), ig.Planes(B2, h4, w4, 4, dev), ig.Planes(B2, h8, w8, 8, dev)
         gz_c3, gz_c2 = ig.Planes(B2, h8, w8, 8, dev), ig.Planes(B2, h4, w4, 4, dev)
+        conv1_native = os.environ.get("UFR_CONV1_IGEMM", "1") != "0"
+        gz_c1, G_p = ig.Planes(B2, h2, w2, 2, dev), ig.GradSum(B2, h2 + 3, w2 + 2, 1, dev)
         G_gw2, G_c1 = ig.GradSum(B2, h4, w4, 4, dev), ig.GradSum(B2, h2, w2, 2, dev)   # G_gw2: the conv2 tap's window gradient
                                                                                        # (first frames; second frames stay 0)
         bias = lambda n: self._conv(n).bias.detach().float().contiguous()
@@ -273,8 +304,12 @@ class FlowNetCHeadEngine:
             # conv3's data gradient + the skip connection's gradient, x LeakyReLU'(conv2) -> conv2's gradient planes
             (ig.conv_backward_weights(self._conv("conv3").weight, 2, 2), gz_c3, (h8, w8), (h4, w4),
              dict(add=G_gw2, mask=c2, out_planes=gz_c2)),
-            (ig.conv_backward_weights(self._conv("conv2").weight, 2, 2), gz_c2, (h4, w4), (h2, w2), dict(out_f32=G_c1)),
+            (ig.conv_backward_weights(self._conv("conv2").weight, 2, 2), gz_c2, (h4, w4), (h2, w2),
+             dict(out_planes=gz_c1, mask=c1) if conv1_native else dict(out_f32=G_c1)),
         ]
+        if conv1_native:                         # conv1's data gradient with respect to the packed planes, then the unpacking
+            plans.append((ig.conv1_packed_backward_weights(self._conv("conv1").weight), gz_c1, (h2 + 3, w2 + 2), (h2 + 3, w2 + 2),
+                          dict(out_f32=G_p)))
         sized = []
         for wi, x, rows, out_hw, kw in plans:
             ktiles = max(len(t) for _, _, t in wi.phases) * wi.KC
@@ -283,12 +318,15 @@ class FlowNetCHeadEngine:
         ws = torch.empty(need, **f32)
         launches = [ig.make_launch(wi, x, 0, rows, out_hw, splitk=S, ws=ws if S > 1 else None, **kw)
                     for (wi, x, rows, out_hw, kw), S in zip(plans, sized)]
-        wis = {k + "_wi": p[0] for k, p in zip(("conv2", "conv3", "conv3_bwd", "conv2_bwd"), plans)}
+        wis = {k + "_wi": p[0] for k, p in zip(("conv2", "conv3", "conv3_bwd", "conv2_bwd", "conv1_bwd"), plans)}
         self._wprefix = dict(**wis, hw=(wh, ww), c1=c1, c2=c2, c3=c3, gz_c3=gz_c3, gz_c2=gz_c2, G_gw2=G_gw2, G_c1=G_c1, ws=ws,
                              conv2=launches[0], conv3=launches[1], conv3_bwd=launches[2], conv2_bwd=launches[3],
                              b1=bias("conv1"), w1=self._conv("conv1").weight.detach(),
                              c2_nchw=torch.zeros(B2, 128, h4, w4, **f32), c3_nchw=torch.zeros(B2, 256, h8, w8, **f32),
                              g_c1=torch.zeros(B2, 64, h2, w2, **f32))
+        if conv1_native:
+            self._wprefix.update(conv1_bwd=launches[4], G_p=G_p, gxw=torch.zeros(B2, 3, wh, ww, **f32))
+        self._wprefix.update(self._conv1_launch(B2, wh, ww, c1))
 
     def window_prefix_forward(self, xw: torch.Tensor, win: torch.Tensor, m2: int, m3: int):
         """conv1-3 of the window stack `xw` [2B, 3, wh, ww] (raw frames; first frames, then second frames), patched into the
@@ -299,9 +337,7 @@ class FlowNetCHeadEngine:
         if P is None or P["hw"] != (wh, ww):
             self._build_window_prefix(wh, ww)
             P = self._wprefix
-        x = self._normalized(xw.detach(), None, P)
-        y1 = torch.nn.functional.conv2d(x, P["w1"], None, 2, 3)
-        P["c1"].load_nchw(y1, 0, 1.0, ig.LEAKY, P["b1"])
+        self._conv1(P, xw.detach(), None)
         P["conv2"]()
         P["conv3"]()
         P["c2"].to_nchw(128, 0, out=P["c2_nchw"])                         # (the scatter kernels take NCHW windows)
@@ -332,6 +368,10 @@ class FlowNetCHeadEngine:
                                                 ww // 8, ig.LEAKY, L.stream()), "window gradient -> planes")
         P["conv3_bwd"]()                         # + G_gw2, x LeakyReLU'(conv2) -> gz_c2 (epilogue)
         P["conv2_bwd"]()
+        if "conv1_bwd" in P:                     # conv2's data gradient wrote conv1's gradient planes (x LeakyReLU'(conv1))
+            P["conv1_bwd"]()                     # -> gradient of the packed planes -> gradient of the raw window stack
+            L.check(L.lib().ufr_conv1_unpack_grad(L.ptr(P["G_p"].t), L.ptr(P["gxw"]), 2 * B, wh, ww, L.stream()), "conv1 unpack")
+            return P["gxw"]
         g1 = P["G_c1"].to_nchw(64, 0, mask=P["c1"], out=P["g_c1"])       # LeakyReLU' of conv1's output fused
         return torch.nn.grad.conv2d_input((2 * B, 3, wh, ww), P["w1"], g1, stride=2, padding=3)
 
@@ -386,13 +426,17 @@ class FlowNetCHeadEngine:
                 rows.append((name, kind, tag, launch, wi.flops(d.B * d.Hr * d.Wr) / 1e9))
         F = self._prefix
         if F is not None:                      # full-frame conv2 / conv3 of both frames, once per attack() call
-            for name, key in (("conv2", "conv2"), ("conv3", "conv3")):
+            for name, key in (("conv1", "conv1"), ("conv2", "conv2"), ("conv3", "conv3")):
+                if key not in F:
+                    continue
                 d = F[key].desc
                 rows.append((name, "fwd", "prefix", F[key], F[key + "_wi"].flops(d.B * d.Hr * d.Wr) / 1e9))
         P = getattr(self, "_wprefix", None)
         if P is not None:                      # conv2 / conv3 of the attack's prefix window (every iteration)
-            for name, kind, key in (("conv2", "fwd", "conv2"), ("conv3", "fwd", "conv3"), ("conv3", "bwd", "conv3_bwd"),
-                                    ("conv2", "bwd", "conv2_bwd")):
+            for name, kind, key in (("conv1", "fwd", "conv1"), ("conv2", "fwd", "conv2"), ("conv3", "fwd", "conv3"),
+                                    ("conv3", "bwd", "conv3_bwd"), ("conv2", "bwd", "conv2_bwd"), ("conv1", "bwd", "conv1_bwd")):
+                if key not in P:
+                    continue
                 d = P[key].desc
                 rows.append((name, kind, "window", P[key], P[key + "_wi"].flops(d.B * d.Hr * d.Wr) / 1e9))
         return rows

@@ -143,6 +143,51 @@ def conv_forward_weights(weight: torch.Tensor, stride: int, padding: int) -> Wei
     return WeightImage(planes, offsets, [(0, 0, taps)], N, npad, KC, dict(in_s=stride, out_s=1), cr)
 
 
+def conv1_packed_weights(weight: torch.Tensor) -> WeightImage:
+    """Conv2d(3, N, 7, 2, 3) weight [N,3,7,7] -> the 8-tap stride-1 launch over the PACKED planes of `ufr_conv1_pack_planes`
+    (csrc/igemm.hip): tap (a, b2) reads packed pixel (Y + a, X + 2 b2), a in 0..3, b2 in 0..1; its chunk holds channel
+    j*12 + (c*2 + p)*2 + q = frame[c, 2 (Y + a - 2) + p, 2 (X + 2 b2 - 2 + j) + q], i.e. kernel tap (2a - 1 + p, 4 b2 - 1 + 2j + q)."""
+    N, Cn, k, _ = weight.shape
+    if (Cn, k) != (3, 7):
+        raise ValueError("conv1_packed_weights: Conv2d(3, N, 7, 2, 3) only")
+    w = weight.detach().float()
+    mat = torch.zeros(N, 8, 32, dtype=torch.float32, device=weight.device)
+    for a in range(4):
+        for b2 in range(2):
+            for j in range(2):
+                for c in range(3):
+                    for p in range(2):
+                        for q in range(2):
+                            ky, kx = 2 * a - 1 + p, 4 * b2 - 1 + 2 * j + q
+                            if 0 <= ky < 7 and 0 <= kx < 7:
+                                mat[:, a * 2 + b2, j * 12 + (c * 2 + p) * 2 + q] = w[:, c, ky, kx]
+    taps = [(a, 2 * b2) for a in range(4) for b2 in range(2)]
+    planes, offsets, n, npad, KC, _ = _pack([mat], weight.device)
+    return WeightImage(planes, offsets, [(0, 0, taps)], n, npad, KC, dict(in_s=1, out_s=1), C=147.0 / 8.0)   # flops(): 147 real taps x channels
+
+
+def conv1_packed_backward_weights(weight: torch.Tensor) -> WeightImage:
+    """Data gradient of `conv1_packed_weights`' launch with respect to the PACKED planes: rows = the packed grid
+    (H/2 + 3, W/2 + 2), gP(yp, xp)[n] = sum_t W_t[o, n] gy(yp - a_t, xp - 2 b2_t)[o]; N = 24 packed channels."""
+    N, Cn, k, _ = weight.shape
+    if (Cn, k) != (3, 7):
+        raise ValueError("conv1_packed_backward_weights: Conv2d(3, N, 7, 2, 3) only")
+    w = weight.detach().float()
+    mat = torch.zeros(24, 8, N, dtype=torch.float32, device=weight.device)
+    for a in range(4):
+        for b2 in range(2):
+            for j in range(2):
+                for c in range(3):
+                    for p in range(2):
+                        for q in range(2):
+                            ky, kx = 2 * a - 1 + p, 4 * b2 - 1 + 2 * j + q
+                            if 0 <= ky < 7 and 0 <= kx < 7:
+                                mat[j * 12 + (c * 2 + p) * 2 + q, a * 2 + b2, :] = w[:, c, ky, kx]
+    taps = [(-a, -2 * b2) for a in range(4) for b2 in range(2)]
+    planes, offsets, n, npad, KC, _ = _pack([mat], weight.device)
+    return WeightImage(planes, offsets, [(0, 0, taps)], n, npad, KC, dict(in_s=1, out_s=1), C=147.0 * N / (8.0 * 24.0))
+
+
 def conv_backward_weights(weight: torch.Tensor, stride: int, padding: int) -> WeightImage:
     """Data gradient of Conv2d(weight [N,C,k,k], stride, padding): gx[C] from gy[N] (rows = the gy grid)."""
     N, Cn, k, _ = weight.shape
