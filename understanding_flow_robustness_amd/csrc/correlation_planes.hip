@@ -197,6 +197,168 @@ __global__ __launch_bounds__(64 * NW) void corr_fwd_planes_kernel(const __bf16* 
   }
 }
 
+// ---- the same kernel with the reduction split over TWO waves per tile --------------------------------------------------
+// 2 NW waves: wave (tile tw, half kh) keeps the f1 fragments of chunks 4 kh .. 4 kh + 3 (48 VGPRs instead of 96) and a
+// stage carries one chunk of EACH half, so a displacement row takes 4 barriers instead of 8 with the same 18 MFMAs per
+// wave and stage; the upper half's accumulators cross to the lower half's wave through LDS once per row.  With one
+// workgroup per CU this doubles the waves that share its issue slots (3,3,2,2 per SIMD instead of 2,1,1,1): 0.356 -> 0.325 ms
+// at 8 pairs.  (Five buffers / four stages in flight on the single-wave form measured SLOWER, 0.417 ms: the kernel is bound
+// by instruction issue and LDS traffic per stage, not by bytes in flight.)
+template <int NW>
+constexpr int corr_planes_k2_lds_bytes() { return 3 * 2 * 3 * (16 * NW + 32) * 32 * 2 + NW * 16 * OT * 4 + NW * 64 * 12 * 4; }
+
+template <int NW>
+__global__ __launch_bounds__(128 * NW) void corr_fwd_planes_k2_kernel(const __bf16* __restrict__ f1, const __bf16* __restrict__ f2,
+                                                                      long in_plane_stride, __bf16* __restrict__ out,
+                                                                      long out_plane_stride, int out_chunk0, int B, int H, int W,
+                                                                      float scale, float slope) {
+  constexpr int NJ = 16 * NW + 32, NRB = NJ / 16;
+  constexpr int PLANE = NJ * 32, HBUF = 3 * PLANE, BUF = 2 * HBUF;        // elements: plane, one half's chunk, a stage
+  constexpr int KH = KCH / 2;                                             // chunks per half
+  extern __shared__ __attribute__((aligned(16))) unsigned char corr_lds[];
+  __bf16* lds = reinterpret_cast<__bf16*>(corr_lds);                     // [3 buffers][2 halves][3 planes][NJ * 32]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kh = wave >= NW ? 1 : 0, tw = wave - kh * NW;
+  float* otile = reinterpret_cast<float*>(corr_lds + 3 * BUF * 2) + tw * 16 * OT;
+  float* part = reinterpret_cast<float*>(corr_lds + 3 * BUF * 2 + NW * 16 * OT * 4) + (tw * 64 + lane) * 12;
+  const int nblk = gridDim.x * gridDim.y * gridDim.z;                    // XCD-contiguous rows: see corr_fwd_planes_kernel
+  int item = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  if ((nblk & 7) == 0) item = (item & 7) * (nblk >> 3) + (item >> 3);
+  const int bx = item % gridDim.x, par = (item / gridDim.x) % gridDim.y, by = item / (gridDim.x * gridDim.y);
+  const int b = by / H, y = by - b * H;
+  const int i0 = bx * 16 * NW;
+  const long M = (long)B * H * W;
+  const long rowbase = ((long)b * H + y) * W;
+  const int ai = i0 + 16 * tw + (lane & 15), ax = 2 * ai + par;
+  const bool a_ok = ax < W;
+  const __bf16* zero = reinterpret_cast<const __bf16*>(corr_zero_page);
+  bf16x8 fa[KH][3];
+#pragma unroll
+  for (int i = 0; i < KH; ++i)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const __bf16* src = a_ok ? f1 + p * in_plane_stride + ((long)(kh * KH + i) * M + rowbase + ax) * 32 + (lane >> 4) * 8 : zero;
+      fa[i][p] = *reinterpret_cast<const bf16x8*>(src);
+    }
+  // staging plan: 2 NRB (half, row block) items per plane over 2 NW waves: item = wave + it * 2 NW
+  const int srow_in = lane >> 2, spiece = lane & 3;
+  int voff[2], sdst[2], shalf[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int itm = wave + it * 2 * NW, h = itm >= NRB ? 1 : 0, rb = itm - h * NRB, r = rb * 16 + srow_in;
+    const int j = i0 - 16 + r, xs = 2 * j + par;
+    voff[it] = (itm < 2 * NRB && j >= 0 && xs < W) ? xs * 32 + ((spiece ^ ((r >> 1) & 3)) << 3) : -1;
+    sdst[it] = h * HBUF + rb * 16 * 32;
+    shalf[it] = h;
+  }
+  const bool two = wave + 2 * NW < 2 * NRB;      // uniform: 6 (else 3) DMA instructions per stage
+  const int frow = lane & 15;
+  const int foff = frow * 32 + (((lane >> 4) ^ ((frow >> 1) & 3)) << 3);
+  auto stage = [&](int dy, int sl, int buf) {    // chunks sl and KH + sl of source row y + 2 (dy - R) -> buffer `buf`
+    const long rowoff = ((long)b * H + (y + 2 * (dy - R))) * W;
+    __bf16* dst = lds + buf * BUF;
+    {
+      const __bf16* sbase = f2 + ((long)(shalf[0] * KH + sl) * M + rowoff) * 32;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) glds16(voff[0] >= 0 ? sbase + p * in_plane_stride + voff[0] : zero, dst + sdst[0] + p * PLANE);
+    }
+    if (two) {
+      const __bf16* sbase = f2 + ((long)(shalf[1] * KH + sl) * M + rowoff) * 32;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) glds16(voff[1] >= 0 ? sbase + p * in_plane_stride + voff[1] : zero, dst + sdst[1] + p * PLANE);
+    }
+  };
+  const int rot = (P - (y >> 1) % P) % P;        // rotated displacement order: see corr_fwd_planes_kernel
+  auto dy_at = [&](int t) { const int d = t + rot; return d >= P ? d - P : d; };
+  auto row_ok = [&](int dy) { const int y2 = y + 2 * (dy - R); return y2 >= 0 && y2 < H; };
+  auto next_valid = [&](int t) { do { ++t; } while (t < P && !row_ok(dy_at(t))); return t; };
+  auto write_row = [&](int d_row, const f32x4 (&acc)[3], bool zeros) {
+    if (!zeros) {
+#pragma unroll
+      for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int il = (lane >> 4) * 4 + rg;
+          const int dx = 16 * tt - 16 + (lane & 15) - il + R;
+          if (dx >= 0 && dx < P) otile[il * OT + dx] = acc[tt][rg];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int e = lane + 64 * q;
+      const int il = e / P, dx = e - il * P;
+      const int x = 2 * (i0 + 16 * tw + il) + par;
+      if (e < 16 * P && x < W) {
+        float v = zeros ? 0.f : otile[il * OT + dx] * scale;
+        v = v > 0.f ? v : v * slope;
+        __bf16 p0, p1, p2;
+        split3(v, p0, p1, p2);
+        const int d = d_row * P + dx;
+        __bf16* o = out + ((long)(out_chunk0 + (d >> 5)) * M + rowbase + x) * 32 + (d & 31);
+        o[0] = p0;
+        o[out_plane_stride] = p1;
+        o[2 * out_plane_stride] = p2;
+      }
+    }
+  };
+  const f32x4 zacc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  if (kh == 0)
+    for (int d0 = 0; d0 < P; ++d0)
+      if (!row_ok(d0)) write_row(d0, zacc, true);
+  int t = next_valid(-1);
+  if (t >= P) return;
+  int cur = 0;
+  stage(dy_at(t), 0, 0);
+  stage(dy_at(t), 1, 1);
+  if (two) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  while (t < P) {
+    const int dy = dy_at(t), tn = next_valid(t);
+    f32x4 acc[3];
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sl = 0; sl < KH; ++sl) {            // unrolled: fa[] indexed statically
+      const bool ahead = sl + 2 < KH || tn < P;  // the stage two ahead: (dy, sl + 2) or (next valid row, sl + 2 - KH)
+      const int nxt = cur == 0 ? 2 : cur - 1;
+      if (ahead) stage(sl + 2 < KH ? dy : dy_at(tn), (sl + 2) & (KH - 1), nxt);
+      bf16x8 fb[3][3];
+      const __bf16* bsrc = lds + cur * BUF + kh * HBUF + tw * 16 * 32 + foff;
+#pragma unroll
+      for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) fb[tt][p] = *reinterpret_cast<const bf16x8*>(bsrc + p * PLANE + tt * 16 * 32);
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt)
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[sl][PROD_A[q]], fb[tt][PROD_B[q]], acc[tt], 0, 0, 0);
+      if (sl == KH - 1 && kh == 1) {              // upper half: hand the partial sums to the tile's lower-half wave
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) *reinterpret_cast<f32x4*>(part + 4 * tt) = acc[tt];
+      }
+      if (ahead) {
+        if (two) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      cur = cur == 2 ? 0 : cur + 1;
+      if (sl == KH - 1 && kh == 0) {              // lower half: add, then the row leaves (its stores precede the next DMA issue)
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+          const f32x4 o = *reinterpret_cast<const f32x4*>(part + 4 * tt);
+          acc[tt][0] += o[0]; acc[tt][1] += o[1]; acc[tt][2] += o[2]; acc[tt][3] += o[3];
+        }
+        write_row(dy, acc, false);
+      }
+    }
+    t = tn;
+  }
+}
+
 template <int NW>
 int launch_corr_planes(const __bf16* a, const __bf16* b, long in_plane_stride, __bf16* o, long out_plane_stride, int out_chunk0,
                        int B, int H, int W, int ni, float scale, float slope, hipStream_t st) {
@@ -206,6 +368,19 @@ int launch_corr_planes(const __bf16* a, const __bf16* b, long in_plane_stride, _
                                        hipFuncAttributeMaxDynamicSharedMemorySize, corr_planes_lds_bytes<NW>());
     if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "correlation (planes): %s", hipGetErrorString(e));
     raised = true;
+  }
+  static const bool k2 = [] { const char* e = getenv("UFR_CORR_PLANES_K2"); return !(e && e[0] == '0'); }();
+  if (k2) {                                       // reduction split over two waves per tile (default)
+    static bool raised2 = false;
+    if (!raised2) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_fwd_planes_k2_kernel<NW>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, corr_planes_k2_lds_bytes<NW>());
+      if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "correlation (planes): %s", hipGetErrorString(e));
+      raised2 = true;
+    }
+    corr_fwd_planes_k2_kernel<NW><<<dim3(ufr::ceil_div(ni, 16 * NW), 2, B * H), 128 * NW, corr_planes_k2_lds_bytes<NW>(), st>>>(
+        a, b, in_plane_stride, o, out_plane_stride, out_chunk0, B, H, W, scale, slope);
+    return UFR_OK;
   }
   corr_fwd_planes_kernel<NW><<<dim3(ufr::ceil_div(ni, 16 * NW), 2, B * H), 64 * NW, corr_planes_lds_bytes<NW>(), st>>>(
       a, b, in_plane_stride, o, out_plane_stride, out_chunk0, B, H, W, scale, slope);
