@@ -168,7 +168,7 @@ def kernel_rooflines(step, device, max_count):
             h8, w8, 21, 2, 1.0 / 256.0, ig.LEAKY, L.stream())), 10)
         tf = CORR_FWD["gflop"] * B / t_f
         nbytes = B * h8 * w8 * (2 * 256 + 441) * 6
-        ks.append(dict(kernel="corr_fwd_planes_kernel<5> (21x21 cost volume, / C, LeakyReLU, planes in / out)", ms=round(t_f, 4), bound="mfma",
+        ks.append(dict(kernel="corr_fwd_planes_k2_kernel<5> (21x21 cost volume, / C, LeakyReLU, planes in / out)", ms=round(t_f, 4), bound="mfma",
                        achieved=round(tf, 2), peak=PEAK_FP32_TFLOPS, unit="TFLOP/s", frac=round(tf / PEAK_FP32_TFLOPS, 4),
                        hbm_gbs=round(nbytes / t_f / 1e6, 1), traffic=_pmc("r2_corr_planes_traffic.json").get("traffic_bytes"),
                        algorithmic_bytes=int(nbytes),

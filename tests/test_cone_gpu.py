@@ -351,3 +351,31 @@ def test_pwc_windowed_pyramid_prefix_equals_full_frame_step():
             assert err <= 1e-4 * upd + 1e-6, f"one iteration: {err:.3e} of {upd:.3e}"
         else:
             _same_update(pf, pc, patch, mask, "PWC-Net, two iterations")
+
+
+def test_attack_notices_new_weights(net):
+    """A cached step (captured graphs, pre-packed engine weights) must not survive a change of the network's weights:
+    after scaling one head convolution in place, attack() gives the result of a freshly built step, not the old one."""
+    import copy
+    from understanding_flow_robustness_amd.patch_attack import _STEP_CACHE_ATTR, attack
+    z = load_golden("attack_flownetc_cone_192x320")
+    args = Namespace(flownet="FlowNetC", l2=False, alpha=0.0, lr=1.0e6, max_count=2)      # saturating step: clamped signs
+    run = lambda n: attack(n, t(z["tgt"], DEV), None, t(z["ref"], DEV), t(z["mid_patch0"], DEV).clone(), t(z["mid_mask"], DEV),
+                           t(z["mid_patch0"], DEV), t(z["target"], DEV), None, args=args)[3]
+    engines = net.__dict__.pop("_ufr_head_engines", None)
+    steps = net.__dict__.pop(_STEP_CACHE_ATTR, None)
+    net2 = copy.deepcopy(net)
+    if engines is not None:
+        net.__dict__["_ufr_head_engines"] = engines
+    if steps is not None:
+        net.__dict__[_STEP_CACHE_ATTR] = steps
+    p_before = run(net2).clone()
+    with torch.no_grad():
+        net2.conv4_1[0].weight.mul_(-1.0)
+    p_after = run(net2).clone()
+    held = {k: net2.__dict__.pop(k) for k in ("_ufr_head_engines", _STEP_CACHE_ATTR) if k in net2.__dict__}
+    fresh = copy.deepcopy(net2)                  # (captured graphs and ctypes descriptors cannot be copied)
+    net2.__dict__.update(held)
+    p_fresh = run(fresh)
+    assert float((p_after - p_before).abs().max()) > 1e-3, "the weight change did not reach the attack"
+    assert float((p_after - p_fresh).abs().max()) <= 1e-6 * max(1.0, float(p_fresh.abs().max()))

@@ -175,9 +175,15 @@ def test_two_channel_layers_vs_torch(B, Cin, H, W):
     xo = x.clone().requires_grad_(True)
     out = flow_head(xo, conv)
     assert out.grad_fn is not None and type(out.grad_fn).__name__.startswith("_Conv3x3C2"), "fast path not taken"
-    assert_close(out, ref, rtol=1e-5, atol_scale=1e-6, what="predict_flow forward")
+    # both are fp32 sums over up to 9 x 1026 terms in different orders: judge them against a float64 evaluation (the
+    # kernel may be no further from it than 3x MIOpen's own error, or 2e-6 of the largest value)
+    x64 = x.double().requires_grad_(True)
+    ref64 = torch.nn.functional.conv2d(x64, conv.weight.double(), conv.bias.double(), 1, 1)
+    (g64,) = torch.autograd.grad(ref64, x64, gy.double())
+    rel = lambda a, b: float((a.double() - b).abs().max()) / float(b.abs().max())
+    assert rel(out, ref64.detach()) <= max(3 * rel(ref, ref64.detach()), 2e-6), (rel(out, ref64.detach()), rel(ref, ref64.detach()))
     (g_out,) = torch.autograd.grad(out, xo, gy)
-    assert_close(g_out, g_ref, rtol=1e-5, atol_scale=1e-6, what="predict_flow data gradient")
+    assert rel(g_out, g64) <= max(3 * rel(g_ref, g64), 2e-6), (rel(g_out, g64), rel(g_ref, g64))
     again = flow_head(x, conv)
     assert torch.equal(again, out.detach()), "channel-split reduction must be deterministic"
     for bias in (True, False):

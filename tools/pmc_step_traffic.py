@@ -31,7 +31,7 @@ def per_iteration(path, counter, iters):
 
 
 # kernels launched once per iteration whose per-launch traffic bench.py quotes beside its live timing
-SINGLE = {"corr_fwd_planes_kernel": "r2_corr_planes_traffic.json", "corr_bwd_window_mfma_kernel": "r2_corr_window_traffic.json"}
+SINGLE = {"corr_fwd_planes": "r2_corr_planes_traffic.json", "corr_bwd_window_mfma_kernel": "r2_corr_window_traffic.json"}
 
 
 def main(fetch_csv, write_csv, iters, igemm_out=None, single_dir=None):

@@ -613,13 +613,21 @@ class _EngineHead(torch.autograd.Function):
         return g2a, g3a, g3b, None, None
 
 
+def _weights_stamp(net):
+    """(storage address, in-place version) of every parameter: the engine packs the weights once, so it must notice a
+    `load_state_dict` / optimiser step on the module it was built from."""
+    return tuple((p.data_ptr(), p._version) for p in net.parameters())
+
+
 def get_engine(net, B: int, H: int, W: int, device) -> FlowNetCHeadEngine:
-    """One engine per batch / frame size, cached on the module."""
+    """One engine per batch / frame size, cached on the module; rebuilt when the module's weights have changed since."""
     key = (int(B), int(H), int(W), str(torch.device(device)))
     cache = net.__dict__.setdefault("_ufr_head_engines", {})
+    stamp = _weights_stamp(net)
     eng = cache.get(key)
-    if eng is None:
+    if eng is None or eng.weights_stamp != stamp:
         eng = cache[key] = FlowNetCHeadEngine(net, B, H, W, device)
+        eng.weights_stamp = stamp
     return eng
 
 

@@ -539,9 +539,13 @@ def attack(flow_net, tgt_img_var, ref_past_img_var, ref_future_img_var, patch_va
            args.flownet, bool(use_graph))
     cache = flow_net.__dict__.setdefault(_STEP_CACHE_ATTR, {})
     step = cache.get(key)
-    if step is None:
+    # a cached step holds captured graphs and (FlowNetC) pre-packed weights: a load_state_dict / in-place update of the
+    # network since then makes it stale
+    stamp = tuple((p.data_ptr(), p._version) for p in flow_net.parameters())
+    if step is None or step.weights_stamp != stamp:
         step = cache[key] = PatchAttackStep(flow_net, args, B, H, W, device=tgt_img_var.device,
                                             shared_patch=shared, use_graph=use_graph, patch_hw=patch_hw)
+        step.weights_stamp = stamp
     step.load(tgt_img_var, ref_future_img_var, patch_var, mask_var, patch_init_var, target_var,
               prefix_features=prefix_features, origins=origins)
     step.run(getattr(args, "max_count", 2))
