@@ -404,8 +404,9 @@ int ufr_host_png_unfilter(const unsigned char* data, unsigned char* out, int row
  * Epilogue: act = 1: LeakyReLU(acc + bias) (forward); act = 0: (acc + add) * LeakyReLU'(mask) with `add` an fp32
  * chunk-major tensor and `mask` plane 0 of the activation this gradient belongs to (either may be NULL).  The result
  * goes to out_planes (at chunk out_chunk0 of a buffer whose planes are out_plane_stride elements apart) and / or
- * out_f32.  splitk > 1: fp32 slabs in `ws` ([nphase*splitk][B*Hr*Wr][Npad]), added in a fixed order by a second
- * kernel (no atomics: bit-reproducible). */
+ * out_f32.  splitk > 1: the phase with the most taps is cut into `splitk` slices of K, the others into proportionally fewer
+ * slices of the same length; fp32 slabs in `ws` (at most [nphase*splitk][B*Hr*Wr][Npad]), added in a fixed order by a
+ * second kernel (no atomics: bit-reproducible). */
 #define UFR_IGEMM_MAX_TAPS 25
 typedef struct {
   int ntaps, oy0, ox0;

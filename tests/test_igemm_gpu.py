@@ -126,6 +126,30 @@ def test_data_gradient_with_addend_and_mask(B, Cin, Cout, H, W, k, s, p):
     _close(got, want * torch.where(act > 0, 1.0, 0.1).double() * 0.25, "gradient sum -> nchw")
 
 
+@pytest.mark.parametrize("k,p,S", [(3, 1, 2), (3, 1, 4), (5, 2, 3), (5, 2, 9)])
+def test_stride2_data_gradient_with_per_phase_slices(k, p, S):
+    """A stride-2 data gradient's four phases reduce over unequal numbers of taps (1, 2, 2, 4 for k = 3; 4, 6, 6, 9 for
+    k = 5): with split-K the longest phase gets S slices, the others proportionally fewer of the same length
+    (csrc/igemm.hip: per_k / sk / zoff); the result equals the unsplit launch bit for bit when no phase is split, and the
+    float64 gradient otherwise; two runs are bit-identical (fixed-order reduction)."""
+    ig = _mods()
+    B, Cin, Cout, H, W = 2, 64, 96, 24, 40
+    Ho, Wo = H // 2, W // 2
+    w, gy = _rand(Cout, Cin, k, k, seed=2, scale=0.05), _rand(B, Cout, Ho, Wo, seed=4)
+    x0 = torch.zeros(B, Cin, H, W, device=DEV, dtype=torch.float64, requires_grad=True)
+    (want,) = torch.autograd.grad(F.conv2d(x0, w.double(), None, 2, p), x0, gy.double())
+    gyp = ig.Planes(B, Ho, Wo, ig.pad32(Cout) // 32, DEV).load_nchw(gy)
+    wi = ig.conv_backward_weights(w, 2, p)
+    ws = torch.empty(len(wi.phases) * S * B * Ho * Wo * wi.Npad, dtype=torch.float32, device=DEV)
+    outs = []
+    for _ in range(2):
+        out = ig.GradSum(B, H, W, ig.pad32(Cin) // 32, DEV)
+        ig.make_launch(wi, gyp, 0, (Ho, Wo), (H, W), out_f32=out, splitk=S, ws=ws)()
+        outs.append(out.to_nchw(Cin))
+    assert torch.equal(outs[0], outs[1])
+    _close(outs[0], want, f"stride-2 data gradient, k={k}, {S} slices")
+
+
 def test_deconv_data_gradient():
     ig = _mods()
     B, Cin, Cout, H, W = 2, 96, 64, 12, 20

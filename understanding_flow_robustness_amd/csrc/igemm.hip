@@ -174,7 +174,8 @@ struct Args {
   RowGeom g;
   Epilogue e;
   int nphase, splitk, xcd;
-  float* ws;                         // split-K slabs [nphase*splitk][M][Npad]
+  int per_k, sk[4], zoff[4];         // K tiles per slice; slices of each phase; first slice (z) of each phase
+  float* ws;                         // split-K slabs [sum of sk][M][Npad]
   Phase ph[4];
 };
 
@@ -258,10 +259,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   int tx, ty, z;
   xcd_tile(a.xcd, tx, ty, z);
   const int bm = ty * BM, bn = tx * BN_;
-  const int phase = z / a.splitk, ks = z - phase * a.splitk;
+  int phase = 0;                                     // z -> (phase, slice): phases with fewer taps have fewer slices
+#pragma unroll
+  for (int p = 1; p < 4; ++p)
+    if (p < a.nphase && z >= a.zoff[p]) phase = p;
+  const int ks = z - a.zoff[phase];
   const Phase& ph = a.ph[phase];
   const int KC = a.KC, KT = ph.ntaps * KC;
-  const int per = (KT + a.splitk - 1) / a.splitk, kt0 = ks * per, kt1 = min(KT, kt0 + per);
+  const int kt0 = ks * a.per_k, kt1 = min(KT, kt0 + a.per_k);
   const long Min = (long)a.g.B * a.Hi * a.Wi;
   const long cstride = Min * 32;                     // elements between consecutive channel chunks of the input
 
@@ -400,10 +405,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   int tx, ty, z;
   xcd_tile(a.xcd, tx, ty, z);
   const int bm = ty * BM, bn = tx * BN_;
-  const int phase = z / a.splitk, ks = z - phase * a.splitk;
+  int phase = 0;                                     // z -> (phase, slice): phases with fewer taps have fewer slices
+#pragma unroll
+  for (int p = 1; p < 4; ++p)
+    if (p < a.nphase && z >= a.zoff[p]) phase = p;
+  const int ks = z - a.zoff[phase];
   const Phase& ph = a.ph[phase];
   const int KC = a.KC, KT = ph.ntaps * KC;
-  const int per = (KT + a.splitk - 1) / a.splitk, kt0 = ks * per, kt1 = min(KT, kt0 + per);
+  const int kt0 = ks * a.per_k, kt1 = min(KT, kt0 + a.per_k);
   const long Min = (long)a.g.B * a.Hi * a.Wi;
   const long cstride = Min * 32;
 
@@ -511,9 +520,9 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const Args a) {
     const int row = (int)(rest % a.g.M), phase = (int)(rest / a.g.M);
     if (n0 >= a.e.Nchunks32 * 32) continue;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const float* src = a.ws + ((long)(phase * a.splitk) * a.g.M + row) * a.Npad + n0;
+    const float* src = a.ws + ((long)a.zoff[phase] * a.g.M + row) * a.Npad + n0;
     const long sstride = (long)a.g.M * a.Npad;
-    for (int s = 0; s < a.splitk; ++s) {
+    for (int s = 0; s < a.sk[phase]; ++s) {
       const float4 lo = *reinterpret_cast<const float4*>(src + s * sstride), hi = *reinterpret_cast<const float4*>(src + s * sstride + 4);
       v[0] += lo.x; v[1] += lo.y; v[2] += lo.z; v[3] += lo.w; v[4] += hi.x; v[5] += hi.y; v[6] += hi.z; v[7] += hi.w;
     }
@@ -797,9 +806,19 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
       a.ph[z].dx[t] = t < p.ntaps ? p.dx[t] : 0;
     }
   }
+  // split-K: `splitk` slices for the phase with the most taps, proportionally fewer for the others (the phases of a stride-2
+  // data gradient reduce over 1, 2, 2 and 4 taps: equal slices per phase would leave the workgroups 4x apart in length)
+  int ktmax = 0, nz = 0;
+  for (int z = 0; z < d->nphase; ++z) ktmax = a.ph[z].ntaps * d->KC > ktmax ? a.ph[z].ntaps * d->KC : ktmax;
+  a.per_k = (ktmax + d->splitk - 1) / d->splitk;
+  for (int z = 0; z < 4; ++z) {
+    a.zoff[z] = nz;
+    a.sk[z] = z < d->nphase ? (a.ph[z].ntaps * d->KC + a.per_k - 1) / a.per_k : 0;
+    nz += a.sk[z];
+  }
   hipStream_t st = ufr::as_stream(stream);
   const int bn = d->Npad % BN == 0 ? BN : 64;        // 64-column tiles where a 128-column tile would be mostly padding
-  const dim3 grid(d->Npad / bn, (unsigned)((M + BM - 1) / BM), d->nphase * d->splitk);
+  const dim3 grid(d->Npad / bn, (unsigned)((M + BM - 1) / BM), nz);
   static const int default_variant = [] { const char* e = getenv("UFR_IGEMM"); return e && e[0] == 'r' ? 1 : 2; }();
   const int variant = d->variant ? d->variant : default_variant;        // 1 = register-staged, 2 = LDS-DMA staging
   UFR_REQUIRE(variant == 1 || variant == 2, "igemm: unknown kernel variant %d", variant);

@@ -105,8 +105,8 @@ class FlowNetCHeadEngine:
 
         def plan(wi, x, in_chunk0, rows, out_hw, **kw):
             M = B * rows[0] * rows[1]
-            ktiles = max(len(t) for _, _, t in wi.phases) * wi.KC
-            S = ig.splitk_for(M, wi.Npad, ktiles, len(wi.phases))
+            pk = [len(t) * wi.KC for _, _, t in wi.phases]
+            S = ig.splitk_for(M, wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk)
             plans.append((wi, x, in_chunk0, rows, out_hw, S, kw))
             return len(plans) - 1
 
@@ -312,8 +312,8 @@ class FlowNetCHeadEngine:
                           dict(out_f32=G_p)))
         sized = []
         for wi, x, rows, out_hw, kw in plans:
-            ktiles = max(len(t) for _, _, t in wi.phases) * wi.KC
-            sized.append(ig.splitk_for(B2 * rows[0] * rows[1], wi.Npad, ktiles, len(wi.phases)))
+            pk = [len(t) * wi.KC for _, _, t in wi.phases]
+            sized.append(ig.splitk_for(B2 * rows[0] * rows[1], wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk))
         need = max([len(wi.phases) * S * B2 * rows[0] * rows[1] * wi.Npad for (wi, _, rows, _, _), S in zip(plans, sized) if S > 1] + [1])
         ws = torch.empty(need, **f32)
         launches = [ig.make_launch(wi, x, 0, rows, out_hw, splitk=S, ws=ws if S > 1 else None, **kw)
@@ -403,8 +403,8 @@ class FlowNetCHeadEngine:
             if ls_in is not None:
                 extra["in_band"] = (origin, 8, ls_in, band.width // ls_in)
             M = self.B * rows_b[0] * rows_b[1]
-            ktiles = max(len(t) for _, _, t in wi.phases) * wi.KC
-            Sb = ig.splitk_for(M, wi.Npad, ktiles, len(wi.phases))
+            pk = [len(t) * wi.KC for _, _, t in wi.phases]
+            Sb = ig.splitk_for(M, wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk)
             if len(wi.phases) * Sb * M * wi.Npad > self.ws.numel():
                 Sb = 1
             return ig.make_launch(wi, x, c0, rows_b, out_hw, splitk=Sb, ws=self.ws if Sb > 1 else None, **kw, **extra)

@@ -304,10 +304,26 @@ def make_launch(wi: WeightImage, x: Planes, in_chunk0: int, rows_hw, out_hw, *, 
     return Launch(d, keep)
 
 
-def splitk_for(M: int, Npad: int, ktiles: int, phases: int = 1, target: int = 768) -> int:
+def splitk_for(M: int, Npad: int, ktiles: int, phases: int = 1, target: int = 768, phase_ktiles=None) -> int:
     """Split the reduction until the launch has about `target` workgroups (3 per CU: the LDS-DMA kernel's occupancy),
-    keeping >= 16 K tiles per slice."""
-    tiles = -(-M // 128) * (Npad // (128 if Npad % 128 == 0 else 64)) * phases
+    keeping >= 16 K tiles per slice.  `phase_ktiles` (K tiles of every phase) switches to a small cost model when the
+    phases are unequal (stride-2 data gradients: 1, 2, 2 and 4 taps): `splitk` then counts the slices of the LONGEST
+    phase, the others get proportionally fewer (ufr_igemm), and the choice minimises rounds x (slice length + epilogue)."""
+    tiles_mn = -(-M // 128) * (Npad // (128 if Npad % 128 == 0 else 64))
+    if phase_ktiles is not None and len(set(phase_ktiles)) > 1:
+        best, best_cost = 1, None
+        s = 1
+        while s <= 16:
+            per = -(-max(phase_ktiles) // s)
+            if s > 1 and per < 8:
+                break
+            wgs = tiles_mn * sum(-(-k // per) for k in phase_ktiles)
+            cost = -(-wgs // target) * (per + 6) + (10 if s > 1 else 0)     # K steps; epilogue ~ 6, the reduce launch ~ 10
+            if best_cost is None or cost < best_cost:
+                best, best_cost = s, cost
+            s *= 2
+        return best
+    tiles = tiles_mn * phases
     s = 1
     while tiles * s * 2 <= target and ktiles // (s * 2) >= 16 and s < 32:
         s *= 2
