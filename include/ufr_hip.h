@@ -471,6 +471,14 @@ int ufr_window_gather_chunks(const float* src, float* dst, const int* win, int n
 int ufr_normalize_frames(const float* frames_a, const float* frames_b, float* out, int Ba, int Bb, int C, int H, int W,
                          const double* mean, ufr_stream_t stream);
 
+/* The incremental form of ufr_corr_forward_planes: recomputes only the columns within the correlation's reach (20 cells) of
+ * each sample's window (win[b*8 + 1] / level_stride, `win_cells` wide, at most 23) -- all rows, all 441 displacements; the
+ * other columns of `out_planes` keep their values.  Exact when the features changed inside the window only. */
+int ufr_corr_forward_planes_window(const void* f1_planes, const void* f2_planes, long in_plane_stride, void* out_planes,
+                                   long out_plane_stride, int out_chunk0, int B, int C, int H, int W, int patch,
+                                   int dilation_patch, float scale, float slope, const int* win, int level_stride,
+                                   int win_cells, ufr_stream_t stream);
+
 /* Both adjoints of FlowNetC's cost volume (correlation_cuda_kernel.cu:86-233; patch 21, dilation_patch 2, 256 channels) on
  * the cells of the prefix window, on the matrix cores (csrc/correlation_window_mfma.hip), fused with everything around it:
  * G = the engine's chunk-major float32 gradient sum of conv3_1's input (the cost volume's channels start at chunk

@@ -136,6 +136,7 @@ SIGNATURES = {
     "ufr_flow_head_planes_backward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "ufr_flow_up_planes_forward": [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp],
     "ufr_flow_up_planes_backward": [_vp, _i, _vp, _vp, _i, _i, _i, _vp],
+    "ufr_corr_forward_planes_window": [_vp, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _i, _i, _vp],
     "ufr_corr_forward_planes": [_vp, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp],
     "ufr_split_bf16x3": [_vp, _vp, _l, _vp],
     "ufr_gemm_split_nt": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],

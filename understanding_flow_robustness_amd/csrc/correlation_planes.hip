@@ -211,7 +211,11 @@ template <int NW>
 __global__ __launch_bounds__(128 * NW) void corr_fwd_planes_k2_kernel(const __bf16* __restrict__ f1, const __bf16* __restrict__ f2,
                                                                       long in_plane_stride, __bf16* __restrict__ out,
                                                                       long out_plane_stride, int out_chunk0, int B, int H, int W,
-                                                                      float scale, float slope) {
+                                                                      float scale, float slope, const int* __restrict__ win,
+                                                                      int win_div) {
+  // win != nullptr: only the 16 NW same-parity columns starting 20 cells left of the sample's window (win[b*8+1] / win_div)
+  // are recomputed -- the incremental forward of the attack: between iterations of a call the features change only inside
+  // the prefix window, so the volume changes only within the correlation's reach of it; grid.x = 1 then.
   constexpr int NJ = 16 * NW + 32, NRB = NJ / 16;
   constexpr int PLANE = NJ * 32, HBUF = 3 * PLANE, BUF = 2 * HBUF;        // elements: plane, one half's chunk, a stage
   constexpr int KH = KCH / 2;                                             // chunks per half
@@ -227,7 +231,8 @@ __global__ __launch_bounds__(128 * NW) void corr_fwd_planes_k2_kernel(const __bf
   if ((nblk & 7) == 0) item = (item & 7) * (nblk >> 3) + (item >> 3);
   const int bx = item % gridDim.x, par = (item / gridDim.x) % gridDim.y, by = item / (gridDim.x * gridDim.y);
   const int b = by / H, y = by - b * H;
-  const int i0 = bx * 16 * NW;
+  int i0 = bx * 16 * NW;
+  if (win) i0 = min(max((win[b * 8 + 1] / win_div - 2 * R) >> 1, 0), max((W + 1) / 2 - 16 * NW, 0));
   const long M = (long)B * H * W;
   const long rowbase = ((long)b * H + y) * W;
   const int ai = i0 + 16 * tw + (lane & 15), ax = 2 * ai + par;
@@ -361,7 +366,8 @@ __global__ __launch_bounds__(128 * NW) void corr_fwd_planes_k2_kernel(const __bf
 
 template <int NW>
 int launch_corr_planes(const __bf16* a, const __bf16* b, long in_plane_stride, __bf16* o, long out_plane_stride, int out_chunk0,
-                       int B, int H, int W, int ni, float scale, float slope, hipStream_t st) {
+                       int B, int H, int W, int ni, float scale, float slope, hipStream_t st, const int* win = nullptr,
+                       int win_div = 1) {
   static bool raised = false;                    // 64.5 KB + the output tiles: above the default dynamic-LDS limit
   if (!raised) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_fwd_planes_kernel<NW>),
@@ -370,7 +376,7 @@ int launch_corr_planes(const __bf16* a, const __bf16* b, long in_plane_stride, _
     raised = true;
   }
   static const bool k2 = [] { const char* e = getenv("UFR_CORR_PLANES_K2"); return !(e && e[0] == '0'); }();
-  if (k2) {                                       // reduction split over two waves per tile (default)
+  if (k2 || win) {                                       // reduction split over two waves per tile (default)
     static bool raised2 = false;
     if (!raised2) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_fwd_planes_k2_kernel<NW>),
@@ -378,8 +384,8 @@ int launch_corr_planes(const __bf16* a, const __bf16* b, long in_plane_stride, _
       if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "correlation (planes): %s", hipGetErrorString(e));
       raised2 = true;
     }
-    corr_fwd_planes_k2_kernel<NW><<<dim3(ufr::ceil_div(ni, 16 * NW), 2, B * H), 128 * NW, corr_planes_k2_lds_bytes<NW>(), st>>>(
-        a, b, in_plane_stride, o, out_plane_stride, out_chunk0, B, H, W, scale, slope);
+    corr_fwd_planes_k2_kernel<NW><<<dim3(win ? 1 : ufr::ceil_div(ni, 16 * NW), 2, B * H), 128 * NW, corr_planes_k2_lds_bytes<NW>(), st>>>(
+        a, b, in_plane_stride, o, out_plane_stride, out_chunk0, B, H, W, scale, slope, win, win_div);
     return UFR_OK;
   }
   corr_fwd_planes_kernel<NW><<<dim3(ufr::ceil_div(ni, 16 * NW), 2, B * H), 64 * NW, corr_planes_lds_bytes<NW>(), st>>>(
@@ -411,4 +417,23 @@ extern "C" int ufr_corr_forward_planes(const void* f1_planes, const void* f2_pla
     rc = launch_corr_planes<5>(a, b, in_plane_stride, o, out_plane_stride, out_chunk0, B, H, W, ni, scale, slope, st);
   if (rc != UFR_OK) return rc;
   return ufr::launched("corr_fwd_planes_kernel");
+}
+
+extern "C" int ufr_corr_forward_planes_window(const void* f1_planes, const void* f2_planes, long in_plane_stride, void* out_planes,
+                                              long out_plane_stride, int out_chunk0, int B, int C, int H, int W, int patch,
+                                              int dilation_patch, float scale, float slope, const int* win, int level_stride,
+                                              int win_cells, ufr_stream_t stream) {
+  UFR_REQUIRE(f1_planes && f2_planes && out_planes && win, "correlation (planes, window): null pointer");
+  UFR_REQUIRE(B > 0 && H > 0 && W > 0 && (long)B * H < 65536 && out_chunk0 >= 0 && level_stride > 0 && win_cells > 0,
+              "correlation (planes, window): bad shape");
+  if (C != 32 * KCH || patch != P || dilation_patch != 2 || win_cells + 4 * R > 63)
+    return ufr::fail(UFR_EUNSUPPORTED, "correlation (planes, window): 256 channels, patch 21, dilation_patch 2, windows of at most "
+                                       "23 cells; got C=%d patch=%d dilation_patch=%d cells=%d", C, patch, dilation_patch, win_cells);
+  // 2 x 32 same-parity columns from 20 cells left of the window cover [x0 - 20, x0 + cells + 20): every cell whose cost
+  // volume can have changed when the features changed inside the window only
+  int rc = launch_corr_planes<2>(static_cast<const __bf16*>(f1_planes), static_cast<const __bf16*>(f2_planes), in_plane_stride,
+                                 static_cast<__bf16*>(out_planes), out_plane_stride, out_chunk0, B, H, W, (W + 1) / 2, scale, slope,
+                                 ufr::as_stream(stream), win, level_stride);
+  if (rc != UFR_OK) return rc;
+  return ufr::launched("corr_fwd_planes_k2_kernel (window)");
 }

@@ -509,7 +509,14 @@ class FlowNetCHeadEngine:
             if planes_corr:
                 self.c3b_p.load_nchw(c3b, 0)
         # submodules.py:124-138 (`correlate`: /C) + FlowNetC.py:139 LeakyReLU fused into the correlation's epilogue
-        if planes_corr:                          # matrix cores, planes in, conv3_1's input planes out (correlation_planes.hip)
+        corr_inc = (inc and planes_corr and band.cone_win is not None and band.cone_hw[1] // 8 <= 23
+                    and os.environ.get("UFR_CORR_INCREMENTAL", "1") != "0")
+        if corr_inc:                             # later iterations of a call: only the window's neighbourhood of the volume changes
+            L.check(L.lib().ufr_corr_forward_planes_window(L.ptr(self.c3a_p.t), L.ptr(self.c3b_p.t), self.c3a_p.plane_stride,
+                                                           L.ptr(self.in31.t), self.in31.plane_stride, 1, self.B, 256, *self.grid[8],
+                                                           21, 2, 1.0 / 256.0, ig.LEAKY, L.ptr(band.cone_win), 8,
+                                                           band.cone_hw[1] // 8, L.stream()), "correlation forward (planes, window)")
+        elif planes_corr:                        # matrix cores, planes in, conv3_1's input planes out (correlation_planes.hip)
             L.check(L.lib().ufr_corr_forward_planes(L.ptr(self.c3a_p.t), L.ptr(self.c3b_p.t), self.c3a_p.plane_stride,
                                                     L.ptr(self.in31.t), self.in31.plane_stride, 1, self.B, 256, *self.grid[8], 21, 2,
                                                     1.0 / 256.0, ig.LEAKY, L.stream()), "correlation forward (planes)")
