@@ -173,7 +173,8 @@ def _same_update(pf, pc, p0, sel, what):
     err = ((pf - pc) * sel).abs()
     assert 1e-3 < upd < 1.9, f"{what}: test lr leaves the update degenerate ({upd})"
     off = float((err > 1e-4 * upd + 1e-6).sum()) / max(float((sel != 0).sum()), 1.0)
-    assert off <= 0.05 and float(err.max()) <= 1e-2 * upd, \
+    worst = 1e-2 if _engine_on() else 3e-2       # MIOpen's split-K data gradients (UFR_ENGINE=0) are not bit-reproducible
+    assert off <= 0.05 and float(err.max()) <= worst * upd, \
         f"{what}: {off:.2%} of the patch pixels differ by more than 1e-4, worst {float(err.max()) / upd:.2e} of the update"
     return upd
 
@@ -378,4 +379,6 @@ def test_attack_notices_new_weights(net):
     net2.__dict__.update(held)
     p_fresh = run(fresh)
     assert float((p_after - p_before).abs().max()) > 1e-3, "the weight change did not reach the attack"
-    assert float((p_after - p_fresh).abs().max()) <= 1e-6 * max(1.0, float(p_fresh.abs().max()))
+    # (identical kernels and data: bit-equal with the engine's fixed-order reductions; MIOpen's prefix under
+    # UFR_ENGINE_PREFIX=0 is not bit-reproducible from one handle to the next)
+    assert float((p_after - p_fresh).abs().max()) <= 1e-5 * max(1.0, float(p_fresh.abs().max()))

@@ -122,7 +122,8 @@ def test_engine_banded_step_equals_full_frame_torch_step(net, monkeypatch):
     _, full = run(False, False, lr, 3, False)
     step, eng = run(True, True, lr, 3, True)
     assert step.cone is not None and step.band is not None and step.band.width == 608 and step.graph_next is not None
-    assert step.eng is not None                       # cached features resident in the native head's planes
+    import os                                          # cached features resident in the native head's planes (unless switched off)
+    assert (step.eng is not None) == (os.environ.get("UFR_ENGINE_PREFIX", "1") == "1")
     for (pf, nf, lf), (pe, ne, le) in zip(full, eng):
         upd = float((pf - patch0).abs().max())
         err = (pf - pe).abs()
@@ -272,7 +273,8 @@ def test_window_prefix_on_the_engine_equals_the_torch_prefix(net):
     c1_32 = F.leaky_relu(F.conv2d(net.normalize_correctly(xw), net.conv1[0].weight, net.conv1[0].bias, 2, 3), 0.1)
     e_eng, e_t = _rel(P["c1"].to_nchw(64, 0), c1_64.detach()), _rel(c1_32, c1_64.detach())
     print(f"conv1: engine {e_eng:.2e}, torch fp32 {e_t:.2e} (vs float64)")
-    assert "conv1" in P and e_eng <= max(3 * e_t, 2e-6)
+    import os
+    assert ("conv1" in P) == (os.environ.get("UFR_CONV1_IGEMM", "1") != "0") and e_eng <= max(3 * e_t, 2e-6)
     for name, got, t32, t64 in (("conv2", P["c2_nchw"], c2, c2_64), ("conv3", P["c3_nchw"], c3, c3_64)):
         e_eng, e_t = _rel(got, t64), _rel(t32.detach(), t64)
         print(f"{name}: engine {e_eng:.2e}, torch fp32 {e_t:.2e} (vs float64)")
