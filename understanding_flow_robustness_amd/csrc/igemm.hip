@@ -163,8 +163,8 @@ __device__ __forceinline__ void xcd_tile(int swz, int& bx, int& by, int& bz) {
 struct Phase {
   int ntaps, oy0, ox0;
   long w_off;                       // bf16 elements from the weight plane's start
-  signed char dy[UFR_IGEMM_MAX_TAPS], dx[UFR_IGEMM_MAX_TAPS];
-};
+  int dyx[UFR_IGEMM_MAX_TAPS];      // (dy & 0xffff) | (dx << 16): one dword per tap, so a wave-uniform tap index becomes an
+};                                  // s_load (a byte table is read with global_load_sbyte, whose wait drains the LDS-DMA too)
 
 struct Args {
   const __bf16* x; long x_plane_stride; int in_chunk0, KC;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   bool ok[2];
   long aoff[2];
   auto set_tap = [&](int t) {
-    const int dyo = ph.dy[t], dxo = ph.dx[t];
+    const int dyx = ph.dyx[t], dyo = (int)(short)(dyx & 0xffff), dxo = dyx >> 16;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int yi = yb[i] + dyo, xi = xb[i] + dxo;
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   bool ok[2];
   long aoff[2];
   auto set_tap = [&](int t) {
-    const int dyo = ph.dy[t], dxo = ph.dx[t];
+    const int dyx = ph.dyx[t], dyo = (int)(short)(dyx & 0xffff), dxo = dyx >> 16;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int yi = yb[i] + dyo, xi = xb[i] + dxo;
@@ -508,6 +508,136 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
   static_assert(4 * 32 * 68 * 4 <= (int)sizeof(lds_all), "epilogue staging does not fit");
   igemm_write_out<NPL, MT>(a, ph, acc, reinterpret_cast<float*>(lds_all), z, bm, bn, wrow, wcol, lane, wave);
+}
+
+// ---- the 256 x 128 tile form: ONE workgroup per CU, the overlap inside the workgroup ---------------------------------
+// Same operands, addressing, swizzle and epilogue as igemm_glds_kernel<128>, but a workgroup owns 256 rows (each wave 128 x
+// 64: 8 x 4 accumulator tiles, ~250 VGPRs at one wave per SIMD) and TWO LDS stages of 72 KB: the DMA of K tile k + 1 is
+// issued before the 192 MFMAs per wave of K tile k and retired by the barrier that ends it (one barrier per K tile).  Per
+// MFMA it moves 94 bytes from L2 instead of 125 and never has every resident workgroup waiting at once.
+constexpr int BMB = 256;
+constexpr int BIG_STAGE = 3 * (BMB + BN) * BK;                            // elements per stage: 3 planes x (A 256 + B 128) rows x 32
+constexpr int BIG_LDS_BYTES = 2 * BIG_STAGE * 2;
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void igemm_big_kernel(const Args a) {
+  constexpr int NPL = 3, MT = 8;
+  extern __shared__ __attribute__((aligned(16))) __bf16 lds_big[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wrow = (wave >> 1) * 128, wcol = (wave & 1) * 64;
+  int tx, ty, z;
+  xcd_tile(a.xcd, tx, ty, z);
+  const int bm = ty * BMB, bn = tx * BN;
+  int phase = 0;
+#pragma unroll
+  for (int p = 1; p < 4; ++p)
+    if (p < a.nphase && z >= a.zoff[p]) phase = p;
+  const int ks = z - a.zoff[phase];
+  const Phase& ph = a.ph[phase];
+  const int KC = a.KC, KT = ph.ntaps * KC;
+  const int kt0 = ks * a.per_k, kt1 = min(KT, kt0 + a.per_k);
+  const long Min = (long)a.g.B * a.Hi * a.Wi;
+  const long cstride = Min * 32;
+
+  const int srow0 = tid >> 2, sch = tid & 3;
+  const int csw = sch ^ ((srow0 >> 1) & 3);
+  int yb[4], xb[4], xlo[4], xhi[4];
+  long ibase[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pm = bm + srow0 + 64 * i;
+    const int hw = a.g.Hr * a.g.Wr;
+    const int b = pm / hw, r = pm - b * hw, yr = r / a.g.Wr, xr = r - yr * a.g.Wr;
+    const bool live = pm < a.g.M;
+    const int bb = live ? b : 0;
+    const int xg = xr + (a.g.row_x0 ? a.g.row_x0[bb * a.g.row_x0_stride] / a.g.row_x0_div : 0);
+    yb[i] = live ? yr * a.in_sy : -(1 << 20);
+    xb[i] = xg * a.in_sx;
+    ibase[i] = (long)bb * a.Hi * a.Wi;
+    xlo[i] = a.in_x0 ? a.in_x0[bb * a.in_x0_stride] / a.in_x0_div : 0;
+    xhi[i] = a.in_x0 ? min(a.Wi, xlo[i] + a.in_xw) : a.Wi;
+    xlo[i] = max(xlo[i], 0);
+  }
+  const __bf16* gx = a.x + (long)a.in_chunk0 * cstride + csw * 8;
+  const __bf16* zero = reinterpret_cast<const __bf16*>(ufr_zero_page);
+  int tap = kt0 / KC, kc = kt0 - tap * KC;
+  const __bf16* wp = a.w + ph.w_off + ((long)kt0 * a.Npad + bn + srow0) * BK + csw * 8;
+  const long wstep = (long)a.Npad * BK;
+  const __bf16* xk = gx + (long)kc * cstride;
+  bool ok[4];
+  long aoff[4];
+  auto set_tap = [&](int t) {
+    const int dyx = ph.dyx[t], dyo = (int)(short)(dyx & 0xffff), dxo = dyx >> 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int yi = yb[i] + dyo, xi = xb[i] + dxo;
+      ok[i] = (unsigned)yi < (unsigned)a.Hi && xi >= xlo[i] && xi < xhi[i];
+      aoff[i] = ok[i] ? (ibase[i] + (long)yi * a.Wi + xi) * 32 : 0;
+    }
+  };
+  auto stage_tile = [&](int buf) {
+    __bf16* sA = lds_big + buf * BIG_STAGE;
+    __bf16* sB = sA + NPL * BMB * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) {
+        const __bf16* src = ok[i] ? xk + aoff[i] + p * a.x_plane_stride : zero;
+        glds16(src, sA + p * (BMB * BK) + (64 * i + wave * 16) * BK);
+      }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p)
+        glds16(wp + p * a.w_plane_stride + (long)(64 * i) * BK, sB + p * (BN * BK) + (64 * i + wave * 16) * BK);
+    wp += wstep;
+    xk += cstride;
+    if (++kc == KC) {
+      kc = 0;
+      xk = gx;
+      if (++tap < ph.ntaps) set_tap(tap);
+    }
+  };
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15;
+  const int foff = frow * BK + ((((lane >> 4)) ^ ((frow >> 1) & 3)) << 3);
+
+  int buf = 0;
+  if (kt0 < kt1) {
+    set_tap(tap);
+    stage_tile(0);
+  }
+  __syncthreads();                     // (hipcc waits vmcnt(0) in front of the barrier: the first tile has landed)
+  for (int kt = kt0; kt < kt1; ++kt) {
+    if (kt + 1 < kt1) stage_tile(buf ^ 1);           // in flight under this tile's MFMAs
+    const __bf16* sA = lds_big + buf * BIG_STAGE;
+    const __bf16* sB = sA + NPL * BMB * BK;
+    bf16x8 fa[NPL][MT];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        fa[p][m] = *reinterpret_cast<const bf16x8*>(sA + p * (BMB * BK) + (wrow + m * 16) * BK + foff);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      bf16x8 fb[NPL];
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) fb[p] = *reinterpret_cast<const bf16x8*>(sB + p * (BN * BK) + (wcol + n * 16) * BK + foff);
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[t]][m], fb[PROD_B[t]], acc[m][n], 0, 0, 0);
+    }
+    __syncthreads();                   // the next tile has landed (vmcnt(0)) and every wave is done with this one
+    buf ^= 1;
+  }
+  static_assert(4 * 32 * 68 * 4 <= BIG_LDS_BYTES, "epilogue staging does not fit");
+  igemm_write_out<NPL, MT>(a, ph, acc, reinterpret_cast<float*>(lds_big), z, bm, bn, wrow, wcol, lane, wave);
 }
 
 // Second stage of split-K: thread = (phase, row, 8 channels); the slabs are added in ascending order.
@@ -801,10 +931,8 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
     UFR_REQUIRE(p.oy0 >= 0 && p.oy0 < d->out_sy && p.ox0 >= 0 && p.ox0 < d->out_sx, "igemm: bad phase offset");
     UFR_REQUIRE(p.w_off + (long)p.ntaps * d->KC * d->Npad * BK <= d->w_plane_stride, "igemm: phase %d weights out of range", z);
     a.ph[z].ntaps = p.ntaps; a.ph[z].oy0 = p.oy0; a.ph[z].ox0 = p.ox0; a.ph[z].w_off = p.w_off;
-    for (int t = 0; t < UFR_IGEMM_MAX_TAPS; ++t) {
-      a.ph[z].dy[t] = t < p.ntaps ? p.dy[t] : 0;
-      a.ph[z].dx[t] = t < p.ntaps ? p.dx[t] : 0;
-    }
+    for (int t = 0; t < UFR_IGEMM_MAX_TAPS; ++t)
+      a.ph[z].dyx[t] = t < p.ntaps ? (((int)p.dy[t] & 0xffff) | ((int)p.dx[t] << 16)) : 0;
   }
   // split-K: `splitk` slices for the phase with the most taps, proportionally fewer for the others (the phases of a stride-2
   // data gradient reduce over 1, 2, 2 and 4 taps: equal slices per phase would leave the workgroups 4x apart in length)
@@ -819,10 +947,23 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   hipStream_t st = ufr::as_stream(stream);
   const int bn = d->Npad % BN == 0 ? BN : 64;        // 64-column tiles where a 128-column tile would be mostly padding
   const dim3 grid(d->Npad / bn, (unsigned)((M + BM - 1) / BM), nz);
-  static const int default_variant = [] { const char* e = getenv("UFR_IGEMM"); return e && e[0] == 'r' ? 1 : 2; }();
-  const int variant = d->variant ? d->variant : default_variant;        // 1 = register-staged, 2 = LDS-DMA staging
-  UFR_REQUIRE(variant == 1 || variant == 2, "igemm: unknown kernel variant %d", variant);
-  if (variant == 2 && d->products == 6) {
+  static const int default_variant = [] {
+    const char* e = getenv("UFR_IGEMM");
+    return e && e[0] == 'r' ? 1 : (e && e[0] == 'b' ? 3 : 2);
+  }();
+  const int variant = d->variant ? d->variant : default_variant;        // 1 = register-staged, 2 = LDS-DMA staging, 3 = 256 x 128 tiles
+  UFR_REQUIRE(variant >= 1 && variant <= 3, "igemm: unknown kernel variant %d", variant);
+  if (variant == 3 && d->products == 6 && bn == BN) {
+    static bool raised = false;
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         BIG_LDS_BYTES);
+      if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "igemm: %s", hipGetErrorString(e));
+      raised = true;
+    }
+    const dim3 gbig(d->Npad / BN, (unsigned)((M + BMB - 1) / BMB), nz);
+    igemm_big_kernel<<<gbig, 256, BIG_LDS_BYTES, st>>>(a);
+  } else if (variant >= 2 && d->products == 6) {
     if (bn == BN) igemm_glds_kernel<128><<<grid, 256, 0, st>>>(a);
     else igemm_glds_kernel<64><<<grid, 256, 0, st>>>(a);
   } else if (bn == BN) {
