@@ -392,19 +392,21 @@ __device__ __forceinline__ void glds16(const __bf16* src, __bf16* lds_wave_base)
   __builtin_amdgcn_global_load_lds(src, lds_wave_base, 16, 0, 0);
 }
 
-template <int BN_>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void igemm_glds_kernel(const Args a) {
+// BM_ x BN_ tiles: 128 x 128 (waves 2 x 2 of 64 x 64), 128 x 64 (waves 4 x 1 of 32 x 64: layers with <= 64 outputs), and
+// 64 x 128 (waves 2 x 2 of 32 x 64; 36 KB of LDS: FOUR workgroups per CU, twice the workgroups for the mid-size layers).
+template <int BM_, int BN_>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM_ == 64 ? 4 : 3, BM_ == 64 ? 4 : 3))) void igemm_glds_kernel(const Args a) {
   constexpr int NPL = 3, FIRST = 0;
-  constexpr int MT = BN_ == 128 ? 4 : 2;
-  constexpr int BPT = BN_ / 64;
-  __shared__ __attribute__((aligned(16))) __bf16 lds_all[NPL * (BM + BN_) * BK];
-  __bf16 (*ldsA)[BM * BK] = reinterpret_cast<__bf16 (*)[BM * BK]>(lds_all);
-  __bf16 (*ldsB)[BN_ * BK] = reinterpret_cast<__bf16 (*)[BN_ * BK]>(lds_all + NPL * BM * BK);
+  constexpr int MT = (BN_ == 128 && BM_ == 128) ? 4 : 2;
+  constexpr int BPT = BN_ / 64, APT = BM_ / 64;
+  __shared__ __attribute__((aligned(16))) __bf16 lds_all[NPL * (BM_ + BN_) * BK];
+  __bf16 (*ldsA)[BM_ * BK] = reinterpret_cast<__bf16 (*)[BM_ * BK]>(lds_all);
+  __bf16 (*ldsB)[BN_ * BK] = reinterpret_cast<__bf16 (*)[BN_ * BK]>(lds_all + NPL * BM_ * BK);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wrow = BN_ == 128 ? (wave >> 1) * 64 : wave * 32, wcol = BN_ == 128 ? (wave & 1) * 64 : 0;
+  const int wrow = BN_ == 128 ? (wave >> 1) * (BM_ / 2) : wave * 32, wcol = BN_ == 128 ? (wave & 1) * 64 : 0;
   int tx, ty, z;
   xcd_tile(a.xcd, tx, ty, z);
-  const int bm = ty * BM, bn = tx * BN_;
+  const int bm = ty * BM_, bn = tx * BN_;
   int phase = 0;                                     // z -> (phase, slice): phases with fewer taps have fewer slices
 #pragma unroll
   for (int p = 1; p < 4; ++p)
@@ -418,10 +420,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
   const int srow0 = tid >> 2, sch = tid & 3;
   const int csw = sch ^ ((srow0 >> 1) & 3);             // the piece this lane fetches (64 more rows keep (row >> 1) & 3)
-  int yb[2], xb[2], xlo[2], xhi[2];
-  long ibase[2];
+  int yb[APT], xb[APT], xlo[APT], xhi[APT];
+  long ibase[APT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < APT; ++i) {
     const int pm = bm + srow0 + 64 * i;
     const int hw = a.g.Hr * a.g.Wr;
     const int b = pm / hw, r = pm - b * hw, yr = r / a.g.Wr, xr = r - yr * a.g.Wr;
@@ -441,12 +443,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const __bf16* wp = a.w + ph.w_off + ((long)kt0 * a.Npad + bn + srow0) * BK + csw * 8;
   const long wstep = (long)a.Npad * BK;
   const __bf16* xk = gx + (long)kc * cstride;
-  bool ok[2];
-  long aoff[2];
+  bool ok[APT];
+  long aoff[APT];
   auto set_tap = [&](int t) {
     const int dyx = ph.dyx[t], dyo = (int)(short)(dyx & 0xffff), dxo = dyx >> 16;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < APT; ++i) {
       const int yi = yb[i] + dyo, xi = xb[i] + dxo;
       ok[i] = (unsigned)yi < (unsigned)a.Hi && xi >= xlo[i] && xi < xhi[i];
       aoff[i] = ok[i] ? (ibase[i] + (long)yi * a.Wi + xi) * 32 : 0;
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   // wave-uniform LDS destinations: the wave's 16 rows of each image (lane l lands at base + 16 l bytes)
   auto stage_tile = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < APT; ++i)
 #pragma unroll
       for (int p = 0; p < NPL; ++p) {
         const __bf16* src = ok[i] ? xk + aoff[i] + p * a.x_plane_stride : zero;
@@ -949,10 +951,10 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   const dim3 grid(d->Npad / bn, (unsigned)((M + BM - 1) / BM), nz);
   static const int default_variant = [] {
     const char* e = getenv("UFR_IGEMM");
-    return e && e[0] == 'r' ? 1 : (e && e[0] == 'b' ? 3 : 2);
+    return e && e[0] == 'r' ? 1 : (e && e[0] == 'b' ? 3 : (e && e[0] == 'm' ? 4 : 2));    // reg | big | m64 | (default) glds
   }();
   const int variant = d->variant ? d->variant : default_variant;        // 1 = register-staged, 2 = LDS-DMA staging, 3 = 256 x 128 tiles
-  UFR_REQUIRE(variant >= 1 && variant <= 3, "igemm: unknown kernel variant %d", variant);
+  UFR_REQUIRE(variant >= 1 && variant <= 4, "igemm: unknown kernel variant %d", variant);
   if (variant == 3 && d->products == 6 && bn == BN) {
     static bool raised = false;
     if (!raised) {
@@ -963,9 +965,12 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
     }
     const dim3 gbig(d->Npad / BN, (unsigned)((M + BMB - 1) / BMB), nz);
     igemm_big_kernel<<<gbig, 256, BIG_LDS_BYTES, st>>>(a);
+  } else if (variant == 4 && d->products == 6 && bn == BN) {       // 64 x 128 tiles: four workgroups per CU
+    const dim3 g64(d->Npad / BN, (unsigned)((M + 63) / 64), nz);
+    igemm_glds_kernel<64, 128><<<g64, 256, 0, st>>>(a);
   } else if (variant >= 2 && d->products == 6) {
-    if (bn == BN) igemm_glds_kernel<128><<<grid, 256, 0, st>>>(a);
-    else igemm_glds_kernel<64><<<grid, 256, 0, st>>>(a);
+    if (bn == BN) igemm_glds_kernel<128, 128><<<grid, 256, 0, st>>>(a);
+    else igemm_glds_kernel<128, 64><<<grid, 256, 0, st>>>(a);
   } else if (bn == BN) {
     if (d->products == 6) igemm_kernel<6, 128><<<grid, 256, 0, st>>>(a);
     else if (d->products == 3) igemm_kernel<3, 128><<<grid, 256, 0, st>>>(a);

@@ -106,9 +106,16 @@ class FlowNetCHeadEngine:
         def plan(wi, x, in_chunk0, rows, out_hw, **kw):
             M = B * rows[0] * rows[1]
             pk = [len(t) * wi.KC for _, _, t in wi.phases]
-            S = ig.splitk_for(M, wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk)
+            m64 = kw.get("variant") == 4       # 64 x 128 tiles, four workgroups per CU
+            S = ig.splitk_for(M, wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=64 if m64 else 128,
+                              target=1024 if m64 else 768)
             plans.append((wi, x, in_chunk0, rows, out_hw, S, kw))
             return len(plans) - 1
+
+        # 64 x 128 tiles (csrc/igemm.hip variant 4, four workgroups per CU): 7-19 % faster on the stride-2 data gradients and
+        # deconv3's in the isolated per-layer bench (profiles/r2_igemm_layers_v4_tile64.jsonl), neutral to slightly slower
+        # inside the step (6.66 / 6.70 vs 6.65 / 6.66 ms) -> opt-in
+        m64 = dict(variant=4) if os.environ.get("UFR_IGEMM_M64", "0") == "1" else {}
 
         fwd, bwd = {}, {}
         cw = lambda n, s, p: ig.conv_forward_weights(self._conv(n).weight, s, p)
@@ -143,18 +150,19 @@ class FlowNetCHeadEngine:
             s_in = {2: 8, 3: 16, 4: 32}[k]
             w = self._conv(f"deconv{k}").weight
             main = w.shape[0] - 2 if self.tail else w.shape[0]
-            bwd[f"deconv{k}"] = plan(ig.deconv_backward_weights(w[:main], 1), src, chunk0, g[s_in], g[s_in], out_f32=Gabove[k])
+            bwd[f"deconv{k}"] = plan(ig.deconv_backward_weights(w[:main], 1), src, chunk0, g[s_in], g[s_in], out_f32=Gabove[k],
+                                     **(m64 if k == 3 else {}))
             if self.tail:
                 self.tail_w[k] = _pack_flow_tail_mfma(w[main:])
                 self.tail_args[k] = (src, chunk0, ig.pad32(w.shape[1]) // 32, Gabove[k], main // 32, g[s_in])
         bwd["deconv5"] = plan(ig.deconv_backward_weights(self._conv("deconv5").weight, 1), self.gz_cat5, 16, g[64], g[64],
                               add=self.G_c6, mask=self.c6, out_planes=self.gz_c6)
         bwd["conv6_1"] = plan(cb("conv6_1", 1, 1), self.gz_c6, 0, g[64], g[64], mask=self.c6a, out_planes=self.gz_c6a)
-        bwd["conv6"] = plan(cb("conv6", 2, 1), self.gz_c6a, 0, g[64], g[32], add=self.G_cat5, mask=self.cat5, out_planes=self.gz_cat5)
+        bwd["conv6"] = plan(cb("conv6", 2, 1), self.gz_c6a, 0, g[64], g[32], add=self.G_cat5, mask=self.cat5, out_planes=self.gz_cat5, **m64)
         bwd["conv5_1"] = plan(cb("conv5_1", 1, 1), self.gz_cat5, 0, g[32], g[32], mask=self.c5a, out_planes=self.gz_c5a)
-        bwd["conv5"] = plan(cb("conv5", 2, 1), self.gz_c5a, 0, g[32], g[16], add=self.G_cat4, mask=self.cat4, out_planes=self.gz_cat4)
+        bwd["conv5"] = plan(cb("conv5", 2, 1), self.gz_c5a, 0, g[32], g[16], add=self.G_cat4, mask=self.cat4, out_planes=self.gz_cat4, **m64)
         bwd["conv4_1"] = plan(cb("conv4_1", 1, 1), self.gz_cat4, 0, g[16], g[16], mask=self.c4a, out_planes=self.gz_c4a)
-        bwd["conv4"] = plan(cb("conv4", 2, 1), self.gz_c4a, 0, g[16], g[8], add=self.G_cat3, mask=self.cat3, out_planes=self.gz_cat3)
+        bwd["conv4"] = plan(cb("conv4", 2, 1), self.gz_c4a, 0, g[16], g[8], add=self.G_cat3, mask=self.cat3, out_planes=self.gz_cat3, **m64)
         bwd["conv3_1"] = plan(cb("conv3_1", 1, 1), self.gz_cat3, 0, g[8], g[8], mask=self.in31, out_planes=self.gz_in31,
                               out_f32=self.G_in31)
         bwd["conv_redir"] = plan(cb("conv_redir", 1, 0), self.gz_in31, 0, g[8], g[8], out_f32=self.G_c3a)
@@ -404,7 +412,8 @@ class FlowNetCHeadEngine:
                 extra["in_band"] = (origin, 8, ls_in, band.width // ls_in)
             M = self.B * rows_b[0] * rows_b[1]
             pk = [len(t) * wi.KC for _, _, t in wi.phases]
-            Sb = ig.splitk_for(M, wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk)
+            v4 = kw.get("variant") == 4
+            Sb = ig.splitk_for(M, wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=64 if v4 else 128, target=1024 if v4 else 768)
             if len(wi.phases) * Sb * M * wi.Npad > self.ws.numel():
                 Sb = 1
             return ig.make_launch(wi, x, c0, rows_b, out_hw, splitk=Sb, ws=self.ws if Sb > 1 else None, **kw, **extra)

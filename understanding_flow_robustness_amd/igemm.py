@@ -304,12 +304,12 @@ def make_launch(wi: WeightImage, x: Planes, in_chunk0: int, rows_hw, out_hw, *, 
     return Launch(d, keep)
 
 
-def splitk_for(M: int, Npad: int, ktiles: int, phases: int = 1, target: int = 768, phase_ktiles=None) -> int:
+def splitk_for(M: int, Npad: int, ktiles: int, phases: int = 1, target: int = 768, phase_ktiles=None, bm: int = 128) -> int:
     """Split the reduction until the launch has about `target` workgroups (3 per CU: the LDS-DMA kernel's occupancy),
     keeping >= 16 K tiles per slice.  `phase_ktiles` (K tiles of every phase) switches to a small cost model when the
     phases are unequal (stride-2 data gradients: 1, 2, 2 and 4 taps): `splitk` then counts the slices of the LONGEST
     phase, the others get proportionally fewer (ufr_igemm), and the choice minimises rounds x (slice length + epilogue)."""
-    tiles_mn = -(-M // 128) * (Npad // (128 if Npad % 128 == 0 else 64))
+    tiles_mn = -(-M // bm) * (Npad // (128 if Npad % 128 == 0 else 64))
     if phase_ktiles is not None and len(set(phase_ktiles)) > 1:
         best, best_cost = 1, None
         s = 1
