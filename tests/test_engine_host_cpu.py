@@ -1,0 +1,134 @@
+"""CPU suite for the host logic of the native FlowNetC engine (igemm.py / flownetc_engine.py): the weight packings and
+tap geometries that turn conv1 (packed planes), predict_flow and the deconvolutions' flow columns into GEMM launches are
+checked against torch convolutions with a plain-torch emulation of what the HIP kernels compute -- no GPU needed."""
+import torch
+import torch.nn.functional as F
+
+from understanding_flow_robustness_amd import igemm as ig
+
+
+def _planes_value(wi: ig.WeightImage, phase: int = 0) -> torch.Tensor:
+    """[taps*KC][Npad][32] float32 image of a phase: the three bf16 planes added back (exact)."""
+    taps = len(wi.phases[phase][2])
+    n = taps * wi.KC * wi.Npad * 32
+    off = wi.offsets[phase]
+    return wi.planes.float().sum(0)[off:off + n].view(taps * wi.KC, wi.Npad, 32)
+
+
+def _pack_frames(x: torch.Tensor) -> torch.Tensor:
+    """Emulation of csrc/igemm.hip conv1_pack_kernel without the mean: [N,3,H,W] -> [N, H/2+3, W/2+2, 32]."""
+    N, _, H, W = x.shape
+    Hh, Wh = H // 2, W // 2
+    out = torch.zeros(N, Hh + 3, Wh + 2, 32, dtype=x.dtype)
+    for j in range(2):
+        for c in range(3):
+            for p in range(2):
+                for q in range(2):
+                    ch = j * 12 + (c * 2 + p) * 2 + q
+                    src = x[:, c, p::2, q::2]                              # [N, Hh, Wh] = frame[c, 2 yh + p, 2 xh + q]
+                    # packed pixel (yp, xp) holds half-grid pixel (yp - 2, xp - 2 + j)
+                    x_lo = 2 - j
+                    out[:, 2:2 + Hh, x_lo:x_lo + Wh, ch] = src[:, :, :Wh + 2 - x_lo] if x_lo + Wh <= Wh + 2 else src
+    return out
+
+
+def test_conv1_packed_launch_is_the_7x7_stride2_convolution():
+    """conv1_packed_weights + the packed planes: sum over the 8 taps (a, 2 b2) of one 32-channel chunk == Conv2d(3, N, 7, 2, 3)."""
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(16, 3, 7, 7, generator=g, dtype=torch.float64)
+    x = torch.randn(2, 3, 12, 20, generator=g, dtype=torch.float64)
+    wi = ig.conv1_packed_weights(w.float())
+    taps = wi.phases[0][2]
+    assert len(taps) == 8 and wi.KC == 1 and wi.geometry == dict(in_s=1, out_s=1)
+    wimg = _planes_value(wi)                                                # [8][Npad][32]
+    P = _pack_frames(x)
+    Hh, Wh = 6, 10
+    out = torch.zeros(2, Hh, Wh, wi.Npad, dtype=torch.float64)
+    for t, (dy, dx) in enumerate(taps):
+        out += torch.einsum("nyxc,oc->nyxo", P[:, dy:dy + Hh, dx:dx + Wh].double(), wimg[t].double())
+    want = F.conv2d(x, w.float().double(), None, 2, 3)
+    assert torch.allclose(out[..., :16].permute(0, 3, 1, 2), want, atol=1e-9)
+    assert float(out[..., 16:].abs().max()) == 0.0
+
+
+def test_conv1_packed_backward_launch_and_unpacking_are_the_data_gradient():
+    """conv1_packed_backward_weights (taps (-a, -2 b2) over the packed grid) + the unpacking (a frame pixel sits in two packed
+    pixels) == the data gradient of Conv2d(3, N, 7, 2, 3)."""
+    g = torch.Generator().manual_seed(1)
+    N = 8
+    w = torch.randn(N, 3, 7, 7, generator=g)
+    H, W, Hh, Wh = 12, 20, 6, 10
+    gy = torch.randn(2, N, Hh, Wh, generator=g, dtype=torch.float64)
+    wi = ig.conv1_packed_backward_weights(w)
+    wimg = _planes_value(wi).double()                                       # [8 taps][Npad=64][32 (o)]
+    Hp, Wp = Hh + 3, Wh + 2
+    gP = torch.zeros(2, Hp, Wp, wi.Npad, dtype=torch.float64)
+    gyh = gy.permute(0, 2, 3, 1)                                            # [n, Y, X, o]
+    for t, (dy, dx) in enumerate(wi.phases[0][2]):
+        # gP(yp, xp) += W_t^T gy(yp + dy, xp + dx), zero outside the (Hh, Wh) grid
+        for yp in range(Hp):
+            Y = yp + dy
+            if not 0 <= Y < Hh:
+                continue
+            xs = [xp for xp in range(Wp) if 0 <= xp + dx < Wh]
+            gP[:, yp, xs] += torch.einsum("nxo,co->nxc", gyh[:, Y, [xp + dx for xp in xs], :N], wimg[t][:, :N])
+    gx = torch.zeros(2, 3, H, W, dtype=torch.float64)
+    for c in range(3):
+        for y in range(H):
+            for x_ in range(W):
+                r = (c * 2 + (y & 1)) * 2 + (x_ & 1)
+                gx[:, c, y, x_] = gP[:, (y >> 1) + 2, (x_ >> 1) + 2, r] + gP[:, (y >> 1) + 2, (x_ >> 1) + 1, 12 + r]
+    x0 = torch.zeros(2, 3, H, W, dtype=torch.float64, requires_grad=True)
+    (want,) = torch.autograd.grad(F.conv2d(x0, w.double(), None, 2, 3), x0, gy)
+    assert torch.allclose(gx, want, atol=1e-9)
+
+
+def test_predict_flow_and_deconv_tail_packings():
+    """_pack_flow_head_mfma: T[p, 2k + o] = sum_c x[p, c] w[o, c, k] gathered over the 9 taps == Conv2d(C, 2, 3, 1, 1);
+    _pack_flow_tail_mfma: the same with 4 x 4 stride-2 taps == the data gradient of ConvTranspose2d(., ., 4, 2, 1) with
+    respect to two input channels (csrc/engine_small.hip flow_head_planes_fwd_mfma<0 / 1>)."""
+    from understanding_flow_robustness_amd.flownetc_engine import _pack_flow_head_mfma, _pack_flow_tail_mfma
+    g = torch.Generator().manual_seed(2)
+    C, H, W = 70, 6, 9
+    w = torch.randn(2, C, 3, 3, generator=g)
+    x = torch.randn(1, C, H, W, generator=g, dtype=torch.float64)
+    wm = _pack_flow_head_mfma(w).float().sum(1).double()                    # [chunks][32 n][32 c]
+    chunks = wm.shape[0]
+    xp = torch.zeros(chunks * 32, H + 2, W + 2, dtype=torch.float64)
+    xp[:C, 1:-1, 1:-1] = x[0]
+    T = torch.einsum("kcyx,knc->nyx", xp.view(chunks, 32, H + 2, W + 2), wm)   # [32 n][H+2][W+2]
+    out = torch.zeros(2, H, W, dtype=torch.float64)
+    for k in range(9):
+        for o in range(2):
+            out[o] += T[2 * k + o, k // 3:k // 3 + H, k % 3:k % 3 + W]
+    assert torch.allclose(out, F.conv2d(x, w.double(), None, 1, 1)[0], atol=1e-9)
+    assert float(T[18:].abs().max()) == 0.0
+    # deconv tail: gy on the fine grid [Cout, 2H, 2W], weights of the two flow input channels [2, Cout, 4, 4]
+    Cout = 40
+    w2 = torch.randn(2, Cout, 4, 4, generator=g)
+    gy = torch.randn(1, Cout, 2 * H, 2 * W, generator=g, dtype=torch.float64)
+    wt = _pack_flow_tail_mfma(w2).float().sum(1).double()
+    ch2 = wt.shape[0]
+    gp = torch.zeros(ch2 * 32, 2 * H + 2, 2 * W + 2, dtype=torch.float64)    # fine grid with one pixel of zero halo
+    gp[:Cout, 1:-1, 1:-1] = gy[0]
+    T2 = torch.einsum("kcyx,knc->nyx", gp.view(ch2, 32, 2 * H + 2, 2 * W + 2), wt)
+    got = torch.zeros(2, H, W, dtype=torch.float64)
+    for k in range(16):
+        ky, kx = k // 4, k % 4
+        for o in range(2):
+            got[o] += T2[2 * k + o, ky:ky + 2 * H:2, kx:kx + 2 * W:2]          # fine pixel (2y - 1 + ky, 2x - 1 + kx) + halo offset 1
+    x0 = torch.zeros(1, 2, H, W, dtype=torch.float64, requires_grad=True)
+    (want,) = torch.autograd.grad(F.conv_transpose2d(x0, w2.double(), None, 2, 1), x0, gy)
+    assert torch.allclose(got, want[0], atol=1e-9)
+
+
+def test_split_k_cost_model_keeps_uniform_launches_and_balances_unequal_phases():
+    """splitk_for: launches with equal phases keep the simple rule (fill ~3 workgroups per CU, >= 16 K tiles per slice);
+    a stride-2 data gradient (K tiles 16, 32, 32, 64) is split so that no workgroup is longer than half the longest phase."""
+    assert ig.splitk_for(61440, 256, 135) == 1                       # conv3_1 forward: 960 workgroups already
+    assert ig.splitk_for(960, 1024, 144) == 8                        # conv6 forward: 64 tiles
+    assert ig.splitk_for(3840, 512, 144) == 4                        # conv5 forward
+    pk = [16, 32, 32, 64]
+    s = ig.splitk_for(7296, 256, 64, 4, phase_ktiles=pk)             # conv4 backward on the band
+    assert s in (2, 4) and -(-max(pk) // s) <= 32
+    assert ig.splitk_for(7296, 256, 64, 4, phase_ktiles=[64, 64, 64, 64]) == ig.splitk_for(7296, 256, 64, 4)
