@@ -207,9 +207,9 @@ int ufr_pwc_warp_forward(const float* x, const float* flow, float* out, int B, i
 int ufr_pwc_warp_backward(const float* x, const float* flow, const float* grad_out, float* grad_x, float* grad_flow,
                           int B, int C, int H, int W, ufr_stream_t stream);
 
-/* ---- float32-accurate GEMM on the bf16 matrix cores (building block, not yet on the product path) ------
- * The convolutions of models/FlowNetC.py:22-50 etc. reach the GPU through MIOpen's fp32 kernels; DESIGN.md 10
- * plans their replacement by implicit GEMMs of this kind.  ufr_split_bf16x3: x[n] -> planes[3][n] bf16 with
+/* ---- float32-accurate GEMM on the bf16 matrix cores (round 1's building block; the product path is ufr_igemm below) ------
+ * Plain GEMM / 3x3 convolution forms of the three-plane arithmetic, kept for the measurements in profiles/r1_* and the
+ * UFR_SPLIT_CONV experiments; FlowNetC's convolutions run through ufr_igemm.  ufr_split_bf16x3: x[n] -> planes[3][n] bf16 with
  * x = p0 + p1 + p2 exactly.  ufr_gemm_split_nt: C[M,N] (fp32) = A[M,K] * B[N,K]^T from pre-split planes
  * ([3][M*K] and [3][N*K] bf16); `products` 6 (float32-accurate), 3 or 1 leading-order bf16 products, fp32
  * accumulation.  M, N multiples of 128, K of 32.  `chunk_major` = 1: planes stored [3][K/32][rows][32] (a 128-row

@@ -2,7 +2,7 @@
 // Conv2d / ConvTranspose2d of models/FlowNetC.py:22-50 (blocks of models/submodules.py:18-46, :75-82) and every one of
 // their data gradients, float32-accurate on the bf16 matrix cores.
 //
-// Arithmetic (DESIGN.md 10): a float32 value is held as THREE bf16 planes, v = p0 + p1 + p2 exactly; a product is the
+// Arithmetic (DESIGN.md 4-5): a float32 value is held as THREE bf16 planes, v = p0 + p1 + p2 exactly; a product is the
 // six leading bf16 products a0b0 + (a0b1 + a1b0) + (a1b1 + a0b2 + a2b0) accumulated in float32 by
 // `v_mfma_f32_16x16x32_bf16` (2.5 PFLOP/s dense / 6 = 417 TFLOP/s fp32-equivalent against the 157 TFLOP/s fp32 peak).
 // Error against float64 equals a plain fp32 GEMM's (profiles/r1_split_conv_accuracy.jsonl).

@@ -1,7 +1,7 @@
 """Host side of csrc/igemm.hip: plane buffers, pre-split weight images and the geometry descriptors that turn every
 Conv2d / ConvTranspose2d block of models/FlowNetC.py:22-50 (models/submodules.py:18-46, :75-82) -- forward and data
 gradient -- into one launch of `ufr_igemm` (float32-accurate on the bf16 matrix cores: three bf16 planes per operand,
-six products, DESIGN.md 10).  No torch arithmetic happens here at run time: weights are packed once (they are frozen
+six products, DESIGN.md 4-5).  No torch arithmetic happens here at run time: weights are packed once (they are frozen
 during an attack), everything else is descriptors over device pointers.
 """
 from __future__ import annotations
