@@ -19,7 +19,13 @@ __global__ void resample2d_fwd(const float* __restrict__ img, const float* __res
   const size_t plane_o = (size_t)H * W, plane_i = (size_t)Hi * Wi;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < npix;
        idx += (long)gridDim.x * blockDim.x) {
-    const int x = (int)(idx % W), y = (int)((idx / W) % H), b = (int)(idx / plane_o);
+    int x, y, b;
+    if (npix < (1L << 31)) {                      // 32-bit index arithmetic (three 64-bit divisions per pixel cost more than the taps)
+      const unsigned ui = (unsigned)idx, uw = (unsigned)W, uh = (unsigned)H, row = ui / uw;
+      x = (int)(ui - row * uw); b = (int)(row / uh); y = (int)(row - (unsigned)b * uh);
+    } else {
+      x = (int)(idx % W); y = (int)((idx / W) % H); b = (int)(idx / plane_o);
+    }
     const size_t pix = (size_t)y * W + x;
     const float dx = flow[((size_t)b * 2 + 0) * plane_o + pix];
     const float dy = flow[((size_t)b * 2 + 1) * plane_o + pix];
@@ -63,7 +69,13 @@ __global__ void resample2d_bwd(const float* __restrict__ img, const float* __res
   const int krad = (ksize - 1) / 2;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < npix;
        idx += (long)gridDim.x * blockDim.x) {
-    const int x = (int)(idx % W), y = (int)((idx / W) % H), b = (int)(idx / plane_o);
+    int x, y, b;
+    if (npix < (1L << 31)) {                      // 32-bit index arithmetic (three 64-bit divisions per pixel cost more than the taps)
+      const unsigned ui = (unsigned)idx, uw = (unsigned)W, uh = (unsigned)H, row = ui / uw;
+      x = (int)(ui - row * uw); b = (int)(row / uh); y = (int)(row - (unsigned)b * uh);
+    } else {
+      x = (int)(idx % W); y = (int)((idx / W) % H); b = (int)(idx / plane_o);
+    }
     const size_t pix = (size_t)y * W + x;
     const float dx = flow[((size_t)b * 2 + 0) * plane_o + pix];
     const float dy = flow[((size_t)b * 2 + 1) * plane_o + pix];
@@ -353,7 +365,11 @@ extern "C" int ufr_resample2d_forward(const float* input1, const float* input2, 
     resample2d_fwd_lds<<<tiles, 256, RS_LDS_BYTES, ufr::as_stream(stream)>>>(input1, input2, output, B, C, H, W, RS_LDS_BYTES / 4);
     return ufr::launched("resample2d_fwd_lds");
   }
-  hipLaunchKernelGGL(resample2d_fwd, dim3(ufr::stream_grid(npix, 256)), dim3(256), 0,
+  // one pixel per thread, every pixel's gathers in flight at once (the grid-stride form with 2048 workgroups serialised
+  // seven dependent flow -> gather chains per thread); UFR_RESAMPLE_GRID=stream restores it for the A/B
+  static const bool full_grid = [] { const char* e = getenv("UFR_RESAMPLE_GRID"); return !(e && e[0] == 's'); }();
+  const unsigned blocks = full_grid ? (unsigned)((npix + 255) / 256) : (unsigned)ufr::stream_grid(npix, 256);
+  hipLaunchKernelGGL(resample2d_fwd, dim3(blocks), dim3(256), 0,
                      ufr::as_stream(stream), input1, input2, output, B, C, Hi, Wi, H, W,
                      kernel_size, bilinear);
   return ufr::launched("resample2d_fwd");
