@@ -202,7 +202,10 @@ class FlowNetCHeadEngine:
         bias = lambda n: self._conv(n).bias.detach().float().contiguous()
         w2 = ig.conv_forward_weights(self._conv("conv2").weight, 2, 2)
         w3 = ig.conv_forward_weights(self._conv("conv3").weight, 2, 2)
-        l2 = ig.make_launch(w2, c1, 0, (H // 4, W // 4), (H // 4, W // 4), out_planes=c2, bias=bias("conv2"))
+        # conv2 (K = 25 taps x 2 chunks) runs 14 % faster on 64 x 128 tiles, four workgroups per CU (1.35 -> 1.19 ms at 2 x 8
+        # frames; conv3 and every large head layer prefer 128 x 128: profiles/r2_bench_m64_all_launches.txt)
+        v64 = 4 if os.environ.get("UFR_IGEMM_M64_PREFIX", "1") != "0" else 0
+        l2 = ig.make_launch(w2, c1, 0, (H // 4, W // 4), (H // 4, W // 4), out_planes=c2, bias=bias("conv2"), variant=v64)
         l3 = ig.make_launch(w3, c2, 0, (H // 8, W // 8), (H // 8, W // 8), out_planes=c3, bias=bias("conv3"))
         self._prefix = dict(c1=c1, c2=c2, c3=c3, conv2=l2, conv3=l3, conv2_wi=w2, conv3_wi=w3, b1=bias("conv1"),
                             w1=self._conv("conv1").weight.detach())
@@ -302,13 +305,17 @@ class FlowNetCHeadEngine:
         c1, c2, c3 = ig.Planes(B2, h2, w2, 2, dev), ig.Planes(B2, h4, w4, 4, dev), ig.Planes(B2, h8, w8, 8, dev)
         gz_c3, gz_c2 = ig.Planes(B2, h8, w8, 8, dev), ig.Planes(B2, h4, w4, 4, dev)
         conv1_native = os.environ.get("UFR_CONV1_IGEMM", "1") != "0"
+        v64 = 4 if os.environ.get("UFR_IGEMM_M64_PREFIX", "1") != "0" else 0
         gz_c1, G_p = ig.Planes(B2, h2, w2, 2, dev), ig.GradSum(B2, h2 + 3, w2 + 2, 1, dev)
         G_gw2, G_c1 = ig.GradSum(B2, h4, w4, 4, dev), ig.GradSum(B2, h2, w2, 2, dev)   # G_gw2: the conv2 tap's window gradient
                                                                                        # (first frames; second frames stay 0)
         bias = lambda n: self._conv(n).bias.detach().float().contiguous()
         plans = [
-            (ig.conv_forward_weights(self._conv("conv2").weight, 2, 2), c1, (h4, w4), (h4, w4), dict(out_planes=c2, bias=bias("conv2"))),
-            (ig.conv_forward_weights(self._conv("conv3").weight, 2, 2), c2, (h8, w8), (h8, w8), dict(out_planes=c3, bias=bias("conv3"))),
+            # (the window's forward convolutions: 64 x 128 tiles measured 1.3x faster than 128 x 128 at the same split)
+            (ig.conv_forward_weights(self._conv("conv2").weight, 2, 2), c1, (h4, w4), (h4, w4),
+             dict(out_planes=c2, bias=bias("conv2"), variant=v64)),
+            (ig.conv_forward_weights(self._conv("conv3").weight, 2, 2), c2, (h8, w8), (h8, w8),
+             dict(out_planes=c3, bias=bias("conv3"), variant=v64)),
             # conv3's data gradient + the skip connection's gradient, x LeakyReLU'(conv2) -> conv2's gradient planes
             (ig.conv_backward_weights(self._conv("conv3").weight, 2, 2), gz_c3, (h8, w8), (h4, w4),
              dict(add=G_gw2, mask=c2, out_planes=gz_c2)),
