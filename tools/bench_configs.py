@@ -88,6 +88,8 @@ def main():
         torch.cuda.reset_peak_memory_stats()
         if w == "c2":
             r = patch_case("c2 FlowNetC 384x1280 patch attack", "FlowNetC", 0, 8, 384, 1280, opt.steps)
+        elif w == "c2b1":                   # the reference's own batch size (train() attacks one pair per loader item)
+            r = patch_case("c2 FlowNetC 384x1280 patch attack, 1 pair (the reference's batch size)", "FlowNetC", 0, 1, 384, 1280, opt.steps)
         elif w == "c3":
             r = patch_case("c3 RAFT 384x1280 all-pairs, 12 GRU iterations, patch attack", "RAFT", 2, 1, 384, 1280, opt.steps)
         elif w == "c3alt":
