@@ -109,8 +109,14 @@ class FlowNetCHeadEngine:
             m64 = kw.get("variant") == 4       # 64 x 128 tiles, four workgroups per CU
             S = ig.splitk_for(M, wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=64 if m64 else 128,
                               target=1024 if m64 else 768)
+            if small_batch and "variant" not in kw:
+                kw["variant"] = 4                  # (split factor as sized for 128-row tiles: the measured combination)
             plans.append((wi, x, in_chunk0, rows, out_hw, S, kw))
             return len(plans) - 1
+
+        # one pair (the reference's own batch size): every launch is under-filled and 64 x 128 tiles with four workgroups per
+        # CU measured 10 % faster for the whole iteration (1.75 -> 1.59 ms; equal at two pairs, slower from four on)
+        small_batch = self._small_batch = B == 1 and os.environ.get("UFR_IGEMM") is None
 
         # 64 x 128 tiles (csrc/igemm.hip variant 4, four workgroups per CU): 7-19 % faster on the stride-2 data gradients and
         # deconv3's in the isolated per-layer bench (profiles/r2_igemm_layers_v4_tile64.jsonl), neutral to slightly slower
@@ -206,7 +212,8 @@ class FlowNetCHeadEngine:
         # frames; conv3 and every large head layer prefer 128 x 128: profiles/r2_bench_m64_all_launches.txt)
         v64 = 4 if os.environ.get("UFR_IGEMM_M64_PREFIX", "1") != "0" else 0
         l2 = ig.make_launch(w2, c1, 0, (H // 4, W // 4), (H // 4, W // 4), out_planes=c2, bias=bias("conv2"), variant=v64)
-        l3 = ig.make_launch(w3, c2, 0, (H // 8, W // 8), (H // 8, W // 8), out_planes=c3, bias=bias("conv3"))
+        l3 = ig.make_launch(w3, c2, 0, (H // 8, W // 8), (H // 8, W // 8), out_planes=c3, bias=bias("conv3"),
+                            variant=4 if getattr(self, "_small_batch", False) else 0)
         self._prefix = dict(c1=c1, c2=c2, c3=c3, conv2=l2, conv3=l3, conv2_wi=w2, conv3_wi=w3, b1=bias("conv1"),
                             w1=self._conv("conv1").weight.detach())
         self._prefix.update(self._conv1_launch(B2, H, W, c1))
@@ -331,6 +338,9 @@ class FlowNetCHeadEngine:
             sized.append(ig.splitk_for(B2 * rows[0] * rows[1], wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk))
         need = max([len(wi.phases) * S * B2 * rows[0] * rows[1] * wi.Npad for (wi, _, rows, _, _), S in zip(plans, sized) if S > 1] + [1])
         ws = torch.empty(need, **f32)
+        if getattr(self, "_small_batch", False):
+            for _, _, _, _, kw in plans:
+                kw.setdefault("variant", 4)
         launches = [ig.make_launch(wi, x, 0, rows, out_hw, splitk=S, ws=ws if S > 1 else None, **kw)
                     for (wi, x, rows, out_hw, kw), S in zip(plans, sized)]
         wis = {k + "_wi": p[0] for k, p in zip(("conv2", "conv3", "conv3_bwd", "conv2_bwd", "conv1_bwd"), plans)}
@@ -419,7 +429,7 @@ class FlowNetCHeadEngine:
                 extra["in_band"] = (origin, 8, ls_in, band.width // ls_in)
             M = self.B * rows_b[0] * rows_b[1]
             pk = [len(t) * wi.KC for _, _, t in wi.phases]
-            v4 = kw.get("variant") == 4
+            v4 = kw.get("variant") == 4 and not self._small_batch
             Sb = ig.splitk_for(M, wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=64 if v4 else 128, target=1024 if v4 else 768)
             if len(wi.phases) * Sb * M * wi.Npad > self.ws.numel():
                 Sb = 1
