@@ -159,9 +159,16 @@ extern "C" int ufr_corr_backward_window_fused(const float* f1, const float* f2, 
     return ufr::fail(UFR_EUNSUPPORTED, "corr backward window (fused): built for 256 channels, patch 21, dilation_patch 2, windows "
                                        "of at most 16 cells across, W a multiple of 4; got C=%d patch=%d dilation=%d ww=%d W=%d",
                      C, patch, dilation_patch, ww, W);
-  constexpr int NR = 2, TPW = 2;
-  const int groups = 2 * ufr::ceil_div(ufr::ceil_div(wh, 2), NR);
-  corr_bwd_window_mfma_kernel<NR, TPW><<<dim3(groups, 2 * (16 / (4 * TPW)), B), 256, 0, ufr::as_stream(stream)>>>(
-      f1, f2, G, g_chunk0, g_scale, G_redir, grad_window, B, H, W, win, level_stride, wh, ww, margin);
+  if (B <= 2) {                                   // one or two pairs: 4x the workgroups (one row, one tile per wave) fill more CUs
+    constexpr int NR = 1, TPW = 1;
+    const int groups = 2 * ufr::ceil_div(ufr::ceil_div(wh, 2), NR);
+    corr_bwd_window_mfma_kernel<NR, TPW><<<dim3(groups, 2 * (16 / (4 * TPW)), B), 256, 0, ufr::as_stream(stream)>>>(
+        f1, f2, G, g_chunk0, g_scale, G_redir, grad_window, B, H, W, win, level_stride, wh, ww, margin);
+  } else {
+    constexpr int NR = 2, TPW = 2;
+    const int groups = 2 * ufr::ceil_div(ufr::ceil_div(wh, 2), NR);
+    corr_bwd_window_mfma_kernel<NR, TPW><<<dim3(groups, 2 * (16 / (4 * TPW)), B), 256, 0, ufr::as_stream(stream)>>>(
+        f1, f2, G, g_chunk0, g_scale, G_redir, grad_window, B, H, W, win, level_stride, wh, ww, margin);
+  }
   return ufr::launched("corr_bwd_window_mfma_kernel");
 }
