@@ -75,12 +75,26 @@ class FlowNetC(_Refinement):
         self._build_refinement(up_bias=True)
         _xavier(self)
 
+    def _engine_ok(self, c2a) -> bool:
+        """Frozen parameters, eval mode, HIP float32 features, frame sides that are multiples of 64 (UFR_ENGINE=0 switches off)."""
+        import os
+        if os.environ.get("UFR_ENGINE", "1") != "1" or os.environ.get("UFR_ENGINE_FLOWNET2", "1") != "1" or self.training:
+            return False
+        frozen = not any(p.requires_grad for p in self.parameters())
+        return (c2a.is_cuda and c2a.dtype == torch.float32 and (frozen or not torch.is_grad_enabled())
+                and c2a.shape[2] % 16 == 0 and c2a.shape[3] % 16 == 0)
+
     def forward(self, x):
         B = x.shape[0]
         both = torch.cat((x[:, 0:3], x[:, 3:]), 0)
         c2 = self.conv2(self.conv1(both))
         c3 = self.conv3(c2)
         c2a, c3a, c3b = c2[:B], c3[:B], c3[B:]
+        if self._engine_ok(c2a):
+            # the same layers under the same names as flownets/flownetc.py: everything behind conv3 on the native head
+            # (flownetc_engine.py: implicit-GEMM convolutions and the cost volume on the matrix cores, forward and data gradient)
+            from ..flownetc_engine import engine_head
+            return (engine_head(self, c2a.contiguous(), c3a.contiguous(), c3b.contiguous()),)
         corr = F.leaky_relu(correlate(c3a.contiguous(), c3b.contiguous()), 0.1)
         c3_1 = self.conv3_1(torch.cat((self.conv_redir(c3a), corr), 1))
         c4 = self.conv4_1(self.conv4(c3_1))
