@@ -279,3 +279,36 @@ def test_raft_gradient_against_float64_truth(alternate, oracle):
 
 
 RAFT_F64_FACTOR = 2.0
+
+
+def test_flownets_trunk_on_the_engine_vs_float64(monkeypatch):
+    """FlowNetS (models/flownet2/FlowNetS.py:15-104: FlowNet2's two refinement stacks, FlowNet2S) routes everything behind
+    conv3 through the native head in its trunk form (no correlation / conv_redir).  Flow and input gradient against the
+    same module evaluated in float64 by torch, with torch's own float32 result as the yardstick."""
+    import copy
+    from understanding_flow_robustness_amd.flownets.flownet2 import FlowNetS
+    torch.manual_seed(11)
+    net = FlowNetS(12).to(DEV).eval().requires_grad_(False)
+    for p in net.parameters():                       # default init gives a flow of ~1e-3: scale it into a readable range
+        if p.dim() > 1:
+            p.mul_(1.6)
+    x = torch.rand(2, 12, 128, 192, device=DEV)
+    w = torch.randn(2, 2, 32, 48, device=DEV)
+
+    def run(module, inp, weight):
+        inp = inp.clone().requires_grad_(True)
+        flow = module(inp)[0]
+        (g,) = torch.autograd.grad((flow * weight).sum(), inp)
+        return flow.detach(), g
+
+    f_eng, g_eng = run(net, x, w)
+    assert net.__dict__.get("_ufr_head_engines"), "the trunk did not run on the engine"
+    assert not next(iter(net._ufr_head_engines.values())).siamese
+    monkeypatch.setenv("UFR_ENGINE_FLOWNET2", "0")
+    f_t, g_t = run(net, x, w)
+    net.__dict__.pop("_ufr_head_engines")
+    f_64, g_64 = run(copy.deepcopy(net).double(), x.double(), w.double())
+    for what, a, b, ref in (("flow", f_eng, f_t, f_64), ("gradient", g_eng, g_t, g_64)):
+        scale = float(ref.abs().max())
+        err, err_t = float((a.double() - ref).abs().max()) / scale, float((b.double() - ref).abs().max()) / scale
+        assert err <= max(3 * err_t, 2e-6), f"{what}: engine {err:.2e} vs torch float32 {err_t:.2e} of the float64 result"

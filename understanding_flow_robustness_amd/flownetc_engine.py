@@ -73,9 +73,12 @@ class FlowNetCHeadEngine:
         self.grid = g
         P = lambda s, chunks: ig.Planes(B, g[s][0], g[s][1], chunks, self.dev)
         G = lambda s, chunks: ig.GradSum(B, g[s][0], g[s][1], chunks, self.dev)
+        # FlowNetC (siamese: correlation + conv_redir in front of conv3_1) or the plain FlowNetS trunk of FlowNet2 / FlowNet2S
+        # (models/flownet2/FlowNetS.py:15-104: conv3_1 reads conv3 directly; same layers and names behind it)
+        self.siamese = hasattr(net, "conv_redir")
         # ---- activations
-        self.c3a_p, self.c3b_p = P(8, 8), P(8, 8)
-        self.in31, self.cat3, self.cat2 = P(8, 15), P(8, 13), P(4, 7)
+        self.c3a_p, self.c3b_p = (P(8, 8), P(8, 8)) if self.siamese else (None, None)
+        self.in31, self.cat3, self.cat2 = P(8, 15 if self.siamese else 8), P(8, 13), P(4, 7)
         self.c4a, self.cat4 = P(16, 16), P(16, 25)
         self.c5a, self.cat5 = P(32, 16), P(32, 33)
         self.c6a, self.c6 = P(64, 32), P(64, 32)
@@ -84,9 +87,10 @@ class FlowNetCHeadEngine:
         self.corr = torch.zeros(B, 21, 21, *g[8], **f32)
         # ---- gradients
         self.G_cat2, self.G_cat3, self.G_cat4, self.G_cat5 = G(4, 7), G(8, 13), G(16, 25), G(32, 33)
-        self.G_c6, self.G_in31, self.G_c3a = G(64, 32), G(8, 15), G(8, 8)
+        self.G_c6, self.G_in31, self.G_c3a = G(64, 32), G(8, 15 if self.siamese else 8), G(8, 8)
         self.gz_cat2, self.gz_cat3, self.gz_cat4, self.gz_cat5 = P(4, 7), P(8, 13), P(16, 25), P(32, 33)
-        self.gz_c6, self.gz_c6a, self.gz_c5a, self.gz_c4a, self.gz_in31 = P(64, 32), P(64, 32), P(32, 16), P(16, 16), P(8, 15)
+        self.gz_c6, self.gz_c6a, self.gz_c5a, self.gz_c4a = P(64, 32), P(64, 32), P(32, 16), P(16, 16)
+        self.gz_in31 = P(8, 15) if self.siamese else None
         self.g_flow = {k: torch.zeros(B, 2, *g[2 ** k], **f32) for k in (6, 5, 4, 3)}
         self.g_corr = torch.zeros(B, 21, 21, *g[8], **f32)
         self.g_c2a = torch.zeros(B, 128, *g[4], **f32)
@@ -128,7 +132,9 @@ class FlowNetCHeadEngine:
         cb = lambda n, s, p: ig.conv_backward_weights(self._conv(n).weight, s, p)
         bias = lambda n: self._conv(n).bias.detach().float().contiguous()
         # forward chain (FlowNetC.py:142-160)
-        fwd["conv_redir"] = plan(cw("conv_redir", 1, 0), self.c3a_p, 0, g[8], g[8], out_planes=self.in31, out_chunk0=0, bias=bias("conv_redir"))
+        if self.siamese:
+            fwd["conv_redir"] = plan(cw("conv_redir", 1, 0), self.c3a_p, 0, g[8], g[8], out_planes=self.in31, out_chunk0=0,
+                                     bias=bias("conv_redir"))
         fwd["conv3_1"] = plan(cw("conv3_1", 1, 1), self.in31, 0, g[8], g[8], out_planes=self.cat3, out_chunk0=0, bias=bias("conv3_1"))
         fwd["conv4"] = plan(cw("conv4", 2, 1), self.cat3, 0, g[16], g[16], out_planes=self.c4a, bias=bias("conv4"))
         fwd["conv4_1"] = plan(cw("conv4_1", 1, 1), self.c4a, 0, g[16], g[16], out_planes=self.cat4, out_chunk0=0, bias=bias("conv4_1"))
@@ -169,9 +175,12 @@ class FlowNetCHeadEngine:
         bwd["conv5"] = plan(cb("conv5", 2, 1), self.gz_c5a, 0, g[32], g[16], add=self.G_cat4, mask=self.cat4, out_planes=self.gz_cat4, **m64)
         bwd["conv4_1"] = plan(cb("conv4_1", 1, 1), self.gz_cat4, 0, g[16], g[16], mask=self.c4a, out_planes=self.gz_c4a)
         bwd["conv4"] = plan(cb("conv4", 2, 1), self.gz_c4a, 0, g[16], g[8], add=self.G_cat3, mask=self.cat3, out_planes=self.gz_cat3, **m64)
-        bwd["conv3_1"] = plan(cb("conv3_1", 1, 1), self.gz_cat3, 0, g[8], g[8], mask=self.in31, out_planes=self.gz_in31,
-                              out_f32=self.G_in31)
-        bwd["conv_redir"] = plan(cb("conv_redir", 1, 0), self.gz_in31, 0, g[8], g[8], out_f32=self.G_c3a)
+        if self.siamese:
+            bwd["conv3_1"] = plan(cb("conv3_1", 1, 1), self.gz_cat3, 0, g[8], g[8], mask=self.in31, out_planes=self.gz_in31,
+                                  out_f32=self.G_in31)
+            bwd["conv_redir"] = plan(cb("conv_redir", 1, 0), self.gz_in31, 0, g[8], g[8], out_f32=self.G_c3a)
+        else:                                   # the trunk's input IS conv3's activation: its gradient leaves unmasked
+            bwd["conv3_1"] = plan(cb("conv3_1", 1, 1), self.gz_cat3, 0, g[8], g[8], out_f32=self.G_in31)
         need = max([len(wi.phases) * S * B * rows[0] * rows[1] * wi.Npad for wi, _, _, rows, _, S, _ in plans if S > 1] + [1])
         self.ws = torch.empty(need, dtype=torch.float32, device=self.dev)
         launches = [ig.make_launch(wi, x, c0, rows, out_hw, splitk=S, ws=self.ws if S > 1 else None, **kw)
@@ -436,9 +445,11 @@ class FlowNetCHeadEngine:
             return ig.make_launch(wi, x, c0, rows_b, out_hw, splitk=Sb, ws=self.ws if Sb > 1 else None, **kw, **extra)
 
         for name, (ls_rows, _) in self._FWD_BAND.items():
-            self.fwd_band[name] = derive("fwd", name, ls_rows, None)       # forward inputs are valid everywhere
+            if ("fwd", name) in self._plans:
+                self.fwd_band[name] = derive("fwd", name, ls_rows, None)   # forward inputs are valid everywhere
         for name, (ls_rows, ls_in) in self._BWD_BAND.items():
-            self.bwd_band[name] = derive("bwd", name, ls_rows, ls_in)
+            if ("bwd", name) in self._plans:
+                self.bwd_band[name] = derive("bwd", name, ls_rows, ls_in)
 
     def launch_table(self):
         """Every prepared igemm launch with its algorithmic work, for bench.py's per-kernel rooflines:
@@ -508,6 +519,21 @@ class FlowNetCHeadEngine:
                                           Gs.M, chunks, ig.LEAKY, L.stream()), "gradient finalize")
 
     # ------------------------------------------------------------------------------------------------ the schedule
+    def _forward_trunk(self, c2: torch.Tensor, c3: torch.Tensor) -> torch.Tensor:
+        """FlowNetS: (conv2 [B,128,H/4,W/4], conv3 [B,256,H/8,W/8]) -> flow2; conv3_1 reads conv3 directly."""
+        L.require_hip(c2, "c2")
+        L.require_hip(c3, "c3")
+        self.cat2.load_nchw(c2, 0)
+        self.in31.load_nchw(c3, 0)
+        for name in ("conv3_1", "conv4", "conv4_1", "conv5", "conv5_1", "conv6", "conv6_1"):
+            self.fwd[name]()
+        self._pf_forward(6)
+        for k in (5, 4, 3, 2):
+            self._up_forward(k + 1)
+            self.fwd[f"deconv{k}"]()
+            self._pf_forward(k)
+        return self.flow[2]
+
     def forward_cached(self, band=None) -> torch.Tensor:
         """`forward` on the features the engine already holds (prefix_full / load_prefix_features + scatter_window_features)."""
         return self.forward(None, self._c3a, self._c3b, band)
@@ -519,6 +545,8 @@ class FlowNetCHeadEngine:
         still hold the previous iteration's activations everywhere else."""
         from . import spatial_correlation_sampler_backend as correlation
         import ctypes as C
+        if not self.siamese:
+            return self._forward_trunk(c2a, c3a)
         for t, name in ((c3a, "c3a"), (c3b, "c3b")):
             L.require_hip(t, name)
         self._c3a, self._c3b = c3a, c3b
@@ -597,6 +625,11 @@ class FlowNetCHeadEngine:
         self._pf_backward(6, self.g_flow[6], accumulate=False)      # G_c6 = predict_flow6^T; deconv5's adjoint adds to it
         for name in ("deconv5", "conv6_1", "conv6", "conv5_1"):
             self.bwd[name]()
+        if not self.siamese:                    # FlowNetS trunk: conv3_1's data gradient IS d/d conv3
+            for name in ("conv5", "conv4_1", "conv4", "conv3_1"):
+                self.bwd[name]()
+            self.G_in31.to_nchw(256, 0, out=self.g_c3a)
+            return self.g_c2a, self.g_c3a, None
         for name in ("conv5", "conv4_1", "conv4", "conv3_1", "conv_redir"):
             (self.bwd_band if banded else self.bwd)[name]()
         # conv_redir's input and the correlation's two inputs
@@ -638,7 +671,7 @@ class _EngineHead(torch.autograd.Function):
     def forward(ctx, c2a, c3a, c3b, engine, band):
         ctx.engine, ctx.band = engine, band
         # the engine's flow2 is a static buffer: hand autograd its own (2-channel, tiny) tensor
-        return engine.forward(c2a.contiguous(), c3a.contiguous(), c3b.contiguous(), band).clone()
+        return engine.forward(c2a.contiguous(), c3a.contiguous(), c3b.contiguous() if c3b is not None else None, band).clone()
 
     @staticmethod
     def backward(ctx, g_flow2):

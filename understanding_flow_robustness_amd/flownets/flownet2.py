@@ -48,6 +48,15 @@ class _Refinement(nn.Module):
         for name in ("upsampled_flow6_to_5", "upsampled_flow5_to_4", "upsampled_flow4_to_3", "upsampled_flow3_to_2"):
             setattr(self, name, FlowUpsample(2, 2, 4, 2, 1, bias=up_bias))
 
+    def _engine_ok(self, c2a) -> bool:
+        """Frozen parameters, eval mode, HIP float32 features, frame sides that are multiples of 64 (UFR_ENGINE=0 switches off)."""
+        import os
+        if os.environ.get("UFR_ENGINE", "1") != "1" or os.environ.get("UFR_ENGINE_FLOWNET2", "1") != "1" or self.training:
+            return False
+        frozen = not any(p.requires_grad for p in self.parameters())
+        return (c2a.is_cuda and c2a.dtype == torch.float32 and (frozen or not torch.is_grad_enabled())
+                and c2a.shape[2] % 16 == 0 and c2a.shape[3] % 16 == 0)
+
     def _refine(self, c6, skips):
         """skips = (conv5, conv4, conv3, conv2) features; returns flow2."""
         flow = self.predict_flow6(c6)
@@ -74,15 +83,6 @@ class FlowNetC(_Refinement):
             setattr(self, name, _conv(cin, cout, k, s))
         self._build_refinement(up_bias=True)
         _xavier(self)
-
-    def _engine_ok(self, c2a) -> bool:
-        """Frozen parameters, eval mode, HIP float32 features, frame sides that are multiples of 64 (UFR_ENGINE=0 switches off)."""
-        import os
-        if os.environ.get("UFR_ENGINE", "1") != "1" or os.environ.get("UFR_ENGINE_FLOWNET2", "1") != "1" or self.training:
-            return False
-        frozen = not any(p.requires_grad for p in self.parameters())
-        return (c2a.is_cuda and c2a.dtype == torch.float32 and (frozen or not torch.is_grad_enabled())
-                and c2a.shape[2] % 16 == 0 and c2a.shape[3] % 16 == 0)
 
     def forward(self, x):
         B = x.shape[0]
@@ -120,6 +120,9 @@ class FlowNetS(_Refinement):
 
     def forward(self, x):
         c2 = self.conv2(self.conv1(x))
+        if self._engine_ok(c2):                # everything behind conv3 on the native head (trunk form: no correlation)
+            from ..flownetc_engine import engine_head
+            return (engine_head(self, c2.contiguous(), self.conv3(c2).contiguous(), None),)
         c3 = self.conv3_1(self.conv3(c2))
         c4 = self.conv4_1(self.conv4(c3))
         c5 = self.conv5_1(self.conv5(c4))
