@@ -393,7 +393,7 @@ int ufr_host_png_unfilter(const unsigned char* data, unsigned char* out, int row
  * (models/submodules.py:18-46 `conv`, :75-82 `deconv`) that torch runs on MIOpen -- forward AND data gradient -- without
  * the activations leaving the device layout between layers.
  *   activation planes: bf16 [3][chunks][M][32], M = B*H*W pixels, 32 channels per chunk (v = p0 + p1 + p2 exactly);
- *   weights:           bf16 [3][taps*KC][Npad][32] per phase, pre-split; Npad a multiple of 64 (128-column tiles when it is
+ *   weights:           bf16 [3][taps*KC][Npad][32] per phase (K tiles ordered as `k_order` says), pre-split; Npad a multiple of 64 (128-column tiles when it is
  *                      a multiple of 128, 64-column tiles otherwise);
  *   gradient sums:     f32 [chunks][M][32].
  * The tile rows are the cells (b, y, x) of a row grid [B,Hr,Wr] (x offset per sample by row_x0[b*row_x0_stride] /
@@ -430,7 +430,10 @@ typedef struct {
   float* out_f32; int out_f32_chunk0;
   int splitk; float* ws;
   int products;                                /* 6 (float32-accurate); 3 / 1 for measurements only */
-  int variant;                                 /* 0 = default (LDS-DMA staging; UFR_IGEMM=reg selects 1), 1 = register-staged, 2 = LDS-DMA */
+  int variant;                                 /* 0 = default (LDS-DMA staging; UFR_IGEMM=reg selects 1), 1 = register-staged, 2 = LDS-DMA,
+                                                  3 = 256 x 128 tiles, 4 = 64 x 128 tiles, 5 = LDS-DMA with register-held fragments */
+  int k_order;                                 /* order of the K tiles in the weight image of a phase: 0 = [taps][KC] (tap-major),
+                                                  1 = [KC][taps] (the taps of one channel chunk back to back: L2 reuse of the pixels) */
 } ufr_igemm_desc;
 int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream);
 /* Layout passes at the engine's edges.  ufr_nchw_to_planes: planes[chunk0 + c/32] = split(leaky(scale * x[B,C,H,W]))

@@ -165,15 +165,17 @@ def _unclamped_lr(net, mask, B, H, W, shared):
 
 def _same_update(pf, pc, p0, sel, what):
     """Two implementations of the same multi-iteration attack.  From the second iteration on a one-ulp
-    difference (MIOpen's split-K data gradients are not bit-reproducible) can flip a LeakyReLU somewhere and
-    move the gradient entries behind it by a few 1e-4 of the largest update, so: at least 95% of the patch
-    pixels agree to 1e-4 of the update and every pixel to 1e-2 (a misplaced window or band is off by O(1); three
-    iterations of two different fp32 summation orders were seen at 8e-3 once, 6e-7 typically)."""
+    difference can flip a LeakyReLU somewhere and move the gradient entries behind it, so: at least 95% of the patch
+    pixels agree to 1e-4 of the update and every pixel to 5e-2 (a misplaced window or band is off by O(1)).
+    The control (tools/diag_step_chaos.py, profiles/r2_step_chaos_control.txt): two FULL-FRAME steps that differ only in
+    the igemm kernel's summation order agree to 2.4e-7 after one iteration and drift to 7.8e-3 / 1.5e-2 of the update on
+    ~1% of one placement's pixels after two / three, while the windowed step stays within 5e-7 of the full-frame step
+    that sums in its order."""
     upd = float(((pf - p0) * sel).abs().max())
     err = ((pf - pc) * sel).abs()
     assert 1e-3 < upd < 1.9, f"{what}: test lr leaves the update degenerate ({upd})"
     off = float((err > 1e-4 * upd + 1e-6).sum()) / max(float((sel != 0).sum()), 1.0)
-    worst = 1e-2 if _engine_on() else 3e-2       # MIOpen's split-K data gradients (UFR_ENGINE=0) are not bit-reproducible
+    worst = 5e-2
     assert off <= 0.05 and float(err.max()) <= worst * upd, \
         f"{what}: {off:.2%} of the patch pixels differ by more than 1e-4, worst {float(err.max()) / upd:.2e} of the update"
     return upd

@@ -62,7 +62,7 @@ class IgemmDesc(C.Structure):
                 ("out_planes", C.c_void_p), ("out_plane_stride", C.c_long), ("out_chunk0", C.c_int),
                 ("out_f32", C.c_void_p), ("out_f32_chunk0", C.c_int),
                 ("splitk", C.c_int), ("ws", C.c_void_p),
-                ("products", C.c_int), ("variant", C.c_int)]
+                ("products", C.c_int), ("variant", C.c_int), ("k_order", C.c_int)]
 
 
 UFR_MAX_CONE_LAYERS = 8

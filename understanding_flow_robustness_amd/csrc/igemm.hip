@@ -174,6 +174,7 @@ struct Args {
   RowGeom g;
   Epilogue e;
   int nphase, splitk, xcd;
+  int korder;                        // K tile kt = tap * KC + chunk (0) or chunk * ntaps + tap (1: a pixel's taps back to back)
   int per_k, sk[4], zoff[4];         // K tiles per slice; slices of each phase; first slice (z) of each phase
   float* ws;                         // split-K slabs [sum of sk][M][Npad]
   Phase ph[4];
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const __bf16* gx = a.x + (long)a.in_chunk0 * cstride + sch * 8;
   const int soff0 = srow0 * BK + ((sch ^ ((srow0 >> 1) & 3)) << 3);
   // running state of the K loop
-  int tap = kt0 / KC, kc = kt0 - tap * KC;
+  int tap = a.korder ? kt0 % ph.ntaps : kt0 / KC, kc = a.korder ? kt0 / ph.ntaps : kt0 - tap * KC;
   const __bf16* wp = a.w + ph.w_off + ((long)kt0 * a.Npad + bn + srow0) * BK + sch * 8;
   const long wstep = (long)a.Npad * BK;
   const __bf16* xk = gx + (long)kc * cstride;
@@ -322,11 +323,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int p = 0; p < NPL; ++p) sb[p][i] = *reinterpret_cast<const u32x4*>(wp + p * a.w_plane_stride + (long)(64 * i) * BK);
     wp += wstep;
-    xk += cstride;
-    if (++kc == KC) {
-      kc = 0;
-      xk = gx;
-      if (++tap < ph.ntaps) set_tap(tap);
+    if (a.korder) {                  // the taps of one channel chunk back to back: their pixels overlap, so they hit in L2
+      if (++tap == ph.ntaps) {
+        tap = 0;
+        xk += cstride;
+      }
+      set_tap(tap);
+    } else {
+      xk += cstride;
+      if (++kc == KC) {
+        kc = 0;
+        xk = gx;
+        if (++tap < ph.ntaps) set_tap(tap);
+      }
     }
   };
   auto store_tile = [&]() {
@@ -394,8 +403,13 @@ __device__ __forceinline__ void glds16(const __bf16* src, __bf16* lds_wave_base)
 
 // BM_ x BN_ tiles: 128 x 128 (waves 2 x 2 of 64 x 64), 128 x 64 (waves 4 x 1 of 32 x 64: layers with <= 64 outputs), and
 // 64 x 128 (waves 2 x 2 of 32 x 64; 36 KB of LDS: FOUR workgroups per CU, twice the workgroups for the mid-size layers).
-template <int BM_, int BN_>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM_ == 64 ? 4 : 3, BM_ == 64 ? 4 : 3))) void igemm_glds_kernel(const Args a) {
+//
+// PIPE_ (variant 5): the same single LDS stage, but a K step first moves ALL of its fragments into registers (24 ds_read_b128
+// per wave, 96 VGPRs), and the DMA of the NEXT K tile is issued into the stage before the 96 MFMAs instead of after them, so
+// the L2 round trip runs under the matrix work of the same workgroup instead of relying on two other workgroups to cover
+// it.  ~210 VGPRs: two workgroups per CU.
+template <int BM_, int BN_, bool PIPE_ = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE_ ? 2 : (BM_ == 64 ? 4 : 3), PIPE_ ? 2 : (BM_ == 64 ? 4 : 3)))) void igemm_glds_kernel(const Args a) {
   constexpr int NPL = 3, FIRST = 0;
   constexpr int MT = (BN_ == 128 && BM_ == 128) ? 4 : 2;
   constexpr int BPT = BN_ / 64, APT = BM_ / 64;
@@ -439,7 +453,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM_ == 64 ?
   }
   const __bf16* gx = a.x + (long)a.in_chunk0 * cstride + csw * 8;
   const __bf16* zero = reinterpret_cast<const __bf16*>(ufr_zero_page);
-  int tap = kt0 / KC, kc = kt0 - tap * KC;
+  int tap = a.korder ? kt0 % ph.ntaps : kt0 / KC, kc = a.korder ? kt0 / ph.ntaps : kt0 - tap * KC;
   const __bf16* wp = a.w + ph.w_off + ((long)kt0 * a.Npad + bn + srow0) * BK + csw * 8;
   const long wstep = (long)a.Npad * BK;
   const __bf16* xk = gx + (long)kc * cstride;
@@ -469,11 +483,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM_ == 64 ?
       for (int p = 0; p < NPL; ++p)
         glds16(wp + p * a.w_plane_stride + (long)(64 * i) * BK, &ldsB[p][(64 * i + wave * 16) * BK]);
     wp += wstep;
-    xk += cstride;
-    if (++kc == KC) {
-      kc = 0;
-      xk = gx;
-      if (++tap < ph.ntaps) set_tap(tap);
+    if (a.korder) {                  // the taps of one channel chunk back to back: their pixels overlap, so they hit in L2
+      if (++tap == ph.ntaps) {
+        tap = 0;
+        xk += cstride;
+      }
+      set_tap(tap);
+    } else {
+      xk += cstride;
+      if (++kc == KC) {
+        kc = 0;
+        xk = gx;
+        if (++tap < ph.ntaps) set_tap(tap);
+      }
     }
   };
 
@@ -486,6 +508,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM_ == 64 ?
   const int foff = frow * BK + ((((lane >> 4)) ^ ((frow >> 1) & 3)) << 3);
 
   if (kt0 < kt1) set_tap(tap);
+  if constexpr (PIPE_) {
+    if (kt0 < kt1) stage_tile();
+    for (int kt = kt0; kt < kt1; ++kt) {
+      __syncthreads();               // vmcnt(0) + barrier: K tile kt has landed for every wave
+      bf16x8 fa[NPL][MT], fb[4][NPL];
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) fa[p][m] = *reinterpret_cast<const bf16x8*>(&ldsA[p][(wrow + m * 16) * BK + foff]);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) fb[n][p] = *reinterpret_cast<const bf16x8*>(&ldsB[p][(wcol + n * 16) * BK + foff]);
+      }
+      __syncthreads();               // lgkmcnt(0) + barrier: every wave holds its fragments, the stage is free
+      if (kt + 1 < kt1) stage_tile();                  // in flight under this tile's MFMAs
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int t = FIRST; t < 6; ++t)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[t]][m], fb[n][PROD_B[t]], acc[m][n], 0, 0, 0);
+    }
+  } else
   for (int kt = kt0; kt < kt1; ++kt) {
     __syncthreads();                 // every wave has read the previous tile's fragments
     stage_tile();
@@ -561,7 +606,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   const __bf16* gx = a.x + (long)a.in_chunk0 * cstride + csw * 8;
   const __bf16* zero = reinterpret_cast<const __bf16*>(ufr_zero_page);
-  int tap = kt0 / KC, kc = kt0 - tap * KC;
+  int tap = a.korder ? kt0 % ph.ntaps : kt0 / KC, kc = a.korder ? kt0 / ph.ntaps : kt0 - tap * KC;
   const __bf16* wp = a.w + ph.w_off + ((long)kt0 * a.Npad + bn + srow0) * BK + csw * 8;
   const long wstep = (long)a.Npad * BK;
   const __bf16* xk = gx + (long)kc * cstride;
@@ -592,11 +637,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int p = 0; p < NPL; ++p)
         glds16(wp + p * a.w_plane_stride + (long)(64 * i) * BK, sB + p * (BN * BK) + (64 * i + wave * 16) * BK);
     wp += wstep;
-    xk += cstride;
-    if (++kc == KC) {
-      kc = 0;
-      xk = gx;
-      if (++tap < ph.ntaps) set_tap(tap);
+    if (a.korder) {                  // the taps of one channel chunk back to back: their pixels overlap, so they hit in L2
+      if (++tap == ph.ntaps) {
+        tap = 0;
+        xk += cstride;
+      }
+      set_tap(tap);
+    } else {
+      xk += cstride;
+      if (++kc == KC) {
+        kc = 0;
+        xk = gx;
+        if (++tap < ph.ntaps) set_tap(tap);
+      }
     }
   };
 
@@ -927,6 +980,7 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   a.nphase = d->nphase; a.splitk = d->splitk; a.ws = d->ws;
   static const int xcd_order = [] { const char* e = getenv("UFR_IGEMM_XCD"); return e && e[0] == '0' ? 0 : 1; }();
   a.xcd = xcd_order;
+  a.korder = d->k_order ? 1 : 0;
   for (int z = 0; z < 4; ++z) {
     const ufr_igemm_phase& p = d->phase[z < d->nphase ? z : 0];
     UFR_REQUIRE(p.ntaps >= 1 && p.ntaps <= UFR_IGEMM_MAX_TAPS && p.w_off >= 0, "igemm: bad phase %d", z);
@@ -951,10 +1005,10 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   const dim3 grid(d->Npad / bn, (unsigned)((M + BM - 1) / BM), nz);
   static const int default_variant = [] {
     const char* e = getenv("UFR_IGEMM");
-    return e && e[0] == 'r' ? 1 : (e && e[0] == 'b' ? 3 : (e && e[0] == 'm' ? 4 : 2));    // reg | big | m64 | (default) glds
+    return e && e[0] == 'r' ? 1 : (e && e[0] == 'b' ? 3 : (e && e[0] == 'm' ? 4 : (e && e[0] == 'p' ? 5 : 2)));   // reg | big | m64 | pipe | (default) glds
   }();
   const int variant = d->variant ? d->variant : default_variant;        // 1 = register-staged, 2 = LDS-DMA staging, 3 = 256 x 128 tiles
-  UFR_REQUIRE(variant >= 1 && variant <= 4, "igemm: unknown kernel variant %d", variant);
+  UFR_REQUIRE(variant >= 1 && variant <= 5, "igemm: unknown kernel variant %d", variant);
   if (variant == 3 && d->products == 6 && bn == BN) {
     static bool raised = false;
     if (!raised) {
@@ -968,6 +1022,8 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   } else if (variant == 4 && d->products == 6 && bn == BN) {       // 64 x 128 tiles: four workgroups per CU
     const dim3 g64(d->Npad / BN, (unsigned)((M + 63) / 64), nz);
     igemm_glds_kernel<64, 128><<<g64, 256, 0, st>>>(a);
+  } else if (variant == 5 && d->products == 6 && bn == BN) {       // register-held fragments, DMA of the next tile under the MFMAs
+    igemm_glds_kernel<128, 128, true><<<grid, 256, 0, st>>>(a);
   } else if (variant >= 2 && d->products == 6) {
     if (bn == BN) igemm_glds_kernel<128, 128><<<grid, 256, 0, st>>>(a);
     else igemm_glds_kernel<128, 64><<<grid, 256, 0, st>>>(a);

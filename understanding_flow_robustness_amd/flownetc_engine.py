@@ -110,9 +110,10 @@ class FlowNetCHeadEngine:
         def plan(wi, x, in_chunk0, rows, out_hw, **kw):
             M = B * rows[0] * rows[1]
             pk = [len(t) * wi.KC for _, _, t in wi.phases]
-            m64 = kw.get("variant") == 4       # 64 x 128 tiles, four workgroups per CU
-            S = ig.splitk_for(M, wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=64 if m64 else 128,
-                              target=1024 if m64 else 768)
+            if self._pipe and not small_batch:
+                kw.setdefault("variant", 5)
+            bm, target = self._tile_rows_and_slots(wi, kw)
+            S = ig.splitk_for(M, wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target)
             if small_batch and "variant" not in kw:
                 kw["variant"] = 4                  # (split factor as sized for 128-row tiles: the measured combination)
             plans.append((wi, x, in_chunk0, rows, out_hw, S, kw))
@@ -121,6 +122,10 @@ class FlowNetCHeadEngine:
         # one pair (the reference's own batch size): every launch is under-filled and 64 x 128 tiles with four workgroups per
         # CU measured 10 % faster for the whole iteration (1.75 -> 1.59 ms; equal at two pairs, slower from four on)
         small_batch = self._small_batch = B == 1 and os.environ.get("UFR_IGEMM") is None
+        # 128 x 128 launches: csrc/igemm.hip variant 5 (fragments held in registers, the DMA of the next K tile under the
+        # MFMAs; two workgroups per CU) -- with the chunk-major K order 8-17 % faster per layer than three single-stage
+        # workgroups per CU (profiles/r2_igemm_layers_v5_pipe_korder.txt).  UFR_IGEMM_PIPE=0: the round's earlier default
+        self._pipe = os.environ.get("UFR_IGEMM_PIPE", "1") != "0" and os.environ.get("UFR_IGEMM") is None
 
         # 64 x 128 tiles (csrc/igemm.hip variant 4, four workgroups per CU): 7-19 % faster on the stride-2 data gradients and
         # deconv3's in the isolated per-layer bench (profiles/r2_igemm_layers_v4_tile64.jsonl), neutral to slightly slower
@@ -205,6 +210,16 @@ class FlowNetCHeadEngine:
         self.up_G = {6: (self.G_cat5, 32), 5: (self.G_cat4, 24), 4: (self.G_cat3, 12), 3: (self.G_cat2, 6)}
 
     # ------------------------------------------------------------------------------------------------ conv1-3
+    @staticmethod
+    def _tile_rows_and_slots(wi, kw):
+        """(tile rows, resident workgroups on the chip) of the kernel a launch runs on: what split-K is sized against."""
+        v = kw.get("variant", 0)
+        if v == 4:
+            return 64, 1024                    # 64 x 128 tiles, four workgroups per CU
+        if v == 5 and wi.Npad % 128 == 0:
+            return 128, 512                    # register-held fragments: two workgroups per CU
+        return 128, 768
+
     def _build_prefix(self):
         """Full-frame conv1-3 for both frames of every pair (models/FlowNetC.py:100-119), run once per attack() call:
         conv1 (3 input channels: a 147-deep reduction, torch / MIOpen) with bias + LeakyReLU fused into the conversion to
@@ -222,7 +237,7 @@ class FlowNetCHeadEngine:
         v64 = 4 if os.environ.get("UFR_IGEMM_M64_PREFIX", "1") != "0" else 0
         l2 = ig.make_launch(w2, c1, 0, (H // 4, W // 4), (H // 4, W // 4), out_planes=c2, bias=bias("conv2"), variant=v64)
         l3 = ig.make_launch(w3, c2, 0, (H // 8, W // 8), (H // 8, W // 8), out_planes=c3, bias=bias("conv3"),
-                            variant=4 if getattr(self, "_small_batch", False) else 0)
+                            variant=4 if getattr(self, "_small_batch", False) else (5 if self._pipe else 0))
         self._prefix = dict(c1=c1, c2=c2, c3=c3, conv2=l2, conv3=l3, conv2_wi=w2, conv3_wi=w3, b1=bias("conv1"),
                             w1=self._conv("conv1").weight.detach())
         self._prefix.update(self._conv1_launch(B2, H, W, c1))
@@ -344,7 +359,10 @@ class FlowNetCHeadEngine:
         sized = []
         for wi, x, rows, out_hw, kw in plans:
             pk = [len(t) * wi.KC for _, _, t in wi.phases]
-            sized.append(ig.splitk_for(B2 * rows[0] * rows[1], wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk))
+            if self._pipe and not getattr(self, "_small_batch", False):
+                kw.setdefault("variant", 5)
+            bm, target = self._tile_rows_and_slots(wi, kw) if kw.get("variant") == 5 else (128, 768)
+            sized.append(ig.splitk_for(B2 * rows[0] * rows[1], wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target))
         need = max([len(wi.phases) * S * B2 * rows[0] * rows[1] * wi.Npad for (wi, _, rows, _, _), S in zip(plans, sized) if S > 1] + [1])
         ws = torch.empty(need, **f32)
         if getattr(self, "_small_batch", False):
@@ -438,8 +456,8 @@ class FlowNetCHeadEngine:
                 extra["in_band"] = (origin, 8, ls_in, band.width // ls_in)
             M = self.B * rows_b[0] * rows_b[1]
             pk = [len(t) * wi.KC for _, _, t in wi.phases]
-            v4 = kw.get("variant") == 4 and not self._small_batch
-            Sb = ig.splitk_for(M, wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=64 if v4 else 128, target=1024 if v4 else 768)
+            bm, target = (128, 768) if self._small_batch else self._tile_rows_and_slots(wi, kw)
+            Sb = ig.splitk_for(M, wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target)
             if len(wi.phases) * Sb * M * wi.Npad > self.ws.numel():
                 Sb = 1
             return ig.make_launch(wi, x, c0, rows_b, out_hw, splitk=Sb, ws=self.ws if Sb > 1 else None, **kw, **extra)

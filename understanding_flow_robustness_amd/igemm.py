@@ -7,6 +7,7 @@ during an attack), everything else is descriptors over device pointers.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -86,6 +87,7 @@ class WeightImage:
         self.N, self.Npad, self.KC = N, Npad, KC
         self.C = C if C is not None else KC * 32          # real input channels (KC*32 includes the chunk padding)
         self.geometry = geometry        # dict(in_s, out_s): strides of the row grid -> input / output pixels
+        self.k_order = K_ORDER          # how _pack ordered the K tiles
 
     def flops(self, rows: int) -> float:
         """Algorithmic FLOPs of one launch over `rows` tile rows: 2 * rows * taps * Cin * Cout, real channel counts."""
@@ -102,6 +104,12 @@ def _split3(w: torch.Tensor) -> torch.Tensor:
     return torch.stack((p0, p1, p2)).contiguous()
 
 
+# Order of a phase's K tiles (ufr_igemm_desc.k_order).  1: all taps of one 32-channel chunk, then the next chunk -- a tile's
+# taps read overlapping pixels, so eight of nine reads of a 3x3 layer hit in L2 instead of streaming the activation again
+# per tap.  UFR_IGEMM_KORDER=0 restores the tap-major order (A/B); the image and the descriptor always agree.
+K_ORDER = int(os.environ.get("UFR_IGEMM_KORDER", "1") != "0")
+
+
 def _pack(mats, device):
     """mats[z] = float32 [N, taps, C] (output channel, tap, input channel) per phase -> WeightImage arrays."""
     images, offsets, total = [], [], 0
@@ -111,7 +119,10 @@ def _pack(mats, device):
         taps = m.shape[1]
         w = torch.zeros(npad, taps, cpad, dtype=torch.float32, device=device)
         w[:N, :, :Cn] = m
-        img = w.view(npad, taps * cpad // 32, 32).permute(1, 0, 2).contiguous().view(-1)        # [taps*KC][Npad][32]
+        if K_ORDER:                      # [KC][taps][Npad][32]: the taps of a channel chunk are consecutive K tiles
+            img = w.view(npad, taps, cpad // 32, 32).permute(2, 1, 0, 3).contiguous().view(-1)
+        else:                            # [taps][KC][Npad][32]
+            img = w.view(npad, taps * cpad // 32, 32).permute(1, 0, 2).contiguous().view(-1)
         offsets.append(total)
         total += img.numel()
         images.append(img)
@@ -300,6 +311,7 @@ def make_launch(wi: WeightImage, x: Planes, in_chunk0: int, rows_hw, out_hw, *, 
             raise RuntimeError(f"igemm: split-K workspace of {need} floats needed")
         d.ws = ws.data_ptr()
     d.products = int(products)
+    d.k_order = int(wi.k_order)
     d.variant = int(variant)               # 0 = library default, 1 = register-staged kernel, 2 = LDS-DMA kernel
     return Launch(d, keep)
 
