@@ -111,7 +111,7 @@ class FlowNetCHeadEngine:
             M = B * rows[0] * rows[1]
             pk = [len(t) * wi.KC for _, _, t in wi.phases]
             if self._pipe and not small_batch:
-                kw.setdefault("variant", 5)
+                kw.setdefault("variant", self._pipe_variant)
             bm, target = self._tile_rows_and_slots(wi, kw)
             S = ig.splitk_for(M, wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target)
             if small_batch and "variant" not in kw:
@@ -126,6 +126,7 @@ class FlowNetCHeadEngine:
         # MFMAs; two workgroups per CU) -- with the chunk-major K order 8-17 % faster per layer than three single-stage
         # workgroups per CU (profiles/r2_igemm_layers_v5_pipe_korder.txt).  UFR_IGEMM_PIPE=0: the round's earlier default
         self._pipe = os.environ.get("UFR_IGEMM_PIPE", "1") != "0" and os.environ.get("UFR_IGEMM") is None
+        self._pipe_variant = 6 if os.environ.get("UFR_IGEMM_PIPE") == "6" else 5      # 6: one activation image (A/B)
 
         # 64 x 128 tiles (csrc/igemm.hip variant 4, four workgroups per CU): 7-19 % faster on the stride-2 data gradients and
         # deconv3's in the isolated per-layer bench (profiles/r2_igemm_layers_v4_tile64.jsonl), neutral to slightly slower
@@ -216,7 +217,7 @@ class FlowNetCHeadEngine:
         v = kw.get("variant", 0)
         if v == 4:
             return 64, 1024                    # 64 x 128 tiles, four workgroups per CU
-        if v == 5 and wi.Npad % 128 == 0:
+        if v in (5, 6) and wi.Npad % 128 == 0:
             return 128, 512                    # register-held fragments: two workgroups per CU
         return 128, 768
 
@@ -237,7 +238,7 @@ class FlowNetCHeadEngine:
         v64 = 4 if os.environ.get("UFR_IGEMM_M64_PREFIX", "1") != "0" else 0
         l2 = ig.make_launch(w2, c1, 0, (H // 4, W // 4), (H // 4, W // 4), out_planes=c2, bias=bias("conv2"), variant=v64)
         l3 = ig.make_launch(w3, c2, 0, (H // 8, W // 8), (H // 8, W // 8), out_planes=c3, bias=bias("conv3"),
-                            variant=4 if getattr(self, "_small_batch", False) else (5 if self._pipe else 0))
+                            variant=4 if getattr(self, "_small_batch", False) else (self._pipe_variant if self._pipe else 0))
         self._prefix = dict(c1=c1, c2=c2, c3=c3, conv2=l2, conv3=l3, conv2_wi=w2, conv3_wi=w3, b1=bias("conv1"),
                             w1=self._conv("conv1").weight.detach())
         self._prefix.update(self._conv1_launch(B2, H, W, c1))
@@ -360,8 +361,8 @@ class FlowNetCHeadEngine:
         for wi, x, rows, out_hw, kw in plans:
             pk = [len(t) * wi.KC for _, _, t in wi.phases]
             if self._pipe and not getattr(self, "_small_batch", False):
-                kw.setdefault("variant", 5)
-            bm, target = self._tile_rows_and_slots(wi, kw) if kw.get("variant") == 5 else (128, 768)
+                kw.setdefault("variant", self._pipe_variant)
+            bm, target = self._tile_rows_and_slots(wi, kw) if kw.get("variant") in (5, 6) else (128, 768)
             sized.append(ig.splitk_for(B2 * rows[0] * rows[1], wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target))
         need = max([len(wi.phases) * S * B2 * rows[0] * rows[1] * wi.Npad for (wi, _, rows, _, _), S in zip(plans, sized) if S > 1] + [1])
         ws = torch.empty(need, **f32)
