@@ -404,19 +404,20 @@ __device__ __forceinline__ void glds16(const __bf16* src, __bf16* lds_wave_base)
 // BM_ x BN_ tiles: 128 x 128 (waves 2 x 2 of 64 x 64), 128 x 64 (waves 4 x 1 of 32 x 64: layers with <= 64 outputs), and
 // 64 x 128 (waves 2 x 2 of 32 x 64; 36 KB of LDS: FOUR workgroups per CU, twice the workgroups for the mid-size layers).
 //
-// PIPE_ (variant 5): the same single LDS stage, but a K step first moves ALL of its fragments into registers (24 ds_read_b128
-// per wave, 96 VGPRs), and the DMA of the NEXT K tile is issued into the stage before the 96 MFMAs instead of after them, so
-// the L2 round trip runs under the matrix work of the same workgroup instead of relying on two other workgroups to cover
-// it.  ~210 VGPRs: two workgroups per CU.
-template <int BM_, int BN_, int PIPE_ = 0>
+// PIPE_ (variant 5, the engine's default for 128 x 128 launches): a K step moves ALL of its fragments into registers first
+// (24 ds_read_b128 per wave, 96 VGPRs), so the DMA of the NEXT K tile can be issued before the 96 MFMAs instead of after
+// them and the L2 round trip runs under the matrix work of the same workgroup -- the plain form relies on two other
+// workgroups to cover it.  A second activation image (72 KB of LDS) gives the operand that misses L2 a whole step to
+// arrive.  ~210 VGPRs: two workgroups per CU.  Measured on one box (profiles/r2_igemm_layers_v5_*.txt): 8-17 % per layer.
+template <int BM_, int BN_, bool PIPE_ = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE_ ? 2 : (BM_ == 64 ? 4 : 3), PIPE_ ? 2 : (BM_ == 64 ? 4 : 3)))) void igemm_glds_kernel(const Args a) {
   constexpr int NPL = 3, FIRST = 0;
   constexpr int MT = (BN_ == 128 && BM_ == 128) ? 4 : 2;
   constexpr int BPT = BN_ / 64, APT = BM_ / 64;
   constexpr int STAGE = NPL * (BM_ + BN_) * BK;       // elements of one (A, B) stage; PIPE_ appends a second A image
-  __shared__ __attribute__((aligned(16))) __bf16 lds_static[PIPE_ == 2 ? 8 : STAGE];
+  __shared__ __attribute__((aligned(16))) __bf16 lds_static[PIPE_ ? 8 : STAGE];
   extern __shared__ __attribute__((aligned(16))) __bf16 lds_dynamic[];
-  __bf16* lds_all = PIPE_ == 2 ? lds_dynamic : lds_static;
+  __bf16* lds_all = PIPE_ ? lds_dynamic : lds_static;
   __bf16 (*ldsA)[BM_ * BK] = reinterpret_cast<__bf16 (*)[BM_ * BK]>(lds_all);
   __bf16 (*ldsB)[BN_ * BK] = reinterpret_cast<__bf16 (*)[BN_ * BK]>(lds_all + NPL * BM_ * BK);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -517,29 +518,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE_ ? 2 :
   const int foff = frow * BK + ((((lane >> 4)) ^ ((frow >> 1) & 3)) << 3);
 
   if (kt0 < kt1) set_tap(tap);
-  if constexpr (PIPE_ == 1) {
-    if (kt0 < kt1) stage_tile();
-    for (int kt = kt0; kt < kt1; ++kt) {
-      __syncthreads();               // vmcnt(0) + barrier: K tile kt has landed for every wave
-      bf16x8 fa[NPL][MT], fb[4][NPL];
-#pragma unroll
-      for (int p = 0; p < NPL; ++p) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) fa[p][m] = *reinterpret_cast<const bf16x8*>(&ldsA[p][(wrow + m * 16) * BK + foff]);
-#pragma unroll
-        for (int n = 0; n < 4; ++n) fb[n][p] = *reinterpret_cast<const bf16x8*>(&ldsB[p][(wcol + n * 16) * BK + foff]);
-      }
-      __syncthreads();               // lgkmcnt(0) + barrier: every wave holds its fragments, the stage is free
-      if (kt + 1 < kt1) stage_tile();                  // in flight under this tile's MFMAs
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int t = FIRST; t < 6; ++t)
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[t]][m], fb[n][PROD_B[t]], acc[m][n], 0, 0, 0);
-    }
-  } else if constexpr (PIPE_ == 2) {
+  if constexpr (PIPE_) {
     // two activation images (the second behind the stage), one weight image.  Step kt: [all DMA landed, barrier] -> DMA of
     // A(kt + 1) into the other image (its last readers finished before the previous step's second barrier) -> 24 fragment
     // reads -> [barrier] -> DMA of B(kt + 1) over B(kt) -> 96 MFMAs.  The activation rows -- the operand that misses L2 --
@@ -552,7 +531,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE_ ? 2 :
       const int cur = (kt - kt0) & 1;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (kt + 1 < kt1) stage_A(cur ? 0 : STAGE);
+      __builtin_amdgcn_s_setprio(2); // the read phase is the exposed one: ahead of the other workgroup's MFMA stream
       const __bf16* sA = lds_all + (cur ? STAGE : 0);
       bf16x8 fa[NPL][MT], fb[4][NPL];
 #pragma unroll
@@ -562,9 +541,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE_ ? 2 :
 #pragma unroll
         for (int n = 0; n < 4; ++n) fb[n][p] = *reinterpret_cast<const bf16x8*>(&ldsB[p][(wcol + n * 16) * BK + foff]);
       }
+      if (kt + 1 < kt1) stage_A(cur ? 0 : STAGE);                  // (its address arithmetic under the reads' latency)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // every wave holds its fragments: the weight image is free
       if (kt + 1 < kt1) stage_B();
+      __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int n = 0; n < 4; ++n)
 #pragma unroll
@@ -1052,7 +1033,7 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
     return e && e[0] == 'r' ? 1 : (e && e[0] == 'b' ? 3 : (e && e[0] == 'm' ? 4 : (e && e[0] == 'p' ? 5 : 2)));   // reg | big | m64 | pipe | (default) glds
   }();
   const int variant = d->variant ? d->variant : default_variant;        // 1 = register-staged, 2 = LDS-DMA staging, 3 = 256 x 128 tiles
-  UFR_REQUIRE(variant >= 1 && variant <= 6, "igemm: unknown kernel variant %d", variant);
+  UFR_REQUIRE(variant >= 1 && variant <= 5, "igemm: unknown kernel variant %d", variant);
   if (variant == 3 && d->products == 6 && bn == BN) {
     static bool raised = false;
     if (!raised) {
@@ -1066,17 +1047,15 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   } else if (variant == 4 && d->products == 6 && bn == BN) {       // 64 x 128 tiles: four workgroups per CU
     const dim3 g64(d->Npad / BN, (unsigned)((M + 63) / 64), nz);
     igemm_glds_kernel<64, 128><<<g64, 256, 0, st>>>(a);
-  } else if (variant == 6 && d->products == 6 && bn == BN) {       // variant 5 without the second activation image (A/B)
-    igemm_glds_kernel<128, 128, 1><<<grid, 256, 0, st>>>(a);
   } else if (variant == 5 && d->products == 6 && bn == BN) {       // register-held fragments, DMA of the next tile under the MFMAs
     static bool raised5 = false;
     if (!raised5) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_glds_kernel<128, 128, 2>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_glds_kernel<128, 128, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS_BYTES);
       if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "igemm: %s", hipGetErrorString(e));
       raised5 = true;
     }
-    igemm_glds_kernel<128, 128, 2><<<grid, 256, PIPE_LDS_BYTES, st>>>(a);
+    igemm_glds_kernel<128, 128, true><<<grid, 256, PIPE_LDS_BYTES, st>>>(a);
   } else if (variant >= 2 && d->products == 6) {
     if (bn == BN) igemm_glds_kernel<128, 128><<<grid, 256, 0, st>>>(a);
     else igemm_glds_kernel<128, 64><<<grid, 256, 0, st>>>(a);
