@@ -1048,12 +1048,14 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
     const dim3 g64(d->Npad / BN, (unsigned)((M + 63) / 64), nz);
     igemm_glds_kernel<64, 128><<<g64, 256, 0, st>>>(a);
   } else if (variant == 5 && d->products == 6 && bn == BN) {       // register-held fragments, DMA of the next tile under the MFMAs
-    static bool raised5 = false;
-    if (!raised5) {
+    static bool raised5[64] = {};          // per device: a process may drive more than one
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ufr::fail(UFR_ELAUNCH, "igemm: no current device");
+    if (!raised5[dev]) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_glds_kernel<128, 128, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS_BYTES);
       if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "igemm: %s", hipGetErrorString(e));
-      raised5 = true;
+      raised5[dev] = true;
     }
     igemm_glds_kernel<128, 128, true><<<grid, 256, PIPE_LDS_BYTES, st>>>(a);
   } else if (variant >= 2 && d->products == 6) {

@@ -235,9 +235,9 @@ class FlowNetCHeadEngine:
         bias = lambda n: self._conv(n).bias.detach().float().contiguous()
         w2 = ig.conv_forward_weights(self._conv("conv2").weight, 2, 2)
         w3 = ig.conv_forward_weights(self._conv("conv3").weight, 2, 2)
-        # conv2 (K = 25 taps x 2 chunks) runs 14 % faster on 64 x 128 tiles, four workgroups per CU (1.35 -> 1.19 ms at 2 x 8
-        # frames; conv3 and every large head layer prefer 128 x 128: profiles/r2_bench_m64_all_launches.txt)
-        v64 = 4 if os.environ.get("UFR_IGEMM_M64_PREFIX", "1") != "0" else 0
+        # conv2 (K = 25 taps x 2 chunks) at 2 x 8 frames: 1.35 ms on single-stage 128 x 128 tiles, 1.02-1.05 on 64 x 128 tiles
+        # (four workgroups per CU), 0.99-1.00 on the pipelined 128 x 128 kernel; conv3 and every large head layer prefer 128 x 128
+        v64 = self._pipe_variant if self._pipe else (4 if os.environ.get("UFR_IGEMM_M64_PREFIX", "1") != "0" else 0)
         l2 = ig.make_launch(w2, c1, 0, (H // 4, W // 4), (H // 4, W // 4), out_planes=c2, bias=bias("conv2"), variant=v64)
         l3 = ig.make_launch(w3, c2, 0, (H // 8, W // 8), (H // 8, W // 8), out_planes=c3, bias=bias("conv3"),
                             variant=4 if getattr(self, "_small_batch", False) else (self._pipe_variant if self._pipe else 0))
@@ -339,7 +339,7 @@ class FlowNetCHeadEngine:
         c1, c2, c3 = ig.Planes(B2, h2, w2, 2, dev), ig.Planes(B2, h4, w4, 4, dev), ig.Planes(B2, h8, w8, 8, dev)
         gz_c3, gz_c2 = ig.Planes(B2, h8, w8, 8, dev), ig.Planes(B2, h4, w4, 4, dev)
         conv1_native = os.environ.get("UFR_CONV1_IGEMM", "1") != "0"
-        v64 = 4 if os.environ.get("UFR_IGEMM_M64_PREFIX", "1") != "0" else 0
+        v64 = 4 if os.environ.get("UFR_IGEMM_M64_PREFIX", "1") != "0" else (self._pipe_variant if self._pipe else 0)   # (0.047 vs 0.055 ms)
         gz_c1, G_p = ig.Planes(B2, h2, w2, 2, dev), ig.GradSum(B2, h2 + 3, w2 + 2, 1, dev)
         G_gw2, G_c1 = ig.GradSum(B2, h4, w4, 4, dev), ig.GradSum(B2, h2, w2, 2, dev)   # G_gw2: the conv2 tap's window gradient
                                                                                        # (first frames; second frames stay 0)
