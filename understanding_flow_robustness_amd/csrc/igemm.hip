@@ -582,6 +582,165 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE_ ? 2 :
 }
 constexpr int PIPE_LDS_BYTES = (3 * (128 + 128) * BK + 3 * 128 * BK) * 2;     // one stage + the second activation image
 
+// ---- ping-pong form (variant 6): 256 x 128 tiles, EIGHT waves = two groups of four, one workgroup per CU -----------------
+// Group g owns rows [128 g, 128 g + 128) of the tile (each wave 64 x 64, as in the pipelined kernel) and runs the same two
+// half-steps -- READ (24 fragment reads into registers, DMA of its next activation image; group 0 also the next weight
+// image) and MFMA (96 MFMAs) -- but half a step behind the other group, so that on every SIMD (which holds one wave of each
+// group) one wave multiplies while the other reads: what two independent pipelined workgroups per CU do when their phases
+// happen to alternate, here by construction.  One s_barrier of the whole workgroup separates the half-steps.  LDS: two
+// activation images per group + two weight images = 6 x 24 KB = 144 KB; every DMA has a whole MFMA half-step to land.
+//   barrier #   1        2        3        4
+//   group 0   | READ 0 | MFMA 0 | READ 1 | MFMA 1 | ...
+//   group 1   | (idle) | READ 0 | MFMA 0 | READ 1 | ...
+// weight image (k + 1) & 1 is refilled by group 0 in READ k: its last readers were group 0's READ k - 1 and group 1's READ
+// k - 1, one and two half-steps earlier, both closed by a barrier.
+constexpr int PP_IMG = 3 * 128 * BK;                                      // elements of one 128-row image (3 planes): 24 KB
+constexpr int PP_LDS_BYTES = 6 * PP_IMG * 2;
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm_pp_kernel(const Args a) {
+  constexpr int NPL = 3, MT = 4;
+  extern __shared__ __attribute__((aligned(16))) __bf16 lds_pp[];
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);      // wave-uniform: scalar control flow
+  const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * 64;
+  int tx, ty, z;
+  xcd_tile(a.xcd, tx, ty, z);
+  const int bm = ty * 256 + grp * 128, bn = tx * BN;
+  int phase = 0;
+#pragma unroll
+  for (int p = 1; p < 4; ++p)
+    if (p < a.nphase && z >= a.zoff[p]) phase = p;
+  const int ks = z - a.zoff[phase];
+  const Phase& ph = a.ph[phase];
+  const int KC = a.KC, KT = ph.ntaps * KC;
+  const int kt0 = ks * a.per_k, kt1 = min(KT, kt0 + a.per_k);
+  const int nk = max(kt1 - kt0, 0);
+  const long Min = (long)a.g.B * a.Hi * a.Wi;
+  const long cstride = Min * 32;
+
+  const int srow0 = tid >> 2, sch = tid & 3;
+  const int csw = sch ^ ((srow0 >> 1) & 3);
+  int yb[2], xb[2], xlo[2], xhi[2];
+  long ibase[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pm = bm + srow0 + 64 * i;
+    const int hw = a.g.Hr * a.g.Wr;
+    const int b = pm / hw, r = pm - b * hw, yr = r / a.g.Wr, xr = r - yr * a.g.Wr;
+    const bool live = pm < a.g.M;
+    const int bb = live ? b : 0;
+    const int xg = xr + (a.g.row_x0 ? a.g.row_x0[bb * a.g.row_x0_stride] / a.g.row_x0_div : 0);
+    yb[i] = live ? yr * a.in_sy : -(1 << 20);
+    xb[i] = xg * a.in_sx;
+    ibase[i] = (long)bb * a.Hi * a.Wi;
+    xlo[i] = a.in_x0 ? a.in_x0[bb * a.in_x0_stride] / a.in_x0_div : 0;
+    xhi[i] = a.in_x0 ? min(a.Wi, xlo[i] + a.in_xw) : a.Wi;
+    xlo[i] = max(xlo[i], 0);
+  }
+  const __bf16* gx = a.x + (long)a.in_chunk0 * cstride + csw * 8;
+  const __bf16* zero = reinterpret_cast<const __bf16*>(ufr_zero_page);
+  int tap = a.korder ? kt0 % ph.ntaps : kt0 / KC, kc = a.korder ? kt0 / ph.ntaps : kt0 - tap * KC;
+  const __bf16* wp = a.w + ph.w_off + ((long)kt0 * a.Npad + bn + srow0) * BK + csw * 8;
+  const long wstep = (long)a.Npad * BK;
+  const __bf16* xk = gx + (long)kc * cstride;
+  bool ok[2];
+  long aoff[2];
+  auto set_tap = [&](int t) {
+    const int dyx = ph.dyx[t], dyo = (int)(short)(dyx & 0xffff), dxo = dyx >> 16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int yi = yb[i] + dyo, xi = xb[i] + dxo;
+      ok[i] = (unsigned)yi < (unsigned)a.Hi && xi >= xlo[i] && xi < xhi[i];
+      aoff[i] = ok[i] ? (ibase[i] + (long)yi * a.Wi + xi) * 32 : 0;
+    }
+  };
+  const int imgA0 = grp * 2 * PP_IMG, imgB0 = 4 * PP_IMG;                 // element offsets: A[grp][0..1], B[0..1]
+  auto stage_A = [&](int img) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) {
+        const __bf16* src = ok[i] ? xk + aoff[i] + p * a.x_plane_stride : zero;
+        glds16(src, lds_pp + img + p * (128 * BK) + (64 * i + wave * 16) * BK);
+      }
+    if (a.korder) {
+      if (++tap == ph.ntaps) {
+        tap = 0;
+        xk += cstride;
+      }
+      set_tap(tap);
+    } else {
+      xk += cstride;
+      if (++kc == KC) {
+        kc = 0;
+        xk = gx;
+        if (++tap < ph.ntaps) set_tap(tap);
+      }
+    }
+  };
+  auto stage_B = [&](int img) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p)
+        glds16(wp + p * a.w_plane_stride + (long)(64 * i) * BK, lds_pp + img + p * (128 * BK) + (64 * i + wave * 16) * BK);
+    wp += wstep;
+  };
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15;
+  const int foff = frow * BK + ((((lane >> 4)) ^ ((frow >> 1) & 3)) << 3);
+
+  if (nk > 0) {
+    set_tap(tap);
+    stage_A(imgA0);
+    if (grp == 0) stage_B(imgB0);
+  }
+  if (grp == 1) {                    // half a step behind group 0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  for (int i = 0; i < nk; ++i) {
+    const int cur = i & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // my DMAs of the previous READ have landed ...
+    __builtin_amdgcn_s_barrier();                                         // ... and everybody else's
+    // ---- READ half-step
+    __builtin_amdgcn_s_setprio(2);
+    const __bf16* sA = lds_pp + imgA0 + cur * PP_IMG;
+    const __bf16* sB = lds_pp + imgB0 + cur * PP_IMG;
+    bf16x8 fa[NPL][MT], fb[4][NPL];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) fa[p][m] = *reinterpret_cast<const bf16x8*>(sA + p * (128 * BK) + (wrow + m * 16) * BK + foff);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) fb[n][p] = *reinterpret_cast<const bf16x8*>(sB + p * (128 * BK) + (wcol + n * 16) * BK + foff);
+    }
+    if (i + 1 < nk) {
+      stage_A(imgA0 + (cur ^ 1) * PP_IMG);
+      if (grp == 0) stage_B(imgB0 + (cur ^ 1) * PP_IMG);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- MFMA half-step (the other group reads)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[t]][m], fb[n][PROD_B[t]], acc[m][n], 0, 0, 0);
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();                             // group 1's extra barrier at the start
+  static_assert(4 * 32 * 68 * 4 <= 2 * PP_IMG * 2, "epilogue staging does not fit a group's activation images");
+  igemm_write_out<NPL, MT>(a, ph, acc, reinterpret_cast<float*>(lds_pp + imgA0), z, bm, bn, wrow, wcol, lane, wave);
+}
+
 // ---- the 256 x 128 tile form: ONE workgroup per CU, the overlap inside the workgroup ---------------------------------
 // Same operands, addressing, swizzle and epilogue as igemm_glds_kernel<128>, but a workgroup owns 256 rows (each wave 128 x
 // 64: 8 x 4 accumulator tiles, ~250 VGPRs at one wave per SIMD) and TWO LDS stages of 72 KB: the DMA of K tile k + 1 is
@@ -1033,7 +1192,7 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
     return e && e[0] == 'r' ? 1 : (e && e[0] == 'b' ? 3 : (e && e[0] == 'm' ? 4 : (e && e[0] == 'p' ? 5 : 2)));   // reg | big | m64 | pipe | (default) glds
   }();
   const int variant = d->variant ? d->variant : default_variant;        // 1 = register-staged, 2 = LDS-DMA staging, 3 = 256 x 128 tiles
-  UFR_REQUIRE(variant >= 1 && variant <= 5, "igemm: unknown kernel variant %d", variant);
+  UFR_REQUIRE(variant >= 1 && variant <= 6, "igemm: unknown kernel variant %d", variant);
   if (variant == 3 && d->products == 6 && bn == BN) {
     static bool raised = false;
     if (!raised) {
@@ -1047,6 +1206,18 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   } else if (variant == 4 && d->products == 6 && bn == BN) {       // 64 x 128 tiles: four workgroups per CU
     const dim3 g64(d->Npad / BN, (unsigned)((M + 63) / 64), nz);
     igemm_glds_kernel<64, 128><<<g64, 256, 0, st>>>(a);
+  } else if (variant == 6 && d->products == 6 && bn == BN) {       // ping-pong: 256 x 128 tiles, two wave groups half a step apart
+    static bool raised6[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ufr::fail(UFR_ELAUNCH, "igemm: no current device");
+    if (!raised6[dev]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         PP_LDS_BYTES);
+      if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "igemm: %s", hipGetErrorString(e));
+      raised6[dev] = true;
+    }
+    const dim3 gpp(d->Npad / BN, (unsigned)((M + 255) / 256), nz);
+    igemm_pp_kernel<<<gpp, 512, PP_LDS_BYTES, st>>>(a);
   } else if (variant == 5 && d->products == 6 && bn == BN) {       // register-held fragments, DMA of the next tile under the MFMAs
     static bool raised5[64] = {};          // per device: a process may drive more than one
     int dev = 0;

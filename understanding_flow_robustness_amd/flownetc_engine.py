@@ -128,7 +128,7 @@ class FlowNetCHeadEngine:
         # MFMAs; two workgroups per CU) -- with the chunk-major K order 8-17 % faster per layer than three single-stage
         # workgroups per CU (profiles/r2_igemm_layers_v5_pipe_korder.txt).  UFR_IGEMM_PIPE=0: the round's earlier default
         self._pipe = os.environ.get("UFR_IGEMM_PIPE", "1") != "0" and os.environ.get("UFR_IGEMM") is None
-        self._pipe_variant = 5
+        self._pipe_variant = 5 if os.environ.get("UFR_IGEMM_PIPE") == "5" else 6      # 6: ping-pong (256 x 128 tiles, two wave groups half a step apart)
 
         # 64 x 128 tiles (csrc/igemm.hip variant 4, four workgroups per CU): 7-19 % faster on the stride-2 data gradients and
         # deconv3's in the isolated per-layer bench (profiles/r2_igemm_layers_v4_tile64.jsonl), neutral to slightly slower
@@ -221,6 +221,8 @@ class FlowNetCHeadEngine:
             return 64, 1024                    # 64 x 128 tiles, four workgroups per CU
         if v == 5 and wi.Npad % 128 == 0:
             return 128, 512                    # register-held fragments: two workgroups per CU
+        if v == 6 and wi.Npad % 128 == 0:
+            return 256, 256                    # ping-pong: one 256-row workgroup per CU
         return 128, 768
 
     def _build_prefix(self):
@@ -364,7 +366,7 @@ class FlowNetCHeadEngine:
             pk = [len(t) * wi.KC for _, _, t in wi.phases]
             if self._pipe and not getattr(self, "_small_batch", False):
                 kw.setdefault("variant", self._pipe_variant)
-            bm, target = self._tile_rows_and_slots(wi, kw) if kw.get("variant") == 5 else (128, 768)
+            bm, target = self._tile_rows_and_slots(wi, kw) if kw.get("variant") in (5, 6) else (128, 768)
             sized.append(ig.splitk_for(B2 * rows[0] * rows[1], wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target))
         need = max([len(wi.phases) * S * B2 * rows[0] * rows[1] * wi.Npad for (wi, _, rows, _, _), S in zip(plans, sized) if S > 1] + [1])
         ws = torch.empty(need, **f32)
