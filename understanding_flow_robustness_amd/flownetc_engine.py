@@ -124,9 +124,9 @@ class FlowNetCHeadEngine:
         # (since the pipelined 128 x 128 kernel: 1.59 ms with 64 x 128 tiles, 1.56 ms without -> opt-in, UFR_IGEMM_SMALL_BATCH=1)
         small_batch = self._small_batch = (B == 1 and os.environ.get("UFR_IGEMM") is None
                                            and os.environ.get("UFR_IGEMM_SMALL_BATCH", "0") == "1")
-        # 128 x 128 launches: csrc/igemm.hip variant 5 (fragments held in registers, the DMA of the next K tile under the
-        # MFMAs; two workgroups per CU) -- with the chunk-major K order 8-17 % faster per layer than three single-stage
-        # workgroups per CU (profiles/r2_igemm_layers_v5_pipe_korder.txt).  UFR_IGEMM_PIPE=0: the round's earlier default
+        # 128-column launches: csrc/igemm.hip variant 6 (ping-pong: 256 x 128 tiles, two wave groups of one workgroup per CU half a
+        # step apart) or 5 (pipelined 128 x 128, two workgroups per CU; UFR_IGEMM_PIPE=5) instead of the single-stage kernel
+        # (UFR_IGEMM_PIPE=0).  Same box, one iteration: 6.27 / 6.56 / 6.88 ms (profiles/r2_bench_pingpong_ab.txt)
         self._pipe = os.environ.get("UFR_IGEMM_PIPE", "1") != "0" and os.environ.get("UFR_IGEMM") is None
         self._pipe_variant = 5 if os.environ.get("UFR_IGEMM_PIPE") == "5" else 6      # 6: ping-pong (256 x 128 tiles, two wave groups half a step apart)
 
