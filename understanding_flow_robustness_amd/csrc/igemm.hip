@@ -595,17 +595,20 @@ constexpr int PIPE_LDS_BYTES = (3 * (128 + 128) * BK + 3 * 128 * BK) * 2;     //
 // weight image (k + 1) & 1 is refilled by group 0 in READ k: its last readers were group 0's READ k - 1 and group 1's READ
 // k - 1, one and two half-steps earlier, both closed by a barrier.
 constexpr int PP_IMG = 3 * 128 * BK;                                      // elements of one 128-row image (3 planes): 24 KB
-constexpr int PP_LDS_BYTES = 6 * PP_IMG * 2;
+constexpr int pp_lds_bytes(int bn) { return (4 * PP_IMG + 2 * 3 * bn * BK) * 2; }
 
+// BN_ = 128: a group's waves 2 x 2 of 64 x 64; BN_ = 64 (layers with <= 64 outputs): 4 x 1 of 32 x 64, 12 KB weight images
+template <int BN_>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm_pp_kernel(const Args a) {
-  constexpr int NPL = 3, MT = 4;
+  constexpr int NPL = 3, MT = BN_ == 128 ? 4 : 2, BPT = BN_ / 64;
+  constexpr int PP_IMG_B = NPL * BN_ * BK;
   extern __shared__ __attribute__((aligned(16))) __bf16 lds_pp[];
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);      // wave-uniform: scalar control flow
-  const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * 64;
+  const int wrow = BN_ == 128 ? (wave >> 1) * 64 : wave * 32, wcol = BN_ == 128 ? (wave & 1) * 64 : 0;
   int tx, ty, z;
   xcd_tile(a.xcd, tx, ty, z);
-  const int bm = ty * 256 + grp * 128, bn = tx * BN;
+  const int bm = ty * 256 + grp * 128, bn = tx * BN_;
   int phase = 0;
 #pragma unroll
   for (int p = 1; p < 4; ++p)
@@ -680,10 +683,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   };
   auto stage_B = [&](int img) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < BPT; ++i)
 #pragma unroll
       for (int p = 0; p < NPL; ++p)
-        glds16(wp + p * a.w_plane_stride + (long)(64 * i) * BK, lds_pp + img + p * (128 * BK) + (64 * i + wave * 16) * BK);
+        glds16(wp + p * a.w_plane_stride + (long)(64 * i) * BK, lds_pp + img + p * (BN_ * BK) + (64 * i + wave * 16) * BK);
     wp += wstep;
   };
 
@@ -711,18 +714,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // ---- READ half-step
     __builtin_amdgcn_s_setprio(2);
     const __bf16* sA = lds_pp + imgA0 + cur * PP_IMG;
-    const __bf16* sB = lds_pp + imgB0 + cur * PP_IMG;
+    const __bf16* sB = lds_pp + imgB0 + cur * PP_IMG_B;
     bf16x8 fa[NPL][MT], fb[4][NPL];
 #pragma unroll
     for (int p = 0; p < NPL; ++p) {
 #pragma unroll
       for (int m = 0; m < MT; ++m) fa[p][m] = *reinterpret_cast<const bf16x8*>(sA + p * (128 * BK) + (wrow + m * 16) * BK + foff);
 #pragma unroll
-      for (int n = 0; n < 4; ++n) fb[n][p] = *reinterpret_cast<const bf16x8*>(sB + p * (128 * BK) + (wcol + n * 16) * BK + foff);
+      for (int n = 0; n < 4; ++n) fb[n][p] = *reinterpret_cast<const bf16x8*>(sB + p * (BN_ * BK) + (wcol + n * 16) * BK + foff);
     }
     if (i + 1 < nk) {
       stage_A(imgA0 + (cur ^ 1) * PP_IMG);
-      if (grp == 0) stage_B(imgB0 + (cur ^ 1) * PP_IMG);
+      if (grp == 0) stage_B(imgB0 + (cur ^ 1) * PP_IMG_B);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_setprio(0);
@@ -1206,18 +1209,22 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   } else if (variant == 4 && d->products == 6 && bn == BN) {       // 64 x 128 tiles: four workgroups per CU
     const dim3 g64(d->Npad / BN, (unsigned)((M + 63) / 64), nz);
     igemm_glds_kernel<64, 128><<<g64, 256, 0, st>>>(a);
-  } else if (variant == 6 && d->products == 6 && bn == BN) {       // ping-pong: 256 x 128 tiles, two wave groups half a step apart
+  } else if (variant == 6 && d->products == 6) {       // ping-pong: 256-row tiles, two wave groups half a step apart
     static bool raised6[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ufr::fail(UFR_ELAUNCH, "igemm: no current device");
     if (!raised6[dev]) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         PP_LDS_BYTES);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_pp_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         pp_lds_bytes(128));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_pp_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                pp_lds_bytes(64));
       if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "igemm: %s", hipGetErrorString(e));
       raised6[dev] = true;
     }
-    const dim3 gpp(d->Npad / BN, (unsigned)((M + 255) / 256), nz);
-    igemm_pp_kernel<<<gpp, 512, PP_LDS_BYTES, st>>>(a);
+    const dim3 gpp(d->Npad / bn, (unsigned)((M + 255) / 256), nz);
+    if (bn == BN) igemm_pp_kernel<128><<<gpp, 512, pp_lds_bytes(128), st>>>(a);
+    else igemm_pp_kernel<64><<<gpp, 512, pp_lds_bytes(64), st>>>(a);
   } else if (variant == 5 && d->products == 6 && bn == BN) {       // register-held fragments, DMA of the next tile under the MFMAs
     static bool raised5[64] = {};          // per device: a process may drive more than one
     int dev = 0;

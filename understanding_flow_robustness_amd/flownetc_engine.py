@@ -111,7 +111,7 @@ class FlowNetCHeadEngine:
             M = B * rows[0] * rows[1]
             pk = [len(t) * wi.KC for _, _, t in wi.phases]
             if self._pipe and not small_batch:
-                kw.setdefault("variant", self._pipe_variant)
+                kw.setdefault("variant", self._pipe_variant if wi.Npad % 128 == 0 or self._pp64 else 2)
             bm, target = self._tile_rows_and_slots(wi, kw)
             S = ig.splitk_for(M, wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target)
             if small_batch and "variant" not in kw:
@@ -128,6 +128,10 @@ class FlowNetCHeadEngine:
         # step apart) or 5 (pipelined 128 x 128, two workgroups per CU; UFR_IGEMM_PIPE=5) instead of the single-stage kernel
         # (UFR_IGEMM_PIPE=0).  Same box, one iteration: 6.27 / 6.56 / 6.88 ms (profiles/r2_bench_pingpong_ab.txt)
         self._pipe = os.environ.get("UFR_IGEMM_PIPE", "1") != "0" and os.environ.get("UFR_IGEMM") is None
+        # 64-column launches (deconv2 forward, conv1, conv_redir) stay on the single-stage kernel: the ping-pong form with 12 KB
+        # weight images measured slower there (deconv2 forward 0.29-0.30 against 0.26 ms, conv1 of the prefix 0.57 against 0.48:
+        # 48 MFMAs per wave and half-step do not cover a group's read half-step).  UFR_IGEMM_PP64=1 switches it on (A/B)
+        self._pp64 = os.environ.get("UFR_IGEMM_PP64", "0") == "1"
         self._pipe_variant = 5 if os.environ.get("UFR_IGEMM_PIPE") == "5" else 6      # 6: ping-pong (256 x 128 tiles, two wave groups half a step apart)
 
         # 64 x 128 tiles (csrc/igemm.hip variant 4, four workgroups per CU): 7-19 % faster on the stride-2 data gradients and
@@ -221,7 +225,7 @@ class FlowNetCHeadEngine:
             return 64, 1024                    # 64 x 128 tiles, four workgroups per CU
         if v == 5 and wi.Npad % 128 == 0:
             return 128, 512                    # register-held fragments: two workgroups per CU
-        if v == 6 and wi.Npad % 128 == 0:
+        if v == 6:
             return 256, 256                    # ping-pong: one 256-row workgroup per CU
         return 128, 768
 
@@ -256,7 +260,8 @@ class FlowNetCHeadEngine:
         packed = ig.Planes(n, H // 2 + 3, W // 2 + 2, 1, self.dev)
         wi = ig.conv1_packed_weights(self._conv("conv1").weight)
         launch = ig.make_launch(wi, packed, 0, (H // 2, W // 2), (H // 2, W // 2), out_planes=c1,
-                                bias=self._conv("conv1").bias.detach().float().contiguous())
+                                bias=self._conv("conv1").bias.detach().float().contiguous(),
+                                variant=int(os.environ.get("UFR_CONV1_VARIANT", "0")))
         return dict(packed=packed, conv1=launch, conv1_wi=wi)
 
     def _conv1(self, P: dict, a: torch.Tensor, b: torch.Tensor | None):
