@@ -370,7 +370,7 @@ class FlowNetCHeadEngine:
         for wi, x, rows, out_hw, kw in plans:
             pk = [len(t) * wi.KC for _, _, t in wi.phases]
             if self._pipe and not getattr(self, "_small_batch", False):
-                kw.setdefault("variant", self._pipe_variant)
+                kw.setdefault("variant", self._pipe_variant if wi.Npad % 128 == 0 or self._pp64 else 2)
             bm, target = self._tile_rows_and_slots(wi, kw) if kw.get("variant") in (5, 6) else (128, 768)
             sized.append(ig.splitk_for(B2 * rows[0] * rows[1], wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target))
         need = max([len(wi.phases) * S * B2 * rows[0] * rows[1] * wi.Npad for (wi, _, rows, _, _), S in zip(plans, sized) if S > 1] + [1])
