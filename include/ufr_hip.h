@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define UFR_ABI_VERSION 2
+#define UFR_ABI_VERSION 3   /* 3: ufr_igemm_desc gained k_order (round 2) */
 
 enum { UFR_F32 = 0, UFR_F64 = 1 };
 enum {
