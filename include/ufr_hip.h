@@ -432,7 +432,8 @@ typedef struct {
   int products;                                /* 6 (float32-accurate); 3 / 1 for measurements only */
   int variant;                                 /* 0 = default (LDS-DMA staging; UFR_IGEMM=reg selects 1), 1 = register-staged, 2 = LDS-DMA,
                                                   3 = 256 x 128 tiles, 4 = 64 x 128 tiles, 5 = LDS-DMA with register-held fragments (pipelined),
-                                                  6 = ping-pong: 256 x 128 tiles, two wave groups half a step apart */
+                                                  6 = ping-pong: 256 x 128 tiles, two wave groups half a step apart,
+                                                  7 = 6 + horizontal runs of taps staged once (launches it does not cover run as 6) */
   int k_order;                                 /* order of the K tiles in the weight image of a phase: 0 = [taps][KC] (tap-major),
                                                   1 = [KC][taps] (the taps of one channel chunk back to back: L2 reuse of the pixels) */
 } ufr_igemm_desc;

@@ -24,7 +24,7 @@ class _Ig:
         return getattr(igemm, name)
 
 
-@pytest.fixture(autouse=True, params=[1, 2, 3, 4, 5, 6], ids=["register-staged", "lds-dma", "tile-256x128", "tile-64x128", "lds-dma-pipelined", "ping-pong"])
+@pytest.fixture(autouse=True, params=[1, 2, 3, 4, 5, 6, 7], ids=["register-staged", "lds-dma", "tile-256x128", "tile-64x128", "lds-dma-pipelined", "ping-pong", "ping-pong-tap-reuse"])
 def _variant(request):
     VARIANT["v"] = request.param
     yield

@@ -30,7 +30,7 @@ def timed(fn, iters=20):
 
 def main():
     only = set(a for a in sys.argv[1:] if not a.startswith("--"))
-    variants = (1, 2) if "--both" in sys.argv else ((2, 3) if "--big" in sys.argv else ((4, 2, 4, 2) if "--m64" in sys.argv else ((5, 2, 5, 2) if "--pipe" in sys.argv else ((6, 5, 6, 5) if "--pp" in sys.argv else (0,)))))
+    variants = (1, 2) if "--both" in sys.argv else ((2, 3) if "--big" in sys.argv else ((4, 2, 4, 2) if "--m64" in sys.argv else ((5, 2, 5, 2) if "--pipe" in sys.argv else ((6, 5, 6, 5) if "--pp" in sys.argv else ((7, 6, 7, 6) if "--pp3" in sys.argv else (0,))))))
     layers = [  # name, kind, Cin, Cout, k, stride, input grid (of the forward)
         ("conv3_1", "conv", 473, 256, 3, 1, (H8, W8)), ("conv4", "conv", 256, 512, 3, 2, (H8, W8)),
         ("conv4_1", "conv", 512, 512, 3, 1, (H8 // 2, W8 // 2)), ("conv5", "conv", 512, 512, 3, 2, (H8 // 2, W8 // 2)),
@@ -66,7 +66,7 @@ def main():
             ktiles = max(len(t) for _, _, t in wimg.phases) * wimg.KC
             S0 = ig.splitk_for(M, wimg.Npad, ktiles, len(wimg.phases))
             cands = sorted({1, S0}) if "--m64" not in sys.argv else sorted({1, max(1, S0 // 2), S0})
-            if "--pp" in sys.argv:         # ping-pong: one 256-row workgroup per CU
+            if "--pp" in sys.argv or "--pp3" in sys.argv:         # ping-pong: one 256-row workgroup per CU
                 cands = sorted({1, ig.splitk_for(M, wimg.Npad, ktiles, len(wimg.phases), target=512),
                                 ig.splitk_for(M, wimg.Npad, ktiles, len(wimg.phases), target=256, bm=256)})
             if "--pipe" in sys.argv:       # two workgroups per CU: 512 slots

@@ -132,7 +132,7 @@ class FlowNetCHeadEngine:
         # weight images measured slower there (deconv2 forward 0.29-0.30 against 0.26 ms, conv1 of the prefix 0.57 against 0.48:
         # 48 MFMAs per wave and half-step do not cover a group's read half-step).  UFR_IGEMM_PP64=1 switches it on (A/B)
         self._pp64 = os.environ.get("UFR_IGEMM_PP64", "0") == "1"
-        self._pipe_variant = 5 if os.environ.get("UFR_IGEMM_PIPE") == "5" else 6      # 6: ping-pong (256 x 128 tiles, two wave groups half a step apart)
+        self._pipe_variant = {"5": 5, "7": 7}.get(os.environ.get("UFR_IGEMM_PIPE"), 6)      # 6: ping-pong (256 x 128 tiles, two wave groups half a step apart)
 
         # 64 x 128 tiles (csrc/igemm.hip variant 4, four workgroups per CU): 7-19 % faster on the stride-2 data gradients and
         # deconv3's in the isolated per-layer bench (profiles/r2_igemm_layers_v4_tile64.jsonl), neutral to slightly slower
@@ -225,7 +225,7 @@ class FlowNetCHeadEngine:
             return 64, 1024                    # 64 x 128 tiles, four workgroups per CU
         if v == 5 and wi.Npad % 128 == 0:
             return 128, 512                    # register-held fragments: two workgroups per CU
-        if v == 6:
+        if v in (6, 7):
             return 256, 256                    # ping-pong: one 256-row workgroup per CU
         return 128, 768
 
@@ -371,7 +371,7 @@ class FlowNetCHeadEngine:
             pk = [len(t) * wi.KC for _, _, t in wi.phases]
             if self._pipe and not getattr(self, "_small_batch", False):
                 kw.setdefault("variant", self._pipe_variant if wi.Npad % 128 == 0 or self._pp64 else 2)
-            bm, target = self._tile_rows_and_slots(wi, kw) if kw.get("variant") in (5, 6) else (128, 768)
+            bm, target = self._tile_rows_and_slots(wi, kw) if kw.get("variant") in (5, 6, 7) else (128, 768)
             sized.append(ig.splitk_for(B2 * rows[0] * rows[1], wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target))
         need = max([len(wi.phases) * S * B2 * rows[0] * rows[1] * wi.Npad for (wi, _, rows, _, _), S in zip(plans, sized) if S > 1] + [1])
         ws = torch.empty(need, **f32)
