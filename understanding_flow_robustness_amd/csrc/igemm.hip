@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE_ ? 2 :
   __bf16* lds_all = PIPE_ ? lds_dynamic : lds_static;
   __bf16 (*ldsA)[BM_ * BK] = reinterpret_cast<__bf16 (*)[BM_ * BK]>(lds_all);
   __bf16 (*ldsB)[BN_ * BK] = reinterpret_cast<__bf16 (*)[BN_ * BK]>(lds_all + NPL * BM_ * BK);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wrow = BN_ == 128 ? (wave >> 1) * (BM_ / 2) : wave * 32, wcol = BN_ == 128 ? (wave & 1) * 64 : 0;
   int tx, ty, z;
   xcd_tile(a.xcd, tx, ty, z);
@@ -600,12 +600,17 @@ constexpr int PP_IMG = 3 * 128 * BK;                                      // ele
 constexpr int pp_lds_bytes(int bn) { return (4 * PP_IMG + 2 * 3 * bn * BK) * 2; }
 
 // BN_ = 128: a group's waves 2 x 2 of 64 x 64; BN_ = 64 (layers with <= 64 outputs): 4 x 1 of 32 x 64, 12 KB weight images
-template <int BN_>
+// BUF_: the activation rows come through a raw buffer resource (`buffer_load_dwordx4 ... lds`): a row outside the frame /
+// band gets an out-of-range offset and the hardware writes zeros -- no zero page, no 64-bit pointer select per plane, the
+// plane / chunk displacement in the scalar offset: ~20 instead of ~70 vector instructions per K step in the READ half-step,
+// which shares the SIMD's issue port with the other group's MFMA stream.
+template <int BN_, bool BUF_ = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm_pp_kernel(const Args a) {
   constexpr int NPL = 3, MT = BN_ == 128 ? 4 : 2, BPT = BN_ / 64;
   constexpr int PP_IMG_B = NPL * BN_ * BK;
   extern __shared__ __attribute__((aligned(16))) __bf16 lds_pp[];
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // wave-uniform: LDS destinations on the scalar unit
   const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);      // wave-uniform: scalar control flow
   const int wrow = BN_ == 128 ? (wave >> 1) * 64 : wave * 32, wcol = BN_ == 128 ? (wave & 1) * 64 : 0;
   int tx, ty, z;
@@ -650,13 +655,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const __bf16* xk = gx + (long)kc * cstride;
   bool ok[2];
   long aoff[2];
+  unsigned voff[2];                                                        // BUF_: byte offset of the row's piece, or out of range
+  const unsigned rowbase[2] = {(unsigned)(ibase[0] * 64 + csw * 16), (unsigned)(ibase[1] * 64 + csw * 16)};
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x), 0, (int)min(6L * a.x_plane_stride, 0x7fffffffL),
+                                                                   0x00020000);
+  long xkoff = (long)(a.in_chunk0 + kc) * cstride;                         // BUF_: elements from plane 0 to the current chunk
   auto set_tap = [&](int t) {
     const int dyx = ph.dyx[t], dyo = (int)(short)(dyx & 0xffff), dxo = dyx >> 16;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int yi = yb[i] + dyo, xi = xb[i] + dxo;
       ok[i] = (unsigned)yi < (unsigned)a.Hi && xi >= xlo[i] && xi < xhi[i];
-      aoff[i] = ok[i] ? (ibase[i] + (long)yi * a.Wi + xi) * 32 : 0;
+      if (BUF_) voff[i] = ok[i] ? rowbase[i] + (unsigned)(yi * a.Wi + xi) * 64u : 0x80000000u;
+      else aoff[i] = ok[i] ? (ibase[i] + (long)yi * a.Wi + xi) * 32 : 0;
     }
   };
   const int imgA0 = grp * 2 * PP_IMG, imgB0 = 4 * PP_IMG;                 // element offsets: A[grp][0..1], B[0..1]
@@ -665,20 +676,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int p = 0; p < NPL; ++p) {
-        const __bf16* src = ok[i] ? xk + aoff[i] + p * a.x_plane_stride : zero;
-        glds16(src, lds_pp + img + p * (128 * BK) + (64 * i + wave * 16) * BK);
+        if (BUF_) {
+          typedef __attribute__((address_space(3))) void* lds_void;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void)(lds_pp + img + p * (128 * BK) + (64 * i + wave * 16) * BK), 16, voff[i],
+                                                   (unsigned)((xkoff + p * a.x_plane_stride) * 2), 0, 0);
+        } else {
+          const __bf16* src = ok[i] ? xk + aoff[i] + p * a.x_plane_stride : zero;
+          glds16(src, lds_pp + img + p * (128 * BK) + (64 * i + wave * 16) * BK);
+        }
       }
     if (a.korder) {
       if (++tap == ph.ntaps) {
         tap = 0;
         xk += cstride;
+        xkoff += cstride;
       }
       set_tap(tap);
     } else {
       xk += cstride;
+      xkoff += cstride;
       if (++kc == KC) {
         kc = 0;
         xk = gx;
+        xkoff = (long)a.in_chunk0 * cstride;
         if (++tap < ph.ntaps) set_tap(tap);
       }
     }
@@ -763,7 +783,7 @@ constexpr int PP3_LDS_BYTES = (4 * PP3_IMG + 2 * PP_IMG) * 2;             // 159
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm_pp3_kernel(const Args a) {
   constexpr int NPL = 3, MT = 4;
   extern __shared__ __attribute__((aligned(16))) __bf16 lds_pp[];
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
   const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * 64;
   int tx, ty, z;
@@ -1436,6 +1456,17 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
       raised6[dev] = true;
     }
     const dim3 gpp(d->Npad / bn, (unsigned)((M + 255) / 256), nz);
+    static const bool buf = [] { const char* e = getenv("UFR_IGEMM_PP_BUF"); return !(e && e[0] == '0'); }();
+    if (bn == BN && buf && 6L * d->x_plane_stride < 0x7fffffffL) {   // activation rows through a buffer resource (planes < 2 GB)
+      static bool raisedb[64] = {};
+      if (!raisedb[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_pp_kernel<128, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, pp_lds_bytes(128));
+        if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "igemm: %s", hipGetErrorString(e));
+        raisedb[dev] = true;
+      }
+      igemm_pp_kernel<128, true><<<gpp, 512, pp_lds_bytes(128), st>>>(a);
+    } else
     if (bn == BN) igemm_pp_kernel<128><<<gpp, 512, pp_lds_bytes(128), st>>>(a);
     else igemm_pp_kernel<64><<<gpp, 512, pp_lds_bytes(64), st>>>(a);
   } else if (variant == 5 && d->products == 6 && bn == BN) {       // register-held fragments, DMA of the next tile under the MFMAs
