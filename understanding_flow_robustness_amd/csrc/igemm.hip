@@ -411,8 +411,10 @@ __device__ __forceinline__ void glds16(const __bf16* src, __bf16* lds_wave_base)
 // them and the L2 round trip runs under the matrix work of the same workgroup -- the plain form relies on two other
 // workgroups to cover it.  A second activation image (72 KB of LDS) gives the operand that misses L2 a whole step to
 // arrive.  ~210 VGPRs: two workgroups per CU.  Measured on one box (profiles/r2_igemm_layers_v5_*.txt): 8-17 % per layer.
-template <int BM_, int BN_, bool PIPE_ = false>
+// BUF_: activation rows through a raw buffer resource (see igemm_pp_kernel)
+template <int BM_, int BN_, bool PIPE_ = false, bool BUF_ = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE_ ? 2 : (BM_ == 64 ? 4 : 3), PIPE_ ? 2 : (BM_ == 64 ? 4 : 3)))) void igemm_glds_kernel(const Args a) {
+  static_assert(!(PIPE_ && BUF_), "the buffer-resource form exists for the single-stage kernel");
   constexpr int NPL = 3, FIRST = 0;
   constexpr int MT = (BN_ == 128 && BM_ == 128) ? 4 : 2;
   constexpr int BPT = BN_ / 64, APT = BM_ / 64;
@@ -465,13 +467,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE_ ? 2 :
   const __bf16* xk = gx + (long)kc * cstride;
   bool ok[APT];
   long aoff[APT];
+  unsigned voff[APT], rowbase[APT];
+#pragma unroll
+  for (int i = 0; i < APT; ++i) rowbase[i] = (unsigned)(ibase[i] * 64 + csw * 16);
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x), 0, (int)min(6L * a.x_plane_stride, 0x7fffffffL),
+                                                                   0x00020000);
+  long xkoff = (long)(a.in_chunk0 + kc) * cstride;
   auto set_tap = [&](int t) {
     const int dyx = ph.dyx[t], dyo = (int)(short)(dyx & 0xffff), dxo = dyx >> 16;
 #pragma unroll
     for (int i = 0; i < APT; ++i) {
       const int yi = yb[i] + dyo, xi = xb[i] + dxo;
       ok[i] = (unsigned)yi < (unsigned)a.Hi && xi >= xlo[i] && xi < xhi[i];
-      aoff[i] = ok[i] ? (ibase[i] + (long)yi * a.Wi + xi) * 32 : 0;
+      if (BUF_) voff[i] = ok[i] ? rowbase[i] + (unsigned)(yi * a.Wi + xi) * 64u : 0x80000000u;
+      else aoff[i] = ok[i] ? (ibase[i] + (long)yi * a.Wi + xi) * 32 : 0;
     }
   };
   // wave-uniform LDS destinations: the wave's 16 rows of each image (lane l lands at base + 16 l bytes)
@@ -480,20 +489,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE_ ? 2 :
     for (int i = 0; i < APT; ++i)
 #pragma unroll
       for (int p = 0; p < NPL; ++p) {
-        const __bf16* src = ok[i] ? xk + aoff[i] + p * a.x_plane_stride : zero;
-        glds16(src, lds_all + img + p * (BM_ * BK) + (64 * i + wave * 16) * BK);
+        if constexpr (BUF_) {                 // (single-stage form only: the static array)
+          typedef __attribute__((address_space(3))) void* lds_void;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void)(lds_static + img + p * (BM_ * BK) + (64 * i + wave * 16) * BK), 16, (int)voff[i],
+                                                   (unsigned)((xkoff + p * a.x_plane_stride) * 2), 0, 0);
+        } else {
+          const __bf16* src = ok[i] ? xk + aoff[i] + p * a.x_plane_stride : zero;
+          glds16(src, lds_all + img + p * (BM_ * BK) + (64 * i + wave * 16) * BK);
+        }
       }
     if (a.korder) {                  // the taps of one channel chunk back to back: their pixels overlap, so they hit in L2
       if (++tap == ph.ntaps) {
         tap = 0;
         xk += cstride;
+        xkoff += cstride;
       }
       set_tap(tap);
     } else {
       xk += cstride;
+      xkoff += cstride;
       if (++kc == KC) {
         kc = 0;
         xk = gx;
+        xkoff = (long)a.in_chunk0 * cstride;
         if (++tap < ph.ntaps) set_tap(tap);
       }
     }
@@ -678,7 +696,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int p = 0; p < NPL; ++p) {
         if (BUF_) {
           typedef __attribute__((address_space(3))) void* lds_void;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void)(lds_pp + img + p * (128 * BK) + (64 * i + wave * 16) * BK), 16, voff[i],
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void)(lds_pp + img + p * (128 * BK) + (64 * i + wave * 16) * BK), 16, (int)voff[i],
                                                    (unsigned)((xkoff + p * a.x_plane_stride) * 2), 0, 0);
         } else {
           const __bf16* src = ok[i] ? xk + aoff[i] + p * a.x_plane_stride : zero;
@@ -1416,6 +1434,9 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   }();
   const int variant = d->variant ? d->variant : default_variant;        // 1 = register-staged, 2 = LDS-DMA staging, 3 = 256 x 128 tiles
   UFR_REQUIRE(variant >= 1 && variant <= 7, "igemm: unknown kernel variant %d", variant);
+  // activation rows through a raw buffer resource (hardware zeros outside the frame): planes below 2 GB; UFR_IGEMM_BUF=0 = A/B
+  static const bool buf_env = [] { const char* e = getenv("UFR_IGEMM_BUF"); return !(e && e[0] == '0'); }();
+  const bool use_buf = buf_env && 6L * d->x_plane_stride < 0x7fffffffL;
   if (variant == 3 && d->products == 6 && bn == BN) {
     static bool raised = false;
     if (!raised) {
@@ -1428,7 +1449,8 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
     igemm_big_kernel<<<gbig, 256, BIG_LDS_BYTES, st>>>(a);
   } else if (variant == 4 && d->products == 6 && bn == BN) {       // 64 x 128 tiles: four workgroups per CU
     const dim3 g64(d->Npad / BN, (unsigned)((M + 63) / 64), nz);
-    igemm_glds_kernel<64, 128><<<g64, 256, 0, st>>>(a);
+    if (use_buf) igemm_glds_kernel<64, 128, false, true><<<g64, 256, 0, st>>>(a);
+    else igemm_glds_kernel<64, 128><<<g64, 256, 0, st>>>(a);
   } else if (variant == 7 && d->products == 6 && bn == BN && d->k_order && d->in_sx == 1 && d->Wr >= 22) {
     // ping-pong + horizontal tap reuse (launches it does not cover fall through to variant 6)
     static bool raised7[64] = {};
@@ -1456,8 +1478,7 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
       raised6[dev] = true;
     }
     const dim3 gpp(d->Npad / bn, (unsigned)((M + 255) / 256), nz);
-    static const bool buf = [] { const char* e = getenv("UFR_IGEMM_PP_BUF"); return !(e && e[0] == '0'); }();
-    if (bn == BN && buf && 6L * d->x_plane_stride < 0x7fffffffL) {   // activation rows through a buffer resource (planes < 2 GB)
+    if (bn == BN && use_buf) {   // activation rows through a buffer resource (planes < 2 GB)
       static bool raisedb[64] = {};
       if (!raisedb[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_pp_kernel<128, true>),
@@ -1481,8 +1502,13 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
     }
     igemm_glds_kernel<128, 128, true><<<grid, 256, PIPE_LDS_BYTES, st>>>(a);
   } else if (variant >= 2 && d->products == 6) {
-    if (bn == BN) igemm_glds_kernel<128, 128><<<grid, 256, 0, st>>>(a);
-    else igemm_glds_kernel<128, 64><<<grid, 256, 0, st>>>(a);
+    if (bn == BN) {
+      if (use_buf) igemm_glds_kernel<128, 128, false, true><<<grid, 256, 0, st>>>(a);
+      else igemm_glds_kernel<128, 128><<<grid, 256, 0, st>>>(a);
+    } else {
+      if (use_buf) igemm_glds_kernel<128, 64, false, true><<<grid, 256, 0, st>>>(a);
+      else igemm_glds_kernel<128, 64><<<grid, 256, 0, st>>>(a);
+    }
   } else if (bn == BN) {
     if (d->products == 6) igemm_kernel<6, 128><<<grid, 256, 0, st>>>(a);
     else if (d->products == 3) igemm_kernel<3, 128><<<grid, 256, 0, st>>>(a);
