@@ -230,26 +230,31 @@ class FlowNetCHeadEngine:
         return 128, 768
 
     def _build_prefix(self):
-        """Full-frame conv1-3 for both frames of every pair (models/FlowNetC.py:100-119), run once per attack() call:
-        conv1 (3 input channels: a 147-deep reduction, torch / MIOpen) with bias + LeakyReLU fused into the conversion to
-        planes; conv2 and conv3 (5x5, stride 2: 91% of the prefix's FLOPs) on the igemm with the fused epilogue."""
-        B2, dev = 2 * self.B, self.dev
+        """Full-frame conv1-3 for both frames of every pair (models/FlowNetC.py:100-119), run once per attack() call, as two
+        chains of three igemm launches -- one per frame set -- that write where the head reads: the first frames' conv2 into
+        cat2's chunks 0-3 (the skip connection) and their conv3 into c3a_p, the second frames' conv3 into c3b_p.  (One chain
+        over both sets needed three strided copies afterwards, 0.2 ms per call; with 256-row tiles the halves fill the same
+        number of rounds: conv2 4 + 4 for 8, conv3 2 + 2 for 4.)"""
+        B, dev = self.B, self.dev
         H, W = self.H, self.W
-        c1 = ig.Planes(B2, H // 2, W // 2, 2, dev)
-        c2 = ig.Planes(B2, H // 4, W // 4, 4, dev)
-        c3 = ig.Planes(B2, H // 8, W // 8, 8, dev)
         bias = lambda n: self._conv(n).bias.detach().float().contiguous()
         w2 = ig.conv_forward_weights(self._conv("conv2").weight, 2, 2)
         w3 = ig.conv_forward_weights(self._conv("conv3").weight, 2, 2)
         # conv2 (K = 25 taps x 2 chunks) at 2 x 8 frames: 1.35 ms on single-stage 128 x 128 tiles, 1.02-1.05 on 64 x 128 tiles
-        # (four workgroups per CU), 0.99-1.00 on the pipelined 128 x 128 kernel; conv3 and every large head layer prefer 128 x 128
-        v64 = self._pipe_variant if self._pipe else (4 if os.environ.get("UFR_IGEMM_M64_PREFIX", "1") != "0" else 0)
-        l2 = ig.make_launch(w2, c1, 0, (H // 4, W // 4), (H // 4, W // 4), out_planes=c2, bias=bias("conv2"), variant=v64)
-        l3 = ig.make_launch(w3, c2, 0, (H // 8, W // 8), (H // 8, W // 8), out_planes=c3, bias=bias("conv3"),
-                            variant=4 if getattr(self, "_small_batch", False) else (self._pipe_variant if self._pipe else 0))
-        self._prefix = dict(c1=c1, c2=c2, c3=c3, conv2=l2, conv3=l3, conv2_wi=w2, conv3_wi=w3, b1=bias("conv1"),
-                            w1=self._conv("conv1").weight.detach())
-        self._prefix.update(self._conv1_launch(B2, H, W, c1))
+        # (four workgroups per CU), 0.99-1.00 on the pipelined 128 x 128 kernel, 0.89-0.94 on the ping-pong kernel
+        v2 = self._pipe_variant if self._pipe else (4 if os.environ.get("UFR_IGEMM_M64_PREFIX", "1") != "0" else 0)
+        v3 = 4 if getattr(self, "_small_batch", False) else (self._pipe_variant if self._pipe else 0)
+        halves = {}
+        for h, c2_dst, c3_dst in (("a", self.cat2, self.c3a_p), ("b", ig.Planes(B, H // 4, W // 4, 4, dev), self.c3b_p)):
+            c1 = ig.Planes(B, H // 2, W // 2, 2, dev)
+            l2 = ig.make_launch(w2, c1, 0, (H // 4, W // 4), (H // 4, W // 4), out_planes=c2_dst, out_chunk0=0, bias=bias("conv2"),
+                                variant=v2)
+            l3 = ig.make_launch(w3, c2_dst, 0, (H // 8, W // 8), (H // 8, W // 8), out_planes=c3_dst, out_chunk0=0,
+                                bias=bias("conv3"), variant=v3)
+            P = dict(c1=c1, conv2=l2, conv3=l3, conv2_wi=w2, conv3_wi=w3, b1=bias("conv1"), w1=self._conv("conv1").weight.detach())
+            P.update(self._conv1_launch(B, H, W, c1))
+            halves[h] = P
+        self._prefix = halves
 
     def _conv1_launch(self, n: int, H: int, W: int, c1: ig.Planes) -> dict:
         """conv1 = Conv2d(3, 64, 7, 2, 3) + bias + LeakyReLU as an igemm launch over the packed planes of the raw frames
@@ -300,15 +305,14 @@ class FlowNetCHeadEngine:
         buffers (cat2[0:4], c3a_p, c3b_p) plus conv3 in NCHW for the correlation kernels."""
         if self._prefix is None:
             self._build_prefix()
-        P, B = self._prefix, self.B
-        self._conv1(P, frames_a, frames_b)
-        P["conv2"]()
-        P["conv3"]()
-        M4, M8 = self.cat2.M, self.c3a_p.M
-        self.cat2.t[:, 0:4].copy_(P["c2"].t[:, :, :M4])                  # conv2 of the first frames: the skip connection
-        self.c3a_p.t.copy_(P["c3"].t[:, :, :M8])
-        self.c3b_p.t.copy_(P["c3"].t[:, :, M8:])
-        P["c3"].to_nchw(256, 0, out=self.c3_nchw)
+        B = self.B
+        for h, frames in (("a", frames_a), ("b", frames_b)):
+            P = self._prefix[h]
+            self._conv1(P, frames, None)
+            P["conv2"]()
+            P["conv3"]()
+        self.c3a_p.to_nchw(256, 0, out=self.c3_nchw[:B])
+        self.c3b_p.to_nchw(256, 0, out=self.c3_nchw[B:])
         self._c3a, self._c3b = self.c3_nchw[:B], self.c3_nchw[B:]
 
     def load_prefix_features(self, c2_all: torch.Tensor, c3_all: torch.Tensor):
@@ -489,13 +493,14 @@ class FlowNetCHeadEngine:
                 wi = self._plans[(kind, name)][0]
                 d = launch.desc
                 rows.append((name, kind, tag, launch, wi.flops(d.B * d.Hr * d.Wr) / 1e9))
-        F = self._prefix
-        if F is not None:                      # full-frame conv2 / conv3 of both frames, once per attack() call
-            for name, key in (("conv1", "conv1"), ("conv2", "conv2"), ("conv3", "conv3")):
-                if key not in F:
-                    continue
-                d = F[key].desc
-                rows.append((name, "fwd", "prefix", F[key], F[key + "_wi"].flops(d.B * d.Hr * d.Wr) / 1e9))
+        if self._prefix is not None:           # full-frame conv1-3 of the first / second frames, once per attack() call
+            for h, suffix in (("a", ""), ("b", " 2nd frames")):
+                F = self._prefix[h]
+                for key in ("conv1", "conv2", "conv3"):
+                    if key not in F:
+                        continue
+                    d = F[key].desc
+                    rows.append((key + suffix, "fwd", "prefix", F[key], F[key + "_wi"].flops(d.B * d.Hr * d.Wr) / 1e9))
         P = getattr(self, "_wprefix", None)
         if P is not None:                      # conv2 / conv3 of the attack's prefix window (every iteration)
             for name, kind, key in (("conv1", "fwd", "conv1"), ("conv2", "fwd", "conv2"), ("conv3", "fwd", "conv3"),
