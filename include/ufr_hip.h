@@ -175,9 +175,17 @@ int ufr_patch_paste_placed(const float* tgt, const float* ref, const float* patc
  *   grad_flow and accumulates the scalar loss into *loss (caller zeroes it).  `partials` = workspace of
  *   UFR_LOSS_PARTIALS floats: the workgroups' partial sums, added in a fixed order by a second one-wave
  *   kernel, so the scalar behind `while loss_scalar > 0.1` (main.py:546) is bit-reproducible run to run. */
-#define UFR_LOSS_PARTIALS 512
+#define UFR_LOSS_PARTIALS 1024
 int ufr_flow_loss(const float* flow, const float* target, float* grad_flow, float* loss, int B,
                   int HW, int kind, float weight, float* partials, ufr_stream_t stream);
+/* ufr_flow2_upsampled_loss: the same loss on flow = interpolate(flow2 * flow_scale, scale_factor 4, bilinear,
+ *   align_corners False) (models/FlowNetC.py:193-197: the reference upsamples flow2 * div_flow before the loss) WITHOUT
+ *   writing the full-size flow: flow2 [B,2,h,w], target [B,2,4h,4w]; writes d loss / d flow2 [B,2,h,w] (the adjoint of
+ *   the upsampling and of the scaling applied, a gather per cell: no atomics, fixed order) and accumulates the scalar.
+ *   Replaces interpolate + ufr_flow_loss + the autograd adjoint of interpolate (three passes over the full-size flow).
+ *   UFR_EUNSUPPORTED when B * ceil(h/16) * ceil(w/16) > UFR_LOSS_PARTIALS (the caller keeps the three-pass form). */
+int ufr_flow2_upsampled_loss(const float* flow2, float flow_scale, const float* target, float* grad_flow2, float* loss, int B,
+                             int h, int w, int kind, float weight, float* partials, ufr_stream_t stream);
 
 /* ---- RAFT SepConvGRU gate arithmetic -----------------------------------------------------------
  * replaces the elementwise half of models/raft/update.py:61-73 (10 launches forward per half-step):

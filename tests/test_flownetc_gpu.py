@@ -158,6 +158,36 @@ def test_attack_fused_kernels_bit_exact_vs_torch(net):
         assert_close(gf, ref_g, rtol=1e-4, atol_scale=1e-5, what=f"loss kind {kind} gradient")
 
 
+@pytest.mark.parametrize("B,h,w", [(8, 96, 320), (2, 24, 40), (1, 7, 9), (3, 16, 33)])
+def test_upsampled_flow_loss_equals_interpolate_then_loss(B, h, w):
+    """csrc/attack.hip `ufr_flow2_upsampled_loss`: loss on interpolate(flow2 * 20, x4, bilinear, align_corners=False)
+    (models/FlowNetC.py:193-197 + main.py:557-566) and its gradient with respect to flow2, against torch's interpolate +
+    ufr_flow_loss + autograd -- the three passes over the full-size flow it replaces; ragged grids included."""
+    from understanding_flow_robustness_amd import _lib as L
+    g = torch.Generator().manual_seed(h * w)
+    flow2 = torch.randn(B, 2, h, w, generator=g).to(DEV)
+    target = torch.randn(B, 2, 4 * h, 4 * w, generator=g).to(DEV)
+    for kind in (0, 1):
+        f2 = flow2.clone().requires_grad_(True)
+        up = torch.nn.functional.interpolate(f2 * 20.0, scale_factor=4, mode="bilinear", align_corners=False)
+        gf, ref_loss, ws = torch.empty_like(up), torch.zeros(1, device=DEV), torch.empty(L.LOSS_PARTIALS, device=DEV)
+        L.check(L.lib().ufr_flow_loss(L.ptr(up.detach().contiguous()), L.ptr(target), L.ptr(gf), L.ptr(ref_loss), B, 16 * h * w, kind,
+                                      0.75, L.ptr(ws), L.stream()))
+        (ref_g,) = torch.autograd.grad(up, f2, gf)
+        got_g, loss = torch.full_like(flow2, float("nan")), torch.zeros(1, device=DEV)
+        L.check(L.lib().ufr_flow2_upsampled_loss(L.ptr(flow2), 20.0, L.ptr(target), L.ptr(got_g), L.ptr(loss), B, h, w, kind, 0.75,
+                                                 L.ptr(ws), L.stream()))
+        assert abs(float(loss) - float(ref_loss)) <= 2e-6 * max(1.0, abs(float(ref_loss))), (kind, float(loss), float(ref_loss))
+        assert_close(got_g, ref_g, rtol=1e-4, atol_scale=1e-4, what=f"upsampled loss kind {kind}: gradient of flow2")  # (sums of ~64 terms in another order: 3e-5 of the max seen)
+        again = torch.zeros(1, device=DEV)
+        L.check(L.lib().ufr_flow2_upsampled_loss(L.ptr(flow2), 20.0, L.ptr(target), L.ptr(got_g), L.ptr(again), B, h, w, kind, 0.75,
+                                                 L.ptr(ws), L.stream()))
+        assert torch.equal(loss, again)                       # fixed-order reduction
+    if B * -(-h // 16) * -(-w // 16) <= L.LOSS_PARTIALS:
+        return
+    pytest.fail("unreachable: every parametrisation fits the partial sums")
+
+
 @pytest.mark.parametrize("B,Cin,H,W", [(8, 1024, 6, 20), (2, 194, 24, 40), (3, 37, 7, 9), (1, 16, 1, 5), (1, 770, 24, 80)])
 def test_two_channel_layers_vs_torch(B, Cin, H, W):
     """csrc/small_cout.hip: predict_flow (Conv2d(Cin,2,3,1,1)) and upsampled_flow (ConvTranspose2d(2,2,4,2,1))

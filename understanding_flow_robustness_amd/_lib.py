@@ -80,7 +80,7 @@ class ConeChain(C.Structure):
 _vp, _i, _f, _l, _d = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_double
 # name -> argtypes; every function returns int.  Kept in one table so tests can check that each
 # symbol declared in include/ufr_hip.h is exported by the built library.
-LOSS_PARTIALS = 512      # UFR_LOSS_PARTIALS (include/ufr_hip.h)
+LOSS_PARTIALS = 1024     # UFR_LOSS_PARTIALS (include/ufr_hip.h)
 SIGNATURES = {
     "ufr_corr_forward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, C.POINTER(CorrParams), _vp],
     "ufr_corr_forward_fused": [_vp, _vp, _vp, _i, _i, _i, _i, _i, C.POINTER(CorrParams), _f, _f, _vp],
@@ -104,6 +104,7 @@ SIGNATURES = {
     "ufr_universal_update": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _i, _i, _i, _i,
                              _i, _vp],
     "ufr_flow_loss": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp],
+    "ufr_flow2_upsampled_loss": [_vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp],
     "ufr_patch_grad_crop": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "ufr_patch_apply": [_vp, _i, _vp, _vp, _i, _i, _f, _f, _vp, _vp],
     "ufr_patch_paste_placed": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp],

@@ -257,6 +257,134 @@ extern "C" int ufr_flow_loss(const float* flow, const float* target, float* grad
   return ufr::launched("flow_loss_kernel");
 }
 
+// ---- loss on the x4-upsampled flow without the full-size flow (ufr_flow2_upsampled_loss) --------------------------------
+// torch's upsample_bilinear2d, align_corners = False, scale 1/4 (aten/src/ATen/native/UpSample.h area_pixel_compute_source_index):
+//   src = max((dst + 0.5) * 0.25 - 0.5, 0); i0 = (int)src; i1 = i0 + (i0 < in - 1); l1 = src - i0; l0 = 1 - l1
+//   out = h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11)
+// A workgroup owns 16 x 16 cells of flow2 = 64 x 64 pixels: it evaluates the loss gradient on those pixels and a rim of 4
+// (the pixels that reach its cells), keeps it in LDS, and every thread gathers one cell's gradient from the <= 10 x 10
+// pixels around it.  Loss terms are counted on the owned pixels only.
+constexpr int F2_T = 16, F2_R = 4 * F2_T + 8;                              // cells per tile side; pixels per region side
+__device__ __forceinline__ void up4_source(int dst, int in, int& i0, int& i1, float& l1) {
+  const float src = fmaxf(((float)dst + 0.5f) * 0.25f - 0.5f, 0.f);
+  i0 = (int)src;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void flow2_upsampled_loss_kernel(const float* __restrict__ flow2, float flow_scale,
+                                                                   const float* __restrict__ target,
+                                                                   float* __restrict__ gflow2, float* __restrict__ partials,
+                                                                   int B, int h, int w, int kind, float weight) {
+  __shared__ float f2[2][F2_T + 4][F2_T + 4];                              // cells cy0 - 2 .. cy0 + 17 (indices clamped), x flow_scale
+  __shared__ float g[2][F2_R][F2_R + 1];                                   // d loss / d flow on the region's pixels
+  __shared__ float red[4];
+  const int tid = threadIdx.x, b = blockIdx.z;
+  const int cy0 = blockIdx.y * F2_T, cx0 = blockIdx.x * F2_T;
+  const int H = 4 * h, W = 4 * w;
+  const long HW = (long)H * W, hw = (long)h * w;
+  const float invn = weight / (float)((long)B * HW);
+  for (int i = tid; i < 2 * (F2_T + 4) * (F2_T + 4); i += 256) {
+    const int c = i / ((F2_T + 4) * (F2_T + 4)), r = i - c * (F2_T + 4) * (F2_T + 4), yy = r / (F2_T + 4), xx = r - yy * (F2_T + 4);
+    const int cy = min(max(cy0 - 2 + yy, 0), h - 1), cx = min(max(cx0 - 2 + xx, 0), w - 1);
+    f2[c][yy][xx] = flow2[((long)b * 2 + c) * hw + (long)cy * w + cx] * flow_scale;
+  }
+  __syncthreads();
+  const int py0 = 4 * cy0 - 4, px0 = 4 * cx0 - 4;
+  float part = 0.f;
+  for (int i = tid; i < F2_R * F2_R; i += 256) {
+    const int ry = i / F2_R, rx = i - ry * F2_R, py = py0 + ry, px = px0 + rx;
+    float gu = 0.f, gv = 0.f;
+    if (py >= 0 && py < H && px >= 0 && px < W) {
+      int y0, y1, x0, x1;
+      float ly, lx;
+      up4_source(py, h, y0, y1, ly);
+      up4_source(px, w, x0, x1, lx);
+      const float hy0 = 1.f - ly, wx0 = 1.f - lx;
+      const int a0 = y0 - (cy0 - 2), a1 = y1 - (cy0 - 2), c0 = x0 - (cx0 - 2), c1 = x1 - (cx0 - 2);
+      const float fu = hy0 * (wx0 * f2[0][a0][c0] + lx * f2[0][a0][c1]) + ly * (wx0 * f2[0][a1][c0] + lx * f2[0][a1][c1]);
+      const float fv = hy0 * (wx0 * f2[1][a0][c0] + lx * f2[1][a0][c1]) + ly * (wx0 * f2[1][a1][c0] + lx * f2[1][a1][c1]);
+      const long o0 = ((long)b * 2) * HW + (long)py * W + px, o1 = o0 + HW;
+      const float tu = target[o0], tv = target[o1];
+      float term;
+      if (kind == 0) {
+        const float dot = fu * tu + fv * tv;
+        const float nf2 = fu * fu + fv * fv, nt2 = tu * tu + tv * tv;
+        const float den = fmaxf(sqrtf(nf2 * nt2), 1e-8f);
+        const float c = dot / den;
+        term = 1.0f - c;
+        if (sqrtf(nf2 * nt2) > 1e-8f) {
+          gu = -(tu / den - c * fu / nf2);
+          gv = -(tv / den - c * fv / nf2);
+        } else {
+          gu = -(tu / den);
+          gv = -(tv / den);
+        }
+      } else {
+        const float du = fu - tu, dv = fv - tv;
+        const float sd = sqrtf(du * du + dv * dv + 1e-8f);
+        term = sd;
+        gu = du / sd;
+        gv = dv / sd;
+      }
+      gu *= invn;
+      gv *= invn;
+      const bool owned = ry >= 4 && ry < F2_R - 4 && rx >= 4 && rx < F2_R - 4;
+      if (owned) part += term;
+    }
+    g[0][ry][rx] = gu;
+    g[1][ry][rx] = gv;
+  }
+  __syncthreads();
+  {                                                                        // one cell per thread
+    const int cyl = tid >> 4, cxl = tid & 15, cy = cy0 + cyl, cx = cx0 + cxl;
+    if (cy < h && cx < w) {
+      float su = 0.f, sv = 0.f;
+      for (int py = 4 * cy - 3; py <= 4 * cy + 6; ++py) {
+        if (py < 0 || py >= H) continue;
+        int y0, y1;
+        float ly;
+        up4_source(py, h, y0, y1, ly);
+        const float wy = (y0 == cy ? 1.f - ly : 0.f) + (y1 == cy ? ly : 0.f);
+        if (wy == 0.f) continue;
+        float ru = 0.f, rv = 0.f;
+        for (int px = 4 * cx - 3; px <= 4 * cx + 6; ++px) {
+          if (px < 0 || px >= W) continue;
+          int x0, x1;
+          float lx;
+          up4_source(px, w, x0, x1, lx);
+          const float wx = (x0 == cx ? 1.f - lx : 0.f) + (x1 == cx ? lx : 0.f);
+          ru += wx * g[0][py - py0][px - px0];
+          rv += wx * g[1][py - py0][px - px0];
+        }
+        su += wy * ru;
+        sv += wy * rv;
+      }
+      gflow2[((long)b * 2) * hw + (long)cy * w + cx] = su * flow_scale;
+      gflow2[((long)b * 2 + 1) * hw + (long)cy * w + cx] = sv * flow_scale;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = part;
+  __syncthreads();
+  if (tid == 0) partials[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (red[0] + red[1] + red[2] + red[3]) * invn;
+}
+
+extern "C" int ufr_flow2_upsampled_loss(const float* flow2, float flow_scale, const float* target, float* grad_flow2, float* loss,
+                                        int B, int h, int w, int kind, float weight, float* partials, ufr_stream_t stream) {
+  UFR_REQUIRE(flow2 && target && grad_flow2 && loss && partials, "upsampled flow loss: null pointer argument");
+  UFR_REQUIRE(B > 0 && h > 0 && w > 0 && (kind == 0 || kind == 1), "upsampled flow loss: bad argument");
+  const dim3 grid(ufr::ceil_div(w, F2_T), ufr::ceil_div(h, F2_T), B);
+  const long n = (long)grid.x * grid.y * grid.z;
+  if (n > UFR_LOSS_PARTIALS || B > 65535)
+    return ufr::fail(UFR_EUNSUPPORTED, "upsampled flow loss: %ld tiles exceed the %d partial sums of the fixed-order reduction", n,
+                     UFR_LOSS_PARTIALS);
+  hipLaunchKernelGGL(flow2_upsampled_loss_kernel, grid, dim3(256), 0, ufr::as_stream(stream), flow2, flow_scale, target, grad_flow2,
+                     partials, B, h, w, kind, weight);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, ufr::as_stream(stream), partials, (int)n, loss);
+  return ufr::launched("flow2_upsampled_loss_kernel");
+}
+
 namespace ufr {
 void loss_finalize_launch(const float* partials, int n, float* loss, hipStream_t st) {
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, partials, n, loss);

@@ -133,6 +133,11 @@ class PatchAttackStep:
         self.adv_ref = torch.zeros_like(self.tgt).requires_grad_(True)
         self.g_flow = torch.zeros_like(self.target)
         self.loss_ws = torch.zeros(L.LOSS_PARTIALS, **f32)     # workgroup partials of the fixed-order loss reduction
+        # engine head: the loss kernel upsamples flow2 itself when its tiles fit the partial sums (UFR_FUSED_LOSS=0: three passes)
+        self._fused_loss = (os.environ.get("UFR_FUSED_LOSS", "1") != "0"
+                            and batch * -(-(height // 4) // 16) * -(-(width // 4) // 16) <= L.LOSS_PARTIALS
+                            and height % 4 == 0 and width % 4 == 0)
+        self.g_flow2 = torch.zeros(batch, 2, height // 4, width // 4, **f32)
         self.state = torch.zeros(4, **f32)     # stopped, executed, last loss, (pad)
         for p in self.net.parameters():        # data gradient only: skips a third of the reference's FLOPs
             p.requires_grad_(False)
@@ -293,6 +298,8 @@ class PatchAttackStep:
             self._feats_w = None
             self.eng.window_prefix_forward(self.xw, self.win, m2, m3)
             self.eng.forward_cached(self.band)
+            if self._fused_loss:                           # the loss kernel upsamples flow2 itself (no full-size flow)
+                return None
             return torch.nn.functional.interpolate(self.eng.flow[2] * self.net.div_flow, scale_factor=4, mode="bilinear",
                                                    align_corners=False)
         self._feats_w = [f[:n] for f, (_, _, n, _, _) in zip(self.net.encode(self.xw), self.taps)]
@@ -301,6 +308,8 @@ class PatchAttackStep:
             wh, ww = self.win_hw
             self.eng.scatter_window_features(self._feats_w[0], self._feats_w[1], self.win, wh, ww, m2, m3)
             self.eng.forward_cached(self.band)             # writes eng.flow[2], the leaf of the remaining torch ops
+            if self._fused_loss:
+                return None
             return torch.nn.functional.interpolate(self.eng.flow[2] * self.net.div_flow, scale_factor=4, mode="bilinear",
                                                    align_corners=False)
         for f, (ls, m, n, full, _) in zip(self._feats_w, self.taps):
@@ -314,7 +323,10 @@ class PatchAttackStep:
         zero outside the window (only mask * gradient is ever used, main.py:575-583)."""
         lib, B, H, W = L.lib(), self.B, self.H, self.W
         if self.eng is not None:
-            (g_flow2,) = torch.autograd.grad(flow, (self.eng.flow[2],), self.g_flow)
+            if flow is None:                     # ufr_flow2_upsampled_loss wrote d loss / d flow2 itself
+                g_flow2 = self.g_flow2
+            else:
+                (g_flow2,) = torch.autograd.grad(flow, (self.eng.flow[2],), self.g_flow)
             (ls2, m2, _, _, gw2), (ls3, m3, _, _, gw3) = self.taps
             if self.band is not None:            # the engine writes conv3's window gradient itself (fused correlation adjoint)
                 self.band.g3_window, self.band.g3_margin = gw3, m3
@@ -348,13 +360,18 @@ class PatchAttackStep:
             flow = self._forward_cone()
         else:
             flow = predict_flow(self.net, None, self.adv_tgt, self.adv_ref, self.args)
-        if not flow.is_contiguous():
-            flow = flow.contiguous()
         # shared patch: loss = mean over the GLOBAL batch; private: every sample its own mean
         weight = (1.0 - self.alpha) * ((1.0 / self.world) if self.shared else float(self.B))
-        L.check(L.lib().ufr_flow_loss(L.ptr(flow), L.ptr(self.target), L.ptr(self.g_flow), L.ptr(self.loss_local),
-                                      self.B, self.H * self.W, self.kind, weight, L.ptr(self.loss_ws), L.stream()),
-                "flow loss")
+        if flow is None:        # engine head: loss on the x4-upsampled flow2 and its adjoint in one kernel (csrc/attack.hip)
+            L.check(L.lib().ufr_flow2_upsampled_loss(L.ptr(self.eng.flow[2]), float(self.net.div_flow), L.ptr(self.target),
+                                                     L.ptr(self.g_flow2), L.ptr(self.loss_local), self.B, self.H // 4, self.W // 4,
+                                                     self.kind, weight, L.ptr(self.loss_ws), L.stream()), "upsampled flow loss")
+        else:
+            if not flow.is_contiguous():
+                flow = flow.contiguous()
+            L.check(L.lib().ufr_flow_loss(L.ptr(flow), L.ptr(self.target), L.ptr(self.g_flow), L.ptr(self.loss_local),
+                                          self.B, self.H * self.W, self.kind, weight, L.ptr(self.loss_ws), L.stream()),
+                    "flow loss")
         if not self.shared:
             self.loss_local.div_(float(self.B))     # gate on the batch-mean loss
         if self.alpha != 0.0:                       # main.py:568-571 (scalar only: no gradient path)
