@@ -215,43 +215,6 @@ int ufr_pwc_warp_forward(const float* x, const float* flow, float* out, int B, i
 int ufr_pwc_warp_backward(const float* x, const float* flow, const float* grad_out, float* grad_x, float* grad_flow,
                           int B, int C, int H, int W, ufr_stream_t stream);
 
-/* ---- float32-accurate GEMM on the bf16 matrix cores (round 1's building block; the product path is ufr_igemm below) ------
- * Plain GEMM / 3x3 convolution forms of the three-plane arithmetic, kept for the measurements in profiles/r1_* and the
- * UFR_SPLIT_CONV experiments; FlowNetC's convolutions run through ufr_igemm.  ufr_split_bf16x3: x[n] -> planes[3][n] bf16 with
- * x = p0 + p1 + p2 exactly.  ufr_gemm_split_nt: C[M,N] (fp32) = A[M,K] * B[N,K]^T from pre-split planes
- * ([3][M*K] and [3][N*K] bf16); `products` 6 (float32-accurate), 3 or 1 leading-order bf16 products, fp32
- * accumulation.  M, N multiples of 128, K of 32.  `chunk_major` = 1: planes stored [3][K/32][rows][32] (a 128-row
- * tile of one K chunk is a contiguous 8 KB run) instead of row-major [3][rows][K]. */
-int ufr_split_bf16x3(const float* x, void* planes, long n, ufr_stream_t stream);
-int ufr_gemm_split_nt(const void* a_planes, const void* b_planes, float* c, int M, int N, int K, int products,
-                      int chunk_major, ufr_stream_t stream);
-/* The same tiles as an implicit GEMM: Conv2d(C, N, 3, stride 1, padding 1) (submodules.py:18-46 blocks).
- * ufr_nchw_to_nhwc_split3: x [B,C,H,W] fp32 -> planes [3][B*H*W][Cpad] bf16, channels zero-padded to Cpad (a multiple
- * of 32).  ufr_conv3x3_split: x planes, weight planes [3][N][9][Cpad] (tap = ky*3+kx; N a multiple of 128) ->
- * y [B*H*W][N] fp32 (NHWC), no bias. */
-int ufr_nchw_to_nhwc_split3(const float* x, void* planes, int B, int C, int H, int W, int Cpad, ufr_stream_t stream);
-int ufr_conv3x3_split(const void* x_planes, const void* w_planes, float* y, int B, int H, int W, int Cpad, int N,
-                      int products, int chunk_major, ufr_stream_t stream);
-/* EXPERIMENTAL (compiled, not yet run on hardware): the same convolution on 128 x 256 tiles with two LDS buffers
- * (csrc/split_conv_wide.hip); N a multiple of 256. */
-int ufr_conv3x3_split_wide(const void* x_planes, const void* w_planes, float* y, int B, int H, int W, int Cpad, int N,
-                           int products, int chunk_major, ufr_stream_t stream);
-/* EXPERIMENTAL layout passes around it: x [B,C,H,W] -> chunk-major planes [3][Cpad/32][B*H*W][32] in one pass;
- * rows y [B*H*W][Npad] -> out [B,N,H,W] = act(y + bias[c]) (bias may be NULL; slope 1 = identity). */
-int ufr_nchw_to_planes_cm(const float* x, void* planes, int B, int C, int H, int W, int Cpad, ufr_stream_t stream);
-/* EXPERIMENTAL: forward Conv2d(C, N, (KH,KW), stride, pad) on the 128x128 tile; weight planes [3][N][KH*KW][Cpad];
- * y [B*Ho*Wo][N] with Ho = (Hi + 2 pad - KH) / stride + 1. */
-int ufr_conv_split_general(const void* x_planes, const void* w_planes, float* y, int B, int Hi, int Wi, int Cpad, int N,
-                           int KH, int KW, int stride, int pad, int products, int chunk_major, ufr_stream_t stream);
-/* EXPERIMENTAL: stride-2 transposed convolution (ConvTranspose2d(., ., 4, 2, 1), models/submodules.py:75-82, and the
- * data gradients of the stride-2 Conv2d layers) as four phase GEMMs.  x: chunk-major planes of the coarse tensor;
- * w_planes: [3][w_plane_elems], per phase a [taps*Cpad/32][N][32] image; plan_host (host memory): 4 x 36 longs =
- * per phase {ntaps, oy0, ox0, weight offset, 16 x (dy, dx)}; y [B*2Hi*2Wi][N]. */
-int ufr_deconv_split(const void* x_planes_cm, const void* w_planes, float* y, int B, int Hi, int Wi, int Cpad, int N,
-                     long w_plane_elems, const long* plan_host, int products, ufr_stream_t stream);
-int ufr_rows_to_nchw(const float* y, const float* bias, float* out, int B, int N, int H, int W, int Npad, float slope,
-                     ufr_stream_t stream);
-
 /* ---- RAFT convex upsampling ------------------------------------------------------------------------
  * replaces RAFT.upsample_flow (models/raft/raft.py:111-122): flow [N,2,H,W], mask [N,576,H,W] (9 x 8 x 8 logits
  * per coarse pixel) -> up [N,2,8H,8W] = softmax-weighted combination of the 3x3 neighbours of 8*flow.
@@ -437,11 +400,10 @@ typedef struct {
   void* out_planes; long out_plane_stride; int out_chunk0;
   float* out_f32; int out_f32_chunk0;
   int splitk; float* ws;
-  int products;                                /* 6 (float32-accurate); 3 / 1 for measurements only */
-  int variant;                                 /* 0 = default (LDS-DMA staging; UFR_IGEMM=reg selects 1), 1 = register-staged, 2 = LDS-DMA,
-                                                  3 = 256 x 128 tiles, 4 = 64 x 128 tiles, 5 = LDS-DMA with register-held fragments (pipelined),
-                                                  6 = ping-pong: 256 x 128 tiles, two wave groups half a step apart,
-                                                  7 = 6 + horizontal runs of taps staged once (launches it does not cover run as 6) */
+  int products;                                /* 6: the float32-accurate six-product form (the only one) */
+  int variant;                                 /* kernel form: 0 / 2 = single-stage LDS-DMA tiles (128 x 128; 128 x 64 when Npad % 128),
+                                                  4 = 64 x 128 tiles, 5 = pipelined 128 x 128 (register-held fragments),
+                                                  6 = ping-pong: 256 x 128 tiles, two wave groups half a step apart */
   int k_order;                                 /* order of the K tiles in the weight image of a phase: 0 = [taps][KC] (tap-major),
                                                   1 = [KC][taps] (the taps of one channel chunk back to back: L2 reuse of the pixels) */
 } ufr_igemm_desc;

@@ -122,8 +122,7 @@ def test_engine_banded_step_equals_full_frame_torch_step(net, monkeypatch):
     _, full = run(False, False, lr, 3, False)
     step, eng = run(True, True, lr, 3, True)
     assert step.cone is not None and step.band is not None and step.band.width == 608 and step.graph_next is not None
-    import os                                          # cached features resident in the native head's planes (unless switched off)
-    assert (step.eng is not None) == (os.environ.get("UFR_ENGINE_PREFIX", "1") == "1")
+    assert step.eng is not None                        # cached features resident in the native head's planes
     for (pf, nf, lf), (pe, ne, le) in zip(full, eng):
         upd = float((pf - patch0).abs().max())
         err = (pf - pe).abs()
@@ -273,8 +272,7 @@ def test_window_prefix_on_the_engine_equals_the_torch_prefix(net):
     c1_32 = F.leaky_relu(F.conv2d(net.normalize_correctly(xw), net.conv1[0].weight, net.conv1[0].bias, 2, 3), 0.1)
     e_eng, e_t = _rel(P["c1"].to_nchw(64, 0), c1_64.detach()), _rel(c1_32, c1_64.detach())
     print(f"conv1: engine {e_eng:.2e}, torch fp32 {e_t:.2e} (vs float64)")
-    import os
-    assert ("conv1" in P) == (os.environ.get("UFR_CONV1_IGEMM", "1") != "0") and e_eng <= max(3 * e_t, 2e-6)
+    assert "conv1" in P and e_eng <= max(3 * e_t, 2e-6)
     for name, got, t32, t64 in (("conv2", P["c2_nchw"], c2, c2_64), ("conv3", P["c3_nchw"], c3, c3_64)):
         e_eng, e_t = _rel(got, t64), _rel(t32.detach(), t64)
         print(f"{name}: engine {e_eng:.2e}, torch fp32 {e_t:.2e} (vs float64)")
@@ -356,3 +354,65 @@ def test_window_gather_chunks_and_gradient_planes_kernels():
     pl = ig.Planes(2, 9, 13, 4, DEV)
     L.check(L.lib().ufr_nchw_grad_to_planes(L.ptr(grad), L.ptr(act), L.ptr(pl.t), pl.plane_stride, 1, 2, 70, 9, 13, 0.1, L.stream()))
     assert torch.equal(pl.to_nchw(70, 1), grad * torch.where(act > 0, 1.0, 0.1))
+
+
+def test_interleaved_forwards_are_refused_not_silently_wrong(net, monkeypatch):
+    """The engine's activations are static buffers: a second grad-mode forward of the same shape before the first one's
+    backward must raise (it would differentiate the second call's activations), and gradients handed to autograd are
+    copies that the next call does not overwrite."""
+    monkeypatch.setenv("UFR_ENGINE", "1")
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 1, 64, 128
+
+    def feats(seed):
+        gg = torch.Generator().manual_seed(seed)
+        return [torch.randn(*s, generator=gg).mul_(0.5).to(DEV).requires_grad_(True)
+                for s in ((B, 128, H // 4, W // 4), (B, 256, H // 8, W // 8), (B, 256, H // 8, W // 8))]
+
+    gflow = torch.randn(B, 2, H, W, generator=g).to(DEV)
+    fa, fb = feats(1), feats(2)
+    flow_a = net.head(*fa)
+    flow_b = net.head(*fb)
+    with pytest.raises(RuntimeError, match="another forward"):
+        torch.autograd.grad(flow_a, fa, gflow)
+    grads_b = torch.autograd.grad(flow_b, fb, gflow)              # the latest forward is still differentiable
+    kept = [t.clone() for t in grads_b]
+    flow_a = net.head(*fa)                                        # a later call must not overwrite the returned gradients
+    torch.autograd.grad(flow_a, fa, gflow)
+    for t, k in zip(grads_b, kept):
+        assert torch.equal(t, k)
+
+
+def test_two_steps_with_different_windows_share_one_engine(net, monkeypatch):
+    """Two PatchAttackSteps on the same network and frame size whose masks need different prefix windows: the engine keeps
+    one window-prefix state per size, so replaying the first step's graphs after the second step was built (and ran)
+    still reads and writes its own buffers -- results equal the runs of each step alone."""
+    from understanding_flow_robustness_amd.patch_attack import PatchAttackStep
+    monkeypatch.setenv("UFR_ENGINE", "1")
+    B, H, W = 2, 256, 512
+    g = torch.Generator().manual_seed(21)
+    tgt, ref = torch.rand(B, 3, H, W, generator=g).to(DEV), torch.rand(B, 3, H, W, generator=g).to(DEV)
+    target = torch.randn(B, 2, H, W, generator=g).to(DEV)
+    args = Namespace(flownet="FlowNetC", l2=False, alpha=0.0, lr=1.0e4, max_count=2)
+
+    def operands(size):
+        mask_p = torch.ones(1, 3, size, size, device=DEV)
+        patch0 = torch.rand(1, 3, size, size, generator=g).to(DEV)
+        return patch0, mask_p, [(40, 100), (120, 300)]
+
+    def run(step, ops):
+        patch0, mask_p, origins = ops
+        step.load(tgt, ref, patch0, mask_p, patch0, target, origins=origins)
+        step.run(2)
+        return step.patch.clone()
+
+    ops_s, ops_l = operands(25), operands(70)
+    small = PatchAttackStep(net, args, B, H, W, device=DEV, patch_hw=(25, 25))
+    alone_small = run(small, ops_s)
+    large = PatchAttackStep(net, args, B, H, W, device=DEV, patch_hw=(70, 70))
+    alone_large = run(large, ops_l)
+    assert small.win_hw == (96, 96) and large.win_hw == (144, 144)
+    assert small.eng is large.eng and len(small.eng._wprefixes) == 2
+    for _ in range(2):                                            # alternate: each replay must find its own buffers intact
+        assert torch.equal(run(small, ops_s), alone_small)
+        assert torch.equal(run(large, ops_l), alone_large)

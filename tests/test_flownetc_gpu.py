@@ -139,6 +139,20 @@ def test_attack_fused_kernels_bit_exact_vs_torch(net):
     rc = L.lib().ufr_patch_paste_placed(L.ptr(tgt4), L.ptr(ref4), L.ptr(P), L.ptr(Mp), L.ptr(origins), bad.ctypes.data,
                                         L.ptr(a4t), L.ptr(a4r), None, B4, H, W, ph, pw, 1, 0.0, 1.0, None, L.stream())
     assert rc != 0
+    # device-resident origins are not validated on the host: a placement that leaves the frame (or starts left of / above
+    # it) is clipped by the paste, and the crop sums only the pixels inside the frame -- no out-of-bounds read
+    off = [(-3, -2), (H - 4, W - 5), (5, 12), (10, 3)]
+    origins_off = torch.tensor(off, dtype=torch.int32, device=DEV)
+    rows = torch.full((1, n + 1), float("nan"), device=DEV)
+    L.check(L.lib().ufr_patch_grad_crop(L.ptr(g4t), L.ptr(g4r), L.ptr(Mp), L.ptr(origins_off), None, L.ptr(loss_local),
+                                        L.ptr(rows), B4, H, W, ph, pw, 1, L.stream()))
+    acc = torch.zeros(3, ph, pw, device=DEV)
+    for b, (oy, ox) in enumerate(off):
+        for i in range(ph):
+            for j in range(pw):
+                if 0 <= oy + i < H and 0 <= ox + j < W:
+                    acc[:, i, j] = acc[:, i, j] + (g4t[b, :, oy + i, ox + j] + g4r[b, :, oy + i, ox + j])
+    assert torch.equal(rows[0, :n].view(3, ph, pw), acc * (Mp[0] != 0))
     flow, target = torch.randn(B, 2, H, W, generator=g).to(DEV), torch.randn(B, 2, H, W, generator=g).to(DEV)
     for kind in (0, 1):
         f = flow.clone().requires_grad_(True)

@@ -15,7 +15,8 @@ VARIANT = {"v": 0}
 
 
 class _Ig:
-    """The igemm host module with `make_launch` pinned to one kernel variant (1 = register-staged, 2 = LDS-DMA)."""
+    """The igemm host module with `make_launch` pinned to one kernel form (csrc/igemm.hip: 2 = single-stage, 4 = 64 x 128
+    tiles, 5 = pipelined, 6 = ping-pong)."""
 
     def __getattr__(self, name):
         from understanding_flow_robustness_amd import igemm
@@ -24,7 +25,7 @@ class _Ig:
         return getattr(igemm, name)
 
 
-@pytest.fixture(autouse=True, params=[1, 2, 3, 4, 5, 6, 7], ids=["register-staged", "lds-dma", "tile-256x128", "tile-64x128", "lds-dma-pipelined", "ping-pong", "ping-pong-tap-reuse"])
+@pytest.fixture(autouse=True, params=[2, 4, 5, 6], ids=["single-stage", "tile-64x128", "pipelined", "ping-pong"])
 def _variant(request):
     VARIANT["v"] = request.param
     yield

@@ -304,7 +304,7 @@ def test_flownets_trunk_on_the_engine_vs_float64(monkeypatch):
     f_eng, g_eng = run(net, x, w)
     assert net.__dict__.get("_ufr_head_engines"), "the trunk did not run on the engine"
     assert not next(iter(net._ufr_head_engines.values())).siamese
-    monkeypatch.setenv("UFR_ENGINE_FLOWNET2", "0")
+    monkeypatch.setenv("UFR_ENGINE", "0")
     f_t, g_t = run(net, x, w)
     net.__dict__.pop("_ufr_head_engines")
     f_64, g_64 = run(copy.deepcopy(net).double(), x.double(), w.double())

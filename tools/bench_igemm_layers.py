@@ -30,7 +30,7 @@ def timed(fn, iters=20):
 
 def main():
     only = set(a for a in sys.argv[1:] if not a.startswith("--"))
-    variants = (1, 2) if "--both" in sys.argv else ((2, 3) if "--big" in sys.argv else ((4, 2, 4, 2) if "--m64" in sys.argv else ((5, 2, 5, 2) if "--pipe" in sys.argv else ((6, 5, 6, 5) if "--pp" in sys.argv else ((7, 6, 7, 6) if "--pp3" in sys.argv else (0,))))))
+    variants = (4, 2, 4, 2) if "--m64" in sys.argv else ((5, 2, 5, 2) if "--pipe" in sys.argv else ((6, 5, 6, 5) if "--pp" in sys.argv else (6,)))
     layers = [  # name, kind, Cin, Cout, k, stride, input grid (of the forward)
         ("conv3_1", "conv", 473, 256, 3, 1, (H8, W8)), ("conv4", "conv", 256, 512, 3, 2, (H8, W8)),
         ("conv4_1", "conv", 512, 512, 3, 1, (H8 // 2, W8 // 2)), ("conv5", "conv", 512, 512, 3, 2, (H8 // 2, W8 // 2)),

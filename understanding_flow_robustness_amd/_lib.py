@@ -139,15 +139,6 @@ SIGNATURES = {
     "ufr_flow_up_planes_backward": [_vp, _i, _vp, _vp, _i, _i, _i, _vp],
     "ufr_corr_forward_planes_window": [_vp, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _i, _i, _vp],
     "ufr_corr_forward_planes": [_vp, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp],
-    "ufr_split_bf16x3": [_vp, _vp, _l, _vp],
-    "ufr_gemm_split_nt": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "ufr_nchw_to_nhwc_split3": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "ufr_conv3x3_split": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "ufr_conv3x3_split_wide": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "ufr_nchw_to_planes_cm": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "ufr_conv_split_general": [_vp, _vp, _vp] + [_i] * 11 + [_vp],
-    "ufr_deconv_split": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _l, _vp, _i, _vp],
-    "ufr_rows_to_nchw": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
     "ufr_convex_upsample_forward": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "ufr_convex_upsample_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ufr_affine_resample_f64": [_vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _d, _d, _d, _i, _vp],

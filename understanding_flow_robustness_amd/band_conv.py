@@ -16,8 +16,6 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib as L
-from .split_gemm import (SplitConv2d, SplitConv3x3, SplitDeconv2x, _experimental, split_any_ok, split_conv3x3_forward,
-                         split_conv3x3_input_gradient, split_conv_applicable, split_conv_ok, split_conv_products)
 
 
 class Band:
@@ -65,11 +63,7 @@ def window_correlation(input1, input2, patch, dilation_patch, band: Band, in_str
 
 
 def _conv_forward(x, weight, s, p):
-    """conv2d without bias inside the band Functions (no autograd here); UFR_SPLIT_CONV routes the 3x3 stride-1
-    layers through split_gemm.py."""
-    products = split_conv_products()
-    if products and split_conv_ok(x, weight, s, p):
-        return split_conv3x3_forward(x, weight, products)
+    """conv2d without bias inside the band Functions (no autograd here)."""
     return F.conv2d(x, weight, None, s, p)
 
 
@@ -78,10 +72,6 @@ class _BandConv2d(torch.autograd.Function):
     def forward(ctx, x, weight, bias, stride, padding, band, in_stride):
         ctx.save_for_backward(weight)
         ctx.meta = (tuple(x.shape), int(stride), int(padding), band, int(in_stride))
-        products = split_conv_products()
-        if products and split_conv_ok(x, weight, int(stride), int(padding)):
-            y = split_conv3x3_forward(x, weight, products)
-            return y if bias is None else y + bias.view(1, -1, 1, 1)
         return F.conv2d(x, weight, bias, stride, padding)
 
     @staticmethod
@@ -103,12 +93,8 @@ def _band_data_gradient(gy, weight, in_shape, s, p, band, ls_in):
     gyb = torch.empty(B, Cout, Ho, wob, dtype=gy.dtype, device=gy.device)
     L.check(lib.ufr_window_gather(L.ptr(gy), L.ptr(gyb), L.ptr(band.win), B, B, Cout, Ho, Wo, Ho, wob, ls_out, 0, st),
             "band gather")
-    products = split_conv_products()
-    if products and split_conv_ok(gyb, weight.transpose(0, 1), s, p):          # the adjoint's channel roles
-        gxb = split_conv3x3_input_gradient(gyb, weight, products)
-    else:
-        gxb = torch.ops.aten.convolution_backward(gyb, gyb.new_empty((B, Cin, Hi, wib)), weight, None, (s, s), (p, p),
-                                                  (1, 1), False, (0, 0), 1, (True, False, False))[0]
+    gxb = torch.ops.aten.convolution_backward(gyb, gyb.new_empty((B, Cin, Hi, wib)), weight, None, (s, s), (p, p),
+                                              (1, 1), False, (0, 0), 1, (True, False, False))[0]
     gx = torch.zeros(B, Cin, Hi, Wi, dtype=gy.dtype, device=gy.device)
     L.check(lib.ufr_window_scatter(L.ptr(gxb.contiguous()), L.ptr(gx), L.ptr(band.win), B, B, Cin, Hi, Wi, Hi, wib,
                                    ls_in, k - 1 - p, st), "band scatter")
@@ -294,15 +280,8 @@ def conv_leaky(x, seq, band: Band | None = None, in_stride: int = 0, name: str |
     if isinstance(conv, torch.nn.Conv2d):
         y = band_conv2d(x, conv, band, in_stride, with_bias=False)
     else:
-        products = split_conv_products()
-        k, pd = conv.kernel_size[0], conv.padding[0]
-        if (products and _experimental() and conv.kernel_size == (k, k) and conv.stride == (2, 2) and conv.padding == (pd, pd)
-                and conv.output_padding == (0, 0) and 2 + 2 * pd - k == 0 and conv.dilation == (1, 1) and conv.groups == 1
-                and split_any_ok(x, conv.weight, 4 * x.shape[0] * x.shape[2] * x.shape[3])):
-            y = SplitDeconv2x.apply(x, conv.weight, pd, products)
-        else:
-            y = F.conv_transpose2d(x, conv.weight, None, conv.stride, conv.padding, conv.output_padding, conv.groups,
-                                   conv.dilation)
+        y = F.conv_transpose2d(x, conv.weight, None, conv.stride, conv.padding, conv.output_padding, conv.groups,
+                               conv.dilation)
     if not y.is_contiguous():
         y = y.contiguous()
     y = _BiasLeaky.apply(y, conv.bias, act.negative_slope)
@@ -320,18 +299,6 @@ def band_conv2d(x, conv: torch.nn.Conv2d, band: Band | None, in_stride: int, wit
     per cell of x."""
     bias = conv.bias if with_bias else None
     if band is None or not band.width or not x.requires_grad:
-        products = split_conv_products()                       # UFR_SPLIT_CONV, off by default (split_gemm.py)
-        if products and (_frozen(conv) or not torch.is_grad_enabled()) and split_conv_applicable(x, conv):
-            y = SplitConv3x3.apply(x, conv.weight, products)
-            return y if bias is None else y + bias.view(1, -1, 1, 1)
-        if (products and _experimental() and (_frozen(conv) or not torch.is_grad_enabled()) and conv.dilation == (1, 1)
-                and conv.groups == 1 and conv.stride in ((1, 1), (2, 2)) and conv.padding[0] == conv.padding[1]
-                and conv.padding_mode == "zeros"):
-            k, sd, pd = conv.kernel_size[0], conv.stride[0], conv.padding[0]
-            out_pixels = x.shape[0] * ((x.shape[2] + 2 * pd - k) // sd + 1) * ((x.shape[3] + 2 * pd - k) // sd + 1)
-            if conv.kernel_size[0] == conv.kernel_size[1] and split_any_ok(x, conv.weight, out_pixels):
-                y = SplitConv2d.apply(x, conv.weight, sd, pd, products)
-                return y if bias is None else y + bias.view(1, -1, 1, 1)
         return F.conv2d(x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
     s, p = conv.stride[0], conv.padding[0]
     if conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1] or conv.dilation != (1, 1) or conv.groups != 1:

@@ -138,7 +138,11 @@ __global__ void patch_grad_crop_kernel(const float* __restrict__ g_tgt, const fl
       float s = 0.f;
       if (shown)
         for (int b = g * per; b < (g + 1) * per; ++b) {
-          const long o = ((long)b * 3 + c) * HW + (long)(origins[2 * b] + i) * W + origins[2 * b + 1] + j;
+          // a placement that leaves the frame (device-resident origins are not validated on the host) shows only the
+          // part inside it, exactly as paste_placed_kernel clips it: pixels outside contribute nothing
+          const int y = origins[2 * b] + i, x = origins[2 * b + 1] + j;
+          if ((unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W) continue;
+          const long o = ((long)b * 3 + c) * HW + (long)y * W + x;
           s += g_tgt[o] + g_ref[o];
         }
       rows[(long)g * (n + 1) + e] = s;

@@ -165,8 +165,7 @@ struct Phase {
   long w_off;                       // bf16 elements from the weight plane's start
   int dyx[UFR_IGEMM_MAX_TAPS];      // (dy & 0xffff) | (dx << 16): one dword per tap, so a wave-uniform tap index becomes an
                                     // s_load (a byte table is read with global_load_sbyte, whose wait drains the LDS-DMA too)
-  int run[UFR_IGEMM_MAX_TAPS];      // horizontal runs of taps (same dy, dx one apart, <= 3): shift | position << 2 | length << 4
-};                                  // (shift = dx - the run's smallest dx): igemm_pp3_kernel stages a run's pixels once
+};
 
 struct Args {
   const __bf16* x; long x_plane_stride; int in_chunk0, KC;
@@ -202,7 +201,7 @@ __device__ __forceinline__ void igemm_write_out(const Args& a, const Phase& ph, 
       }
     return;
   }
-  if constexpr (NPL == 3) {
+  {
     // transpose each wave's 32 x 64 accumulator slabs through LDS so that a lane owns 8 consecutive channels of one
     // pixel: 16-byte plane / fp32 stores instead of 2-byte ones (row stride 68 floats: conflict-free both ways)
     constexpr int TS = 68;
@@ -229,171 +228,13 @@ __device__ __forceinline__ void igemm_write_out(const Args& a, const Phase& ph, 
         }
       }
     }
-  } else {
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = bm + wrow + m * 16 + (lane >> 4) * 4 + j;
-        if (row < a.g.M) {
-          const long pout = out_pixel(a.g, row, ph.oy0, ph.ox0);
-#pragma unroll
-          for (int n = 0; n < 4; ++n) epilogue_store(a.e, pout, bn + wcol + n * 16 + (lane & 15), acc[m][n][j]);
-        }
-      }
   }
 }
 
-// Tile BM x BN_ per workgroup of four waves: BN_ = 128 -> waves 2 x 2, 64 x 64 each (4 x 4 accumulators);
-// BN_ = 64 (layers with <= 64 output channels: deconv2) -> waves 4 x 1, 32 x 64 each (2 x 4 accumulators).
-// K tiles run tap-major; the staging addresses advance incrementally (a pointer bump per tile, the bounds tests and pixel
-// offsets once per tap) so that the loop body is loads, LDS traffic and MFMAs only.
-template <int NPROD, int BN_>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm_kernel(const Args a) {
-  constexpr int NPL = NPROD == 1 ? 1 : (NPROD == 3 ? 2 : 3);
-  constexpr int FIRST = 6 - NPROD;
-  constexpr int MT = BN_ == 128 ? 4 : 2;             // 16-row accumulator blocks per wave
-  constexpr int BPT = BN_ / 64;                      // weight pieces per thread and plane
-  __shared__ __attribute__((aligned(16))) __bf16 lds_all[NPL * (BM + BN_) * BK];      // one array: the epilogue reuses it
-  __bf16 (*ldsA)[BM * BK] = reinterpret_cast<__bf16 (*)[BM * BK]>(lds_all);
-  __bf16 (*ldsB)[BN_ * BK] = reinterpret_cast<__bf16 (*)[BN_ * BK]>(lds_all + NPL * BM * BK);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wrow = BN_ == 128 ? (wave >> 1) * 64 : wave * 32, wcol = BN_ == 128 ? (wave & 1) * 64 : 0;
-  int tx, ty, z;
-  xcd_tile(a.xcd, tx, ty, z);
-  const int bm = ty * BM, bn = tx * BN_;
-  int phase = 0;                                     // z -> (phase, slice): phases with fewer taps have fewer slices
-#pragma unroll
-  for (int p = 1; p < 4; ++p)
-    if (p < a.nphase && z >= a.zoff[p]) phase = p;
-  const int ks = z - a.zoff[phase];
-  const Phase& ph = a.ph[phase];
-  const int KC = a.KC, KT = ph.ntaps * KC;
-  const int kt0 = ks * a.per_k, kt1 = min(KT, kt0 + a.per_k);
-  const long Min = (long)a.g.B * a.Hi * a.Wi;
-  const long cstride = Min * 32;                     // elements between consecutive channel chunks of the input
-
-  // staging: 512 16-byte pieces per activation image, two rows per thread
-  const int srow0 = tid >> 2, sch = tid & 3;
-  int yb[2], xb[2], xlo[2], xhi[2];
-  long ibase[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int pm = bm + srow0 + 64 * i;
-    const int hw = a.g.Hr * a.g.Wr;
-    const int b = pm / hw, r = pm - b * hw, yr = r / a.g.Wr, xr = r - yr * a.g.Wr;
-    const bool live = pm < a.g.M;
-    const int bb = live ? b : 0;
-    const int xg = xr + (a.g.row_x0 ? a.g.row_x0[bb * a.g.row_x0_stride] / a.g.row_x0_div : 0);
-    yb[i] = live ? yr * a.in_sy : -(1 << 20);        // rows past the end never pass the bounds test
-    xb[i] = xg * a.in_sx;
-    ibase[i] = (long)bb * a.Hi * a.Wi;
-    xlo[i] = a.in_x0 ? a.in_x0[bb * a.in_x0_stride] / a.in_x0_div : 0;
-    xhi[i] = a.in_x0 ? min(a.Wi, xlo[i] + a.in_xw) : a.Wi;
-    xlo[i] = max(xlo[i], 0);
-  }
-  u32x4 sa[NPL][2], sb[NPL][BPT];
-  const __bf16* gx = a.x + (long)a.in_chunk0 * cstride + sch * 8;
-  const int soff0 = srow0 * BK + ((sch ^ ((srow0 >> 1) & 3)) << 3);
-  // running state of the K loop
-  int tap = a.korder ? kt0 % ph.ntaps : kt0 / KC, kc = a.korder ? kt0 / ph.ntaps : kt0 - tap * KC;
-  const __bf16* wp = a.w + ph.w_off + ((long)kt0 * a.Npad + bn + srow0) * BK + sch * 8;
-  const long wstep = (long)a.Npad * BK;
-  const __bf16* xk = gx + (long)kc * cstride;
-  bool ok[2];
-  long aoff[2];
-  auto set_tap = [&](int t) {
-    const int dyx = ph.dyx[t], dyo = (int)(short)(dyx & 0xffff), dxo = dyx >> 16;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int yi = yb[i] + dyo, xi = xb[i] + dxo;
-      ok[i] = (unsigned)yi < (unsigned)a.Hi && xi >= xlo[i] && xi < xhi[i];
-      aoff[i] = ok[i] ? (ibase[i] + (long)yi * a.Wi + xi) * 32 : 0;
-    }
-  };
-  auto load_tile = [&]() {           // loads K tile (tap, kc) into registers and advances the state
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int p = 0; p < NPL; ++p) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(xk + aoff[i] + p * a.x_plane_stride);
-        sa[p][i] = ok[i] ? v : u32x4{0u, 0u, 0u, 0u};
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < BPT; ++i)
-#pragma unroll
-      for (int p = 0; p < NPL; ++p) sb[p][i] = *reinterpret_cast<const u32x4*>(wp + p * a.w_plane_stride + (long)(64 * i) * BK);
-    wp += wstep;
-    if (a.korder) {                  // the taps of one channel chunk back to back: their pixels overlap, so they hit in L2
-      if (++tap == ph.ntaps) {
-        tap = 0;
-        xk += cstride;
-      }
-      set_tap(tap);
-    } else {
-      xk += cstride;
-      if (++kc == KC) {
-        kc = 0;
-        xk = gx;
-        if (++tap < ph.ntaps) set_tap(tap);
-      }
-    }
-  };
-  auto store_tile = [&]() {
-#pragma unroll
-    for (int p = 0; p < NPL; ++p) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(&ldsA[p][soff0 + 64 * i * BK]) = sa[p][i];
-#pragma unroll
-      for (int i = 0; i < BPT; ++i) *reinterpret_cast<u32x4*>(&ldsB[p][soff0 + 64 * i * BK]) = sb[p][i];
-    }
-  };
-
-  f32x4 acc[MT][4];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int frow = lane & 15;
-  const int foff = frow * BK + ((((lane >> 4)) ^ ((frow >> 1) & 3)) << 3);
-
-  if (kt0 < kt1) {
-    set_tap(tap);
-    load_tile();
-  }
-  for (int kt = kt0; kt < kt1; ++kt) {
-    __syncthreads();
-    store_tile();
-    __syncthreads();
-    if (kt + 1 < kt1) load_tile();
-    bf16x8 fa[NPL][MT];
-#pragma unroll
-    for (int p = 0; p < NPL; ++p)
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-        fa[p][m] = *reinterpret_cast<const bf16x8*>(&ldsA[p][(wrow + m * 16) * BK + foff]);
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      bf16x8 fb[NPL];
-#pragma unroll
-      for (int p = 0; p < NPL; ++p) fb[p] = *reinterpret_cast<const bf16x8*>(&ldsB[p][(wcol + n * 16) * BK + foff]);
-#pragma unroll
-      for (int t = FIRST; t < 6; ++t)
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[t]][m], fb[PROD_B[t]], acc[m][n], 0, 0, 0);
-    }
-  }
-
-  static_assert(NPL != 3 || 4 * 32 * 68 * 4 <= (int)sizeof(lds_all), "epilogue staging does not fit");
-  igemm_write_out<NPL, MT>(a, ph, acc, reinterpret_cast<float*>(lds_all), z, bm, bn, wrow, wcol, lane, wave);
-}
-
-// The same tile with LDS-DMA staging (`global_load_lds_dwordx4`: HBM/L2 -> LDS without passing through registers).
-// No staging registers and no ds_write pass: 3 workgroups per CU instead of 2 (<= 168 VGPRs, 3 x 48 KB of LDS), so that
-// while one workgroup waits for its tile two others have MFMA work -- the register-staged kernel's matrix pipe sits idle
-// half of the time (profiles/r2_igemm_v1_pmc1.txt: SQ_VALU_MFMA_BUSY 50 %).  The LDS image is the same XOR-swizzled one;
+// Staging is LDS-DMA (`global_load_lds_dwordx4`: HBM/L2 -> LDS without passing through registers).
+// No staging registers and no ds_write pass: 3 workgroups per CU (<= 168 VGPRs, 3 x 48 KB of LDS), so that while one
+// workgroup waits for its tile two others have MFMA work (a register-staged form of round 2 left the matrix pipe idle
+// half of the time, profiles/r2_igemm_v1_pmc1.txt: SQ_VALU_MFMA_BUSY 50 %).  The LDS image is the same XOR-swizzled one;
 // an LDS-DMA writes lane-linearly (wave base + lane * 16 B), so the swizzle moves to the SOURCE address (lane (row, slot)
 // fetches 16-byte piece slot ^ ((row >> 1) & 3) of its row).  Rows outside the frame fetch a zero page.
 __device__ __attribute__((aligned(64))) unsigned ufr_zero_page[16];
@@ -617,7 +458,8 @@ constexpr int PIPE_LDS_BYTES = (3 * (128 + 128) * BK + 3 * 128 * BK) * 2;     //
 constexpr int PP_IMG = 3 * 128 * BK;                                      // elements of one 128-row image (3 planes): 24 KB
 constexpr int pp_lds_bytes(int bn) { return (4 * PP_IMG + 2 * 3 * bn * BK) * 2; }
 
-// BN_ = 128: a group's waves 2 x 2 of 64 x 64; BN_ = 64 (layers with <= 64 outputs): 4 x 1 of 32 x 64, 12 KB weight images
+// A group's waves: 2 x 2 of 64 x 64 (a 64-column form with 12 KB weight images measured slower than the single-stage 128 x 64
+// tile and was removed).
 // BUF_: the activation rows come through a raw buffer resource (`buffer_load_dwordx4 ... lds`): a row outside the frame /
 // band gets an out-of-range offset and the hardware writes zeros -- no zero page, no 64-bit pointer select per plane, the
 // plane / chunk displacement in the scalar offset: ~20 instead of ~70 vector instructions per K step in the READ half-step,
@@ -782,328 +624,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (grp == 0) __builtin_amdgcn_s_barrier();                             // group 1's extra barrier at the start
   static_assert(4 * 32 * 68 * 4 <= 2 * PP_IMG * 2, "epilogue staging does not fit a group's activation images");
   igemm_write_out<NPL, MT>(a, ph, acc, reinterpret_cast<float*>(lds_pp + imgA0), z, bm, bn, wrow, wcol, lane, wave);
-}
-
-// ---- ping-pong with horizontal tap reuse (variant 7) ----------------------------------------------------------------------
-// The taps of one run (same dy, dx one apart: the three columns of a 3x3 row, the two of a deconvolution phase) read the SAME
-// activation pixels one cell apart, so a group stages a run's pixels ONCE per channel chunk -- image row j = cell (bm + j)'s
-// pixel at the run's smallest dx -- and tap `shift` reads row j + shift.  That is exact while cell j + shift lies in the
-// same row of the row grid; the last one or two cells of a grid row need the pixels one and two PAST the row's end (zeros
-// at a frame edge, real pixels beside a column band), which are staged into fix-up rows behind the image:
-//   rows 0..127 the tile's cells | 128, 129 the two cells after the tile | 130 + 2 e + w: pixel w + 1 past the end of the
-//   e-th grid row the tile touches (e < 7: the host sends launches with Wr < 22 to igemm_pp_kernel).
-// A lane's fragment rows are fixed, so the row it reads for (m, shift) is a per-lane constant: 12 LDS offsets.
-// L2 -> LDS bytes per K step: 24 KB of weights + 2 x 27 KB of activations per RUN instead of 72 KB (3x3: 42 KB).
-constexpr int PP3_ROWS = 144;
-constexpr int PP3_IMG = 3 * PP3_ROWS * BK;                                // elements of one activation image: 27 KB
-constexpr int PP3_LDS_BYTES = (4 * PP3_IMG + 2 * PP_IMG) * 2;             // 159,744 B
-
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm_pp3_kernel(const Args a) {
-  constexpr int NPL = 3, MT = 4;
-  extern __shared__ __attribute__((aligned(16))) __bf16 lds_pp[];
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
-  const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * 64;
-  int tx, ty, z;
-  xcd_tile(a.xcd, tx, ty, z);
-  const int bm = ty * 256 + grp * 128, bn = tx * BN;
-  int phase = 0;
-#pragma unroll
-  for (int p = 1; p < 4; ++p)
-    if (p < a.nphase && z >= a.zoff[p]) phase = p;
-  const int ks = z - a.zoff[phase];
-  const Phase& ph = a.ph[phase];
-  const int ntaps = ph.ntaps, KT = ntaps * a.KC;
-  const int kt0 = ks * a.per_k, kt1 = min(KT, kt0 + a.per_k);
-  const int nk = max(kt1 - kt0, 0);
-  const long Min = (long)a.g.B * a.Hi * a.Wi;
-  const long cstride = Min * 32;
-  const int Wr = a.g.Wr, hw = a.g.Hr * Wr;
-
-  // ---- staging geometry: image rows srow0, srow0 + 64 (cells of the tile) and, on wave 0, extra row 128 + (lane >> 2)
-  const int srow0 = tid >> 2, sch = tid & 3;
-  const int csw = sch ^ ((srow0 >> 1) & 3);
-  const int xrow = lane >> 2, cswx = sch ^ ((xrow >> 1) & 3);             // (128 + xrow) >> 1 & 3 == xrow >> 1 & 3
-  int yb[3], xb[3], xlo[3], xhi[3];
-  long ibase[3];
-  auto cell_geometry = [&](int i, long cell, int xr_override) {            // cell = flat index into [B, Hr, Wr]
-    const bool live = cell >= 0 && cell < a.g.M;
-    const int c = live ? (int)cell : 0;
-    const int b = c / hw, r = c - b * hw, yr = r / Wr;
-    const int xr = xr_override >= 0 ? xr_override : r - yr * Wr;
-    const int xg = xr + (a.g.row_x0 ? a.g.row_x0[b * a.g.row_x0_stride] / a.g.row_x0_div : 0);
-    yb[i] = live ? yr * a.in_sy : -(1 << 20);
-    xb[i] = xg * a.in_sx;
-    ibase[i] = (long)b * a.Hi * a.Wi;
-    xlo[i] = a.in_x0 ? a.in_x0[b * a.in_x0_stride] / a.in_x0_div : 0;
-    xhi[i] = a.in_x0 ? min(a.Wi, xlo[i] + a.in_xw) : a.Wi;
-    xlo[i] = max(xlo[i], 0);
-  };
-  cell_geometry(0, (long)bm + srow0, -1);
-  cell_geometry(1, (long)bm + srow0 + 64, -1);
-  const int grow0 = bm / Wr;                                              // first grid row (flat over B * Hr) the tile touches
-  if (xrow < 2) {
-    cell_geometry(2, (long)bm + 128 + xrow, -1);
-  } else {                                                                // pixel (xrow & 1) + 1 past the end of grid row grow0 + e
-    const int e = (xrow - 2) >> 1, w = (xrow - 2) & 1;
-    const long rowcell = (long)(grow0 + e) * Wr;                          // that grid row's first cell
-    cell_geometry(2, rowcell < a.g.M ? rowcell : -1, Wr + w);
-  }
-  const __bf16* gx = a.x + (long)a.in_chunk0 * cstride + csw * 8;
-  const __bf16* gxx = a.x + (long)a.in_chunk0 * cstride + cswx * 8;
-  const __bf16* zero = reinterpret_cast<const __bf16*>(ufr_zero_page);
-  const __bf16* wp = a.w + ph.w_off + ((long)kt0 * a.Npad + bn + srow0) * BK + csw * 8;
-  const long wstep = (long)a.Npad * BK;
-
-  const int imgA0 = grp * 2 * PP3_IMG, imgB0 = 4 * PP3_IMG;
-  // one run's pixels of channel chunk kc -> activation image at element `img`
-  auto stage_A = [&](int img, int kc, int tap) {
-    const int dyx = ph.dyx[tap], dyo = (int)(short)(dyx & 0xffff), dxo = (dyx >> 16) - (ph.run[tap] & 3);
-    const long coff = (long)kc * cstride;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int yi = yb[i] + dyo, xi = xb[i] + dxo;
-      const bool ok = (unsigned)yi < (unsigned)a.Hi && xi >= xlo[i] && xi < xhi[i];
-      const long off = ok ? (ibase[i] + (long)yi * a.Wi + xi) * 32 + coff : 0;
-#pragma unroll
-      for (int p = 0; p < NPL; ++p)
-        glds16(ok ? gx + off + p * a.x_plane_stride : zero, lds_pp + img + p * (PP3_ROWS * BK) + (64 * i + wave * 16) * BK);
-    }
-    if (wave == 0) {                                                      // the 16 extra rows: lane -> (row 128 + lane / 4, piece)
-      const int yi = yb[2] + dyo, xi = xb[2] + dxo;
-      const bool ok = (unsigned)yi < (unsigned)a.Hi && xi >= xlo[2] && xi < xhi[2];
-      const long off = ok ? (ibase[2] + (long)yi * a.Wi + xi) * 32 + coff : 0;
-#pragma unroll
-      for (int p = 0; p < NPL; ++p)
-        glds16(ok ? gxx + off + p * a.x_plane_stride : zero, lds_pp + img + p * (PP3_ROWS * BK) + 128 * BK);
-    }
-  };
-  auto stage_B = [&](int img) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int p = 0; p < NPL; ++p)
-        glds16(wp + p * a.w_plane_stride + (long)(64 * i) * BK, lds_pp + img + p * (BN * BK) + (64 * i + wave * 16) * BK);
-    wp += wstep;
-  };
-
-  // ---- fragment rows: lane reads image row of cell (wrow + 16 m + frow) shifted by 0, 1, 2 cells
-  const int frow = lane & 15;
-  int foffs[MT][3];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int i = wrow + m * 16 + frow;
-    const int cell = bm + i, gr = cell / Wr, xr = cell - gr * Wr, e = min(gr - grow0, 6);
-#pragma unroll
-    for (int sft = 0; sft < 3; ++sft) {
-      const int t = xr + sft;
-      const int r = t < Wr ? i + sft : 130 + 2 * e + min(t - Wr, 1);
-      foffs[m][sft] = r * BK + (((lane >> 4) ^ ((r >> 1) & 3)) << 3);
-    }
-  }
-  const int fboff = frow * BK + (((lane >> 4) ^ ((frow >> 1) & 3)) << 3);
-
-  f32x4 acc[MT][4];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // ---- K steps kt = chunk * ntaps + tap (chunk-major: the host requires k_order = 1)
-  int kc = kt0 / ntaps, tap = kt0 - kc * ntaps;
-  int ebuf = 0;                                                           // activation image of the current run
-  if (nk > 0) {
-    stage_A(imgA0, kc, tap);
-    if (grp == 0) stage_B(imgB0);
-  }
-  if (grp == 1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-  bool first_of_run = true;                                               // this step is the first of its run inside the slice
-  for (int i = 0; i < nk; ++i) {
-    const int cur = i & 1;
-    const int ri = ph.run[tap], sft = ri & 3, pos = (ri >> 2) & 3, len = ri >> 4;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    // ---- READ half-step
-    __builtin_amdgcn_s_setprio(2);
-    const __bf16* sA = lds_pp + imgA0 + ebuf * PP3_IMG;
-    const __bf16* sB = lds_pp + imgB0 + cur * PP_IMG;
-    bf16x8 fa[NPL][MT], fb[4][NPL];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int fo = sft == 0 ? foffs[m][0] : (sft == 1 ? foffs[m][1] : foffs[m][2]);
-#pragma unroll
-      for (int p = 0; p < NPL; ++p) fa[p][m] = *reinterpret_cast<const bf16x8*>(sA + p * (PP3_ROWS * BK) + fo);
-    }
-#pragma unroll
-    for (int p = 0; p < NPL; ++p)
-#pragma unroll
-      for (int n = 0; n < 4; ++n) fb[n][p] = *reinterpret_cast<const bf16x8*>(sB + p * (BN * BK) + (wcol + n * 16) * BK + fboff);
-    // the next run's image: issued in the first step of this run (its other image was last read in the previous run)
-    int ntap = tap - pos + len, nkc = kc;
-    if (ntap >= ntaps) { ntap = 0; ++nkc; }
-    const int steps_left_in_run = len - 1 - pos;                           // steps of this run after this one
-    if (first_of_run && i + 1 + steps_left_in_run < nk) stage_A(imgA0 + (ebuf ^ 1) * PP3_IMG, nkc, ntap);
-    if (grp == 0 && i + 1 < nk) stage_B(imgB0 + (cur ^ 1) * PP_IMG);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_s_barrier();
-    // ---- MFMA half-step
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-      for (int t = 0; t < 6; ++t)
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[t]][m], fb[n][PROD_B[t]], acc[m][n], 0, 0, 0);
-    // advance (kc, tap); a new run flips the image
-    first_of_run = pos == len - 1;
-    if (first_of_run) ebuf ^= 1;
-    if (++tap == ntaps) { tap = 0; ++kc; }
-  }
-  if (grp == 0) __builtin_amdgcn_s_barrier();
-  static_assert(4 * 32 * 68 * 4 <= 2 * PP3_IMG * 2, "epilogue staging does not fit a group's activation images");
-  igemm_write_out<NPL, MT>(a, ph, acc, reinterpret_cast<float*>(lds_pp + imgA0), z, bm, bn, wrow, wcol, lane, wave);
-}
-
-// ---- the 256 x 128 tile form: ONE workgroup per CU, the overlap inside the workgroup ---------------------------------
-// Same operands, addressing, swizzle and epilogue as igemm_glds_kernel<128>, but a workgroup owns 256 rows (each wave 128 x
-// 64: 8 x 4 accumulator tiles, ~250 VGPRs at one wave per SIMD) and TWO LDS stages of 72 KB: the DMA of K tile k + 1 is
-// issued before the 192 MFMAs per wave of K tile k and retired by the barrier that ends it (one barrier per K tile).  Per
-// MFMA it moves 94 bytes from L2 instead of 125 and never has every resident workgroup waiting at once.
-constexpr int BMB = 256;
-constexpr int BIG_STAGE = 3 * (BMB + BN) * BK;                            // elements per stage: 3 planes x (A 256 + B 128) rows x 32
-constexpr int BIG_LDS_BYTES = 2 * BIG_STAGE * 2;
-
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void igemm_big_kernel(const Args a) {
-  constexpr int NPL = 3, MT = 8;
-  extern __shared__ __attribute__((aligned(16))) __bf16 lds_big[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wrow = (wave >> 1) * 128, wcol = (wave & 1) * 64;
-  int tx, ty, z;
-  xcd_tile(a.xcd, tx, ty, z);
-  const int bm = ty * BMB, bn = tx * BN;
-  int phase = 0;
-#pragma unroll
-  for (int p = 1; p < 4; ++p)
-    if (p < a.nphase && z >= a.zoff[p]) phase = p;
-  const int ks = z - a.zoff[phase];
-  const Phase& ph = a.ph[phase];
-  const int KC = a.KC, KT = ph.ntaps * KC;
-  const int kt0 = ks * a.per_k, kt1 = min(KT, kt0 + a.per_k);
-  const long Min = (long)a.g.B * a.Hi * a.Wi;
-  const long cstride = Min * 32;
-
-  const int srow0 = tid >> 2, sch = tid & 3;
-  const int csw = sch ^ ((srow0 >> 1) & 3);
-  int yb[4], xb[4], xlo[4], xhi[4];
-  long ibase[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int pm = bm + srow0 + 64 * i;
-    const int hw = a.g.Hr * a.g.Wr;
-    const int b = pm / hw, r = pm - b * hw, yr = r / a.g.Wr, xr = r - yr * a.g.Wr;
-    const bool live = pm < a.g.M;
-    const int bb = live ? b : 0;
-    const int xg = xr + (a.g.row_x0 ? a.g.row_x0[bb * a.g.row_x0_stride] / a.g.row_x0_div : 0);
-    yb[i] = live ? yr * a.in_sy : -(1 << 20);
-    xb[i] = xg * a.in_sx;
-    ibase[i] = (long)bb * a.Hi * a.Wi;
-    xlo[i] = a.in_x0 ? a.in_x0[bb * a.in_x0_stride] / a.in_x0_div : 0;
-    xhi[i] = a.in_x0 ? min(a.Wi, xlo[i] + a.in_xw) : a.Wi;
-    xlo[i] = max(xlo[i], 0);
-  }
-  const __bf16* gx = a.x + (long)a.in_chunk0 * cstride + csw * 8;
-  const __bf16* zero = reinterpret_cast<const __bf16*>(ufr_zero_page);
-  int tap = a.korder ? kt0 % ph.ntaps : kt0 / KC, kc = a.korder ? kt0 / ph.ntaps : kt0 - tap * KC;
-  const __bf16* wp = a.w + ph.w_off + ((long)kt0 * a.Npad + bn + srow0) * BK + csw * 8;
-  const long wstep = (long)a.Npad * BK;
-  const __bf16* xk = gx + (long)kc * cstride;
-  bool ok[4];
-  long aoff[4];
-  auto set_tap = [&](int t) {
-    const int dyx = ph.dyx[t], dyo = (int)(short)(dyx & 0xffff), dxo = dyx >> 16;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int yi = yb[i] + dyo, xi = xb[i] + dxo;
-      ok[i] = (unsigned)yi < (unsigned)a.Hi && xi >= xlo[i] && xi < xhi[i];
-      aoff[i] = ok[i] ? (ibase[i] + (long)yi * a.Wi + xi) * 32 : 0;
-    }
-  };
-  auto stage_tile = [&](int buf) {
-    __bf16* sA = lds_big + buf * BIG_STAGE;
-    __bf16* sB = sA + NPL * BMB * BK;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int p = 0; p < NPL; ++p) {
-        const __bf16* src = ok[i] ? xk + aoff[i] + p * a.x_plane_stride : zero;
-        glds16(src, sA + p * (BMB * BK) + (64 * i + wave * 16) * BK);
-      }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int p = 0; p < NPL; ++p)
-        glds16(wp + p * a.w_plane_stride + (long)(64 * i) * BK, sB + p * (BN * BK) + (64 * i + wave * 16) * BK);
-    wp += wstep;
-    if (a.korder) {                  // the taps of one channel chunk back to back: their pixels overlap, so they hit in L2
-      if (++tap == ph.ntaps) {
-        tap = 0;
-        xk += cstride;
-      }
-      set_tap(tap);
-    } else {
-      xk += cstride;
-      if (++kc == KC) {
-        kc = 0;
-        xk = gx;
-        if (++tap < ph.ntaps) set_tap(tap);
-      }
-    }
-  };
-
-  f32x4 acc[MT][4];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int frow = lane & 15;
-  const int foff = frow * BK + ((((lane >> 4)) ^ ((frow >> 1) & 3)) << 3);
-
-  int buf = 0;
-  if (kt0 < kt1) {
-    set_tap(tap);
-    stage_tile(0);
-  }
-  __syncthreads();                     // (hipcc waits vmcnt(0) in front of the barrier: the first tile has landed)
-  for (int kt = kt0; kt < kt1; ++kt) {
-    if (kt + 1 < kt1) stage_tile(buf ^ 1);           // in flight under this tile's MFMAs
-    const __bf16* sA = lds_big + buf * BIG_STAGE;
-    const __bf16* sB = sA + NPL * BMB * BK;
-    bf16x8 fa[NPL][MT];
-#pragma unroll
-    for (int p = 0; p < NPL; ++p)
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-        fa[p][m] = *reinterpret_cast<const bf16x8*>(sA + p * (BMB * BK) + (wrow + m * 16) * BK + foff);
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      bf16x8 fb[NPL];
-#pragma unroll
-      for (int p = 0; p < NPL; ++p) fb[p] = *reinterpret_cast<const bf16x8*>(sB + p * (BN * BK) + (wcol + n * 16) * BK + foff);
-#pragma unroll
-      for (int t = 0; t < 6; ++t)
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[t]][m], fb[PROD_B[t]], acc[m][n], 0, 0, 0);
-    }
-    __syncthreads();                   // the next tile has landed (vmcnt(0)) and every wave is done with this one
-    buf ^= 1;
-  }
-  static_assert(4 * 32 * 68 * 4 <= BIG_LDS_BYTES, "epilogue staging does not fit");
-  igemm_write_out<NPL, MT>(a, ph, acc, reinterpret_cast<float*>(lds_big), z, bm, bn, wrow, wcol, lane, wave);
 }
 
 // Second stage of split-K: thread = (phase, row, 8 channels); the slabs are added in ascending order.
@@ -1389,8 +909,7 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   a.e.out_f32 = d->out_f32; a.e.out_f32_chunk0 = d->out_f32_chunk0;
   a.e.Mout = (long)d->B * d->Ho * d->Wo; a.e.N = d->N; a.e.Nchunks32 = (d->N + 31) / 32;
   a.nphase = d->nphase; a.splitk = d->splitk; a.ws = d->ws;
-  static const int xcd_order = [] { const char* e = getenv("UFR_IGEMM_XCD"); return e && e[0] == '0' ? 0 : 1; }();
-  a.xcd = xcd_order;
+  a.xcd = 1;                              // XCD-aware tile order (off: +0.2 ms per iteration, profiles/r2_bench_engine_v4_no_xcd_order)
   a.korder = d->k_order ? 1 : 0;
   for (int z = 0; z < 4; ++z) {
     const ufr_igemm_phase& p = d->phase[z < d->nphase ? z : 0];
@@ -1400,20 +919,6 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
     a.ph[z].ntaps = p.ntaps; a.ph[z].oy0 = p.oy0; a.ph[z].ox0 = p.ox0; a.ph[z].w_off = p.w_off;
     for (int t = 0; t < UFR_IGEMM_MAX_TAPS; ++t)
       a.ph[z].dyx[t] = t < p.ntaps ? (((int)p.dy[t] & 0xffff) | ((int)p.dx[t] << 16)) : 0;
-    for (int t = 0; t < UFR_IGEMM_MAX_TAPS; ++t) a.ph[z].run[t] = 1 << 4;         // default: every tap its own run
-    for (int t = 0; t < p.ntaps;) {                // maximal runs of <= 3 taps with equal dy and dx stepping by +1 or -1
-      int len = 1, dir = 0;
-      while (len < 3 && t + len < p.ntaps && p.dy[t + len] == p.dy[t]) {
-        const int step = p.dx[t + len] - p.dx[t + len - 1];
-        if ((step != 1 && step != -1) || (dir && step != dir)) break;
-        dir = step;
-        ++len;
-      }
-      int dmin = p.dx[t];
-      for (int i = 1; i < len; ++i) dmin = p.dx[t + i] < dmin ? p.dx[t + i] : dmin;
-      for (int i = 0; i < len; ++i) a.ph[z].run[t + i] = (p.dx[t + i] - dmin) | (i << 2) | (len << 4);
-      t += len;
-    }
   }
   // split-K: `splitk` slices for the phase with the most taps, proportionally fewer for the others (the phases of a stride-2
   // data gradient reduce over 1, 2, 2 and 4 taps: equal slices per phase would leave the workgroups 4x apart in length)
@@ -1428,94 +933,45 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   hipStream_t st = ufr::as_stream(stream);
   const int bn = d->Npad % BN == 0 ? BN : 64;        // 64-column tiles where a 128-column tile would be mostly padding
   const dim3 grid(d->Npad / bn, (unsigned)((M + BM - 1) / BM), nz);
-  static const int default_variant = [] {
-    const char* e = getenv("UFR_IGEMM");
-    return e && e[0] == 'r' ? 1 : (e && e[0] == 'b' ? 3 : (e && e[0] == 'm' ? 4 : (e && e[0] == 'p' ? 5 : 2)));   // reg | big | m64 | pipe | (default) glds
-  }();
-  const int variant = d->variant ? d->variant : default_variant;        // 1 = register-staged, 2 = LDS-DMA staging, 3 = 256 x 128 tiles
-  UFR_REQUIRE(variant >= 1 && variant <= 7, "igemm: unknown kernel variant %d", variant);
-  // activation rows through a raw buffer resource (hardware zeros outside the frame): planes below 2 GB; UFR_IGEMM_BUF=0 = A/B
-  static const bool buf_env = [] { const char* e = getenv("UFR_IGEMM_BUF"); return !(e && e[0] == '0'); }();
-  const bool use_buf = buf_env && 6L * d->x_plane_stride < 0x7fffffffL;
-  if (variant == 3 && d->products == 6 && bn == BN) {
-    static bool raised = false;
-    if (!raised) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         BIG_LDS_BYTES);
-      if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "igemm: %s", hipGetErrorString(e));
-      raised = true;
-    }
-    const dim3 gbig(d->Npad / BN, (unsigned)((M + BMB - 1) / BMB), nz);
-    igemm_big_kernel<<<gbig, 256, BIG_LDS_BYTES, st>>>(a);
-  } else if (variant == 4 && d->products == 6 && bn == BN) {       // 64 x 128 tiles: four workgroups per CU
+  // kernel forms: 0 / 2 = single-stage LDS-DMA tiles (128 x 128, or 128 x 64 where Npad is not a multiple of 128),
+  // 4 = 64 x 128 tiles (four workgroups per CU), 5 = pipelined 128 x 128, 6 = ping-pong 256 x 128 (128-column launches only;
+  // the 64-column ones run the single-stage 128 x 64 tile, which measured faster there)
+  const int variant = d->variant ? d->variant : 2;
+  UFR_REQUIRE(variant == 2 || variant == 4 || variant == 5 || variant == 6, "igemm: unknown kernel variant %d", variant);
+  UFR_REQUIRE(d->products == 6, "igemm: six products only (float32-accurate); the 3- and 1-product forms were removed");
+  // activation rows through a raw buffer resource (hardware zeros outside the frame) while the planes stay below 2 GB
+  const bool use_buf = 6L * d->x_plane_stride < 0x7fffffffL;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ufr::fail(UFR_ELAUNCH, "igemm: no current device");
+  static bool raised[64] = {};              // per device: a process may drive more than one
+  if (!raised[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_pp_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       pp_lds_bytes(128));
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_pp_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              pp_lds_bytes(128));
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_glds_kernel<128, 128, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS_BYTES);
+    if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "igemm: %s", hipGetErrorString(e));
+    raised[dev] = true;
+  }
+  if (variant == 4 && bn == BN) {                  // 64 x 128 tiles: four workgroups per CU
     const dim3 g64(d->Npad / BN, (unsigned)((M + 63) / 64), nz);
     if (use_buf) igemm_glds_kernel<64, 128, false, true><<<g64, 256, 0, st>>>(a);
     else igemm_glds_kernel<64, 128><<<g64, 256, 0, st>>>(a);
-  } else if (variant == 7 && d->products == 6 && bn == BN && d->k_order && d->in_sx == 1 && d->Wr >= 22) {
-    // ping-pong + horizontal tap reuse (launches it does not cover fall through to variant 6)
-    static bool raised7[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ufr::fail(UFR_ELAUNCH, "igemm: no current device");
-    if (!raised7[dev]) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_pp3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         PP3_LDS_BYTES);
-      if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "igemm: %s", hipGetErrorString(e));
-      raised7[dev] = true;
-    }
+  } else if (variant == 6 && bn == BN) {           // ping-pong: 256-row tiles, two wave groups half a step apart
     const dim3 gpp(d->Npad / BN, (unsigned)((M + 255) / 256), nz);
-    igemm_pp3_kernel<<<gpp, 512, PP3_LDS_BYTES, st>>>(a);
-  } else if ((variant == 6 || variant == 7) && d->products == 6) {       // ping-pong: 256-row tiles, two wave groups half a step apart
-    static bool raised6[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ufr::fail(UFR_ELAUNCH, "igemm: no current device");
-    if (!raised6[dev]) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_pp_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         pp_lds_bytes(128));
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_pp_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                pp_lds_bytes(64));
-      if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "igemm: %s", hipGetErrorString(e));
-      raised6[dev] = true;
-    }
-    const dim3 gpp(d->Npad / bn, (unsigned)((M + 255) / 256), nz);
-    if (bn == BN && use_buf) {   // activation rows through a buffer resource (planes < 2 GB)
-      static bool raisedb[64] = {};
-      if (!raisedb[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_pp_kernel<128, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, pp_lds_bytes(128));
-        if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "igemm: %s", hipGetErrorString(e));
-        raisedb[dev] = true;
-      }
-      igemm_pp_kernel<128, true><<<gpp, 512, pp_lds_bytes(128), st>>>(a);
-    } else
-    if (bn == BN) igemm_pp_kernel<128><<<gpp, 512, pp_lds_bytes(128), st>>>(a);
-    else igemm_pp_kernel<64><<<gpp, 512, pp_lds_bytes(64), st>>>(a);
-  } else if (variant == 5 && d->products == 6 && bn == BN) {       // register-held fragments, DMA of the next tile under the MFMAs
-    static bool raised5[64] = {};          // per device: a process may drive more than one
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ufr::fail(UFR_ELAUNCH, "igemm: no current device");
-    if (!raised5[dev]) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_glds_kernel<128, 128, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS_BYTES);
-      if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "igemm: %s", hipGetErrorString(e));
-      raised5[dev] = true;
-    }
+    if (use_buf) igemm_pp_kernel<128, true><<<gpp, 512, pp_lds_bytes(128), st>>>(a);
+    else igemm_pp_kernel<128><<<gpp, 512, pp_lds_bytes(128), st>>>(a);
+  } else if (variant == 5 && bn == BN) {           // register-held fragments, DMA of the next tile under the MFMAs
     igemm_glds_kernel<128, 128, true><<<grid, 256, PIPE_LDS_BYTES, st>>>(a);
-  } else if (variant >= 2 && d->products == 6) {
-    if (bn == BN) {
-      if (use_buf) igemm_glds_kernel<128, 128, false, true><<<grid, 256, 0, st>>>(a);
-      else igemm_glds_kernel<128, 128><<<grid, 256, 0, st>>>(a);
-    } else {
-      if (use_buf) igemm_glds_kernel<128, 64, false, true><<<grid, 256, 0, st>>>(a);
-      else igemm_glds_kernel<128, 64><<<grid, 256, 0, st>>>(a);
-    }
   } else if (bn == BN) {
-    if (d->products == 6) igemm_kernel<6, 128><<<grid, 256, 0, st>>>(a);
-    else if (d->products == 3) igemm_kernel<3, 128><<<grid, 256, 0, st>>>(a);
-    else igemm_kernel<1, 128><<<grid, 256, 0, st>>>(a);
+    if (use_buf) igemm_glds_kernel<128, 128, false, true><<<grid, 256, 0, st>>>(a);
+    else igemm_glds_kernel<128, 128><<<grid, 256, 0, st>>>(a);
   } else {
-    UFR_REQUIRE(d->products == 6, "igemm: 64-column tiles are built for six products only");
-    igemm_kernel<6, 64><<<grid, 256, 0, st>>>(a);
+    if (use_buf) igemm_glds_kernel<128, 64, false, true><<<grid, 256, 0, st>>>(a);
+    else igemm_glds_kernel<128, 64><<<grid, 256, 0, st>>>(a);
   }
   int rc = ufr::launched("igemm_kernel");
   if (rc != UFR_OK || d->splitk == 1) return rc;

@@ -84,7 +84,6 @@ class FlowNetCHeadEngine:
         self.c6a, self.c6 = P(64, 32), P(64, 32)
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.flow = {k: torch.zeros(B, 2, *g[2 ** k], **f32) for k in (6, 5, 4, 3, 2)}
-        self.corr = torch.zeros(B, 21, 21, *g[8], **f32)
         # ---- gradients
         self.G_cat2, self.G_cat3, self.G_cat4, self.G_cat5 = G(4, 7), G(8, 13), G(16, 25), G(32, 33)
         self.G_c6, self.G_in31, self.G_c3a = G(64, 32), G(8, 15 if self.siamese else 8), G(8, 8)
@@ -97,6 +96,7 @@ class FlowNetCHeadEngine:
         self.g_c3a, self.g_c3a_redir, self.g_c3b = (torch.zeros(B, 256, *g[8], **f32) for _ in range(3))
         self.c3_nchw = torch.zeros(2 * B, 256, *g[8], **f32)        # both frames' conv3 for the correlation kernels
         self._prefix = None                                          # full-frame conv1-3 buffers + launches, built on first use
+        self._wprefixes, self._wprefix = {}, None                    # window-prefix state per window size; the one used last
         self._build_launches()
 
     # ------------------------------------------------------------------------------------------------ set-up
@@ -110,34 +110,17 @@ class FlowNetCHeadEngine:
         def plan(wi, x, in_chunk0, rows, out_hw, **kw):
             M = B * rows[0] * rows[1]
             pk = [len(t) * wi.KC for _, _, t in wi.phases]
-            if self._pipe and not small_batch:
-                kw.setdefault("variant", self._pipe_variant if wi.Npad % 128 == 0 or self._pp64 else 2)
+            kw.setdefault("variant", self._variant_for(wi))
             bm, target = self._tile_rows_and_slots(wi, kw)
             S = ig.splitk_for(M, wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target)
-            if small_batch and "variant" not in kw:
-                kw["variant"] = 4                  # (split factor as sized for 128-row tiles: the measured combination)
             plans.append((wi, x, in_chunk0, rows, out_hw, S, kw))
             return len(plans) - 1
 
-        # one pair (the reference's own batch size): every launch is under-filled and 64 x 128 tiles with four workgroups per
-        # CU measured 10 % faster for the whole iteration (1.75 -> 1.59 ms; equal at two pairs, slower from four on)
-        # (since the pipelined 128 x 128 kernel: 1.59 ms with 64 x 128 tiles, 1.56 ms without -> opt-in, UFR_IGEMM_SMALL_BATCH=1)
-        small_batch = self._small_batch = (B == 1 and os.environ.get("UFR_IGEMM") is None
-                                           and os.environ.get("UFR_IGEMM_SMALL_BATCH", "0") == "1")
         # 128-column launches: csrc/igemm.hip variant 6 (ping-pong: 256 x 128 tiles, two wave groups of one workgroup per CU half a
-        # step apart) or 5 (pipelined 128 x 128, two workgroups per CU; UFR_IGEMM_PIPE=5) instead of the single-stage kernel
-        # (UFR_IGEMM_PIPE=0).  Same box, one iteration: 6.27 / 6.56 / 6.88 ms (profiles/r2_bench_pingpong_ab.txt)
-        self._pipe = os.environ.get("UFR_IGEMM_PIPE", "1") != "0" and os.environ.get("UFR_IGEMM") is None
-        # 64-column launches (deconv2 forward, conv1, conv_redir) stay on the single-stage kernel: the ping-pong form with 12 KB
-        # weight images measured slower there (deconv2 forward 0.29-0.30 against 0.26 ms, conv1 of the prefix 0.57 against 0.48:
-        # 48 MFMAs per wave and half-step do not cover a group's read half-step).  UFR_IGEMM_PP64=1 switches it on (A/B)
-        self._pp64 = os.environ.get("UFR_IGEMM_PP64", "0") == "1"
-        self._pipe_variant = {"5": 5, "7": 7}.get(os.environ.get("UFR_IGEMM_PIPE"), 6)      # 6: ping-pong (256 x 128 tiles, two wave groups half a step apart)
-
-        # 64 x 128 tiles (csrc/igemm.hip variant 4, four workgroups per CU): 7-19 % faster on the stride-2 data gradients and
-        # deconv3's in the isolated per-layer bench (profiles/r2_igemm_layers_v4_tile64.jsonl), neutral to slightly slower
-        # inside the step (6.66 / 6.70 vs 6.65 / 6.66 ms) -> opt-in
-        m64 = dict(variant=4) if os.environ.get("UFR_IGEMM_M64", "0") == "1" else {}
+        # step apart); UFR_IGEMM_PIPE=5: pipelined 128 x 128, two workgroups per CU; UFR_IGEMM_PIPE=0: the single-stage kernel.
+        # Same box, one iteration: 6.27 / 6.56 / 6.88 ms (profiles/r2_bench_pingpong_ab.txt).  64-column launches (deconv2
+        # forward, conv1, conv_redir) always run the single-stage 128 x 64 tile.
+        self._pipe_variant = {"0": 2, "5": 5}.get(os.environ.get("UFR_IGEMM_PIPE", "6"), 6)
 
         fwd, bwd = {}, {}
         cw = lambda n, s, p: ig.conv_forward_weights(self._conv(n).weight, s, p)
@@ -167,26 +150,23 @@ class FlowNetCHeadEngine:
         # deconvK's input ends with the two channels of the upsampled flow: 386 / 770 / 1026 columns would pad the GEMM to
         # 512 / 896 / 1152 (and deconv3 / deconv4 to a second round of workgroups); the 384 / 768 / 1024 feature channels go
         # through the igemm and the two flow columns through the 2-channel kernel (`_deconv_tail`)
-        self.tail = os.environ.get("UFR_DECONV_TAIL", "1") != "0"
         self.tail_w, self.tail_args = {}, {}
         for k in (2, 3, 4):
             src, chunk0, _ = gz[k]
             s_in = {2: 8, 3: 16, 4: 32}[k]
             w = self._conv(f"deconv{k}").weight
-            main = w.shape[0] - 2 if self.tail else w.shape[0]
-            bwd[f"deconv{k}"] = plan(ig.deconv_backward_weights(w[:main], 1), src, chunk0, g[s_in], g[s_in], out_f32=Gabove[k],
-                                     **(m64 if k == 3 else {}))
-            if self.tail:
-                self.tail_w[k] = _pack_flow_tail_mfma(w[main:])
-                self.tail_args[k] = (src, chunk0, ig.pad32(w.shape[1]) // 32, Gabove[k], main // 32, g[s_in])
+            main = w.shape[0] - 2
+            bwd[f"deconv{k}"] = plan(ig.deconv_backward_weights(w[:main], 1), src, chunk0, g[s_in], g[s_in], out_f32=Gabove[k])
+            self.tail_w[k] = _pack_flow_tail_mfma(w[main:])
+            self.tail_args[k] = (src, chunk0, ig.pad32(w.shape[1]) // 32, Gabove[k], main // 32, g[s_in])
         bwd["deconv5"] = plan(ig.deconv_backward_weights(self._conv("deconv5").weight, 1), self.gz_cat5, 16, g[64], g[64],
                               add=self.G_c6, mask=self.c6, out_planes=self.gz_c6)
         bwd["conv6_1"] = plan(cb("conv6_1", 1, 1), self.gz_c6, 0, g[64], g[64], mask=self.c6a, out_planes=self.gz_c6a)
-        bwd["conv6"] = plan(cb("conv6", 2, 1), self.gz_c6a, 0, g[64], g[32], add=self.G_cat5, mask=self.cat5, out_planes=self.gz_cat5, **m64)
+        bwd["conv6"] = plan(cb("conv6", 2, 1), self.gz_c6a, 0, g[64], g[32], add=self.G_cat5, mask=self.cat5, out_planes=self.gz_cat5)
         bwd["conv5_1"] = plan(cb("conv5_1", 1, 1), self.gz_cat5, 0, g[32], g[32], mask=self.c5a, out_planes=self.gz_c5a)
-        bwd["conv5"] = plan(cb("conv5", 2, 1), self.gz_c5a, 0, g[32], g[16], add=self.G_cat4, mask=self.cat4, out_planes=self.gz_cat4, **m64)
+        bwd["conv5"] = plan(cb("conv5", 2, 1), self.gz_c5a, 0, g[32], g[16], add=self.G_cat4, mask=self.cat4, out_planes=self.gz_cat4)
         bwd["conv4_1"] = plan(cb("conv4_1", 1, 1), self.gz_cat4, 0, g[16], g[16], mask=self.c4a, out_planes=self.gz_c4a)
-        bwd["conv4"] = plan(cb("conv4", 2, 1), self.gz_c4a, 0, g[16], g[8], add=self.G_cat3, mask=self.cat3, out_planes=self.gz_cat3, **m64)
+        bwd["conv4"] = plan(cb("conv4", 2, 1), self.gz_c4a, 0, g[16], g[8], add=self.G_cat3, mask=self.cat3, out_planes=self.gz_cat3)
         if self.siamese:
             bwd["conv3_1"] = plan(cb("conv3_1", 1, 1), self.gz_cat3, 0, g[8], g[8], mask=self.in31, out_planes=self.gz_in31,
                                   out_f32=self.G_in31)
@@ -205,7 +185,6 @@ class FlowNetCHeadEngine:
         # 2-channel layers
         self.pf_w = {k: _pack_flow_head(getattr(net, f"predict_flow{k}").weight) for k, _ in _HEADS}
         self.pf_wm = {k: _pack_flow_head_mfma(getattr(net, f"predict_flow{k}").weight) for k, _ in _HEADS}
-        self.pf_mfma = os.environ.get("UFR_PF_MFMA", "1") != "0"
         self.pf_b = {k: getattr(net, f"predict_flow{k}").bias.detach().float().contiguous() for k, _ in _HEADS}
         self.up = {k: getattr(net, f"upsampled_flow{k}_to_{k - 1}") for k in (6, 5, 4, 3)}
         self.up_w = {k: m.weight.detach().float().contiguous() for k, m in self.up.items()}
@@ -217,15 +196,21 @@ class FlowNetCHeadEngine:
         self.up_G = {6: (self.G_cat5, 32), 5: (self.G_cat4, 24), 4: (self.G_cat3, 12), 3: (self.G_cat2, 6)}
 
     # ------------------------------------------------------------------------------------------------ conv1-3
+    def _variant_for(self, wi):
+        """The igemm form of a launch: the 128-column forms as `UFR_IGEMM_PIPE` says, 64-column launches single-stage."""
+        return self._pipe_variant if wi.Npad % 128 == 0 else 2
+
     @staticmethod
     def _tile_rows_and_slots(wi, kw):
         """(tile rows, resident workgroups on the chip) of the kernel a launch runs on: what split-K is sized against."""
         v = kw.get("variant", 0)
+        if wi.Npad % 128:
+            return 128, 768                    # single-stage 128 x 64 tiles, three workgroups per CU
         if v == 4:
             return 64, 1024                    # 64 x 128 tiles, four workgroups per CU
-        if v == 5 and wi.Npad % 128 == 0:
+        if v == 5:
             return 128, 512                    # register-held fragments: two workgroups per CU
-        if v in (6, 7):
+        if v == 6:
             return 256, 256                    # ping-pong: one 256-row workgroup per CU
         return 128, 768
 
@@ -242,8 +227,7 @@ class FlowNetCHeadEngine:
         w3 = ig.conv_forward_weights(self._conv("conv3").weight, 2, 2)
         # conv2 (K = 25 taps x 2 chunks) at 2 x 8 frames: 1.35 ms on single-stage 128 x 128 tiles, 1.02-1.05 on 64 x 128 tiles
         # (four workgroups per CU), 0.99-1.00 on the pipelined 128 x 128 kernel, 0.89-0.94 on the ping-pong kernel
-        v2 = self._pipe_variant if self._pipe else (4 if os.environ.get("UFR_IGEMM_M64_PREFIX", "1") != "0" else 0)
-        v3 = 4 if getattr(self, "_small_batch", False) else (self._pipe_variant if self._pipe else 0)
+        v2 = v3 = self._pipe_variant
         halves = {}
         for h, c2_dst, c3_dst in (("a", self.cat2, self.c3a_p), ("b", ig.Planes(B, H // 4, W // 4, 4, dev), self.c3b_p)):
             c1 = ig.Planes(B, H // 2, W // 2, 2, dev)
@@ -260,45 +244,23 @@ class FlowNetCHeadEngine:
         """conv1 = Conv2d(3, 64, 7, 2, 3) + bias + LeakyReLU as an igemm launch over the packed planes of the raw frames
         (csrc/igemm.hip `conv1_pack_kernel`: pixel-unshuffle + two columns per chunk -> 8 taps of one chunk, the mean
         subtraction and the zero padding inside the buffer), writing conv1's planes directly."""
-        if os.environ.get("UFR_CONV1_IGEMM", "1") == "0":
-            return {}
         packed = ig.Planes(n, H // 2 + 3, W // 2 + 2, 1, self.dev)
         wi = ig.conv1_packed_weights(self._conv("conv1").weight)
         launch = ig.make_launch(wi, packed, 0, (H // 2, W // 2), (H // 2, W // 2), out_planes=c1,
-                                bias=self._conv("conv1").bias.detach().float().contiguous(),
-                                variant=int(os.environ.get("UFR_CONV1_VARIANT", "0")))
+                                bias=self._conv("conv1").bias.detach().float().contiguous(), variant=2)
         return dict(packed=packed, conv1=launch, conv1_wi=wi)
 
     def _conv1(self, P: dict, a: torch.Tensor, b: torch.Tensor | None):
         """conv1 + bias + LeakyReLU of one or two raw frame stacks into P['c1']."""
-        if "conv1" in P:
-            a = a.contiguous()
-            L.require_hip(a, "frames")
-            nb = 0 if b is None else int(b.shape[0])
-            mean = self.net._mean64.reshape(-1).contiguous()
-            pk = P["packed"]
-            L.check(L.lib().ufr_conv1_pack_planes(L.ptr(a), L.ptr(b.contiguous()) if b is not None else None, L.ptr(pk.t),
-                                                  pk.plane_stride, int(a.shape[0]), nb, int(a.shape[2]), int(a.shape[3]),
-                                                  L.ptr(mean), L.stream()), "conv1 pack")
-            P["conv1"]()
-            return
-        x = self._normalized(a, b, P)
-        y1 = torch.nn.functional.conv2d(x, P["w1"], None, 2, 3)
-        P["c1"].load_nchw(y1, 0, 1.0, ig.LEAKY, P["b1"])                 # bias + LeakyReLU + split, one pass
-
-    def _normalized(self, a: torch.Tensor, b: torch.Tensor | None, P: dict) -> torch.Tensor:
-        """`normalize_correctly` (float64 mean subtraction, FlowNetC.py:73-79) of one or two frame stacks as one float32 stack."""
         a = a.contiguous()
         L.require_hip(a, "frames")
         nb = 0 if b is None else int(b.shape[0])
-        shape = (int(a.shape[0]) + nb, 3, int(a.shape[2]), int(a.shape[3]))
-        x = P.get("x")
-        if x is None or tuple(x.shape) != shape:
-            x = P["x"] = torch.empty(shape, dtype=torch.float32, device=self.dev)
         mean = self.net._mean64.reshape(-1).contiguous()
-        L.check(L.lib().ufr_normalize_frames(L.ptr(a), L.ptr(b.contiguous()) if b is not None else None, L.ptr(x), int(a.shape[0]), nb,
-                                             3, shape[2], shape[3], L.ptr(mean), L.stream()), "normalize frames")
-        return x
+        pk = P["packed"]
+        L.check(L.lib().ufr_conv1_pack_planes(L.ptr(a), L.ptr(b.contiguous()) if b is not None else None, L.ptr(pk.t),
+                                              pk.plane_stride, int(a.shape[0]), nb, int(a.shape[2]), int(a.shape[3]),
+                                              L.ptr(mean), L.stream()), "conv1 pack")
+        P["conv1"]()
 
     def prefix_full(self, frames_a: torch.Tensor, frames_b: torch.Tensor):
         """New frames: conv2 of the first frames and conv3 of both, for the full frame, straight into the head's plane
@@ -343,66 +305,65 @@ class FlowNetCHeadEngine:
         """conv1-3 of both frames on the patch attack's prefix window (patch_attack.py `_forward_cone`: [2B, 3, wh, ww]) and
         their data gradients, all on the igemm: conv2 / conv3 (5x5, stride 2: 92% of the window's FLOPs) as they are, conv1
         (3 input channels) over the packed planes of the raw window stack (`_conv1_launch`), its data gradient with respect
-        to those planes followed by the unpacking.  `UFR_CONV1_IGEMM=0` keeps conv1 and its gradient on torch / MIOpen."""
+        to those planes followed by the unpacking.  One state per window size, kept for the engine's life: a step's captured
+        HIP graphs hold raw pointers into these buffers, and another step on the same network may use another size."""
         B2, dev = 2 * self.B, self.dev
         f32 = dict(dtype=torch.float32, device=dev)
         h2, w2, h4, w4, h8, w8 = wh // 2, ww // 2, wh // 4, ww // 4, wh // 8, ww // 8
         c1, c2, c3 = ig.Planes(B2, h2, w2, 2, dev), ig.Planes(B2, h4, w4, 4, dev), ig.Planes(B2, h8, w8, 8, dev)
         gz_c3, gz_c2 = ig.Planes(B2, h8, w8, 8, dev), ig.Planes(B2, h4, w4, 4, dev)
-        conv1_native = os.environ.get("UFR_CONV1_IGEMM", "1") != "0"
-        v64 = 4 if os.environ.get("UFR_IGEMM_M64_PREFIX", "1") != "0" else (self._pipe_variant if self._pipe else 0)   # (0.047 vs 0.055 ms)
         gz_c1, G_p = ig.Planes(B2, h2, w2, 2, dev), ig.GradSum(B2, h2 + 3, w2 + 2, 1, dev)
-        G_gw2, G_c1 = ig.GradSum(B2, h4, w4, 4, dev), ig.GradSum(B2, h2, w2, 2, dev)   # G_gw2: the conv2 tap's window gradient
-                                                                                       # (first frames; second frames stay 0)
+        G_gw2 = ig.GradSum(B2, h4, w4, 4, dev)       # the conv2 tap's window gradient (first frames; second frames stay 0)
         bias = lambda n: self._conv(n).bias.detach().float().contiguous()
         plans = [
-            # (the window's forward convolutions: 64 x 128 tiles measured 1.3x faster than 128 x 128 at the same split)
+            # (the window's forward convolutions: 64 x 128 tiles measured 1.3x faster than 128 x 128 at the same split,
+            # 0.047 vs 0.055 ms)
             (ig.conv_forward_weights(self._conv("conv2").weight, 2, 2), c1, (h4, w4), (h4, w4),
-             dict(out_planes=c2, bias=bias("conv2"), variant=v64)),
+             dict(out_planes=c2, bias=bias("conv2"), variant=4)),
             (ig.conv_forward_weights(self._conv("conv3").weight, 2, 2), c2, (h8, w8), (h8, w8),
-             dict(out_planes=c3, bias=bias("conv3"), variant=v64)),
+             dict(out_planes=c3, bias=bias("conv3"), variant=4)),
             # conv3's data gradient + the skip connection's gradient, x LeakyReLU'(conv2) -> conv2's gradient planes
             (ig.conv_backward_weights(self._conv("conv3").weight, 2, 2), gz_c3, (h8, w8), (h4, w4),
              dict(add=G_gw2, mask=c2, out_planes=gz_c2)),
             (ig.conv_backward_weights(self._conv("conv2").weight, 2, 2), gz_c2, (h4, w4), (h2, w2),
-             dict(out_planes=gz_c1, mask=c1) if conv1_native else dict(out_f32=G_c1)),
+             dict(out_planes=gz_c1, mask=c1)),
+            # conv1's data gradient with respect to the packed planes (the unpacking follows)
+            (ig.conv1_packed_backward_weights(self._conv("conv1").weight), gz_c1, (h2 + 3, w2 + 2), (h2 + 3, w2 + 2),
+             dict(out_f32=G_p)),
         ]
-        if conv1_native:                         # conv1's data gradient with respect to the packed planes, then the unpacking
-            plans.append((ig.conv1_packed_backward_weights(self._conv("conv1").weight), gz_c1, (h2 + 3, w2 + 2), (h2 + 3, w2 + 2),
-                          dict(out_f32=G_p)))
         sized = []
         for wi, x, rows, out_hw, kw in plans:
             pk = [len(t) * wi.KC for _, _, t in wi.phases]
-            if self._pipe and not getattr(self, "_small_batch", False):
-                kw.setdefault("variant", self._pipe_variant if wi.Npad % 128 == 0 or self._pp64 else 2)
-            bm, target = self._tile_rows_and_slots(wi, kw) if kw.get("variant") in (5, 6, 7) else (128, 768)
+            kw.setdefault("variant", self._variant_for(wi))
+            bm, target = self._tile_rows_and_slots(wi, kw) if kw.get("variant") in (5, 6) else (128, 768)
             sized.append(ig.splitk_for(B2 * rows[0] * rows[1], wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target))
         need = max([len(wi.phases) * S * B2 * rows[0] * rows[1] * wi.Npad for (wi, _, rows, _, _), S in zip(plans, sized) if S > 1] + [1])
         ws = torch.empty(need, **f32)
-        if getattr(self, "_small_batch", False):
-            for _, _, _, _, kw in plans:
-                kw.setdefault("variant", 4)
         launches = [ig.make_launch(wi, x, 0, rows, out_hw, splitk=S, ws=ws if S > 1 else None, **kw)
                     for (wi, x, rows, out_hw, kw), S in zip(plans, sized)]
         wis = {k + "_wi": p[0] for k, p in zip(("conv2", "conv3", "conv3_bwd", "conv2_bwd", "conv1_bwd"), plans)}
-        self._wprefix = dict(**wis, hw=(wh, ww), c1=c1, c2=c2, c3=c3, gz_c3=gz_c3, gz_c2=gz_c2, G_gw2=G_gw2, G_c1=G_c1, ws=ws,
-                             conv2=launches[0], conv3=launches[1], conv3_bwd=launches[2], conv2_bwd=launches[3],
-                             b1=bias("conv1"), w1=self._conv("conv1").weight.detach(),
-                             c2_nchw=torch.zeros(B2, 128, h4, w4, **f32), c3_nchw=torch.zeros(B2, 256, h8, w8, **f32),
-                             g_c1=torch.zeros(B2, 64, h2, w2, **f32))
-        if conv1_native:
-            self._wprefix.update(conv1_bwd=launches[4], G_p=G_p, gxw=torch.zeros(B2, 3, wh, ww, **f32))
-        self._wprefix.update(self._conv1_launch(B2, wh, ww, c1))
+        P = dict(**wis, hw=(wh, ww), c1=c1, c2=c2, c3=c3, gz_c3=gz_c3, gz_c2=gz_c2, G_gw2=G_gw2, ws=ws,
+                 conv2=launches[0], conv3=launches[1], conv3_bwd=launches[2], conv2_bwd=launches[3], conv1_bwd=launches[4],
+                 G_p=G_p, gxw=torch.zeros(B2, 3, wh, ww, **f32),
+                 c2_nchw=torch.zeros(B2, 128, h4, w4, **f32), c3_nchw=torch.zeros(B2, 256, h8, w8, **f32))
+        P.update(self._conv1_launch(B2, wh, ww, c1))
+        self._wprefixes[(wh, ww)] = P
+        return P
+
+    def window_prefix(self, wh: int, ww: int) -> dict:
+        """The window-prefix state for a (wh, ww) window; `_wprefix` = the one used last (launch_table, the backward)."""
+        P = self._wprefixes.get((int(wh), int(ww)))
+        if P is None:
+            P = self._build_window_prefix(int(wh), int(ww))
+        self._wprefix = P
+        return P
 
     def window_prefix_forward(self, xw: torch.Tensor, win: torch.Tensor, m2: int, m3: int):
         """conv1-3 of the window stack `xw` [2B, 3, wh, ww] (raw frames; first frames, then second frames), patched into the
         cached full-frame features.  The window's convolutions zero-pad at the window's edges exactly like the torch
         prefix they replace; the inexact rim (m2 / m3 cells) is skipped by the scatter."""
         wh, ww = int(xw.shape[2]), int(xw.shape[3])
-        P = getattr(self, "_wprefix", None)
-        if P is None or P["hw"] != (wh, ww):
-            self._build_window_prefix(wh, ww)
-            P = self._wprefix
+        P = self.window_prefix(wh, ww)
         self._conv1(P, xw.detach(), None)
         P["conv2"]()
         P["conv3"]()
@@ -433,13 +394,10 @@ class FlowNetCHeadEngine:
         L.check(L.lib().ufr_nchw_grad_to_planes(L.ptr(gw3), L.ptr(P["c3_nchw"]), L.ptr(gz.t), gz.plane_stride, 0, 2 * B, 256, wh // 8,
                                                 ww // 8, ig.LEAKY, L.stream()), "window gradient -> planes")
         P["conv3_bwd"]()                         # + G_gw2, x LeakyReLU'(conv2) -> gz_c2 (epilogue)
-        P["conv2_bwd"]()
-        if "conv1_bwd" in P:                     # conv2's data gradient wrote conv1's gradient planes (x LeakyReLU'(conv1))
-            P["conv1_bwd"]()                     # -> gradient of the packed planes -> gradient of the raw window stack
-            L.check(L.lib().ufr_conv1_unpack_grad(L.ptr(P["G_p"].t), L.ptr(P["gxw"]), 2 * B, wh, ww, L.stream()), "conv1 unpack")
-            return P["gxw"]
-        g1 = P["G_c1"].to_nchw(64, 0, mask=P["c1"], out=P["g_c1"])       # LeakyReLU' of conv1's output fused
-        return torch.nn.grad.conv2d_input((2 * B, 3, wh, ww), P["w1"], g1, stride=2, padding=3)
+        P["conv2_bwd"]()                         # x LeakyReLU'(conv1) -> conv1's gradient planes
+        P["conv1_bwd"]()                         # -> gradient of the packed planes -> gradient of the raw window stack
+        L.check(L.lib().ufr_conv1_unpack_grad(L.ptr(P["G_p"].t), L.ptr(P["gxw"]), 2 * B, wh, ww, L.stream()), "conv1 unpack")
+        return P["gxw"]
 
     # ------------------------------------------------------------------------------------------------ column band
     # (level stride of the ROW grid, of the input grid) of the launches that run on the band's columns only
@@ -470,7 +428,7 @@ class FlowNetCHeadEngine:
                 extra["in_band"] = (origin, 8, ls_in, band.width // ls_in)
             M = self.B * rows_b[0] * rows_b[1]
             pk = [len(t) * wi.KC for _, _, t in wi.phases]
-            bm, target = (128, 768) if self._small_batch else self._tile_rows_and_slots(wi, kw)
+            bm, target = self._tile_rows_and_slots(wi, kw)
             Sb = ig.splitk_for(M, wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target)
             if len(wi.phases) * Sb * M * wi.Npad > self.ws.numel():
                 Sb = 1
@@ -514,14 +472,9 @@ class FlowNetCHeadEngine:
     # ------------------------------------------------------------------------------------------------ small launches
     def _pf_forward(self, k):
         src, chunks = self.pf_src[k]
-        if self.pf_mfma:
-            L.check(L.lib().ufr_flow_head_planes_forward_mfma(L.ptr(src.t), src.plane_stride, 0, chunks, L.ptr(self.pf_wm[k]),
-                                                              L.ptr(self.pf_b[k]), L.ptr(self.flow[k]), self.B, src.H, src.W,
-                                                              L.stream()), "predict_flow forward (mfma)")
-            return
-        L.check(L.lib().ufr_flow_head_planes_forward(L.ptr(src.t), src.plane_stride, 0, chunks, L.ptr(self.pf_w[k]),
-                                                     L.ptr(self.pf_b[k]), L.ptr(self.flow[k]), self.B, src.H, src.W,
-                                                     L.stream()), "predict_flow forward")
+        L.check(L.lib().ufr_flow_head_planes_forward_mfma(L.ptr(src.t), src.plane_stride, 0, chunks, L.ptr(self.pf_wm[k]),
+                                                          L.ptr(self.pf_b[k]), L.ptr(self.flow[k]), self.B, src.H, src.W,
+                                                          L.stream()), "predict_flow forward (mfma)")
 
     def _pf_backward(self, k, gy, accumulate):
         src, chunks = self.pf_src[k]
@@ -576,8 +529,6 @@ class FlowNetCHeadEngine:
         `band` (band_conv.Band) with `incremental` set: the features differ from the previous call's only inside the
         prefix window, so conv_redir / conv3_1 / conv4 / conv4_1 recompute the band's columns only -- the plane buffers
         still hold the previous iteration's activations everywhere else."""
-        from . import spatial_correlation_sampler_backend as correlation
-        import ctypes as C
         if not self.siamese:
             return self._forward_trunk(c2a, c3a)
         for t, name in ((c3a, "c3a"), (c3b, "c3b")):
@@ -587,31 +538,23 @@ class FlowNetCHeadEngine:
         if band is not None:
             self.attach_band(band)
             inc = bool(band.width and band.incremental and band.inc_layers)
-        import os
-        planes_corr = os.environ.get("UFR_CORR_PLANES", "1") == "1"
         if c2a is not None:                      # features handed over in NCHW: convert; None: the planes are up to date
             L.require_hip(c2a, "c2a")
             self.cat2.load_nchw(c2a, 0)
             self.c3a_p.load_nchw(c3a, 0)
-            if planes_corr:
-                self.c3b_p.load_nchw(c3b, 0)
-        # submodules.py:124-138 (`correlate`: /C) + FlowNetC.py:139 LeakyReLU fused into the correlation's epilogue
-        corr_inc = (inc and planes_corr and band.cone_win is not None and band.cone_hw[1] // 8 <= 23
-                    and os.environ.get("UFR_CORR_INCREMENTAL", "1") != "0")
-        if corr_inc:                             # later iterations of a call: only the window's neighbourhood of the volume changes
+            self.c3b_p.load_nchw(c3b, 0)
+        # submodules.py:124-138 (`correlate`: /C) + FlowNetC.py:139 LeakyReLU fused into the correlation's epilogue:
+        # matrix cores, planes in, conv3_1's input planes out (correlation_planes.hip)
+        if inc and band.cone_win is not None and band.cone_hw[1] // 8 <= 23:
+            # later iterations of a call: only the window's neighbourhood of the volume changes
             L.check(L.lib().ufr_corr_forward_planes_window(L.ptr(self.c3a_p.t), L.ptr(self.c3b_p.t), self.c3a_p.plane_stride,
                                                            L.ptr(self.in31.t), self.in31.plane_stride, 1, self.B, 256, *self.grid[8],
                                                            21, 2, 1.0 / 256.0, ig.LEAKY, L.ptr(band.cone_win), 8,
                                                            band.cone_hw[1] // 8, L.stream()), "correlation forward (planes, window)")
-        elif planes_corr:                        # matrix cores, planes in, conv3_1's input planes out (correlation_planes.hip)
+        else:
             L.check(L.lib().ufr_corr_forward_planes(L.ptr(self.c3a_p.t), L.ptr(self.c3b_p.t), self.c3a_p.plane_stride,
                                                     L.ptr(self.in31.t), self.in31.plane_stride, 1, self.B, 256, *self.grid[8], 21, 2,
                                                     1.0 / 256.0, ig.LEAKY, L.stream()), "correlation forward (planes)")
-        else:
-            p = correlation._params(1, 1, 21, 21, 0, 0, 1, 1, 2, 2, 1, 1)
-            L.check(L.lib().ufr_corr_forward_fused(L.ptr(c3a), L.ptr(c3b), L.ptr(self.corr), L.UFR_F32, self.B, 256, *self.grid[8],
-                                                   C.byref(p), 1.0 / 256.0, ig.LEAKY, L.stream()), "correlation forward")
-            self.in31.load_nchw(self.corr.view(self.B, 441, *self.grid[8]), 1)
         for name in ("conv_redir", "conv3_1", "conv4", "conv4_1"):
             (self.fwd_band if inc else self.fwd)[name]()
         for name in ("conv5", "conv5_1", "conv6", "conv6_1"):
@@ -649,8 +592,7 @@ class FlowNetCHeadEngine:
             self._finalize(Gs, act, out, chunk0, chunks)          # LeakyReLU' of deconvK's output
             self._up_backward(k + 1)                               # -> d/d flow(K+1)
             self.bwd[f"deconv{k}"]()                               # writes the gradient sum of cat(K+1)
-            if self.tail:
-                self._deconv_tail(k)
+            self._deconv_tail(k)
             self._pf_backward(k + 1, self.g_flow[k + 1], accumulate=True)
         Gs, act, out, chunk0, chunks = gz[5]
         self._finalize(Gs, act, out, chunk0, chunks)
@@ -668,8 +610,7 @@ class FlowNetCHeadEngine:
         # conv_redir's input and the correlation's two inputs
         gw = getattr(band, "g3_window", None) if (band is not None and fused_window) else None
         h8, w8 = self.grid[8]
-        if (gw is not None and band.cone_win is not None and band.cone_hw[1] // 8 <= 16 and w8 % 4 == 0
-                and os.environ.get("UFR_CORR_BWD_MFMA", "1") != "0"):
+        if gw is not None and band.cone_win is not None and band.cone_hw[1] // 8 <= 16 and w8 % 4 == 0:
             # windowed prefix behind the head: the cost volume's adjoints on the window's cells, on the matrix cores, straight
             # from the gradient sums into the window-sized gradient (correlation_window_mfma.hip)
             L.check(L.lib().ufr_corr_backward_window_fused(L.ptr(self._c3a), L.ptr(self._c3b), L.ptr(self.G_in31.t), 1, 1.0 / 256.0,
@@ -700,16 +641,27 @@ class FlowNetCHeadEngine:
 
 
 class _EngineHead(torch.autograd.Function):
+    """The engine keeps its activations in static buffers, so a forward is only differentiable until the NEXT forward of
+    the same engine: `generation` counts forwards, backward refuses a stale one (two grad-mode forwards of one shape before
+    a backward -- e.g. loss(flow(a), flow(b)) -- would otherwise silently differentiate the second call twice)."""
+
     @staticmethod
     def forward(ctx, c2a, c3a, c3b, engine, band):
         ctx.engine, ctx.band = engine, band
+        engine.generation = ctx.generation = getattr(engine, "generation", 0) + 1
         # the engine's flow2 is a static buffer: hand autograd its own (2-channel, tiny) tensor
         return engine.forward(c2a.contiguous(), c3a.contiguous(), c3b.contiguous() if c3b is not None else None, band).clone()
 
     @staticmethod
     def backward(ctx, g_flow2):
+        if ctx.engine.generation != ctx.generation:
+            raise RuntimeError("FlowNetC head engine: another forward of this network (same batch and frame size) ran before this "
+                               "backward; its activations are gone.  Call backward() before the next forward, or set "
+                               "UFR_ENGINE=0 for interleaved forwards")
         g2a, g3a, g3b = ctx.engine.backward(g_flow2.contiguous(), ctx.band, fused_window=False)
-        return g2a, g3a, g3b, None, None
+        # static buffers as well: autograd (and a caller who retains .grad) gets its own copies
+        return (g2a.clone() if g2a is not None else None, g3a.clone() if g3a is not None else None,
+                g3b.clone() if g3b is not None else None, None, None)
 
 
 def _weights_stamp(net):

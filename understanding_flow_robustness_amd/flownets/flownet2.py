@@ -51,7 +51,7 @@ class _Refinement(nn.Module):
     def _engine_ok(self, c2a) -> bool:
         """Frozen parameters, eval mode, HIP float32 features, frame sides that are multiples of 64 (UFR_ENGINE=0 switches off)."""
         import os
-        if os.environ.get("UFR_ENGINE", "1") != "1" or os.environ.get("UFR_ENGINE_FLOWNET2", "1") != "1" or self.training:
+        if os.environ.get("UFR_ENGINE", "1") != "1" or self.training:
             return False
         frozen = not any(p.requires_grad for p in self.parameters())
         return (c2a.is_cuda and c2a.dtype == torch.float32 and (frozen or not torch.is_grad_enabled())

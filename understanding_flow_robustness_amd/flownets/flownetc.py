@@ -134,7 +134,7 @@ class FlowNetC(nn.Module):
         iteration)?  Same conditions as `_engine_ok`, asked before any feature exists."""
         import os
         frozen = not any(p.requires_grad for p in self.parameters())
-        return (os.environ.get("UFR_ENGINE", "1") == "1" and os.environ.get("UFR_ENGINE_PREFIX", "1") == "1" and not self.training
+        return (os.environ.get("UFR_ENGINE", "1") == "1" and not self.training
                 and not self.return_feat_maps and frozen and torch.device(device).type == "cuda" and H % 64 == 0 and W % 64 == 0)
 
     def _engine_ok(self, c2a, feats, band):

@@ -7,7 +7,6 @@ during an attack), everything else is descriptors over device pointers.
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import torch
 
@@ -106,8 +105,8 @@ def _split3(w: torch.Tensor) -> torch.Tensor:
 
 # Order of a phase's K tiles (ufr_igemm_desc.k_order).  1: all taps of one 32-channel chunk, then the next chunk -- a tile's
 # taps read overlapping pixels, so eight of nine reads of a 3x3 layer hit in L2 instead of streaming the activation again
-# per tap.  UFR_IGEMM_KORDER=0 restores the tap-major order (A/B); the image and the descriptor always agree.
-K_ORDER = int(os.environ.get("UFR_IGEMM_KORDER", "1") != "0")
+# per tap (0 = tap-major, round 2's first form: 18.5 instead of 10.1 GB per iteration); the image and the descriptor agree.
+K_ORDER = 1
 
 
 def _pack(mats, device):
@@ -312,7 +311,7 @@ def make_launch(wi: WeightImage, x: Planes, in_chunk0: int, rows_hw, out_hw, *, 
         d.ws = ws.data_ptr()
     d.products = int(products)
     d.k_order = int(wi.k_order)
-    d.variant = int(variant)               # 0 = library default, 1 = register-staged kernel, 2 = LDS-DMA kernel
+    d.variant = int(variant)               # 0 / 2 = single-stage tiles, 4 = 64 x 128, 5 = pipelined, 6 = ping-pong (csrc/igemm.hip)
     return Launch(d, keep)
 
 

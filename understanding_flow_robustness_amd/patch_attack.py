@@ -133,9 +133,8 @@ class PatchAttackStep:
         self.adv_ref = torch.zeros_like(self.tgt).requires_grad_(True)
         self.g_flow = torch.zeros_like(self.target)
         self.loss_ws = torch.zeros(L.LOSS_PARTIALS, **f32)     # workgroup partials of the fixed-order loss reduction
-        # engine head: the loss kernel upsamples flow2 itself when its tiles fit the partial sums (UFR_FUSED_LOSS=0: three passes)
-        self._fused_loss = (os.environ.get("UFR_FUSED_LOSS", "1") != "0"
-                            and batch * -(-(height // 4) // 16) * -(-(width // 4) // 16) <= L.LOSS_PARTIALS
+        # engine head: the loss kernel upsamples flow2 itself when its tiles fit the partial sums (else three passes)
+        self._fused_loss = (batch * -(-(height // 4) // 16) * -(-(width // 4) // 16) <= L.LOSS_PARTIALS
                             and height % 4 == 0 and width % 4 == 0)
         self.g_flow2 = torch.zeros(batch, 2, height // 4, width // 4, **f32)
         self.state = torch.zeros(4, **f32)     # stopped, executed, last loss, (pad)
@@ -230,7 +229,7 @@ class PatchAttackStep:
             self.eng = get_engine(self.net, B, H, W, self.dev)
             self.eng.flow[2].requires_grad_(True)
         # the window's conv2 / conv3 and their data gradients on the engine's igemm instead of torch / MIOpen
-        self._eng_window = self.eng is not None and os.environ.get("UFR_ENGINE_WINDOW", "1") != "0"
+        self._eng_window = self.eng is not None
         self.taps = []                         # (level stride, margin, frames, full leaf, window gradient)
         with torch.no_grad():
             feats = self.net.encode(torch.zeros(2, 3, spec.total_stride * 2, spec.total_stride * 2, **f32))
