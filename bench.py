@@ -270,10 +270,44 @@ def cpu_baseline():
         _, _, _, k, _ = fo.patch_attack(predict, tgt, ref, patch0.clone(), mask, patch0, target, lr=1e3, max_count=2)
         n, calls = n + k, calls + 1
     dt = time.time() - t0
-    return dict(value=round(n / dt, 4), unit="frame-pairs*steps/s", cores=cores, kind="port", c1_cpu_forward_s=round(c1, 3),
+    return dict(value=round(n / dt, 4), unit="frame-pairs*steps/s", cores=cores, cpu_model=cpu_model(), kind="port",
+                c1_cpu_forward_s=round(c1, 3),
                 sample=f"{calls} attack() calls of 2 iterations ({n} iterations), 1 pair 384x1280 (the reference's "
                        f"batch size), FlowNetC fp32, torch-CPU convs + C oracle correlation (OpenMP over "
                        f"batch*channels; the reference's CPU backward is single-threaded at batch 1), {dt:.1f} s")
+
+
+def launch_ranks(n, argv):
+    """One process per GPU through `python -m torch.distributed.run` on 127.0.0.1 (a free port), as a CHILD process: this
+    process has made no HIP call yet and makes none.  Returns the exit code; rank 0's stdout (the one JSON line) is relayed."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in lines[-1:]:
+        print(ln, flush=True)
+    if proc.returncode == 0 and not lines:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
 
 
 def main():
@@ -287,9 +321,15 @@ def main():
     ap.add_argument("--max-count", type=int, default=2, help="iterations per attack() call (main.py:79)")
     opt = ap.parse_args()
 
+    if opt.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, BEFORE this process touches the GPU
+        # (a child launcher, never a re-exec), relay rank 0's JSON line and fail if any rank fails
+        raise SystemExit(launch_ranks(opt.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != opt.gpus:
+        raise SystemExit(f"bench.py --gpus {opt.gpus} was started with WORLD_SIZE={world}: launch one rank per GPU")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     # one rank per GPU; on a box with fewer devices than ranks (the 1-GPU rehearsal of the N>1 path,
@@ -407,9 +447,9 @@ def main():
         line["config"]["arithmetic"] = (
             "float32 end to end; the head's convolutions compute each float32 product on the bf16 matrix cores as three bf16 "
             "planes per operand and the six leading products, float32 accumulation (csrc/igemm.hip: error vs float64 at "
-            "MIOpen's own fp32 level, tests/test_igemm_gpu.py) -- the head, conv2 / conv3 of the full-frame prefix and of the "
-            "window and their data gradients, the cost volume and both of its adjoints, predict_flow; conv1 (3 input channels) "
-            "and its data gradient on MIOpen fp32" if engine_on else
+            "MIOpen's own fp32 level, tests/test_igemm_gpu.py) -- the head, conv1 / conv2 / conv3 of the full-frame prefix and of "
+            "the window and their data gradients, the cost volume and both of its adjoints, predict_flow; no vendor "
+            "convolution kernel runs in an iteration" if engine_on else
             "float32 end to end on MIOpen (UFR_ENGINE=0)")
         if world == 1:
             kernels, agg = kernel_rooflines(step, device, mc)

@@ -161,3 +161,20 @@ def test_two_rank_sharded_universal_update_equals_single_process_batch(oracle, t
     differing = float((r0["delta"] != d).float().mean())
     assert differing <= 2e-3, f"{differing:.3%} of the perturbation entries differ"
     assert float((r0["delta"] - d).abs().max()) <= 2 * 2e-3 * 3
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks (a child torch.distributed.run on
+    127.0.0.1) instead of silently running one: without a GPU each rank refuses to run -- there is no CPU fallback -- and
+    the failure is relayed as a non-zero exit code, never as a result line."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    if torch.cuda.is_available():
+        pytest.skip("covered by tests/test_sharding_gpu.py::test_bench_two_rank_rehearsal on a GPU box")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.stderr.count("bench.py needs an MI355X") >= 2, out.stderr[-2000:]

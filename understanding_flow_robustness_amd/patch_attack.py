@@ -69,9 +69,8 @@ class ShardedExchange:
 
     def gather(self, rows_local: torch.Tensor, rows_all: torch.Tensor) -> torch.Tensor:
         """rows_all[r*g:(r+1)*g] = rank r's rows_local ([g, n]); rows_all is [world*g, n], contiguous."""
-        if self.world > 1:
-            g = rows_local.shape[0]
-            self.dist.all_gather([rows_all[r * g:(r + 1) * g] for r in range(self.world)], rows_local, group=self.group)
+        if self.world > 1:                       # one collective straight into the [world*g, n] buffer (no list of views)
+            self.dist.all_gather_into_tensor(rows_all, rows_local, group=self.group)
         return rows_all
 
 
