@@ -1,0 +1,40 @@
+#!/bin/bash
+# One parametrised GPU call (replaces round 2's per-call scripts):
+#   gpurun --timeout T -- 'bash tools/gpu_call.sh NAME STEP [STEP ...]'
+# Steps run in order and stop at the first failure; outputs go to gpurun_out/NAME/.
+#   suite            python -m pytest tests -m gpu -q -x -rs
+#   tests:<expr>     python -m pytest <files / -k expression> -q -x
+#   bench[:flags]    python bench.py <flags>
+#   stats[:flags]    rocprofv3 --kernel-trace --stats of bench.py <flags> + the summaries under the same directory
+#   configs:<list>   tools/bench_configs.py <list>
+#   py:<script args> python <script args>
+set -o pipefail
+name=$1; shift
+out=gpurun_out/$name
+mkdir -p $out
+export TMPDIR=/tmp
+for step in "$@"; do
+  kind=${step%%:*}; arg=""; [ "$kind" != "$step" ] && arg=${step#*:}
+  echo "== $step"
+  case $kind in
+    suite)   timeout -k 10 1500 python -m pytest tests -m gpu -q -x -rs > $out/gpu_suite.log 2>&1; rc=$?; tail -n 6 $out/gpu_suite.log
+             [ $rc -ne 0 ] && { grep -E "^E |FAILED|Error" $out/gpu_suite.log | head -n 20; exit $rc; } ;;
+    tests)   timeout -k 10 1100 python -m pytest $arg -q -x > $out/tests.log 2>&1; rc=$?; tail -n 4 $out/tests.log
+             [ $rc -ne 0 ] && { grep -E "^E |FAILED|Error" $out/tests.log | head -n 30; exit $rc; } ;;
+    bench)   timeout -k 10 900 python bench.py $arg > $out/bench.json 2> $out/bench.err; rc=$?
+             [ $rc -ne 0 ] && { tail -n 20 $out/bench.err; exit $rc; }
+             python tools/summarize_bench.py $out/bench.json ;;
+    stats)   (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/stats -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-full-frame $arg > $GRAFT_REPO_ROOT/$out/stats_bench.json 2> $GRAFT_REPO_ROOT/$out/stats.err); rc=$?
+             [ $rc -ne 0 ] && { tail -n 20 $out/stats.err; exit $rc; }
+             f=$(find $out/stats -name "*kernel_stats.csv" | head -n 1); ft=$(find $out/stats -name "*kernel_trace.csv" | head -n 1)
+             [ -n "$f" ] && python tools/summarize_stats.py $f 25 > $out/kernel_stats.md && head -n 14 $out/kernel_stats.md
+             [ -n "$ft" ] && python tools/summarize_trace.py $ft 10 > $out/step_trace.md && head -n 30 $out/step_trace.md
+             rm -rf $out/stats ;;
+    configs) timeout -k 10 1100 python tools/bench_configs.py $arg > $out/configs.log 2>&1; rc=$?; tail -n 12 $out/configs.log
+             [ $rc -ne 0 ] && exit $rc ;;
+    py)      timeout -k 10 1100 python $arg > $out/py.log 2>&1; rc=$?; tail -n 40 $out/py.log
+             [ $rc -ne 0 ] && exit $rc ;;
+    *)       echo "unknown step $step"; exit 2 ;;
+  esac
+done
+exit 0
