@@ -494,6 +494,14 @@ int ufr_deconv_flow_tail_backward_mfma(const void* grad_planes, long plane_strid
                                        float* G, int out_chunk, int B, int H, int W, ufr_stream_t stream);
 int ufr_flow_head_planes_backward(const float* grad_y, const float* wpk, float* G, int chunk0, int chunks, int B, int H,
                                   int W, int accumulate, ufr_stream_t stream);
+/* PWC-Net's `upfeat*` = ConvTranspose2d(C, 2, 4, 2, 1) (models/PWCNet.py:115-143, used at :284,:299,:314,:329) on the engine's planes:
+ * forward from `chunks` chunks of the COARSE [B,H,W] planes to out [B,2,2H,2W] (NCHW fp32, + bias) on the matrix cores
+ * (wmf: bf16 [chunks][3][2][16][32] with n = 2 (4 ky + kx) + o); backward from grad_y [B,2,2H,2W] into the coarse gradient
+ * sum G[chunk0 ..][B*H*W][32] (wpk: fp32 [chunks][16][2][32]; accumulate != 0 adds). */
+int ufr_upfeat_planes_forward_mfma(const void* planes, long plane_stride, int chunk0, int chunks, const void* wmf,
+                                   const float* bias, float* out, int B, int H, int W, ufr_stream_t stream);
+int ufr_upfeat_planes_backward(const float* grad_y, const float* wpk, float* G, int chunk0, int chunks, int B, int H, int W,
+                               int accumulate, ufr_stream_t stream);
 int ufr_flow_up_planes_forward(const float* x, const float* w, const float* bias, void* planes, long plane_stride,
                                int chunk, int B, int H, int W, ufr_stream_t stream);
 int ufr_flow_up_planes_backward(const float* G, int chunk, const float* w, float* grad_x, int B, int H, int W,

@@ -1,0 +1,99 @@
+"""GPU suite: the native PWC-Net head (pwc_engine.py: pyramid levels 3-6, the DenseNet decoder stages as chunk offsets of
+one plane buffer with the reversed-DenseNet adjoint, the dilated context network -- models/PWCNet.py:225-367) against the
+torch / MIOpen spelling of the same module with the same weights, both judged against a float64 evaluation."""
+from argparse import Namespace
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def net():
+    from understanding_flow_robustness_amd.flownets.utils_model import fetch_model
+    n = fetch_model(Namespace(flownet="PWCNet"), synthetic_seed=1).to(DEV)
+    for p in n.parameters():
+        p.requires_grad_(False)
+    return n.eval()
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max()) / float(b.double().abs().max())
+
+
+@pytest.mark.parametrize("C,H,W", [(565, 12, 20), (96, 5, 7), (32, 24, 40)])
+def test_upfeat_kernels_match_conv_transpose(C, H, W):
+    """`upfeat*` = ConvTranspose2d(C, 2, 4, 2, 1) on the engine's planes: forward on the matrix cores (per-pixel GEMM +
+    stride-2 gather) and the 16-tap data gradient into the coarse gradient sum, vs torch in float64."""
+    from understanding_flow_robustness_amd import _lib as L
+    from understanding_flow_robustness_amd import igemm as ig
+    from understanding_flow_robustness_amd.flownetc_engine import _pack_flow_tail_mfma
+    from understanding_flow_robustness_amd.pwc_engine import _pack_tail_bwd
+    B = 2
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, C, H, W, generator=g).to(DEV)
+    w = (torch.randn(C, 2, 4, 4, generator=g) * 0.1).to(DEV)
+    b = torch.randn(2, generator=g).to(DEV)
+    chunks = ig.pad32(C) // 32
+    planes = ig.Planes(B, H, W, chunks + 1, DEV).load_nchw(x, 1)           # at chunk 1 of a wider buffer
+    wbuf = torch.zeros(chunks * 32, 2, 4, 4, device=DEV)
+    wbuf[:C] = w
+    out = torch.full((B, 2, 2 * H, 2 * W), float("nan"), device=DEV)
+    L.check(L.lib().ufr_upfeat_planes_forward_mfma(L.ptr(planes.t), planes.plane_stride, 1, chunks,
+                                                   L.ptr(_pack_flow_tail_mfma(wbuf.permute(1, 0, 2, 3).contiguous())), L.ptr(b), L.ptr(out),
+                                                   B, H, W, L.stream()))
+    want = torch.nn.functional.conv_transpose2d(x.double(), w.double(), b.double(), 2, 1)
+    assert _rel(out, want) <= 2e-6
+    gy = torch.randn(B, 2, 2 * H, 2 * W, generator=g).to(DEV)
+    Gs = ig.GradSum(B, H, W, chunks + 1, DEV)
+    base = torch.randn_like(Gs.t)
+    for accumulate in (0, 1):
+        Gs.t.copy_(base)
+        L.check(L.lib().ufr_upfeat_planes_backward(L.ptr(gy), L.ptr(_pack_tail_bwd(wbuf)), L.ptr(Gs.t), 1, chunks, B, H, W, accumulate,
+                                                   L.stream()))
+        xg = x.double().requires_grad_(True)
+        (gx,) = torch.autograd.grad(torch.nn.functional.conv_transpose2d(xg, w.double(), None, 2, 1), xg, gy.double())
+        got = Gs.to_nchw(C, 1, slope=1.0)
+        if accumulate:
+            keep = ig.GradSum(B, H, W, chunks + 1, DEV)
+            keep.t.copy_(base)
+            gx = gx + keep.to_nchw(C, 1, slope=1.0).double()
+        assert _rel(got, gx) <= 2e-6
+        assert torch.equal(Gs.t[0], base[0])                                # the chunk in front is not touched
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 128, 192), (2, 64, 128)])
+def test_pwc_engine_head_forward_and_gradient_match_the_torch_head(net, monkeypatch, B, H, W):
+    """flow2-level output and the gradient with respect to the level-2 features: engine vs the torch / MIOpen spelling,
+    both against float64 (the engine may be no further from it than MIOpen's fp32 path, x3)."""
+    import copy
+    g = torch.Generator().manual_seed(3)
+    f2 = [torch.randn(B, 32, H // 4, W // 4, generator=g).mul_(0.5).to(DEV) for _ in range(2)]
+    gflow = torch.randn(B, 2, H, W, generator=g).to(DEV)
+    outs = {}
+    for knob in ("0", "1"):
+        monkeypatch.setenv("UFR_ENGINE", knob)
+        leaves = [f.clone().requires_grad_(True) for f in f2]
+        flow = net.head(*leaves)
+        outs[knob] = (flow.detach(), torch.autograd.grad(flow, leaves, gflow))
+    assert net.__dict__.get("_ufr_head_engines"), "the head did not run on the engine"
+    monkeypatch.setenv("UFR_ENGINE", "0")
+    engines = net.__dict__.pop("_ufr_head_engines")              # ctypes descriptors: not copyable
+    net64 = copy.deepcopy(net).double()
+    net.__dict__["_ufr_head_engines"] = engines
+    leaves = [f.double().requires_grad_(True) for f in f2]
+    flow64 = net64.head(*leaves)
+    grads64 = torch.autograd.grad(flow64, leaves, gflow.double())
+    (f0, g0), (f1, g1) = outs["0"], outs["1"]
+    print(f"flow: engine {_rel(f1, flow64):.2e}, torch fp32 {_rel(f0, flow64):.2e} of max |flow| (vs float64)")
+    assert _rel(f1, flow64) <= max(3 * _rel(f0, flow64), 1e-5)
+    for name, a, b, truth in zip(("d/d f2a", "d/d f2b"), g1, g0, grads64):
+        e_eng, e_t32 = _rel(a, truth), _rel(b, truth)
+        print(f"{name}: engine {e_eng:.2e}, torch fp32 {e_t32:.2e} of max |gradient| (vs float64)")
+        # a LeakyReLU whose pre-activation sits within rounding of zero takes the other slope in an fp32 evaluation, and
+        # the warps' validity mask / bilinear cells are piecewise: isolated entries, in either implementation
+        assert e_eng <= max(3 * e_t32, 5e-4), f"{name}: engine {e_eng:.2e} vs torch fp32 {e_t32:.2e}"
+        frac = float(((a.double() - truth).abs() > 1e-4 * float(truth.abs().max())).float().mean())
+        assert frac <= 1e-2, f"{name}: {frac:.2e} of the entries beyond 1e-4"

@@ -1,0 +1,9 @@
+#!/bin/bash
+# Build everything in-tree, then send the tree to the GPU box:  tools/gpu.sh TIMEOUT NAME STEP [STEP ...]
+# (a stale libufr_hip.so travelling with new tests cost round 3 its first call)
+set -e
+cd "$(dirname "$0")/.."
+make -s -j8 -C understanding_flow_robustness_amd/csrc
+make -s -C oracle all >/dev/null
+t=$1; shift
+exec /usr/local/graft/bin/gpurun --timeout $t -- "bash tools/gpu_call.sh $*"

@@ -135,6 +135,8 @@ SIGNATURES = {
     "ufr_flow_head_planes_forward_mfma": [_vp, _l, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ufr_deconv_flow_tail_backward_mfma": [_vp, _l, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_flow_head_planes_backward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "ufr_upfeat_planes_forward_mfma": [_vp, _l, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "ufr_upfeat_planes_backward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "ufr_flow_up_planes_forward": [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp],
     "ufr_flow_up_planes_backward": [_vp, _i, _vp, _vp, _i, _i, _i, _vp],
     "ufr_corr_forward_planes_window": [_vp, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _i, _i, _vp],

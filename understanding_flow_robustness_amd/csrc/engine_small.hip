@@ -184,7 +184,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 __device__ constexpr int PFM_A[6] = {2, 0, 1, 1, 0, 0};
 __device__ constexpr int PFM_B[6] = {0, 2, 1, 0, 1, 0};
 __device__ __attribute__((aligned(64))) unsigned pf_zero_page[16];
-constexpr int PFM_HW = 34, PFM_MAXT = 6;          // pixels across a staged tile (32 + halo, or 2 x 16 + 2); m-tiles per wave
+constexpr int PFM_MAXT = 6;                        // m-tiles per wave
 
 // MODE 0: predict_flow (3 x 3, stride 1, pad 1): tile = TH x 32 outputs, staged pixels = the tile + halo; N = 18 of 32;
 //         out = NCHW [B, 2, H, W] + bias.
@@ -192,22 +192,27 @@ constexpr int PFM_HW = 34, PFM_MAXT = 6;          // pixels across a staged tile
 //         the upsampled flow; the other channels go through ufr_igemm with an N that is a multiple of 128):
 //         g[o, y, x] = sum_{ky,kx} sum_c gz[c, 2y - 1 + ky, 2x - 1 + kx] w[o, c, ky, kx];  tile = TH x 16 coarse outputs,
 //         staged pixels = the (2 TH + 2) x 34 fine pixels under it; N = 32; out = lanes 0-1 of chunk `out_chunk` of the
-//         coarse grid's float32 gradient sum.  H, W = the OUTPUT grid in both modes.
+//         coarse grid's float32 gradient sum.  H, W = the OUTPUT grid in modes 0 and 1.
+// MODE 2: ConvTranspose2d(C, 2, 4, 2, 1) forward (PWC-Net's `upfeat*`, models/PWCNet.py:115-143): per COARSE pixel
+//         T[p, n = 2 (4 ky + kx) + o] = sum_c x[p, c] w[c, o, ky, kx] (N = 32), then fine pixel (Y, X) adds its <= 4 (pixel, tap)
+//         pairs: ky = (Y + 1) mod 2 (+ 2), y = (Y + 1 - ky) / 2.  tile = TH x 16 coarse pixels, staged = the tile + halo
+//         (TH + 2) x 18; out = NCHW [B, 2, 2H, 2W] + bias.  H, W = the COARSE (input) grid.
 template <int MODE>
 __global__ __launch_bounds__(512) void flow_head_planes_fwd_mfma(const __bf16* __restrict__ x, long plane_stride, int chunk0,
                                                                  int chunks, const __bf16* __restrict__ wmf,
                                                                  const float* __restrict__ bias, float* __restrict__ out,
                                                                  int out_chunk, int B, int H, int W, int TH, int S) {
   constexpr int TW = MODE == 0 ? 32 : 16, TS = MODE == 0 ? 20 : 36;        // T row stride (floats): 18 / 32 used
+  constexpr int PFM_HW = MODE == 2 ? 18 : 34;                              // pixels across a staged tile (tile + halo, or 2 x 16 + 2)
   extern __shared__ __attribute__((aligned(16))) float pfm_T[];            // [S][mt * 16][TS]
-  const int Hs = MODE == 0 ? H : 2 * H, Ws = MODE == 0 ? W : 2 * W;        // the staged (input) grid
+  const int Hs = MODE == 1 ? 2 * H : H, Ws = MODE == 1 ? 2 * W : W;        // the staged (input) grid
   const long M = (long)B * Hs * Ws;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, slice = wave >> 2, tw = wave & 3;
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
   const int b = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x - b * tiles_x * tiles_y;
   const int y0 = (tr / tiles_x) * TH, x0 = (tr % tiles_x) * TW;
-  const int sy0 = MODE == 0 ? y0 - 1 : 2 * y0 - 1, sx0 = MODE == 0 ? x0 - 1 : 2 * x0 - 1;   // first staged pixel
-  const int nh = (MODE == 0 ? TH + 2 : 2 * TH + 2) * PFM_HW, mt = (nh + 15) >> 4;
+  const int sy0 = MODE == 1 ? 2 * y0 - 1 : y0 - 1, sx0 = MODE == 1 ? 2 * x0 - 1 : x0 - 1;   // first staged pixel
+  const int nh = (MODE == 1 ? 2 * TH + 2 : TH + 2) * PFM_HW, mt = (nh + 15) >> 4;
   const __bf16* zero = reinterpret_cast<const __bf16*>(pf_zero_page);
   // this lane's staged pixel in each of its m-tiles
   const __bf16* abase[PFM_MAXT];
@@ -261,10 +266,37 @@ __global__ __launch_bounds__(512) void flow_head_planes_fwd_mfma(const __bf16* _
       for (int r = 0; r < 4; ++r) {
         float* row = T + ((tw + 4 * s) * 16 + (lane >> 4) * 4 + r) * TS;
         row[lane & 15] = acc[s][0][r];
-        if (MODE == 1 || (lane & 15) < 2) row[16 + (lane & 15)] = acc[s][1][r];
+        if (MODE != 0 || (lane & 15) < 2) row[16 + (lane & 15)] = acc[s][1][r];
       }
     }
   __syncthreads();
+  if constexpr (MODE == 2) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    for (int idx = tid; idx < 2 * TH * 32; idx += blockDim.x) {           // the tile's fine pixels
+      const int ly = idx >> 5, lx = idx & 31;
+      const int Y = 2 * y0 + ly, X = 2 * x0 + lx;
+      if (Y >= Ho || X >= Wo) continue;
+      float r0 = 0.f, r1 = 0.f;
+      for (int sl = 0; sl < S; ++sl) {
+        const float* Ts = pfm_T + (long)sl * mt * 16 * TS;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int ky = ((Y + 1) & 1) + 2 * t, hy = (Y + 1 - ky) / 2 - sy0;       // (Y + 1 - ky is even, >= -2: halo row 0)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int kx = ((X + 1) & 1) + 2 * u, hx = (X + 1 - kx) / 2 - sx0;
+            const float* e = Ts + (hy * PFM_HW + hx) * TS + 2 * (ky * 4 + kx);
+            r0 += e[0];
+            r1 += e[1];
+          }
+        }
+      }
+      const long HWo = (long)Ho * Wo, p = (long)Y * Wo + X;
+      out[((long)b * 2 + 0) * HWo + p] = r0 + bias[0];
+      out[((long)b * 2 + 1) * HWo + p] = r1 + bias[1];
+    }
+    return;
+  }
   if (tid < TH * TW) {
     const int ly = tid / TW, lx = tid - ly * TW;
     const int yy = y0 + ly, xx = x0 + lx;
@@ -342,6 +374,58 @@ __global__ __launch_bounds__(256) void flow_head_planes_bwd(const float* __restr
       const float w1[8] = {w1a.x, w1a.y, w1a.z, w1a.w, w1b.x, w1b.y, w1b.z, w1b.w};
 #pragma unroll
       for (int j = 0; j < 8; ++j) a[j] = fmaf(g1[k], w1[j], a[j]);
+    }
+    float4* dst = reinterpret_cast<float4*>(G + ((long)(chunk0 + ch) * M + pix) * 32 + q * 8);
+    float4 lo = make_float4(a[0], a[1], a[2], a[3]), hi = make_float4(a[4], a[5], a[6], a[7]);
+    if (accumulate) {
+      const float4 o0 = dst[0], o1 = dst[1];
+      lo.x += o0.x; lo.y += o0.y; lo.z += o0.z; lo.w += o0.w;
+      hi.x += o1.x; hi.y += o1.y; hi.z += o1.z; hi.w += o1.w;
+    }
+    dst[0] = lo;
+    dst[1] = hi;
+  }
+}
+
+// Data gradient of ConvTranspose2d(C, 2, 4, 2, 1) (PWC-Net's `upfeat*`): gy [B, 2, 2H, 2W] -> the coarse grid's gradient sum
+// G[chunk0 + ch][pix][c] (+)= sum_o sum_{ky,kx} gy[b, o, 2y - 1 + ky, 2x - 1 + kx] * w[32 ch + c][o][ky][kx]
+// wpk [chunks][16][2][32]; thread = (coarse pixel, 8-channel group), blockIdx.y = slice of the chunks.
+__global__ __launch_bounds__(256) void flow_tail_planes_bwd(const float* __restrict__ gy, const float* __restrict__ wpk,
+                                                            float* __restrict__ G, int chunk0, int chunks, int B, int H, int W,
+                                                            int accumulate, int per) {
+  extern __shared__ __attribute__((aligned(16))) float lds_w[];          // this slice's [per][16][2][32]
+  const long M = (long)B * H * W;
+  const int c_lo = blockIdx.y * per, c_hi = min(chunks, c_lo + per);
+  for (int i = threadIdx.x; i < (c_hi - c_lo) * 1024 / 4; i += blockDim.x)
+    reinterpret_cast<float4*>(lds_w)[i] = reinterpret_cast<const float4*>(wpk + (long)c_lo * 1024)[i];
+  __syncthreads();
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long pix = t >> 2;
+  const int q = (int)(t & 3);
+  if (pix >= M) return;
+  const long HW = (long)H * W, b = pix / HW, p = pix - b * HW;
+  const int yy = (int)(p / W), xx = (int)(p - (long)yy * W);
+  const int Ho = 2 * H, Wo = 2 * W;
+  const long HWo = (long)Ho * Wo;
+  float g0[16], g1[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int Y = 2 * yy - 1 + (k >> 2), X = 2 * xx - 1 + (k & 3);
+    const bool ok = Y >= 0 && Y < Ho && X >= 0 && X < Wo;
+    g0[k] = ok ? gy[(b * 2 + 0) * HWo + (long)Y * Wo + X] : 0.f;
+    g1[k] = ok ? gy[(b * 2 + 1) * HWo + (long)Y * Wo + X] : 0.f;
+  }
+  for (int ch = c_lo; ch < c_hi; ++ch) {
+    const float* wc = lds_w + (ch - c_lo) * 1024 + q * 8;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float4 w0a = *reinterpret_cast<const float4*>(wc + (k * 2 + 0) * 32), w0b = *reinterpret_cast<const float4*>(wc + (k * 2 + 0) * 32 + 4);
+      const float4 w1a = *reinterpret_cast<const float4*>(wc + (k * 2 + 1) * 32), w1b = *reinterpret_cast<const float4*>(wc + (k * 2 + 1) * 32 + 4);
+      const float w0[8] = {w0a.x, w0a.y, w0a.z, w0a.w, w0b.x, w0b.y, w0b.z, w0b.w};
+      const float w1[8] = {w1a.x, w1a.y, w1a.z, w1a.w, w1b.x, w1b.y, w1b.z, w1b.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = fmaf(g1[k], w1[j], fmaf(g0[k], w0[j], a[j]));
     }
     float4* dst = reinterpret_cast<float4*>(G + ((long)(chunk0 + ch) * M + pix) * 32 + q * 8);
     float4 lo = make_float4(a[0], a[1], a[2], a[3]), hi = make_float4(a[4], a[5], a[6], a[7]);
@@ -460,14 +544,15 @@ namespace {
 template <int MODE>
 int launch_pf_mfma(const void* planes, long plane_stride, int chunk0, int chunks, const void* wmf, const float* bias, float* out,
                    int out_chunk, int B, int H, int W, hipStream_t st, const char* what) {
-  constexpr int TW = MODE == 0 ? 32 : 16, TS = MODE == 0 ? 20 : 36;
+  constexpr int TW = MODE == 0 ? 32 : 16, TS = MODE == 0 ? 20 : 36, HWs = MODE == 2 ? 18 : 34;
   auto blocks_of = [&](int th) { return B * ufr::ceil_div(H, th) * ufr::ceil_div(W, TW); };
-  int TH;                                       // MODE 0: 10 / 6 / 4 staged rows; MODE 1: 2 TH + 2 <= 10
+  int TH;                                       // MODE 0: 10 / 6 / 4 staged rows; MODE 1: 2 TH + 2 <= 10; MODE 2: (TH + 2) x 18 pixels
   if (MODE == 0) TH = blocks_of(8) >= 512 ? 8 : (blocks_of(4) >= 256 ? 4 : 2);
-  else TH = blocks_of(4) >= 256 ? 4 : 2;
+  else if (MODE == 1) TH = blocks_of(4) >= 256 ? 4 : 2;
+  else TH = blocks_of(16) >= 512 ? 16 : (blocks_of(8) >= 256 ? 8 : 4);      // 18 x 18 = 324 staged pixels: 21 m-tiles of <= 24
   const int blocks = blocks_of(TH);
   const int S = (blocks >= 512 || chunks < 4) ? 1 : 2;
-  const int mt = ((MODE == 0 ? TH + 2 : 2 * TH + 2) * PFM_HW + 15) / 16;
+  const int mt = ((MODE == 1 ? 2 * TH + 2 : TH + 2) * HWs + 15) / 16;
   const size_t lds = (size_t)S * mt * 16 * TS * sizeof(float);
   static size_t lds_allowed = 64 * 1024;
   if (lds > lds_allowed) {
@@ -498,6 +583,33 @@ extern "C" int ufr_deconv_flow_tail_backward_mfma(const void* grad_planes, long 
                   (long)B * H * W < (1L << 27), "deconv flow tail backward: bad shape");
   return launch_pf_mfma<1>(grad_planes, plane_stride, chunk0, chunks, wmf, nullptr, G, out_chunk, B, H, W, ufr::as_stream(stream),
                            "deconv_flow_tail_bwd_mfma");
+}
+
+extern "C" int ufr_upfeat_planes_forward_mfma(const void* planes, long plane_stride, int chunk0, int chunks, const void* wmf,
+                                              const float* bias, float* out, int B, int H, int W, ufr_stream_t stream) {
+  UFR_REQUIRE(planes && wmf && bias && out, "upfeat (planes, mfma) forward: null pointer");
+  UFR_REQUIRE(B > 0 && H > 0 && W > 0 && chunks > 0 && chunks <= 48 && chunk0 >= 0 && (long)B * H * W < (1L << 27),
+              "upfeat (planes, mfma) forward: bad shape");
+  return launch_pf_mfma<2>(planes, plane_stride, chunk0, chunks, wmf, bias, out, 0, B, H, W, ufr::as_stream(stream),
+                           "upfeat_planes_fwd_mfma");
+}
+
+extern "C" int ufr_upfeat_planes_backward(const float* grad_y, const float* wpk, float* G, int chunk0, int chunks, int B, int H,
+                                          int W, int accumulate, ufr_stream_t stream) {
+  UFR_REQUIRE(grad_y && wpk && G, "upfeat (planes) backward: null pointer");
+  UFR_REQUIRE(B > 0 && H > 0 && W > 0 && chunks > 0 && chunks <= 48 && chunk0 >= 0 && (long)B * H * W < (1L << 27),
+              "upfeat (planes) backward: bad shape");
+  const long threads = (long)B * H * W * 4;
+  const int bx = ufr::ceil_div(threads, 256);
+  int slices = 1;
+  while ((long)bx * slices < 1024 && slices < chunks) slices *= 2;
+  if (slices > chunks) slices = chunks;
+  int per = ufr::ceil_div(chunks, slices);
+  if (per > 12) per = 12;                       // 12 x 4 KB of weights per slice in LDS
+  slices = ufr::ceil_div(chunks, per);
+  flow_tail_planes_bwd<<<dim3(bx, slices), 256, (size_t)per * 1024 * 4, ufr::as_stream(stream)>>>(grad_y, wpk, G, chunk0, chunks, B,
+                                                                                                 H, W, accumulate, per);
+  return ufr::launched("flow_tail_planes_bwd");
 }
 
 extern "C" int ufr_flow_head_planes_backward(const float* grad_y, const float* wpk, float* G, int chunk0, int chunks, int B,

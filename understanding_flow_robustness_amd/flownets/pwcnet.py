@@ -127,8 +127,22 @@ class PWCDCNet(nn.Module):
             x = self._cl("conv" + third, self._cl("conv" + second, self._cl("conv" + first, x)))
         return [x]
 
+    def _engine_ok(self, f2a) -> bool:
+        """The native head (pwc_engine.py) serves the attack's configuration: frozen parameters, eval mode, HIP float32
+        features, frame sides that are multiples of 64 (UFR_ENGINE=0 switches it off)."""
+        import os
+        if os.environ.get("UFR_ENGINE", "1") != "1" or self.training:
+            return False
+        frozen = not any(p.requires_grad for p in self.parameters())
+        return (f2a.is_cuda and f2a.dtype == torch.float32 and (frozen or not torch.is_grad_enabled())
+                and f2a.shape[2] % 16 == 0 and f2a.shape[3] % 16 == 0)
+
     def head(self, f2a, f2b):
         """Pyramid levels 3-6, the coarse-to-fine decoder and the context network."""
+        if self._engine_ok(f2a):
+            from ..pwc_engine import engine_head
+            flow2 = engine_head(self, f2a, f2b)
+            return 20 * F.interpolate(flow2, scale_factor=4, mode="bilinear", align_corners=False)
         B = f2a.shape[0]
         x = torch.cat((f2a, f2b), 0)
         feats = [None, x]

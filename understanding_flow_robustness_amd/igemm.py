@@ -143,12 +143,12 @@ def _deconv_phases(kernel: int, padding: int):
     return phases
 
 
-def conv_forward_weights(weight: torch.Tensor, stride: int, padding: int) -> WeightImage:
-    """Conv2d weight [N,C,k,k] -> the forward launch (rows = output grid)."""
+def conv_forward_weights(weight: torch.Tensor, stride: int, padding: int, dilation: int = 1) -> WeightImage:
+    """Conv2d weight [N,C,k,k] -> the forward launch (rows = output grid); a dilation is just other tap offsets."""
     N, Cn, k, _ = weight.shape
     w = weight.detach().float()
     mat = w.permute(0, 2, 3, 1).reshape(N, k * k, Cn)
-    taps = [(ky - padding, kx - padding) for ky in range(k) for kx in range(k)]
+    taps = [(ky * dilation - padding, kx * dilation - padding) for ky in range(k) for kx in range(k)]
     planes, offsets, N, npad, KC, cr = _pack([mat], weight.device)
     return WeightImage(planes, offsets, [(0, 0, taps)], N, npad, KC, dict(in_s=stride, out_s=1), cr)
 
@@ -198,18 +198,18 @@ def conv1_packed_backward_weights(weight: torch.Tensor) -> WeightImage:
     return WeightImage(planes, offsets, [(0, 0, taps)], n, npad, KC, dict(in_s=1, out_s=1), C=147.0 * N / (8.0 * 24.0))
 
 
-def conv_backward_weights(weight: torch.Tensor, stride: int, padding: int) -> WeightImage:
-    """Data gradient of Conv2d(weight [N,C,k,k], stride, padding): gx[C] from gy[N] (rows = the gy grid)."""
+def conv_backward_weights(weight: torch.Tensor, stride: int, padding: int, dilation: int = 1) -> WeightImage:
+    """Data gradient of Conv2d(weight [N,C,k,k], stride, padding, dilation): gx[C] from gy[N] (rows = the gy grid)."""
     N, Cn, k, _ = weight.shape
     w = weight.detach().float()
     if stride == 1:
-        # gx[y] = sum_ky gy[y + p - ky] * w[ky]: a convolution of gy with the transposed weights
+        # gx[y] = sum_ky gy[y + p - d ky] * w[ky]: a convolution of gy with the transposed weights
         mat = w.permute(1, 2, 3, 0).reshape(Cn, k * k, N)
-        taps = [(padding - ky, padding - kx) for ky in range(k) for kx in range(k)]
+        taps = [(padding - ky * dilation, padding - kx * dilation) for ky in range(k) for kx in range(k)]
         planes, offsets, n, npad, KC, cr = _pack([mat], weight.device)
         return WeightImage(planes, offsets, [(0, 0, taps)], n, npad, KC, dict(in_s=1, out_s=1), cr)
-    if stride != 2:
-        raise NotImplementedError("data gradient: stride 1 or 2")
+    if stride != 2 or dilation != 1:
+        raise NotImplementedError("data gradient: stride 1 (any dilation) or 2")
     phases = _deconv_phases(k, padding)          # gx = conv_transpose(gy, weight): 'input' channels N, output channels C
     mats = [torch.stack([w[:, :, ky, kx].t() for ky, kx, _, _ in taps], dim=1) for _, _, taps in phases]   # [C, taps, N]
     planes, offsets, n, npad, KC, cr = _pack(mats, weight.device)

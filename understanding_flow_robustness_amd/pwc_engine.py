@@ -1,0 +1,389 @@
+"""Native PWC-DC-Net head: everything of models/PWCNet.py:225-367 behind pyramid level 2 -- pyramid levels 3-6, the five
+coarse-to-fine decoder stages (cost volume, DenseNet block, flow / feature upsampling) and the dilated context network --
+forward AND data gradient as an explicit schedule of hand-written gfx950 kernels.  Config C4 of BASELINE.json.
+
+    3x3 convolutions (stride 1 / 2, dilation 1..16)   csrc/igemm.hip: implicit GEMMs on bf16 split planes (six products)
+    predict_flow*, dc_conv7, upfeat*                  csrc/engine_small.hip (per-pixel GEMM + gather on the matrix cores)
+    deconv* (2 -> 2), warp, 9x9 cost volume           csrc/small_cout.hip, pwc_warp.hip, correlation*.hip (NCHW float32)
+
+Layout.  A decoder stage's DenseNet block (PWCNet.py:78-113: x = cat((conv_i(x), x), 1) five times) is ONE plane buffer
+D_k whose chunks are [conv_4 32 | conv_3 64 | conv_2 96 | conv_1 128 | conv_0 128 | x]: conv_i reads the chunk suffix
+behind its own output, predict_flow / upfeat / dc_conv1 read all of it -- no concatenation is ever copied.  The stage
+input x = cat(corr 81, c1, up_flow 2, up_feat 2) (PWCNet.py:287) is stored as [corr 81, up_flow 2, up_feat 2, 11 zeros |
+c1]; every weight is re-indexed once for that order.
+
+Backward.  The data gradient of a DenseNet block is a DenseNet block in reverse: the gradient of segment j is the sum over
+the later convolutions i > j of W_i[:, segment j]^T * gz_i, i.e. ONE 3x3 convolution over the gradient planes of all later
+outputs, which sit in one buffer gz_k in the same order.  Each segment is written once, by a GEMM epilogue that adds the
+two-channel consumers' part (predict_flow^T, upfeat^T: a float32 sum) and applies LeakyReLU' -- no read-modify-write of
+float32 sums, no separate activation-gradient passes.  Parameters are frozen (data gradients only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import igemm as ig
+from . import spatial_correlation_sampler_backend as correlation
+from .flownetc_engine import _pack_flow_head, _pack_flow_head_mfma, _pack_flow_tail_mfma
+
+SEG = {4: 32, 3: 64, 2: 96, 1: 128, 0: 128}          # output channels of conv{k}_i (PWCNet.py:80-112)
+A_OFF = {4: 0, 3: 1, 2: 3, 1: 6, 0: 10}              # first chunk of conv_i's output inside D_k
+X0 = 14                                              # first chunk of the stage input x
+FEAT = {2: 32, 3: 64, 4: 96, 5: 128, 6: 196}         # pyramid channels (PWCNet.py:55-72)
+FLOW_SCALE = {5: 0.625, 4: 1.25, 3: 2.5, 2: 5.0}     # PWCNet.py:286, :301, :316, :332
+NCORR = 81
+DC = ((1, 128, 1), (2, 128, 2), (3, 128, 4), (4, 96, 8), (5, 64, 16), (6, 32, 1))      # dc_conv{i}: outputs, dilation
+
+
+def _x_map(lvl: int):
+    """Buffer position (relative to chunk X0) of every channel of the reference's stage input."""
+    if lvl == 6:
+        return list(range(NCORR))
+    c = FEAT[lvl]
+    return list(range(NCORR)) + [96 + j for j in range(c)] + [81, 82] + [83, 84]
+
+
+def _x_chunks(lvl: int) -> int:
+    return 3 if lvl == 6 else 3 + ig.pad32(FEAT[lvl]) // 32
+
+
+def _remap_in(weight: torch.Tensor, cmap, cbuf: int) -> torch.Tensor:
+    """Conv2d weight [N, Cref, k, k] -> [N, cbuf, k, k] with input channel c moved to cmap[c] (zeros elsewhere)."""
+    w = torch.zeros(weight.shape[0], cbuf, *weight.shape[2:], dtype=torch.float32, device=weight.device)
+    w[:, torch.tensor(cmap, device=weight.device)] = weight.detach().float()
+    return w
+
+
+def _pack_tail_bwd(weight: torch.Tensor) -> torch.Tensor:
+    """ConvTranspose2d(C, 2, 4, 2, 1).weight [C,2,4,4] (C in buffer order, a multiple of 32) -> [chunks][16][2][32] float32
+    (csrc/engine_small.hip `flow_tail_planes_bwd`)."""
+    c = weight.shape[0]
+    return weight.detach().float().reshape(c // 32, 32, 2, 16).permute(0, 3, 2, 1).contiguous()
+
+
+class PwcHeadEngine:
+    def __init__(self, net, B: int, H: int, W: int, device):
+        if H % 64 or W % 64:
+            raise ValueError("PWC-Net head engine: frame sides must be multiples of 64")
+        L.lib()
+        self.net, self.B, self.H, self.W, self.dev = net, int(B), int(H), int(W), torch.device(device)
+        self.grid = {k: (H >> k, W >> k) for k in range(2, 7)}
+        self.generation = 0
+        self._pipe_variant = 6
+        self._build()
+
+    # ------------------------------------------------------------------------------------------------ set-up
+    def _conv(self, name):
+        return getattr(self.net, name)[0]
+
+    def _variant_for(self, wi):
+        return self._pipe_variant if wi.Npad % 128 == 0 else 2
+
+    def _tile(self, wi, variant):
+        if wi.Npad % 128:
+            return 128, 768
+        return {4: (64, 1024), 5: (128, 512), 6: (256, 256)}.get(variant, (128, 768))
+
+    def _build(self):
+        net, B, dev, g = self.net, self.B, self.dev, self.grid
+        f32 = dict(dtype=torch.float32, device=dev)
+        P = lambda n, k, chunks: ig.Planes(n, g[k][0], g[k][1], chunks, dev)
+        G = lambda n, k, chunks: ig.GradSum(n, g[k][0], g[k][1], chunks, dev)
+        Z = lambda n, c, k: torch.zeros(n, c, *g[k], **f32)
+        plans, self.fwd, self.bwd = [], {}, {}
+
+        def plan(key, kind, wi, x, in_chunk0, rows_k, out_k, **kw):
+            """Queue a launch over the row grid of level rows_k whose output lives on level out_k."""
+            n = x.B
+            kw.setdefault("variant", self._variant_for(wi))
+            pk = [len(t) * wi.KC for _, _, t in wi.phases]
+            bm, target = self._tile(wi, kw["variant"])
+            S = ig.splitk_for(n * g[rows_k][0] * g[rows_k][1], wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target)
+            plans.append((key, kind, wi, x, in_chunk0, g[rows_k], g[out_k], S, kw))
+
+        bias = lambda name: self._conv(name).bias.detach().float().contiguous()
+        # ---- pyramid levels 3-6 on both frames (2B images) ---------------------------------------------------------------
+        self.F = {2: P(2 * B, 2, 1)}                                   # feature planes; level 2 is the engine's input
+        self.F_nchw = {k: Z(2 * B, FEAT[k], k) for k in range(3, 7)}
+        self.Fa, self.Faa, self.gzF, self.gzFa, self.gzFaa, self.T = {}, {}, {}, {}, {}, {}
+        self.G_F = {k: Z(2 * B, FEAT[k], k) for k in range(2, 7)}      # d loss / d features, NCHW: [c1 half | c2 half]
+        for k, (_, cout, first, second, third) in zip(range(3, 7), net._PYRAMID[2:]):
+            ch = ig.pad32(cout) // 32
+            self.Fa[k], self.Faa[k], self.F[k] = P(2 * B, k, ch), P(2 * B, k, ch), P(2 * B, k, ch)
+            self.gzF[k], self.gzFaa[k], self.gzFa[k] = P(2 * B, k, ch), P(2 * B, k, ch), P(2 * B, k, ch)
+            self.T[k - 1] = G(2 * B, k - 1, self.F[k - 1].chunks)      # conv{k}a's data gradient = part of d / d F[k-1]
+            names = ("conv" + first, "conv" + second, "conv" + third)
+            w = [self._conv(n).weight for n in names]
+            plan(("pyr", k, 0), "fwd", ig.conv_forward_weights(w[0], 2, 1), self.F[k - 1], 0, k, k, out_planes=self.Fa[k], bias=bias(names[0]))
+            plan(("pyr", k, 1), "fwd", ig.conv_forward_weights(w[1], 1, 1), self.Fa[k], 0, k, k, out_planes=self.Faa[k], bias=bias(names[1]))
+            plan(("pyr", k, 2), "fwd", ig.conv_forward_weights(w[2], 1, 1), self.Faa[k], 0, k, k, out_planes=self.F[k], bias=bias(names[2]))
+            plan(("pyr", k, 2), "bwd", ig.conv_backward_weights(w[2], 1, 1), self.gzF[k], 0, k, k, mask=self.Faa[k], out_planes=self.gzFaa[k])
+            plan(("pyr", k, 1), "bwd", ig.conv_backward_weights(w[1], 1, 1), self.gzFaa[k], 0, k, k, mask=self.Fa[k], out_planes=self.gzFa[k])
+            plan(("pyr", k, 0), "bwd", ig.conv_backward_weights(w[0], 2, 1), self.gzFa[k], 0, k, k - 1, out_f32=self.T[k - 1])
+        # ---- decoder stages ------------------------------------------------------------------------------------------------
+        self.D, self.gzD, self.G_D, self.G_x = {}, {}, {}, {}
+        self.x_nchw, self.gx_nchw, self.corr, self.g_corr = {}, {}, {}, {}
+        self.flow = {k: Z(B, 2, k) for k in range(2, 7)}
+        self.g_flow = {k: Z(B, 2, k) for k in range(2, 7)}
+        self.up_flow, self.up_flow_s, self.up_feat = {}, {}, {}
+        self.warped, self.g_warped, self.g_c1corr = {}, {}, {}
+        self.g_upflow, self.g_upfeat, self.g_flow_s = {}, {}, {}
+        self.pf_w, self.pf_wm, self.pf_b = {}, {}, {}
+        self.uf_wm, self.uf_wb, self.uf_b = {}, {}, {}
+        self.dec_w, self.dec_b = {}, {}
+        for k in (6, 5, 4, 3, 2):
+            xc = _x_chunks(k)
+            nch, xw = X0 + xc, xc * 32
+            gz0 = 4 if k == 2 else 0                                  # level 2: dc_conv1's gradient planes in front
+            self.D[k], self.gzD[k] = P(B, k, nch), P(B, k, gz0 + X0)
+            self.G_D[k], self.G_x[k] = G(B, k, nch), G(B, k, xc)
+            cx = NCORR if k == 6 else NCORR + 4
+            self.x_nchw[k], self.gx_nchw[k] = Z(B, cx, k), Z(B, xw, k)
+            self.corr[k], self.g_corr[k] = Z(B, NCORR, k), Z(B, NCORR, k)
+            self.g_c1corr[k], self.g_warped[k] = Z(B, FEAT[k], k), Z(B, FEAT[k], k)
+            if k < 6:
+                self.up_flow[k], self.up_flow_s[k], self.up_feat[k] = Z(B, 2, k), Z(B, 2, k), Z(B, 2, k)
+                self.warped[k] = Z(B, FEAT[k], k)
+                self.g_upflow[k], self.g_upfeat[k], self.g_flow_s[k] = Z(B, 2, k), Z(B, 2, k), Z(B, 2, k)
+            xmap = _x_map(k)
+            wbuf = {}                                                  # conv{k}_i in buffer channel order
+            for i in range(5):
+                pre = (X0 - (A_OFF[i - 1] if i else X0)) * 32          # channels of conv_{i-1} .. conv_0 in front of x
+                wref = self._conv(f"conv{k}_{i}").weight
+                wbuf[i] = _remap_in(wref, list(range(pre)) + [pre + m for m in xmap], pre + xw)
+                c0 = A_OFF[i - 1] if i else X0
+                plan(("dec", k, i), "fwd", ig.conv_forward_weights(wbuf[i], 1, 1), self.D[k], c0, k, k, out_planes=self.D[k],
+                     out_chunk0=A_OFF[i], bias=bias(f"conv{k}_{i}"))
+            full_map = list(range(X0 * 32)) + [X0 * 32 + m for m in xmap]
+            pf = getattr(net, f"predict_flow{k}")
+            wpf = _remap_in(pf.weight, full_map, nch * 32)
+            self.pf_w[k], self.pf_wm[k] = _pack_flow_head(wpf), _pack_flow_head_mfma(wpf)
+            self.pf_b[k] = pf.bias.detach().float().contiguous()
+            if k > 2:
+                uf = getattr(net, f"upfeat{k}")                        # ConvTranspose2d(C, 2, 4, 2, 1): weight [C, 2, 4, 4]
+                wuf = _remap_in(uf.weight.detach().permute(1, 0, 2, 3), full_map, nch * 32)        # [2, Cbuf, 4, 4]
+                self.uf_wm[k] = _pack_flow_tail_mfma(wuf)
+                self.uf_wb[k] = _pack_tail_bwd(wuf.permute(1, 0, 2, 3).contiguous())
+                self.uf_b[k] = uf.bias.detach().float().contiguous()
+                dec = getattr(net, f"deconv{k}")
+                self.dec_w[k], self.dec_b[k] = dec.weight.detach().float().contiguous(), dec.bias.detach().float().contiguous()
+            # the reversed DenseNet block: sources in gz order = [dc_conv1 (level 2) | conv_4 | conv_3 | ... ]
+            src = []                                                   # (id, weight in buffer order, first buffer chunk it reads)
+            if k == 2:
+                self.w_dc1 = _remap_in(self._conv("dc_conv1").weight, full_map, nch * 32)
+                src.append(("dc1", self.w_dc1, 0))
+            for i in (4, 3, 2, 1, 0):
+                src.append((i, wbuf[i], A_OFF[i - 1] if i else X0))
+            for j in (4, 3, 2, 1, 0, "x"):
+                dst0, width = (X0, xw) if j == "x" else (A_OFF[j], SEG[j])
+                later = [(w, c0) for sid, w, c0 in src if sid == "dc1" or j == "x" or sid > j]      # the convolutions that read segment j
+                if not later:
+                    continue                                           # conv_4 of levels 3-6: predict_flow^T and upfeat^T only
+                # stacked like the gradient planes in gzD: [gz channels of the later outputs, segment channels, 3, 3]
+                wv = torch.cat([w[:, (dst0 - c0) * 32:(dst0 - c0) * 32 + width] for w, c0 in later], 0)
+                wi = ig.conv_backward_weights(wv, 1, 1)
+                if wi.KC != gz0 + (X0 if j == "x" else A_OFF[j]):
+                    raise AssertionError("reversed DenseNet block: gradient planes and weights disagree")
+                if j == "x":
+                    plan(("dec", k, "x"), "bwd", wi, self.gzD[k], 0, k, k, add=self.G_D[k], add_chunk0=X0, out_f32=self.G_x[k])
+                else:
+                    plan(("dec", k, j), "bwd", wi, self.gzD[k], 0, k, k, add=self.G_D[k], add_chunk0=A_OFF[j], mask=self.D[k],
+                         mask_chunk0=A_OFF[j], out_planes=self.gzD[k], out_chunk0=gz0 + A_OFF[j])
+        # ---- context network (PWCNet.py:145-152, :340-346) ----------------------------------------------------------------
+        self.dc, self.gz_dc = {}, {}
+        prev, prev_c0 = self.D[2], 0
+        for i, cout, dil in DC:
+            self.dc[i] = P(B, 2, ig.pad32(cout) // 32)
+            w = self.w_dc1 if i == 1 else self._conv(f"dc_conv{i}").weight
+            plan(("dc", i), "fwd", ig.conv_forward_weights(w, 1, dil, dil), prev, prev_c0, 2, 2, out_planes=self.dc[i], bias=bias(f"dc_conv{i}"))
+            prev = self.dc[i]
+        for i, cout, dil in DC[1:]:                                   # dc_conv1's data gradient is part of the reversed block
+            self.gz_dc[i] = P(B, 2, ig.pad32(cout) // 32)
+        for i, cout, dil in reversed(DC[1:]):
+            out = self.gzD[2] if i == 2 else self.gz_dc[i - 1]
+            plan(("dc", i), "bwd", ig.conv_backward_weights(self._conv(f"dc_conv{i}").weight, 1, dil, dil), self.gz_dc[i], 0, 2, 2,
+                 mask=self.dc[i - 1], out_planes=out)
+        self.G_dc6 = G(B, 2, 1)
+        w7 = self.net.dc_conv7.weight
+        self.dc7_w, self.dc7_wm = _pack_flow_head(w7), _pack_flow_head_mfma(w7)
+        self.dc7_b = self.net.dc_conv7.bias.detach().float().contiguous()
+        self.dc7_out, self.flow2 = Z(B, 2, 2), Z(B, 2, 2)
+        self.g_f2 = Z(2 * B, FEAT[2], 2)
+        # ---- one split-K workspace for every launch ------------------------------------------------------------------------
+        need = max([len(wi.phases) * S * x.B * rows[0] * rows[1] * wi.Npad for _, _, wi, x, _, rows, _, S, _ in plans if S > 1] + [1])
+        self.ws = torch.empty(need, **f32)
+        self._plans = {}
+        for key, kind, wi, x, c0, rows, out_hw, S, kw in plans:
+            launch = ig.make_launch(wi, x, c0, rows, out_hw, splitk=S, ws=self.ws if S > 1 else None, **kw)
+            (self.fwd if kind == "fwd" else self.bwd)[key] = launch
+            self._plans[(kind, key)] = wi
+        self._corr_p = correlation._params(1, 1, 9, 9, 0, 0, 1, 1, 1, 1, 1, 1)              # PWCNet.py:42-50
+
+    def launch_table(self):
+        """Every prepared igemm launch with its algorithmic work: [(name, 'fwd' | 'bwd', launch, GFLOP)]."""
+        rows = []
+        for kind, table in (("fwd", self.fwd), ("bwd", self.bwd)):
+            for key, launch in table.items():
+                d = launch.desc
+                rows.append(("_".join(str(v) for v in key), kind, launch, self._plans[(kind, key)].flops(d.B * d.Hr * d.Wr) / 1e9))
+        return rows
+
+    # ------------------------------------------------------------------------------------------------ small launches
+    def _pf_forward(self, src, chunks, wm, b, out):
+        L.check(L.lib().ufr_flow_head_planes_forward_mfma(L.ptr(src.t), src.plane_stride, 0, chunks, L.ptr(wm), L.ptr(b), L.ptr(out),
+                                                          src.B, src.H, src.W, L.stream()), "predict_flow forward (mfma)")
+
+    def _pf_backward(self, gy, w, Gs, chunks, accumulate=False):
+        L.check(L.lib().ufr_flow_head_planes_backward(L.ptr(gy), L.ptr(w), L.ptr(Gs.t), 0, chunks, Gs.B, Gs.H, Gs.W, int(accumulate),
+                                                      L.stream()), "predict_flow backward")
+
+    def _finalize(self, Gs, g_chunk0, mask, mask_chunk0, out, out_chunk0, chunks):
+        L.check(L.lib().ufr_grad_finalize(L.ptr(Gs.t), g_chunk0, L.ptr(mask.t), mask_chunk0, L.ptr(out.t), out.plane_stride,
+                                          out_chunk0, Gs.M, chunks, ig.LEAKY, L.stream()), "gradient finalize")
+
+    def _corr_forward(self, a, b, out):
+        n, c, h, w = a.shape
+        L.check(L.lib().ufr_corr_forward_fused(L.ptr(a), L.ptr(b), L.ptr(out), L.UFR_F32, n, c, h, w, C.byref(self._corr_p),
+                                               1.0 / c, ig.LEAKY, L.stream()), "correlation forward")
+
+    def _corr_backward(self, a, b, g, ga, gb):
+        n, c, h, w = a.shape
+        L.check(L.lib().ufr_corr_backward(L.ptr(a), L.ptr(b), L.ptr(g), L.ptr(ga), L.ptr(gb), L.UFR_F32, n, c, h, w,
+                                          C.byref(self._corr_p), L.stream()), "correlation backward")
+
+    # ------------------------------------------------------------------------------------------------ the schedule
+    def forward(self, f2: torch.Tensor) -> torch.Tensor:
+        """Level-2 features of both frames [2B, 32, H/4, W/4] (first frames, then second frames; NCHW float32) -> flow2
+        [B, 2, H/4, W/4] (PWCNet.py:355 before the x4 upsampling and the factor 20)."""
+        L.require_hip(f2, "f2")
+        B, lib, st = self.B, L.lib(), L.stream
+        if tuple(f2.shape) != (2 * B, FEAT[2], *self.grid[2]) or f2.dtype != torch.float32:
+            raise RuntimeError("PWC-Net head engine: level-2 features of another shape")
+        self.generation += 1
+        self.F_nchw[2] = f2
+        self.F[2].load_nchw(f2, 0)
+        for k in range(3, 7):
+            for i in range(3):
+                self.fwd[("pyr", k, i)]()
+            self.F[k].to_nchw(FEAT[k], 0, out=self.F_nchw[k])
+        for k in (6, 5, 4, 3, 2):
+            c1, c2 = self.F_nchw[k][:B], self.F_nchw[k][B:]
+            D = self.D[k]
+            if k == 6:
+                self._corr_forward(c1, c2, self.x_nchw[6])
+            else:
+                h, w = self.grid[k + 1]
+                L.check(lib.ufr_deconv4x4s2_c2_forward(L.ptr(self.flow[k + 1]), L.ptr(self.dec_w[k + 1]), L.ptr(self.dec_b[k + 1]),
+                                                       L.ptr(self.up_flow[k]), B, h, w, st()), "deconv forward")
+                Dc = self.D[k + 1]
+                L.check(lib.ufr_upfeat_planes_forward_mfma(L.ptr(Dc.t), Dc.plane_stride, 0, Dc.chunks, L.ptr(self.uf_wm[k + 1]),
+                                                           L.ptr(self.uf_b[k + 1]), L.ptr(self.up_feat[k]), B, h, w, st()), "upfeat forward")
+                torch.mul(self.up_flow[k], FLOW_SCALE[k], out=self.up_flow_s[k])
+                L.check(lib.ufr_pwc_warp_forward(L.ptr(c2), L.ptr(self.up_flow_s[k]), L.ptr(self.warped[k]), B, FEAT[k], *self.grid[k], st()),
+                        "warp forward")
+                self._corr_forward(c1, self.warped[k], self.corr[k])
+                x = self.x_nchw[k]
+                x[:, :NCORR].copy_(self.corr[k])
+                x[:, NCORR:NCORR + 2].copy_(self.up_flow[k])
+                x[:, NCORR + 2:].copy_(self.up_feat[k])
+                D.load_nchw(c1, X0 + 3)
+            D.load_nchw(self.x_nchw[k], X0)
+            for i in range(5):
+                self.fwd[("dec", k, i)]()
+            self._pf_forward(D, D.chunks, self.pf_wm[k], self.pf_b[k], self.flow[k])
+        for i, _, _ in DC:
+            self.fwd[("dc", i)]()
+        self._pf_forward(self.dc[6], 1, self.dc7_wm, self.dc7_b, self.dc7_out)
+        torch.add(self.flow[2], self.dc7_out, out=self.flow2)
+        return self.flow2
+
+    def backward(self, g_flow2: torch.Tensor) -> torch.Tensor:
+        """d loss / d flow2 -> d loss / d (level-2 features) [2B, 32, H/4, W/4] (a static buffer)."""
+        L.require_hip(g_flow2, "g_flow2")
+        B, lib, st = self.B, L.lib(), L.stream
+        # context network: flow2 = flow[2] + dc_conv7(...)
+        self._pf_backward(g_flow2, self.dc7_w, self.G_dc6, 1)
+        self._finalize(self.G_dc6, 0, self.dc[6], 0, self.gz_dc[6], 0, 1)
+        for i in (6, 5, 4, 3, 2):
+            self.bwd[("dc", i)]()                                      # dc_conv2's writes dc_conv1's gradient planes into gzD[2]
+        g_flow = g_flow2
+        for k in (2, 3, 4, 5, 6):
+            D, Gd, gz = self.D[k], self.G_D[k], self.gzD[k]
+            self._pf_backward(g_flow, self.pf_w[k], Gd, D.chunks)
+            if k > 2:                                                  # + upfeat^T of the finer level's up_feat gradient
+                L.check(lib.ufr_upfeat_planes_backward(L.ptr(self.g_upfeat[k - 1]), L.ptr(self.uf_wb[k]), L.ptr(Gd.t), 0, D.chunks, B,
+                                                       *self.grid[k], 1, st()), "upfeat backward")
+                self._finalize(Gd, 0, D, 0, gz, 0, 1)                  # conv_4: no later convolution reads it
+            for j in ((4, 3, 2, 1, 0) if k == 2 else (3, 2, 1, 0)):
+                self.bwd[("dec", k, j)]()
+            self.bwd[("dec", k, "x")]()
+            gx = self.G_x[k].to_nchw(self.gx_nchw[k].shape[1], 0, slope=1.0, out=self.gx_nchw[k])
+            c1, c2 = self.F_nchw[k][:B], self.F_nchw[k][B:]
+            corr_act = self.x_nchw[k][:, :NCORR] if k < 6 else self.x_nchw[6]
+            # correlate = / C then LeakyReLU (PWCNet.py:42-50, :262): the sign of the activation is the pre-activation's
+            torch.mul(gx[:, :NCORR], torch.where(corr_act > 0, 1.0 / FEAT[k], ig.LEAKY / FEAT[k]), out=self.g_corr[k])
+            gF = self.G_F[k]
+            if k == 6:
+                self._corr_backward(c1, c2, self.g_corr[6], gF[:B], gF[B:])
+                break
+            self._corr_backward(c1, self.warped[k], self.g_corr[k], self.g_c1corr[k], self.g_warped[k])
+            torch.add(gx[:, 96:96 + FEAT[k]], self.g_c1corr[k], out=gF[:B])
+            L.check(lib.ufr_pwc_warp_backward(L.ptr(c2), L.ptr(self.up_flow_s[k]), L.ptr(self.g_warped[k]), L.ptr(gF[B:]),
+                                              L.ptr(self.g_flow_s[k]), B, FEAT[k], *self.grid[k], st()), "warp backward")
+            torch.add(gx[:, NCORR:NCORR + 2], self.g_flow_s[k], alpha=FLOW_SCALE[k], out=self.g_upflow[k])
+            self.g_upfeat[k].copy_(gx[:, NCORR + 2:NCORR + 4])
+            L.check(lib.ufr_deconv4x4s2_c2_backward_data(L.ptr(self.g_upflow[k]), L.ptr(self.dec_w[k + 1]), L.ptr(self.g_flow[k + 1]), B,
+                                                         *self.grid[k + 1], st()), "deconv backward")
+            g_flow = self.g_flow[k + 1]
+        # pyramid levels 6..3: d / d F[k] = the decoder's part (NCHW) + the stride-2 convolution of the level above
+        for k in (6, 5, 4, 3):
+            gF = self.G_F[k]
+            if k < 6:
+                gF.add_(self.T[k].to_nchw(FEAT[k], 0, slope=1.0))
+            gz = self.gzF[k]
+            L.check(lib.ufr_nchw_grad_to_planes(L.ptr(gF), L.ptr(self.F_nchw[k]), L.ptr(gz.t), gz.plane_stride, 0, 2 * B, FEAT[k],
+                                                *self.grid[k], ig.LEAKY, st()), "feature gradient -> planes")
+            for i in (2, 1, 0):
+                self.bwd[("pyr", k, i)]()
+        torch.add(self.G_F[2], self.T[2].to_nchw(FEAT[2], 0, slope=1.0), out=self.g_f2)
+        return self.g_f2
+
+
+class _PwcEngineHead(torch.autograd.Function):
+    """flow2 of PWC-Net's head as an autograd Function of the level-2 features (static buffers: see
+    flownetc_engine._EngineHead for the generation rule)."""
+
+    @staticmethod
+    def forward(ctx, f2, engine):
+        ctx.engine = engine
+        out = engine.forward(f2.contiguous()).clone()
+        ctx.generation = engine.generation
+        return out
+
+    @staticmethod
+    def backward(ctx, g_flow2):
+        if ctx.engine.generation != ctx.generation:
+            raise RuntimeError("PWC-Net head engine: another forward of this network (same batch and frame size) ran before this "
+                               "backward; its activations are gone.  Call backward() before the next forward, or set UFR_ENGINE=0")
+        return ctx.engine.backward(g_flow2.contiguous()).clone(), None
+
+
+def get_engine(net, B: int, H: int, W: int, device) -> PwcHeadEngine:
+    """One engine per batch / frame size, cached on the module; rebuilt when the module's weights have changed since."""
+    from .flownetc_engine import _weights_stamp
+    key = (int(B), int(H), int(W), str(torch.device(device)))
+    cache = net.__dict__.setdefault("_ufr_head_engines", {})
+    stamp = _weights_stamp(net)
+    eng = cache.get(key)
+    if eng is None or eng.weights_stamp != stamp:
+        eng = cache[key] = PwcHeadEngine(net, B, H, W, device)
+        eng.weights_stamp = stamp
+    return eng
+
+
+def engine_head(net, f2a: torch.Tensor, f2b: torch.Tensor) -> torch.Tensor:
+    B, _, h4, w4 = f2a.shape
+    return _PwcEngineHead.apply(torch.cat((f2a, f2b), 0), get_engine(net, B, h4 * 4, w4 * 4, f2a.device))
