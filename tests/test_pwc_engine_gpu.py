@@ -95,5 +95,10 @@ def test_pwc_engine_head_forward_and_gradient_match_the_torch_head(net, monkeypa
         # a LeakyReLU whose pre-activation sits within rounding of zero takes the other slope in an fp32 evaluation, and
         # the warps' validity mask / bilinear cells are piecewise: isolated entries, in either implementation
         assert e_eng <= max(3 * e_t32, 5e-4), f"{name}: engine {e_eng:.2e} vs torch fp32 {e_t32:.2e}"
-        frac = float(((a.double() - truth).abs() > 1e-4 * float(truth.abs().max())).float().mean())
-        assert frac <= 1e-2, f"{name}: {frac:.2e} of the entries beyond 1e-4"
+        beyond = lambda v: float(((v.double() - truth).abs() > 1e-4 * float(truth.abs().max())).float().mean())
+        frac, frac_t32 = beyond(a), beyond(b)
+        print(f"{name}: entries beyond 1e-4 of the float64 gradient: engine {frac:.2e}, torch fp32 {frac_t32:.2e}; "
+              f"engine vs torch fp32 {_rel(a, b):.2e}")
+        # random features put many warp samples within rounding of a cell border / the validity threshold: the float64
+        # evaluation takes the other branch there for EITHER fp32 implementation, so the engine is held to torch's own count
+        assert frac <= max(2 * frac_t32, 1e-2), f"{name}: {frac:.2e} of the entries beyond 1e-4 (torch fp32: {frac_t32:.2e})"

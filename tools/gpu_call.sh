@@ -3,7 +3,7 @@
 #   gpurun --timeout T -- 'bash tools/gpu_call.sh NAME STEP [STEP ...]'
 # Steps run in order and stop at the first failure; outputs go to gpurun_out/NAME/.
 #   suite            python -m pytest tests -m gpu -q -x -rs
-#   tests:<expr>     python -m pytest <files / -k expression> -q -x
+#   tests:<a,b,..>   python -m pytest a b .. -q -x   (commas separate the words of a step's argument)
 #   bench[:flags]    python bench.py <flags>
 #   stats[:flags]    rocprofv3 --kernel-trace --stats of bench.py <flags> + the summaries under the same directory
 #   configs:<list>   tools/bench_configs.py <list>
@@ -15,6 +15,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 for step in "$@"; do
   kind=${step%%:*}; arg=""; [ "$kind" != "$step" ] && arg=${step#*:}
+  arg=${arg//,/ }                       # commas separate the words of one step's argument
   echo "== $step"
   case $kind in
     suite)   timeout -k 10 1500 python -m pytest tests -m gpu -q -x -rs > $out/gpu_suite.log 2>&1; rc=$?; tail -n 6 $out/gpu_suite.log
