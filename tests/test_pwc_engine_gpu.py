@@ -102,3 +102,41 @@ def test_pwc_engine_head_forward_and_gradient_match_the_torch_head(net, monkeypa
         # random features put many warp samples within rounding of a cell border / the validity threshold: the float64
         # evaluation takes the other branch there for EITHER fp32 implementation, so the engine is held to torch's own count
         assert frac <= max(2 * frac_t32, 1e-2), f"{name}: {frac:.2e} of the entries beyond 1e-4 (torch fp32: {frac_t32:.2e})"
+
+
+def test_pwc_engine_step_equals_full_frame_torch_step(net, monkeypatch):
+    """Config C4's step (windowed pyramid levels 1-2 on the igemm, cached level-2 features in the engine's planes, fused
+    loss, one HIP graph) against the full-frame torch / MIOpen step (UFR_ENGINE=0, no window, eager) after ONE iteration:
+    4 pairs behind one 51x51 patch at 384x1280, placements at a corner, two edges and the interior -- 1e-4 of the update."""
+    from understanding_flow_robustness_amd.patch_attack import PatchAttackStep
+    B, H, W = 4, 384, 1280
+    g = torch.Generator().manual_seed(11)
+    tgt, ref = torch.rand(B, 3, H, W, generator=g).to(DEV), torch.rand(B, 3, H, W, generator=g).to(DEV)
+    target = torch.randn(B, 2, H, W, generator=g).to(DEV)
+    yy, xx = torch.meshgrid(torch.arange(51), torch.arange(51), indexing="ij")
+    mask_p = (((yy - 25) ** 2 + (xx - 25) ** 2) <= 23 ** 2).float().expand(1, 3, 51, 51).contiguous().to(DEV)
+    patch0 = torch.rand(1, 3, 51, 51, generator=g).to(DEV)
+    placements = ([(0, 0), (333, 1229), (0, 600), (170, 640)], [(333, 0), (160, 640), (7, 1221), (100, 300)])
+
+    def run(engine, cone, lr, graph):
+        monkeypatch.setenv("UFR_ENGINE", "1" if engine else "0")
+        args = Namespace(flownet="PWCNet", l2=False, alpha=0.0, lr=lr, max_count=1)
+        step = PatchAttackStep(net, args, B, H, W, device=DEV, patch_hw=(51, 51), use_cone=cone, use_graph=graph)
+        outs = []
+        for origins in placements:
+            step.load(tgt, ref, patch0, mask_p, patch0, target, origins=origins)
+            n, loss = step.run(1)
+            outs.append((step.patch.clone(), n, loss))
+        return step, outs
+
+    _, probe = run(False, False, 1.0, False)
+    lr = 0.5 / float((probe[0][0] - patch0).abs().max())          # first update peaks at 0.5: the +-2 clamp stays inactive
+    _, full = run(False, False, lr, False)
+    step, eng = run(True, True, lr, True)
+    assert step.cone is not None and step.eng is not None and step.eng_kind == "pwc" and step.graph is not None
+    for (pf, nf, lf), (pe, ne, le) in zip(full, eng):
+        upd = float((pf - patch0).abs().max())
+        err = float((pf - pe).abs().max())
+        print(f"update {upd:.3e}, engine step vs torch step {err / upd:.2e} of it; loss {lf:.6f} / {le:.6f}")
+        assert nf == ne == 1 and abs(lf - le) <= 1e-5
+        assert 1e-3 < upd < 1.9 and err <= 1e-4 * upd, f"{err / upd:.2e} of the update"

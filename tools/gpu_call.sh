@@ -6,6 +6,7 @@
 #   tests:<a,b,..>   python -m pytest a b .. -q -x   (commas separate the words of a step's argument)
 #   bench[:flags]    python bench.py <flags>
 #   stats[:flags]    rocprofv3 --kernel-trace --stats of bench.py <flags> + the summaries under the same directory
+#   trace:<tag>,<iters>,<script>,<args>   rocprofv3 --kernel-trace of a python tool + steady-state table (tools/summarize_trace.py)
 #   configs:<list>   tools/bench_configs.py <list>
 #   py:<script args> python <script args>
 set -o pipefail
@@ -31,6 +32,13 @@ for step in "$@"; do
              [ -n "$f" ] && python tools/summarize_stats.py $f 25 > $out/kernel_stats.md && head -n 14 $out/kernel_stats.md
              [ -n "$ft" ] && python tools/summarize_trace.py $ft 10 > $out/step_trace.md && head -n 30 $out/step_trace.md
              rm -rf $out/stats ;;
+    trace)   # trace:<tag>,<iters>,<script>,<args...>: rocprofv3 --kernel-trace of `python <script> <args>`, steady-state table
+             set -- $arg; tag=$1; iters=$2; shift 2
+             (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/trace_$tag -- python $GRAFT_REPO_ROOT/$1 "${@:2}" > $GRAFT_REPO_ROOT/$out/trace_$tag.log 2>&1); rc=$?
+             [ $rc -ne 0 ] && { tail -n 20 $out/trace_$tag.log; exit $rc; }
+             ft=$(find $out/trace_$tag -name "*kernel_trace.csv" | head -n 1)
+             [ -n "$ft" ] && python tools/summarize_trace.py $ft $iters > $out/${tag}_step_trace.md && head -n 45 $out/${tag}_step_trace.md
+             rm -rf $out/trace_$tag ;;
     configs) timeout -k 10 1100 python tools/bench_configs.py $arg > $out/configs.log 2>&1; rc=$?; tail -n 12 $out/configs.log
              [ $rc -ne 0 ] && exit $rc ;;
     py)      timeout -k 10 1100 python $arg > $out/py.log 2>&1; rc=$?; tail -n 40 $out/py.log

@@ -127,6 +127,15 @@ class PWCDCNet(nn.Module):
             x = self._cl("conv" + third, self._cl("conv" + second, self._cl("conv" + first, x)))
         return [x]
 
+    ENGINE = "pwc"                                                  # patch_attack.py: which native head serves this network
+
+    def engine_available(self, H, W, device) -> bool:
+        """Can the attack step keep this network's cached level-2 features inside the native head (pwc_engine.py)?"""
+        import os
+        frozen = not any(p.requires_grad for p in self.parameters())
+        return (os.environ.get("UFR_ENGINE", "1") == "1" and not self.training and frozen
+                and torch.device(device).type == "cuda" and H % 64 == 0 and W % 64 == 0)
+
     def _engine_ok(self, f2a) -> bool:
         """The native head (pwc_engine.py) serves the attack's configuration: frozen parameters, eval mode, HIP float32
         features, frame sides that are multiples of 64 (UFR_ENGINE=0 switches it off)."""

@@ -315,9 +315,11 @@ def make_launch(wi: WeightImage, x: Planes, in_chunk0: int, rows_hw, out_hw, *, 
     return Launch(d, keep)
 
 
-def splitk_for(M: int, Npad: int, ktiles: int, phases: int = 1, target: int = 768, phase_ktiles=None, bm: int = 128) -> int:
+def splitk_for(M: int, Npad: int, ktiles: int, phases: int = 1, target: int = 768, phase_ktiles=None, bm: int = 128,
+               min_ktiles: int = 16) -> int:
     """Split the reduction until the launch has about `target` workgroups (3 per CU: the LDS-DMA kernel's occupancy),
-    keeping >= 16 K tiles per slice.  `phase_ktiles` (K tiles of every phase) switches to a small cost model when the
+    keeping >= `min_ktiles` K tiles per slice (16; PWC-Net's 6x20 .. 24x80 grids with K of 30-150 tiles pass 4: a lone workgroup
+    per CU pays ~1.1 us per K step, so eight slices of 8 steps beat two of 32 even with the reduction pass behind them).  `phase_ktiles` (K tiles of every phase) switches to a small cost model when the
     phases are unequal (stride-2 data gradients: 1, 2, 2 and 4 taps): `splitk` then counts the slices of the LONGEST
     phase, the others get proportionally fewer (ufr_igemm), and the choice minimises rounds x (slice length + epilogue)."""
     tiles_mn = -(-M // bm) * (Npad // (128 if Npad % 128 == 0 else 64))
@@ -326,7 +328,7 @@ def splitk_for(M: int, Npad: int, ktiles: int, phases: int = 1, target: int = 76
         s = 1
         while s <= 16:
             per = -(-max(phase_ktiles) // s)
-            if s > 1 and per < 8:
+            if s > 1 and per < min(8, min_ktiles):
                 break
             wgs = tiles_mn * sum(-(-k // per) for k in phase_ktiles)
             cost = -(-wgs // target) * (per + 6) + (10 if s > 1 else 0)     # K steps; epilogue ~ 6, the reduce launch ~ 10
@@ -336,6 +338,6 @@ def splitk_for(M: int, Npad: int, ktiles: int, phases: int = 1, target: int = 76
         return best
     tiles = tiles_mn * phases
     s = 1
-    while tiles * s * 2 <= target and ktiles // (s * 2) >= 16 and s < 32:
+    while tiles * s * 2 <= target and ktiles // (s * 2) >= min_ktiles and s < 32:
         s *= 2
     return s

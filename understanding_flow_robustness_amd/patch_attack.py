@@ -220,15 +220,18 @@ class PatchAttackStep:
         self.win_hw = (wh, ww)
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.xw = torch.zeros(2 * B, 3, wh, ww, **f32).requires_grad_(True)
-        # native head (flownetc_engine.py): the cached full-frame features live in its plane buffers, the head and its
-        # adjoint are explicit launch schedules (no torch operator, no autograd between the features and flow2)
-        self.eng = None
+        # native head (flownetc_engine.py / pwc_engine.py): the cached full-frame features live in its plane buffers, the head,
+        # the windowed prefix and their adjoints are explicit launch schedules (no torch operator, no autograd between the
+        # window stack and flow2)
+        self.eng = self.eng_kind = None
         if getattr(self.net, "engine_available", None) is not None and self.net.engine_available(H, W, self.dev):
-            from .flownetc_engine import get_engine
+            self.eng_kind = getattr(self.net, "ENGINE", "flownetc")
+            if self.eng_kind == "pwc":
+                from .pwc_engine import get_engine
+            else:
+                from .flownetc_engine import get_engine
             self.eng = get_engine(self.net, B, H, W, self.dev)
-            self.eng.flow[2].requires_grad_(True)
-        # the window's conv2 / conv3 and their data gradients on the engine's igemm instead of torch / MIOpen
-        self._eng_window = self.eng is not None
+            self.eng.flow_out.requires_grad_(True)
         self.taps = []                         # (level stride, margin, frames, full leaf, window gradient)
         with torch.no_grad():
             feats = self.net.encode(torch.zeros(2, 3, spec.total_stride * 2, spec.total_stride * 2, **f32))
@@ -275,7 +278,7 @@ class PatchAttackStep:
             self.band.win[:, 1] = start.clamp(0, self.W - self.band.width)
         if self.eng is not None:
             if prefix_features is not None:
-                self.eng.load_prefix_features(prefix_features[0], prefix_features[1])
+                self.eng.load_prefix_features(*prefix_features)
             else:
                 self.eng.prefix_full(self.adv_tgt.detach(), self.adv_ref.detach())
             return
@@ -291,25 +294,20 @@ class PatchAttackStep:
         lib, B, H, W = L.lib(), self.B, self.H, self.W
         self._win_copy(lib.ufr_window_gather, self.adv_tgt, self.xw, B, 3, H, W, 1, 0)
         self._win_copy(lib.ufr_window_gather, self.adv_ref, self.xw[B:], B, 3, H, W, 1, 0)
-        if self.eng is not None and self._eng_window:      # conv1-3 of the window on the engine too (no autograd graph)
-            (_, m2, _, _, _), (_, m3, _, _, _) = self.taps
+        if self.eng is not None:               # the window's prefix on the engine too (no autograd graph)
             self._feats_w = None
-            self.eng.window_prefix_forward(self.xw, self.win, m2, m3)
-            self.eng.forward_cached(self.band)
-            if self._fused_loss:                           # the loss kernel upsamples flow2 itself (no full-size flow)
+            if self.eng_kind == "pwc":
+                self.eng.window_prefix_forward(self.xw, self.win, self.taps[0][1])
+                self.eng.forward_cached()
+            else:
+                (_, m2, _, _, _), (_, m3, _, _, _) = self.taps
+                self.eng.window_prefix_forward(self.xw, self.win, m2, m3)
+                self.eng.forward_cached(self.band)
+            if self._fused_loss:                   # the loss kernel upsamples flow2 itself (no full-size flow)
                 return None
-            return torch.nn.functional.interpolate(self.eng.flow[2] * self.net.div_flow, scale_factor=4, mode="bilinear",
+            return torch.nn.functional.interpolate(self.eng.flow_out * self.eng.flow_scale, scale_factor=4, mode="bilinear",
                                                    align_corners=False)
         self._feats_w = [f[:n] for f, (_, _, n, _, _) in zip(self.net.encode(self.xw), self.taps)]
-        if self.eng is not None:
-            (_, m2, _, _, _), (_, m3, _, _, _) = self.taps
-            wh, ww = self.win_hw
-            self.eng.scatter_window_features(self._feats_w[0], self._feats_w[1], self.win, wh, ww, m2, m3)
-            self.eng.forward_cached(self.band)             # writes eng.flow[2], the leaf of the remaining torch ops
-            if self._fused_loss:
-                return None
-            return torch.nn.functional.interpolate(self.eng.flow[2] * self.net.div_flow, scale_factor=4, mode="bilinear",
-                                                   align_corners=False)
         for f, (ls, m, n, full, _) in zip(self._feats_w, self.taps):
             self._win_copy(lib.ufr_window_scatter, f, full, n, f.shape[1], H // ls, W // ls, ls, m)
         full = [t[3] for t in self.taps]
@@ -324,24 +322,28 @@ class PatchAttackStep:
             if flow is None:                     # ufr_flow2_upsampled_loss wrote d loss / d flow2 itself
                 g_flow2 = self.g_flow2
             else:
-                (g_flow2,) = torch.autograd.grad(flow, (self.eng.flow[2],), self.g_flow)
-            (ls2, m2, _, _, gw2), (ls3, m3, _, _, gw3) = self.taps
-            if self.band is not None:            # the engine writes conv3's window gradient itself (fused correlation adjoint)
-                self.band.g3_window, self.band.g3_margin = gw3, m3
-                self.band.eng_window, self.band.g2_margin = self._eng_window, m2
-            g2a, g3a, g3b = self.eng.backward(g_flow2.contiguous(), self.band)
-            if g2a is not None:
-                self._win_copy(lib.ufr_window_gather, g2a, gw2, B, 128, H // ls2, W // ls2, ls2, m2)
-            if g3a is not None:
-                self._win_copy(lib.ufr_window_gather, g3a, gw3, B, 256, H // ls3, W // ls3, ls3, m3)
-                self._win_copy(lib.ufr_window_gather, g3b, gw3[B:], B, 256, H // ls3, W // ls3, ls3, m3)
+                (g_flow2,) = torch.autograd.grad(flow, (self.eng.flow_out,), self.g_flow)
+            if self.eng_kind == "pwc":           # one tap: level-2 features of both frames
+                ls, m, n, _, gw = self.taps[0]
+                g_f2 = self.eng.backward(g_flow2.contiguous())
+                self._win_copy(lib.ufr_window_gather, g_f2, gw, n, g_f2.shape[1], H // ls, W // ls, ls, m)
+                gxw = self.eng.window_prefix_backward(gw)
+            else:
+                (ls2, m2, _, _, gw2), (ls3, m3, _, _, gw3) = self.taps
+                if self.band is not None:        # the engine writes conv3's window gradient itself (fused correlation adjoint)
+                    self.band.g3_window, self.band.g3_margin = gw3, m3
+                    self.band.eng_window, self.band.g2_margin = True, m2
+                g2a, g3a, g3b = self.eng.backward(g_flow2.contiguous(), self.band)
+                if g2a is not None:
+                    self._win_copy(lib.ufr_window_gather, g2a, gw2, B, 128, H // ls2, W // ls2, ls2, m2)
+                if g3a is not None:
+                    self._win_copy(lib.ufr_window_gather, g3a, gw3, B, 256, H // ls3, W // ls3, ls3, m3)
+                    self._win_copy(lib.ufr_window_gather, g3b, gw3[B:], B, 256, H // ls3, W // ls3, ls3, m3)
+                gxw = self.eng.window_prefix_backward(self.taps[1][4], None if g2a is None else self.taps[0][4])
         else:
             g_full = torch.autograd.grad(flow, [t[3] for t in self.taps], self.g_flow)
             for g, (ls, m, n, _, gwin) in zip(g_full, self.taps):
                 self._win_copy(lib.ufr_window_gather, g.contiguous(), gwin, n, g.shape[1], H // ls, W // ls, ls, m)
-        if self.eng is not None and self._eng_window:
-            gxw = self.eng.window_prefix_backward(self.taps[1][4], None if g2a is None else self.taps[0][4])
-        else:
             gxw, = torch.autograd.grad(self._feats_w, (self.xw,), [t[4] for t in self.taps])
         self._feats_w = None
         gxw = gxw.contiguous()
@@ -361,7 +363,7 @@ class PatchAttackStep:
         # shared patch: loss = mean over the GLOBAL batch; private: every sample its own mean
         weight = (1.0 - self.alpha) * ((1.0 / self.world) if self.shared else float(self.B))
         if flow is None:        # engine head: loss on the x4-upsampled flow2 and its adjoint in one kernel (csrc/attack.hip)
-            L.check(L.lib().ufr_flow2_upsampled_loss(L.ptr(self.eng.flow[2]), float(self.net.div_flow), L.ptr(self.target),
+            L.check(L.lib().ufr_flow2_upsampled_loss(L.ptr(self.eng.flow_out), float(self.eng.flow_scale), L.ptr(self.target),
                                                      L.ptr(self.g_flow2), L.ptr(self.loss_local), self.B, self.H // 4, self.W // 4,
                                                      self.kind, weight, L.ptr(self.loss_ws), L.stream()), "upsampled flow loss")
         else:

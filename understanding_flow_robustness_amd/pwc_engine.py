@@ -64,6 +64,73 @@ def _pack_tail_bwd(weight: torch.Tensor) -> torch.Tensor:
     return weight.detach().float().reshape(c // 32, 32, 2, 16).permute(0, 3, 2, 1).contiguous()
 
 
+class _PyramidPrefix:
+    """Pyramid levels 1-2 (PWCNet.py:55-60, :235-240: six 3x3 convolutions, strides 2,1,1,2,1,1, 3 -> 16 -> 32 channels) of `n`
+    raw frames of h x w pixels on the igemm, forward and (optionally) data gradient.  The RGB -> BGR flip of PWCNet.py:230-231
+    is folded into conv1a's weights.  Used for the full frames once per attack() call and for the attack's window per iteration."""
+
+    def __init__(self, eng, n: int, h: int, w: int, backward: bool, f2_out: ig.Planes | None = None):
+        net, dev = eng.net, eng.dev
+        self.n, self.h, self.w = n, h, w
+        dims = {0: (h, w), 1: (h // 2, w // 2), 2: (h // 4, w // 4)}
+        P = lambda lvl, chunks=1: ig.Planes(n, dims[lvl][0], dims[lvl][1], chunks, dev)
+        self.x, self.a1, self.aa1, self.b1, self.a2, self.aa2 = P(0), P(1), P(1), P(1), P(2), P(2)
+        self.f2 = f2_out if f2_out is not None else P(2)             # the full-frame prefix writes the head's own input planes
+        names = [nm for _, _, first, second, third in net._PYRAMID[:2] for nm in ("conv" + first, "conv" + second, "conv" + third)]
+        acts = [self.x, self.a1, self.aa1, self.b1, self.a2, self.aa2, self.f2]
+        lv = [0, 1, 1, 1, 2, 2, 2]
+        plans = []
+        for i, nm in enumerate(names):
+            conv = getattr(net, nm)[0]
+            wgt = conv.weight.detach().flip(1) if i == 0 else conv.weight.detach()
+            stride = 2 if i in (0, 3) else 1
+            plans.append(("fwd", i, ig.conv_forward_weights(wgt, stride, 1), acts[i], dims[lv[i + 1]], dims[lv[i + 1]],
+                          dict(out_planes=acts[i + 1], bias=conv.bias.detach().float().contiguous())))
+        if backward:
+            self.gz = [None] + [P(lv[i]) for i in range(1, 7)]          # gradient planes of the six outputs
+            self.G_x = ig.GradSum(n, h, w, 1, dev)
+            self.f2_nchw = torch.zeros(n, FEAT[2], *dims[2], dtype=torch.float32, device=dev)
+            self.gx = torch.zeros(n, 3, h, w, dtype=torch.float32, device=dev)
+            for i in range(5, -1, -1):
+                conv = getattr(net, names[i])[0]
+                wgt = conv.weight.detach().flip(1) if i == 0 else conv.weight.detach()
+                stride = 2 if i in (0, 3) else 1
+                kw = dict(out_f32=self.G_x) if i == 0 else dict(out_planes=self.gz[i], mask=acts[i])
+                plans.append(("bwd", i, ig.conv_backward_weights(wgt, stride, 1), self.gz[i + 1], dims[lv[i + 1]], dims[lv[i]], kw))
+        sized = []
+        for kind, i, wi, x, rows, out_hw, kw in plans:
+            kw["variant"] = eng._variant_for(wi)
+            pk = [len(t) * wi.KC for _, _, t in wi.phases]
+            bm, target = eng._tile(wi, kw["variant"])
+            sized.append(ig.splitk_for(n * rows[0] * rows[1], wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target,
+                                       min_ktiles=4))
+        need = max([len(p[2].phases) * S * n * p[4][0] * p[4][1] * p[2].Npad for p, S in zip(plans, sized) if S > 1] + [1])
+        self.ws = torch.empty(need, dtype=torch.float32, device=dev)
+        self.fwd, self.bwd, self.wi = {}, {}, {}
+        for (kind, i, wi, x, rows, out_hw, kw), S in zip(plans, sized):
+            launch = ig.make_launch(wi, x, 0, rows, out_hw, splitk=S, ws=self.ws if S > 1 else None, **kw)
+            (self.fwd if kind == "fwd" else self.bwd)[i] = launch
+            self.wi[(kind, i)] = wi
+
+    @torch.no_grad()
+    def forward(self, frames: torch.Tensor) -> ig.Planes:
+        """Level-2 features (planes) of the frame stack [n, 3, h, w]."""
+        self.x.load_nchw(frames.contiguous(), 0)
+        for i in range(6):
+            self.fwd[i]()
+        return self.f2
+
+    @torch.no_grad()
+    def backward(self, g_f2: torch.Tensor) -> torch.Tensor:
+        """d loss / d frames [n, 3, h, w] from d loss / d (level-2 features) [n, 32, h/4, w/4] (NCHW)."""
+        gz = self.gz[6]
+        L.check(L.lib().ufr_nchw_grad_to_planes(L.ptr(g_f2), L.ptr(self.f2_nchw), L.ptr(gz.t), gz.plane_stride, 0, self.n, FEAT[2],
+                                                self.h // 4, self.w // 4, ig.LEAKY, L.stream()), "level-2 gradient -> planes")
+        for i in range(5, -1, -1):
+            self.bwd[i]()
+        return self.G_x.to_nchw(3, 0, slope=1.0, out=self.gx)
+
+
 class PwcHeadEngine:
     def __init__(self, net, B: int, H: int, W: int, device):
         if H % 64 or W % 64:
@@ -101,7 +168,8 @@ class PwcHeadEngine:
             kw.setdefault("variant", self._variant_for(wi))
             pk = [len(t) * wi.KC for _, _, t in wi.phases]
             bm, target = self._tile(wi, kw["variant"])
-            S = ig.splitk_for(n * g[rows_k][0] * g[rows_k][1], wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target)
+            S = ig.splitk_for(n * g[rows_k][0] * g[rows_k][1], wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target,
+                              min_ktiles=4)
             plans.append((key, kind, wi, x, in_chunk0, g[rows_k], g[out_k], S, kw))
 
         bias = lambda name: self._conv(name).bias.detach().float().contiguous()
@@ -212,6 +280,9 @@ class PwcHeadEngine:
         self.dc7_b = self.net.dc_conv7.bias.detach().float().contiguous()
         self.dc7_out, self.flow2 = Z(B, 2, 2), Z(B, 2, 2)
         self.g_f2 = Z(2 * B, FEAT[2], 2)
+        self.f2_cache = Z(2 * B, FEAT[2], 2)                            # the attack step's cached level-2 features (NCHW)
+        self._prefix, self._wprefixes, self._wprefix = None, {}, None
+        self.flow_out, self.flow_scale = self.flow2, 20.0             # what the step's fused loss kernel reads (PWCNet.py:367)
         # ---- one split-K workspace for every launch ------------------------------------------------------------------------
         need = max([len(wi.phases) * S * x.B * rows[0] * rows[1] * wi.Npad for _, _, wi, x, _, rows, _, S, _ in plans if S > 1] + [1])
         self.ws = torch.empty(need, **f32)
@@ -255,16 +326,75 @@ class PwcHeadEngine:
                                           C.byref(self._corr_p), L.stream()), "correlation backward")
 
     # ------------------------------------------------------------------------------------------------ the schedule
+    # ---- the attack step's cached prefix (patch_attack.py): full-frame levels 1-2 once per call, the window per iteration
+    @torch.no_grad()
+    def prefix_full(self, frames_a: torch.Tensor, frames_b: torch.Tensor):
+        """New frames: pyramid levels 1-2 of both full frames straight into the head's input planes (+ NCHW for the cost
+        volume / warp kernels of level 2)."""
+        if self._prefix is None:
+            self._prefix = _PyramidPrefix(self, 2 * self.B, self.H, self.W, backward=False, f2_out=self.F[2])
+        self._prefix.forward(torch.cat((frames_a, frames_b), 0))
+        self.F[2].to_nchw(FEAT[2], 0, out=self.f2_cache)
+        self.F_nchw[2] = self.f2_cache
+
+    @torch.no_grad()
+    def load_prefix_features(self, f2: torch.Tensor):
+        """The same from level-2 features the caller already holds (train()'s clean forward seeds the attack's cache)."""
+        self.f2_cache.copy_(f2[:2 * self.B])
+        self.F_nchw[2] = self.f2_cache
+        self.F[2].load_nchw(self.f2_cache, 0)
+
+    def window_prefix(self, wh: int, ww: int) -> _PyramidPrefix:
+        """One state per window size, kept for the engine's life (captured graphs hold raw pointers into it)."""
+        P = self._wprefixes.get((int(wh), int(ww)))
+        if P is None:
+            P = self._wprefixes[(int(wh), int(ww))] = _PyramidPrefix(self, 2 * self.B, int(wh), int(ww), backward=True)
+        self._wprefix = P
+        return P
+
+    @torch.no_grad()
+    def window_prefix_forward(self, xw: torch.Tensor, win: torch.Tensor, margin: int):
+        """Levels 1-2 of the window stack `xw` [2B, 3, wh, ww] (first frames, then second frames), patched into the cached
+        full-frame level-2 features; the inexact rim (`margin` cells, cone.py) is skipped by the scatter."""
+        wh, ww = int(xw.shape[2]), int(xw.shape[3])
+        P = self.window_prefix(wh, ww)
+        P.forward(xw.detach())
+        P.f2.to_nchw(FEAT[2], 0, out=P.f2_nchw)
+        lib, B, st = L.lib(), self.B, L.stream()
+        h4, w4 = self.grid[2]
+        L.check(lib.ufr_window_scatter_planes(L.ptr(P.f2_nchw), L.ptr(self.F[2].t), self.F[2].plane_stride, 0, L.ptr(win), B, 2 * B,
+                                              FEAT[2], h4, w4, wh // 4, ww // 4, 4, int(margin), st), "window -> planes (level 2)")
+        L.check(lib.ufr_window_scatter(L.ptr(P.f2_nchw), L.ptr(self.f2_cache), L.ptr(win), B, 2 * B, FEAT[2], h4, w4, wh // 4, ww // 4, 4,
+                                       int(margin), st), "window -> nchw (level 2)")
+
+    @torch.no_grad()
+    def window_prefix_backward(self, gw: torch.Tensor) -> torch.Tensor:
+        """d loss / d xw [2B, 3, wh, ww] from the window's level-2 gradient [2B, 32, wh/4, ww/4] (rim zeroed)."""
+        return self._wprefix.backward(gw)
+
+    @torch.no_grad()
+    def forward_cached(self) -> torch.Tensor:
+        """`forward` on the level-2 features the engine already holds (prefix_full / load_prefix_features + the window)."""
+        self.generation += 1
+        self.F_nchw[2] = self.f2_cache
+        return self._forward_head()
+
+    @torch.no_grad()
     def forward(self, f2: torch.Tensor) -> torch.Tensor:
         """Level-2 features of both frames [2B, 32, H/4, W/4] (first frames, then second frames; NCHW float32) -> flow2
         [B, 2, H/4, W/4] (PWCNet.py:355 before the x4 upsampling and the factor 20)."""
         L.require_hip(f2, "f2")
-        B, lib, st = self.B, L.lib(), L.stream
+        B = self.B
         if tuple(f2.shape) != (2 * B, FEAT[2], *self.grid[2]) or f2.dtype != torch.float32:
             raise RuntimeError("PWC-Net head engine: level-2 features of another shape")
         self.generation += 1
         self.F_nchw[2] = f2
         self.F[2].load_nchw(f2, 0)
+        return self._forward_head()
+
+    @torch.no_grad()
+    def _forward_head(self) -> torch.Tensor:
+        B, lib, st = self.B, L.lib(), L.stream
         for k in range(3, 7):
             for i in range(3):
                 self.fwd[("pyr", k, i)]()
@@ -300,6 +430,7 @@ class PwcHeadEngine:
         torch.add(self.flow[2], self.dc7_out, out=self.flow2)
         return self.flow2
 
+    @torch.no_grad()
     def backward(self, g_flow2: torch.Tensor) -> torch.Tensor:
         """d loss / d flow2 -> d loss / d (level-2 features) [2B, 32, H/4, W/4] (a static buffer)."""
         L.require_hip(g_flow2, "g_flow2")
