@@ -403,7 +403,9 @@ typedef struct {
   int products;                                /* 6: the float32-accurate six-product form (the only one) */
   int variant;                                 /* kernel form: 0 / 2 = single-stage LDS-DMA tiles (128 x 128; 128 x 64 when Npad % 128),
                                                   4 = 64 x 128 tiles, 5 = pipelined 128 x 128 (register-held fragments),
-                                                  6 = ping-pong: 256 x 128 tiles, two wave groups half a step apart */
+                                                  6 = ping-pong: 256 x 128 tiles, two wave groups half a step apart,
+                                                  7 = 6 with horizontal runs of taps staged once (256 x 128 or 256 x 64 tiles; launches it
+                                                      does not cover -- stride 2, fewer than 22 columns -- run as 6 / 2) */
   int k_order;                                 /* order of the K tiles in the weight image of a phase: 0 = [taps][KC] (tap-major),
                                                   1 = [KC][taps] (the taps of one channel chunk back to back: L2 reuse of the pixels) */
 } ufr_igemm_desc;

@@ -16,7 +16,7 @@ VARIANT = {"v": 0}
 
 class _Ig:
     """The igemm host module with `make_launch` pinned to one kernel form (csrc/igemm.hip: 2 = single-stage, 4 = 64 x 128
-    tiles, 5 = pipelined, 6 = ping-pong)."""
+    tiles, 5 = pipelined, 6 = ping-pong, 7 = ping-pong with horizontal runs of taps staged once)."""
 
     def __getattr__(self, name):
         from understanding_flow_robustness_amd import igemm
@@ -25,7 +25,7 @@ class _Ig:
         return getattr(igemm, name)
 
 
-@pytest.fixture(autouse=True, params=[2, 4, 5, 6], ids=["single-stage", "tile-64x128", "pipelined", "ping-pong"])
+@pytest.fixture(autouse=True, params=[2, 4, 5, 6, 7], ids=["single-stage", "tile-64x128", "pipelined", "ping-pong", "ping-pong-tap-reuse"])
 def _variant(request):
     VARIANT["v"] = request.param
     yield
@@ -52,6 +52,8 @@ def _rand(*shape, seed=0, scale=1.0):
     (3, 70, 130, 13, 21, 3, 2, 1),        # stride 2, odd sizes (M not a multiple of 128)
     (2, 256, 32, 12, 20, 1, 1, 0),        # conv_redir
     (1, 64, 128, 20, 36, 5, 2, 2),        # conv2 / conv3 shape (25 taps)
+    (2, 160, 64, 24, 40, 3, 1, 1),        # PWC-Net's decoder: 64 outputs behind a long K (256 x 64 tiles in the tap-reuse form)
+    (3, 117, 32, 13, 29, 3, 1, 1),        # ... 32 outputs, a row grid that ends inside a tile row, odd width
 ])
 def test_forward_convolution_with_bias_and_leaky(B, Cin, Cout, H, W, k, s, p):
     ig = _mods()
@@ -95,7 +97,8 @@ def test_deconv_forward_phases(B, Cin, Cout, H, W):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,k,s,p", [(2, 96, 160, 24, 40, 3, 1, 1), (2, 70, 130, 24, 40, 3, 2, 1),
-                                                   (1, 256, 32, 12, 20, 1, 1, 0)])
+                                                   (1, 256, 32, 12, 20, 1, 1, 0), (2, 64, 224, 24, 40, 3, 1, 1),
+                                                   (3, 32, 160, 13, 29, 3, 1, 1)])
 def test_data_gradient_with_addend_and_mask(B, Cin, Cout, H, W, k, s, p):
     """gx = (conv^T(gy) + addend) * LeakyReLU'(activation): planes and fp32 outputs of the gradient epilogue."""
     ig = _mods()

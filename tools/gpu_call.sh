@@ -30,17 +30,18 @@ for step in "$@"; do
              [ $rc -ne 0 ] && { tail -n 20 $out/stats.err; exit $rc; }
              f=$(find $out/stats -name "*kernel_stats.csv" | head -n 1); ft=$(find $out/stats -name "*kernel_trace.csv" | head -n 1)
              [ -n "$f" ] && python tools/summarize_stats.py $f 25 > $out/kernel_stats.md && head -n 14 $out/kernel_stats.md
-             [ -n "$ft" ] && python tools/summarize_trace.py $ft 10 > $out/step_trace.md && head -n 30 $out/step_trace.md
+             [ -n "$ft" ] && python tools/summarize_trace.py $ft 10 > $out/step_trace.md && sed -n "1,/^last iteration/p" $out/step_trace.md | head -n 30
              rm -rf $out/stats ;;
     trace)   # trace:<tag>,<iters>,<script>,<args...>: rocprofv3 --kernel-trace of `python <script> <args>`, steady-state table
              set -- $arg; tag=$1; iters=$2; shift 2
              (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/trace_$tag -- python $GRAFT_REPO_ROOT/$1 "${@:2}" > $GRAFT_REPO_ROOT/$out/trace_$tag.log 2>&1); rc=$?
              [ $rc -ne 0 ] && { tail -n 20 $out/trace_$tag.log; exit $rc; }
              ft=$(find $out/trace_$tag -name "*kernel_trace.csv" | head -n 1)
-             [ -n "$ft" ] && python tools/summarize_trace.py $ft $iters > $out/${tag}_step_trace.md && head -n 45 $out/${tag}_step_trace.md
+             [ -n "$ft" ] && python tools/summarize_trace.py $ft $iters > $out/${tag}_step_trace.md && sed -n "1,/^last iteration/p" $out/${tag}_step_trace.md | head -n 45
              rm -rf $out/trace_$tag ;;
     configs) timeout -k 10 1100 python tools/bench_configs.py $arg > $out/configs.log 2>&1; rc=$?; tail -n 12 $out/configs.log
              [ $rc -ne 0 ] && exit $rc ;;
+    env)     export $arg ;;                      # env:NAME=VALUE for the steps behind it
     py)      timeout -k 10 1100 python $arg > $out/py.log 2>&1; rc=$?; tail -n 40 $out/py.log
              [ $rc -ne 0 ] && exit $rc ;;
     *)       echo "unknown step $step"; exit 2 ;;

@@ -47,6 +47,11 @@ def main(path, iters, marker="gate_kernel"):
     print("|---|---|---|---|---|")
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f"| `{k}` | {c / iters:.1f} | {t / c / 1e3:.1f} | {t / 1e6 / iters:.3f} | {100 * t / 1e6 / busy:.1f} |")
+    # the last iteration, dispatch by dispatch (which launch of a kernel is the slow one)
+    last = rows[marks[-2] + 1:marks[-1] + 1]
+    print(f"\nlast iteration, in order ({len(last)} dispatches): kernel, us")
+    for r in last:
+        print(f"{short(r[ncol])[:60]:60s} {(int(r[ecol]) - int(r[scol])) / 1e3:8.1f}")
 
 
 if __name__ == "__main__":

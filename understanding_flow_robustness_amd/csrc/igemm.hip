@@ -165,7 +165,8 @@ struct Phase {
   long w_off;                       // bf16 elements from the weight plane's start
   int dyx[UFR_IGEMM_MAX_TAPS];      // (dy & 0xffff) | (dx << 16): one dword per tap, so a wave-uniform tap index becomes an
                                     // s_load (a byte table is read with global_load_sbyte, whose wait drains the LDS-DMA too)
-};
+  int run[UFR_IGEMM_MAX_TAPS];      // horizontal runs of taps (same dy, dx one apart, <= 3): shift | position << 2 | length << 4
+};                                  // (shift = dx - the run's smallest dx): igemm_pp3_kernel stages a run's pixels once
 
 struct Args {
   const __bf16* x; long x_plane_stride; int in_chunk0, KC;
@@ -626,6 +627,193 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   igemm_write_out<NPL, MT>(a, ph, acc, reinterpret_cast<float*>(lds_pp + imgA0), z, bm, bn, wrow, wcol, lane, wave);
 }
 
+// ---- ping-pong with horizontal tap reuse (variant 7) ----------------------------------------------------------------------
+// The taps of one run (same dy, dx one apart: the three columns of a 3x3 row, the two of a deconvolution phase) read the SAME
+// activation pixels one cell apart, so a group stages a run's pixels ONCE per channel chunk -- image row j = cell (bm + j)'s
+// pixel at the run's smallest dx -- and tap `shift` reads row j + shift.  That is exact while cell j + shift lies in the
+// same row of the row grid; the last one or two cells of a grid row need the pixels one and two PAST the row's end (zeros
+// at a frame edge, real pixels beside a column band), which are staged into fix-up rows behind the image:
+//   rows 0..127 the tile's cells | 128, 129 the two cells after the tile | 130 + 2 e + w: pixel w + 1 past the end of the
+//   e-th grid row the tile touches (e < 7: the host sends launches with Wr < 22 to igemm_pp_kernel).
+// A lane's fragment rows are fixed, so the row it reads for (m, shift) is a per-lane constant: 12 LDS offsets.
+// L2 -> LDS bytes per K step: 24 KB of weights + 2 x 27 KB of activations per RUN instead of 72 KB (3x3: 42 KB).
+constexpr int PP3_ROWS = 144;
+constexpr int PP3_IMG = 3 * PP3_ROWS * BK;                                // elements of one activation image: 27 KB
+constexpr int pp3_lds_bytes(int bn) { return (4 * PP3_IMG + 2 * 3 * bn * BK) * 2; }   // 159,744 B at 128 columns
+
+// BN_ = 128: a group's waves 2 x 2 of 64 x 64.  BN_ = 64 (PWC-Net's decoder: 64 and 32 outputs behind 500 input channels, where
+// the activation rows are 80 % of a K step's L2 -> LDS bytes and the plain forms are bound by that delivery): 4 x 1 of 32 x 64.
+template <int BN_>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm_pp3_kernel(const Args a) {
+  constexpr int NPL = 3, MT = BN_ == 128 ? 4 : 2, BPT = BN_ / 64, PP_IMG_B = 3 * BN_ * BK;
+  extern __shared__ __attribute__((aligned(16))) __bf16 lds_pp[];
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+  const int wrow = BN_ == 128 ? (wave >> 1) * 64 : wave * 32, wcol = BN_ == 128 ? (wave & 1) * 64 : 0;
+  int tx, ty, z;
+  xcd_tile(a.xcd, tx, ty, z);
+  const int bm = ty * 256 + grp * 128, bn = tx * BN_;
+  int phase = 0;
+#pragma unroll
+  for (int p = 1; p < 4; ++p)
+    if (p < a.nphase && z >= a.zoff[p]) phase = p;
+  const int ks = z - a.zoff[phase];
+  const Phase& ph = a.ph[phase];
+  const int ntaps = ph.ntaps, KT = ntaps * a.KC;
+  const int kt0 = ks * a.per_k, kt1 = min(KT, kt0 + a.per_k);
+  const int nk = max(kt1 - kt0, 0);
+  const long Min = (long)a.g.B * a.Hi * a.Wi;
+  const long cstride = Min * 32;
+  const int Wr = a.g.Wr, hw = a.g.Hr * Wr;
+
+  // ---- staging geometry: image rows srow0, srow0 + 64 (cells of the tile) and, on wave 0, extra row 128 + (lane >> 2)
+  const int srow0 = tid >> 2, sch = tid & 3;
+  const int csw = sch ^ ((srow0 >> 1) & 3);
+  const int xrow = lane >> 2, cswx = sch ^ ((xrow >> 1) & 3);             // (128 + xrow) >> 1 & 3 == xrow >> 1 & 3
+  int yb[3], xb[3], xlo[3], xhi[3];
+  long ibase[3];
+  auto cell_geometry = [&](int i, long cell, int xr_override) {            // cell = flat index into [B, Hr, Wr]
+    const bool live = cell >= 0 && cell < a.g.M;
+    const int c = live ? (int)cell : 0;
+    const int b = c / hw, r = c - b * hw, yr = r / Wr;
+    const int xr = xr_override >= 0 ? xr_override : r - yr * Wr;
+    const int xg = xr + (a.g.row_x0 ? a.g.row_x0[b * a.g.row_x0_stride] / a.g.row_x0_div : 0);
+    yb[i] = live ? yr * a.in_sy : -(1 << 20);
+    xb[i] = xg * a.in_sx;
+    ibase[i] = (long)b * a.Hi * a.Wi;
+    xlo[i] = a.in_x0 ? a.in_x0[b * a.in_x0_stride] / a.in_x0_div : 0;
+    xhi[i] = a.in_x0 ? min(a.Wi, xlo[i] + a.in_xw) : a.Wi;
+    xlo[i] = max(xlo[i], 0);
+  };
+  cell_geometry(0, (long)bm + srow0, -1);
+  cell_geometry(1, (long)bm + srow0 + 64, -1);
+  const int grow0 = bm / Wr;                                              // first grid row (flat over B * Hr) the tile touches
+  if (xrow < 2) {
+    cell_geometry(2, (long)bm + 128 + xrow, -1);
+  } else {                                                                // pixel (xrow & 1) + 1 past the end of grid row grow0 + e
+    const int e = (xrow - 2) >> 1, w = (xrow - 2) & 1;
+    const long rowcell = (long)(grow0 + e) * Wr;                          // that grid row's first cell
+    cell_geometry(2, rowcell < a.g.M ? rowcell : -1, Wr + w);
+  }
+  const __bf16* gx = a.x + (long)a.in_chunk0 * cstride + csw * 8;
+  const __bf16* gxx = a.x + (long)a.in_chunk0 * cstride + cswx * 8;
+  const __bf16* zero = reinterpret_cast<const __bf16*>(ufr_zero_page);
+  const __bf16* wp = a.w + ph.w_off + ((long)kt0 * a.Npad + bn + srow0) * BK + csw * 8;
+  const long wstep = (long)a.Npad * BK;
+
+  const int imgA0 = grp * 2 * PP3_IMG, imgB0 = 4 * PP3_IMG;
+  // one run's pixels of channel chunk kc -> activation image at element `img`
+  auto stage_A = [&](int img, int kc, int tap) {
+    const int dyx = ph.dyx[tap], dyo = (int)(short)(dyx & 0xffff), dxo = (dyx >> 16) - (ph.run[tap] & 3);
+    const long coff = (long)kc * cstride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int yi = yb[i] + dyo, xi = xb[i] + dxo;
+      const bool ok = (unsigned)yi < (unsigned)a.Hi && xi >= xlo[i] && xi < xhi[i];
+      const long off = ok ? (ibase[i] + (long)yi * a.Wi + xi) * 32 + coff : 0;
+#pragma unroll
+      for (int p = 0; p < NPL; ++p)
+        glds16(ok ? gx + off + p * a.x_plane_stride : zero, lds_pp + img + p * (PP3_ROWS * BK) + (64 * i + wave * 16) * BK);
+    }
+    if (wave == 0) {                                                      // the 16 extra rows: lane -> (row 128 + lane / 4, piece)
+      const int yi = yb[2] + dyo, xi = xb[2] + dxo;
+      const bool ok = (unsigned)yi < (unsigned)a.Hi && xi >= xlo[2] && xi < xhi[2];
+      const long off = ok ? (ibase[2] + (long)yi * a.Wi + xi) * 32 + coff : 0;
+#pragma unroll
+      for (int p = 0; p < NPL; ++p)
+        glds16(ok ? gxx + off + p * a.x_plane_stride : zero, lds_pp + img + p * (PP3_ROWS * BK) + 128 * BK);
+    }
+  };
+  auto stage_B = [&](int img) {
+#pragma unroll
+    for (int i = 0; i < BPT; ++i)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p)
+        glds16(wp + p * a.w_plane_stride + (long)(64 * i) * BK, lds_pp + img + p * (BN_ * BK) + (64 * i + wave * 16) * BK);
+    wp += wstep;
+  };
+
+  // ---- fragment rows: lane reads image row of cell (wrow + 16 m + frow) shifted by 0, 1, 2 cells
+  const int frow = lane & 15;
+  int foffs[MT][3];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int i = wrow + m * 16 + frow;
+    const int cell = bm + i, gr = cell / Wr, xr = cell - gr * Wr, e = min(gr - grow0, 6);
+#pragma unroll
+    for (int sft = 0; sft < 3; ++sft) {
+      const int t = xr + sft;
+      const int r = t < Wr ? i + sft : 130 + 2 * e + min(t - Wr, 1);
+      foffs[m][sft] = r * BK + (((lane >> 4) ^ ((r >> 1) & 3)) << 3);
+    }
+  }
+  const int fboff = frow * BK + (((lane >> 4) ^ ((frow >> 1) & 3)) << 3);
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- K steps kt = chunk * ntaps + tap (chunk-major: the host requires k_order = 1)
+  int kc = kt0 / ntaps, tap = kt0 - kc * ntaps;
+  int ebuf = 0;                                                           // activation image of the current run
+  if (nk > 0) {
+    stage_A(imgA0, kc, tap);
+    if (grp == 0) stage_B(imgB0);
+  }
+  if (grp == 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  bool first_of_run = true;                                               // this step is the first of its run inside the slice
+  for (int i = 0; i < nk; ++i) {
+    const int cur = i & 1;
+    const int ri = ph.run[tap], sft = ri & 3, pos = (ri >> 2) & 3, len = ri >> 4;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // ---- READ half-step
+    __builtin_amdgcn_s_setprio(2);
+    const __bf16* sA = lds_pp + imgA0 + ebuf * PP3_IMG;
+    const __bf16* sB = lds_pp + imgB0 + cur * PP_IMG_B;
+    bf16x8 fa[NPL][MT], fb[4][NPL];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int fo = sft == 0 ? foffs[m][0] : (sft == 1 ? foffs[m][1] : foffs[m][2]);
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) fa[p][m] = *reinterpret_cast<const bf16x8*>(sA + p * (PP3_ROWS * BK) + fo);
+    }
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) fb[n][p] = *reinterpret_cast<const bf16x8*>(sB + p * (BN_ * BK) + (wcol + n * 16) * BK + fboff);
+    // the next run's image: issued in the first step of this run (its other image was last read in the previous run)
+    int ntap = tap - pos + len, nkc = kc;
+    if (ntap >= ntaps) { ntap = 0; ++nkc; }
+    const int steps_left_in_run = len - 1 - pos;                           // steps of this run after this one
+    if (first_of_run && i + 1 + steps_left_in_run < nk) stage_A(imgA0 + (ebuf ^ 1) * PP3_IMG, nkc, ntap);
+    if (grp == 0 && i + 1 < nk) stage_B(imgB0 + (cur ^ 1) * PP_IMG_B);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- MFMA half-step
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[t]][m], fb[n][PROD_B[t]], acc[m][n], 0, 0, 0);
+    // advance (kc, tap); a new run flips the image
+    first_of_run = pos == len - 1;
+    if (first_of_run) ebuf ^= 1;
+    if (++tap == ntaps) { tap = 0; ++kc; }
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+  static_assert(4 * 32 * 68 * 4 <= 2 * PP3_IMG * 2, "epilogue staging does not fit a group's activation images");
+  igemm_write_out<NPL, MT>(a, ph, acc, reinterpret_cast<float*>(lds_pp + imgA0), z, bm, bn, wrow, wcol, lane, wave);
+}
+
 // Second stage of split-K: thread = (phase, row, 8 channels); the slabs are added in ascending order.
 __global__ __launch_bounds__(256) void igemm_reduce_kernel(const Args a) {
   const int n8 = a.Npad / 8;
@@ -919,6 +1107,20 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
     a.ph[z].ntaps = p.ntaps; a.ph[z].oy0 = p.oy0; a.ph[z].ox0 = p.ox0; a.ph[z].w_off = p.w_off;
     for (int t = 0; t < UFR_IGEMM_MAX_TAPS; ++t)
       a.ph[z].dyx[t] = t < p.ntaps ? (((int)p.dy[t] & 0xffff) | ((int)p.dx[t] << 16)) : 0;
+    for (int t = 0; t < UFR_IGEMM_MAX_TAPS; ++t) a.ph[z].run[t] = 1 << 4;         // default: every tap its own run
+    for (int t = 0; t < p.ntaps;) {                // maximal runs of <= 3 taps with equal dy and dx stepping by +1 or -1
+      int len = 1, dir = 0;
+      while (len < 3 && t + len < p.ntaps && p.dy[t + len] == p.dy[t]) {
+        const int step = p.dx[t + len] - p.dx[t + len - 1];
+        if ((step != 1 && step != -1) || (dir && step != dir)) break;
+        dir = step;
+        ++len;
+      }
+      int dmin = p.dx[t];
+      for (int i = 1; i < len; ++i) dmin = p.dx[t + i] < dmin ? p.dx[t + i] : dmin;
+      for (int i = 0; i < len; ++i) a.ph[z].run[t + i] = (p.dx[t + i] - dmin) | (i << 2) | (len << 4);
+      t += len;
+    }
   }
   // split-K: `splitk` slices for the phase with the most taps, proportionally fewer for the others (the phases of a stride-2
   // data gradient reduce over 1, 2, 2 and 4 taps: equal slices per phase would leave the workgroups 4x apart in length)
@@ -935,9 +1137,10 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   const dim3 grid(d->Npad / bn, (unsigned)((M + BM - 1) / BM), nz);
   // kernel forms: 0 / 2 = single-stage LDS-DMA tiles (128 x 128, or 128 x 64 where Npad is not a multiple of 128),
   // 4 = 64 x 128 tiles (four workgroups per CU), 5 = pipelined 128 x 128, 6 = ping-pong 256 x 128 (128-column launches only;
-  // the 64-column ones run the single-stage 128 x 64 tile, which measured faster there)
+  // the 64-column ones run the single-stage 128 x 64 tile, which measured faster there), 7 = ping-pong with horizontal runs of
+  // taps staged once (256 x 128 or 256 x 64: stride-1 launches with >= 22 columns, the narrow-N / long-K layers of PWC-Net)
   const int variant = d->variant ? d->variant : 2;
-  UFR_REQUIRE(variant == 2 || variant == 4 || variant == 5 || variant == 6, "igemm: unknown kernel variant %d", variant);
+  UFR_REQUIRE(variant == 2 || variant == 4 || variant == 5 || variant == 6 || variant == 7, "igemm: unknown kernel variant %d", variant);
   UFR_REQUIRE(d->products == 6, "igemm: six products only (float32-accurate); the 3- and 1-product forms were removed");
   // activation rows through a raw buffer resource (hardware zeros outside the frame) while the planes stay below 2 GB
   const bool use_buf = 6L * d->x_plane_stride < 0x7fffffffL;
@@ -953,14 +1156,25 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_glds_kernel<128, 128, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_pp3_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              pp3_lds_bytes(128));
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_pp3_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              pp3_lds_bytes(64));
     if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "igemm: %s", hipGetErrorString(e));
     raised[dev] = true;
   }
-  if (variant == 4 && bn == BN) {                  // 64 x 128 tiles: four workgroups per CU
+  if (variant == 7 && d->k_order && d->in_sx == 1 && d->Wr >= 22) {
+    // ping-pong + horizontal runs of taps staged once (launches it does not cover fall through to the plain forms)
+    const dim3 gpp(d->Npad / bn, (unsigned)((M + 255) / 256), nz);
+    if (bn == BN) igemm_pp3_kernel<128><<<gpp, 512, pp3_lds_bytes(128), st>>>(a);
+    else igemm_pp3_kernel<64><<<gpp, 512, pp3_lds_bytes(64), st>>>(a);
+  } else if (variant == 4 && bn == BN) {                  // 64 x 128 tiles: four workgroups per CU
     const dim3 g64(d->Npad / BN, (unsigned)((M + 63) / 64), nz);
     if (use_buf) igemm_glds_kernel<64, 128, false, true><<<g64, 256, 0, st>>>(a);
     else igemm_glds_kernel<64, 128><<<g64, 256, 0, st>>>(a);
-  } else if (variant == 6 && bn == BN) {           // ping-pong: 256-row tiles, two wave groups half a step apart
+  } else if ((variant == 6 || variant == 7) && bn == BN) {           // ping-pong: 256-row tiles, two wave groups half a step apart
     const dim3 gpp(d->Npad / BN, (unsigned)((M + 255) / 256), nz);
     if (use_buf) igemm_pp_kernel<128, true><<<gpp, 512, pp_lds_bytes(128), st>>>(a);
     else igemm_pp_kernel<128><<<gpp, 512, pp_lds_bytes(128), st>>>(a);

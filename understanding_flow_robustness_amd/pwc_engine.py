@@ -21,6 +21,7 @@ float32 sums, no separate activation-gradient passes.  Parameters are frozen (da
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -140,6 +141,7 @@ class PwcHeadEngine:
         self.grid = {k: (H >> k, W >> k) for k in range(2, 7)}
         self.generation = 0
         self._pipe_variant = 6
+        self._narrow_variant = int(os.environ.get("UFR_PWC_NARROW", "7"))         # A/B during development: 2 = single-stage 128 x 64
         self._build()
 
     # ------------------------------------------------------------------------------------------------ set-up
@@ -147,12 +149,15 @@ class PwcHeadEngine:
         return getattr(self.net, name)[0]
 
     def _variant_for(self, wi):
-        return self._pipe_variant if wi.Npad % 128 == 0 else 2
+        """128-column launches: the ping-pong kernel.  64-column launches (64 / 32 outputs behind up to 565 input channels):
+        its tap-reuse form with 256 x 64 tiles -- the activation rows are 80 % of their L2 -> LDS bytes and a horizontal run
+        of taps is staged once (csrc/igemm.hip variant 7; launches it does not cover run the single-stage 128 x 64 tile)."""
+        return self._pipe_variant if wi.Npad % 128 == 0 else self._narrow_variant
 
     def _tile(self, wi, variant):
         if wi.Npad % 128:
-            return 128, 768
-        return {4: (64, 1024), 5: (128, 512), 6: (256, 256)}.get(variant, (128, 768))
+            return (256, 256) if variant == 7 else (128, 768)
+        return {4: (64, 1024), 5: (128, 512), 6: (256, 256), 7: (256, 256)}.get(variant, (128, 768))
 
     def _build(self):
         net, B, dev, g = self.net, self.B, self.dev, self.grid
