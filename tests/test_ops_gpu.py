@@ -228,6 +228,44 @@ def test_altcorr_autograd_function(ops):
     assert f1.grad is not None and f2.grad is not None and float(f1.grad.abs().sum()) > 0
 
 
+@pytest.mark.parametrize("B,H,W,C,r,spread", [(1, 48, 160, 256, 4, 3.0), (2, 24, 40, 128, 3, 0.4), (1, 16, 40, 256, 4, 40.0),
+                                                (1, 8, 21, 128, 4, 3.0)])
+def test_altcorr_pyramid_on_the_matrix_cores_vs_oracle(oracle, B, H, W, C, r, spread):
+    """AlternateCorrBlock.__call__ (corr.py:121-137) as ONE launch per direction on the fp32 matrix cores: all four levels
+    of the forward, d / d fmap1 and d / d fmap2_l, against the CPU oracle level by level -- smooth and wild coordinate
+    fields (the bounding box is data, not an assumption), a width that is not a multiple of the 16-pixel tile, and two
+    lookups accumulating into one set of gradient buffers as RAFT's iterations do."""
+    import math
+    from understanding_flow_robustness_amd.flownets.raft_corr import AltCorrPyramidFunction, _SharedGrad
+    g = torch.Generator().manual_seed(B * 1000 + H + int(spread))
+    L = 4 if H % 8 == 0 else 2
+    f1 = torch.randn(B, H, W, C, generator=g)
+    f2s = [torch.randn(B, max(H >> i, 1), max(W >> i, 1), C, generator=g) for i in range(L)]
+    xs = torch.arange(W).float().view(1, 1, 1, W).expand(B, 1, H, W)
+    ys = torch.arange(H).float().view(1, 1, H, 1).expand(B, 1, H, W)
+    lookups = [(torch.cat([xs, ys], 1) + spread * torch.randn(B, 2, H, W, generator=g)).contiguous() for _ in range(2)]
+    scale = 1.0 / math.sqrt(C)
+    rd = 2 * r + 1
+    f1d = f1.to(DEV).requires_grad_(True)
+    f2d = [f.to(DEV).requires_grad_(True) for f in f2s]
+    shared = _SharedGrad()
+    outs = [AltCorrPyramidFunction.apply(f1d, c.to(DEV), r, scale, shared, *f2d) for c in lookups]
+    gos = [torch.randn(o.shape, generator=g) for o in outs]
+    want1, want2 = torch.zeros_like(f1), [torch.zeros_like(f) for f in f2s]
+    for c, o, go in zip(lookups, outs, gos):
+        for i in range(L):
+            ci = (c.permute(0, 2, 3, 1) / 2 ** i).reshape(B, 1, H, W, 2).contiguous()
+            (ref,) = oracle.altcorr_forward(f1, f2s[i], ci, r)
+            assert_close(o[:, i * rd * rd:(i + 1) * rd * rd], ref.squeeze(1) * scale, rtol=1e-4, atol_scale=2e-6, what=f"level {i} forward")
+            r1, r2, _ = oracle.altcorr_backward(f1, f2s[i], ci, (go[:, i * rd * rd:(i + 1) * rd * rd] * scale).unsqueeze(1).contiguous(), r)
+            want1 += r1
+            want2[i] += r2
+    torch.autograd.backward(outs, [go.to(DEV) for go in gos])
+    assert_close(f1d.grad, want1, rtol=1e-4, atol_scale=5e-6, what="d / d fmap1 (two lookups, all levels)")
+    for i in range(L):
+        assert_close(f2d[i].grad, want2[i], rtol=1e-4, atol_scale=1e-5, what=f"d / d fmap2 level {i}")
+
+
 # ---------------------------------------------------------------------------- CorrBlock lookup
 def test_lookup_matches_corrblock_golden_and_oracle(ops, oracle):
     from understanding_flow_robustness_amd.flownets.raft_corr import corr_lookup

@@ -36,6 +36,12 @@ class Pyramid(C.Structure):
                 ("Wl", C.c_int * UFR_MAX_LEVELS)]
 
 
+class AltCorrLevels(C.Structure):
+    """ufr_altcorr_levels (include/ufr_hip.h)."""
+    _fields_ = [("num_levels", C.c_int), ("fmap2", C.c_void_p * 4), ("fmap2_grad", C.c_void_p * 4),
+                ("H2", C.c_int * 4), ("W2", C.c_int * 4), ("coord_scale", C.c_float * 4)]
+
+
 UFR_IGEMM_MAX_TAPS = 25
 
 
@@ -135,6 +141,8 @@ SIGNATURES = {
     "ufr_flow_head_planes_forward_mfma": [_vp, _l, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ufr_deconv_flow_tail_backward_mfma": [_vp, _l, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_flow_head_planes_backward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "ufr_altcorr_pyramid_forward": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
+    "ufr_altcorr_pyramid_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "ufr_upfeat_planes_forward_mfma": [_vp, _l, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ufr_upfeat_planes_backward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "ufr_flow_up_planes_forward": [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp],
@@ -154,7 +162,8 @@ SIGNATURES = {
 }
 PLAIN = {"ufr_abi_version": (C.c_int, []), "ufr_last_error": (C.c_char_p, []),
          "ufr_device_count": (C.c_int, []),
-         "ufr_conv3x3_c2_workspace_floats": (C.c_long, [_i, _i, _i, _i])}
+         "ufr_conv3x3_c2_workspace_floats": (C.c_long, [_i, _i, _i, _i]),
+         "ufr_altcorr_pyramid_workspace_ints": (C.c_long, [_i, _i, _i, _i])}
 
 
 def lib():

@@ -12,6 +12,11 @@
 
 #include "ufr_common.h"
 
+// raft_altcorr_mfma.hip
+bool ufr_altcorr_mfma_serves(int C, int radius);
+int ufr_altcorr_mfma_forward(const float* f1, const ufr_altcorr_levels* lv, const float* coords, int planar, float* out, int B,
+                             int H1, int W1, int C, int radius, float scale, hipStream_t st);
+
 namespace {
 
 constexpr int ALT_MAX_GRID = 12;  // rd+1 <= 12  (radius <= 5)
@@ -390,6 +395,11 @@ extern "C" int ufr_altcorr_forward(const float* fmap1, const float* fmap2, const
   UFR_REQUIRE(B > 0 && N > 0 && H1 > 0 && W1 > 0 && H2 > 0 && W2 > 0 && C > 0, "alt_corr forward: bad shape");
   UFR_REQUIRE(radius >= 0 && 2 * radius + 2 <= ALT_MAX_GRID, "alt_corr forward: radius %d unsupported (max %d)",
               radius, (ALT_MAX_GRID - 2) / 2);
+  if (N == 1 && ufr_altcorr_mfma_serves(C, radius)) {     // gather-GEMM on the fp32 matrix cores (raft_altcorr_mfma.hip)
+    ufr_altcorr_levels lv{};
+    lv.num_levels = 1; lv.fmap2[0] = fmap2; lv.H2[0] = H2; lv.W2[0] = W2; lv.coord_scale[0] = 1.0f;
+    return ufr_altcorr_mfma_forward(fmap1, &lv, coords, 0, corr, B, H1, W1, C, radius, 1.0f, ufr::as_stream(stream));
+  }
   const int gd = 2 * radius + 2;
   const int nt = ufr::round_up(gd * gd, 64);
   const size_t lds = (size_t)(ufr::kWave * ((C + 63) / 64) + gd * gd) * sizeof(float);

@@ -123,10 +123,84 @@ class CorrBlock:
         return corr.view(batch, ht, wd, 1, ht, wd) / math.sqrt(dim)
 
 
-class AlternateCorrBlock:
-    """models/raft/corr.py:109-137, differentiable here (the reference calls the raw forward)."""
+def _levels_struct(f2s, grads=None) -> L.AltCorrLevels:
+    lv = L.AltCorrLevels()
+    lv.num_levels = len(f2s)
+    for i, f in enumerate(f2s):
+        lv.fmap2[i] = f.data_ptr()
+        lv.fmap2_grad[i] = grads[i].data_ptr() if grads is not None else None
+        lv.H2[i], lv.W2[i] = int(f.shape[1]), int(f.shape[2])
+        lv.coord_scale[i] = 1.0 / 2 ** i                            # corr.py:126
+    return lv
 
-    def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
+
+class AltCorrPyramidFunction(torch.autograd.Function):
+    """All levels of one AlternateCorrBlock lookup (corr.py:121-137) as ONE launch of the matrix-core kernel
+    (csrc/raft_altcorr_mfma.hip): out [B, L*(2r+1)^2, H, W] = stack_l alt_corr(fmap1, fmap2_l, coords / 2^l) / sqrt(dim).
+    `shared` (a `_SharedGrad`): every lookup of one block (RAFT's 12 iterations) adds its adjoint into ONE set of
+    buffers inside the kernels; the last adjoint to run hands them to autograd."""
+
+    @staticmethod
+    def forward(ctx, fmap1, coords, radius, scale, shared, *f2s):
+        L.require_hip(fmap1, "fmap1")
+        L.require_hip(coords, "coords", contiguous=False)
+        coords = coords.contiguous()
+        B, H1, W1, Cc = fmap1.shape
+        if tuple(coords.shape) != (B, 2, H1, W1) or coords.dtype != torch.float32 or fmap1.dtype != torch.float32:
+            raise RuntimeError("alt_corr pyramid: fmap1 [B,H,W,C] and coords [B,2,H,W], float32")
+        for f in f2s:
+            L.require_hip(f, "fmap2 level")
+            if f.dim() != 4 or f.shape[0] != B or f.shape[3] != Cc or f.dtype != torch.float32:
+                raise RuntimeError("alt_corr pyramid: every fmap2 level must be [B,H2,W2,C] float32")
+        rd = 2 * int(radius) + 1
+        with torch.cuda.device(fmap1.device):
+            out = torch.empty((B, len(f2s) * rd * rd, H1, W1), dtype=torch.float32, device=fmap1.device)
+            lv = _levels_struct(f2s)
+            L.check(L.lib().ufr_altcorr_pyramid_forward(L.ptr(fmap1), C.byref(lv), L.ptr(coords), L.ptr(out), B, H1, W1, Cc,
+                                                        int(radius), float(scale), L.stream()), "alt_corr pyramid forward")
+        ctx.save_for_backward(fmap1, coords, *f2s)
+        ctx.meta = (int(radius), float(scale))
+        ctx.shared = shared
+        if shared is not None:
+            shared.pending += 1
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        fmap1, coords, *f2s = ctx.saved_tensors
+        radius, scale = ctx.meta
+        grad_out = grad_out.contiguous()
+        B, H1, W1, Cc = fmap1.shape
+        shared = ctx.shared
+        with torch.cuda.device(fmap1.device):
+            if shared is None or shared.acc is None:
+                grads = [torch.empty_like(fmap1)] + [torch.empty_like(f) for f in f2s]
+                ws = torch.empty(L.lib().ufr_altcorr_pyramid_workspace_ints(B, H1, W1, len(f2s)), dtype=torch.int32,
+                                 device=fmap1.device)
+                accumulate = 0
+                if shared is not None:
+                    shared.acc = (grads, ws)
+            else:
+                grads, ws = shared.acc
+                accumulate = 1
+            lv = _levels_struct(f2s, grads[1:])
+            L.check(L.lib().ufr_altcorr_pyramid_backward(L.ptr(fmap1), C.byref(lv), L.ptr(coords), L.ptr(grad_out), L.ptr(grads[0]),
+                                                         L.ptr(ws), B, H1, W1, Cc, radius, scale, accumulate, L.stream()),
+                    "alt_corr pyramid backward")
+        if shared is not None:
+            shared.pending -= 1
+            if shared.pending > 0:          # more adjoints to come: hand autograd nothing yet
+                return (None,) * (5 + len(f2s))
+            shared.acc = None               # the last adjoint delivers the accumulated gradients
+        return (grads[0], None, None, None, None, *grads[1:])     # coords are detached every RAFT iteration (raft.py:190)
+
+
+class AlternateCorrBlock:
+    """models/raft/corr.py:109-137, differentiable here (the reference calls the raw forward).  Feature maps with 128 or
+    256 channels and radius 3 / 4 (both RAFT variants) take the one-launch matrix-core form; anything else the per-level
+    drop-in calls."""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4, share_grad=True):
         self.num_levels, self.radius = num_levels, radius
         self.pyramid = [(fmap1, fmap2)]
         for _ in range(num_levels):
@@ -136,11 +210,19 @@ class AlternateCorrBlock:
         # NHWC copies made once, not once per lookup as in the reference (:128-129)
         self._f1 = self.pyramid[0][0].permute(0, 2, 3, 1).contiguous()
         self._f2 = [self.pyramid[i][1].permute(0, 2, 3, 1).contiguous() for i in range(num_levels)]
+        self._shared = _SharedGrad() if share_grad else None
+        dim = self.pyramid[0][0].shape[1]
+        self._fused = (self._f1.is_cuda and self._f1.dtype == torch.float32 and dim in (128, 256) and radius in (3, 4)
+                       and 1 <= num_levels <= 4)
 
     def __call__(self, coords):
+        dim = self.pyramid[0][0].shape[1]
+        if self._fused:
+            needs_grad = torch.is_grad_enabled() and (self._f1.requires_grad or any(f.requires_grad for f in self._f2))
+            return AltCorrPyramidFunction.apply(self._f1, coords, self.radius, 1.0 / math.sqrt(dim),
+                                                self._shared if needs_grad else None, *self._f2)
         coords = coords.permute(0, 2, 3, 1)
         B, H, W, _ = coords.shape
-        dim = self.pyramid[0][0].shape[1]
         corr_list = []
         for i in range(self.num_levels):
             coords_i = (coords / 2 ** i).reshape(B, 1, H, W, 2).contiguous()
