@@ -84,7 +84,8 @@ int ufr_altcorr_backward(const float* fmap1, const float* fmap2, const float* co
  * out / grad_out: [B, L*(2r+1)^2, H1, W1] = scale * the stacked per-level volumes.  C in {128, 256}, radius in {3, 4}, N = 1.
  * backward: fmap1_grad [B,H1,W1,C] and every fmap2_grad[l] [B,H2,W2,C]; accumulate != 0 adds onto the buffers (RAFT's 12
  * lookups share them).  fmap2_grad of a level whose segments are split over workgroups is added with float atomics (the
- * coarse levels); everything else has one writer per element.  workspace: ufr_altcorr_pyramid_workspace_ints() ints. */
+ * coarse levels); everything else has one writer per element.  workspace: ufr_altcorr_pyramid_workspace_bytes() bytes of
+ * device memory (per-pixel window origins and blend adjoints, the tiles' boxes, per-level partial sums). */
 typedef struct {
   int num_levels;
   const float* fmap2[4];
@@ -95,9 +96,9 @@ typedef struct {
 int ufr_altcorr_pyramid_forward(const float* fmap1, const ufr_altcorr_levels* levels, const float* coords, float* out, int B,
                                 int H1, int W1, int C, int radius, float scale, ufr_stream_t stream);
 int ufr_altcorr_pyramid_backward(const float* fmap1, const ufr_altcorr_levels* levels, const float* coords, const float* grad_out,
-                                 float* fmap1_grad, int* workspace, int B, int H1, int W1, int C, int radius, float scale,
+                                 float* fmap1_grad, void* workspace, int B, int H1, int W1, int C, int radius, float scale,
                                  int accumulate, ufr_stream_t stream);
-long ufr_altcorr_pyramid_workspace_ints(int B, int H1, int W1, int num_levels);
+long ufr_altcorr_pyramid_workspace_bytes(int B, int H1, int W1, int C, int radius, int num_levels);
 
 /* ---- RAFT all-pairs pyramid lookup -----------------------------------------------------------
  * replaces CorrBlock.__call__ (models/raft/corr.py:72-96): per level a (2r+1)^2 bilinear window

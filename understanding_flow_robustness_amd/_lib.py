@@ -163,7 +163,7 @@ SIGNATURES = {
 PLAIN = {"ufr_abi_version": (C.c_int, []), "ufr_last_error": (C.c_char_p, []),
          "ufr_device_count": (C.c_int, []),
          "ufr_conv3x3_c2_workspace_floats": (C.c_long, [_i, _i, _i, _i]),
-         "ufr_altcorr_pyramid_workspace_ints": (C.c_long, [_i, _i, _i, _i])}
+         "ufr_altcorr_pyramid_workspace_bytes": (C.c_long, [_i, _i, _i, _i, _i, _i])}
 
 
 def lib():

@@ -16,6 +16,7 @@
 // (the reference's kernels do one 4 x 8 pixel block per workgroup with a serial channel loop; round 2's form here was one
 // workgroup per pixel on the vector ALU: 0.026 of the fp32 peak, 43x the algorithmic bytes through L2).
 #include <climits>
+#include <cstdint>
 
 #include "ufr_common.h"
 
@@ -95,14 +96,15 @@ __global__ __launch_bounds__(256) void altcorr_mfma_fwd(const float* __restrict_
     const int y0 = max(bb[0], 0), y1 = min(bb[1] + gd, H2), x0 = max(bb[2], 0), x1 = min(bb[3] + gd, W2);
     const int ncb = (x1 - x0 + 15) >> 4, nblk = (y1 - y0) * ncb;
     const int pi = lane & 15, g = lane >> 4;
-    // A operand: this lane's pixel, channels [g * CPG, (g + 1) * CPG) -- the MFMA's k index is the lane group, step j takes
-    // channel g * CPG + j of BOTH operands, so every lane reads CPG contiguous floats
+    // A operand: this lane's pixel.  The MFMA's k index is the lane group g, and step 4 i + e takes channel 16 i + 4 g + e of
+    // BOTH operands: one 16-byte load per lane covers four steps and the four lane groups of a pixel read 64 contiguous
+    // bytes (a [g * CPG, (g + 1) * CPG) split made every load instruction touch 64 different cache lines)
     float a[CPG];
     {
-      const float* ap = f1 + (((size_t)b * H1 + h1) * W1 + min(w0 + pi, W1 - 1)) * C + g * CPG;
+      const float* ap = f1 + (((size_t)b * H1 + h1) * W1 + min(w0 + pi, W1 - 1)) * C + 4 * g;
 #pragma unroll
       for (int j = 0; j < CPG; j += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(ap + j);
+        const float4 v = *reinterpret_cast<const float4*>(ap + 4 * j);
         a[j] = v.x; a[j + 1] = v.y; a[j + 2] = v.z; a[j + 3] = v.w;
       }
     }
@@ -111,11 +113,14 @@ __global__ __launch_bounds__(256) void altcorr_mfma_fwd(const float* __restrict_
     for (int r4 = 0; r4 < 4; ++r4) { cyr[r4] = cys[4 * g + r4]; cxr[r4] = cxs[4 * g + r4]; }
     for (int blk = wave; blk < nblk; blk += 4) {
       const int hy = y0 + blk / ncb, xb = x0 + (blk % ncb) * 16, q = xb + pi;
-      const float* bp = f2 + (((size_t)b * H2 + hy) * W2 + min(q, W2 - 1)) * C + g * CPG;
+      const float* bp = f2 + (((size_t)b * H2 + hy) * W2 + min(q, W2 - 1)) * C + 4 * g;
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      float4 bv[CPG / 4];
+#pragma unroll
+      for (int j = 0; j < CPG / 4; ++j) bv[j] = *reinterpret_cast<const float4*>(bp + 16 * j);
 #pragma unroll
       for (int j = 0; j < CPG; j += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(bp + j);
+        const float4 v = bv[j / 4];
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], v.x, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j + 1], v.y, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j + 2], v.z, acc0, 0, 0, 0);
@@ -145,132 +150,148 @@ __global__ __launch_bounds__(256) void altcorr_mfma_fwd(const float* __restrict_
   }
 }
 
-// gs[i][iy * gd + ix] of the tile's pixels: the adjoint of the bilinear blend (correlation_kernel.cu:196-214)
+// ------------------------------------------------------------------------------------------------ backward, pre-pass
+// One workgroup (64 threads) per (pixel tile, level): every pixel's window origin, gs = the adjoint of the bilinear blend
+// (correlation_kernel.cu:196-214) times `scale`, and the tile's box.  Both adjoints read these instead of recomputing them
+// per (tile, segment) pair.   gs_all [L][npix][npt] | win [L][npix][2] | boxes [L][ntiles][4]: {y0, y1, x0, x1}, empty = 0s
 template <int R>
-__device__ __forceinline__ void tile_gs(float (*gs)[(2 * R + 2) * (2 * R + 2)], const float* __restrict__ gout, size_t base,
-                                        size_t plane, int w0, int W1, const float* dxs, const float* dys, float scale, int tid,
-                                        int nthreads) {
+__global__ __launch_bounds__(64) void altcorr_prepass(const AcLevels lv, const float* __restrict__ coords, int planar,
+                                                      const float* __restrict__ gout, float* __restrict__ gs_all,
+                                                      int* __restrict__ win, int* __restrict__ boxes, int B, int H1, int W1,
+                                                      float scale) {
   constexpr int rd = 2 * R + 1, gd = rd + 1, npt = gd * gd;
-  for (int t = tid; t < AC_TP * npt; t += nthreads) {
-    const int i = t & 15, pt = t >> 4, iy = pt / gd, ix = pt - iy * gd;
-    float g = 0.f;
-    if (w0 + i < W1) {
-      const float* gp = gout + base + w0 + i;
-      const float dx = dxs[i], dy = dys[i];
-      if (iy > 0 && ix > 0)   g += gp[plane * ((iy - 1) + rd * (ix - 1))] * dy * dx;
-      if (iy > 0 && ix < rd)  g += gp[plane * ((iy - 1) + rd * ix)] * dy * (1 - dx);
-      if (iy < rd && ix > 0)  g += gp[plane * (iy + rd * (ix - 1))] * (1 - dy) * dx;
-      if (iy < rd && ix < rd) g += gp[plane * (iy + rd * ix)] * (1 - dy) * (1 - dx);
+  __shared__ float dxs[AC_TP], dys[AC_TP];
+  const int tiles_x = (W1 + AC_TP - 1) / AC_TP, ntiles = B * H1 * tiles_x;
+  const int l = blockIdx.y, tile = blockIdx.x;
+  const int b = tile / (H1 * tiles_x), rem = tile - b * H1 * tiles_x, h1 = rem / tiles_x, w0 = (rem % tiles_x) * AC_TP;
+  const int H2 = lv.H2[l], W2 = lv.W2[l], tid = threadIdx.x;
+  const size_t plane = (size_t)H1 * W1, npix = (size_t)B * plane;
+  {
+    const int i = tid & 15;
+    const PixelWindow pw = pixel_window(coords, planar, b, h1, w0 + i, H1, W1, lv.cscale[l], R);
+    const bool m = meets(pw, gd, H2, W2);
+    int ymin = m ? pw.cy : INT_MAX, ymax = m ? pw.cy : INT_MIN, xmin = m ? pw.cx : INT_MAX, xmax = m ? pw.cx : INT_MIN;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+      ymin = min(ymin, __shfl_xor(ymin, off, 16)); ymax = max(ymax, __shfl_xor(ymax, off, 16));
+      xmin = min(xmin, __shfl_xor(xmin, off, 16)); xmax = max(xmax, __shfl_xor(xmax, off, 16));
     }
-    gs[i][pt] = g * scale;
+    if (tid < AC_TP) {
+      dxs[i] = pw.dx; dys[i] = pw.dy;
+      if (w0 + i < W1) {
+        int* wp = win + ((size_t)l * npix + (size_t)b * plane + (size_t)h1 * W1 + w0 + i) * 2;
+        wp[0] = pw.cx; wp[1] = pw.cy;
+      }
+    }
+    if (tid == 0) {
+      int* o = boxes + ((size_t)l * ntiles + tile) * 4;
+      if (ymin == INT_MAX) { o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; }
+      else { o[0] = max(ymin, 0); o[1] = min(ymax + gd, H2); o[2] = max(xmin, 0); o[3] = min(xmax + gd, W2); }
+    }
+  }
+  __syncthreads();
+  const size_t gbase = (((size_t)b * lv.n + l) * rd * rd) * plane + (size_t)h1 * W1;
+  for (int t = tid; t < AC_TP * npt; t += 64) {
+    const int i = t & 15, pt = t >> 4, iy = pt / gd, ix = pt - iy * gd;
+    if (w0 + i >= W1) continue;
+    const float* gp = gout + gbase + w0 + i;
+    const float dx = dxs[i], dy = dys[i];
+    float g = 0.f;
+    if (iy > 0 && ix > 0)   g += gp[plane * ((iy - 1) + rd * (ix - 1))] * dy * dx;
+    if (iy > 0 && ix < rd)  g += gp[plane * ((iy - 1) + rd * ix)] * dy * (1 - dx);
+    if (iy < rd && ix > 0)  g += gp[plane * (iy + rd * (ix - 1))] * (1 - dy) * dx;
+    if (iy < rd && ix < rd) g += gp[plane * (iy + rd * ix)] * (1 - dy) * (1 - dx);
+    gs_all[((size_t)l * npix + (size_t)b * plane + (size_t)h1 * W1 + w0 + i) * npt + pt] = g * scale;
   }
 }
 
 // ------------------------------------------------------------------------------------------------ d / d fmap1
-// g1[p, c] (+)= sum over levels and fmap2 pixels q of gs_l[p, q] fmap2_l[q, c].  Wave w owns channels [w C/4, (w+1) C/4):
-// no reduction between waves, one writer per element (accumulate = read-add-store).
+// part[l][p, c] = sum over fmap2_l pixels q of gs_l[p, q] fmap2_l[q, c]: one workgroup per (pixel tile, level), wave w owns
+// channels [w C/4, (w+1) C/4) -- no reduction between waves; the levels are added in a fixed order by altcorr_sum_levels.
+// Lane (pi, g) of wave w: A[m = pixel pi][k = fmap2 pixel 4 kk + g]; B[k][n]: channel w CPG + pi NT + nt, so that a lane's NT
+// channels are one 16-byte load and its NT results one 16-byte store.
 template <int R, int CPG>
-__global__ __launch_bounds__(256) void altcorr_mfma_bwd1(const AcLevels lv, const float* __restrict__ coords, int planar,
-                                                         const float* __restrict__ gout, float* __restrict__ g1, int B, int H1,
-                                                         int W1, float scale, int accumulate) {
-  constexpr int rd = 2 * R + 1, gd = rd + 1, npt = gd * gd, C = 4 * CPG, NT = CPG / 16;
-  __shared__ float gs[AC_TP][npt];
-  __shared__ int cxs[AC_TP], cys[AC_TP];
-  __shared__ float dxs[AC_TP], dys[AC_TP];
-  __shared__ int bb[4];
-  const int tiles_x = (W1 + AC_TP - 1) / AC_TP;
-  const int tile = blockIdx.x, b = tile / (H1 * tiles_x), rem = tile - b * H1 * tiles_x, h1 = rem / tiles_x, w0 = (rem % tiles_x) * AC_TP;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int pi = lane & 15, g = lane >> 4;
-  const size_t plane = (size_t)H1 * W1;
+__global__ __launch_bounds__(256) void altcorr_mfma_bwd1(const AcLevels lv, const float* __restrict__ gs_all,
+                                                         const int* __restrict__ win, const int* __restrict__ boxes,
+                                                         float* __restrict__ part, int B, int H1, int W1) {
+  constexpr int gd = 2 * R + 2, npt = gd * gd, C = 4 * CPG, NT = CPG / 16;
+  static_assert(NT == 4 || NT == 2, "channel quarters of 64 or 32");
+  const int tiles_x = (W1 + AC_TP - 1) / AC_TP, ntiles = B * H1 * tiles_x;
+  const int l = blockIdx.y, tile = blockIdx.x;
+  const int b = tile / (H1 * tiles_x), rem = tile - b * H1 * tiles_x, h1 = rem / tiles_x, w0 = (rem % tiles_x) * AC_TP;
+  const int H2 = lv.H2[l], W2 = lv.W2[l];
+  const float* __restrict__ f2 = lv.f2[l];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pi = lane & 15, g = lane >> 4;
+  const size_t plane = (size_t)H1 * W1, npix = (size_t)B * plane;
+  const int4 bx = *reinterpret_cast<const int4*>(boxes + ((size_t)l * ntiles + tile) * 4);
+  const int y0 = bx.x, y1 = bx.y, x0 = bx.z, x1 = bx.w;
   f32x4 acc[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int l = 0; l < lv.n; ++l) {
-    const int H2 = lv.H2[l], W2 = lv.W2[l];
-    const float* __restrict__ f2 = lv.f2[l];
-    __syncthreads();                                     // the previous level's gs / windows are no longer read
-    if (tid == 0) { bb[0] = INT_MAX; bb[1] = INT_MIN; bb[2] = INT_MAX; bb[3] = INT_MIN; }
-    __syncthreads();
-    if (tid < AC_TP) {
-      const PixelWindow pw = pixel_window(coords, planar, b, h1, w0 + tid, H1, W1, lv.cscale[l], R);
-      cxs[tid] = pw.cx; cys[tid] = pw.cy; dxs[tid] = pw.dx; dys[tid] = pw.dy;
-      if (meets(pw, gd, H2, W2)) {
-        atomicMin(&bb[0], pw.cy); atomicMax(&bb[1], pw.cy);
-        atomicMin(&bb[2], pw.cx); atomicMax(&bb[3], pw.cx);
-      }
-    }
-    __syncthreads();
-    tile_gs<R>(gs, gout, (((size_t)b * lv.n + l) * rd * rd) * plane + (size_t)h1 * W1, plane, w0, W1, dxs, dys, scale, tid, 256);
-    __syncthreads();
-    if (bb[0] == INT_MAX) continue;
-    const int y0 = max(bb[0], 0), y1 = min(bb[1] + gd, H2), x0 = max(bb[2], 0), x1 = min(bb[3] + gd, W2);
+  const int w1 = min(w0 + pi, W1 - 1);
+  const size_t pix = (size_t)l * npix + (size_t)b * plane + (size_t)h1 * W1 + w1;
+  const bool live = w0 + pi < W1;
+  const int cxi = win[pix * 2], cyi = win[pix * 2 + 1];
+  const float* __restrict__ gsp = gs_all + pix * npt;
+  if (y1 > y0 && x1 > x0) {
     const int ncb = (x1 - x0 + 15) >> 4, nblk = (y1 - y0) * ncb;
-    const int cyi = cys[pi], cxi = cxs[pi];
     for (int blk = 0; blk < nblk; ++blk) {
       const int hy = y0 + blk / ncb, xb = x0 + (blk % ncb) * 16;
       const int iy = hy - cyi;
+      float av[4];
+      float bvv[4][NT];
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        // A[m = pixel pi][k = fmap2 pixel q]: the pixel's gradient for that window point (0 outside window / image)
         const int q = xb + 4 * kk + g, ix = q - cxi;
-        const float av = ((unsigned)iy < (unsigned)gd && (unsigned)ix < (unsigned)gd && q < W2) ? gs[pi][iy * gd + ix] : 0.f;
-        // B[k = q][n = channel]: lanes 0-15 read 16 consecutive channels
-        const float* bp = f2 + (((size_t)b * H2 + hy) * W2 + min(q, W2 - 1)) * C + wave * CPG + pi;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[nt * 16], acc[nt], 0, 0, 0);
+        av[kk] = (live && (unsigned)iy < (unsigned)gd && (unsigned)ix < (unsigned)gd && q < W2) ? gsp[iy * gd + ix] : 0.f;
+        const float* bp = f2 + (((size_t)b * H2 + hy) * W2 + min(q, W2 - 1)) * C + wave * CPG + pi * NT;
+        if (NT == 4) {
+          const float4 v = *reinterpret_cast<const float4*>(bp);
+          bvv[kk][0] = v.x; bvv[kk][1] = v.y; bvv[kk][2 % NT] = v.z; bvv[kk][3 % NT] = v.w;
+        } else {
+          const float2 v = *reinterpret_cast<const float2*>(bp);
+          bvv[kk][0] = v.x; bvv[kk][1] = v.y;
+        }
       }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bvv[kk][nt], acc[nt], 0, 0, 0);
     }
   }
-  // D[row = pixel 4 g + r][col = channel wave * CPG + nt * 16 + pi]
+  // D[row = pixel 4 g + r][col pi] of n-tile nt = channel wave * CPG + pi * NT + nt
 #pragma unroll
   for (int r4 = 0; r4 < 4; ++r4) {
-    const int w1 = w0 + 4 * g + r4;
-    if (w1 >= W1) continue;
-    float* op = g1 + (((size_t)b * H1 + h1) * W1 + w1) * C + wave * CPG + pi;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) op[nt * 16] = (accumulate ? op[nt * 16] : 0.f) + acc[nt][r4];
+    const int wq = w0 + 4 * g + r4;
+    if (wq >= W1) continue;
+    float* op = part + (((size_t)l * B + b) * plane + (size_t)h1 * W1 + wq) * C + wave * CPG + pi * NT;
+    if (NT == 4) *reinterpret_cast<float4*>(op) = make_float4(acc[0][r4], acc[1][r4], acc[2 % NT][r4], acc[3 % NT][r4]);
+    else *reinterpret_cast<float2*>(op) = make_float2(acc[0][r4], acc[1][r4]);
+  }
+}
+
+// g1 (+)= part[0] + part[1] + ... in ascending level order
+__global__ void altcorr_sum_levels(const float* __restrict__ part, float* __restrict__ g1, long n4, int levels, int accumulate) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 s = accumulate ? reinterpret_cast<const float4*>(g1)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int l = 0; l < levels; ++l) {
+      const float4 v = reinterpret_cast<const float4*>(part)[(long)l * n4 + i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    reinterpret_cast<float4*>(g1)[i] = s;
   }
 }
 
 // ------------------------------------------------------------------------------------------------ d / d fmap2
-// boxes[(l * ntiles + tile) * 4 ..] = {y0, y1, x0, x1} of every pixel tile's windows on level l (y1 <= y0: empty)
-template <int R>
-__global__ __launch_bounds__(64) void altcorr_boxes(const AcLevels lv, const float* __restrict__ coords, int planar,
-                                                    int* __restrict__ boxes, int B, int H1, int W1) {
-  constexpr int gd = 2 * R + 2;
-  const int tiles_x = (W1 + AC_TP - 1) / AC_TP, ntiles = B * H1 * tiles_x;
-  const int item = blockIdx.x * 4 + (threadIdx.x >> 4);           // 16 lanes per (tile, level)
-  const int i = threadIdx.x & 15;
-  if (item >= ntiles * lv.n) return;
-  const int l = item / ntiles, tile = item - l * ntiles;
-  const int b = tile / (H1 * tiles_x), rem = tile - b * H1 * tiles_x, h1 = rem / tiles_x, w0 = (rem % tiles_x) * AC_TP;
-  const int H2 = lv.H2[l], W2 = lv.W2[l];
-  const PixelWindow pw = pixel_window(coords, planar, b, h1, w0 + i, H1, W1, lv.cscale[l], R);
-  const bool m = meets(pw, gd, H2, W2);
-  int ymin = m ? pw.cy : INT_MAX, ymax = m ? pw.cy : INT_MIN, xmin = m ? pw.cx : INT_MAX, xmax = m ? pw.cx : INT_MIN;
-#pragma unroll
-  for (int off = 8; off > 0; off >>= 1) {
-    ymin = min(ymin, __shfl_xor(ymin, off, 16)); ymax = max(ymax, __shfl_xor(ymax, off, 16));
-    xmin = min(xmin, __shfl_xor(xmin, off, 16)); xmax = max(xmax, __shfl_xor(xmax, off, 16));
-  }
-  if (i == 0) {
-    int* o = boxes + (size_t)item * 4;
-    if (ymin == INT_MAX) { o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; }
-    else { o[0] = max(ymin, 0); o[1] = min(ymax + gd, H2); o[2] = max(xmin, 0); o[3] = min(xmax + gd, W2); }
-  }
-}
-
 // A workgroup owns fmap2 pixels (hy, xq0 .. xq0 + 15) of one level and (a slice of) the pixel tiles; wave = channel quarter.
-// For every pixel tile whose box contains the segment: acc[q, c] += sum_p gs[p, q] fmap1[p, c], gs taken straight from the
-// output gradient (four reads per entry).  split == 1: one writer per element (read-add-store: deterministic); split > 1 (the
-// coarse levels, where 12-36 segments would otherwise serialise all of the tiles): float atomics for the final add.
+// For every pixel tile whose box contains the segment: acc[q, c] += sum_p gs[p, q] fmap1[p, c].  split == 1: one writer per
+// element (read-add-store: deterministic); split > 1 (the coarse levels, where 12-36 segments would otherwise serialise all
+// of the tiles): float atomics for the final add.
 template <int R, int CPG>
 __global__ __launch_bounds__(256) void altcorr_mfma_bwd2(const float* __restrict__ f1, const AcLevels lv,
-                                                         const float* __restrict__ coords, int planar,
-                                                         const float* __restrict__ gout, const int* __restrict__ boxes, int B,
-                                                         int H1, int W1, float scale, int accumulate) {
-  constexpr int rd = 2 * R + 1, gd = rd + 1, C = 4 * CPG, NT = CPG / 16;
+                                                         const float* __restrict__ gs_all, const int* __restrict__ win,
+                                                         const int* __restrict__ boxes, int B, int H1, int W1, int accumulate) {
+  constexpr int gd = 2 * R + 2, npt = gd * gd, C = 4 * CPG, NT = CPG / 16;
   int l = 0;
 #pragma unroll
   for (int k = 1; k < 4; ++k)
@@ -281,9 +302,10 @@ __global__ __launch_bounds__(256) void altcorr_mfma_bwd2(const float* __restrict
   const int b = seg / (H2 * segs_x), rem = seg - b * H2 * segs_x, hy = rem / segs_x, xq0 = (rem % segs_x) * 16;
   const int tiles_x = (W1 + AC_TP - 1) / AC_TP, tiles_b = H1 * tiles_x, ntiles = B * tiles_b;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pi = lane & 15, g = lane >> 4;
-  const size_t plane = (size_t)H1 * W1;
+  const size_t plane = (size_t)H1 * W1, npix = (size_t)B * plane;
   const int* __restrict__ bx = boxes + ((size_t)l * ntiles + (size_t)b * tiles_b) * 4;
-  const float cscale = lv.cscale[l];
+  const size_t lbase = (size_t)l * npix + (size_t)b * plane;
+  const bool qlive = xq0 + pi < W2;
   f32x4 acc[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -300,27 +322,30 @@ __global__ __launch_bounds__(256) void altcorr_mfma_bwd2(const float* __restrict
       const int tt = t0 + __builtin_ctzll(m);
       m &= m - 1;
       const int h1 = tt / tiles_x, w0 = (tt - h1 * tiles_x) * AC_TP;
-      const size_t gbase = (((size_t)b * lv.n + l) * rd * rd) * plane + (size_t)h1 * W1;
+      float av[4];
+      float bvv[4][NT];
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         // A[m = fmap2 pixel xq0 + pi][k = pixel w0 + 4 kk + g] = gs[pixel][window point of that fmap2 pixel]
-        const int w1 = w0 + 4 * kk + g;
-        const PixelWindow pw = pixel_window(coords, planar, b, h1, w1, H1, W1, cscale, R);
-        const int iy = hy - pw.cy, ix = xq0 + pi - pw.cx;
-        float av = 0.f;
-        if ((unsigned)iy < (unsigned)gd && (unsigned)ix < (unsigned)gd && xq0 + pi < W2) {
-          const float* gp = gout + gbase + w1;
-          if (iy > 0 && ix > 0)   av += gp[plane * ((iy - 1) + rd * (ix - 1))] * pw.dy * pw.dx;
-          if (iy > 0 && ix < rd)  av += gp[plane * ((iy - 1) + rd * ix)] * pw.dy * (1 - pw.dx);
-          if (iy < rd && ix > 0)  av += gp[plane * (iy + rd * (ix - 1))] * (1 - pw.dy) * pw.dx;
-          if (iy < rd && ix < rd) av += gp[plane * (iy + rd * ix)] * (1 - pw.dy) * (1 - pw.dx);
-          av *= scale;
+        const int w1 = w0 + 4 * kk + g, w1c = min(w1, W1 - 1);
+        const size_t pix = lbase + (size_t)h1 * W1 + w1c;
+        const int2 wv = *reinterpret_cast<const int2*>(win + pix * 2);
+        const int iy = hy - wv.y, ix = xq0 + pi - wv.x;
+        av[kk] = (w1 < W1 && qlive && (unsigned)iy < (unsigned)gd && (unsigned)ix < (unsigned)gd) ? gs_all[pix * npt + iy * gd + ix] : 0.f;
+        // B[k = pixel][n]: channel wave * CPG + pi * NT + nt
+        const float* bp = f1 + (((size_t)b * H1 + h1) * W1 + w1c) * C + wave * CPG + pi * NT;
+        if (NT == 4) {
+          const float4 v = *reinterpret_cast<const float4*>(bp);
+          bvv[kk][0] = v.x; bvv[kk][1] = v.y; bvv[kk][2 % NT] = v.z; bvv[kk][3 % NT] = v.w;
+        } else {
+          const float2 v = *reinterpret_cast<const float2*>(bp);
+          bvv[kk][0] = v.x; bvv[kk][1] = v.y;
         }
-        // B[k = pixel][n = channel]
-        const float* bp = f1 + (((size_t)b * H1 + h1) * W1 + min(w1, W1 - 1)) * C + wave * CPG + pi;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[nt * 16], acc[nt], 0, 0, 0);
       }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bvv[kk][nt], acc[nt], 0, 0, 0);
     }
   }
   float* g2 = lv.g2[l];
@@ -328,11 +353,11 @@ __global__ __launch_bounds__(256) void altcorr_mfma_bwd2(const float* __restrict
   for (int r4 = 0; r4 < 4; ++r4) {
     const int q = xq0 + 4 * g + r4;
     if (q >= W2) continue;
-    float* op = g2 + (((size_t)b * H2 + hy) * W2 + q) * C + wave * CPG + pi;
+    float* op = g2 + (((size_t)b * H2 + hy) * W2 + q) * C + wave * CPG + pi * NT;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      if (split > 1) atomicAdd(op + nt * 16, acc[nt][r4]);          // (the buffer was zeroed or holds the running sum)
-      else op[nt * 16] = (accumulate ? op[nt * 16] : 0.f) + acc[nt][r4];
+      if (split > 1) atomicAdd(op + nt, acc[nt][r4]);          // (the buffer was zeroed or holds the running sum)
+      else op[nt] = (accumulate ? op[nt] : 0.f) + acc[nt][r4];
     }
   }
 }
@@ -345,15 +370,35 @@ int launch_fwd(const float* f1, const AcLevels& lv, const float* coords, int pla
   return ufr::launched("altcorr_mfma_fwd");
 }
 
+// workspace layout (bytes): gs_all f32 [L][npix][npt] | part f32 [L][npix][C] | win i32 [L][npix][2] | boxes i32 [L][ntiles][4]
+struct AcWorkspace { float* gs_all; float* part; int* win; int* boxes; };
+
+long workspace_bytes(int B, int H1, int W1, int C, int radius, int levels) {
+  const long npix = (long)B * H1 * W1, ntiles = (long)B * H1 * ((W1 + AC_TP - 1) / AC_TP), npt = (2L * radius + 2) * (2 * radius + 2);
+  return 4 * (levels * npix * npt + levels * npix * C + levels * npix * 2 + levels * ntiles * 4 + 64);
+}
+
 template <int R, int CPG>
-int launch_bwd(const float* f1, AcLevels lv, const float* coords, int planar, const float* gout, float* g1, int* boxes, int B, int H1,
-               int W1, float scale, int accumulate, hipStream_t st) {
+int launch_bwd(const float* f1, AcLevels lv, const float* coords, int planar, const float* gout, float* g1, void* workspace, int B,
+               int H1, int W1, float scale, int accumulate, hipStream_t st) {
+  constexpr int C = 4 * CPG, npt = (2 * R + 2) * (2 * R + 2);
   const int tiles_b = H1 * ((W1 + AC_TP - 1) / AC_TP), tiles = B * tiles_b;
-  altcorr_mfma_bwd1<R, CPG><<<tiles, 256, 0, st>>>(lv, coords, planar, gout, g1, B, H1, W1, scale, accumulate);
-  int rc = ufr::launched("altcorr_mfma_bwd1");
+  const long npix = (long)B * H1 * W1;
+  AcWorkspace ws;
+  ws.gs_all = static_cast<float*>(workspace);
+  ws.part = ws.gs_all + (long)lv.n * npix * npt;
+  ws.win = reinterpret_cast<int*>(ws.part + (long)lv.n * npix * C);
+  ws.boxes = ws.win + (long)lv.n * npix * 2;
+  ws.boxes += (4 - ((reinterpret_cast<uintptr_t>(ws.boxes) / 4) & 3)) & 3;            // 16-byte aligned rows
+  altcorr_prepass<R><<<dim3(tiles, lv.n), 64, 0, st>>>(lv, coords, planar, gout, ws.gs_all, ws.win, ws.boxes, B, H1, W1, scale);
+  int rc = ufr::launched("altcorr_prepass");
   if (rc != UFR_OK) return rc;
-  altcorr_boxes<R><<<(tiles * lv.n + 3) / 4, 64, 0, st>>>(lv, coords, planar, boxes, B, H1, W1);
-  rc = ufr::launched("altcorr_boxes");
+  altcorr_mfma_bwd1<R, CPG><<<dim3(tiles, lv.n), 256, 0, st>>>(lv, ws.gs_all, ws.win, ws.boxes, ws.part, B, H1, W1);
+  rc = ufr::launched("altcorr_mfma_bwd1");
+  if (rc != UFR_OK) return rc;
+  const long n4 = npix * C / 4;
+  altcorr_sum_levels<<<ufr::stream_grid(n4, 256), 256, 0, st>>>(ws.part, g1, n4, lv.n, accumulate);
+  rc = ufr::launched("altcorr_sum_levels");
   if (rc != UFR_OK) return rc;
   int total = 0;
   for (int l = 0; l < lv.n; ++l) {
@@ -365,13 +410,13 @@ int launch_bwd(const float* f1, AcLevels lv, const float* coords, int planar, co
     lv.split[l] = split;
     total += segs * split;
     if (split > 1 && !accumulate) {               // atomics add onto the buffer: start from zero
-      hipError_t e = hipMemsetAsync(lv.g2[l], 0, sizeof(float) * (size_t)B * lv.H2[l] * lv.W2[l] * 4 * CPG, st);
+      hipError_t e = hipMemsetAsync(lv.g2[l], 0, sizeof(float) * (size_t)B * lv.H2[l] * lv.W2[l] * C, st);
       if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "altcorr backward: memset: %s", hipGetErrorString(e));
     }
   }
   lv.tile0[lv.n] = total;
   for (int l = lv.n + 1; l < 5; ++l) lv.tile0[l] = total;
-  altcorr_mfma_bwd2<R, CPG><<<total, 256, 0, st>>>(f1, lv, coords, planar, gout, boxes, B, H1, W1, scale, accumulate);
+  altcorr_mfma_bwd2<R, CPG><<<total, 256, 0, st>>>(f1, lv, ws.gs_all, ws.win, ws.boxes, B, H1, W1, accumulate);
   return ufr::launched("altcorr_mfma_bwd2");
 }
 
@@ -394,7 +439,7 @@ int ufr_altcorr_mfma_forward(const float* f1, const ufr_altcorr_levels* lv_in, c
 }
 
 int ufr_altcorr_mfma_backward(const float* f1, const ufr_altcorr_levels* lv_in, const float* coords, int planar, const float* gout,
-                              float* g1, int* boxes, int B, int H1, int W1, int C, int radius, float scale, int accumulate,
+                              float* g1, void* workspace, int B, int H1, int W1, int C, int radius, float scale, int accumulate,
                               hipStream_t st) {
   AcLevels lv{};
   lv.n = lv_in->num_levels;
@@ -402,10 +447,10 @@ int ufr_altcorr_mfma_backward(const float* f1, const ufr_altcorr_levels* lv_in, 
     lv.f2[l] = lv_in->fmap2[l]; lv.g2[l] = lv_in->fmap2_grad[l]; lv.H2[l] = lv_in->H2[l]; lv.W2[l] = lv_in->W2[l];
     lv.cscale[l] = lv_in->coord_scale[l];
   }
-  if (C == 256 && radius == 4) return launch_bwd<4, 64>(f1, lv, coords, planar, gout, g1, boxes, B, H1, W1, scale, accumulate, st);
-  if (C == 128 && radius == 4) return launch_bwd<4, 32>(f1, lv, coords, planar, gout, g1, boxes, B, H1, W1, scale, accumulate, st);
-  if (C == 256 && radius == 3) return launch_bwd<3, 64>(f1, lv, coords, planar, gout, g1, boxes, B, H1, W1, scale, accumulate, st);
-  return launch_bwd<3, 32>(f1, lv, coords, planar, gout, g1, boxes, B, H1, W1, scale, accumulate, st);
+  if (C == 256 && radius == 4) return launch_bwd<4, 64>(f1, lv, coords, planar, gout, g1, workspace, B, H1, W1, scale, accumulate, st);
+  if (C == 128 && radius == 4) return launch_bwd<4, 32>(f1, lv, coords, planar, gout, g1, workspace, B, H1, W1, scale, accumulate, st);
+  if (C == 256 && radius == 3) return launch_bwd<3, 64>(f1, lv, coords, planar, gout, g1, workspace, B, H1, W1, scale, accumulate, st);
+  return launch_bwd<3, 32>(f1, lv, coords, planar, gout, g1, workspace, B, H1, W1, scale, accumulate, st);
 }
 
 bool ufr_altcorr_mfma_serves(int C, int radius) { return mfma_form_serves(C, radius); }
@@ -421,7 +466,7 @@ extern "C" int ufr_altcorr_pyramid_forward(const float* fmap1, const ufr_altcorr
 }
 
 extern "C" int ufr_altcorr_pyramid_backward(const float* fmap1, const ufr_altcorr_levels* levels, const float* coords,
-                                            const float* grad_out, float* fmap1_grad, int* workspace, int B, int H1, int W1, int C,
+                                            const float* grad_out, float* fmap1_grad, void* workspace, int B, int H1, int W1, int C,
                                             int radius, float scale, int accumulate, ufr_stream_t stream) {
   UFR_REQUIRE(fmap1 && levels && coords && grad_out && fmap1_grad && workspace, "altcorr pyramid backward: null pointer");
   UFR_REQUIRE(B > 0 && H1 > 0 && W1 > 0 && levels->num_levels >= 1 && levels->num_levels <= 4, "altcorr pyramid backward: bad shape");
@@ -432,6 +477,6 @@ extern "C" int ufr_altcorr_pyramid_backward(const float* fmap1, const ufr_altcor
                                    ufr::as_stream(stream));
 }
 
-extern "C" long ufr_altcorr_pyramid_workspace_ints(int B, int H1, int W1, int num_levels) {
-  return (long)B * H1 * ((W1 + AC_TP - 1) / AC_TP) * 4 * (num_levels > 0 ? num_levels : 1);
+extern "C" long ufr_altcorr_pyramid_workspace_bytes(int B, int H1, int W1, int C, int radius, int num_levels) {
+  return workspace_bytes(B, H1, W1, C, radius, num_levels > 0 ? num_levels : 1);
 }

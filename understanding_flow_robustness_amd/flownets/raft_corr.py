@@ -175,7 +175,7 @@ class AltCorrPyramidFunction(torch.autograd.Function):
         with torch.cuda.device(fmap1.device):
             if shared is None or shared.acc is None:
                 grads = [torch.empty_like(fmap1)] + [torch.empty_like(f) for f in f2s]
-                ws = torch.empty(L.lib().ufr_altcorr_pyramid_workspace_ints(B, H1, W1, len(f2s)), dtype=torch.int32,
+                ws = torch.empty(L.lib().ufr_altcorr_pyramid_workspace_bytes(B, H1, W1, Cc, radius, len(f2s)), dtype=torch.uint8,
                                  device=fmap1.device)
                 accumulate = 0
                 if shared is not None:
