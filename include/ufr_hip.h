@@ -227,6 +227,29 @@ int ufr_gru_blend_forward(const float* q_pre, const float* z, const float* h, fl
 int ufr_gru_blend_backward(const float* q_pre, const float* z, const float* h, const float* g, float* g_qpre,
                            float* g_z, float* g_h, long total, ufr_stream_t stream);
 
+/* ---- RAFT update block on the engine's chunk-major layout (csrc/raft_update.hip; the convolutions run through ufr_igemm) ----
+ * replaces the non-convolution arithmetic of models/raft/update.py:35-162 on activation planes bf16 [3][chunks][M][32] and
+ * float32 tensors [chunks][M][32] (M = B*H*W):
+ *   ufr_raft_flow_patches: the 7x7x2 neighbourhood of `flow` [B,2,H,W] (convf1, update.py:99,:113) as 98 of 128 plane channels
+ *     k = (ky*7 + kx)*2 + c at chunks [chunk0, chunk0 + 4): the 49-tap convolution becomes a 1x1 launch;
+ *   ufr_raft_motion_finish: cat([out, flow]) (update.py:120): channels 126 / 127 of the 4 motion chunks at chunk0 of p1 = flow,
+ *     and the 4 chunks copied to the same place in p2 (the second half-step's GRU buffer);
+ *   ufr_gru_gates_cm_*: zr [2*chunks][M][32] pre-activations -> sigmoid values IN PLACE, rh = r*h (planes); adjoint: g_zr planes
+ *     [g_z z(1-z) | g_rh h r(1-r)], g_h += g_rh r;
+ *   ufr_gru_blend_cm_*: q -> tanh IN PLACE, out = (1-z) h + z q (planes); adjoint: g_q_pre planes, g_z, g_h = g (1-z). */
+int ufr_raft_flow_patches(const float* flow, void* planes, long plane_stride, int chunk0, int B, int H, int W, ufr_stream_t stream);
+int ufr_raft_motion_finish(void* p1, long plane_stride1, void* p2, long plane_stride2, int chunk0, const float* flow, int B, int H,
+                           int W, ufr_stream_t stream);
+int ufr_gru_gates_cm_forward(float* zr, const void* h, long h_plane_stride, int h_chunk0, void* rh, long rh_plane_stride,
+                             int rh_chunk0, long M, int chunks, ufr_stream_t stream);
+int ufr_gru_blend_cm_forward(float* q, const float* z, const void* h, long h_plane_stride, int h_chunk0, void* out,
+                             long out_plane_stride, int out_chunk0, long M, int chunks, ufr_stream_t stream);
+int ufr_gru_blend_cm_backward(const float* q, const float* z, const void* h, long h_plane_stride, int h_chunk0, const float* g,
+                              void* gq, long gq_plane_stride, int gq_chunk0, float* g_z, float* g_h, long M, int chunks,
+                              ufr_stream_t stream);
+int ufr_gru_gates_cm_backward(const float* zr, const void* h, long h_plane_stride, int h_chunk0, const float* g_z, const float* g_rh,
+                              void* gzr, long gzr_plane_stride, int gzr_chunk0, float* g_h, long M, int chunks, ufr_stream_t stream);
+
 /* ---- PWC-Net backward warp ----------------------------------------------------------------------
  * replaces PWCDCNet.warp (models/PWCNet.py:164-204): grid from the flow (normalised with W-1, sampled with
  * align_corners=False, as the reference does), bilinear grid_sample with zero padding, times the validity mask

@@ -269,6 +269,16 @@ class RAFT(nn.Module):
         self.cnet = BasicEncoder(output_dim=256, norm_fn=args.cnorm, dropout=args.dropout)
         self.update_block = BasicUpdateBlock(args, hidden_dim=128)
 
+    def _engine_ok(self, net, H, W) -> bool:
+        """The native refinement loop (raft_engine.py) serves the attack's configuration: frozen parameters, eval mode, HIP
+        float32 tensors, the raft-things update block, frame sides that are multiples of 8 (UFR_ENGINE=0 switches it off)."""
+        import os
+        if os.environ.get("UFR_ENGINE", "1") != "1" or self.training or getattr(self.args, "update_no_motion_downsampling", False):
+            return False
+        frozen = not any(p.requires_grad for p in self.parameters())
+        return (net.is_cuda and net.dtype == torch.float32 and (frozen or not torch.is_grad_enabled()) and H % 8 == 0 and W % 8 == 0
+                and self.args.corr_levels == 4 and self.args.corr_radius == 4)
+
     def freeze_bn(self):
         for m in self.modules():
             if isinstance(m, nn.BatchNorm2d):
@@ -300,6 +310,11 @@ class RAFT(nn.Module):
         net, inp = torch.tanh(net), torch.relu(inp)
 
         N, _, H, W = image1.shape
+        if test_mode and flow_init is None and self._engine_ok(net, H, W):
+            # the 12 iterations as one explicit schedule on the native engine (raft_engine.py): same operands, same result
+            from ..raft_engine import refine
+            flow_lr, up_mask = refine(self, net.contiguous(), inp.contiguous(), corr_fn, H, W)
+            return flow_lr, self.upsample_flow(flow_lr, up_mask)
         coords0 = coords_grid(N, H // 8, W // 8, image1.device)
         coords1 = coords0.clone()
         if flow_init is not None:

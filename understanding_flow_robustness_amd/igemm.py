@@ -143,12 +143,18 @@ def _deconv_phases(kernel: int, padding: int):
     return phases
 
 
-def conv_forward_weights(weight: torch.Tensor, stride: int, padding: int, dilation: int = 1) -> WeightImage:
-    """Conv2d weight [N,C,k,k] -> the forward launch (rows = output grid); a dilation is just other tap offsets."""
-    N, Cn, k, _ = weight.shape
+def _pair(v):
+    return (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
+
+
+def conv_forward_weights(weight: torch.Tensor, stride: int, padding, dilation: int = 1) -> WeightImage:
+    """Conv2d weight [N,C,kh,kw] -> the forward launch (rows = output grid); a dilation is just other tap offsets, a
+    rectangular kernel (RAFT's 1x5 / 5x1 GRU convolutions, padding = (ph, pw)) just another tap list."""
+    N, Cn, kh, kw = weight.shape
+    ph, pw = _pair(padding)
     w = weight.detach().float()
-    mat = w.permute(0, 2, 3, 1).reshape(N, k * k, Cn)
-    taps = [(ky * dilation - padding, kx * dilation - padding) for ky in range(k) for kx in range(k)]
+    mat = w.permute(0, 2, 3, 1).reshape(N, kh * kw, Cn)
+    taps = [(ky * dilation - ph, kx * dilation - pw) for ky in range(kh) for kx in range(kw)]
     planes, offsets, N, npad, KC, cr = _pack([mat], weight.device)
     return WeightImage(planes, offsets, [(0, 0, taps)], N, npad, KC, dict(in_s=stride, out_s=1), cr)
 
@@ -198,16 +204,20 @@ def conv1_packed_backward_weights(weight: torch.Tensor) -> WeightImage:
     return WeightImage(planes, offsets, [(0, 0, taps)], n, npad, KC, dict(in_s=1, out_s=1), C=147.0 * N / (8.0 * 24.0))
 
 
-def conv_backward_weights(weight: torch.Tensor, stride: int, padding: int, dilation: int = 1) -> WeightImage:
-    """Data gradient of Conv2d(weight [N,C,k,k], stride, padding, dilation): gx[C] from gy[N] (rows = the gy grid)."""
-    N, Cn, k, _ = weight.shape
+def conv_backward_weights(weight: torch.Tensor, stride: int, padding, dilation: int = 1) -> WeightImage:
+    """Data gradient of Conv2d(weight [N,C,kh,kw], stride, padding, dilation): gx[C] from gy[N] (rows = the gy grid)."""
+    N, Cn, kh, kw = weight.shape
+    ph, pw = _pair(padding)
     w = weight.detach().float()
     if stride == 1:
         # gx[y] = sum_ky gy[y + p - d ky] * w[ky]: a convolution of gy with the transposed weights
-        mat = w.permute(1, 2, 3, 0).reshape(Cn, k * k, N)
-        taps = [(padding - ky * dilation, padding - kx * dilation) for ky in range(k) for kx in range(k)]
+        mat = w.permute(1, 2, 3, 0).reshape(Cn, kh * kw, N)
+        taps = [(ph - ky * dilation, pw - kx * dilation) for ky in range(kh) for kx in range(kw)]
         planes, offsets, n, npad, KC, cr = _pack([mat], weight.device)
         return WeightImage(planes, offsets, [(0, 0, taps)], n, npad, KC, dict(in_s=1, out_s=1), cr)
+    k, padding = kh, ph
+    if kh != kw or ph != pw:
+        raise NotImplementedError("data gradient of a strided convolution: square kernels only")
     if stride != 2 or dilation != 1:
         raise NotImplementedError("data gradient: stride 1 (any dilation) or 2")
     phases = _deconv_phases(k, padding)          # gx = conv_transpose(gy, weight): 'input' channels N, output channels C

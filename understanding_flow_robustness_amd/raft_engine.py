@@ -1,0 +1,342 @@
+"""Native RAFT refinement loop: the 12 iterations of models/raft/raft.py:189-228 -- cost-volume lookup, motion encoder,
+SepConvGRU, flow head, and the mask head of the last iteration (models/raft/update.py:6-162) -- forward AND data gradient as an
+explicit schedule of hand-written gfx950 kernels, one autograd Function around the whole loop.  Config C3 of BASELINE.json.
+
+    every convolution (1x1, 3x3, 1x5, 5x1; 7x7 via gathered patches)   csrc/igemm.hip (bf16 split planes, six products)
+    GRU gate arithmetic, flow patches, cat([out, flow])                csrc/raft_update.hip (chunk-major, streaming)
+    lookup                                                              csrc/raft_altcorr_mfma.hip (alt_cuda_corr, one launch
+                                                                        for all levels) or csrc/raft_corr.hip (all-pairs pyramid)
+    delta_flow = Conv2d(256, 2, 3)                                      csrc/engine_small.hip (per-pixel GEMM + gather)
+
+Layout.  A GRU half-step's two concatenations -- cat([h, x]) for the z / r gates and cat([r*h, x]) for q, x = cat([inp, motion])
+(update.py:50-66) -- are ONE 16-chunk plane buffer [h 4 | inp 4 | motion 4 | r*h 4]: the gate convolution reads chunks 0-11, the
+q convolution chunks 4-15 (its weights re-indexed once).  motion = cat([out 126, flow 2]) is exactly four chunks.
+
+What the loop's structure allows (raft.py:190: coords1 is detached at the top of every iteration): the flow head runs its
+adjoint for the LAST iteration only, the whole flow branch of the motion encoder (convf1, convf2) has no adjoint at all, and the
+mask head exists only in the last iteration.  Parameters are frozen (data gradients only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+
+import torch
+
+from . import _lib as L
+from . import igemm as ig
+from .flownetc_engine import _pack_flow_head, _pack_flow_head_mfma
+
+HC = 4                                  # chunks of the hidden state / context / motion features (128 channels each)
+
+
+def _ptr(gs: ig.GradSum, chunk0: int) -> C.c_void_p:
+    """Device pointer to chunk `chunk0` of a float32 [chunks][M][32] tensor."""
+    return C.c_void_p(gs.t.data_ptr() + chunk0 * gs.M * 32 * 4)
+
+
+class RaftUpdateEngine:
+    def __init__(self, net, B: int, H: int, W: int, device):
+        if H % 8 or W % 8:
+            raise ValueError("RAFT engine: frame sides must be multiples of 8")
+        L.lib()
+        self.net, self.B, self.H, self.W, self.dev = net, int(B), int(H), int(W), torch.device(device)
+        self.h, self.w = H // 8, W // 8
+        self.M = self.B * self.h * self.w
+        self.iters = int(net.args.iters)
+        self.radius, self.levels = int(net.args.corr_radius), int(net.args.corr_levels)
+        self.generation = 0
+        self._build()
+
+    # ------------------------------------------------------------------------------------------------ set-up
+    def _build(self):
+        net, B, h, w, dev, IT = self.net, self.B, self.h, self.w, self.dev, self.iters
+        ub, enc, gru = net.update_block, net.update_block.encoder, net.update_block.gru
+        f32 = dict(dtype=torch.float32, device=dev)
+        P = lambda chunks: ig.Planes(B, h, w, chunks, dev)
+        G = lambda chunks: ig.GradSum(B, h, w, chunks, dev)
+        cor_planes = self.levels * (2 * self.radius + 1) ** 2
+        self.cor_planes, self.cor_chunks = cor_planes, ig.pad32(cor_planes) // 32
+        # ---- activations: per iteration what an adjoint reads (ReLU masks, gate values), shared buffers for the rest
+        self.corr_p = [P(self.cor_chunks) for _ in range(IT)]
+        self.cor1 = [P(8) for _ in range(IT)]
+        self.CF = [P(8) for _ in range(IT)]                           # [cor2 192 | flo2 64] = cat([cor, flo]) (update.py:118)
+        self.P1 = [P(4 * HC) for _ in range(IT)] + [P(HC)]            # [h | inp | motion | r*h]; the extra one holds the final h
+        self.P2 = [P(4 * HC) for _ in range(IT)]
+        self.ZR = [[G(2 * HC) for _ in range(IT)] for _ in range(2)]  # sigmoid(z) | sigmoid(r) of the two half-steps
+        self.Q = [[G(HC) for _ in range(IT)] for _ in range(2)]       # tanh(q)
+        self.fpat, self.flo1 = P(4), P(4)                             # flow branch: no adjoint, one buffer serves every iteration
+        self.FH, self.MH = P(8), P(8)                                 # flow-head / mask-head hidden layers (last iteration's are kept)
+        self.mask_f32 = G(18)
+        self.corr = torch.zeros(B, cor_planes, h, w, **f32)
+        self.flows = [torch.zeros(B, 2, h, w, **f32) for _ in range(IT)]
+        self.delta = torch.zeros(B, 2, h, w, **f32)
+        self.coords0 = torch.zeros(B, 2, h, w, **f32)
+        ys, xs = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing="ij")
+        self.coords0.copy_(torch.stack((xs, ys), dim=0).float()[None].expand(B, -1, -1, -1))     # utils/utils.py:80-83
+        self.coords1 = torch.zeros(B, 2, h, w, **f32)
+        self.flow_lr = torch.zeros(B, 2, h, w, **f32)
+        self.up_mask = torch.zeros(B, 576, h, w, **f32)
+        # ---- gradients
+        self.G_h, self.G_hp, self.G_z = G(HC), G(HC), G(HC)
+        self.G_qx, self.G_zrx, self.G_x = G(3 * HC), G(3 * HC), G(2 * HC)
+        self.G_inp = G(HC)
+        self.gzq, self.gzr, self.gz_mot = P(HC), P(2 * HC), P(HC)
+        self.gz_cor2, self.gz_cor1 = P(6), P(8)
+        self.G_corr = G(self.cor_chunks)
+        self.g_corr = torch.zeros(B, cor_planes, h, w, **f32)
+        self.G_fh, self.gz_fh = G(8), P(8)
+        self.gz_mask, self.gz_mh = P(18), P(8)
+        self.g_net0, self.g_inp = torch.zeros(B, 128, h, w, **f32), torch.zeros(B, 128, h, w, **f32)
+        # ---- weights (frozen), in buffer channel order
+        cw = lambda conv, pad, **kw: ig.conv_forward_weights(conv if torch.is_tensor(conv) else conv.weight, 1, pad, **kw)
+        bw = lambda conv, pad: ig.conv_backward_weights(conv if torch.is_tensor(conv) else conv.weight, 1, pad)
+        bias = lambda conv: conv.bias.detach().float().contiguous()
+        wf1 = torch.zeros(128, 128, 1, 1, **f32)                      # convf1 over the gathered 7x7x2 patches: k = (ky*7 + kx)*2 + c
+        wf1[:, :98, 0, 0] = enc.convf1.weight.detach().float().permute(0, 2, 3, 1).reshape(128, 98)
+        w_zr, b_zr, w_q = {}, {}, {}
+        for tag in ("1", "2"):
+            convz, convr, convq = (getattr(gru, f"conv{g}{tag}") for g in "zrq")
+            w_zr[tag] = torch.cat([convz.weight, convr.weight]).detach().float()          # [256, 384 = h | inp | motion, kh, kw]
+            b_zr[tag] = torch.cat([convz.bias, convr.bias]).detach().float().contiguous()
+            wq = convq.weight.detach().float()                                             # reference input: [r*h | inp | motion]
+            w_q[tag] = torch.cat([wq[:, 128:], wq[:, :128]], 1).contiguous()              # buffer: [inp | motion | r*h]
+        self._pads = {"1": (0, 2), "2": (2, 0)}
+        plans = []
+
+        def plan(key, wi, x, in_chunk0, **kw):
+            pk = [len(t) * wi.KC for _, _, t in wi.phases]
+            kw.setdefault("variant", 6 if wi.Npad % 128 == 0 else 2)
+            bm, target = (256, 256) if kw["variant"] == 6 else (128, 768)
+            S = ig.splitk_for(self.M, wi.Npad, max(pk), 1, phase_ktiles=pk, bm=bm, target=target, min_ktiles=4)
+            plans.append((key, wi, x, in_chunk0, S, kw))
+
+        W = dict(convc1=cw(enc.convc1, 0), convc2=cw(enc.convc2, 1), convf1=cw(wf1, 0), convf2=cw(enc.convf2, 1), conv=cw(enc.conv, 1),
+                 fh1=cw(ub.flow_head.conv1, 1), mask1=cw(ub.mask[0], 1), mask2=cw(ub.mask[2], 0))
+        Wb = dict(conv=bw(enc.conv.weight[:, :192], 1), convc2=bw(enc.convc2, 1), convc1=bw(enc.convc1, 0), fh1=bw(ub.flow_head.conv1, 1),
+                  mask1=bw(ub.mask[0], 1), mask2=bw(ub.mask[2], 0))
+        for tag in ("1", "2"):
+            W["zr" + tag], W["q" + tag] = cw(w_zr[tag], self._pads[tag]), cw(w_q[tag], self._pads[tag])
+            Wb["zr" + tag], Wb["q" + tag] = bw(w_zr[tag], self._pads[tag]), bw(w_q[tag], self._pads[tag])
+        relu, lin = dict(slope=0.0), dict(slope=1.0)
+        for it in range(IT):
+            P1, P2 = self.P1[it], self.P2[it]
+            plan(("convc1", it), W["convc1"], self.corr_p[it], 0, out_planes=self.cor1[it], bias=bias(enc.convc1), **relu)
+            plan(("convc2", it), W["convc2"], self.cor1[it], 0, out_planes=self.CF[it], out_chunk0=0, bias=bias(enc.convc2), **relu)
+            plan(("convf1", it), W["convf1"], self.fpat, 0, out_planes=self.flo1, bias=bias(enc.convf1), **relu)
+            plan(("convf2", it), W["convf2"], self.flo1, 0, out_planes=self.CF[it], out_chunk0=6, bias=bias(enc.convf2), **relu)
+            plan(("conv", it), W["conv"], self.CF[it], 0, out_planes=P1, out_chunk0=2 * HC, bias=bias(enc.conv), **relu)
+            for half, (tag, buf, nxt) in enumerate((("1", P1, P2), ("2", P2, self.P1[it + 1]))):
+                plan(("zr" + tag, it), W["zr" + tag], buf, 0, out_f32=self.ZR[half][it], bias=b_zr[tag], **lin)
+                plan(("q" + tag, it), W["q" + tag], buf, HC, out_f32=self.Q[half][it], bias=bias(getattr(gru, "convq" + tag)), **lin)
+                # adjoints: d / d [inp | motion | r*h] of q, d / d [h | inp | motion] of the gates
+                plan(("q" + tag + "^T", it), Wb["q" + tag], self.gzq, 0, out_f32=self.G_qx)
+                plan(("zr" + tag + "^T", it), Wb["zr" + tag], self.gzr, 0, out_f32=self.G_zrx)
+            plan(("fh1", it), W["fh1"], self.P1[it + 1], 0, out_planes=self.FH, bias=bias(ub.flow_head.conv1), **relu)
+            # motion encoder adjoint (the correlation branch only): masks are the ReLU outputs of that iteration
+            plan(("conv^T", it), Wb["conv"], self.gz_mot, 0, mask=self.CF[it], out_planes=self.gz_cor2, **relu)
+            plan(("convc2^T", it), Wb["convc2"], self.gz_cor2, 0, mask=self.cor1[it], out_planes=self.gz_cor1, **relu)
+            plan(("convc1^T", it), Wb["convc1"], self.gz_cor1, 0, out_f32=self.G_corr)
+        last = self.P1[IT]
+        plan(("mask1",), W["mask1"], last, 0, out_planes=self.MH, bias=bias(ub.mask[0]), **relu)
+        plan(("mask2",), W["mask2"], self.MH, 0, out_f32=self.mask_f32, bias=bias(ub.mask[2]), **lin)
+        plan(("mask2^T",), Wb["mask2"], self.gz_mask, 0, mask=self.MH, out_planes=self.gz_mh, **relu)
+        plan(("mask1^T",), Wb["mask1"], self.gz_mh, 0, out_f32=self.G_h)
+        plan(("fh1^T",), Wb["fh1"], self.gz_fh, 0, add=self.G_h, out_f32=self.G_h)
+        need = max([S * self.M * wi.Npad for _, wi, _, _, S, _ in plans if S > 1] + [1])
+        self.ws = torch.empty(need, **f32)
+        self.launch, self._wi = {}, {}
+        for key, wi, x, c0, S, kw in plans:
+            self.launch[key] = ig.make_launch(wi, x, c0, (h, w), (h, w), splitk=S, ws=self.ws if S > 1 else None, **kw)
+            self._wi[key] = wi
+        fh2 = ub.flow_head.conv2
+        self.fh2_w, self.fh2_wm = _pack_flow_head(fh2.weight), _pack_flow_head_mfma(fh2.weight)
+        self.fh2_b = fh2.bias.detach().float().contiguous()
+
+    def launch_table(self):
+        rows = []
+        for key, launch in self.launch.items():
+            d = launch.desc
+            rows.append(("_".join(str(v) for v in key), launch, self._wi[key].flops(d.B * d.Hr * d.Wr) / 1e9))
+        return rows
+
+    # ------------------------------------------------------------------------------------------------ lookups
+    def _alt_levels(self, f2s, grads=None):
+        from .flownets.raft_corr import _levels_struct
+        return _levels_struct(f2s, grads)
+
+    def _lookup_forward(self, src, coords):
+        lib, B, h, w = L.lib(), self.B, self.h, self.w
+        if src["alt"]:
+            lv = self._alt_levels(src["f2"])
+            L.check(lib.ufr_altcorr_pyramid_forward(L.ptr(src["f1"]), C.byref(lv), L.ptr(coords), L.ptr(self.corr), B, h, w,
+                                                    src["f1"].shape[3], self.radius, src["scale"], L.stream()), "alt_corr forward")
+        else:
+            from .flownets.raft_corr import _pyramid_struct
+            pyr = _pyramid_struct(src["vols"])
+            L.check(lib.ufr_corr_lookup_forward(C.byref(pyr), L.ptr(coords), L.ptr(self.corr), B, h, w, self.radius, L.stream()),
+                    "corr lookup forward")
+
+    def _lookup_backward(self, src, coords, first):
+        lib, B, h, w = L.lib(), self.B, self.h, self.w
+        if src["alt"]:
+            lv = self._alt_levels(src["f2"], src["g_f2"])
+            L.check(lib.ufr_altcorr_pyramid_backward(L.ptr(src["f1"]), C.byref(lv), L.ptr(coords), L.ptr(self.g_corr), L.ptr(src["g_f1"]),
+                                                     L.ptr(src["ws"]), B, h, w, src["f1"].shape[3], self.radius, src["scale"],
+                                                     0 if first else 1, L.stream()), "alt_corr backward")
+        else:
+            from .flownets.raft_corr import _pyramid_struct
+            pyr = _pyramid_struct(src["vols"], src["g_vols"])          # accumulates (+=): the buffers were zeroed
+            L.check(lib.ufr_corr_lookup_backward(C.byref(pyr), L.ptr(coords), L.ptr(self.g_corr), B, h, w, self.radius, L.stream()),
+                    "corr lookup backward")
+
+    # ------------------------------------------------------------------------------------------------ the schedule
+    @torch.no_grad()
+    def forward(self, net0: torch.Tensor, inp: torch.Tensor, src: dict, flow_init: torch.Tensor | None = None):
+        """net0 = tanh(context[:128]), inp = relu(context[128:]) [B,128,H/8,W/8]; src = the lookup's operands.
+        -> (coords1 - coords0 [B,2,H/8,W/8], 0.25 * mask [B,576,H/8,W/8]) of the last iteration (raft.py:213-233, test_mode)."""
+        lib, st, B, h, w, M, IT = L.lib(), L.stream, self.B, self.h, self.w, self.M, self.iters
+        self.generation += 1
+        self._src = src
+        self.P1[0].load_nchw(net0.contiguous(), 0)
+        inp = inp.contiguous()
+        for it in range(IT):                                          # the context features are the same in every iteration
+            self.P1[it].load_nchw(inp, HC)
+            self.P2[it].load_nchw(inp, HC)
+        self.coords1.copy_(self.coords0)
+        if flow_init is not None:
+            self.coords1.add_(flow_init)
+        self._coords = []
+        for it in range(IT):
+            coords = self.coords1.clone()                             # (the adjoint of this iteration's lookup reads them)
+            self._coords.append(coords)
+            self._lookup_forward(src, coords)
+            self.corr_p[it].load_nchw(self.corr, 0)
+            torch.sub(coords, self.coords0, out=self.flows[it])
+            L.check(lib.ufr_raft_flow_patches(L.ptr(self.flows[it]), L.ptr(self.fpat.t), self.fpat.plane_stride, 0, B, h, w, st()),
+                    "flow patches")
+            for name in ("convc1", "convc2", "convf1", "convf2", "conv"):
+                self.launch[(name, it)]()
+            P1, P2 = self.P1[it], self.P2[it]
+            L.check(lib.ufr_raft_motion_finish(L.ptr(P1.t), P1.plane_stride, L.ptr(P2.t), P2.plane_stride, 2 * HC, L.ptr(self.flows[it]),
+                                               B, h, w, st()), "motion finish")
+            for half, (tag, buf, nxt) in enumerate((("1", P1, P2), ("2", P2, self.P1[it + 1]))):
+                ZR, Q = self.ZR[half][it], self.Q[half][it]
+                self.launch[("zr" + tag, it)]()
+                L.check(lib.ufr_gru_gates_cm_forward(L.ptr(ZR.t), L.ptr(buf.t), buf.plane_stride, 0, L.ptr(buf.t), buf.plane_stride,
+                                                     3 * HC, M, HC, st()), "gru gates forward")
+                self.launch[("q" + tag, it)]()
+                L.check(lib.ufr_gru_blend_cm_forward(L.ptr(Q.t), L.ptr(ZR.t), L.ptr(buf.t), buf.plane_stride, 0, L.ptr(nxt.t),
+                                                     nxt.plane_stride, 0, M, HC, st()), "gru blend forward")
+            self.launch[("fh1", it)]()
+            L.check(lib.ufr_flow_head_planes_forward_mfma(L.ptr(self.FH.t), self.FH.plane_stride, 0, 8, L.ptr(self.fh2_wm), L.ptr(self.fh2_b),
+                                                          L.ptr(self.delta), B, h, w, st()), "delta_flow")
+            self.coords1.add_(self.delta)
+        self.launch[("mask1",)]()
+        self.launch[("mask2",)]()
+        self.mask_f32.to_nchw(576, 0, scale=0.25, slope=1.0, out=self.up_mask)
+        torch.sub(self.coords1, self.coords0, out=self.flow_lr)
+        return self.flow_lr, self.up_mask
+
+    @torch.no_grad()
+    def backward(self, g_flow: torch.Tensor, g_mask: torch.Tensor | None):
+        """(d loss / d flow_lr, d loss / d up_mask) -> (d / d net0, d / d inp) NCHW; the lookup operands' gradients are added into
+        src['g_f1'] / src['g_f2'] (alt_corr) or src['g_vols'] (all-pairs)."""
+        lib, st, B, h, w, M, IT = L.lib(), L.stream, self.B, self.h, self.w, self.M, self.iters
+        src = self._src
+        # ---- last iteration: mask head and flow head -> d / d h
+        if g_mask is not None:
+            self.gz_mask.load_nchw(g_mask.contiguous(), 0, scale=0.25)
+            self.launch[("mask2^T",)]()
+            self.launch[("mask1^T",)]()
+        else:
+            self.G_h.t.zero_()
+        L.check(lib.ufr_flow_head_planes_backward(L.ptr(g_flow.contiguous()), L.ptr(self.fh2_w), L.ptr(self.G_fh.t), 0, 8, B, h, w, 0,
+                                                  st()), "delta_flow backward")
+        L.check(lib.ufr_grad_finalize(L.ptr(self.G_fh.t), 0, L.ptr(self.FH.t), 0, L.ptr(self.gz_fh.t), self.gz_fh.plane_stride, 0, M, 8,
+                                      0.0, st()), "flow head finalize")
+        self.launch[("fh1^T",)]()
+        self.G_inp.t.zero_()
+        cur, prev = self.G_h, self.G_hp                               # d / d (a half-step's output h), d / d (its input h)
+        for it in range(IT - 1, -1, -1):
+            self.G_x.t.zero_()
+            for half, (tag, buf) in ((1, ("2", self.P2[it])), (0, ("1", self.P1[it]))):
+                ZR, Q = self.ZR[half][it], self.Q[half][it]
+                L.check(lib.ufr_gru_blend_cm_backward(L.ptr(Q.t), L.ptr(ZR.t), L.ptr(buf.t), buf.plane_stride, 0, L.ptr(cur.t),
+                                                      L.ptr(self.gzq.t), self.gzq.plane_stride, 0, L.ptr(self.G_z.t), L.ptr(prev.t), M,
+                                                      HC, st()), "gru blend backward")
+                self.launch[("q" + tag + "^T", it)]()                 # -> G_qx = d / d [inp | motion | r*h]
+                L.check(lib.ufr_gru_gates_cm_backward(L.ptr(ZR.t), L.ptr(buf.t), buf.plane_stride, 0, L.ptr(self.G_z.t), _ptr(self.G_qx, 2 * HC),
+                                                      L.ptr(self.gzr.t), self.gzr.plane_stride, 0, L.ptr(prev.t), M, HC, st()),
+                        "gru gates backward")
+                self.launch[("zr" + tag + "^T", it)]()                # -> G_zrx = d / d [h | inp | motion]
+                prev.t.add_(self.G_zrx.t[:HC])
+                self.G_x.t.add_(self.G_qx.t[:2 * HC]).add_(self.G_zrx.t[HC:])
+                cur, prev = prev, cur                                 # the half-step's input gradient feeds the one before it
+            self.G_inp.t.add_(self.G_x.t[:HC])
+            # motion features -> ReLU' -> conv^T (correlation branch) -> convc2^T -> convc1^T -> the lookup's adjoint
+            L.check(lib.ufr_grad_finalize(_ptr(self.G_x, HC), 0, L.ptr(self.P1[it].t), 2 * HC, L.ptr(self.gz_mot.t), self.gz_mot.plane_stride,
+                                          0, M, HC, 0.0, st()), "motion finalize")
+            for name in ("conv^T", "convc2^T", "convc1^T"):
+                self.launch[(name, it)]()
+            self.G_corr.to_nchw(self.cor_planes, 0, slope=1.0, out=self.g_corr)
+            self._lookup_backward(src, self._coords[it], first=(it == IT - 1))
+        cur.to_nchw(128, 0, slope=1.0, out=self.g_net0)             # (an even number of half-steps: cur is G_h again)
+        self.G_inp.to_nchw(128, 0, slope=1.0, out=self.g_inp)
+        return self.g_net0, self.g_inp
+
+
+class _RaftRefine(torch.autograd.Function):
+    """The refinement loop as one Function of (net0, inp, lookup operands); static buffers: see flownetc_engine._EngineHead."""
+
+    @staticmethod
+    def forward(ctx, net0, inp, engine, alt, scale, f1, *rest):
+        if alt:
+            src = dict(alt=True, f1=f1, f2=list(rest), scale=float(scale))
+        else:
+            src = dict(alt=False, vols=list(rest))
+        flow_lr, up_mask = engine.forward(net0, inp, src)
+        ctx.engine, ctx.src, ctx.generation = engine, src, engine.generation
+        return flow_lr.clone(), up_mask.clone()
+
+    @staticmethod
+    def backward(ctx, g_flow, g_mask):
+        eng, src = ctx.engine, ctx.src
+        if eng.generation != ctx.generation:
+            raise RuntimeError("RAFT engine: another forward of this network (same batch and frame size) ran before this backward; its "
+                               "activations are gone.  Call backward() before the next forward, or set UFR_ENGINE=0")
+        if src["alt"]:
+            f1 = src["f1"]
+            src["g_f1"], src["g_f2"] = torch.empty_like(f1), [torch.empty_like(f) for f in src["f2"]]
+            nbytes = L.lib().ufr_altcorr_pyramid_workspace_bytes(eng.B, eng.h, eng.w, f1.shape[3], eng.radius, len(src["f2"]))
+            src["ws"] = torch.empty(nbytes, dtype=torch.uint8, device=f1.device)
+        else:
+            src["g_vols"] = [torch.zeros_like(v) for v in src["vols"]]
+        g_net0, g_inp = eng.backward(g_flow, g_mask)
+        if src["alt"]:
+            return (g_net0.clone(), g_inp.clone(), None, None, None, src["g_f1"], *src["g_f2"])
+        return (g_net0.clone(), g_inp.clone(), None, None, None, None, *src["g_vols"])
+
+
+def get_engine(net, B: int, H: int, W: int, device) -> RaftUpdateEngine:
+    from .flownetc_engine import _weights_stamp
+    key = (int(B), int(H), int(W), str(torch.device(device)))
+    cache = net.__dict__.setdefault("_ufr_head_engines", {})
+    stamp = _weights_stamp(net)
+    eng = cache.get(key)
+    if eng is None or eng.weights_stamp != stamp:
+        eng = cache[key] = RaftUpdateEngine(net, B, H, W, device)
+        eng.weights_stamp = stamp
+    return eng
+
+
+def refine(net, net0, inp, corr_fn, H: int, W: int):
+    """(flow at 1/8 resolution, up_mask) of the 12 iterations on the engine; corr_fn = the AlternateCorrBlock / CorrBlock the
+    reference's loop would call (its operands are taken, its per-iteration autograd Functions are not used)."""
+    eng = get_engine(net, net0.shape[0], H, W, net0.device)
+    from .flownets.raft_corr import AlternateCorrBlock
+    if isinstance(corr_fn, AlternateCorrBlock):
+        dim = corr_fn._f1.shape[3]
+        return _RaftRefine.apply(net0, inp, eng, True, 1.0 / math.sqrt(dim), corr_fn._f1, *corr_fn._f2)
+    return _RaftRefine.apply(net0, inp, eng, False, 1.0, None, *[v.contiguous() for v in corr_fn.corr_pyramid])
