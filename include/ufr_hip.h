@@ -250,6 +250,25 @@ int ufr_gru_blend_cm_backward(const float* q, const float* z, const void* h, lon
 int ufr_gru_gates_cm_backward(const float* zr, const void* h, long h_plane_stride, int h_chunk0, const float* g_z, const float* g_rh,
                               void* gzr, long gzr_plane_stride, int gzr_chunk0, float* g_h, long M, int chunks, ufr_stream_t stream);
 
+/* ---- RAFT BasicEncoder: normalisation / ReLU / residual arithmetic between the convolutions (csrc/raft_norm.hip) -----------
+ * replaces nn.InstanceNorm2d / nn.BatchNorm2d (eval) + ReLU + the residual add of models/raft/extractor.py:5-78, :142-215 on
+ * x = float32 [chunks][n*HW][32] (a convolution's output, ufr_igemm out_f32) and activation planes:
+ *   ufr_cm_norm_stats: stats[(image * C + c) * 2 + {0,1}] = mean, 1 / sqrt(var + eps) over the image's HW pixels (biased
+ *     variance; float64 partial sums in `workspace`, ufr_cm_norm_workspace_doubles() doubles);
+ *   ufr_cm_norm_apply: out planes = relu2(res + relu1((x - mean) * rstd)); stats NULL = identity (BatchNorm folded into the
+ *     convolution), res NULL = no residual;
+ *   ufr_cm_norm_backward: gz planes = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = G * [outmask > 0] * [xhat > 0 if relu1]
+ *     (G float32 chunk-major; outmask = plane 0 of the block's output, NULL = none; stats NULL = no statistics terms);
+ *   ufr_cm_masked_copy: out = G * [mask > 0] over `elems` float32 elements (the skip connection's share). */
+long ufr_cm_norm_workspace_doubles(long HW, int n, int chunks);
+int ufr_cm_norm_stats(const float* x, float* stats, double* workspace, long HW, int n, int chunks, float eps, ufr_stream_t stream);
+int ufr_cm_norm_apply(const float* x, const float* stats, const void* res, long res_plane_stride, int res_chunk0, void* out,
+                      long out_plane_stride, int out_chunk0, long HW, int n, int chunks, int relu1, int relu2, ufr_stream_t stream);
+int ufr_cm_norm_backward(const float* x, const float* G, const void* outmask, int mask_chunk0, const float* stats, float* sums,
+                         double* workspace, void* gz, long gz_plane_stride, int gz_chunk0, long HW, int n, int chunks, int relu1,
+                         ufr_stream_t stream);
+int ufr_cm_masked_copy(const float* G, const void* outmask, long mask_elem_offset, float* out, long elems, ufr_stream_t stream);
+
 /* ---- PWC-Net backward warp ----------------------------------------------------------------------
  * replaces PWCDCNet.warp (models/PWCNet.py:164-204): grid from the flow (normalised with W-1, sampled with
  * align_corners=False, as the reference does), bilinear grid_sample with zero padding, times the validity mask

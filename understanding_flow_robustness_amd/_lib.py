@@ -141,6 +141,10 @@ SIGNATURES = {
     "ufr_flow_head_planes_forward_mfma": [_vp, _l, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ufr_deconv_flow_tail_backward_mfma": [_vp, _l, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_flow_head_planes_backward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "ufr_cm_norm_stats": [_vp, _vp, _vp, _l, _i, _i, _f, _vp],
+    "ufr_cm_norm_apply": [_vp, _vp, _vp, _l, _i, _vp, _l, _i, _l, _i, _i, _i, _i, _vp],
+    "ufr_cm_norm_backward": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _l, _i, _l, _i, _i, _i, _vp],
+    "ufr_cm_masked_copy": [_vp, _vp, _l, _vp, _l, _vp],
     "ufr_raft_flow_patches": [_vp, _vp, _l, _i, _i, _i, _i, _vp],
     "ufr_raft_motion_finish": [_vp, _l, _vp, _l, _i, _vp, _i, _i, _i, _vp],
     "ufr_gru_gates_cm_forward": [_vp, _vp, _l, _i, _vp, _l, _i, _l, _i, _vp],
@@ -169,6 +173,7 @@ SIGNATURES = {
 PLAIN = {"ufr_abi_version": (C.c_int, []), "ufr_last_error": (C.c_char_p, []),
          "ufr_device_count": (C.c_int, []),
          "ufr_conv3x3_c2_workspace_floats": (C.c_long, [_i, _i, _i, _i]),
+         "ufr_cm_norm_workspace_doubles": (C.c_long, [_l, _i, _i]),
          "ufr_altcorr_pyramid_workspace_bytes": (C.c_long, [_i, _i, _i, _i, _i, _i])}
 
 

@@ -75,11 +75,25 @@ class BasicEncoder(nn.Module):
                 if m.bias is not None:
                     nn.init.constant_(m.bias, 0)
 
+    def _engine_ok(self, x) -> bool:
+        """raft_encoder_engine.py serves the attack's configuration: eval mode, frozen parameters, HIP float32 frames whose sides
+        are multiples of 8, instance or (eval) batch normalisation (UFR_ENGINE=0 switches it off)."""
+        import os
+        if os.environ.get("UFR_ENGINE", "1") != "1" or self.training or self.norm_fn not in ("instance", "batch"):
+            return False
+        frozen = not any(p.requires_grad for p in self.parameters())
+        return (x.is_cuda and x.dtype == torch.float32 and (frozen or not torch.is_grad_enabled()) and x.shape[2] % 8 == 0
+                and x.shape[3] % 8 == 0)
+
     def forward(self, x):
         pair = isinstance(x, (tuple, list))
         if pair:
             n = x[0].shape[0]
             x = torch.cat(x, dim=0)
+        if self._engine_ok(x):
+            from ..raft_encoder_engine import encode      # stem, residual stages and head on the native engine
+            x = encode(self, x)
+            return torch.split(x, [n, n], dim=0) if pair else x
         x = self.relu1(self.norm1(self.conv1(x)))
         x = self.conv2(self.layer3(self.layer2(self.layer1(x))))
         if self.training and self.dropout is not None:
