@@ -96,7 +96,7 @@ class FlowNetCHeadEngine:
         self.g_c3a, self.g_c3a_redir, self.g_c3b = (torch.zeros(B, 256, *g[8], **f32) for _ in range(3))
         self.c3_nchw = torch.zeros(2 * B, 256, *g[8], **f32)        # both frames' conv3 for the correlation kernels
         self._prefix = None                                          # full-frame conv1-3 buffers + launches, built on first use
-        self.flow_out, self.flow_scale = self.flow[2], float(net.div_flow)   # what the step's fused loss kernel reads
+        self.flow_out, self.flow_scale = self.flow[2], float(getattr(net, "div_flow", 20.0))   # what the step's fused loss kernel reads
         self._wprefixes, self._wprefix = {}, None                    # window-prefix state per window size; the one used last
         self._build_launches()
 
