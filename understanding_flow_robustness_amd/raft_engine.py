@@ -20,7 +20,6 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-import os
 
 import torch
 
@@ -107,6 +106,8 @@ class RaftUpdateEngine:
 
         def plan(key, wi, x, in_chunk0, **kw):
             pk = [len(t) * wi.KC for _, _, t in wi.phases]
+            # ping-pong tiles with a deep split (>= 4 K tiles per slice) measured best on these 48 x 160 grids: 18.1 ms per
+            # iteration against 18.4 (>= 8), 19.8 (>= 16), 18.4 with 64 x 128 tiles and 18.6 with single-stage 128 x 128 tiles
             kw.setdefault("variant", 6 if wi.Npad % 128 == 0 else 2)
             bm, target = (256, 256) if kw["variant"] == 6 else (128, 768)
             S = ig.splitk_for(self.M, wi.Npad, max(pk), 1, phase_ktiles=pk, bm=bm, target=target, min_ktiles=4)
