@@ -416,3 +416,38 @@ def test_two_steps_with_different_windows_share_one_engine(net, monkeypatch):
     for _ in range(2):                                            # alternate: each replay must find its own buffers intact
         assert torch.equal(run(small, ops_s), alone_small)
         assert torch.equal(run(large, ops_l), alone_large)
+
+
+def test_one_iteration_of_the_headline_step_equals_the_full_frame_torch_step(net, monkeypatch):
+    """The deterministic half of parity, checked strictly: ONE iteration of the benchmark's step (8 pairs, 384x1280, 128x128
+    window, 608-pixel band, engine, HIP graph) against the full-frame torch / MIOpen step (no window, no band, eager) with the
+    patch at the four corners, two edges and two overlapping placements.  After one iteration no LeakyReLU can have flipped
+    on a state difference: the two gradients differ by float32 rounding only."""
+    from understanding_flow_robustness_amd.patch_attack import PatchAttackStep
+    from test_flownetc_gpu import EDGE_PLACEMENTS
+    B, H, W = 8, 384, 1280
+    g = torch.Generator().manual_seed(31)
+    tgt, ref = torch.rand(B, 3, H, W, generator=g).to(DEV), torch.rand(B, 3, H, W, generator=g).to(DEV)
+    target = torch.randn(B, 2, H, W, generator=g).to(DEV)
+    yy, xx = torch.meshgrid(torch.arange(51), torch.arange(51), indexing="ij")
+    mask_p = (((yy - 25) ** 2 + (xx - 25) ** 2) <= 23 ** 2).float().expand(1, 3, 51, 51).contiguous().to(DEV)
+    patch0 = torch.rand(1, 3, 51, 51, generator=g).to(DEV)
+
+    def run(engine, cone, lr, graph):
+        monkeypatch.setenv("UFR_ENGINE", "1" if engine else "0")
+        args = Namespace(flownet="FlowNetC", l2=False, alpha=0.0, lr=lr, max_count=1)
+        step = PatchAttackStep(net, args, B, H, W, device=DEV, patch_hw=(51, 51), use_cone=cone, use_graph=graph)
+        step.load(tgt, ref, patch0, mask_p, patch0, target, origins=EDGE_PLACEMENTS)
+        n, loss = step.run(1)
+        return step, step.patch.clone(), n, loss
+
+    _, probe, _, _ = run(False, False, 1.0, False)
+    lr = 0.5 / float((probe - patch0).abs().max())
+    _, pf, nf, lf = run(False, False, lr, False)
+    step, pe, ne, le = run(True, True, lr, True)
+    assert step.cone is not None and step.eng is not None and step.band.width == 608 and step.graph is not None
+    upd = float((pf - patch0).abs().max())
+    err = float((pf - pe).abs().max())
+    print(f"one iteration, 8 edge / corner / overlapping placements: engine step vs full-frame torch step {err / upd:.2e} of the update")
+    assert nf == ne == 1 and abs(lf - le) <= 1e-5 and 0.3 < upd < 1.9
+    assert err <= 1e-5 * upd                               # (measured 8e-7)

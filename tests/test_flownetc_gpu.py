@@ -385,18 +385,25 @@ def test_attack_full_size_properties(net):
     assert float((outs[0][0] - patch).abs().max()) > 0
 
 
+# placements that exercise every clipping case of the windowed step: the four corners, two edges, and two pairs whose
+# windows overlap each other's columns (the band's origin table is per pair)
+EDGE_PLACEMENTS = [(0, 0), (333, 1229), (0, 1229), (333, 0), (170, 0), (0, 600), (150, 600), (160, 615)]
+
+
 @pytest.mark.timeout(1500)
-def test_headline_configuration_vs_cpu_oracle(net, sd, oracle):
+@pytest.mark.parametrize("seed,case", [(2, "interior"), (5, "edges")])
+def test_headline_configuration_vs_cpu_oracle(net, sd, oracle, seed, case):
     """The benchmark's own configuration -- 8 pairs at 384x1280 behind one 51x51 circular patch, windowed prefix,
     column band, incremental head forward, captured graphs, 2 iterations -- against the CPU oracle's
-    `patch_attack_placed` (minutes of CPU work, once): patch pixels to 1e-4 relative."""
+    `patch_attack_placed` (minutes of CPU work, once per case): patch pixels to 1e-4 relative.  Two seeds: the bench's interior
+    placements, and placements at the frame's corners / edges with overlapping windows."""
     from oracle import flow_oracle as fo
     from understanding_flow_robustness_amd.patch_attack import PatchAttackStep
     torch.set_num_threads(min(16, torch.get_num_threads()))
     B, H, W = 8, 384, 1280
-    g = torch.Generator().manual_seed(2)
+    g = torch.Generator().manual_seed(seed)
     tgt, ref = torch.rand(B, 3, H, W, generator=g), torch.rand(B, 3, H, W, generator=g)
-    origins, mask_p = _bench_placements(B, H, W), _disc()
+    origins, mask_p = (_bench_placements(B, H, W) if case == "interior" else EDGE_PLACEMENTS), _disc()
     patch0 = torch.rand(1, 3, 51, 51, generator=g)
     predict = lambda a, b: fo.flownetc_forward(sd, a, b)
     with torch.no_grad():

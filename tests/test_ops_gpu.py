@@ -363,3 +363,52 @@ def test_channelnorm_module_autograd(ops):
     y.sum().backward()
     ref = x.detach() / (x.detach().pow(2).sum(1, keepdim=True).sqrt() + 1e-9)
     assert_close(x.grad, ref, rtol=1e-5, atol_scale=1e-6)
+
+
+def test_resample2d_and_channelnorm_independent_pins_at_full_size(ops):
+    """Parity of these two operators is UNPINNED BY THE REFERENCE (CUDA-only there, no vectors; the oracle is a literal
+    restatement).  An independent pin for the forward at config C5's size, 448x1024: where every sample and its +1
+    neighbour stay inside the image, Resample2d (resample2d_kernel.cu:15-72) is the bilinear gather that torch's
+    grid_sample(align_corners=True) computes, and ChannelNorm (channelnorm_kernel.cu:18-60) is x.norm(dim=1); the adjoints
+    against autograd of those spellings on the same samples."""
+    B, C, H, W = 2, 3, 448, 1024
+    g = torch.Generator().manual_seed(448)
+    img = torch.rand(B, C, H, W, generator=g).to(DEV)
+    flow = (6.0 * torch.rand(B, 2, H, W, generator=g) - 3.0).to(DEV)
+    ys, xs = torch.meshgrid(torch.arange(H, device=DEV), torch.arange(W, device=DEV), indexing="ij")
+    sx, sy = xs[None] + flow[:, 0], ys[None] + flow[:, 1]
+    inside = ((sx >= 0) & (sx <= W - 2) & (sy >= 0) & (sy <= H - 2)).unsqueeze(1)          # no clamped corner, no int()-vs-floor() case
+    assert float(inside.float().mean()) > 0.97
+    # (grid_sample in float64: its normalised-coordinate round trip costs 1e-4 px in float32, the kernel samples at x + flow)
+    img_r, flow_r = img.double().requires_grad_(True), flow.double().requires_grad_(True)
+    grid = torch.stack((2 * (xs[None] + flow_r[:, 0]) / (W - 1) - 1, 2 * (ys[None] + flow_r[:, 1]) / (H - 1) - 1), -1)
+    want = torch.nn.functional.grid_sample(img_r, grid, mode="bilinear", padding_mode="border", align_corners=True)
+    out = torch.empty(B, C, H, W, device=DEV)
+    ops["rs"].forward(img, flow, out, 1, True)
+    err = float(((out - want.detach()) * inside).abs().max())
+    # the reference forms x + flow in float32 (resample2d_kernel.cu:40-41): at x ~ 1000 the fractional weight carries up to
+    # half an ulp(1024) = 6e-5 of error against exact arithmetic -- the operator's own rounding, reproduced bit for bit by
+    # the kernel and the oracle alike; a wrong corner or weight is off by O(0.1)
+    assert err <= 1.5e-4, f"Resample2d vs grid_sample on in-range samples: {err:.2e}"
+    go = torch.randn(B, C, H, W, generator=g).to(DEV) * inside
+    gi_ref, gf_ref = torch.autograd.grad(want, (img_r, flow_r), go.double())
+    g1, g2 = torch.empty(B, C, H, W, device=DEV), torch.empty(B, 2, H, W, device=DEV)
+    ops["rs"].backward(img, flow, go, g1, g2, 1, True)
+    assert_close(g1, gi_ref, rtol=1e-3, atol_scale=2e-4, what="Resample2d image adjoint vs grid_sample's")
+    # d / d flow is piecewise constant per bilinear cell: a sample within float32 rounding of an integer coordinate lies in the
+    # neighbouring cell for one of the two evaluations
+    frac = lambda v: (v - v.floor())
+    smooth = inside & ((frac(sx) > 1e-3) & (frac(sx) < 1 - 1e-3) & (frac(sy) > 1e-3) & (frac(sy) < 1 - 1e-3)).unsqueeze(1)
+    assert float(smooth.float().mean()) > 0.96
+    assert_close(g2 * smooth, gf_ref * smooth, rtol=1e-3, atol_scale=2e-4, what="Resample2d flow adjoint vs grid_sample's")
+    x = torch.randn(B, C, H, W, generator=g).to(DEV)
+    outn = torch.empty(B, 1, H, W, device=DEV)
+    ops["cn"].forward(x, outn, 2)
+    xr = x.clone().requires_grad_(True)
+    wantn = xr.norm(dim=1, keepdim=True)
+    assert_close(outn, wantn.detach(), rtol=1e-6, atol_scale=1e-7, what="ChannelNorm vs x.norm(dim=1)")
+    gon = torch.randn(B, 1, H, W, generator=g).to(DEV)
+    (gn_ref,) = torch.autograd.grad(wantn, xr, gon)
+    gin = torch.empty(B, C, H, W, device=DEV)
+    ops["cn"].backward(x, outn, gon, gin, 2)
+    assert_close(gin, gn_ref, rtol=1e-5, atol_scale=1e-6, what="ChannelNorm adjoint vs autograd of x.norm(dim=1)")
