@@ -318,6 +318,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-full-frame", action="store_true", help="skip the full-frame side measurement")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the live side measurements of configs C3 / C4 / C5")
     ap.add_argument("--max-count", type=int, default=2, help="iterations per attack() call (main.py:79)")
     opt = ap.parse_args()
 
@@ -465,7 +466,13 @@ def main():
                                     "peak_note": "fp32-equivalent: 2.5 PFLOP/s dense bf16 MFMA / 6 products per float32 product",
                                     "step": step_line}
             line["roofline"]["kernels"] = kernels
-            line["config"]["other_configs"] = _pmc("r2_configs.json") or None
+            if not opt.no_other_configs:
+                # the other BASELINE configs, one GPU's share each, measured live in this very process (steady-state inner
+                # loop of their own step + the rooflines of their igemm launches): C4 PWC-Net, C3 RAFT with alt_cuda_corr,
+                # C5 FlowNet2's universal-perturbation step (tools/bench_configs.py measures more: all-pairs RAFT, 8-pair RAFT)
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import bench_configs
+                line["config"]["other_configs"] = [bench_configs.measure(w, 6) for w in ("c4", "c3alt", "c5")]
             if step.cone is not None and not opt.no_full_frame:
                 # the same protocol with every frame-sized shortcut off (UFR_CONE=0): what the windowed prefix,
                 # band and incremental forward are worth, measured in this very process

@@ -21,6 +21,47 @@ from understanding_flow_robustness_amd.universal_perturbation import UniversalPe
 DEV = "cuda:0"
 
 
+PEAK_SPLIT6_TFLOPS = 2500.0 / 6     # bf16 dense MFMA peak / six products per float32 product (csrc/igemm.hip)
+
+
+def event_time(fn, iters=6, warm=1):
+    """Average duration (ms) of `fn` with HIP events on the stream the kernels are launched on."""
+    for _ in range(warm):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    e.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def igemm_roofline(net):
+    """The dominant kernel of a config = csrc/igemm.hip: every prepared launch of every native engine the network's step ran
+    on, timed live with HIP events on the step's own buffers (they hold the last iteration's real activations: zero operands
+    draw less power and clock higher), algorithmic FLOPs 2 * rows * taps * Cin * Cout / the six-product ceiling."""
+    engines = [eng for mod in net.modules() for attr in ("_ufr_head_engines", "_ufr_encoder_engines")
+               for eng in mod.__dict__.get(attr, {}).values()]
+    batch = lambda e: getattr(e, "B", None) or getattr(e, "n", 1)
+    top = max([batch(e) for e in engines] + [1])
+    # (the clean forward that makes the target runs pair by pair on its own one-pair engines: not the step's)
+    tables = [e.launch_table() for e in engines if batch(e) * 2 > top]
+    ms = gflop = 0.0
+    n = 0
+    for table in tables:
+        for row in table:
+            launch, gf = row[-2], row[-1]
+            ms += event_time(launch)
+            gflop += gf
+            n += 1
+    if not n:
+        return None
+    return dict(bound="mfma", kernel="igemm (csrc/igemm.hip), every prepared launch of the config's engines, run once each",
+                achieved=round(gflop / ms, 1), peak=round(PEAK_SPLIT6_TFLOPS, 1), unit="TFLOP/s", frac=round(gflop / ms / PEAK_SPLIT6_TFLOPS, 3),
+                launches=n, ms=round(ms, 3), algorithmic_gflop=round(gflop, 1), traffic=None)
+
+
 def timed(step, steps):
     step.enqueue(2)
     torch.cuda.synchronize()
@@ -53,7 +94,7 @@ def patch_case(name, flownet, seed, B, H, W, steps, **extra):
     ms = timed(step, steps)
     mem = torch.cuda.max_memory_allocated() / 2 ** 30
     return dict(config=name, pairs=B, ms_per_iteration=round(ms, 3), attack_iters_per_s=round(B * 1e3 / ms, 2),
-                peak_mem_gib=round(mem, 2))
+                peak_mem_gib=round(mem, 2), roofline=igemm_roofline(net))
 
 
 def universal_case(steps):
@@ -75,7 +116,30 @@ def universal_case(steps):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / steps
     return dict(config="c5 FlowNet2 448x1024 universal perturbation step", pairs=B, ms_per_iteration=round(ms, 3),
-                attack_iters_per_s=round(B * 1e3 / ms, 2), peak_mem_gib=round(torch.cuda.max_memory_allocated() / 2 ** 30, 2))
+                attack_iters_per_s=round(B * 1e3 / ms, 2), peak_mem_gib=round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+                roofline=igemm_roofline(net))
+
+
+def measure(which, steps=10):
+    torch.cuda.reset_peak_memory_stats()
+    if which == "c2":
+        r = patch_case("c2 FlowNetC 384x1280 patch attack", "FlowNetC", 0, 8, 384, 1280, steps)
+    elif which == "c2b1":                   # the reference's own batch size (train() attacks one pair per loader item)
+        r = patch_case("c2 FlowNetC 384x1280 patch attack, 1 pair (the reference's batch size)", "FlowNetC", 0, 1, 384, 1280, steps)
+    elif which == "c3":
+        r = patch_case("c3 RAFT 384x1280 all-pairs, 12 GRU iterations, patch attack", "RAFT", 2, 1, 384, 1280, steps)
+    elif which == "c3alt":
+        r = patch_case("c3 RAFT 384x1280 alt_cuda_corr, 12 GRU iterations, patch attack", "RAFT", 2, 1, 384, 1280, steps,
+                       alternate_corr=True)
+    elif which in ("c3b8", "c3altb8"):      # the same RAFT step with 8 pairs behind one patch (batch extension)
+        r = patch_case(f"c3 RAFT 384x1280 {'alt_cuda_corr' if 'alt' in which else 'all-pairs'}, 12 GRU iterations, "
+                       "patch attack, 8 pairs", "RAFT", 2, 8, 384, 1280, steps, alternate_corr="alt" in which)
+    elif which == "c4":
+        r = patch_case("c4 PWC-Net 384x1280 patch attack", "PWCNet", 1, 8, 384, 1280, steps)
+    else:
+        r = universal_case(steps)
+    torch.cuda.empty_cache()
+    return r
 
 
 def main():
@@ -85,25 +149,7 @@ def main():
     opt = ap.parse_args()
     torch.backends.cudnn.benchmark = True
     for w in opt.which:
-        torch.cuda.reset_peak_memory_stats()
-        if w == "c2":
-            r = patch_case("c2 FlowNetC 384x1280 patch attack", "FlowNetC", 0, 8, 384, 1280, opt.steps)
-        elif w == "c2b1":                   # the reference's own batch size (train() attacks one pair per loader item)
-            r = patch_case("c2 FlowNetC 384x1280 patch attack, 1 pair (the reference's batch size)", "FlowNetC", 0, 1, 384, 1280, opt.steps)
-        elif w == "c3":
-            r = patch_case("c3 RAFT 384x1280 all-pairs, 12 GRU iterations, patch attack", "RAFT", 2, 1, 384, 1280, opt.steps)
-        elif w == "c3alt":
-            r = patch_case("c3 RAFT 384x1280 alt_cuda_corr, 12 GRU iterations, patch attack", "RAFT", 2, 1, 384, 1280,
-                           opt.steps, alternate_corr=True)
-        elif w in ("c3b8", "c3altb8"):      # the same RAFT step with 8 pairs behind one patch (batch extension)
-            r = patch_case(f"c3 RAFT 384x1280 {'alt_cuda_corr' if 'alt' in w else 'all-pairs'}, 12 GRU iterations, "
-                           "patch attack, 8 pairs", "RAFT", 2, 8, 384, 1280, opt.steps, alternate_corr="alt" in w)
-        elif w == "c4":
-            r = patch_case("c4 PWC-Net 384x1280 patch attack", "PWCNet", 1, 8, 384, 1280, opt.steps)
-        else:
-            r = universal_case(opt.steps)
-        print(json.dumps(r), flush=True)
-        torch.cuda.empty_cache()
+        print(json.dumps(measure(w, opt.steps)), flush=True)
 
 
 if __name__ == "__main__":

@@ -26,7 +26,7 @@ for step in "$@"; do
     bench)   timeout -k 10 900 python bench.py $arg > $out/bench.json 2> $out/bench.err; rc=$?
              [ $rc -ne 0 ] && { tail -n 20 $out/bench.err; exit $rc; }
              python tools/summarize_bench.py $out/bench.json ;;
-    stats)   (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/stats -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-full-frame $arg > $GRAFT_REPO_ROOT/$out/stats_bench.json 2> $GRAFT_REPO_ROOT/$out/stats.err); rc=$?
+    stats)   (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/stats -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-full-frame --no-other-configs $arg > $GRAFT_REPO_ROOT/$out/stats_bench.json 2> $GRAFT_REPO_ROOT/$out/stats.err); rc=$?
              [ $rc -ne 0 ] && { tail -n 20 $out/stats.err; exit $rc; }
              f=$(find $out/stats -name "*kernel_stats.csv" | head -n 1); ft=$(find $out/stats -name "*kernel_trace.csv" | head -n 1)
              [ -n "$f" ] && python tools/summarize_stats.py $f 25 > $out/kernel_stats.md && head -n 14 $out/kernel_stats.md
