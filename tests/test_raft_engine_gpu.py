@@ -60,3 +60,54 @@ def test_encoder_engine_matches_the_torch_encoder(raft, monkeypatch, which, n, H
           f"torch fp32 {_rel(g0, g64):.2e} (vs float64); engine vs torch {_rel(g1, g0):.2e}")
     assert _rel(y1, y64) <= max(3 * _rel(y0, y64), 2e-6)
     assert _rel(g1, g64) <= max(3 * _rel(g0, g64), 2e-5)
+
+
+@pytest.mark.parametrize("alternate", [True, False])
+def test_raft_attack_at_full_size_engine_vs_torch_spelling(raft, monkeypatch, alternate, oracle):
+    """Config C3 as BASELINE states it: attack() on RAFT at 384x1280 with alt_cuda_corr (and the all-pairs volume), ONE
+    iteration, everything on the native engines (encoders, lookups on the matrix cores, the 12-iteration refinement, convex
+    upsampling) against (a) the same step with UFR_ENGINE=0 -- the torch / MIOpen spelling of the same modules on this device --
+    and (b) the float64 evaluation of the oracle's RAFT on this device, the conditioning-free truth: RAFT's image gradient
+    loses ~1e-3 .. 1e-2 in float32 (tests/test_models_gpu.py), so the gate is the truth, with the torch spelling as yardstick."""
+    from oracle import flow_oracle as fo
+    from understanding_flow_robustness_amd.patch_attack import PatchAttackStep
+    net, _ = raft
+    H, W = 384, 1280
+    g = torch.Generator().manual_seed(17)
+    tgt, ref = torch.rand(1, 3, H, W, generator=g).to(DEV), torch.rand(1, 3, H, W, generator=g).to(DEV)
+    target = torch.randn(1, 2, H, W, generator=g).to(DEV)
+    mask = torch.zeros(1, 3, H, W, device=DEV)
+    mask[:, :, 100:151, 600:651] = 1
+    patch0 = torch.rand(1, 3, H, W, generator=g).to(DEV) * mask
+
+    def run(engine, lr):
+        monkeypatch.setenv("UFR_ENGINE", "1" if engine else "0")
+        args = Namespace(flownet="RAFT", l2=False, alpha=0.0, lr=lr, max_count=1, alternate_corr=alternate, mixed_precision=False)
+        net.args.alternate_corr = alternate
+        step = PatchAttackStep(net, args, 1, H, W, device=DEV, use_graph=engine)
+        step.load(tgt, ref, patch0, mask, patch0, target)
+        n, loss = step.run(1)
+        return step.patch.clone(), n, loss
+
+    probe, _, _ = run(False, 1.0)
+    lr = 0.5 / float(((probe - patch0) * mask).abs().max())
+    pf, nf, lf = run(False, lr)
+    pe, ne, le = run(True, lr)
+    engines = [e for m in net.modules() for a in ("_ufr_head_engines", "_ufr_encoder_engines") for e in m.__dict__.get(a, {}).values()]
+    assert len(engines) >= 3, "the engines (two encoders + the refinement loop) did not run"
+    # float64 truth of the same iteration (main.py:546-600 for one pair: paste, forward, loss, gradient, clamped step)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in net.state_dict().items()}
+    m64 = mask.double()
+    adv_t = ((1 - m64) * tgt.double() + m64 * patch0.double()).requires_grad_(True)
+    adv_r = ((1 - m64) * ref.double() + m64 * patch0.double()).requires_grad_(True)
+    flow64 = fo.raft_forward(sd64, adv_t * 255.0, adv_r * 255.0)[1]
+    g_t, g_r = torch.autograd.grad(fo.flow_loss(flow64, target.double()), (adv_t, adv_r))
+    truth = patch0.double() - torch.clamp(0.5 * lr * (g_t + g_r), -2.0, 2.0)
+    upd = float(((truth - patch0) * mask).abs().max())
+    e_eng = float(((pe - truth) * mask).abs().max()) / upd
+    e_torch = float(((pf - truth) * mask).abs().max()) / upd
+    e_same = float(((pf - pe) * mask).abs().max()) / upd
+    print(f"RAFT alt={alternate} 384x1280, one iteration, of the update: engines vs float64 {e_eng:.2e}, torch spelling vs float64 "
+          f"{e_torch:.2e}, engines vs torch spelling {e_same:.2e}; loss {lf:.6f} / {le:.6f}")
+    assert nf == ne == 1 and abs(lf - le) <= 1e-5 and 0.3 < upd < 1.9
+    assert e_eng <= max(1.5 * e_torch, 1e-3) and e_same <= 1e-2

@@ -6,7 +6,8 @@
 #   tests:<a,b,..>   python -m pytest a b .. -q -x   (commas separate the words of a step's argument)
 #   bench[:flags]    python bench.py <flags>
 #   stats[:flags]    rocprofv3 --kernel-trace --stats of bench.py <flags> + the summaries under the same directory
-#   trace:<tag>,<iters>,<script>,<args>   rocprofv3 --kernel-trace of a python tool + steady-state table (tools/summarize_trace.py)
+#   trace:<tag>,<iters>,<script>,<args>   rocprofv3 --kernel-trace of a python tool + steady-state table (tools/summarize_trace.py;
+#                    env:TRACE_MARKER=<kernel> names the last kernel of an iteration, default gate_kernel)
 #   configs:<list>   tools/bench_configs.py <list>
 #   py:<script args> python <script args>
 set -o pipefail
@@ -37,7 +38,7 @@ for step in "$@"; do
              (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/trace_$tag -- python $GRAFT_REPO_ROOT/$1 "${@:2}" > $GRAFT_REPO_ROOT/$out/trace_$tag.log 2>&1); rc=$?
              [ $rc -ne 0 ] && { tail -n 20 $out/trace_$tag.log; exit $rc; }
              ft=$(find $out/trace_$tag -name "*kernel_trace.csv" | head -n 1)
-             [ -n "$ft" ] && python tools/summarize_trace.py $ft $iters > $out/${tag}_step_trace.md && sed -n "1,/^last iteration/p" $out/${tag}_step_trace.md | head -n 45
+             [ -n "$ft" ] && python tools/summarize_trace.py $ft $iters ${TRACE_MARKER:-gate_kernel} > $out/${tag}_step_trace.md && sed -n "1,/^last iteration/p" $out/${tag}_step_trace.md | head -n 45
              rm -rf $out/trace_$tag ;;
     configs) timeout -k 10 1100 python tools/bench_configs.py $arg > $out/configs.log 2>&1; rc=$?; tail -n 12 $out/configs.log
              [ $rc -ne 0 ] && exit $rc ;;
