@@ -17,12 +17,26 @@ PEAK = 8000.0
 
 
 def timed(fn, iters=30):
+    """Average duration (ms) of `fn`: `iters` calls captured in ONE HIP graph and replayed between two events, so that the
+    figure is kernel time (round 2 timed an eager loop: for 7 us kernels behind an autograd Function that measured the host,
+    ~77 us per call, not the kernels)."""
     for _ in range(3):
         fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        fn()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(iters):
+                fn()
+    torch.cuda.current_stream().wait_stream(side)
+    graph.replay()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(iters):
-        fn()
+    graph.replay()
     e.record()
     e.synchronize()
     return s.elapsed_time(e) / iters
@@ -71,9 +85,9 @@ def main():
     from understanding_flow_robustness_amd import alt_cuda_corr
     from understanding_flow_robustness_amd.flownets import raft as R
     from understanding_flow_robustness_amd.flownets.raft_corr import CorrBlock
-    B, H, W, C, r = 1, 48, 160, 256, 4
+    B, H, W, C_, r = 1, 48, 160, 256, 4
     cfg = "RAFT 384x1280, 1 pair"
-    f1, f2 = rnd(B, C, H, W), rnd(B, C, H, W)
+    f1, f2 = rnd(B, C_, H, W), rnd(B, C_, H, W)
     xs = torch.arange(W).float().view(1, 1, 1, W).expand(B, 1, H, W)
     ys = torch.arange(H).float().view(1, 1, H, 1).expand(B, 1, H, W)
     coords = (torch.cat([xs, ys], 1) + 3.0 * torch.randn(B, 2, H, W, generator=g)).to(DEV)
@@ -83,45 +97,79 @@ def main():
     out_bytes = B * 324 * H * W * 4
     gathered = B * H * W * 4 * (2 * r + 2) ** 2 * 4                  # (2r+2)^2 volume cells per pixel and level
     emit("lookup_fwd (4 levels, one call)", cfg, ms, out_bytes + gathered, "bytes = 324-channel output + the (2r+2)^2 cells read per level")
-    vols = [v.clone().requires_grad_(True) for v in blk.get_corr_pyramid()]
-    from understanding_flow_robustness_amd.flownets.raft_corr import corr_lookup
-    y = corr_lookup(vols, coords, r)
-    gy = torch.randn_like(y)
-    ms = timed(lambda: torch.autograd.grad(y, vols, gy, retain_graph=True))
+    import ctypes as C
+    from understanding_flow_robustness_amd.flownets.raft_corr import _levels_struct, _pyramid_struct
+    vols = [v.contiguous() for v in blk.get_corr_pyramid()]
+    gvols = [torch.zeros_like(v) for v in vols]
+    gy = torch.randn(B, 324, H, W, generator=g).to(DEV)
+    pyr = _pyramid_struct(vols, gvols)
+    ms = timed(lambda: L.check(lib.ufr_corr_lookup_backward(C.byref(pyr), L.ptr(coords), L.ptr(gy), B, H, W, r, st())))
     emit("lookup_bwd (4 levels, one call)", cfg, ms, out_bytes + 2 * gathered, "read-modify-write of the touched volume cells")
     f1n, c5 = f1.permute(0, 2, 3, 1).contiguous(), coords.permute(0, 2, 3, 1).reshape(B, 1, H, W, 2).contiguous()
     for lvl in range(4):
-        f2n = rnd(B, H >> lvl, W >> lvl, C)
+        f2n = rnd(B, H >> lvl, W >> lvl, C_)
         cl = (c5 / 2 ** lvl).contiguous()
         (o,) = alt_cuda_corr.forward(f1n, f2n, cl, r)
         go = torch.randn_like(o)
-        win_bytes = B * H * W * (2 * r + 2) ** 2 * C * 4             # every pixel reads its (2r+2)^2 x C window of fmap2 (L2-served)
+        win_bytes = B * H * W * (2 * r + 2) ** 2 * C_ * 4             # every pixel reads its (2r+2)^2 x C window of fmap2 (L2-served)
         ms = timed(lambda: alt_cuda_corr.forward(f1n, f2n, cl, r))
         emit(f"altcorr_fwd level {lvl}", cfg, ms, (f1n.numel() + f2n.numel() + o.numel()) * 4,
              f"HBM-algorithmic bytes; the per-pixel windows re-read {win_bytes / 1e6:.0f} MB through L2")
         ms = timed(lambda: alt_cuda_corr.backward(f1n, f2n, cl, go, r))
         emit(f"altcorr_bwd level {lvl} (both adjoints)", cfg, ms, (2 * f1n.numel() + 2 * f2n.numel() + o.numel()) * 4, "")
+    # the model's form: all four levels of a lookup in one launch per direction on the fp32 matrix cores (raft_altcorr_mfma.hip)
+    from understanding_flow_robustness_amd.flownets.raft_corr import AltCorrPyramidFunction
+    f2s = [rnd(B, H >> lvl, W >> lvl, C_) for lvl in range(4)]
+    scale = 1.0 / 16.0
+    o4 = AltCorrPyramidFunction.apply(f1n, coords, r, scale, None, *f2s)
+    nb_in = (f1n.numel() + sum(f.numel() for f in f2s)) * 4
+    ms = timed(lambda: AltCorrPyramidFunction.apply(f1n, coords, r, scale, None, *f2s))
+    emit("altcorr_mfma_fwd (4 levels, one launch)", cfg, ms, nb_in + o4.numel() * 4, "fmap1 + the four fmap2 levels in, [B,324,H,W] out")
+    g1, g2s, go4 = torch.empty_like(f1n), [torch.empty_like(f) for f in f2s], torch.randn_like(o4)
+    wsb = torch.empty(lib.ufr_altcorr_pyramid_workspace_bytes(B, H, W, C_, r, 4), dtype=torch.uint8, device=DEV)
+    lv = _levels_struct(f2s, g2s)
+    ms = timed(lambda: L.check(lib.ufr_altcorr_pyramid_backward(L.ptr(f1n), C.byref(lv), L.ptr(coords), L.ptr(go4), L.ptr(g1), L.ptr(wsb), B, H, W,
+                                                                C_, r, scale, 0, st())))
+    emit("altcorr_mfma backward (prepass + d/d fmap1 + level sum + d/d fmap2, 4 levels)", cfg, ms, 2 * nb_in + o4.numel() * 4, "")
     hcn = 128
     zr, h = rnd(B, 2 * hcn, H, W), rnd(B, hcn, H, W)
-    out = R._GruGates.apply(zr.requires_grad_(True), h.requires_grad_(True))
-    ms = timed(lambda: R._GruGates.apply(zr, h))
+    z, rh = torch.empty_like(h), torch.empty_like(h)
+    ms = timed(lambda: L.check(lib.ufr_gru_gates_forward(L.ptr(zr), L.ptr(h), L.ptr(z), L.ptr(rh), B, hcn, H * W, hcn * H * W, st())))
     emit("gru_gates_fwd", cfg, ms, (zr.numel() + h.numel() + 2 * h.numel()) * 4)
-    gz, grh = torch.randn_like(out[0]), torch.randn_like(out[1])
-    ms = timed(lambda: torch.autograd.grad(out, (zr, h), (gz, grh), retain_graph=True))
+    gz, grh, gzr, gh = rnd(B, hcn, H, W), rnd(B, hcn, H, W), torch.empty_like(zr), torch.empty_like(h)
+    ms = timed(lambda: L.check(lib.ufr_gru_gates_backward(L.ptr(zr), L.ptr(h), L.ptr(gz), L.ptr(grh), L.ptr(gzr), L.ptr(gh), B, hcn, H * W,
+                                                          hcn * H * W, st())))
     emit("gru_gates_bwd", cfg, ms, (zr.numel() + h.numel() + 2 * h.numel() + zr.numel() + h.numel()) * 4)
-    q, z = rnd(B, hcn, H, W).requires_grad_(True), torch.rand(B, hcn, H, W, generator=g).to(DEV).requires_grad_(True)
-    ob = R._GruBlend.apply(q, z, h)
-    ms = timed(lambda: R._GruBlend.apply(q, z, h))
+    q, zz, ho = rnd(B, hcn, H, W), torch.rand(B, hcn, H, W, generator=g).to(DEV), torch.empty_like(h)
+    ms = timed(lambda: L.check(lib.ufr_gru_blend_forward(L.ptr(q), L.ptr(zz), L.ptr(h), L.ptr(ho), h.numel(), st())))
     emit("gru_blend_fwd", cfg, ms, 4 * h.numel() * 4)
-    gb = torch.randn_like(ob)
-    ms = timed(lambda: torch.autograd.grad(ob, (q, z, h), gb, retain_graph=True))
+    gb, gq, gz2, gh2 = rnd(B, hcn, H, W), torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
+    ms = timed(lambda: L.check(lib.ufr_gru_blend_backward(L.ptr(q), L.ptr(zz), L.ptr(h), L.ptr(gb), L.ptr(gq), L.ptr(gz2), L.ptr(gh2), h.numel(), st())))
     emit("gru_blend_bwd", cfg, ms, 7 * h.numel() * 4)
-    fl, mk = rnd(B, 2, H, W).requires_grad_(True), rnd(B, 576, H, W).requires_grad_(True)
-    up = R._ConvexUpsample.apply(fl, mk)
-    ms = timed(lambda: R._ConvexUpsample.apply(fl, mk))
+    # the engine's chunk-major forms (csrc/raft_update.hip): values in place, r*h / h' as planes
+    from understanding_flow_robustness_amd import igemm as ig
+    M = B * H * W
+    ZR, Q, Pb, Gz, Gh, Grh = ig.GradSum(B, H, W, 8, DEV), ig.GradSum(B, H, W, 4, DEV), ig.Planes(B, H, W, 16, DEV), ig.GradSum(B, H, W, 4, DEV), \
+        ig.GradSum(B, H, W, 4, DEV), ig.GradSum(B, H, W, 4, DEV)
+    gzq, gzrp = ig.Planes(B, H, W, 4, DEV), ig.Planes(B, H, W, 8, DEV)
+    ZR.t.normal_(); Q.t.normal_(); Pb.t.normal_(); Gh.t.normal_(); Grh.t.normal_()
+    ms = timed(lambda: L.check(lib.ufr_gru_gates_cm_forward(L.ptr(ZR.t), L.ptr(Pb.t), Pb.plane_stride, 0, L.ptr(Pb.t), Pb.plane_stride, 12, M, 4, st())))
+    emit("gates_fwd_kernel (chunk-major: zr in place, r*h planes)", cfg, ms, M * 128 * (8 + 8 + 6 + 6))
+    ms = timed(lambda: L.check(lib.ufr_gru_blend_cm_forward(L.ptr(Q.t), L.ptr(ZR.t), L.ptr(Pb.t), Pb.plane_stride, 0, L.ptr(Pb.t), Pb.plane_stride, 4, M,
+                                                            4, st())))
+    emit("blend_fwd_kernel (chunk-major)", cfg, ms, M * 128 * (4 + 4 + 4 + 6 + 6))
+    ms = timed(lambda: L.check(lib.ufr_gru_blend_cm_backward(L.ptr(Q.t), L.ptr(ZR.t), L.ptr(Pb.t), Pb.plane_stride, 0, L.ptr(Gh.t), L.ptr(gzq.t),
+                                                             gzq.plane_stride, 0, L.ptr(Gz.t), L.ptr(Grh.t), M, 4, st())))
+    emit("blend_bwd_kernel (chunk-major)", cfg, ms, M * 128 * (4 + 4 + 6 + 4 + 6 + 4 + 4))
+    ms = timed(lambda: L.check(lib.ufr_gru_gates_cm_backward(L.ptr(ZR.t), L.ptr(Pb.t), Pb.plane_stride, 0, L.ptr(Gz.t), L.ptr(Grh.t), L.ptr(gzrp.t),
+                                                             gzrp.plane_stride, 0, L.ptr(Gh.t), M, 4, st())))
+    emit("gates_bwd_kernel (chunk-major)", cfg, ms, M * 128 * (8 + 6 + 4 + 4 + 12 + 8))
+    fl, mk = rnd(B, 2, H, W), rnd(B, 576, H, W)
+    up = torch.empty(B, 2, 8 * H, 8 * W, device=DEV)
+    ms = timed(lambda: L.check(lib.ufr_convex_upsample_forward(L.ptr(fl), L.ptr(mk), L.ptr(up), B, H, W, st())))
     emit("convex_up_fwd", cfg, ms, (mk.numel() + fl.numel() + up.numel()) * 4)
-    gu = torch.randn_like(up)
-    ms = timed(lambda: torch.autograd.grad(up, (fl, mk), gu, retain_graph=True))
+    gu, gfl, gmk, wsu = torch.randn_like(up), torch.empty_like(fl), torch.empty_like(mk), torch.empty(B, 2, 9, H, W, device=DEV)
+    ms = timed(lambda: L.check(lib.ufr_convex_upsample_backward(L.ptr(fl), L.ptr(mk), L.ptr(gu), L.ptr(gfl), L.ptr(gmk), L.ptr(wsu), B, H, W, st())))
     emit("convex_up_bwd", cfg, ms, (2 * mk.numel() + 2 * fl.numel() + up.numel()) * 4)
 
 
