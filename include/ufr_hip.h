@@ -500,6 +500,11 @@ int ufr_conv1_pack_planes(const float* frames_a, const float* frames_b, void* pl
 /* Adjoint of the packing: d loss / d frames [N, 3, H, W] from the float32 gradient sum of the packed planes
  * [1][N * (H/2 + 3) * (W/2 + 2)][32] (the output of conv1's data-gradient launch). */
 int ufr_conv1_unpack_grad(const float* G, float* grad_frames, int N, int H, int W, ufr_stream_t stream);
+/* 2x2 pixel-unshuffle of x [N,C,2H,2W] into planes [N,H,W] with channel (c*2 + p)*2 + q = x[c, 2y+p, 2x+q] (a stride-2 7x7
+ * convolution becomes a stride-1 4x4 launch over 4C channels: FlowNetS's 12-channel stem, models/flownet2/FlowNetS.py:24), and the
+ * adjoint from the float32 gradient sum G [chunks][N*H*W][32] back to [N,C,2H,2W]. */
+int ufr_unshuffle_pack_planes(const float* x, void* planes, long plane_stride, int N, int C, int H, int W, ufr_stream_t stream);
+int ufr_unshuffle_unpack_grad(const float* G, float* grad_x, int N, int C, int H, int W, ufr_stream_t stream);
 /* NCHW float32 gradient x LeakyReLU'(NCHW activation) -> the engine's gradient planes (three bf16 planes, chunk-major), one pass. */
 int ufr_nchw_grad_to_planes(const float* grad, const float* act, void* planes, long plane_stride, int chunk0, int B, int C, int H,
                             int W, float slope, ufr_stream_t stream);

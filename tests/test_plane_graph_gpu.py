@@ -1,0 +1,108 @@
+"""GPU suite: FlowNet2's remaining sub-networks on the native kernels (plane_graph.py) -- FlowNetSD, FlowNetFusion and the
+conv1-3 prefixes of FlowNetC / FlowNetS (models/flownet2/FlowNetSD.py:12-126, FlowNetFusion.py:12-71, FlowNetS.py:15-104,
+FlowNetC.py:10-131) -- against the torch spelling of the same module with the same weights, both judged against a float64
+evaluation: output and input gradient."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).abs().max()) / float(b.abs().max())
+
+
+def _frozen(m):
+    for p in m.parameters():
+        p.requires_grad_(False)
+    return m.eval().to(DEV)
+
+
+def _realistic(m, seed):
+    """Xavier leaves the 2-channel heads tiny; give every bias and weight a scale that makes each branch matter."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+            else:
+                fan = p[0].numel() if p.dim() == 4 else p.numel()
+                p.copy_(torch.randn(p.shape, generator=g) * (1.6 / fan) ** 0.5)
+    return m
+
+
+def _run(m, x, gy, monkeypatch, engine):
+    monkeypatch.setenv("UFR_ENGINE", "1" if engine else "0")
+    xr = x.clone().requires_grad_(True)
+    out = m(xr)
+    out = out[0] if isinstance(out, tuple) else out
+    (gx,) = torch.autograd.grad(out, xr, gy.to(out.dtype))
+    return out.detach(), gx
+
+
+def _three_way(make, cin, B, H, W, monkeypatch, out_hw, seed):
+    m = _frozen(_realistic(make(), seed))
+    m64 = copy.deepcopy(m).double()
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(B, cin, H, W, generator=g).to(DEV)
+    gy = torch.randn(B, 2, *out_hw, generator=g).to(DEV)
+    want, gwant = _run(m64, x.double(), gy.double(), monkeypatch, False)
+    tout, tg = _run(m, x, gy, monkeypatch, False)
+    nout, ng = _run(m, x, gy, monkeypatch, True)
+    assert "_ufr_plane_graphs" in m.__dict__, "the native schedule did not run"
+    e_out, e_g = _rel(nout, want), _rel(ng, gwant)
+    t_out, t_g = _rel(tout, want), _rel(tg, gwant)
+    print(f"native {e_out:.2e} / {e_g:.2e}   torch {t_out:.2e} / {t_g:.2e}")
+    assert e_out <= 5e-6 and e_g <= 5e-6          # (MIOpen's own data gradient is 4e-3 off at B = 2; the six-product igemm is not)
+    # second call through the cached schedule: same bits
+    nout2, ng2 = _run(m, x, gy, monkeypatch, True)
+    assert torch.equal(nout, nout2) and torch.equal(ng, ng2)
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 64, 128), (2, 128, 192)])
+def test_flownetsd_schedule(B, H, W, monkeypatch):
+    from understanding_flow_robustness_amd.flownets.flownet2 import FlowNetSD
+    _three_way(FlowNetSD, 6, B, H, W, monkeypatch, (H // 4, W // 4), 3)
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 64, 128), (2, 128, 192)])
+def test_flownetfusion_schedule(B, H, W, monkeypatch):
+    from understanding_flow_robustness_amd.flownets.flownet2 import FlowNetFusion
+    _three_way(FlowNetFusion, 11, B, H, W, monkeypatch, (H, W), 5)
+
+
+@pytest.mark.parametrize("cin,B,H,W", [(12, 1, 64, 128), (12, 2, 128, 192), (3, 4, 64, 64)])
+def test_stem_prefix_schedule(cin, B, H, W):
+    """conv1 (7x7 stride 2 as a 16-tap launch over the 2x2-unshuffled frame), conv2, conv3 -> conv2 / conv3 features and the
+    gradient of the frame, vs the three torch convolutions in float64."""
+    from understanding_flow_robustness_amd.flownets.flownet2 import FlowNetS, _prefix_graph
+    from understanding_flow_robustness_amd.plane_graph import run
+    net = _frozen(_realistic(FlowNetS(cin), 7))
+    n64 = copy.deepcopy(net).double()
+    g = torch.Generator().manual_seed(cin + B)
+    x = torch.randn(B, cin, H, W, generator=g).to(DEV)
+    g2 = torch.randn(B, 128, H // 4, W // 4, generator=g).to(DEV)
+    g3 = torch.randn(B, 256, H // 8, W // 8, generator=g).to(DEV)
+    xr = x.clone().requires_grad_(True)
+    c2, c3 = run(_prefix_graph(net, B, H, W, cin, DEV), xr)
+    (gx,) = torch.autograd.grad([c2, c3], xr, [g2, g3])
+    xd = x.double().requires_grad_(True)
+    w2 = n64.conv2(n64.conv1(xd))
+    w3 = n64.conv3(w2)
+    (gwant,) = torch.autograd.grad([w2, w3], xd, [g2.double(), g3.double()])
+    assert _rel(c2, w2) <= 2e-6 and _rel(c3, w3) <= 2e-6 and _rel(gx, gwant) <= 5e-6
+
+
+def test_stale_schedule_backward_raises(monkeypatch):
+    from understanding_flow_robustness_amd.flownets.flownet2 import FlowNetSD
+    monkeypatch.setenv("UFR_ENGINE", "1")
+    m = _frozen(FlowNetSD())
+    x = torch.randn(1, 6, 64, 64, device=DEV, requires_grad=True)
+    (a,) = m(x)
+    m(x.detach().clone().requires_grad_(True))
+    with pytest.raises(RuntimeError, match="another forward"):
+        a.sum().backward()

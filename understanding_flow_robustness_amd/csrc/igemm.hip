@@ -932,6 +932,44 @@ __global__ __launch_bounds__(256) void conv1_unpack_grad_kernel(const float* __r
   }
 }
 
+// 2x2 pixel-unshuffle of x [N, C, 2H, 2W] into planes [N, H, W, 4C channels]: channel (c*2 + p)*2 + q = x[c, 2y + p, 2x + q].  A
+// stride-2 7x7 convolution of x is a stride-1 4x4 one over these planes (FlowNetS's 12-channel stem: 49 taps of one chunk would
+// exceed the tap table, 16 taps of 48 channels do not; plane_graph.py).  Thread = (pixel, 8-channel group).
+__global__ __launch_bounds__(256) void unshuffle_pack_kernel(const float* __restrict__ x, __bf16* __restrict__ planes, long plane_stride,
+                                                             int N, int C, int H, int W, int chunks) {
+  const long M = (long)N * H * W, total = M * chunks * 4;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int g8 = (int)(t % (chunks * 4));
+    const long m = t / (chunks * 4);
+    const int xx = (int)(m % W), yy = (int)((m / W) % H), n = (int)(m / ((long)W * H));
+    bf16x8 q0, q1, q2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ch = g8 * 8 + j, c = ch >> 2, p = (ch >> 1) & 1, q = ch & 1;
+      const float v = c < C ? x[(((long)n * C + c) * (2 * H) + 2 * yy + p) * (2 * W) + 2 * xx + q] : 0.f;
+      __bf16 a, b, d;
+      split3(v, a, b, d);
+      q0[j] = a; q1[j] = b; q2[j] = d;
+    }
+    __bf16* dst = planes + ((long)(g8 >> 2) * M + m) * 32 + (g8 & 3) * 8;
+    *reinterpret_cast<bf16x8*>(dst) = q0;
+    *reinterpret_cast<bf16x8*>(dst + plane_stride) = q1;
+    *reinterpret_cast<bf16x8*>(dst + 2 * plane_stride) = q2;
+  }
+}
+
+// its adjoint: gx[n, c, 2y + p, 2x + q] = G[(c*2 + p)*2 + q] of pixel (n, y, x), G float32 [chunks][M][32]
+__global__ __launch_bounds__(256) void unshuffle_unpack_grad_kernel(const float* __restrict__ G, float* __restrict__ gx, int N, int C, int H,
+                                                                    int W) {
+  const long M = (long)N * H * W, total = (long)N * C * 4 * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % (2 * W)), Y = (int)((i / (2 * W)) % (2 * H)), c = (int)((i / ((long)4 * W * H)) % C), n = (int)(i / ((long)4 * W * H * C));
+    const int ch = (c * 2 + (Y & 1)) * 2 + (X & 1);
+    const long m = ((long)n * H + (Y >> 1)) * W + (X >> 1);
+    gx[i] = G[((long)(ch >> 5) * M + m) * 32 + (ch & 31)];
+  }
+}
+
 // chunk-major tensor (planes: p0 + p1 + p2, or fp32) -> out [B][C][HW] float32 (NCHW), optionally
 // out = scale * leaky'(mask) * v with `mask` = plane 0 of an activation in the same chunk-major geometry.
 __global__ __launch_bounds__(256) void chunks_to_nchw_kernel(const __bf16* __restrict__ planes, long plane_stride,
@@ -1231,6 +1269,20 @@ extern "C" int ufr_conv1_unpack_grad(const float* G, float* grad_frames, int N, 
   const long total = (long)N * 3 * H * W;
   conv1_unpack_grad_kernel<<<ufr::stream_grid(total, 256), 256, 0, ufr::as_stream(stream)>>>(G, grad_frames, N, H, W);
   return ufr::launched("conv1_unpack_grad_kernel");
+}
+
+extern "C" int ufr_unshuffle_pack_planes(const float* x, void* planes, long plane_stride, int N, int C, int H, int W, ufr_stream_t stream) {
+  UFR_REQUIRE(x && planes && N > 0 && C > 0 && H > 0 && W > 0 && plane_stride > 0, "unshuffle pack: bad argument");
+  const int chunks = (4 * C + 31) / 32;
+  unshuffle_pack_kernel<<<ufr::stream_grid((long)N * H * W * chunks * 4, 256), 256, 0, ufr::as_stream(stream)>>>(
+      x, static_cast<__bf16*>(planes), plane_stride, N, C, H, W, chunks);
+  return ufr::launched("unshuffle_pack_kernel");
+}
+
+extern "C" int ufr_unshuffle_unpack_grad(const float* G, float* grad_x, int N, int C, int H, int W, ufr_stream_t stream) {
+  UFR_REQUIRE(G && grad_x && N > 0 && C > 0 && H > 0 && W > 0, "unshuffle unpack: bad argument");
+  unshuffle_unpack_grad_kernel<<<ufr::stream_grid((long)N * C * 4 * H * W, 256), 256, 0, ufr::as_stream(stream)>>>(G, grad_x, N, C, H, W);
+  return ufr::launched("unshuffle_unpack_grad_kernel");
 }
 
 extern "C" int ufr_chunks_to_nchw(const void* planes, long plane_stride, const float* f32, int chunk0, const void* mask,

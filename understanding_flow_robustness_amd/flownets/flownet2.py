@@ -87,8 +87,14 @@ class FlowNetC(_Refinement):
     def forward(self, x):
         B = x.shape[0]
         both = torch.cat((x[:, 0:3], x[:, 3:]), 0)
-        c2 = self.conv2(self.conv1(both))
-        c3 = self.conv3(c2)
+        if _native_ok(self, x):                # conv1-3 of both frames on the igemm too (plane_graph.py)
+            from ..plane_graph import run
+            g = _graph_for(self, ("prefix", 2 * B, x.shape[2], x.shape[3], str(x.device)),
+                           lambda: _prefix_graph(self, 2 * B, x.shape[2], x.shape[3], 3, x.device))
+            c2, c3 = run(g, both)
+        else:
+            c2 = self.conv2(self.conv1(both))
+            c3 = self.conv3(c2)
         c2a, c3a, c3b = c2[:B], c3[:B], c3[B:]
         if self._engine_ok(c2a):
             # the same layers under the same names as flownets/flownetc.py: everything behind conv3 on the native head
@@ -119,6 +125,13 @@ class FlowNetS(_Refinement):
         _xavier(self)
 
     def forward(self, x):
+        if _native_ok(self, x):                # conv1-3 on the igemm (plane_graph.py), everything behind on the native head
+            from ..flownetc_engine import engine_head
+            from ..plane_graph import run
+            g = _graph_for(self, ("prefix", x.shape[0], x.shape[2], x.shape[3], str(x.device)),
+                           lambda: _prefix_graph(self, x.shape[0], x.shape[2], x.shape[3], x.shape[1], x.device))
+            c2, c3 = run(g, x)
+            return (engine_head(self, c2.contiguous(), c3.contiguous(), None),)
         c2 = self.conv2(self.conv1(x))
         if self._engine_ok(c2):                # everything behind conv3 on the native head (trunk form: no correlation)
             from ..flownetc_engine import engine_head
@@ -195,6 +208,11 @@ class FlowNetSD(nn.Module):
         _xavier(self)
 
     def forward(self, x):
+        if _native_ok(self, x):                # the whole sub-network as one schedule on the native kernels (plane_graph.py)
+            from ..plane_graph import run
+            g = _graph_for(self, (x.shape[0], x.shape[2], x.shape[3], str(x.device)),
+                           lambda: _sd_graph(self, x.shape[0], x.shape[2], x.shape[3], x.device))
+            return (run(g, x)[0],)
         c0 = self.conv0(x)
         c1 = self.conv1_1(self.conv1(c0))
         c2 = self.conv2_1(self.conv2(c1))
@@ -227,6 +245,11 @@ class FlowNetFusion(nn.Module):
         _xavier(self)
 
     def forward(self, x):
+        if _native_ok(self, x):
+            from ..plane_graph import run
+            g = _graph_for(self, (x.shape[0], x.shape[2], x.shape[3], str(x.device)),
+                           lambda: _fusion_graph(self, x.shape[0], x.shape[2], x.shape[3], x.device))
+            return run(g, x)[0]
         c0 = self.conv0(x)
         c1 = self.conv1_1(self.conv1(c0))
         c2 = self.conv2_1(self.conv2(c1))
@@ -235,6 +258,108 @@ class FlowNetFusion(nn.Module):
         flow1 = self.predict_flow1(self.inter_conv1(cat1))
         cat0 = torch.cat((c0, self.deconv0(cat1), self.upsampled_flow1_to_0(flow1)), 1)
         return self.predict_flow0(self.inter_conv0(cat0))
+
+
+def _graph_for(module, key, build):
+    """One PlaneGraph per (batch, frame size, device), cached on the module; rebuilt when its weights changed since."""
+    from ..flownetc_engine import _weights_stamp
+    cache = module.__dict__.setdefault("_ufr_plane_graphs", {})
+    stamp = _weights_stamp(module)
+    g = cache.get(key)
+    if g is None or g.weights_stamp != stamp:
+        g = cache[key] = build()
+        g.weights_stamp = stamp
+    return g
+
+
+def _native_ok(module, x) -> bool:
+    """plane_graph.py serves the attack's configuration: frozen parameters, eval mode, HIP float32, sides multiples of 64."""
+    import os
+    if os.environ.get("UFR_ENGINE", "1") != "1" or module.training:
+        return False
+    frozen = not any(p.requires_grad for p in module.parameters())
+    return (x.is_cuda and x.dtype == torch.float32 and (frozen or not torch.is_grad_enabled()) and x.shape[2] % 64 == 0
+            and x.shape[3] % 64 == 0)
+
+
+def _prefix_graph(net, n, H, W, cin, dev):
+    """conv1 (7x7 / 2 over the 2x2-unshuffled input), conv2, conv3 (5x5 / 2) of FlowNetC / FlowNetS -> conv2 and conv3 as NCHW."""
+    from ..plane_graph import PlaneGraph
+    g = PlaneGraph(n, dev)
+    g.buffer("pin", H // 2, W // 2, (4 * cin + 31) // 32)
+    g.buffer("c1", H // 2, W // 2, 2)
+    g.buffer("c2", H // 4, W // 4, 4)
+    g.buffer("c3", H // 8, W // 8, 8)
+    g.input_packed12("pin", cin)
+    c1, c2, c3 = net.conv1[0], net.conv2[0], net.conv3[0]
+    g.conv(c1.weight, c1.bias, ("pin", 0, (4 * cin + 31) // 32), ("c1", 0), taps_unshuffled=True)
+    g.conv(c2.weight, c2.bias, ("c1", 0, 2), ("c2", 0), stride=2)
+    g.conv(c3.weight, c3.bias, ("c2", 0, 4), ("c3", 0), stride=2)
+    g.tensor_output("c2", 128)
+    g.tensor_output("c3", 256)
+    return g.build()
+
+
+def _sd_graph(net, B, H, W, dev):
+    """FlowNetSD (models/flownet2/FlowNetSD.py:12-126): concatK = [convK_1 | deconvK | flow(K+1) up] is one buffer, the
+    stride-2 convolution of the next level reads its first segment."""
+    from ..plane_graph import PlaneGraph
+    g = PlaneGraph(B, dev)
+    L = lambda s: (H >> s, W >> s)
+    for name, s, chunks in (("in0", 0, 1), ("c0", 0, 2), ("c1a", 1, 2), ("c1", 1, 4), ("c2a", 2, 4), ("cat2", 2, 7), ("c3a", 3, 8), ("cat3", 3, 13),
+                            ("c4a", 4, 16), ("cat4", 4, 25), ("c5a", 5, 16), ("cat5", 5, 33), ("c6a", 6, 32), ("c6", 6, 32),
+                            ("ic5", 5, 16), ("ic4", 4, 8), ("ic3", 3, 4), ("ic2", 2, 2)):
+        g.buffer(name, *L(s), chunks)
+    g.input("in0", 6)
+    cv = lambda name: (getattr(net, name)[0].weight, getattr(net, name)[0].bias)
+    for name, src, dst, stride in (("conv0", ("in0", 0, 1), ("c0", 0), 1), ("conv1", ("c0", 0, 2), ("c1a", 0), 2),
+                                   ("conv1_1", ("c1a", 0, 2), ("c1", 0), 1), ("conv2", ("c1", 0, 4), ("c2a", 0), 2),
+                                   ("conv2_1", ("c2a", 0, 4), ("cat2", 0), 1), ("conv3", ("cat2", 0, 4), ("c3a", 0), 2),
+                                   ("conv3_1", ("c3a", 0, 8), ("cat3", 0), 1), ("conv4", ("cat3", 0, 8), ("c4a", 0), 2),
+                                   ("conv4_1", ("c4a", 0, 16), ("cat4", 0), 1), ("conv5", ("cat4", 0, 16), ("c5a", 0), 2),
+                                   ("conv5_1", ("c5a", 0, 16), ("cat5", 0), 1), ("conv6", ("cat5", 0, 16), ("c6a", 0), 2),
+                                   ("conv6_1", ("c6a", 0, 32), ("c6", 0), 1)):
+        g.conv(*cv(name), src, dst, stride=stride)
+    g.predict_flow(net.predict_flow6, ("c6", 0, 32), "flow6")
+    prev, prev_chunks = "c6", 32
+    for lvl, cat, nskip, ndec, ic in ((5, "cat5", 16, 16, "ic5"), (4, "cat4", 16, 8, "ic4"), (3, "cat3", 8, 4, "ic3"), (2, "cat2", 4, 2, "ic2")):
+        total = nskip + ndec + 1
+        g.up_flow(getattr(net, f"upsampled_flow{lvl + 1}_to_{lvl}"), f"flow{lvl + 1}", (cat, nskip + ndec))
+        g.deconv(*cv(f"deconv{lvl}"), (prev, 0, prev_chunks), (cat, nskip))
+        g.conv(*cv(f"inter_conv{lvl}"), (cat, 0, total), (ic, 0), slope=1.0)
+        g.predict_flow(getattr(net, f"predict_flow{lvl}"), (ic, 0, g.bufs[ic].chunks), f"flow{lvl}")
+        prev, prev_chunks = cat, total
+    g.output("flow2")
+    return g.build()
+
+
+def _fusion_graph(net, B, H, W, dev):
+    """FlowNetFusion (models/flownet2/FlowNetFusion.py:12-71) at full resolution: cat1 = [conv1_1 128 | deconv1 32 | up 2],
+    cat0 = [conv0 64 | deconv0 16 (half a chunk) | up 2] -- the 82 reference channels sit at 0..79 and 96, 97."""
+    from ..plane_graph import PlaneGraph
+    g = PlaneGraph(B, dev)
+    L = lambda s: (H >> s, W >> s)
+    for name, s, chunks in (("in0", 0, 1), ("cat0", 0, 4), ("c1a", 1, 2), ("cat1", 1, 6), ("c2a", 2, 4), ("c2", 2, 4), ("ic1", 1, 1), ("ic0", 0, 1)):
+        g.buffer(name, *L(s), chunks)
+    g.input("in0", 11)
+    cv = lambda name: (getattr(net, name)[0].weight, getattr(net, name)[0].bias)
+    g.conv(*cv("conv0"), ("in0", 0, 1), ("cat0", 0))
+    g.conv(*cv("conv1"), ("cat0", 0, 2), ("c1a", 0), stride=2)
+    g.conv(*cv("conv1_1"), ("c1a", 0, 2), ("cat1", 0))
+    g.conv(*cv("conv2"), ("cat1", 0, 4), ("c2a", 0), stride=2)
+    g.conv(*cv("conv2_1"), ("c2a", 0, 4), ("c2", 0))
+    g.predict_flow(net.predict_flow2, ("c2", 0, 4), "flow2")
+    g.up_flow(net.upsampled_flow2_to_1, "flow2", ("cat1", 5))
+    g.deconv(*cv("deconv1"), ("c2", 0, 4), ("cat1", 4))
+    g.conv(*cv("inter_conv1"), ("cat1", 0, 6), ("ic1", 0), slope=1.0)
+    g.predict_flow(net.predict_flow1, ("ic1", 0, 1), "flow1")
+    g.up_flow(net.upsampled_flow1_to_0, "flow1", ("cat0", 3))
+    g.deconv(*cv("deconv0"), ("cat1", 0, 6), ("cat0", 2))
+    seg0 = [(0, 64, 0), (64, 16, 64), (80, 2, 96)]
+    g.conv(*cv("inter_conv0"), ("cat0", 0, 4), ("ic0", 0), slope=1.0, in_segments=seg0)
+    g.predict_flow(net.predict_flow0, ("ic0", 0, 1), "flow0")
+    g.output("flow0")
+    return g.build()
 
 
 class FlowNet2(nn.Module):

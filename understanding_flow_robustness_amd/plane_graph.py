@@ -1,0 +1,281 @@
+"""A small schedule builder for the convolutional sub-networks that have no bespoke engine: FlowNet2's FlowNetSD and
+FlowNetFusion and the conv1-3 prefixes of its FlowNetS stacks (models/flownet2/FlowNetSD.py:12-126, FlowNetFusion.py:12-71,
+FlowNetS.py:15-104) -- every layer forward AND data gradient on the hand-written gfx950 kernels, activations resident in
+the plane layout between layers.
+
+    conv / deconv / inter_conv            csrc/igemm.hip (bf16 split planes, six products; bias + LeakyReLU or linear epilogue)
+    predict_flow*, upsampled_flow*        csrc/engine_small.hip
+    7x7 stride-2 stem on 12 channels      pixel-unshuffle pack (csrc/window.hip) + a 16-tap stride-1 launch over 48 channels
+
+A `torch.cat` of the reference is a chunk offset into one buffer (a segment list says where each member sits; weights are
+re-indexed once).  Adjoint: every buffer has a float32 gradient sum of the same layout, zero-filled at the start of a
+backward; each operator's adjoint ADDS its share (igemm epilogue `add` = its own output, the 2-channel kernels with
+accumulate), then LeakyReLU' and the split into gradient planes happen once per produced segment.  Parameters are frozen.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from . import igemm as ig
+from .flownetc_engine import _pack_flow_head, _pack_flow_head_mfma
+
+
+class _Buf:
+    def __init__(self, B, H, W, chunks, dev):
+        self.planes = ig.Planes(B, H, W, chunks, dev)
+        self.grad = ig.GradSum(B, H, W, chunks, dev)
+        self.H, self.W, self.chunks = H, W, chunks
+
+
+def remap_in(weight: torch.Tensor, segments, cbuf: int, dim: int = 1) -> torch.Tensor:
+    """Move the reference's input channels to their buffer positions: segments = [(first reference channel, count, first buffer
+    channel)]; everything else of the `cbuf` buffer channels gets zero weights."""
+    shape = list(weight.shape)
+    shape[dim] = cbuf
+    w = torch.zeros(shape, dtype=torch.float32, device=weight.device)
+    src = weight.detach().float()
+    for r0, n, b0 in segments:
+        idx_w = [slice(None)] * w.dim()
+        idx_s = [slice(None)] * w.dim()
+        idx_w[dim], idx_s[dim] = slice(b0, b0 + n), slice(r0, r0 + n)
+        w[tuple(idx_w)] = src[tuple(idx_s)]
+    return w
+
+
+class PlaneGraph:
+    def __init__(self, B: int, device):
+        L.lib()
+        self.B, self.dev = int(B), torch.device(device)
+        self.bufs: dict[str, _Buf] = {}
+        self.ops = []                      # forward order
+        self._plans = []
+        self.flows: dict[str, torch.Tensor] = {}
+        self.g_flows: dict[str, torch.Tensor] = {}
+        self.inputs, self.outputs, self.tensor_outputs = [], [], []
+        self.generation = 0
+
+    # ------------------------------------------------------------------------------------------------ building
+    def buffer(self, name, H, W, chunks):
+        self.bufs[name] = _Buf(self.B, H, W, chunks, self.dev)
+        return self.bufs[name]
+
+    def _launch(self, wi, x, in_chunk0, rows, out_hw, **kw):
+        holder = _Deferred()
+        kw.setdefault("variant", 6 if wi.Npad % 128 == 0 else 7)
+        self._plans.append((holder, wi, x, in_chunk0, rows, out_hw, kw))
+        return holder
+
+    def input(self, buf, channels, chunk0=0):
+        """An NCHW float32 tensor [B, channels, H, W] loaded into `buf` at chunk0; its gradient is returned by backward()."""
+        b = self.bufs[buf]
+        self.inputs.append(dict(buf=b, C=channels, chunk0=chunk0, g=torch.zeros(self.B, channels, b.H, b.W, dtype=torch.float32, device=self.dev)))
+
+    def input_packed12(self, buf, channels):
+        """A [B, channels, 2H, 2W] tensor entering as its 2x2 pixel-unshuffle (channel (c*2 + p)*2 + q = x[c, 2y + p, 2x + q]) for a
+        7x7 stride-2 stem run as a 16-tap stride-1 launch (`conv7x7s2_unshuffled`)."""
+        b = self.bufs[buf]
+        self.inputs.append(dict(buf=b, C=channels, chunk0=0, packed=True,
+                                g=torch.zeros(self.B, channels, 2 * b.H, 2 * b.W, dtype=torch.float32, device=self.dev)))
+
+    def conv(self, weight, bias, src, dst, stride=1, slope=ig.LEAKY, in_segments=None, taps_unshuffled=False):
+        """dst segment = act(conv(src segment)).  src = (buffer, first chunk, chunks), dst = (buffer, first chunk).
+        in_segments: where the reference's input channels sit inside the src chunks (default: contiguous from channel 0)."""
+        sb, s0, sk = self.bufs[src[0]], src[1], src[2]
+        db, d0 = self.bufs[dst[0]], dst[1]
+        w = weight.detach().float()
+        if taps_unshuffled:               # Conv2d(C, N, 7, 2, 3) over the 2x2-unshuffled input: 4x4 taps a, b in [-2, 1], channel (c, p, q)
+            N, Cn = w.shape[:2]
+            wu = torch.zeros(N, 4 * Cn, 4, 4, dtype=torch.float32, device=w.device)
+            for ky in range(7):
+                a, p = (ky - 3) // 2, (ky - 3) % 2
+                for kx in range(7):
+                    bb, q = (kx - 3) // 2, (kx - 3) % 2
+                    wu[:, (torch.arange(Cn, device=w.device) * 2 + p) * 2 + q, a + 2, bb + 2] = w[:, :, ky, kx]
+            w, stride, pad = wu, 1, 2     # taps (a, b) = (ky' - 2, kx' - 2): "padding 2" of a 4x4 kernel
+        else:
+            pad = (w.shape[-1] - 1) // 2
+        if in_segments is not None or w.shape[1] != sk * 32:
+            w = remap_in(w, in_segments or [(0, w.shape[1], 0)], sk * 32)
+        N = w.shape[0]
+        nch = ig.pad32(N) // 32
+        wi = ig.conv_forward_weights(w, stride, pad)
+        wib = ig.conv_backward_weights(w, stride, pad)
+        rows = (db.H, db.W)
+        gz = ig.Planes(self.B, db.H, db.W, nch, self.dev)
+        fwd = self._launch(wi, sb.planes, s0, rows, rows, out_planes=db.planes, out_chunk0=d0, bias=bias.detach().float().contiguous(), slope=slope)
+        bwd = self._launch(wib, gz, 0, rows, (sb.H, sb.W), add=sb.grad, add_chunk0=s0, out_f32=sb.grad, out_f32_chunk0=s0)
+        self.ops.append(dict(kind="conv", fwd=fwd, bwd=bwd, gz=gz, db=db, d0=d0, nch=nch, slope=slope, wi=wi, wib=wib))
+
+    def deconv(self, weight, bias, src, dst, slope=ig.LEAKY, in_segments=None):
+        """ConvTranspose2d(Cin, Cout, 4, 2, 1) + bias + LeakyReLU (submodules.py:75-82)."""
+        sb, s0, sk = self.bufs[src[0]], src[1], src[2]
+        db, d0 = self.bufs[dst[0]], dst[1]
+        w = weight.detach().float()                         # [Cin, Cout, 4, 4]
+        if in_segments is not None or w.shape[0] != sk * 32:
+            w = remap_in(w, in_segments or [(0, w.shape[0], 0)], sk * 32, dim=0)
+        N = w.shape[1]
+        nch = ig.pad32(N) // 32
+        wi, wib = ig.deconv_forward_weights(w, 1), ig.deconv_backward_weights(w, 1)
+        gz = ig.Planes(self.B, db.H, db.W, nch, self.dev)
+        fwd = self._launch(wi, sb.planes, s0, (sb.H, sb.W), (db.H, db.W), out_planes=db.planes, out_chunk0=d0,
+                           bias=bias.detach().float().contiguous(), slope=slope)
+        bwd = self._launch(wib, gz, 0, (sb.H, sb.W), (sb.H, sb.W), add=sb.grad, add_chunk0=s0, out_f32=sb.grad, out_f32_chunk0=s0)
+        self.ops.append(dict(kind="conv", fwd=fwd, bwd=bwd, gz=gz, db=db, d0=d0, nch=nch, slope=slope, wi=wi, wib=wib))
+
+    def predict_flow(self, conv, src, name, in_segments=None):
+        """Conv2d(C, 2, 3, 1, 1) on a buffer's chunks -> flow `name` [B, 2, H, W] (NCHW float32)."""
+        sb, s0, sk = self.bufs[src[0]], src[1], src[2]
+        w = conv.weight.detach().float()
+        if in_segments is not None or w.shape[1] != sk * 32:
+            w = remap_in(w, in_segments or [(0, w.shape[1], 0)], sk * 32)
+        self.flows[name] = torch.zeros(self.B, 2, sb.H, sb.W, dtype=torch.float32, device=self.dev)
+        self.g_flows[name] = torch.zeros_like(self.flows[name])
+        self.ops.append(dict(kind="pf", sb=sb, s0=s0, sk=sk, wm=_pack_flow_head_mfma(w), wb=_pack_flow_head(w),
+                             b=conv.bias.detach().float().contiguous(), name=name))
+
+    def up_flow(self, deconv, flow, dst):
+        """ConvTranspose2d(2, 2, 4, 2, 1) of flow `flow` into lanes 0-1 of one chunk of `dst` = (buffer, chunk)."""
+        db, chunk = self.bufs[dst[0]], dst[1]
+        self.ops.append(dict(kind="up", flow=flow, db=db, chunk=chunk, w=deconv.weight.detach().float().contiguous(),
+                             b=deconv.bias.detach().float().contiguous() if deconv.bias is not None else None))
+
+    def output(self, flow):
+        self.outputs.append(flow)
+
+    def tensor_output(self, buf, channels, chunk0=0):
+        """A buffer segment handed out as an NCHW float32 tensor (a feature map another engine consumes); its gradient comes
+        back as NCHW and is added to the buffer's gradient sum."""
+        b = self.bufs[buf]
+        self.tensor_outputs.append(dict(buf=b, C=channels, chunk0=chunk0,
+                                        t=torch.zeros(self.B, channels, b.H, b.W, dtype=torch.float32, device=self.dev)))
+
+    def build(self):
+        B = self.B
+        sized = []
+        for holder, wi, x, c0, rows, out_hw, kw in self._plans:
+            pk = [len(t) * wi.KC for _, _, t in wi.phases]
+            bm, target = (256, 256) if kw["variant"] in (6, 7) else (128, 768)
+            sized.append(ig.splitk_for(B * rows[0] * rows[1], wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target,
+                                       min_ktiles=4))
+        need = max([len(p[1].phases) * S * B * p[4][0] * p[4][1] * p[1].Npad for p, S in zip(self._plans, sized) if S > 1] + [1])
+        self.ws = torch.empty(need, dtype=torch.float32, device=self.dev)
+        for (holder, wi, x, c0, rows, out_hw, kw), S in zip(self._plans, sized):
+            holder.launch = ig.make_launch(wi, x, c0, rows, out_hw, splitk=S, ws=self.ws if S > 1 else None, **kw)
+            holder.wi = wi
+        return self
+
+    def launch_table(self):
+        rows = []
+        for i, (holder, wi, x, c0, r, o, kw) in enumerate(self._plans):
+            d = holder.launch.desc
+            rows.append((f"launch_{i}", holder.launch, wi.flops(d.B * d.Hr * d.Wr) / 1e9))
+        return rows
+
+    # ------------------------------------------------------------------------------------------------ running
+    @torch.no_grad()
+    def forward(self, *tensors):
+        lib, st = L.lib(), L.stream
+        self.generation += 1
+        for spec, x in zip(self.inputs, tensors):
+            L.require_hip(x, "input")
+            b = spec["buf"]
+            if spec.get("packed"):
+                L.check(lib.ufr_unshuffle_pack_planes(L.ptr(x.contiguous()), L.ptr(b.planes.t), b.planes.plane_stride, self.B, spec["C"], b.H, b.W,
+                                                      st()), "unshuffle pack")
+            else:
+                b.planes.load_nchw(x.contiguous(), spec["chunk0"])
+        for op in self.ops:
+            if op["kind"] == "conv":
+                op["fwd"]()
+            elif op["kind"] == "pf":
+                sb = op["sb"]
+                L.check(lib.ufr_flow_head_planes_forward_mfma(L.ptr(sb.planes.t), sb.planes.plane_stride, op["s0"], op["sk"], L.ptr(op["wm"]),
+                                                              L.ptr(op["b"]), L.ptr(self.flows[op["name"]]), self.B, sb.H, sb.W, st()),
+                        "predict_flow forward")
+            else:
+                f, db = self.flows[op["flow"]], op["db"]
+                L.check(lib.ufr_flow_up_planes_forward(L.ptr(f), L.ptr(op["w"]), L.ptr(op["b"]) if op["b"] is not None else None,
+                                                       L.ptr(db.planes.t), db.planes.plane_stride, op["chunk"], self.B, f.shape[2], f.shape[3],
+                                                       st()), "upsampled_flow forward")
+        outs = [self.flows[n] for n in self.outputs]
+        for spec in self.tensor_outputs:
+            outs.append(spec["buf"].planes.to_nchw(spec["C"], spec["chunk0"], out=spec["t"]))
+        return outs
+
+    @torch.no_grad()
+    def backward(self, *grads):
+        lib, st = L.lib(), L.stream
+        for b in self.bufs.values():
+            b.grad.t.zero_()
+        for g in self.g_flows.values():
+            g.zero_()
+        for name, g in zip(self.outputs, grads):
+            self.g_flows[name].copy_(g)
+        for spec, g in zip(self.tensor_outputs, grads[len(self.outputs):]):
+            b, C_, c0 = spec["buf"], spec["C"], spec["chunk0"]          # NCHW -> chunk-major float32, added to the buffer's sum
+            n = C_ // 32
+            if C_ % 32:
+                raise NotImplementedError("tensor outputs are whole chunks")
+            b.grad.t[c0:c0 + n].add_(g.view(self.B, n, 32, b.H, b.W).permute(1, 0, 3, 4, 2).reshape(n, -1, 32))
+        for op in reversed(self.ops):
+            if op["kind"] == "conv":
+                db, gz = op["db"], op["gz"]
+                mask = db.planes if op["slope"] != 1.0 else None
+                L.check(lib.ufr_grad_finalize(L.ptr(db.grad.t), op["d0"], L.ptr(mask.t) if mask is not None else None, op["d0"], L.ptr(gz.t),
+                                              gz.plane_stride, 0, db.grad.M, op["nch"], float(op["slope"]), st()), "gradient finalize")
+                op["bwd"]()
+            elif op["kind"] == "pf":
+                sb = op["sb"]
+                L.check(lib.ufr_flow_head_planes_backward(L.ptr(self.g_flows[op["name"]]), L.ptr(op["wb"]), L.ptr(sb.grad.t), op["s0"], op["sk"],
+                                                          self.B, sb.H, sb.W, 1, st()), "predict_flow backward")
+            else:
+                gf, db = self.g_flows[op["flow"]], op["db"]
+                L.check(lib.ufr_flow_up_planes_backward(L.ptr(db.grad.t), op["chunk"], L.ptr(op["w"]), L.ptr(self._tmp_like(gf)), self.B,
+                                                        gf.shape[2], gf.shape[3], st()), "upsampled_flow backward")
+                gf.add_(self._tmp_like(gf))
+        outs = []
+        for spec in self.inputs:
+            b = spec["buf"]
+            if spec.get("packed"):
+                L.check(lib.ufr_unshuffle_unpack_grad(L.ptr(b.grad.t), L.ptr(spec["g"]), self.B, spec["C"], b.H, b.W, st()), "unshuffle unpack")
+            else:
+                b.grad.to_nchw(spec["C"], spec["chunk0"], slope=1.0, out=spec["g"])
+            outs.append(spec["g"])
+        return outs
+
+    def _tmp_like(self, t):
+        key = tuple(t.shape)
+        tmp = self.__dict__.setdefault("_tmps", {})
+        if key not in tmp:
+            tmp[key] = torch.zeros_like(t)
+        return tmp[key]
+
+
+class _Deferred:
+    launch = None
+
+    def __call__(self):
+        self.launch()
+
+
+class _GraphFunction(torch.autograd.Function):
+    """A PlaneGraph as an autograd Function of its NCHW inputs (static buffers: a forward is differentiable until the next one)."""
+
+    @staticmethod
+    def forward(ctx, graph, *inputs):
+        outs = [o.clone() for o in graph.forward(*inputs)]
+        ctx.graph, ctx.generation = graph, graph.generation
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        if ctx.graph.generation != ctx.generation:
+            raise RuntimeError("native sub-network: another forward (same batch and frame size) ran before this backward; its "
+                               "activations are gone.  Call backward() before the next forward, or set UFR_ENGINE=0")
+        gs = ctx.graph.backward(*[g.contiguous() for g in grads])
+        return (None, *[g.clone() for g in gs])
+
+
+def run(graph: PlaneGraph, *inputs):
+    return _GraphFunction.apply(graph, *inputs)
