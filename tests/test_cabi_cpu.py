@@ -171,3 +171,20 @@ def test_reference_model_files_import_the_dropin_ops_unchanged(tmp_path):
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(root, "dropin"), root])
     out = subprocess.run([sys.executable, "-c", code], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "reference imports ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_engine_cache_is_not_copied_with_the_module():
+    """Engines hold device buffers and ctypes descriptors: deepcopy / pickle of a module that has run must not try to take them."""
+    import copy
+    import pickle
+
+    import torch
+
+    from understanding_flow_robustness_amd._lib import EngineCache, engine_cache
+    m = torch.nn.Linear(2, 2)
+    c = engine_cache(m, "_ufr_head_engines")
+    c["k"] = (ctypes.c_void_p(1), ctypes.pointer(ctypes.c_int(3)))
+    assert engine_cache(m, "_ufr_head_engines") is c
+    m2 = copy.deepcopy(m)
+    assert isinstance(m2.__dict__["_ufr_head_engines"], EngineCache) and not m2.__dict__["_ufr_head_engines"]
+    assert not pickle.loads(pickle.dumps(m)).__dict__["_ufr_head_engines"] and c["k"]

@@ -228,3 +228,19 @@ def dtype_code(t: torch.Tensor) -> int:
     if t.dtype == torch.float64:
         return UFR_F64
     raise RuntimeError(f"unsupported dtype {t.dtype}: the gfx950 build implements float32 and float64")
+
+
+class EngineCache(dict):
+    """Per-module cache of native engines / schedules / captured steps (static device buffers, ctypes descriptors).  It is
+    state OF the process, not of the module: `copy.deepcopy(net)`, `pickle` and `torch.save(net)` get an empty one and the copy
+    builds its own engines on first use."""
+
+    def __deepcopy__(self, memo):
+        return EngineCache()
+
+    def __reduce__(self):
+        return (EngineCache, ())
+
+
+def engine_cache(module, attr: str) -> EngineCache:
+    return module.__dict__.setdefault(attr, EngineCache())

@@ -9,6 +9,7 @@ flows are upsampled with `nearest`, FlowNetS's flow up-convolutions have no bias
 from __future__ import annotations
 
 import torch
+from .._lib import engine_cache as _engine_cache
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -263,7 +264,7 @@ class FlowNetFusion(nn.Module):
 def _graph_for(module, key, build):
     """One PlaneGraph per (batch, frame size, device), cached on the module; rebuilt when its weights changed since."""
     from ..flownetc_engine import _weights_stamp
-    cache = module.__dict__.setdefault("_ufr_plane_graphs", {})
+    cache = _engine_cache(module, "_ufr_plane_graphs")
     stamp = _weights_stamp(module)
     g = cache.get(key)
     if g is None or g.weights_stamp != stamp:

@@ -37,6 +37,7 @@ from argparse import Namespace
 
 import numpy as np
 import torch
+from ._lib import engine_cache as _engine_cache
 
 from . import _lib as L
 from .flownets.utils_model import predict_flow
@@ -554,7 +555,7 @@ def attack(flow_net, tgt_img_var, ref_past_img_var, ref_future_img_var, patch_va
     patch_hw = tuple(patch_var.shape[-2:]) if origins is not None else None
     key = (B, H, W, shared, patch_hw, bool(getattr(args, "l2", False)), float(args.lr), float(getattr(args, "alpha", 0.0)),
            args.flownet, bool(use_graph))
-    cache = flow_net.__dict__.setdefault(_STEP_CACHE_ATTR, {})
+    cache = _engine_cache(flow_net, _STEP_CACHE_ATTR)
     step = cache.get(key)
     # a cached step holds captured graphs and (FlowNetC) pre-packed weights: a load_state_dict / in-place update of the
     # network since then makes it stale

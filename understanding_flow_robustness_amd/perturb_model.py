@@ -15,6 +15,7 @@ from argparse import Namespace
 
 import numpy as np
 import torch
+from ._lib import engine_cache as _engine_cache
 import torch.nn as nn
 
 from . import _lib as L
@@ -135,7 +136,7 @@ class PerturbationsModel:
         B, _, H, W = image0.shape
         # cached on the network (a new PerturbationsModel per training batch, train.py:172-186, must not
         # re-capture the graph): weights are read through their storage, so optimiser updates are seen
-        self._steps = model.__dict__.setdefault("_ufr_perturb_steps", {})
+        self._steps = _engine_cache(model, "_ufr_perturb_steps")
         key = (B, H, W, ground_truth.shape[1], self.method, self.mode, self.lr, self.eps, self.targeted, self.use_graph,
                getattr(self.args, "flow_loss", None), getattr(self.args, "flownet", None))
         step = self._steps.get(key)

@@ -152,6 +152,19 @@ class PlaneGraph:
 
     def build(self):
         B = self.B
+        # every gradient sum and flow gradient in one arena: a backward starts with ONE fill instead of one per buffer
+        r64 = lambda n: (n + 63) // 64 * 64                   # keep every member 256-byte aligned
+        sizes = [b.grad.t.numel() for b in self.bufs.values()] + [r64(g.numel()) for g in self.g_flows.values()]
+        self._zero_arena = torch.zeros(sum(sizes), dtype=torch.float32, device=self.dev)
+        off = 0
+        for b in self.bufs.values():
+            n = b.grad.t.numel()
+            b.grad.t = self._zero_arena[off:off + n].view_as(b.grad.t)
+            off += n
+        for k in list(self.g_flows):
+            n = self.g_flows[k].numel()
+            self.g_flows[k] = self._zero_arena[off:off + n].view_as(self.g_flows[k])
+            off += r64(n)
         sized = []
         for holder, wi, x, c0, rows, out_hw, kw in self._plans:
             pk = [len(t) * wi.KC for _, _, t in wi.phases]
@@ -206,10 +219,7 @@ class PlaneGraph:
     @torch.no_grad()
     def backward(self, *grads):
         lib, st = L.lib(), L.stream
-        for b in self.bufs.values():
-            b.grad.t.zero_()
-        for g in self.g_flows.values():
-            g.zero_()
+        self._zero_arena.zero_()
         for name, g in zip(self.outputs, grads):
             self.g_flows[name].copy_(g)
         for spec, g in zip(self.tensor_outputs, grads[len(self.outputs):]):

@@ -23,6 +23,7 @@ from __future__ import annotations
 import ctypes as C
 
 import torch
+from ._lib import engine_cache as _engine_cache
 
 from . import _lib as L
 from . import igemm as ig
@@ -510,7 +511,7 @@ def get_engine(net, B: int, H: int, W: int, device) -> PwcHeadEngine:
     """One engine per batch / frame size, cached on the module; rebuilt when the module's weights have changed since."""
     from .flownetc_engine import _weights_stamp
     key = (int(B), int(H), int(W), str(torch.device(device)))
-    cache = net.__dict__.setdefault("_ufr_head_engines", {})
+    cache = _engine_cache(net, "_ufr_head_engines")
     stamp = _weights_stamp(net)
     eng = cache.get(key)
     if eng is None or eng.weights_stamp != stamp:

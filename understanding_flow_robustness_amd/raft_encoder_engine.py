@@ -12,6 +12,7 @@ Parameters are frozen (data gradients only).
 from __future__ import annotations
 
 import torch
+from ._lib import engine_cache as _engine_cache
 
 from . import _lib as L
 from . import igemm as ig
@@ -247,7 +248,7 @@ def encode(enc, images: torch.Tensor) -> torch.Tensor:
     from .flownetc_engine import _weights_stamp
     n, _, H, W = images.shape
     key = (int(n), int(H), int(W), str(images.device))
-    cache = enc.__dict__.setdefault("_ufr_encoder_engines", {})
+    cache = _engine_cache(enc, "_ufr_encoder_engines")
     stamp = _weights_stamp(enc) + tuple((b.data_ptr(), b._version) for b in enc.buffers())
     eng = cache.get(key)
     if eng is None or eng.weights_stamp != stamp:

@@ -22,6 +22,7 @@ import ctypes as C
 import math
 
 import torch
+from ._lib import engine_cache as _engine_cache
 
 from . import _lib as L
 from . import igemm as ig
@@ -323,7 +324,7 @@ class _RaftRefine(torch.autograd.Function):
 def get_engine(net, B: int, H: int, W: int, device) -> RaftUpdateEngine:
     from .flownetc_engine import _weights_stamp
     key = (int(B), int(H), int(W), str(torch.device(device)))
-    cache = net.__dict__.setdefault("_ufr_head_engines", {})
+    cache = _engine_cache(net, "_ufr_head_engines")
     stamp = _weights_stamp(net)
     eng = cache.get(key)
     if eng is None or eng.weights_stamp != stamp:

@@ -21,6 +21,7 @@ from __future__ import annotations
 from argparse import Namespace
 
 import torch
+from ._lib import engine_cache as _engine_cache
 
 from . import _lib as L
 from .flownets.utils_model import predict_flow
@@ -178,7 +179,7 @@ def attack(model, img0_var, img1_var, universal_perturbation_var, target_var, ar
     key = (B, H, W, target_var.shape[1], args.flow_loss, args.perturb_method, args.perturb_mode,
            float(args.learning_rate), float(args.output_norm), bool(getattr(args, "add_gaussian", False)),
            args.flownet, bool(use_graph))
-    cache = model.__dict__.setdefault(_CACHE, {})
+    cache = _engine_cache(model, _CACHE)
     step = cache.get(key)
     if step is None:
         step = cache[key] = UniversalPerturbationStep(model, args, B, H, W, gt_channels=target_var.shape[1],
