@@ -402,3 +402,52 @@ def gen_perturb_noise():
 GENERATORS["perturb_noise"] = gen_perturb_noise
 
 GENERATORS["flownet2s"] = gen_flownet2s
+
+
+def gen_patch_square():
+    """`--patch_type square` (patch_attacks/main.py:280-283, :383-386, :646-654; utils_patch.py:781-846): the placement
+    under fixed np.random seeds, one loader item through main.train and a 3-item validation, FlowNetC."""
+    up = rh.ref_module("patch_attacks.utils_patch")
+    main = rh.ref_module("patch_attacks.main")
+    out = {}
+    np.random.seed(321)
+    patch, shape = up.init_patch_square(384, 0.1329)
+    mask = np.ones(shape)
+    out.update(init_patch=patch, init_shape=np.array(shape))
+    for tag, seed, dshape, norot in (("t0", 7, (1, 3, 256, 256), False), ("t1", 8, (1, 3, 384, 1280), False),
+                                     ("t2", 9, (1, 3, 384, 1280), True)):
+        np.random.seed(seed)
+        p, m, pi = patch.copy(), mask.copy(), patch.copy()
+        x, xm, xp, rx, ry = up.square_transform(p, m, pi, dshape, shape, norotate=norot)
+        ys, xs = slice(ry, ry + shape[-2]), slice(rx, rx + shape[-1])
+        out.update({f"{tag}_patch": x[:, :, ys, xs], f"{tag}_loc": np.array([rx, ry]), f"{tag}_rotated_in_place": p,
+                    f"{tag}_sum": np.array([x.sum(), xm.sum(), xp.sum()]), f"{tag}_next_draw": np.array(np.random.random())})
+    net, sd = _ref_flownetc(seed=0)
+    g = torch.Generator().manual_seed(131)
+    tgt, ref = torch.rand(1, 3, 128, 192, generator=g), torch.rand(1, 3, 128, 192, generator=g)
+    np.random.seed(77)
+    p0, sh0 = up.init_patch_square(128, 0.2)
+    m0 = np.ones(sh0)
+    main.args = Namespace(flownet="FlowNetC", l2=False, alpha=0.0, lr=1.0e5, max_count=2, log_terminal=False,
+                          patch_type="square", norotate=False, training_output_freq=0, epoch_size=1)
+    main.n_iter = 0
+    np.random.seed(6)
+    p1, m1, pi1, sh1 = main.train(p0.copy(), m0.copy(), p0.copy(), sh0, [(tgt, [ref, ref])], net)
+    out.update(train_tgt=tgt, train_ref=ref, train_patch0=p0, train_patch1=p1, train_mask1=m1, train_init1=pi1,
+               train_shape1=np.array(sh1), weight_digest=state_dict_digest(sd))
+    items = []
+    for _ in range(3):
+        a, b = torch.rand(1, 3, 128, 192, generator=g), torch.rand(1, 3, 128, 192, generator=g)
+        gt = torch.cat((4 * torch.randn(1, 2, 100, 150, generator=g), (torch.rand(1, 1, 100, 150, generator=g) > 0.3).float()), 1)
+        items.append((b, a, b, gt, None, None, None))
+    main.args = Namespace(flownet="FlowNetC", patch_type="square", norotate=False, log_output=False, log_terminal=False)
+    np.random.seed(29)
+    vp, vm = p0.copy(), m0.copy()
+    avg, names = main.validate_flow_with_gt(vp, vm, sh0, items, net, 0, None, None)
+    out.update(val_tgt=torch.cat([i[1] for i in items]), val_ref=torch.cat([i[2] for i in items]),
+               val_gt=torch.cat([i[3] for i in items]), val_errors=np.array(avg), val_patch_after=vp)
+    save("patch_square", **out)
+    print(dict(zip(names, avg)))
+
+
+GENERATORS["patch_square"] = gen_patch_square

@@ -24,9 +24,10 @@ for step in "$@"; do
              [ $rc -ne 0 ] && { grep -E "^E |FAILED|Error" $out/gpu_suite.log | head -n 20; exit $rc; } ;;
     tests)   timeout -k 10 1100 python -m pytest $arg -q -x > $out/tests.log 2>&1; rc=$?; tail -n 4 $out/tests.log
              [ $rc -ne 0 ] && { grep -E "^E |FAILED|Error" $out/tests.log | head -n 30; exit $rc; } ;;
-    bench)   timeout -k 10 900 python bench.py $arg > $out/bench.json 2> $out/bench.err; rc=$?
+    bench)   nb=$((${nb:-0} + 1)); bj=$out/bench$([ $nb -gt 1 ] && echo _$nb).json      # a second bench step of a call: bench_2.json
+             timeout -k 10 900 python bench.py $arg > $bj 2> $out/bench.err; rc=$?
              [ $rc -ne 0 ] && { tail -n 20 $out/bench.err; exit $rc; }
-             python tools/summarize_bench.py $out/bench.json ;;
+             python tools/summarize_bench.py $bj | head -n ${BENCH_LINES:-400} ;;
     stats)   (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/stats -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-full-frame --no-other-configs $arg > $GRAFT_REPO_ROOT/$out/stats_bench.json 2> $GRAFT_REPO_ROOT/$out/stats.err); rc=$?
              [ $rc -ne 0 ] && { tail -n 20 $out/stats.err; exit $rc; }
              f=$(find $out/stats -name "*kernel_stats.csv" | head -n 1); ft=$(find $out/stats -name "*kernel_trace.csv" | head -n 1)

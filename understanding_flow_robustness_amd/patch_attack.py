@@ -572,21 +572,31 @@ def attack(flow_net, tgt_img_var, ref_past_img_var, ref_future_img_var, patch_va
     return step.adv_tgt.detach().clone(), None, step.adv_ref.detach().clone(), patch_var
 
 
+def _patch_type(args) -> str:
+    """`--patch_type` (main.py:277-285): "circle" (the README's configuration) or "square"."""
+    kind = getattr(args, "patch_type", "circle")
+    if kind not in ("circle", "square"):
+        raise ValueError("Please choose a square or circle patch")      # the reference's sys.exit message (main.py:285)
+    return kind
+
+
 def train_sample(flow_net, tgt_img, ref_past_img, ref_future_img, patch, mask, patch_init, patch_shape,
                  patch_shape_orig, args: Namespace, use_graph=True):
     """One loader item of patch_attacks/main.py::train (:363-461): clean forward, host-side
     `circle_transform` (numpy RNG consumed like the reference), H2D, the fused `attack`, D2H, crop at
     the placement and resample to the original patch size.  numpy patch state in, numpy patch state out:
     returns (patch, mask, patch_init, patch_shape).  Batch 1, like the reference (`patch[i]` indexing)."""
-    from .utils_patch import circle_transform, crop_and_restore
+    from .utils_patch import circle_transform, crop_and_restore, square_transform
     dev = tgt_img.device
     with torch.no_grad():
         flow_pred = predict_flow(flow_net, ref_past_img, tgt_img, ref_future_img, args)
-    if getattr(args, "patch_type", "circle") != "circle":
-        raise NotImplementedError("only --patch_type circle (the README's configuration) is mirrored")
-    # NB the reference passes `True` as the 6th positional argument, i.e. margin=1 (main.py:377)
-    patch, mask, patch_init, rx, ry, patch_shape = circle_transform(
-        patch, mask, patch_init, tuple(tgt_img.shape), patch_shape, True)
+    if _patch_type(args) == "square":            # main.py:383-386 (no zoom: patch_shape stays)
+        patch, mask, patch_init, rx, ry = square_transform(patch, mask, patch_init, tuple(tgt_img.shape), patch_shape,
+                                                           norotate=getattr(args, "norotate", False))
+    else:
+        # NB the reference passes `True` as the 6th positional argument, i.e. margin=1 (main.py:377)
+        patch, mask, patch_init, rx, ry, patch_shape = circle_transform(
+            patch, mask, patch_init, tuple(tgt_img.shape), patch_shape, True)
     patch_t = torch.FloatTensor(patch).to(dev)
     mask_t = torch.FloatTensor(mask).to(dev)
     init_t = torch.FloatTensor(patch_init).to(dev)
@@ -603,7 +613,7 @@ def train_sample_device(flow_net, tgt_img, ref_past_img, ref_future_img, patch, 
     """`train_sample` with the patch state resident on the device (float64 HIP tensors [1,3,S,S], SURVEY.md 8
     f2): placement, attack, crop and resampling all run on the GPU (patch_transform.py); the only host work is
     drawing the reference's `np.random` numbers.  Returns (patch, mask, patch_init, patch_shape) as HIP tensors."""
-    from .patch_transform import circle_transform_device, crop_and_restore_device
+    from .patch_transform import circle_transform_device, crop_and_restore_device, square_transform_device
     with torch.no_grad():
         prefix = None
         if (getattr(flow_net, "CONE", None) is not None and not flow_net.training
@@ -615,10 +625,12 @@ def train_sample_device(flow_net, tgt_img, ref_past_img, ref_future_img, patch, 
             flow_pred = flow_net.head(*[f[:B] for f in prefix[:-1]], prefix[-1][:B], prefix[-1][B:])
         else:
             flow_pred = predict_flow(flow_net, ref_past_img, tgt_img, ref_future_img, args)
-        if getattr(args, "patch_type", "circle") != "circle":
-            raise NotImplementedError("only --patch_type circle (the README's configuration) is mirrored")
-        patch_t, mask_t, init_t, rx, ry, patch_shape = circle_transform_device(
-            patch, mask, patch_init, tuple(tgt_img.shape), patch_shape, True)     # margin=1, main.py:377
+        if _patch_type(args) == "square":
+            patch_t, mask_t, init_t, rx, ry, _ = square_transform_device(patch, mask, patch_init, tuple(tgt_img.shape), patch_shape,
+                                                                         norotate=getattr(args, "norotate", False))
+        else:
+            patch_t, mask_t, init_t, rx, ry, patch_shape = circle_transform_device(
+                patch, mask, patch_init, tuple(tgt_img.shape), patch_shape, True)     # margin=1, main.py:377
     target = -flow_pred.detach()
     _, _, _, patch_t = attack(flow_net, tgt_img, ref_past_img, ref_future_img, patch_t, mask_t, init_t, target,
                               None, args=args, use_graph=use_graph, prefix_features=prefix)
@@ -640,9 +652,8 @@ def validate_flow_with_gt(patch, mask, patch_shape, val_loader, flow_net, args: 
     run as ONE batch of two, paste+clamp is the fused kernel, the four metrics stay on the device and the
     host synchronises once at the end instead of four times per item (`.item()` in losses.py)."""
     from . import losses
-    from .patch_transform import circle_transform_device
-    if getattr(args, "patch_type", "circle") != "circle":
-        raise NotImplementedError("only --patch_type circle is mirrored")
+    from .patch_transform import circle_transform_device, square_transform_device
+    square = _patch_type(args) == "square"
     flow_net.eval()
     lo, hi = _pixel_range(args.flownet)
     sums, count, patch_d, mask_d = None, 0, None, None
@@ -654,7 +665,11 @@ def validate_flow_with_gt(patch, mask, patch_shape, val_loader, flow_net, args: 
             if patch_d is None:
                 f64 = lambda a: (a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))).to(dev, torch.float64)
                 patch_d, mask_d = f64(patch), f64(mask)
-            patch_t, mask_t, _, _, _, _ = circle_transform_device(patch_d, mask_d, patch_d, tuple(tgt.shape), patch_shape)
+            if square:                           # main.py:646-654; the turns accumulate on patch / mask like the reference's in-place rot90
+                patch_t, mask_t, _, _, _, (patch_d, mask_d, _) = square_transform_device(
+                    patch_d, mask_d, patch_d, tuple(tgt.shape), patch_shape, norotate=getattr(args, "norotate", False))
+            else:
+                patch_t, mask_t, _, _, _, _ = circle_transform_device(patch_d, mask_d, patch_d, tuple(tgt.shape), patch_shape)
             tgt, ref_future = tgt.contiguous(), ref_future.contiguous()
             B, _, H, W = tgt.shape
             adv_tgt, adv_ref = torch.empty_like(tgt), torch.empty_like(ref_future)

@@ -91,6 +91,28 @@ def circle_transform_device(patch, mask, patch_init, data_shape, patch_shape, ma
     return canvases[0], canvases[1], canvases[2], int(x), int(y), new_shape
 
 
+def square_transform_device(patch, mask, patch_init, data_shape, patch_shape, norotate=False):
+    """utils_patch.square_transform (utils_patch.py:781-846) with HIP tensors: float64 state in, float32 canvases out.
+    RNG: `choice(4)` quarter turns (unless norotate), `choice(W - S - 1)`, `choice(H - S - 1)`.  The reference rotates
+    the caller's arrays in place; tensors are immutable here, so the ROTATED state is returned as well:
+    (canvas_patch, canvas_mask, canvas_init, x, y, (patch, mask, patch_init) after the turns)."""
+    if data_shape[0] != 1 or patch.shape[0] != 1:
+        raise NotImplementedError("batch 1, like the reference (`patch[i]` for i < data_shape[0])")
+    image_w, image_h = data_shape[-1], data_shape[-2]
+    side = patch_shape[-1]
+    if not norotate:
+        turns = int(np.random.choice(4))
+        patch, mask, patch_init = (torch.rot90(t, turns, (-2, -1)).contiguous() for t in (patch, mask, patch_init))
+    x = int(np.random.choice(image_w - side - 1))
+    y = int(np.random.choice(image_h - side - 1))
+    C = patch.shape[1]
+    canvases = [torch.empty(1, C, image_h, image_w, dtype=torch.float32, device=patch.device) for _ in range(3)]
+    L.check(L.lib().ufr_patch_place(L.ptr(patch.contiguous()), L.ptr(mask.contiguous()), L.ptr(patch_init.contiguous()), C,
+                                    patch.shape[-2], patch.shape[-1], L.ptr(canvases[0]), L.ptr(canvases[1]),
+                                    L.ptr(canvases[2]), image_h, image_w, y, x, L.stream()), "patch place")
+    return canvases[0], canvases[1], canvases[2], x, y, (patch, mask, patch_init)
+
+
 def crop_and_restore_device(canvas_patch, canvas_mask, canvas_init, rx, ry, patch_shape, patch_shape_orig):
     """patch_attacks/main.py:408-461 on the device: mask * patch in float32, cut the zoomed patch out of the
     canvas, resample to the original size (order 1; mask order 0).  float64 state out."""

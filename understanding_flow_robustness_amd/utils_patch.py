@@ -1,5 +1,5 @@
 """Host-side patch initialisation and placement (patch_attacks/utils_patch.py:236-358, :760-766):
-`createCircularMask`, `init_patch_square`, `init_patch_circle`, `circle_transform`.
+`createCircularMask`, `init_patch_square`, `init_patch_circle`, `circle_transform`, and `square_transform` (:781-846).
 
 These feed the inner loop once per sample; they stay on the host in numpy /
 scipy like the reference so that `np.random` is consumed call for call in the same order and the
@@ -79,6 +79,32 @@ def circle_transform(patch, mask, patch_init, data_shape, patch_shape, margin=0,
         canvas_mask[i][:, ys, xs] = mask[i]
         canvas_init[i][:, ys, xs] = patch_init[i]
     return canvas, canvas_mask, canvas_init, random_x, random_y, patch_shape
+
+
+def square_transform(patch, mask, patch_init, data_shape, patch_shape, norotate=False):
+    """utils_patch.py:781-846 (`--patch_type square`, main.py:383-386): per sample a random quarter-turn count (`choice(4)`,
+    applied IN PLACE to the caller's patch / mask / patch_init like the reference) and a random corner
+    `choice(W - S - 1)`, `choice(H - S - 1)` (the reference's redraw loop behind it can never trigger: the draw is
+    <= W - S - 2).  No brightness offset, no zoom: `patch_shape` is unchanged.  Returns canvas-sized
+    (patch, mask, patch_init) and the corner (x, y) of the LAST sample."""
+    canvas, canvas_mask, canvas_init = np.zeros(data_shape), np.zeros(data_shape), np.zeros(data_shape)
+    image_w, image_h = data_shape[-1], data_shape[-2]
+    side = patch_shape[-1]
+    random_x = random_y = None
+    for i in range(canvas.shape[0]):
+        if not norotate:
+            turns = np.random.choice(4)
+            for ch in range(patch[i].shape[0]):
+                patch[i][ch] = np.rot90(patch[i][ch], turns)
+                mask[i][ch] = np.rot90(mask[i][ch], turns)
+                patch_init[i][ch] = np.rot90(patch_init[i][ch], turns)
+        random_x = np.random.choice(image_w - side - 1)
+        random_y = np.random.choice(image_h - side - 1)
+        ys, xs = slice(random_y, random_y + patch_shape[-2]), slice(random_x, random_x + patch_shape[-1])
+        canvas[i][:3, ys, xs] = patch[i][:3]
+        canvas_mask[i][:3, ys, xs] = mask[i][:3]
+        canvas_init[i][:3, ys, xs] = patch_init[i][:3]
+    return canvas, canvas_mask, canvas_init, random_x, random_y
 
 
 def crop_and_restore(canvas_patch, canvas_mask, canvas_init, rx, ry, patch_shape, patch_shape_orig):
