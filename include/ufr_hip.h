@@ -12,8 +12,8 @@
  *     enqueues work on that stream (no allocation, no synchronisation -> hipGraph-capturable);
  *   - return value: 0 on success, a negative UFR_E* code otherwise; ufr_last_error() returns a
  *     thread-local human-readable message (mirrors TORCH_CHECK text of the reference);
- *   - dtype codes: UFR_F32 / UFR_F64 (the reference CUDA correlation also takes fp16; the
- *     attack path is fp32).
+ *   - dtype codes: UFR_F32 / UFR_F64, and UFR_F16 for the spatial correlation, which the reference's CUDA
+ *     op dispatches for half too (correlation_cuda_kernel.cu:262, :297); the attack path is fp32.
  */
 #ifndef UFR_HIP_H_
 #define UFR_HIP_H_
@@ -26,7 +26,7 @@ extern "C" {
 
 #define UFR_ABI_VERSION 3   /* 3: ufr_igemm_desc gained k_order (round 2) */
 
-enum { UFR_F32 = 0, UFR_F64 = 1 };
+enum { UFR_F32 = 0, UFR_F64 = 1, UFR_F16 = 2 };   /* UFR_F16: the spatial correlation only (generic kernels, float32 sums) */
 enum {
   UFR_OK = 0,
   UFR_EINVAL = -1,      /* bad argument (shape, dtype, null pointer) */

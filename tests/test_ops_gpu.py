@@ -127,6 +127,24 @@ def test_corr_autograd_module_and_gradcheck(ops):
     assert torch.autograd.gradcheck(sampler, [a, b])
 
 
+@pytest.mark.parametrize("case", ["corr_flownetc_small_f32", "corr_pwc_ragged_f32", "corr_rect_f32"])
+def test_corr_float16_storage(ops, case):
+    """The reference's CUDA op dispatches half as well (correlation_cuda_kernel.cu:262, :297).  Here: float16 storage,
+    float32 sums -- compared with the float32 path (pinned to the reference by the tests above) on the same half-rounded
+    inputs, at the resolution of one rounding to half; the golden's unrounded outputs bound the whole thing."""
+    z = load_golden(case)
+    prm = expand_params(z["params"])
+    a, b, go = (t(z[k], DEV).half() for k in ("input1", "input2", "grad_output"))
+    want = ops["be"].forward(a.float(), b.float(), *prm)
+    w1, w2 = ops["be"].backward(a.float(), b.float(), go.float(), *prm)
+    assert_close(want, t(z["output"]), rtol=3e-2, atol_scale=1e-2, what="rounded inputs move the output by half-epsilons only")
+    out = ops["be"].forward(a, b, *prm)
+    g1, g2 = ops["be"].backward(a, b, go, *prm)
+    assert out.dtype == g1.dtype == g2.dtype == torch.float16
+    for got, ref, what in ((out, want, "forward"), (g1, w1, "grad1"), (g2, w2, "grad2")):
+        assert_close(got.float(), ref, rtol=1e-3, atol_scale=1e-3, what=f"{case} float16 {what}")     # one rounding to half
+
+
 def test_corr_fused_epilogue(ops):
     g = torch.Generator().manual_seed(8)
     a = torch.randn(2, 16, 12, 20, generator=g).to(DEV)

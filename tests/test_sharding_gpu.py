@@ -112,3 +112,30 @@ def test_bench_two_rank_rehearsal():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                          env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
+
+
+def _rccl_rank(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    torch.cuda.set_device(DEV)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    rows_local = torch.arange(2 * 7, dtype=torch.float32, device=DEV).view(2, 7)
+    rows_all = torch.full((2, 7), -1.0, device=DEV)
+    dist.all_gather_into_tensor(rows_all, rows_local)              # the call ShardedExchange.gather makes for world > 1
+    packed = torch.ones(1 << 20, device=DEV)
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM)                  # ShardedExchange.__call__ (universal perturbation)
+    dist.barrier()
+    torch.cuda.synchronize()
+    torch.save(dict(backend=dist.get_backend(), gathered=rows_all.cpu(), reduced=float(packed.sum())),
+               os.path.join(out_dir, "rccl.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rccl_initialises_and_runs_the_exchange_collectives(tmp_path):
+    """The one-GPU box cannot run two RCCL ranks, so the N > 1 tests above move their rows over gloo.  This one brings RCCL
+    itself up on the MI355X (backend "nccl", one rank) and issues the two collectives the exchange uses on HIP tensors."""
+    mp.spawn(_rccl_rank, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(tmp_path / "rccl.pt")
+    assert r["backend"] == "nccl"
+    assert torch.equal(r["gathered"], torch.arange(14, dtype=torch.float32).view(2, 7)) and r["reduced"] == float(1 << 20)

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libufr_hip.so")
-UFR_F32, UFR_F64 = 0, 1
+UFR_F32, UFR_F64, UFR_F16 = 0, 1, 2
 _lib = None
 
 
@@ -227,7 +227,9 @@ def dtype_code(t: torch.Tensor) -> int:
         return UFR_F32
     if t.dtype == torch.float64:
         return UFR_F64
-    raise RuntimeError(f"unsupported dtype {t.dtype}: the gfx950 build implements float32 and float64")
+    if t.dtype == torch.float16:
+        return UFR_F16
+    raise RuntimeError(f"unsupported dtype {t.dtype}: the gfx950 build implements float32, float64 and (correlation only) float16")
 
 
 class EngineCache(dict):

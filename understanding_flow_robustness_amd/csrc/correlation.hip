@@ -25,7 +25,8 @@ using ufr::ceil_div;
 // ------------------------------------------------------------------------------------------------
 // generic kernels
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+// T = storage type, A = accumulation type (float for float32 / float16 storage, double for float64)
+template <typename T, typename A = T>
 __global__ void corr_fwd_generic(const T* __restrict__ in1, const T* __restrict__ in2,
                                  T* __restrict__ out, int B, int C, int H, int W, int oH, int oW,
                                  ufr_corr_params p, float scale, float slope) {
@@ -42,7 +43,7 @@ __global__ void corr_fwd_generic(const T* __restrict__ in1, const T* __restrict_
     const int u = -p.padH + h * p.dH, v = -p.padW + w * p.dW;
     const T* a = in1 + (size_t)n * C * H * W;
     const T* b = in2 + (size_t)n * C * H * W;
-    T acc = 0;
+    A acc = 0;
     for (int c = 0; c < C; ++c)
       for (int i = 0; i < p.kH; ++i) {
         const int i1 = u + i * p.dilationH, i2 = i1 + su;
@@ -50,16 +51,16 @@ __global__ void corr_fwd_generic(const T* __restrict__ in1, const T* __restrict_
         for (int j = 0; j < p.kW; ++j) {
           const int j1 = v + j * p.dilationW, j2 = j1 + sv;
           if (j1 < 0 || j1 >= W || j2 < 0 || j2 >= W) continue;
-          acc += a[((size_t)c * H + i1) * W + j1] * b[((size_t)c * H + i2) * W + j2];
+          acc += (A)a[((size_t)c * H + i1) * W + j1] * (A)b[((size_t)c * H + i2) * W + j2];
         }
       }
-    T r = acc * (T)scale;
-    out[idx] = r > (T)0 ? r : r * (T)slope;
+    const A r = acc * (A)scale;
+    out[idx] = (T)(r > (A)0 ? r : r * (A)slope);
   }
 }
 
 // One thread per input element (n,c,y,x): gathers both adjoints, no atomics.
-template <typename T>
+template <typename T, typename A = T>
 __global__ void corr_bwd_generic(const T* __restrict__ in1, const T* __restrict__ in2,
                                  const T* __restrict__ gout, T* __restrict__ gin1,
                                  T* __restrict__ gin2, int B, int C, int H, int W, int oH, int oW,
@@ -74,7 +75,7 @@ __global__ void corr_bwd_generic(const T* __restrict__ in1, const T* __restrict_
     const int n = (int)(idx / ((long)W * H * C));
     const T* a = in1 + ((size_t)n * C + c) * H * W;
     const T* b = in2 + ((size_t)n * C + c) * H * W;
-    T acc1 = 0, acc2 = 0;
+    A acc1 = 0, acc2 = 0;
     for (int ph = 0; ph < p.patchH; ++ph) {
       const int su = (ph - radH) * p.dilation_patchH;
       for (int pw = 0; pw < p.patchW; ++pw) {
@@ -83,7 +84,7 @@ __global__ void corr_bwd_generic(const T* __restrict__ in1, const T* __restrict_
         // d/d in1[y,x]: (y,x) is the in1 tap (i1,j1); partner in2 tap at (y+su, x+sv)
         const int y2 = y + su, x2 = x + sv;
         if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) {
-          T gs = 0;
+          A gs = 0;
           for (int i = 0; i < p.kH; ++i) {
             const int hn = y + p.padH - i * p.dilationH;
             if (hn < 0 || hn % p.dH) continue;
@@ -94,15 +95,15 @@ __global__ void corr_bwd_generic(const T* __restrict__ in1, const T* __restrict_
               if (wn < 0 || wn % p.dW) continue;
               const int w = wn / p.dW;
               if (w >= oW) continue;
-              gs += g[(size_t)h * oW + w];
+              gs += (A)g[(size_t)h * oW + w];
             }
           }
-          acc1 += gs * b[(size_t)y2 * W + x2];
+          acc1 += gs * (A)b[(size_t)y2 * W + x2];
         }
         // d/d in2[y,x]: (y,x) is the in2 tap (i2,j2); partner in1 tap at (y-su, x-sv)
         const int y1 = y - su, x1 = x - sv;
         if (y1 >= 0 && y1 < H && x1 >= 0 && x1 < W) {
-          T gs = 0;
+          A gs = 0;
           for (int i = 0; i < p.kH; ++i) {
             const int hn = y1 + p.padH - i * p.dilationH;
             if (hn < 0 || hn % p.dH) continue;
@@ -113,15 +114,15 @@ __global__ void corr_bwd_generic(const T* __restrict__ in1, const T* __restrict_
               if (wn < 0 || wn % p.dW) continue;
               const int w = wn / p.dW;
               if (w >= oW) continue;
-              gs += g[(size_t)h * oW + w];
+              gs += (A)g[(size_t)h * oW + w];
             }
           }
-          acc2 += gs * a[(size_t)y1 * W + x1];
+          acc2 += gs * (A)a[(size_t)y1 * W + x1];
         }
       }
     }
-    gin1[idx] = acc1;
-    gin2[idx] = acc2;
+    gin1[idx] = (T)acc1;
+    gin2[idx] = (T)acc2;
   }
 }
 
@@ -399,7 +400,7 @@ int launch_bwd_fast(const float* other, const float* gout, float* gin, int B, in
 int check_common(const void* a, const void* b, const void* c, int dtype, int B, int C, int H, int W,
                  const ufr_corr_params* p, int* oH, int* oW) {
   UFR_REQUIRE(a && b && c && p, "correlation: null pointer argument");
-  UFR_REQUIRE(dtype == UFR_F32 || dtype == UFR_F64, "correlation: unsupported dtype code %d", dtype);
+  UFR_REQUIRE(dtype == UFR_F32 || dtype == UFR_F64 || dtype == UFR_F16, "correlation: unsupported dtype code %d", dtype);
   UFR_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "correlation: empty input [%d,%d,%d,%d]", B, C, H, W);
   UFR_REQUIRE(p->kH > 0 && p->kW > 0 && p->patchH > 0 && p->patchW > 0 && p->dH > 0 && p->dW > 0 &&
                   p->dilationH > 0 && p->dilationW > 0 && p->dilation_patchH > 0 &&
@@ -440,6 +441,9 @@ extern "C" int ufr_corr_forward_fused(const void* input1, const void* input2, vo
   if (dtype == UFR_F32)
     hipLaunchKernelGGL(corr_fwd_generic<float>, dim3(grid), dim3(256), 0, st, (const float*)input1,
                        (const float*)input2, (float*)output, B, C, H, W, oH, oW, *p, scale, slope);
+  else if (dtype == UFR_F16)          // correlation_cuda_kernel.cu:262 dispatches half too; sums are kept in float32 here
+    hipLaunchKernelGGL((corr_fwd_generic<_Float16, float>), dim3(grid), dim3(256), 0, st, (const _Float16*)input1,
+                       (const _Float16*)input2, (_Float16*)output, B, C, H, W, oH, oW, *p, scale, slope);
   else
     hipLaunchKernelGGL(corr_fwd_generic<double>, dim3(grid), dim3(256), 0, st,
                        (const double*)input1, (const double*)input2, (double*)output, B, C, H, W,
@@ -482,6 +486,10 @@ extern "C" int ufr_corr_backward(const void* input1, const void* input2, const v
     hipLaunchKernelGGL(corr_bwd_generic<float>, dim3(grid), dim3(256), 0, st, (const float*)input1,
                        (const float*)input2, (const float*)grad_output, (float*)grad_input1,
                        (float*)grad_input2, B, C, H, W, oH, oW, *p);
+  else if (dtype == UFR_F16)          // correlation_cuda_kernel.cu:297
+    hipLaunchKernelGGL((corr_bwd_generic<_Float16, float>), dim3(grid), dim3(256), 0, st, (const _Float16*)input1,
+                       (const _Float16*)input2, (const _Float16*)grad_output, (_Float16*)grad_input1,
+                       (_Float16*)grad_input2, B, C, H, W, oH, oW, *p);
   else
     hipLaunchKernelGGL(corr_bwd_generic<double>, dim3(grid), dim3(256), 0, st,
                        (const double*)input1, (const double*)input2, (const double*)grad_output,
