@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define UFR_ABI_VERSION 3   /* 3: ufr_igemm_desc gained k_order (round 2) */
+#define UFR_ABI_VERSION 4   /* 4: ufr_igemm_desc gained tail / tail_n0 (round 3); 3: k_order (round 2) */
 
 enum { UFR_F32 = 0, UFR_F64 = 1, UFR_F16 = 2 };   /* UFR_F16: the spatial correlation only (generic kernels, float32 sums) */
 enum {
@@ -436,7 +436,7 @@ int ufr_host_png_unfilter(const unsigned char* data, unsigned char* out, int row
  * (y*in_sy + dy[t], x*in_sx + dx[t]) -- zero outside [0,Hi) x [0,Wi), or outside the per-sample input band
  * [in_x0[b*in_x0_stride]/in_x0_div, + in_xw) when in_x0 != NULL -- and the result lands on output pixel
  * (y*out_sy + oy0, x*out_sx + ox0) of the [B,Ho,Wo] grid.
- * Epilogue: act = 1: LeakyReLU(acc + bias) (forward); act = 0: (acc + add) * LeakyReLU'(mask) with `add` an fp32
+ * Epilogue: act = 1: LeakyReLU(acc + add + bias) (forward; `add` normally NULL); act = 0: (acc + add) * LeakyReLU'(mask) with `add` an fp32
  * chunk-major tensor and `mask` plane 0 of the activation this gradient belongs to (either may be NULL).  The result
  * goes to out_planes (at chunk out_chunk0 of a buffer whose planes are out_plane_stride elements apart) and / or
  * out_f32.  splitk > 1: the phase with the most taps is cut into `splitk` slices of K, the others into proportionally fewer
@@ -463,6 +463,10 @@ typedef struct {
   const void* mask; int mask_chunk0;
   void* out_planes; long out_plane_stride; int out_chunk0;
   float* out_f32; int out_f32_chunk0;
+  float* tail; int tail_n0;                    /* optional: output columns >= tail_n0 (a multiple of 32) leave as RAW sums into this fp32
+                                                  chunk-major tensor [(N - tail_n0) / 32 chunks][B*Ho*Wo][32] instead of passing the epilogue:
+                                                  a later layer's partial sum over the same input chunks, which that layer's own launch
+                                                  takes back as `add` (with act = 1: LeakyReLU(acc + add + bias)) */
   int splitk; float* ws;
   int products;                                /* 6: the float32-accurate six-product form (the only one) */
   int variant;                                 /* kernel form: 0 / 2 = single-stage LDS-DMA tiles (128 x 128; 128 x 64 when Npad % 128),

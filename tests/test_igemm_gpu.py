@@ -186,6 +186,36 @@ def test_split_k_equals_one_pass_and_is_reproducible():
     assert torch.equal(many.t, again.t)                         # fixed-order reduction: no atomics
 
 
+@pytest.mark.parametrize("splitk", [1, 3])
+def test_tail_columns_and_activation_with_addend(splitk):
+    """PWC-Net's DenseNet forward push (pwc_engine.py): conv_2's launch carries conv_4's partial sum over the shared input
+    chunks in its spare columns (raw fp32 `tail`), conv_4's own launch reduces over the rest and takes it back before its
+    bias: both results equal the two plain convolutions."""
+    ig = _mods()
+    B, H, W = 2, 13, 29
+    xa, xb = _rand(B, 64, H, W, seed=1), _rand(B, 96, H, W, seed=2)              # [front | shared] input chunks: 2 + 3
+    w2, b2 = _rand(96, 96, 3, 3, seed=3, scale=0.05), _rand(96, seed=4)          # conv_2 reads the shared chunks only
+    w4, b4 = _rand(32, 160, 3, 3, seed=5, scale=0.05), _rand(32, seed=6)         # conv_4 reads all five
+    xin = ig.Planes(B, H, W, 5, DEV)
+    xin.load_nchw(xa, 0)
+    xin.load_nchw(xb, 2)
+    out2, out4 = ig.Planes(B, H, W, 4, DEV), ig.Planes(B, H, W, 1, DEV)
+    out2.t.fill_(7.0)
+    part = ig.GradSum(B, H, W, 1, DEV)
+    ws = torch.empty(splitk * B * H * W * 128, device=DEV)
+    kw = dict(splitk=splitk, ws=ws) if splitk > 1 else {}
+    wi2 = ig.conv_forward_weights(torch.cat((w2, w4[:, 64:]), 0), 1, 1)
+    ig.make_launch(wi2, xin, 2, (H, W), (H, W), out_planes=out2, out_chunk0=0, bias=torch.cat((b2, torch.zeros(32, device=DEV))),
+                   tail=part, tail_n0=96, **kw)()
+    assert bool((out2.t[:, 3] == 7.0).all())                                     # the tail columns never reach the planes
+    _close(out2.to_nchw(96, 0), F.leaky_relu(F.conv2d(xb.double(), w2.double(), b2.double(), 1, 1), 0.1), "conv_2")
+    _close(part.to_nchw(32, 0, slope=1.0), F.conv2d(xb.double(), w4[:, 64:].double(), None, 1, 1), "conv_4's partial")
+    wi4 = ig.conv_forward_weights(w4[:, :64].contiguous(), 1, 1)
+    ig.make_launch(wi4, xin, 0, (H, W), (H, W), out_planes=out4, bias=b4, add=part, add_chunk0=0, **kw)()
+    want = F.leaky_relu(F.conv2d(torch.cat((xa, xb), 1).double(), w4.double(), b4.double(), 1, 1), 0.1)
+    _close(out4.to_nchw(32, 0), want, "conv_4")
+
+
 def test_column_band_rows_and_input_band():
     """Rows restricted to a per-sample column band (origins in device memory): only the band's columns are written, with
     the full-frame result; an input band makes columns outside it read as zero."""

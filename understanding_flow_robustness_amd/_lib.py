@@ -14,6 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libufr_hip.so")
 UFR_F32, UFR_F64, UFR_F16 = 0, 1, 2
+ABI_VERSION = 4            # UFR_ABI_VERSION of include/ufr_hip.h these ctypes mirrors were written against
 _lib = None
 
 
@@ -67,6 +68,7 @@ class IgemmDesc(C.Structure):
                 ("mask", C.c_void_p), ("mask_chunk0", C.c_int),
                 ("out_planes", C.c_void_p), ("out_plane_stride", C.c_long), ("out_chunk0", C.c_int),
                 ("out_f32", C.c_void_p), ("out_f32_chunk0", C.c_int),
+                ("tail", C.c_void_p), ("tail_n0", C.c_int),
                 ("splitk", C.c_int), ("ws", C.c_void_p),
                 ("products", C.c_int), ("variant", C.c_int), ("k_order", C.c_int)]
 
@@ -195,6 +197,9 @@ def lib():
         for name, (res, args) in PLAIN.items():
             fn = getattr(handle, name)
             fn.argtypes, fn.restype = args, res
+        if handle.ufr_abi_version() != ABI_VERSION:      # a stale .so with another ufr_igemm_desc layout would read garbage
+            raise RuntimeError(f"{LIB_PATH} has ABI version {handle.ufr_abi_version()}, these bindings are written for "
+                               f"{ABI_VERSION}: rebuild it (`make -C understanding_flow_robustness_amd/csrc`)")
         _lib = handle
     return _lib
 

@@ -61,13 +61,19 @@ struct Epilogue {
   const __bf16* mask; int mask_chunk0;
   __bf16* out_planes; long out_plane_stride; int out_chunk0;
   float* out_f32; int out_f32_chunk0;
+  float* tail; int tail_n0;           // columns >= tail_n0 (a multiple of 32): raw sums to this fp32 chunk-major tensor (no bias / act)
   long Mout; int N, Nchunks32;        // channels < Nchunks32*32 are written (zeros beyond N: the chunk's padding)
 };
 
 __device__ __forceinline__ void epilogue_store(const Epilogue& e, long pout, int n, float v) {
   if (n >= e.Nchunks32 * 32) return;
+  if (e.tail && n >= e.tail_n0) {
+    e.tail[((long)((n - e.tail_n0) >> 5) * e.Mout + pout) * 32 + (n & 31)] = n < e.N ? v : 0.f;
+    return;
+  }
   const long cm = ((long)(n >> 5) * e.Mout + pout) * 32 + (n & 31);          // chunk-major element inside a tensor
   if (e.act) {
+    if (e.add) v += e.add[(long)e.add_chunk0 * e.Mout * 32 + cm];
     v += (n < e.N) ? e.bias[n] : 0.f;
     v = v > 0.f ? v : v * e.slope;
   } else {
@@ -96,8 +102,22 @@ __device__ __forceinline__ long out_pixel(const RowGeom& g, int pm, int oy0, int
 // Eight consecutive channels of one output pixel through the epilogue (n0 a multiple of 8): 16-byte accesses.
 __device__ __forceinline__ void epilogue_store8(const Epilogue& e, long pout, int n0, float v[8]) {
   if (n0 >= e.Nchunks32 * 32) return;
+  if (e.tail && n0 >= e.tail_n0) {       // a later layer's partial sum over the same input chunks (DenseNet forward push)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (n0 + j >= e.N) v[j] = 0.f;
+    float* tp = e.tail + ((long)((n0 - e.tail_n0) >> 5) * e.Mout + pout) * 32 + (n0 & 31);
+    *reinterpret_cast<float4*>(tp) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(tp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    return;
+  }
   const long cm = ((long)(n0 >> 5) * e.Mout + pout) * 32 + (n0 & 31);
   if (e.act) {
+    if (e.add) {                         // the partial sum an earlier launch left in its tail columns
+      const float* ap = e.add + (long)e.add_chunk0 * e.Mout * 32 + cm;
+      const float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
+      v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       v[j] += (n0 + j < e.N) ? e.bias[n0 + j] : 0.f;
@@ -1111,6 +1131,7 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   UFR_REQUIRE(d->splitk == 1 || d->ws, "igemm: split-K needs a workspace");
   UFR_REQUIRE(d->out_planes || d->out_f32, "igemm: no output");
   UFR_REQUIRE(!d->act || d->bias, "igemm: the forward epilogue needs the bias");
+  UFR_REQUIRE(!d->tail || (d->tail_n0 > 0 && d->tail_n0 % 32 == 0 && d->tail_n0 < d->N), "igemm: bad tail column");
   UFR_REQUIRE(!d->row_x0 || (d->row_x0_div > 0), "igemm: bad band divisor");
   UFR_REQUIRE(!d->in_x0 || (d->in_x0_div > 0 && d->in_xw > 0), "igemm: bad input band");
   const long M = (long)d->B * d->Hr * d->Wr;
@@ -1133,6 +1154,7 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   a.e.mask = static_cast<const __bf16*>(d->mask); a.e.mask_chunk0 = d->mask_chunk0;
   a.e.out_planes = static_cast<__bf16*>(d->out_planes); a.e.out_plane_stride = d->out_plane_stride; a.e.out_chunk0 = d->out_chunk0;
   a.e.out_f32 = d->out_f32; a.e.out_f32_chunk0 = d->out_f32_chunk0;
+  a.e.tail = d->tail; a.e.tail_n0 = d->tail_n0;
   a.e.Mout = (long)d->B * d->Ho * d->Wo; a.e.N = d->N; a.e.Nchunks32 = (d->N + 31) / 32;
   a.nphase = d->nphase; a.splitk = d->splitk; a.ws = d->ws;
   a.xcd = 1;                              // XCD-aware tile order (off: +0.2 ms per iteration, profiles/r2_bench_engine_v4_no_xcd_order)

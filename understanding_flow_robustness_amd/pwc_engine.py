@@ -197,7 +197,7 @@ class PwcHeadEngine:
             plan(("pyr", k, 1), "bwd", ig.conv_backward_weights(w[1], 1, 1), self.gzFaa[k], 0, k, k, mask=self.Fa[k], out_planes=self.gzFa[k])
             plan(("pyr", k, 0), "bwd", ig.conv_backward_weights(w[0], 2, 1), self.gzFa[k], 0, k, k - 1, out_f32=self.T[k - 1])
         # ---- decoder stages ------------------------------------------------------------------------------------------------
-        self.D, self.gzD, self.G_D, self.G_x = {}, {}, {}, {}
+        self.D, self.gzD, self.G_D, self.G_x, self.P4 = {}, {}, {}, {}, {}
         self.x_nchw, self.gx_nchw, self.corr, self.g_corr = {}, {}, {}, {}
         self.flow = {k: Z(B, 2, k) for k in range(2, 7)}
         self.g_flow = {k: Z(B, 2, k) for k in range(2, 7)}
@@ -227,9 +227,25 @@ class PwcHeadEngine:
                 pre = (X0 - (A_OFF[i - 1] if i else X0)) * 32          # channels of conv_{i-1} .. conv_0 in front of x
                 wref = self._conv(f"conv{k}_{i}").weight
                 wbuf[i] = _remap_in(wref, list(range(pre)) + [pre + m for m in xmap], pre + xw)
+            # DenseNet forward push: conv_2 has 96 outputs (a quarter of its 128-column tiles would be padding) and conv_4 has 32
+            # behind the longest reduction of the block (half of a 64-column tile).  conv_4's sum over the chunks conv_2 reads
+            # anyway ([conv_1 | conv_0 | x]) rides in conv_2's spare columns as a raw fp32 partial (`tail`); conv_4's own launch
+            # then reduces over [conv_3 | conv_2] only and takes the partial back before its bias.
+            self.P4[k] = G(B, k, 1)
+            skip = (A_OFF[1] - A_OFF[3]) * 32                          # conv_4's input channels in front of conv_1: conv_3, conv_2
+            for i in range(5):
                 c0 = A_OFF[i - 1] if i else X0
-                plan(("dec", k, i), "fwd", ig.conv_forward_weights(wbuf[i], 1, 1), self.D[k], c0, k, k, out_planes=self.D[k],
-                     out_chunk0=A_OFF[i], bias=bias(f"conv{k}_{i}"))
+                w, kw = wbuf[i], {}
+                if i == 2:
+                    w = torch.cat((wbuf[2], wbuf[4][:, skip:]), 0)     # [96 + 32, conv_1 | conv_0 | x, 3, 3]
+                    b2 = torch.cat((bias(f"conv{k}_2"), torch.zeros(SEG[4], **f32)))
+                    kw = dict(tail=self.P4[k], tail_n0=SEG[2], bias=b2)
+                elif i == 4:
+                    w = wbuf[4][:, :skip].contiguous()
+                    kw = dict(add=self.P4[k], add_chunk0=0)
+                kw.setdefault("bias", bias(f"conv{k}_{i}"))
+                plan(("dec", k, i), "fwd", ig.conv_forward_weights(w, 1, 1), self.D[k], c0, k, k, out_planes=self.D[k],
+                     out_chunk0=A_OFF[i], **kw)
             full_map = list(range(X0 * 32)) + [X0 * 32 + m for m in xmap]
             pf = getattr(net, f"predict_flow{k}")
             wpf = _remap_in(pf.weight, full_map, nch * 32)
