@@ -102,6 +102,10 @@ def event_time(fn, iters, warm=2):
     return s.elapsed_time(e) / iters
 
 
+# PMC summaries of the latest passes over this command (tools/gpu_call.sh `traffic` step -> tools/pmc_step_traffic.py)
+IGEMM_TRAFFIC, STEP_TRAFFIC, CORR_TRAFFIC = "r3_igemm_traffic.json", "r3_step_traffic.json", "r3_corr_planes_traffic.json"
+
+
 def _pmc(name):
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -117,7 +121,7 @@ def kernel_rooflines(step, device, max_count):
     from understanding_flow_robustness_amd import spatial_correlation_sampler_backend as be
     B = B_PER_GPU
     ks = []
-    traffic = _pmc("r2_igemm_traffic.json")           # HBM-side bytes per launch from the PMC passes (rocprofv3 only)
+    traffic = _pmc(IGEMM_TRAFFIC)                     # HBM-side bytes per launch from the PMC passes (rocprofv3 only)
     # ---- the head's convolutions: every prepared igemm launch of the engine the step runs
     eng = None
     for e in getattr(step.net, "__dict__", {}).get("_ufr_head_engines", {}).values():
@@ -130,15 +134,15 @@ def kernel_rooflines(step, device, max_count):
             t = event_time(launch, 10)
             tf = gflop / t
             key = f"igemm {name} {kind} ({tag})"
-            per[(name, kind, tag)] = (t, gflop)
+            per[(name, kind, tag)] = (t, gflop, launch.algorithmic_bytes())
             ks.append(dict(kernel=key, ms=round(t, 4), bound="mfma", achieved=round(tf, 1), peak=round(PEAK_SPLIT6_TFLOPS, 1),
                            unit="TFLOP/s", frac=round(tf / PEAK_SPLIT6_TFLOPS, 3), gflop=round(gflop, 2),
                            traffic=traffic.get(key)))
         # one average iteration of an attack() call of `max_count` iterations: the first runs the full forward, later
         # ones the band's columns of conv_redir / conv3_1 / conv4 / conv4_1; five data gradients always run on the band
         banded = bool(eng.bwd_band)
-        t_sum = g_sum = 0.0
-        for (name, kind, tag), (t, gflop) in per.items():
+        t_sum = g_sum = b_sum = 0.0
+        for (name, kind, tag), (t, gflop, nbytes) in per.items():
             if tag == "window":
                 w = 1.0
             elif tag == "prefix":              # full-frame conv2 / conv3 of load(): once per attack() call
@@ -151,7 +155,8 @@ def kernel_rooflines(step, device, max_count):
                 w = (0.0 if has_band else 1.0) if tag == "full" else 1.0
             t_sum += w * t
             g_sum += w * gflop
-        agg = dict(ms=t_sum, gflop=g_sum)
+            b_sum += w * nbytes
+        agg = dict(ms=t_sum, gflop=g_sum, bytes=b_sum)
     # ---- correlation
     a = torch.randn(B, 256, H // 8, W // 8, device=device)
     b = torch.randn(B, 256, H // 8, W // 8, device=device)
@@ -170,7 +175,7 @@ def kernel_rooflines(step, device, max_count):
         nbytes = B * h8 * w8 * (2 * 256 + 441) * 6
         ks.append(dict(kernel="corr_fwd_planes_k2_kernel<5> (21x21 cost volume, / C, LeakyReLU, planes in / out)", ms=round(t_f, 4), bound="mfma",
                        achieved=round(tf, 2), peak=PEAK_FP32_TFLOPS, unit="TFLOP/s", frac=round(tf / PEAK_FP32_TFLOPS, 4),
-                       hbm_gbs=round(nbytes / t_f / 1e6, 1), traffic=_pmc("r2_corr_planes_traffic.json").get("traffic_bytes"),
+                       hbm_gbs=round(nbytes / t_f / 1e6, 1), traffic=_pmc(CORR_TRAFFIC).get("traffic_bytes"),
                        algorithmic_bytes=int(nbytes),
                        note="useful fp32 flops against the fp32 vector peak; on the matrix cores 44 % of the six-product MFMA work lies in the band"))
     else:
@@ -204,7 +209,7 @@ def kernel_rooflines(step, device, max_count):
     ks.append(dict(kernel=name, ms=round(t_w, 4), bound="hbm",
                    achieved=round(bytes_w / t_w / 1e6, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                    frac=round(bytes_w / t_w / 1e6 / PEAK_HBM_GBS, 4), tflops=round(GFLOP_CORR_BWD_WINDOW * B / t_w, 2),
-                   traffic=_pmc("r2_corr_window_traffic.json").get("traffic_bytes"), algorithmic_bytes=int(bytes_w)))
+                   traffic=_pmc("r3_corr_window_traffic.json").get("traffic_bytes"), algorithmic_bytes=int(bytes_w)))
     # ---- the 2-channel layers of the refinement (HBM-bound: one pass over the concatenation's planes)
     if eng is not None:
         for k in (6, 5, 4, 3, 2):
@@ -231,9 +236,9 @@ def kernel_rooflines(step, device, max_count):
 
 def step_traffic():
     """HBM-side bytes of one iteration of the windowed step from this round's PMC passes
-    (tools/pmc_step_traffic.py -> profiles/r2_step_traffic.json); counters cannot be read live."""
+    (tools/pmc_step_traffic.py -> profiles/r3_step_traffic.json); counters cannot be read live."""
     try:
-        return int(_pmc("r2_step_traffic.json")["traffic_bytes_per_iteration"])
+        return int(_pmc(STEP_TRAFFIC)["traffic_bytes_per_iteration"])
     except (KeyError, ValueError):
         return None
 
@@ -352,8 +357,6 @@ def main():
     torch.backends.cudnn.benchmark = True      # patch_attacks/main.py:276 (MIOpen find mode)
     args = Namespace(flownet="FlowNetC", l2=False, alpha=0.0, lr=1000.0, max_count=2)
     net = fetch_model(args, synthetic_seed=0).to(device)
-    if os.environ.get("UFR_CHANNELS_LAST", "0") == "1":      # layout experiment
-        net = net.to(memory_format=torch.channels_last)
     exchange = ShardedExchange() if world > 1 else None
     step = PatchAttackStep(net, args, B_PER_GPU, H, W, device=device, shared_patch=True, exchange=exchange,
                            use_graph=not opt.no_graph, warmup=2, patch_hw=(PATCH, PATCH))
@@ -461,7 +464,8 @@ def main():
                 line["roofline"] = {"bound": "mfma", "kernel": "igemm (csrc/igemm.hip), all launches of one iteration",
                                     "achieved": round(tf_i, 1), "peak": round(PEAK_SPLIT6_TFLOPS, 1), "unit": "TFLOP/s",
                                     "frac": round(tf_i / PEAK_SPLIT6_TFLOPS, 3),
-                                    "traffic": _pmc("r2_igemm_traffic.json").get("per_iteration_bytes"),
+                                    "traffic": _pmc(IGEMM_TRAFFIC).get("per_iteration_bytes"),
+                                    "algorithmic_bytes_per_iteration": round(agg["bytes"]),
                                     "ms_per_iteration": round(agg["ms"], 3), "algorithmic_gflop_per_iteration": round(agg["gflop"], 1),
                                     "peak_note": "fp32-equivalent: 2.5 PFLOP/s dense bf16 MFMA / 6 products per float32 product",
                                     "step": step_line}

@@ -62,8 +62,8 @@ def test_raft_vs_reference(alternate):
     # Flow / EPE hold the 1e-4 gate (measured 6e-7).  RAFT's IMAGE GRADIENT at random init is
     # ill-conditioned: through the instance-normalised encoder and 12 recurrent lookups, two fp32
     # evaluation orders on the same CPU already differ by 1e-3 and fp32 vs fp64 by 3e-4
-    # (tools/diag_raft2.py); MIOpen vs oneDNN lands at ~2e-2 of the gradient's max.  The HIP lookup
-    # itself matches torch's grid_sample formulation to 6e-6 on the same device (tools/diag_raft.py).
+    # (profiles/r2_raft_f64_diag.txt); MIOpen vs oneDNN lands at ~2e-2 of the gradient's max.  The HIP lookup
+    # itself matches torch's grid_sample formulation to 6e-6 on the same device (profiles/r2_raft_f64_diag.txt).
     _check(z, net, args, gtol=5e-2, g_atol=5e-2)
     _attack_check(z, net, args, "attack_it2_patch", 1e4, 2, tol=5e-2)
 

@@ -8,6 +8,7 @@
 #   stats[:flags]    rocprofv3 --kernel-trace --stats of bench.py <flags> + the summaries under the same directory
 #   trace:<tag>,<iters>,<script>,<args>   rocprofv3 --kernel-trace of a python tool + steady-state table (tools/summarize_trace.py;
 #                    env:TRACE_MARKER=<kernel> names the last kernel of an iteration, default gate_kernel)
+#   traffic:<tag>,<iters>,<script>,<args>   two --pmc passes (FETCH_SIZE / WRITE_SIZE) + tools/pmc_step_traffic.py
 #   configs:<list>   tools/bench_configs.py <list>
 #   py:<script args> python <script args>
 set -o pipefail
@@ -41,6 +42,17 @@ for step in "$@"; do
              ft=$(find $out/trace_$tag -name "*kernel_trace.csv" | head -n 1)
              [ -n "$ft" ] && python tools/summarize_trace.py $ft $iters ${TRACE_MARKER:-gate_kernel} > $out/${tag}_step_trace.md && sed -n "1,/^last iteration/p" $out/${tag}_step_trace.md | head -n 45
              rm -rf $out/trace_$tag ;;
+    traffic) # traffic:<tag>,<iters>,<script>,<args...>: HBM bytes per iteration from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
+             # each with --kernel-trace only), summed by tools/pmc_step_traffic.py (env:TRACE_MARKER as for trace)
+             set -- $arg; tag=$1; iters=$2; shift 2
+             for ctr in FETCH_SIZE WRITE_SIZE; do
+               (cd /tmp && timeout -k 10 900 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_${tag}_$ctr -- python $GRAFT_REPO_ROOT/$1 "${@:2}" > $GRAFT_REPO_ROOT/$out/pmc_${tag}_$ctr.log 2>&1); rc=$?
+               [ $rc -ne 0 ] && { tail -n 20 $out/pmc_${tag}_$ctr.log; exit $rc; }
+             done
+             ff=$(find /tmp/pmc_${tag}_FETCH_SIZE -name "*counter_collection.csv" | head -n 1); fw=$(find /tmp/pmc_${tag}_WRITE_SIZE -name "*counter_collection.csv" | head -n 1)
+             python tools/pmc_step_traffic.py $ff $fw $iters $out/${tag}_igemm_traffic.json $out ${TRACE_MARKER:-gate_kernel} > $out/${tag}_step_traffic.json; rc=$?
+             [ $rc -ne 0 ] && exit $rc
+             head -n 12 $out/${tag}_step_traffic.json; cat $out/${tag}_igemm_traffic.json ;;
     configs) timeout -k 10 1100 python tools/bench_configs.py $arg > $out/configs.log 2>&1; rc=$?; tail -n 12 $out/configs.log
              [ $rc -ne 0 ] && exit $rc ;;
     env)     export $arg ;;                      # env:NAME=VALUE for the steps behind it

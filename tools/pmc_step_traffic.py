@@ -14,13 +14,16 @@ import sys
 from collections import defaultdict
 
 
+MARKER = ["gate_kernel"]
+
+
 def per_iteration(path, counter, iters):
     rows = [r for r in csv.DictReader(open(path)) if r.get("Counter_Name", r.get("counter_name")) == counter]
     key = lambda r, *names: next(r[n] for n in names if n in r)
     rows.sort(key=lambda r: int(key(r, "Dispatch_Id", "dispatch_id")))
     names = [key(r, "Kernel_Name", "kernel_name") for r in rows]
     vals = [float(key(r, "Counter_Value", "counter_value")) for r in rows]
-    marks = [i for i, n in enumerate(names) if "gate_kernel" in n]
+    marks = [i for i, n in enumerate(names) if MARKER[0] in n]
     if len(marks) < iters + 1:
         raise SystemExit(f"{path}: only {len(marks)} iterations recorded")
     lo, hi = marks[-iters - 1] + 1, marks[-1] + 1
@@ -31,7 +34,8 @@ def per_iteration(path, counter, iters):
 
 
 # kernels launched once per iteration whose per-launch traffic bench.py quotes beside its live timing
-SINGLE = {"corr_fwd_planes": "r2_corr_planes_traffic.json", "corr_bwd_window_mfma_kernel": "r2_corr_window_traffic.json"}
+SINGLE = {"corr_fwd_planes": "corr_planes_traffic.json", "corr_bwd_window_mfma_kernel": "corr_window_traffic.json",
+          "altcorr_mfma_fwd": "altcorr_fwd_traffic.json", "altcorr_mfma_bwd2": "altcorr_bwd2_traffic.json"}
 
 
 def main(fetch_csv, write_csv, iters, igemm_out=None, single_dir=None):
@@ -43,7 +47,7 @@ def main(fetch_csv, write_csv, iters, igemm_out=None, single_dir=None):
             wk = sum(v for k, v in w_k.items() if pat in k)
             if fk or wk:
                 with open(f"{single_dir}/{name}", "w") as f:
-                    json.dump({"_provenance": f"{pat}: the same two rocprofv3 --pmc passes as r2_step_traffic.json, one launch per "
+                    json.dump({"_provenance": f"{pat}: the same two rocprofv3 --pmc passes as the step traffic file, one launch per "
                                               "iteration; KB -> bytes, FETCH_SIZE x2 per MI355X_MICROARCH.md",
                                "fetch_bytes": round(2.0 * fk * 1024), "write_bytes": round(wk * 1024),
                                "traffic_bytes": round(2.0 * fk * 1024 + wk * 1024)}, f, indent=1)
@@ -52,7 +56,7 @@ def main(fetch_csv, write_csv, iters, igemm_out=None, single_dir=None):
         fi = sum(v for k, v in f_k.items() if "igemm" in k)
         wi = sum(v for k, v in w_k.items() if "igemm" in k)
         with open(igemm_out, "w") as f:
-            json.dump({"_provenance": "igemm_* dispatches of the same two rocprofv3 --pmc passes as r2_step_traffic.json, per "
+            json.dump({"_provenance": "igemm_* dispatches of the same two rocprofv3 --pmc passes as the step traffic file, per "
                                       "iteration; KB -> bytes, FETCH_SIZE x2 per MI355X_MICROARCH.md",
                        "fetch_bytes": round(2.0 * fi * 1024), "write_bytes": round(wi * 1024),
                        "per_iteration_bytes": round(2.0 * fi * 1024 + wi * 1024)}, f, indent=1)
@@ -69,5 +73,7 @@ def main(fetch_csv, write_csv, iters, igemm_out=None, single_dir=None):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 6:
+        MARKER[0] = sys.argv[6]          # the last kernel of an iteration (universal_update_kernel for the perturbation step)
     main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 4, sys.argv[4] if len(sys.argv) > 4 else None,
          sys.argv[5] if len(sys.argv) > 5 else None)

@@ -221,24 +221,9 @@ namespace ufr {
 int corr_bwd_mfma_launch(const float* in1, const float* in2, const float* gout, float* gin1, float* gin2,
                          int B, int C, int H, int W, int P, int DP, hipStream_t st) {
   if (W % 4 != 0) return 1;
-  // tuning knob: (channels per workgroup, groups per wave); default = measured best (tools/microbench.py)
-  static const int cfg = [] { const char* e = getenv("UFR_CORR_MFMA_CFG"); return e ? atoi(e) : 0; }();
-  if (P == 21 && DP == 2) {
-    switch (cfg) {
-      case 1: return launch_pair<21, 2, 32, 1>(in1, in2, gout, gin1, gin2, B, C, H, W, st);
-      case 2: return launch_pair<21, 2, 64, 2>(in1, in2, gout, gin1, gin2, B, C, H, W, st);
-      case 3: return launch_pair<21, 2, 64, 1>(in1, in2, gout, gin1, gin2, B, C, H, W, st);
-      default: return launch_pair<21, 2, 32, 2>(in1, in2, gout, gin1, gin2, B, C, H, W, st);
-    }
-  }
-  if (P == 9 && DP == 1) {
-    switch (cfg) {
-      case 1: return launch_pair<9, 1, 32, 1>(in1, in2, gout, gin1, gin2, B, C, H, W, st);
-      case 2: return launch_pair<9, 1, 64, 2>(in1, in2, gout, gin1, gin2, B, C, H, W, st);
-      case 3: return launch_pair<9, 1, 64, 1>(in1, in2, gout, gin1, gin2, B, C, H, W, st);
-      default: return launch_pair<9, 1, 32, 2>(in1, in2, gout, gin1, gin2, B, C, H, W, st);
-    }
-  }
+  // (channels per workgroup, groups per wave) = (32, 2): the measured best of {32, 64} x {1, 2}
+  if (P == 21 && DP == 2) return launch_pair<21, 2, 32, 2>(in1, in2, gout, gin1, gin2, B, C, H, W, st);
+  if (P == 9 && DP == 1) return launch_pair<9, 1, 32, 2>(in1, in2, gout, gin1, gin2, B, C, H, W, st);
   return 1;
 }
 

@@ -36,9 +36,6 @@ __device__ __forceinline__ void split3(float v, __bf16& a, __bf16& b, __bf16& c)
 constexpr int P = 21, R = 10, KCH = 8;           // 21 displacements per axis, reach 10 same-parity columns, 8 chunks of 32 channels
 constexpr int OT = 24;                            // per-wave output tile: 16 columns x 21 displacements, row stride 24 floats
 
-template <int NW>
-constexpr int corr_planes_lds_bytes() { return 3 * 3 * (16 * NW + 32) * 32 * 2 + NW * 16 * OT * 4; }
-
 // f1, f2: planes [3][KCH][M][32] (M = B*H*W); out: planes [3][out_chunks][M][32], channels written at chunk out_chunk0 + d / 32.
 // grid = (column blocks, 2 parities, B*H); block = NW waves; ONE workgroup per CU is resident (5 waves x 165 VGPRs), so all
 // overlap is built into the workgroup:
@@ -49,155 +46,15 @@ constexpr int corr_planes_lds_bytes() { return 3 * 3 * (16 * NW + 32) * 32 * 2 +
 //  * the nine B fragments of a stage are read in one batch, then 18 MFMAs;
 //  * a displacement row's 16 x 21 results per wave go through a wave-private LDS tile and leave as dense 2-byte stores
 //    (18 instructions instead of 36 quarter-full ones), BEFORE the stage's DMA is issued so the counted wait stays exact.
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void corr_fwd_planes_kernel(const __bf16* __restrict__ f1, const __bf16* __restrict__ f2,
-                                                                  long in_plane_stride, __bf16* __restrict__ out,
-                                                                  long out_plane_stride, int out_chunk0, int B, int H, int W,
-                                                                  float scale, float slope) {
-  constexpr int NJ = 16 * NW + 32;               // staged source columns: [i0 - 16, i0 + 16 NW + 16)
-  constexpr int NRB = NJ / 16;                   // 16-column row blocks of a stage (= NW + 2)
-  constexpr int PLANE = NJ * 32, BUF = 3 * PLANE;                         // elements
-  extern __shared__ __attribute__((aligned(16))) unsigned char corr_lds[];
-  __bf16* lds = reinterpret_cast<__bf16*>(corr_lds);                     // [3 buffers][3 planes][NJ * 32]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float* otile = reinterpret_cast<float*>(corr_lds + 3 * BUF * 2) + wave * 16 * OT;
-  // Workgroup -> (row, parity, column block).  The hardware deals consecutive workgroups round-robin to the 8 XCDs, each
-  // with its own 4 MB L2; a row of f2 is read by the 2 x 21 workgroups of the rows around it, so neighbouring rows must
-  // land on the SAME XCD: XCD k takes the k-th eighth of the (row, parity, block) list (a bijection when 8 divides it).
-  const int nblk = gridDim.x * gridDim.y * gridDim.z;
-  int item = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-  if ((nblk & 7) == 0) item = (item & 7) * (nblk >> 3) + (item >> 3);
-  const int bx = item % gridDim.x, par = (item / gridDim.x) % gridDim.y, by = item / (gridDim.x * gridDim.y);
-  const int b = by / H, y = by - b * H;
-  const int i0 = bx * 16 * NW;
-  const long M = (long)B * H * W;
-  const long rowbase = ((long)b * H + y) * W;
-  // ---- this wave's f1 fragments: row = column i0 + 16 wave + (lane & 15), k group lane >> 4
-  const int ai = i0 + 16 * wave + (lane & 15), ax = 2 * ai + par;
-  const bool a_ok = ax < W;
-  const __bf16* zero = reinterpret_cast<const __bf16*>(corr_zero_page);
-  bf16x8 fa[KCH][3];
-#pragma unroll
-  for (int kc = 0; kc < KCH; ++kc)
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      const __bf16* src = a_ok ? f1 + p * in_plane_stride + ((long)kc * M + rowbase + ax) * 32 + (lane >> 4) * 8 : zero;
-      fa[kc][p] = *reinterpret_cast<const bf16x8*>(src);
-    }
-  // ---- staging plan of this wave: row blocks wave and wave + NW; per lane one 16-byte piece of one column
-  const int srow_in = lane >> 2, spiece = lane & 3;
-  int voff[2];                                   // element offset inside a source row's chunk, -1 = outside the frame
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int rb = wave + it * NW, r = rb * 16 + srow_in;
-    const int j = i0 - 16 + r, xs = 2 * j + par;
-    voff[it] = (rb < NRB && j >= 0 && xs < W) ? xs * 32 + ((spiece ^ ((r >> 1) & 3)) << 3) : -1;
-  }
-  const bool two = wave + NW < NRB;              // uniform: this wave issues 6 (else 3) DMA instructions per stage
-  const int frow = lane & 15;
-  const int foff = frow * 32 + (((lane >> 4) ^ ((frow >> 1) & 3)) << 3);
-  auto stage = [&](int dy, int kc, int buf) {    // LDS-DMA of chunk kc of source row y + 2 (dy - R) into buffer `buf`
-    const __bf16* sbase = f2 + ((long)kc * M + ((long)b * H + (y + 2 * (dy - R))) * W) * 32;      // uniform
-    __bf16* dst = lds + buf * BUF + wave * 16 * 32;
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-      glds16(voff[0] >= 0 ? sbase + p * in_plane_stride + voff[0] : zero, dst + p * PLANE);
-    if (two) {
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-        glds16(voff[1] >= 0 ? sbase + p * in_plane_stride + voff[1] : zero, dst + p * PLANE + NW * 16 * 32);
-    }
-  };
-  // Displacement rows are independent, so every workgroup walks them in a ROTATED order chosen so that all rows y of one
-  // parity read the SAME source row at the same step (row y + 2 (dy - 10) with dy = (t - y / 2) mod 21 is 2 t - 20 or
-  // 2 t + 22 for every y): the workgroups resident on an XCD share each fetched row through its L2.
-  const int rot = (P - (y >> 1) % P) % P;
-  auto dy_at = [&](int t) { const int d = t + rot; return d >= P ? d - P : d; };
-  auto row_ok = [&](int dy) { const int y2 = y + 2 * (dy - R); return y2 >= 0 && y2 < H; };
-  auto next_valid = [&](int t) { do { ++t; } while (t < P && !row_ok(dy_at(t))); return t; };
-  // one displacement row of this wave's 16 columns -> planes, through the wave's LDS tile
-  auto write_row = [&](int d_row, const f32x4 (&acc)[3], bool zeros) {
-    if (!zeros) {
-#pragma unroll
-      for (int tt = 0; tt < 3; ++tt)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int il = (lane >> 4) * 4 + rg;                      // output column inside the wave
-          const int dx = 16 * tt - 16 + (lane & 15) - il + R;        // j - i + 10
-          if (dx >= 0 && dx < P) otile[il * OT + dx] = acc[tt][rg];
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      const int e = lane + 64 * q;                                  // 16 x 21 = 336 results
-      const int il = e / P, dx = e - il * P;
-      const int x = 2 * (i0 + 16 * wave + il) + par;
-      if (e < 16 * P && x < W) {
-        float v = zeros ? 0.f : otile[il * OT + dx] * scale;
-        v = v > 0.f ? v : v * slope;
-        __bf16 p0, p1, p2;
-        split3(v, p0, p1, p2);
-        const int d = d_row * P + dx;
-        __bf16* o = out + ((long)(out_chunk0 + (d >> 5)) * M + rowbase + x) * 32 + (d & 31);
-        o[0] = p0;
-        o[out_plane_stride] = p1;
-        o[2 * out_plane_stride] = p2;
-      }
-    }
-  };
-  const f32x4 zacc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  for (int d0 = 0; d0 < P; ++d0)                  // source rows outside the frame: zero channels
-    if (!row_ok(d0)) write_row(d0, zacc, true);
-  int t = next_valid(-1);
-  if (t >= P) return;                             // (cannot happen: dy = 10 reads the row itself)
-  // ---- prologue: stages 0 and 1 in flight, stage 0 retired
-  int cur = 0;                                    // buffer of the stage being computed
-  stage(dy_at(t), 0, 0);
-  stage(dy_at(t), 1, 1);
-  if (two) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  while (t < P) {
-    const int dy = dy_at(t), tn = next_valid(t);
-    f32x4 acc[3];
-#pragma unroll
-    for (int tt = 0; tt < 3; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kc = 0; kc < KCH; ++kc) {           // unrolled: fa[] indexed statically
-      // the stage two ahead: chunk kc + 2 of this row, or chunk kc + 2 - 8 of the next valid row
-      const bool ahead = kc + 2 < KCH || tn < P;
-      const int nxt = cur == 0 ? 2 : cur - 1;    // (cur + 2) % 3
-      if (kc != KCH - 1 && ahead) stage(kc + 2 < KCH ? dy : dy_at(tn), (kc + 2) & (KCH - 1), nxt);
-      bf16x8 fb[3][3];
-      const __bf16* bsrc = lds + cur * BUF + wave * 16 * 32 + foff;
-#pragma unroll
-      for (int tt = 0; tt < 3; ++tt)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) fb[tt][p] = *reinterpret_cast<const bf16x8*>(bsrc + p * PLANE + tt * 16 * 32);
-#pragma unroll
-      for (int q = 0; q < 6; ++q)                // the three tiles' accumulation chains interleaved: no back-to-back dependence
-#pragma unroll
-        for (int tt = 0; tt < 3; ++tt)
-          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kc][PROD_A[q]], fb[tt][PROD_B[q]], acc[tt], 0, 0, 0);
-      if (kc == KCH - 1) {                        // the row is complete: its stores go out BEFORE the next DMA is issued,
-        write_row(dy, acc, false);                // so the youngest `n` memory operations below are exactly that DMA
-        if (ahead) stage(dy_at(tn), 1, nxt);
-      }
-      // retire the stage computed NEXT (issued one iteration ago); leave the one just issued in flight
-      if (ahead) {
-        if (two) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      cur = cur == 2 ? 0 : cur + 1;
-    }
-    t = tn;
-  }
-}
-
-// ---- the same kernel with the reduction split over TWO waves per tile --------------------------------------------------
+// Workgroup -> (row, parity, column block).  The hardware deals consecutive workgroups round-robin to the 8 XCDs, each with
+// its own 4 MB L2; a row of f2 is read by the 2 x 21 workgroups of the rows around it, so neighbouring rows must land on the
+// SAME XCD: XCD k takes the k-th eighth of the (row, parity, block) list (a bijection when 8 divides it).
+// Displacement rows are independent, so every workgroup walks them in a ROTATED order chosen so that all rows y of one parity
+// read the SAME source row at the same step (row y + 2 (dy - 10) with dy = (t - y / 2) mod 21 is 2 t - 20 or 2 t + 22 for
+// every y): the workgroups resident on an XCD share each fetched row through its L2.
+// (The single-wave-per-tile form of this kernel -- one wave keeps all 8 chunks' f1 fragments, 96 VGPRs, 8 barriers per
+// displacement row -- measured 0.356 ms against 0.325 and was removed in round 3.)
+// ---- the reduction is split over TWO waves per tile ---------------------------------------------------------------------
 // 2 NW waves: wave (tile tw, half kh) keeps the f1 fragments of chunks 4 kh .. 4 kh + 3 (48 VGPRs instead of 96) and a
 // stage carries one chunk of EACH half, so a displacement row takes 4 barriers instead of 8 with the same 18 MFMAs per
 // wave and stage; the upper half's accumulators cross to the lower half's wave through LDS once per row.  With one
@@ -226,7 +83,7 @@ __global__ __launch_bounds__(128 * NW) void corr_fwd_planes_k2_kernel(const __bf
   const int kh = wave >= NW ? 1 : 0, tw = wave - kh * NW;
   float* otile = reinterpret_cast<float*>(corr_lds + 3 * BUF * 2) + tw * 16 * OT;
   float* part = reinterpret_cast<float*>(corr_lds + 3 * BUF * 2 + NW * 16 * OT * 4) + (tw * 64 + lane) * 12;
-  const int nblk = gridDim.x * gridDim.y * gridDim.z;                    // XCD-contiguous rows: see corr_fwd_planes_kernel
+  const int nblk = gridDim.x * gridDim.y * gridDim.z;                    // XCD-contiguous rows: see the notes above
   int item = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
   if ((nblk & 7) == 0) item = (item & 7) * (nblk >> 3) + (item >> 3);
   const int bx = item % gridDim.x, par = (item / gridDim.x) % gridDim.y, by = item / (gridDim.x * gridDim.y);
@@ -274,7 +131,7 @@ __global__ __launch_bounds__(128 * NW) void corr_fwd_planes_k2_kernel(const __bf
       for (int p = 0; p < 3; ++p) glds16(voff[1] >= 0 ? sbase + p * in_plane_stride + voff[1] : zero, dst + sdst[1] + p * PLANE);
     }
   };
-  const int rot = (P - (y >> 1) % P) % P;        // rotated displacement order: see corr_fwd_planes_kernel
+  const int rot = (P - (y >> 1) % P) % P;        // rotated displacement order: see the notes above
   auto dy_at = [&](int t) { const int d = t + rot; return d >= P ? d - P : d; };
   auto row_ok = [&](int dy) { const int y2 = y + 2 * (dy - R); return y2 >= 0 && y2 < H; };
   auto next_valid = [&](int t) { do { ++t; } while (t < P && !row_ok(dy_at(t))); return t; };
@@ -368,28 +225,15 @@ template <int NW>
 int launch_corr_planes(const __bf16* a, const __bf16* b, long in_plane_stride, __bf16* o, long out_plane_stride, int out_chunk0,
                        int B, int H, int W, int ni, float scale, float slope, hipStream_t st, const int* win = nullptr,
                        int win_div = 1) {
-  static bool raised = false;                    // 64.5 KB + the output tiles: above the default dynamic-LDS limit
+  static bool raised = false;                    // above the default dynamic-LDS limit
   if (!raised) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_fwd_planes_kernel<NW>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, corr_planes_lds_bytes<NW>());
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_fwd_planes_k2_kernel<NW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, corr_planes_k2_lds_bytes<NW>());
     if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "correlation (planes): %s", hipGetErrorString(e));
     raised = true;
   }
-  static const bool k2 = [] { const char* e = getenv("UFR_CORR_PLANES_K2"); return !(e && e[0] == '0'); }();
-  if (k2 || win) {                                       // reduction split over two waves per tile (default)
-    static bool raised2 = false;
-    if (!raised2) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_fwd_planes_k2_kernel<NW>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, corr_planes_k2_lds_bytes<NW>());
-      if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "correlation (planes): %s", hipGetErrorString(e));
-      raised2 = true;
-    }
-    corr_fwd_planes_k2_kernel<NW><<<dim3(win ? 1 : ufr::ceil_div(ni, 16 * NW), 2, B * H), 128 * NW, corr_planes_k2_lds_bytes<NW>(), st>>>(
-        a, b, in_plane_stride, o, out_plane_stride, out_chunk0, B, H, W, scale, slope, win, win_div);
-    return UFR_OK;
-  }
-  corr_fwd_planes_kernel<NW><<<dim3(ufr::ceil_div(ni, 16 * NW), 2, B * H), 64 * NW, corr_planes_lds_bytes<NW>(), st>>>(
-      a, b, in_plane_stride, o, out_plane_stride, out_chunk0, B, H, W, scale, slope);
+  corr_fwd_planes_k2_kernel<NW><<<dim3(win ? 1 : ufr::ceil_div(ni, 16 * NW), 2, B * H), 128 * NW, corr_planes_k2_lds_bytes<NW>(), st>>>(
+      a, b, in_plane_stride, o, out_plane_stride, out_chunk0, B, H, W, scale, slope, win, win_div);
   return UFR_OK;
 }
 

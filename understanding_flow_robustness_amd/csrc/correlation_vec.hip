@@ -367,16 +367,11 @@ int launch_fwd(const float* in1, const float* in2, float* out, int B, int C, int
   if (NT > kVecMaxThreads || lds > (size_t)ufr::kMaxLds) return 1;   // not eligible: caller falls back
   auto kern = corr_fwd_vec<P, DP, PHB, CK>;
   if (int rc = set_lds(kern, lds)) return rc;
-  static const int swz_env = [] { const char* e = getenv("UFR_CORR_FWD_SWZ"); return e ? atoi(e) : 1; }();
   constexpr int NPHG = (P + PHB - 1) / PHB;
-  if (swz_env == 1) {
-    const int F = H + DP * PHB * (NPHG - 1), FQ = (F + 7) / 8;
-    const long nblk = (long)B * FQ * NPHG * 8;
-    if (nblk >= 2147483647L) return 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NT), lds, st, in1, in2, out, C, H, W, G, scale, slope, 1);
-  } else {
-    hipLaunchKernelGGL(kern, dim3(H * NPHG, B), dim3(NT), lds, st, in1, in2, out, C, H, W, G, scale, slope, 0);
-  }
+  const int F = H + DP * PHB * (NPHG - 1), FQ = (F + 7) / 8;     // XCD-swizzled block order (the plain order measured slower)
+  const long nblk = (long)B * FQ * NPHG * 8;
+  if (nblk >= 2147483647L) return 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NT), lds, st, in1, in2, out, C, H, W, G, scale, slope, 1);
   return ufr::launched("corr_fwd_vec");
 }
 
@@ -390,10 +385,9 @@ int launch_bwd(const float* other, const float* gout, float* gin, int B, int C, 
   if ((long)CB * H * W >= 2147483647L) return 1;   // 32-bit piece offsets
   auto kern = corr_bwd_vec<P, DP, CB, CT, WRT2>;
   if (int rc = set_lds(kern, lds)) return rc;
-  static const int swz_env = [] { const char* e = getenv("UFR_CORR_BWD_SWZ"); return e ? atoi(e) : 1; }();
   const int ncb = ceil_div(C, CB);
   const long nblk = (long)B * H * ncb;
-  const int swz = (swz_env == 1 && ncb == 8 && H % 4 == 0 && nblk % 8 == 0) ? 1 : 0;
+  const int swz = (ncb == 8 && H % 4 == 0 && nblk % 8 == 0) ? 1 : 0;
   if (nblk >= 2147483647L) return 1;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NT), lds, st, other, gout, gin, C, H, W, G, swz);
   return ufr::launched("corr_bwd_vec");
@@ -407,53 +401,22 @@ namespace ufr {
 int corr_fwd_vec_launch(const float* in1, const float* in2, float* out, int B, int C, int H, int W, int P,
                         int DP, float scale, float slope, hipStream_t st) {
   if (W % 4 != 0 || (long)8 * H * W >= 2147483647L) return 1;
-  // tuning knob (tools/microbench.py sweeps it); the default is the measured best
-  static const int variant = [] { const char* e = getenv("UFR_CORR_FWD_VARIANT"); return e ? atoi(e) : 1; }();
-  if (P == 21 && DP == 2) {
-    switch (variant) {
-      case 0: return launch_fwd<21, 2, 3, 8>(in1, in2, out, B, C, H, W, scale, slope, st);
-      case 2: return launch_fwd<21, 2, 7, 4>(in1, in2, out, B, C, H, W, scale, slope, st);
-      case 3: return launch_fwd<21, 2, 7, 8>(in1, in2, out, B, C, H, W, scale, slope, st);
-      case 4: return 1;   // general path (correlation.hip)
-      default: return launch_fwd<21, 2, 3, 4>(in1, in2, out, B, C, H, W, scale, slope, st);
-    }
-  }
-  if (P == 9 && DP == 1) {
-    switch (variant) {
-      case 0: return launch_fwd<9, 1, 3, 8>(in1, in2, out, B, C, H, W, scale, slope, st);
-      case 2: return launch_fwd<9, 1, 9, 4>(in1, in2, out, B, C, H, W, scale, slope, st);
-      case 3: return launch_fwd<9, 1, 9, 8>(in1, in2, out, B, C, H, W, scale, slope, st);
-      case 4: return 1;
-      default: return launch_fwd<9, 1, 3, 4>(in1, in2, out, B, C, H, W, scale, slope, st);
-    }
-  }
+  // (displacement rows per block, channels per stage) = (3, 4): the measured best of round 1's sweep
+  if (P == 21 && DP == 2) return launch_fwd<21, 2, 3, 4>(in1, in2, out, B, C, H, W, scale, slope, st);
+  if (P == 9 && DP == 1) return launch_fwd<9, 1, 3, 4>(in1, in2, out, B, C, H, W, scale, slope, st);
   return 1;
 }
 
 int corr_bwd_vec_launch(const float* in1, const float* in2, const float* gout, float* gin1, float* gin2,
                         int B, int C, int H, int W, int P, int DP, hipStream_t st) {
   if (W % 4 != 0) return 1;
-  static const int variant = [] { const char* e = getenv("UFR_CORR_BWD_VARIANT"); return e ? atoi(e) : 3; }();
-  if (variant == 4) return 1;
-  if (variant == 3) {   // MFMA formulation (correlation_mfma.hip); 1 = shape not covered -> VALU kernels below
-    const int rc = ufr::corr_bwd_mfma_launch(in1, in2, gout, gin1, gin2, B, C, H, W, P, DP, st);
-    if (rc <= 0) return rc;
-  }
-  int rc;
+  // the fp32-MFMA formulation (correlation_mfma.hip); 1 = shape not covered -> the VALU gather kernels below
+  int rc = ufr::corr_bwd_mfma_launch(in1, in2, gout, gin1, gin2, B, C, H, W, P, DP, st);
+  if (rc <= 0) return rc;
   if (P == 21 && DP == 2) {
-    if (variant == 1 || variant == 3) {
-      rc = launch_bwd<21, 2, 16, 4, false>(in2, gout, gin1, B, C, H, W, st);
-      if (rc) return rc;
-      return launch_bwd<21, 2, 16, 4, true>(in1, gout, gin2, B, C, H, W, st);
-    }
-    if (variant == 2) {
-      rc = launch_bwd<21, 2, 16, 2, false>(in2, gout, gin1, B, C, H, W, st);
-      if (rc) return rc;
-      return launch_bwd<21, 2, 16, 2, true>(in1, gout, gin2, B, C, H, W, st);
-    }
-    rc = launch_bwd<21, 2, 32, 4, false>(in2, gout, gin1, B, C, H, W, st);
+    rc = launch_bwd<21, 2, 16, 4, false>(in2, gout, gin1, B, C, H, W, st);
     if (rc) return rc;
-    return launch_bwd<21, 2, 32, 4, true>(in1, gout, gin2, B, C, H, W, st);
+    return launch_bwd<21, 2, 16, 4, true>(in1, gout, gin2, B, C, H, W, st);
   }
   if (P == 9 && DP == 1) {
     rc = launch_bwd<9, 1, 32, 4, false>(in2, gout, gin1, B, C, H, W, st);

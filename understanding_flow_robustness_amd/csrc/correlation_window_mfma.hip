@@ -159,18 +159,15 @@ extern "C" int ufr_corr_backward_window_fused(const float* f1, const float* f2, 
     return ufr::fail(UFR_EUNSUPPORTED, "corr backward window (fused): built for 256 channels, patch 21, dilation_patch 2, windows "
                                        "of at most 16 cells across, W a multiple of 4; got C=%d patch=%d dilation=%d ww=%d W=%d",
                      C, patch, dilation_patch, ww, W);
-  // (rows per workgroup, channel tiles per wave): 2 x 2 shares source rows and B fragments best, 1 x 1 has 4x the workgroups.
-  // UFR_CORR_BWD_CFG=11|12|21|22 overrides the choice (A/B)
-  static const int forced = [] { const char* e = getenv("UFR_CORR_BWD_CFG"); return e ? atoi(e) : 0; }();
-  const int cfg = forced ? forced : (B <= 2 ? 11 : 21);        // measured at 8 pairs: 21 0.067 ms, 22 0.077, 11 / 12 0.085
+  // (rows per workgroup, channel tiles per wave): 2 x 1 at 8 pairs (measured 0.067 ms; 2 x 2 0.077, 1 x 1 / 1 x 2 0.085),
+  // 1 x 1 (4x the workgroups) for one or two pairs
+  const int cfg = B <= 2 ? 11 : 21;
 #define UFR_CBW_LAUNCH(NR, TPW)                                                                                             \
   corr_bwd_window_mfma_kernel<NR, TPW><<<dim3(2 * ufr::ceil_div(ufr::ceil_div(wh, 2), NR), 2 * (16 / (4 * TPW)), B), 256, 0, \
                                          ufr::as_stream(stream)>>>(f1, f2, G, g_chunk0, g_scale, G_redir, grad_window, B, H, W, \
                                                                    win, level_stride, wh, ww, margin)
   if (cfg == 11) UFR_CBW_LAUNCH(1, 1);
-  else if (cfg == 12) UFR_CBW_LAUNCH(1, 2);
-  else if (cfg == 21) UFR_CBW_LAUNCH(2, 1);
-  else UFR_CBW_LAUNCH(2, 2);
+  else UFR_CBW_LAUNCH(2, 1);
 #undef UFR_CBW_LAUNCH
   return ufr::launched("corr_bwd_window_mfma_kernel");
 }

@@ -427,9 +427,8 @@ extern "C" int ufr_altcorr_backward(const float* fmap1, const float* fmap2, cons
   const long blocks = (long)B * N * H1 * W1;
   UFR_REQUIRE(blocks < 2147483647L, "alt_corr backward: too many pixels");
   const int nt = C >= 256 ? 256 : ufr::round_up(C, 64);
-  static const int variant = [] { const char* e = getenv("UFR_ALTCORR_BWD_VARIANT"); return e ? atoi(e) : 1; }();
-  if (variant == 0 || (long)B * N > 65535 || (radius != 4 && radius != 3)) {
-    // v1: one workgroup per pixel does both adjoints, global atomics
+  if ((long)B * N > 65535 || (radius != 4 && radius != 3)) {
+    // shapes the tiled form does not cover: one workgroup per pixel does both adjoints, global atomics
     hipLaunchKernelGGL(altcorr_bwd<true>, dim3((unsigned)blocks), dim3(nt), 0, st, fmap1, fmap2, coords,
                        corr_grad, fmap1_grad, fmap2_grad, N, H1, W1, H2, W2, C, radius);
     return ufr::launched("altcorr_bwd");

@@ -366,9 +366,8 @@ extern "C" int ufr_resample2d_forward(const float* input1, const float* input2, 
     return ufr::launched("resample2d_fwd_lds");
   }
   // one pixel per thread, every pixel's gathers in flight at once (the grid-stride form with 2048 workgroups serialised
-  // seven dependent flow -> gather chains per thread); UFR_RESAMPLE_GRID=stream restores it for the A/B
-  static const bool full_grid = [] { const char* e = getenv("UFR_RESAMPLE_GRID"); return !(e && e[0] == 's'); }();
-  const unsigned blocks = full_grid ? (unsigned)((npix + 255) / 256) : (unsigned)ufr::stream_grid(npix, 256);
+  // seven dependent flow -> gather chains per thread: measured slower)
+  const unsigned blocks = (unsigned)((npix + 255) / 256);
   hipLaunchKernelGGL(resample2d_fwd, dim3(blocks), dim3(256), 0,
                      ufr::as_stream(stream), input1, input2, output, B, C, Hi, Wi, H, W,
                      kernel_size, bilinear);

@@ -259,6 +259,21 @@ class Launch:
     def __call__(self):
         L.check(L.lib().ufr_igemm(C.byref(self.desc), L.stream()), "igemm")
 
+    def algorithmic_bytes(self) -> float:
+        """What one launch has to move if every operand crosses HBM exactly once (the yardstick its PMC traffic is read
+        against): the input pixels under the row grid (three bf16 planes of KC chunks), the weight image, the output (three
+        planes or one fp32 value per element), the fp32 addend and the mask plane; split-K slabs count as waste, not work."""
+        d = self.desc
+        rows = d.B * d.Hr * d.Wr
+        pix_in = min(d.B * d.Hi * d.Wi, rows * d.in_sy * d.in_sx)
+        taps = sum(d.phase[z].ntaps for z in range(d.nphase))
+        out_el = rows * d.nphase * ((d.tail_n0 if d.tail else d.N) + 31) // 32 * 32
+        b = pix_in * d.KC * 32 * 6 + taps * d.KC * d.Npad * 32 * 6
+        b += out_el * ((6 if d.out_planes else 0) + (4 if d.out_f32 else 0) + (4 if d.add else 0) + (2 if d.mask else 0))
+        if d.tail:
+            b += rows * (d.N - d.tail_n0) * 4
+        return float(b)
+
 
 def make_launch(wi: WeightImage, x: Planes, in_chunk0: int, rows_hw, out_hw, *, out_planes: Planes | None = None,
                 out_chunk0: int = 0, out_f32: GradSum | None = None, out_f32_chunk0: int = 0, bias: torch.Tensor | None = None,
