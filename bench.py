@@ -223,14 +223,6 @@ def kernel_rooflines(step, device, max_count):
             t = event_time(lambda: eng._pf_backward(k, gsrc, accumulate=k not in (2, 6)), 10)
             ks.append(dict(kernel=f"flow_head_planes_bwd predict_flow{k}", ms=round(t, 4), bound="hbm", achieved=round(nbytes_b / t / 1e6, 1),
                            peak=PEAK_HBM_GBS, unit="GB/s", frac=round(nbytes_b / t / 1e6 / PEAK_HBM_GBS, 4), algorithmic_bytes=int(nbytes_b), traffic=None))
-    # ---- the full-frame prefix of load() in its torch / MIOpen spelling, for comparison with the engine's 'prefix' launches
-    x = torch.rand(2 * B, 3, H, W, device=device)
-    with torch.no_grad():
-        t_p = event_time(lambda: step.net.encode(x), 5)
-    tf = GFLOP_PREFIX_FWD * B / t_p
-    ks.append(dict(kernel="torch / MIOpen fp32 conv1-3, full frame (comparison only: the step runs them on the igemm, 'prefix' rows)",
-                   ms=round(t_p, 4), bound="mfma", achieved=round(tf, 1),
-                   peak=PEAK_FP32_TFLOPS, unit="TFLOP/s", frac=round(tf / PEAK_FP32_TFLOPS, 3), gflop=round(GFLOP_PREFIX_FWD * B, 1), traffic=None))
     return ks, agg
 
 
