@@ -188,3 +188,13 @@ def test_engine_cache_is_not_copied_with_the_module():
     m2 = copy.deepcopy(m)
     assert isinstance(m2.__dict__["_ufr_head_engines"], EngineCache) and not m2.__dict__["_ufr_head_engines"]
     assert not pickle.loads(pickle.dumps(m)).__dict__["_ufr_head_engines"] and c["k"]
+
+
+def test_engine_cache_is_bounded():
+    from understanding_flow_robustness_amd._lib import EngineCache
+    c = EngineCache()
+    for i in range(EngineCache.MAX_ENTRIES + 3):
+        c[i] = object()
+    assert len(c) == EngineCache.MAX_ENTRIES and 0 not in c and EngineCache.MAX_ENTRIES + 2 in c
+    c[EngineCache.MAX_ENTRIES + 2] = "replaced"          # an existing key never evicts
+    assert len(c) == EngineCache.MAX_ENTRIES

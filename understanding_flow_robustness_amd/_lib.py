@@ -242,6 +242,15 @@ class EngineCache(dict):
     state OF the process, not of the module: `copy.deepcopy(net)`, `pickle` and `torch.save(net)` get an empty one and the copy
     builds its own engines on first use."""
 
+    MAX_ENTRIES = 6                     # engines hold GBs of static planes: a validation loop over many frame sizes must not keep them all
+
+    def __setitem__(self, key, value):
+        """Least-recently-BUILT eviction.  A step that captured graphs over an evicted engine's buffers holds the engine object
+        itself, so its memory stays valid; the cache only stops handing it out."""
+        if key not in self and len(self) >= self.MAX_ENTRIES:
+            del self[next(iter(self))]
+        super().__setitem__(key, value)
+
     def __deepcopy__(self, memo):
         return EngineCache()
 
