@@ -40,6 +40,19 @@ struct PixelWindow {
   float dx, dy;
 };
 
+// The hardware deals consecutive workgroups (x fastest) round-robin to the 8 XCDs, each with its own 4 MB L2; a level's fmap2
+// (7.9 MB at 48 x 160 x 256) does not fit one L2, and with tiles in launch order every XCD walks every row of it: PMC had
+// 216 - 235 MB fetched per lookup and kernel for 28 MB of operands (profiles/r3_c3alt_step_traffic.json).  Pixel ROWS are
+// dealt to the XCDs instead: launch index i = 8 j + k becomes the j-th tile of XCD k, which owns the pixel rows r with
+// r % 8 == k (all tiles of a row share their fmap2 rows).  One contiguous band of rows per XCD moved fewer bytes still but
+// ran slower (image borders and flow discontinuities leave whole XCDs idle: d/d fmap2 0.123 -> 0.150 ms); interleaved
+// rows keep the balance.  The grid's x extent is (rows padded to a multiple of 8) x tiles per row; -1 = padding.
+__device__ __forceinline__ int xcd_row_tile(int i, int tiles_x, int ntiles) {
+  const int k = i & 7, j = i >> 3;
+  const int t = ((j / tiles_x) * 8 + k) * tiles_x + j % tiles_x;
+  return t < ntiles ? t : -1;
+}
+
 // window of pixel (b, h1, w1) on a level; invalid (never inside an image) for w1 >= W1
 __device__ __forceinline__ PixelWindow pixel_window(const float* __restrict__ coords, int planar, int b, int h1, int w1, int H1,
                                                     int W1, float cscale, int r) {
@@ -78,7 +91,9 @@ __global__ __launch_bounds__(256) void altcorr_mfma_fwd(const float* __restrict_
   const int l = blockIdx.y, H2 = lv.H2[l], W2 = lv.W2[l];
   const float* __restrict__ f2 = lv.f2[l];
   const int tiles_x = (W1 + AC_TP - 1) / AC_TP;
-  const int tile = blockIdx.x, b = tile / (H1 * tiles_x), rem = tile - b * H1 * tiles_x, h1 = rem / tiles_x, w0 = (rem % tiles_x) * AC_TP;
+  const int tile = xcd_row_tile(blockIdx.x, tiles_x, B * H1 * tiles_x);
+  if (tile < 0) return;
+  const int b = tile / (H1 * tiles_x), rem = tile - b * H1 * tiles_x, h1 = rem / tiles_x, w0 = (rem % tiles_x) * AC_TP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) { bb[0] = INT_MAX; bb[1] = INT_MIN; bb[2] = INT_MAX; bb[3] = INT_MIN; }
   for (int i = tid; i < AC_TP * npt; i += 256) (&s[0][0])[i] = 0.f;
@@ -162,7 +177,8 @@ __global__ __launch_bounds__(64) void altcorr_prepass(const AcLevels lv, const f
   constexpr int rd = 2 * R + 1, gd = rd + 1, npt = gd * gd;
   __shared__ float dxs[AC_TP], dys[AC_TP];
   const int tiles_x = (W1 + AC_TP - 1) / AC_TP, ntiles = B * H1 * tiles_x;
-  const int l = blockIdx.y, tile = blockIdx.x;
+  const int l = blockIdx.y, tile = xcd_row_tile(blockIdx.x, tiles_x, ntiles);
+  if (tile < 0) return;
   const int b = tile / (H1 * tiles_x), rem = tile - b * H1 * tiles_x, h1 = rem / tiles_x, w0 = (rem % tiles_x) * AC_TP;
   const int H2 = lv.H2[l], W2 = lv.W2[l], tid = threadIdx.x;
   const size_t plane = (size_t)H1 * W1, npix = (size_t)B * plane;
@@ -217,7 +233,8 @@ __global__ __launch_bounds__(256) void altcorr_mfma_bwd1(const AcLevels lv, cons
   constexpr int gd = 2 * R + 2, npt = gd * gd, C = 4 * CPG, NT = CPG / 16;
   static_assert(NT == 4 || NT == 2, "channel quarters of 64 or 32");
   const int tiles_x = (W1 + AC_TP - 1) / AC_TP, ntiles = B * H1 * tiles_x;
-  const int l = blockIdx.y, tile = blockIdx.x;
+  const int l = blockIdx.y, tile = xcd_row_tile(blockIdx.x, tiles_x, ntiles);
+  if (tile < 0) return;
   const int b = tile / (H1 * tiles_x), rem = tile - b * H1 * tiles_x, h1 = rem / tiles_x, w0 = (rem % tiles_x) * AC_TP;
   const int H2 = lv.H2[l], W2 = lv.W2[l];
   const float* __restrict__ f2 = lv.f2[l];
@@ -365,7 +382,7 @@ __global__ __launch_bounds__(256) void altcorr_mfma_bwd2(const float* __restrict
 template <int R, int CPG>
 int launch_fwd(const float* f1, const AcLevels& lv, const float* coords, int planar, float* out, int B, int H1, int W1, float scale,
                hipStream_t st) {
-  const int tiles = B * H1 * ((W1 + AC_TP - 1) / AC_TP);
+  const int tiles = (B * H1 + 7) / 8 * 8 * ((W1 + AC_TP - 1) / AC_TP);          // rows padded to a multiple of 8: see xcd_row_tile
   altcorr_mfma_fwd<R, CPG><<<dim3(tiles, lv.n), 256, 0, st>>>(f1, lv, coords, planar, out, B, H1, W1, scale);
   return ufr::launched("altcorr_mfma_fwd");
 }
@@ -382,7 +399,7 @@ template <int R, int CPG>
 int launch_bwd(const float* f1, AcLevels lv, const float* coords, int planar, const float* gout, float* g1, void* workspace, int B,
                int H1, int W1, float scale, int accumulate, hipStream_t st) {
   constexpr int C = 4 * CPG, npt = (2 * R + 2) * (2 * R + 2);
-  const int tiles_b = H1 * ((W1 + AC_TP - 1) / AC_TP), tiles = B * tiles_b;
+  const int tiles_b = H1 * ((W1 + AC_TP - 1) / AC_TP);
   const long npix = (long)B * H1 * W1;
   AcWorkspace ws;
   ws.gs_all = static_cast<float*>(workspace);
@@ -390,10 +407,11 @@ int launch_bwd(const float* f1, AcLevels lv, const float* coords, int planar, co
   ws.win = reinterpret_cast<int*>(ws.part + (long)lv.n * npix * C);
   ws.boxes = ws.win + (long)lv.n * npix * 2;
   ws.boxes += (4 - ((reinterpret_cast<uintptr_t>(ws.boxes) / 4) & 3)) & 3;            // 16-byte aligned rows
-  altcorr_prepass<R><<<dim3(tiles, lv.n), 64, 0, st>>>(lv, coords, planar, gout, ws.gs_all, ws.win, ws.boxes, B, H1, W1, scale);
+  const int tiles_pad = (B * H1 + 7) / 8 * 8 * (tiles_b / H1);                 // rows padded to a multiple of 8: see xcd_row_tile
+  altcorr_prepass<R><<<dim3(tiles_pad, lv.n), 64, 0, st>>>(lv, coords, planar, gout, ws.gs_all, ws.win, ws.boxes, B, H1, W1, scale);
   int rc = ufr::launched("altcorr_prepass");
   if (rc != UFR_OK) return rc;
-  altcorr_mfma_bwd1<R, CPG><<<dim3(tiles, lv.n), 256, 0, st>>>(lv, ws.gs_all, ws.win, ws.boxes, ws.part, B, H1, W1);
+  altcorr_mfma_bwd1<R, CPG><<<dim3(tiles_pad, lv.n), 256, 0, st>>>(lv, ws.gs_all, ws.win, ws.boxes, ws.part, B, H1, W1);
   rc = ufr::launched("altcorr_mfma_bwd1");
   if (rc != UFR_OK) return rc;
   const long n4 = npix * C / 4;
