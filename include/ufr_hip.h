@@ -235,7 +235,8 @@ int ufr_gru_blend_backward(const float* q_pre, const float* z, const float* h, c
  *   ufr_raft_motion_finish: cat([out, flow]) (update.py:120): channels 126 / 127 of the 4 motion chunks at chunk0 of p1 = flow,
  *     and the 4 chunks copied to the same place in p2 (the second half-step's GRU buffer);
  *   ufr_gru_gates_cm_*: zr [2*chunks][M][32] pre-activations -> sigmoid values IN PLACE, rh = r*h (planes); adjoint: g_zr planes
- *     [g_z z(1-z) | g_rh h r(1-r)], g_h += g_rh r;
+ *     [g_z z(1-z) | g_rh h r(1-r)], g_h += g_rh r; consume_g_rh != 0 leaves zeros in g_rh (it then lives in a running-sum
+ *     buffer [h | inp | motion | r*h] whose next writer, an igemm epilogue, adds onto it);
  *   ufr_gru_blend_cm_*: q -> tanh IN PLACE, out = (1-z) h + z q (planes); adjoint: g_q_pre planes, g_z, g_h = g (1-z). */
 int ufr_raft_flow_patches(const float* flow, void* planes, long plane_stride, int chunk0, int B, int H, int W, ufr_stream_t stream);
 int ufr_raft_motion_finish(void* p1, long plane_stride1, void* p2, long plane_stride2, int chunk0, const float* flow, int B, int H,
@@ -247,8 +248,9 @@ int ufr_gru_blend_cm_forward(float* q, const float* z, const void* h, long h_pla
 int ufr_gru_blend_cm_backward(const float* q, const float* z, const void* h, long h_plane_stride, int h_chunk0, const float* g,
                               void* gq, long gq_plane_stride, int gq_chunk0, float* g_z, float* g_h, long M, int chunks,
                               ufr_stream_t stream);
-int ufr_gru_gates_cm_backward(const float* zr, const void* h, long h_plane_stride, int h_chunk0, const float* g_z, const float* g_rh,
-                              void* gzr, long gzr_plane_stride, int gzr_chunk0, float* g_h, long M, int chunks, ufr_stream_t stream);
+int ufr_gru_gates_cm_backward(const float* zr, const void* h, long h_plane_stride, int h_chunk0, const float* g_z, float* g_rh,
+                              void* gzr, long gzr_plane_stride, int gzr_chunk0, float* g_h, long M, int chunks, int consume_g_rh,
+                              ufr_stream_t stream);
 
 /* ---- RAFT BasicEncoder: normalisation / ReLU / residual arithmetic between the convolutions (csrc/raft_norm.hip) -----------
  * replaces nn.InstanceNorm2d / nn.BatchNorm2d (eval) + ReLU + the residual add of models/raft/extractor.py:5-78, :142-215 on

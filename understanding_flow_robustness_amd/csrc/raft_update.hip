@@ -168,8 +168,8 @@ __global__ void blend_bwd_kernel(const float* __restrict__ q, const float* __res
 
 // g_zr planes [2 chunks]: [g_z z (1 - z) | g_rh h r (1 - r)];  g_h += g_rh r   (zr holds the sigmoid values)
 __global__ void gates_bwd_kernel(const float* __restrict__ zr, const __bf16* __restrict__ h, long hs, int h_chunk0,
-                                 const float* __restrict__ g_z, const float* __restrict__ g_rh, __bf16* __restrict__ gzr, long gs,
-                                 int gzr_chunk0, float* __restrict__ g_h, long M, int chunks) {
+                                 const float* __restrict__ g_z, float* __restrict__ g_rh, __bf16* __restrict__ gzr, long gs,
+                                 int gzr_chunk0, float* __restrict__ g_h, long M, int chunks, int consume) {
   const long n8 = (long)chunks * M * 4;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n8; t += (long)gridDim.x * blockDim.x) {
     const long e = t * 8;
@@ -189,6 +189,10 @@ __global__ void gates_bwd_kernel(const float* __restrict__ zr, const __bf16* __r
     store_planes8(gzr + (long)gzr_chunk0 * M * 32 + e, gs, a);
     store_planes8(gzr + ((long)gzr_chunk0 + chunks) * M * 32 + e, gs, b);
     store_f8(g_h + e, gh);
+    if (consume) {                       // g_rh sits in a running-sum buffer whose next writer ADDS: leave zeros behind
+      const float zero[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      store_f8(g_rh + e, zero);
+    }
   }
 }
 
@@ -239,11 +243,11 @@ extern "C" int ufr_gru_blend_cm_backward(const float* q, const float* z, const v
 }
 
 extern "C" int ufr_gru_gates_cm_backward(const float* zr, const void* h, long h_plane_stride, int h_chunk0, const float* g_z,
-                                         const float* g_rh, void* gzr, long gzr_plane_stride, int gzr_chunk0, float* g_h, long M,
-                                         int chunks, ufr_stream_t stream) {
+                                         float* g_rh, void* gzr, long gzr_plane_stride, int gzr_chunk0, float* g_h, long M,
+                                         int chunks, int consume_g_rh, ufr_stream_t stream) {
   UFR_REQUIRE(zr && h && g_z && g_rh && gzr && g_h && M > 0 && chunks > 0, "gru gates (chunk-major) backward: bad argument");
   gates_bwd_kernel<<<ufr::stream_grid((long)chunks * M * 4, 256), 256, 0, ufr::as_stream(stream)>>>(
       zr, static_cast<const __bf16*>(h), h_plane_stride, h_chunk0, g_z, g_rh, static_cast<__bf16*>(gzr), gzr_plane_stride, gzr_chunk0, g_h,
-      M, chunks);
+      M, chunks, consume_g_rh);
   return ufr::launched("gates_bwd_kernel");
 }

@@ -79,9 +79,10 @@ class RaftUpdateEngine:
         self.flow_lr = torch.zeros(B, 2, h, w, **f32)
         self.up_mask = torch.zeros(B, 576, h, w, **f32)
         # ---- gradients
-        self.G_h, self.G_hp, self.G_z = G(HC), G(HC), G(HC)
-        self.G_qx, self.G_zrx, self.G_x = G(3 * HC), G(3 * HC), G(2 * HC)
-        self.G_inp = G(HC)
+        # two running-sum buffers in the GRU buffer's own order [h | inp | motion | r*h]: a half-step's adjoint launches ADD into
+        # them in their epilogues (q^T: chunks 4-15 of the other buffer + its result -> this one; zr^T: chunks 0-11 in place),
+        # so d / d h, the running d / d inp and the iteration's d / d motion need no separate add kernels (7 per iteration before)
+        self.TA, self.TB, self.G_z = G(4 * HC), G(4 * HC), G(HC)
         self.gzq, self.gzr, self.gz_mot = P(HC), P(2 * HC), P(HC)
         self.gz_cor2, self.gz_cor1 = P(6), P(8)
         self.G_corr = G(self.cor_chunks)
@@ -133,8 +134,9 @@ class RaftUpdateEngine:
                 plan(("zr" + tag, it), W["zr" + tag], buf, 0, out_f32=self.ZR[half][it], bias=b_zr[tag], **lin)
                 plan(("q" + tag, it), W["q" + tag], buf, HC, out_f32=self.Q[half][it], bias=bias(getattr(gru, "convq" + tag)), **lin)
                 # adjoints: d / d [inp | motion | r*h] of q, d / d [h | inp | motion] of the gates
-                plan(("q" + tag + "^T", it), Wb["q" + tag], self.gzq, 0, out_f32=self.G_qx)
-                plan(("zr" + tag + "^T", it), Wb["zr" + tag], self.gzr, 0, out_f32=self.G_zrx)
+                src, dst = (self.TA, self.TB) if tag == "2" else (self.TB, self.TA)    # the backward walks half-step 2 first
+                plan(("q" + tag + "^T", it), Wb["q" + tag], self.gzq, 0, add=src, add_chunk0=HC, out_f32=dst, out_f32_chunk0=HC)
+                plan(("zr" + tag + "^T", it), Wb["zr" + tag], self.gzr, 0, add=dst, add_chunk0=0, out_f32=dst, out_f32_chunk0=0)
             plan(("fh1", it), W["fh1"], self.P1[it + 1], 0, out_planes=self.FH, bias=bias(ub.flow_head.conv1), **relu)
             # motion encoder adjoint (the correlation branch only): masks are the ReLU outputs of that iteration
             plan(("conv^T", it), Wb["conv"], self.gz_mot, 0, mask=self.CF[it], out_planes=self.gz_cor2, **relu)
@@ -144,8 +146,8 @@ class RaftUpdateEngine:
         plan(("mask1",), W["mask1"], last, 0, out_planes=self.MH, bias=bias(ub.mask[0]), **relu)
         plan(("mask2",), W["mask2"], self.MH, 0, out_f32=self.mask_f32, bias=bias(ub.mask[2]), **lin)
         plan(("mask2^T",), Wb["mask2"], self.gz_mask, 0, mask=self.MH, out_planes=self.gz_mh, **relu)
-        plan(("mask1^T",), Wb["mask1"], self.gz_mh, 0, out_f32=self.G_h)
-        plan(("fh1^T",), Wb["fh1"], self.gz_fh, 0, add=self.G_h, out_f32=self.G_h)
+        plan(("mask1^T",), Wb["mask1"], self.gz_mh, 0, out_f32=self.TA, out_f32_chunk0=0)
+        plan(("fh1^T",), Wb["fh1"], self.gz_fh, 0, add=self.TA, add_chunk0=0, out_f32=self.TA, out_f32_chunk0=0)
         need = max([S * self.M * wi.Npad for _, wi, _, _, S, _ in plans if S > 1] + [1])
         self.ws = torch.empty(need, **f32)
         self.launch, self._wi = {}, {}
@@ -253,39 +255,36 @@ class RaftUpdateEngine:
             self.launch[("mask2^T",)]()
             self.launch[("mask1^T",)]()
         else:
-            self.G_h.t.zero_()
+            self.TA.t[:HC].zero_()
         L.check(lib.ufr_flow_head_planes_backward(L.ptr(g_flow.contiguous()), L.ptr(self.fh2_w), L.ptr(self.G_fh.t), 0, 8, B, h, w, 0,
                                                   st()), "delta_flow backward")
         L.check(lib.ufr_grad_finalize(L.ptr(self.G_fh.t), 0, L.ptr(self.FH.t), 0, L.ptr(self.gz_fh.t), self.gz_fh.plane_stride, 0, M, 8,
                                       0.0, st()), "flow head finalize")
         self.launch[("fh1^T",)]()
-        self.G_inp.t.zero_()
-        cur, prev = self.G_h, self.G_hp                               # d / d (a half-step's output h), d / d (its input h)
+        self.TA.t[HC:].zero_()                                        # running d / d inp, d / d motion; r*h slots start at zero
+        self.TB.t[3 * HC:].zero_()
         for it in range(IT - 1, -1, -1):
-            self.G_x.t.zero_()
-            for half, (tag, buf) in ((1, ("2", self.P2[it])), (0, ("1", self.P1[it]))):
+            # cur = chunks 0-3 of `gin` (d / d the half-step's output h), prev = chunks 0-3 of `gout` (d / d its input h)
+            for half, (tag, buf, gin, gout) in ((1, ("2", self.P2[it], self.TA, self.TB)), (0, ("1", self.P1[it], self.TB, self.TA))):
                 ZR, Q = self.ZR[half][it], self.Q[half][it]
-                L.check(lib.ufr_gru_blend_cm_backward(L.ptr(Q.t), L.ptr(ZR.t), L.ptr(buf.t), buf.plane_stride, 0, L.ptr(cur.t),
-                                                      L.ptr(self.gzq.t), self.gzq.plane_stride, 0, L.ptr(self.G_z.t), L.ptr(prev.t), M,
+                L.check(lib.ufr_gru_blend_cm_backward(L.ptr(Q.t), L.ptr(ZR.t), L.ptr(buf.t), buf.plane_stride, 0, L.ptr(gin.t),
+                                                      L.ptr(self.gzq.t), self.gzq.plane_stride, 0, L.ptr(self.G_z.t), L.ptr(gout.t), M,
                                                       HC, st()), "gru blend backward")
-                self.launch[("q" + tag + "^T", it)]()                 # -> G_qx = d / d [inp | motion | r*h]
-                L.check(lib.ufr_gru_gates_cm_backward(L.ptr(ZR.t), L.ptr(buf.t), buf.plane_stride, 0, L.ptr(self.G_z.t), _ptr(self.G_qx, 2 * HC),
-                                                      L.ptr(self.gzr.t), self.gzr.plane_stride, 0, L.ptr(prev.t), M, HC, st()),
-                        "gru gates backward")
-                self.launch[("zr" + tag + "^T", it)]()                # -> G_zrx = d / d [h | inp | motion]
-                prev.t.add_(self.G_zrx.t[:HC])
-                self.G_x.t.add_(self.G_qx.t[:2 * HC]).add_(self.G_zrx.t[HC:])
-                cur, prev = prev, cur                                 # the half-step's input gradient feeds the one before it
-            self.G_inp.t.add_(self.G_x.t[:HC])
+                self.launch[("q" + tag + "^T", it)]()                 # gout[inp | motion | r*h] = gin[...] + d / d [inp | motion | r*h]
+                L.check(lib.ufr_gru_gates_cm_backward(L.ptr(ZR.t), L.ptr(buf.t), buf.plane_stride, 0, L.ptr(self.G_z.t), _ptr(gout, 3 * HC),
+                                                      L.ptr(self.gzr.t), self.gzr.plane_stride, 0, L.ptr(gout.t), M, HC, 1, st()),
+                        "gru gates backward")                         # (consumes the r*h slot: zeros for the next adder)
+                self.launch[("zr" + tag + "^T", it)]()                # gout[h | inp | motion] += d / d [h | inp | motion]
             # motion features -> ReLU' -> conv^T (correlation branch) -> convc2^T -> convc1^T -> the lookup's adjoint
-            L.check(lib.ufr_grad_finalize(_ptr(self.G_x, HC), 0, L.ptr(self.P1[it].t), 2 * HC, L.ptr(self.gz_mot.t), self.gz_mot.plane_stride,
+            L.check(lib.ufr_grad_finalize(_ptr(self.TA, 2 * HC), 0, L.ptr(self.P1[it].t), 2 * HC, L.ptr(self.gz_mot.t), self.gz_mot.plane_stride,
                                           0, M, HC, 0.0, st()), "motion finalize")
+            self.TA.t[2 * HC:3 * HC].zero_()                           # the next iteration's motion gradient starts from zero
             for name in ("conv^T", "convc2^T", "convc1^T"):
                 self.launch[(name, it)]()
             self.G_corr.to_nchw(self.cor_planes, 0, slope=1.0, out=self.g_corr)
             self._lookup_backward(src, self._coords[it], first=(it == IT - 1))
-        cur.to_nchw(128, 0, slope=1.0, out=self.g_net0)             # (an even number of half-steps: cur is G_h again)
-        self.G_inp.to_nchw(128, 0, slope=1.0, out=self.g_inp)
+        self.TA.to_nchw(128, 0, slope=1.0, out=self.g_net0)          # (an even number of half-steps: TA holds d / d net0)
+        self.TA.to_nchw(128, HC, slope=1.0, out=self.g_inp)
         return self.g_net0, self.g_inp
 
 
