@@ -79,7 +79,8 @@ def test_flownetfusion_schedule(B, H, W, monkeypatch):
 def test_stem_prefix_schedule(cin, B, H, W):
     """conv1 (7x7 stride 2 as a 16-tap launch over the 2x2-unshuffled frame), conv2, conv3 -> conv2 / conv3 features and the
     gradient of the frame, vs the three torch convolutions in float64."""
-    from understanding_flow_robustness_amd.flownets.flownet2 import FlowNetS, _prefix_graph
+    from understanding_flow_robustness_amd.flownets.flownet2 import FlowNetS
+    from understanding_flow_robustness_amd.plane_graph import stem_graph as _prefix_graph
     from understanding_flow_robustness_amd.plane_graph import run
     net = _frozen(_realistic(FlowNetS(cin), 7))
     n64 = copy.deepcopy(net).double()

@@ -9,7 +9,7 @@ flows are upsampled with `nearest`, FlowNetS's flow up-convolutions have no bias
 from __future__ import annotations
 
 import torch
-from .._lib import engine_cache as _engine_cache
+from ..plane_graph import graph_for as _graph_for, native_ok as _native_ok, stem_graph as _prefix_graph
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -171,6 +171,10 @@ class FlowNet2S(FlowNetS):
         x1 = (x1.double() - self._mean64).float()
         x2 = (x2.double() - self._mean64).float()
         x = torch.cat((x1, x2), dim=1)
+        if not self.training and _native_ok(self, x):          # eval + frozen: the FlowNetS trunk on the native kernels (stem + head)
+            flow2 = FlowNetS.forward(self, x)[0]
+            up = F.interpolate(flow2 * 20, scale_factor=4, mode="bilinear", align_corners=False)
+            return (up, []) if self.return_feat_maps else up
         c2 = self.conv2(self.conv1(x))
         c3 = self.conv3_1(self.conv3(c2))
         c4 = self.conv4_1(self.conv4(c3))
@@ -259,46 +263,6 @@ class FlowNetFusion(nn.Module):
         flow1 = self.predict_flow1(self.inter_conv1(cat1))
         cat0 = torch.cat((c0, self.deconv0(cat1), self.upsampled_flow1_to_0(flow1)), 1)
         return self.predict_flow0(self.inter_conv0(cat0))
-
-
-def _graph_for(module, key, build):
-    """One PlaneGraph per (batch, frame size, device), cached on the module; rebuilt when its weights changed since."""
-    from ..flownetc_engine import _weights_stamp
-    cache = _engine_cache(module, "_ufr_plane_graphs")
-    stamp = _weights_stamp(module)
-    g = cache.get(key)
-    if g is None or g.weights_stamp != stamp:
-        g = cache[key] = build()
-        g.weights_stamp = stamp
-    return g
-
-
-def _native_ok(module, x) -> bool:
-    """plane_graph.py serves the attack's configuration: frozen parameters, eval mode, HIP float32, sides multiples of 64."""
-    import os
-    if os.environ.get("UFR_ENGINE", "1") != "1" or module.training:
-        return False
-    frozen = not any(p.requires_grad for p in module.parameters())
-    return (x.is_cuda and x.dtype == torch.float32 and (frozen or not torch.is_grad_enabled()) and x.shape[2] % 64 == 0
-            and x.shape[3] % 64 == 0)
-
-
-def _prefix_graph(net, n, H, W, cin, dev):
-    """conv1 (7x7 / 2 over the 2x2-unshuffled input), conv2, conv3 (5x5 / 2) of FlowNetC / FlowNetS -> conv2 and conv3 as NCHW."""
-    from ..plane_graph import PlaneGraph
-    g = PlaneGraph(n, dev)
-    g.buffer("pin", H // 2, W // 2, (4 * cin + 31) // 32)
-    g.buffer("c1", H // 2, W // 2, 2)
-    g.buffer("c2", H // 4, W // 4, 4)
-    g.buffer("c3", H // 8, W // 8, 8)
-    g.input_packed12("pin", cin)
-    c1, c2, c3 = net.conv1[0], net.conv2[0], net.conv3[0]
-    g.conv(c1.weight, c1.bias, ("pin", 0, (4 * cin + 31) // 32), ("c1", 0), taps_unshuffled=True)
-    g.conv(c2.weight, c2.bias, ("c1", 0, 2), ("c2", 0), stride=2)
-    g.conv(c3.weight, c3.bias, ("c2", 0, 4), ("c3", 0), stride=2)
-    g.tensor_output("c2", 128)
-    g.tensor_output("c3", 256)
-    return g.build()
 
 
 def _sd_graph(net, B, H, W, dev):

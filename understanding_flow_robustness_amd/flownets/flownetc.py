@@ -91,9 +91,26 @@ class FlowNetC(nn.Module):
 
     def encode(self, x):
         """Siamese prefix on a stack of raw frames [N,3,h,w] (h, w multiples of 8): (conv2, conv3)."""
-        c1 = self._cl("conv1", self.normalize_correctly(x))
+        x = self.normalize_correctly(x)
+        stem = self._native_stem(x)
+        if stem is not None:
+            return stem
+        c1 = self._cl("conv1", x)
         c2 = self._cl("conv2", c1)
         return c2, self._cl("conv3", c2)
+
+    def _native_stem(self, x):
+        """conv1-3 on the hand-written kernels (plane_graph.stem_graph: forward and data gradient on the igemm) whenever the
+        network is frozen and in eval mode -- the clean forward that makes the attack's target, the validation loop, the
+        full-frame attack iteration -- so that no vendor convolution runs for FlowNetC at all; None = not served (training,
+        other sizes, UFR_ENGINE=0)."""
+        from ..plane_graph import graph_for, native_ok, run, stem_graph
+        if not native_ok(self, x):
+            return None
+        n, _, h, w = x.shape
+        g = graph_for(self, ("stem", n, h, w, str(x.device)), lambda: stem_graph(self, n, h, w, 3, x.device))
+        c2, c3 = run(g, x)
+        return c2, c3
 
     def head(self, c2a, c3a, c3b, band=None):
         """Everything after the prefix: correlation, conv_redir, conv3_1..6_1, refinement -> flow.
@@ -122,9 +139,13 @@ class FlowNetC(nn.Module):
             raise NotImplementedError("feature-map overwriting belongs to the analysis scripts (out of scope)")
         B = x1.shape[0]
         x = self.normalize_correctly(torch.cat((x1, x2), 0))
-        c1 = self._cl("conv1", x)
-        c2 = self._cl("conv2", c1)
-        c3 = self._cl("conv3", c2)
+        stem = None if self.return_feat_maps else self._native_stem(x)
+        if stem is not None:
+            c1, (c2, c3) = None, stem
+        else:
+            c1 = self._cl("conv1", x)
+            c2 = self._cl("conv2", c1)
+            c3 = self._cl("conv3", c2)
         c2a, c3a, c3b = c2[:B], c3[:B], c3[B:]
         feats = [c1[:B], c2a, c3a, c1[B:], c2[B:], c3b] if self.return_feat_maps else None
         return self._rest(c2a, c3a, c3b, feats)

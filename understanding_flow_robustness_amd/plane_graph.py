@@ -289,3 +289,43 @@ class _GraphFunction(torch.autograd.Function):
 
 def run(graph: PlaneGraph, *inputs):
     return _GraphFunction.apply(graph, *inputs)
+
+
+def graph_for(module, key, build):
+    """One PlaneGraph per (batch, frame size, device), cached on the module; rebuilt when its weights changed since."""
+    from .flownetc_engine import _weights_stamp
+    cache = L.engine_cache(module, "_ufr_plane_graphs")
+    stamp = _weights_stamp(module)
+    g = cache.get(key)
+    if g is None or g.weights_stamp != stamp:
+        g = cache[key] = build()
+        g.weights_stamp = stamp
+    return g
+
+
+def native_ok(module, x) -> bool:
+    """plane_graph.py serves the attack's configuration: frozen parameters, eval mode, HIP float32, sides multiples of 64."""
+    import os
+    if os.environ.get("UFR_ENGINE", "1") != "1" or module.training:
+        return False
+    frozen = not any(p.requires_grad for p in module.parameters())
+    return (x.is_cuda and x.dtype == torch.float32 and (frozen or not torch.is_grad_enabled()) and x.shape[2] % 64 == 0
+            and x.shape[3] % 64 == 0)
+
+
+def stem_graph(net, n, H, W, cin, dev):
+    """conv1 (7x7 / 2 over the 2x2-unshuffled input), conv2, conv3 (5x5 / 2) of FlowNetC / FlowNetS (models/FlowNetC.py:100-119,
+    models/flownet2/FlowNetS.py:15-60) -> conv2 and conv3 as NCHW tensors; `net` has conv1 / conv2 / conv3 = Sequential(Conv2d, LeakyReLU)."""
+    g = PlaneGraph(n, dev)
+    g.buffer("pin", H // 2, W // 2, (4 * cin + 31) // 32)
+    g.buffer("c1", H // 2, W // 2, 2)
+    g.buffer("c2", H // 4, W // 4, 4)
+    g.buffer("c3", H // 8, W // 8, 8)
+    g.input_packed12("pin", cin)
+    c1, c2, c3 = net.conv1[0], net.conv2[0], net.conv3[0]
+    g.conv(c1.weight, c1.bias, ("pin", 0, (4 * cin + 31) // 32), ("c1", 0), taps_unshuffled=True)
+    g.conv(c2.weight, c2.bias, ("c1", 0, 2), ("c2", 0), stride=2)
+    g.conv(c3.weight, c3.bias, ("c2", 0, 4), ("c3", 0), stride=2)
+    g.tensor_output("c2", 128)
+    g.tensor_output("c3", 256)
+    return g.build()
