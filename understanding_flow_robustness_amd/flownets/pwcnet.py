@@ -122,10 +122,42 @@ class PWCDCNet(nn.Module):
 
     def encode(self, x):
         """Levels 1-2 of the feature pyramid on a stack of raw frames [N,3,h,w] -> [level-2 features]."""
+        native = self._native_prefix(x)
+        if native is not None:
+            return [native]
         x = x.flip(1)                                              # RGB -> BGR (PWCNet.py:230-231)
         for _, _, first, second, third in self._PYRAMID[:2]:
             x = self._cl("conv" + third, self._cl("conv" + second, self._cl("conv" + first, x)))
         return [x]
+
+    def _native_prefix(self, x):
+        """Levels 1-2 on the hand-written kernels (plane_graph.py: six 3x3 convolutions, forward and data gradient on the igemm,
+        the BGR flip folded into conv1a's weights) whenever the network is frozen and in eval mode: the clean forward behind the
+        attack's target, the validation loop, the full-frame iteration.  None = not served (training, other sizes, UFR_ENGINE=0)."""
+        from ..plane_graph import PlaneGraph, graph_for, native_ok, run
+        if not native_ok(self, x):
+            return None
+        n, _, H, W = x.shape
+
+        def build():
+            g = PlaneGraph(n, x.device)
+            g.buffer("in0", H, W, 1)
+            g.input("in0", 3)
+            prev, level = "in0", 0
+            for lvl, (_, cout, first, second, third) in enumerate(self._PYRAMID[:2], start=1):
+                for j, name in enumerate((first, second, third)):
+                    conv = getattr(self, "conv" + name)[0]
+                    w = conv.weight.detach()
+                    if lvl == 1 and j == 0:
+                        w = w.flip(1)                               # x.flip(1) of the reference (PWCNet.py:230-231)
+                    buf = f"l{lvl}_{j}"
+                    g.buffer(buf, H >> lvl, W >> lvl, 1)
+                    g.conv(w, conv.bias, (prev, 0, 1), (buf, 0), stride=2 if j == 0 else 1)
+                    prev = buf
+            g.tensor_output(prev, 32)
+            return g.build()
+
+        return run(graph_for(self, ("pyramid12", n, H, W, str(x.device)), build), x)[0]
 
     ENGINE = "pwc"                                                  # patch_attack.py: which native head serves this network
 
