@@ -198,3 +198,10 @@ def test_engine_cache_is_bounded():
     assert len(c) == EngineCache.MAX_ENTRIES and 0 not in c and EngineCache.MAX_ENTRIES + 2 in c
     c[EngineCache.MAX_ENTRIES + 2] = "replaced"          # an existing key never evicts
     assert len(c) == EngineCache.MAX_ENTRIES
+
+
+def test_graft_entry_build_runs():
+    """The driver's "does it build" check: `__graft_entry__.build()` (incremental make of the library and the oracle + the ABI
+    check) must pass in the build container."""
+    import __graft_entry__ as g
+    g.build()
