@@ -9,6 +9,7 @@
 #   trace:<tag>,<iters>,<script>,<args>   rocprofv3 --kernel-trace of a python tool + steady-state table (tools/summarize_trace.py;
 #                    env:TRACE_MARKER=<kernel> names the last kernel of an iteration, default gate_kernel)
 #   traffic:<tag>,<iters>,<script>,<args>   two --pmc passes (FETCH_SIZE / WRITE_SIZE) + tools/pmc_step_traffic.py
+#   counters:<tag>,<C1+C2+..>,<kernel pattern>,<script>,<args>   one --pmc pass + tools/pmc_summary.py
 #   configs:<list>   tools/bench_configs.py <list>
 #   py:<script args> python <script args>
 set -o pipefail
@@ -53,6 +54,15 @@ for step in "$@"; do
              python tools/pmc_step_traffic.py $ff $fw $iters $out/${tag}_igemm_traffic.json $out ${TRACE_MARKER:-gate_kernel} > $out/${tag}_step_traffic.json; rc=$?
              [ $rc -ne 0 ] && exit $rc
              head -n 12 $out/${tag}_step_traffic.json; cat $out/${tag}_igemm_traffic.json ;;
+    counters) # counters:<tag>,<COUNTER+COUNTER+...>,<kernel pattern>,<script>,<args...>: one rocprofv3 --pmc pass (with --kernel-trace only),
+             # per-kernel averages by tools/pmc_summary.py
+             set -- $arg; tag=$1; ctrs=${2//+/ }; pat=$3; shift 3
+             (cd /tmp && timeout -k 10 900 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d /tmp/ctr_$tag -- python $GRAFT_REPO_ROOT/$1 "${@:2}" > $GRAFT_REPO_ROOT/$out/ctr_$tag.log 2>&1); rc=$?
+             [ $rc -ne 0 ] && { tail -n 20 $out/ctr_$tag.log; exit $rc; }
+             fc=$(find /tmp/ctr_$tag -name "*counter_collection.csv" | head -n 1)
+             python tools/pmc_summary.py $fc $pat > $out/${tag}_counters.txt; rc=$?
+             [ $rc -ne 0 ] && exit $rc
+             cat $out/${tag}_counters.txt ;;
     configs) timeout -k 10 1100 python tools/bench_configs.py $arg > $out/configs.log 2>&1; rc=$?; tail -n 12 $out/configs.log
              [ $rc -ne 0 ] && exit $rc ;;
     env)     export $arg ;;                      # env:NAME=VALUE for the steps behind it
