@@ -12,5 +12,10 @@ if "step" in roof:
 if "cpu_baseline" in r:
     print("cpu:", r["cpu_baseline"])
 print("full-frame it/s:", r["config"].get("full_frame_attack_iters_per_s"))
-for k in roof.get("kernels", []):
-    print(f"  {k['kernel'][:70]:70s} {k['ms']:8.4f} ms  {k['frac']:.3f}")
+for c in r["config"].get("other_configs", []):
+    print("other:", c["config"], c["ms_per_iteration"], "ms, igemm", c["roofline"]["frac"] if c.get("roofline") else None)
+try:
+    for k in roof.get("kernels", []):
+        print(f"  {k['kernel'][:70]:70s} {k['ms']:8.4f} ms  {k['frac']:.3f}")
+except BrokenPipeError:                 # `| head` in tools/gpu_call.sh
+    sys.stderr.close()
