@@ -494,6 +494,14 @@ int ufr_window_scatter_planes(const float* src, void* planes, long plane_stride,
 int ufr_chunks_to_nchw(const void* planes, long plane_stride, const float* f32, int chunk0, const void* mask,
                        int mask_chunk0, float* out, int B, int C, int H, int W, float scale, float slope,
                        ufr_stream_t stream);
+/* A concatenation of up to four NCHW float32 tensors <-> `chunks` chunks of the plane layout (PWC-Net's stage input
+ * x = cat(corr, up_flow, up_feat | c1), models/PWCNet.py:287): member s covers buffer channels [dst_channel0[s], + channels[s]),
+ * ascending and disjoint; uncovered channels are zero.  ufr_chunks_to_nchw_cat is the adjoint from a float32 chunk-major
+ * gradient sum; member 0 may pass through its activation: g * (act0 > 0 ? pos0 : neg0) with act0 the member's NCHW activation. */
+int ufr_nchw_cat_to_planes(const float* const* srcs, const int* channels, const int* dst_channel0, int nseg, void* planes,
+                           long plane_stride, int chunk0, int chunks, int B, int H, int W, ufr_stream_t stream);
+int ufr_chunks_to_nchw_cat(const float* g, int chunk0, int chunks, float* const* dsts, const int* channels, const int* src_channel0,
+                           int nseg, const float* act0, float pos0, float neg0, int B, int H, int W, ufr_stream_t stream);
 int ufr_grad_finalize(const float* g, int g_chunk0, const void* mask, int mask_chunk0, void* out, long out_plane_stride,
                       int out_chunk0, long M, int chunks, float slope, ufr_stream_t stream);
 

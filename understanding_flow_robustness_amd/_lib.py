@@ -138,6 +138,8 @@ SIGNATURES = {
     "ufr_nchw_to_planes": [_vp, _vp, _l, _i, _i, _i, _i, _i, _f, _f, _vp, _vp],
     "ufr_window_scatter_planes": [_vp, _vp, _l, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ufr_chunks_to_nchw": [_vp, _l, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _f, _vp],
+    "ufr_nchw_cat_to_planes": [_vp, _vp, _vp, _i, _vp, _l, _i, _i, _i, _i, _i, _vp],
+    "ufr_chunks_to_nchw_cat": [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _f, _f, _i, _i, _i, _vp],
     "ufr_grad_finalize": [_vp, _i, _vp, _i, _vp, _l, _i, _l, _i, _f, _vp],
     "ufr_flow_head_planes_forward": [_vp, _l, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ufr_flow_head_planes_forward_mfma": [_vp, _l, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp],

@@ -1035,6 +1035,84 @@ __global__ __launch_bounds__(256) void chunks_to_nchw_kernel(const __bf16* __res
   }
 }
 
+// ---- a concatenation of NCHW tensors <-> chunks (PWC-Net's stage input x = cat(corr, up_flow, up_feat | c1), PWCNet.py:287) ----
+// Up to four NCHW float32 members, member s covering buffer channels [dst0[s], dst0[s] + C[s]); channels no member covers are 0.
+struct CatSegs {
+  int n;
+  const float* src[4];      // forward: the members; backward: their gradient outputs (written), cast away below
+  int C[4], dst0[4];
+};
+
+__global__ __launch_bounds__(256) void nchw_cat_to_planes_kernel(const CatSegs segs, __bf16* __restrict__ planes, long plane_stride,
+                                                                 int chunk0, int B, int HW) {
+  __shared__ float tile[32][65];
+  const int c0 = blockIdx.x * 32, p0 = blockIdx.y * 64, b = blockIdx.z, tid = threadIdx.x;
+  {
+    const int p = tid & 63;
+#pragma unroll
+    for (int cc = tid >> 6; cc < 32; cc += 4) {
+      const int c = c0 + cc;
+      float v = 0.f;
+      if (p0 + p < HW) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          if (s < segs.n && c >= segs.dst0[s] && c < segs.dst0[s] + segs.C[s])
+            v = segs.src[s][((size_t)b * segs.C[s] + (c - segs.dst0[s])) * HW + p0 + p];
+      }
+      tile[cc][p] = v;
+    }
+  }
+  __syncthreads();
+  const int p = tid >> 2, ch = tid & 3;
+  if (p0 + p >= HW) return;
+  const size_t rows = (size_t)B * HW;
+  __bf16* dst = planes + (((size_t)chunk0 + blockIdx.x) * rows + (size_t)b * HW + p0 + p) * 32 + ch * 8;
+  bf16x8 q0, q1, q2;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    __bf16 a, bq, c;
+    split3(tile[ch * 8 + j][p], a, bq, c);
+    q0[j] = a; q1[j] = bq; q2[j] = c;
+  }
+  *reinterpret_cast<bf16x8*>(dst) = q0;
+  *reinterpret_cast<bf16x8*>(dst + plane_stride) = q1;
+  *reinterpret_cast<bf16x8*>(dst + 2 * plane_stride) = q2;
+}
+
+// The adjoint: a float32 chunk-major gradient sum -> the members' NCHW gradients.  Member 0 may pass through the activation
+// it carries in the forward (act0 = its NCHW activation: g * (act0 > 0 ? pos0 : neg0); PWC-Net: correlate's / C and LeakyReLU').
+__global__ __launch_bounds__(256) void chunks_to_nchw_cat_kernel(const float* __restrict__ g, int chunk0, const CatSegs segs,
+                                                                 const float* __restrict__ act0, float pos0, float neg0, int B, int HW) {
+  __shared__ float tile[32][65];
+  const int c0 = blockIdx.x * 32, p0 = blockIdx.y * 64, b = blockIdx.z, tid = threadIdx.x;
+  const size_t rows = (size_t)B * HW;
+  {
+    const int p = tid >> 2, q = tid & 3;
+    if (p0 + p < HW) {
+      const size_t o = (((size_t)chunk0 + blockIdx.x) * rows + (size_t)b * HW + p0 + p) * 32 + q * 8;
+      const float4 a = *reinterpret_cast<const float4*>(g + o), bq = *reinterpret_cast<const float4*>(g + o + 4);
+      const float v[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) tile[q * 8 + j][p] = v[j];
+    }
+  }
+  __syncthreads();
+  const int p = tid & 63;
+  if (p0 + p >= HW) return;
+#pragma unroll
+  for (int cc = tid >> 6; cc < 32; cc += 4) {
+    const int c = c0 + cc;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (s < segs.n && c >= segs.dst0[s] && c < segs.dst0[s] + segs.C[s]) {
+        const size_t e = ((size_t)b * segs.C[s] + (c - segs.dst0[s])) * HW + p0 + p;
+        float v = tile[cc][p];
+        if (s == 0 && act0) v *= act0[e] > 0.f ? pos0 : neg0;
+        const_cast<float*>(segs.src[s])[e] = v;
+      }
+  }
+}
+
 // fp32 chunk-major gradient sum -> gradient planes: g * leaky'(mask), chunk by chunk (a gradient with several sources
 // whose last writer is not a GEMM epilogue).
 __global__ __launch_bounds__(256) void grad_finalize_kernel(const float* __restrict__ g, int g_chunk0,
@@ -1317,6 +1395,40 @@ extern "C" int ufr_chunks_to_nchw(const void* planes, long plane_stride, const f
                                                                    static_cast<const __bf16*>(mask), mask_chunk0, out, B, C,
                                                                    H * W, scale, slope);
   return ufr::launched("chunks_to_nchw_kernel");
+}
+
+static int cat_segs(CatSegs& cs, const float* const* ptrs, const int* channels, const int* dst_channel0, int nseg, int chunks) {
+  UFR_REQUIRE(ptrs && channels && dst_channel0 && nseg >= 1 && nseg <= 4 && chunks > 0, "nchw cat: bad segment list");
+  cs.n = nseg;
+  for (int s = 0; s < 4; ++s) { cs.src[s] = nullptr; cs.C[s] = 0; cs.dst0[s] = 0; }
+  for (int s = 0; s < nseg; ++s) {
+    UFR_REQUIRE(ptrs[s] && channels[s] > 0 && dst_channel0[s] >= 0 && dst_channel0[s] + channels[s] <= chunks * 32 &&
+                    (s == 0 || dst_channel0[s] >= dst_channel0[s - 1] + channels[s - 1]),
+                "nchw cat: segment %d out of order or outside the %d chunks", s, chunks);
+    cs.src[s] = ptrs[s]; cs.C[s] = channels[s]; cs.dst0[s] = dst_channel0[s];
+  }
+  return UFR_OK;
+}
+
+extern "C" int ufr_nchw_cat_to_planes(const float* const* srcs, const int* channels, const int* dst_channel0, int nseg, void* planes,
+                                      long plane_stride, int chunk0, int chunks, int B, int H, int W, ufr_stream_t stream) {
+  UFR_REQUIRE(planes && plane_stride > 0 && chunk0 >= 0 && B > 0 && B < 65536 && H > 0 && W > 0, "nchw cat -> planes: bad argument");
+  CatSegs cs;
+  if (int rc = cat_segs(cs, srcs, channels, dst_channel0, nseg, chunks)) return rc;
+  const dim3 grid(chunks, (H * W + 63) / 64, B);
+  nchw_cat_to_planes_kernel<<<grid, 256, 0, ufr::as_stream(stream)>>>(cs, static_cast<__bf16*>(planes), plane_stride, chunk0, B, H * W);
+  return ufr::launched("nchw_cat_to_planes_kernel");
+}
+
+extern "C" int ufr_chunks_to_nchw_cat(const float* g, int chunk0, int chunks, float* const* dsts, const int* channels,
+                                      const int* src_channel0, int nseg, const float* act0, float pos0, float neg0, int B, int H, int W,
+                                      ufr_stream_t stream) {
+  UFR_REQUIRE(g && chunk0 >= 0 && B > 0 && B < 65536 && H > 0 && W > 0, "chunks -> nchw cat: bad argument");
+  CatSegs cs;
+  if (int rc = cat_segs(cs, const_cast<const float* const*>(dsts), channels, src_channel0, nseg, chunks)) return rc;
+  const dim3 grid(chunks, (H * W + 63) / 64, B);
+  chunks_to_nchw_cat_kernel<<<grid, 256, 0, ufr::as_stream(stream)>>>(g, chunk0, cs, act0, pos0, neg0, B, H * W);
+  return ufr::launched("chunks_to_nchw_cat_kernel");
 }
 
 extern "C" int ufr_grad_finalize(const float* g, int g_chunk0, const void* mask, int mask_chunk0, void* out,

@@ -199,6 +199,7 @@ class PwcHeadEngine:
         # ---- decoder stages ------------------------------------------------------------------------------------------------
         self.D, self.gzD, self.G_D, self.G_x, self.P4 = {}, {}, {}, {}, {}
         self.x_nchw, self.gx_nchw, self.corr, self.g_corr = {}, {}, {}, {}
+        self.gx_upflow, self.gx_c1 = {}, {}
         self.flow = {k: Z(B, 2, k) for k in range(2, 7)}
         self.g_flow = {k: Z(B, 2, k) for k in range(2, 7)}
         self.up_flow, self.up_flow_s, self.up_feat = {}, {}, {}
@@ -214,7 +215,9 @@ class PwcHeadEngine:
             self.D[k], self.gzD[k] = P(B, k, nch), P(B, k, gz0 + X0)
             self.G_D[k], self.G_x[k] = G(B, k, nch), G(B, k, xc)
             cx = NCORR if k == 6 else NCORR + 4
-            self.x_nchw[k], self.gx_nchw[k] = Z(B, cx, k), Z(B, xw, k)
+            self.x_nchw[k], self.gx_nchw[k] = Z(B, cx, k), Z(B, xw, k)            # (level 6 only: its x is the cost volume alone)
+            if k < 6:
+                self.gx_upflow[k], self.gx_c1[k] = Z(B, 2, k), Z(B, FEAT[k], k)   # the stage input's gradient, member by member
             self.corr[k], self.g_corr[k] = Z(B, NCORR, k), Z(B, NCORR, k)
             self.g_c1corr[k], self.g_warped[k] = Z(B, FEAT[k], k), Z(B, FEAT[k], k)
             if k < 6:
@@ -336,6 +339,17 @@ class PwcHeadEngine:
         L.check(L.lib().ufr_grad_finalize(L.ptr(Gs.t), g_chunk0, L.ptr(mask.t), mask_chunk0, L.ptr(out.t), out.plane_stride,
                                           out_chunk0, Gs.M, chunks, ig.LEAKY, L.stream()), "gradient finalize")
 
+    def _cat_call(self, fn, members, k, *front, after=()):
+        """One of the two stage-input layout calls (include/ufr_hip.h: ufr_nchw_cat_to_planes / ufr_chunks_to_nchw_cat) over the
+        members (corr 81, up_flow 2, up_feat 2, c1) of level k's x at buffer channels 0, 81, 83, 96."""
+        ptrs = (C.c_void_p * 4)(*[m.data_ptr() for m in members])
+        chans = (C.c_int * 4)(NCORR, 2, 2, FEAT[k])
+        first = (C.c_int * 4)(0, NCORR, NCORR + 2, 96)
+        if after:          # backward: (G, chunk0, chunks, dsts, channels, first, n, act0, pos, neg, B, H, W, stream)
+            L.check(fn(*front, ptrs, chans, first, 4, *after), "stage input backward")
+        else:              # forward: (srcs, channels, first, n, planes, plane_stride, chunk0, chunks, B, H, W, stream)
+            L.check(fn(ptrs, chans, first, 4, *front), "stage input forward")
+
     def _corr_forward(self, a, b, out):
         n, c, h, w = a.shape
         L.check(L.lib().ufr_corr_forward_fused(L.ptr(a), L.ptr(b), L.ptr(out), L.UFR_F32, n, c, h, w, C.byref(self._corr_p),
@@ -425,6 +439,7 @@ class PwcHeadEngine:
             D = self.D[k]
             if k == 6:
                 self._corr_forward(c1, c2, self.x_nchw[6])
+                D.load_nchw(self.x_nchw[6], X0)
             else:
                 h, w = self.grid[k + 1]
                 L.check(lib.ufr_deconv4x4s2_c2_forward(L.ptr(self.flow[k + 1]), L.ptr(self.dec_w[k + 1]), L.ptr(self.dec_b[k + 1]),
@@ -436,12 +451,9 @@ class PwcHeadEngine:
                 L.check(lib.ufr_pwc_warp_forward(L.ptr(c2), L.ptr(self.up_flow_s[k]), L.ptr(self.warped[k]), B, FEAT[k], *self.grid[k], st()),
                         "warp forward")
                 self._corr_forward(c1, self.warped[k], self.corr[k])
-                x = self.x_nchw[k]
-                x[:, :NCORR].copy_(self.corr[k])
-                x[:, NCORR:NCORR + 2].copy_(self.up_flow[k])
-                x[:, NCORR + 2:].copy_(self.up_feat[k])
-                D.load_nchw(c1, X0 + 3)
-            D.load_nchw(self.x_nchw[k], X0)
+                # x = [corr 81 | up_flow 2 | up_feat 2 | 11 zeros | c1] straight into the planes (one pass instead of five)
+                self._cat_call(lib.ufr_nchw_cat_to_planes, (self.corr[k], self.up_flow[k], self.up_feat[k], c1), k,
+                               L.ptr(D.t), D.plane_stride, X0, _x_chunks(k), B, *self.grid[k], st())
             for i in range(5):
                 self.fwd[("dec", k, i)]()
             self._pf_forward(D, D.chunks, self.pf_wm[k], self.pf_b[k], self.flow[k])
@@ -472,21 +484,23 @@ class PwcHeadEngine:
             for j in ((4, 3, 2, 1, 0) if k == 2 else (3, 2, 1, 0)):
                 self.bwd[("dec", k, j)]()
             self.bwd[("dec", k, "x")]()
-            gx = self.G_x[k].to_nchw(self.gx_nchw[k].shape[1], 0, slope=1.0, out=self.gx_nchw[k])
             c1, c2 = self.F_nchw[k][:B], self.F_nchw[k][B:]
-            corr_act = self.x_nchw[k][:, :NCORR] if k < 6 else self.x_nchw[6]
-            # correlate = / C then LeakyReLU (PWCNet.py:42-50, :262): the sign of the activation is the pre-activation's
-            torch.mul(gx[:, :NCORR], torch.where(corr_act > 0, 1.0 / FEAT[k], ig.LEAKY / FEAT[k]), out=self.g_corr[k])
             gF = self.G_F[k]
+            # correlate = / C then LeakyReLU (PWCNet.py:42-50, :262): the sign of the activation is the pre-activation's
             if k == 6:
+                gx = self.G_x[6].to_nchw(self.gx_nchw[6].shape[1], 0, slope=1.0, out=self.gx_nchw[6])
+                torch.mul(gx[:, :NCORR], torch.where(self.x_nchw[6] > 0, 1.0 / FEAT[6], ig.LEAKY / FEAT[6]), out=self.g_corr[6])
                 self._corr_backward(c1, c2, self.g_corr[6], gF[:B], gF[B:])
                 break
+            # d / d x, member by member, in one pass: the cost volume's part through its activation, up_flow, up_feat, c1
+            self._cat_call(lib.ufr_chunks_to_nchw_cat, (self.g_corr[k], self.gx_upflow[k], self.g_upfeat[k], self.gx_c1[k]), k,
+                           L.ptr(self.G_x[k].t), 0, _x_chunks(k), after=(L.ptr(self.corr[k]), 1.0 / FEAT[k], ig.LEAKY / FEAT[k], B,
+                                                                          *self.grid[k], st()))
             self._corr_backward(c1, self.warped[k], self.g_corr[k], self.g_c1corr[k], self.g_warped[k])
-            torch.add(gx[:, 96:96 + FEAT[k]], self.g_c1corr[k], out=gF[:B])
+            torch.add(self.gx_c1[k], self.g_c1corr[k], out=gF[:B])
             L.check(lib.ufr_pwc_warp_backward(L.ptr(c2), L.ptr(self.up_flow_s[k]), L.ptr(self.g_warped[k]), L.ptr(gF[B:]),
                                               L.ptr(self.g_flow_s[k]), B, FEAT[k], *self.grid[k], st()), "warp backward")
-            torch.add(gx[:, NCORR:NCORR + 2], self.g_flow_s[k], alpha=FLOW_SCALE[k], out=self.g_upflow[k])
-            self.g_upfeat[k].copy_(gx[:, NCORR + 2:NCORR + 4])
+            torch.add(self.gx_upflow[k], self.g_flow_s[k], alpha=FLOW_SCALE[k], out=self.g_upflow[k])
             L.check(lib.ufr_deconv4x4s2_c2_backward_data(L.ptr(self.g_upflow[k]), L.ptr(self.dec_w[k + 1]), L.ptr(self.g_flow[k + 1]), B,
                                                          *self.grid[k + 1], st()), "deconv backward")
             g_flow = self.g_flow[k + 1]
