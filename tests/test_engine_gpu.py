@@ -334,7 +334,7 @@ def test_normalize_frames_kernel_is_bit_exact(net):
 
 def test_window_gather_chunks_and_gradient_planes_kernels():
     """csrc/window.hip `window_gather_chunks_kernel` == ufr_window_gather on the NCHW form of the same chunk-major tensor;
-    csrc/igemm.hip `ufr_nchw_grad_to_planes` == gradient x LeakyReLU'(activation), split exactly."""
+    csrc/plane_layout.hip `ufr_nchw_grad_to_planes` == gradient x LeakyReLU'(activation), split exactly."""
     from understanding_flow_robustness_amd import _lib as L
     from understanding_flow_robustness_amd import igemm as ig
     g = torch.Generator().manual_seed(6)

@@ -16,7 +16,7 @@ def _planes_value(wi: ig.WeightImage, phase: int = 0) -> torch.Tensor:
 
 
 def _pack_frames(x: torch.Tensor) -> torch.Tensor:
-    """Emulation of csrc/igemm.hip conv1_pack_kernel without the mean: [N,3,H,W] -> [N, H/2+3, W/2+2, 32]."""
+    """Emulation of csrc/plane_layout.hip conv1_pack_kernel without the mean: [N,3,H,W] -> [N, H/2+3, W/2+2, 32]."""
     N, _, H, W = x.shape
     Hh, Wh = H // 2, W // 2
     out = torch.zeros(N, Hh + 3, Wh + 2, 32, dtype=x.dtype)

@@ -244,7 +244,7 @@ class FlowNetCHeadEngine:
 
     def _conv1_launch(self, n: int, H: int, W: int, c1: ig.Planes) -> dict:
         """conv1 = Conv2d(3, 64, 7, 2, 3) + bias + LeakyReLU as an igemm launch over the packed planes of the raw frames
-        (csrc/igemm.hip `conv1_pack_kernel`: pixel-unshuffle + two columns per chunk -> 8 taps of one chunk, the mean
+        (csrc/plane_layout.hip `conv1_pack_kernel`: pixel-unshuffle + two columns per chunk -> 8 taps of one chunk, the mean
         subtraction and the zero padding inside the buffer), writing conv1's planes directly."""
         packed = ig.Planes(n, H // 2 + 3, W // 2 + 2, 1, self.dev)
         wi = ig.conv1_packed_weights(self._conv("conv1").weight)

@@ -5,7 +5,7 @@ the plane layout between layers.
 
     conv / deconv / inter_conv            csrc/igemm.hip (bf16 split planes, six products; bias + LeakyReLU or linear epilogue)
     predict_flow*, upsampled_flow*        csrc/engine_small.hip
-    7x7 stride-2 stem on 12 channels      pixel-unshuffle pack (csrc/window.hip) + a 16-tap stride-1 launch over 48 channels
+    7x7 stride-2 stem on 12 channels      pixel-unshuffle pack (csrc/plane_layout.hip) + a 16-tap stride-1 launch over 48 channels
 
 A `torch.cat` of the reference is a chunk offset into one buffer (a segment list says where each member sits; weights are
 re-indexed once).  Adjoint: every buffer has a float32 gradient sum of the same layout, zero-filled at the start of a
