@@ -140,3 +140,39 @@ def test_pwc_engine_step_equals_full_frame_torch_step(net, monkeypatch):
         print(f"update {upd:.3e}, engine step vs torch step {err / upd:.2e} of it; loss {lf:.6f} / {le:.6f}")
         assert nf == ne == 1 and abs(lf - le) <= 1e-5
         assert 1e-3 < upd < 1.9 and err <= 1e-4 * upd, f"{err / upd:.2e} of the update"
+
+
+@pytest.mark.parametrize("B,F,H,W", [(2, 32, 24, 40), (1, 96, 13, 29)])
+def test_stage_input_cat_kernels(B, F, H, W):
+    """x = cat(corr 81, up_flow 2, up_feat 2 | c1) -> planes (ufr_nchw_cat_to_planes) and the member gradients back out of the
+    float32 gradient sum (ufr_chunks_to_nchw_cat; the cost volume's part through its activation): exact copies / products."""
+    import ctypes as C
+
+    from understanding_flow_robustness_amd import _lib as L
+    from understanding_flow_robustness_amd import igemm as ig
+    g = torch.Generator().manual_seed(F + H)
+    members = [torch.randn(B, c, H, W, generator=g).to(DEV) for c in (81, 2, 2, F)]
+    chans, first = (C.c_int * 4)(81, 2, 2, F), (C.c_int * 4)(0, 81, 83, 96)
+    chunks = 3 + ig.pad32(F) // 32
+    planes = ig.Planes(B, H, W, chunks + 2, DEV)
+    planes.t.fill_(7.0)
+    ptrs = (C.c_void_p * 4)(*[m.data_ptr() for m in members])
+    L.check(L.lib().ufr_nchw_cat_to_planes(ptrs, chans, first, 4, L.ptr(planes.t), planes.plane_stride, 1, chunks, B, H, W, L.stream()))
+    got = planes.to_nchw(chunks * 32, 1)
+    want = torch.zeros(B, chunks * 32, H, W, device=DEV)
+    for m, c0 in zip(members, (0, 81, 83, 96)):
+        want[:, c0:c0 + m.shape[1]] = m
+    assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())          # three bf16 planes hold a float32 exactly
+    assert bool((planes.t[:, 0] == 7.0).all()) and bool((planes.t[:, chunks + 1] == 7.0).all())
+    G = ig.GradSum(B, H, W, chunks + 1, DEV)
+    G.t.copy_(torch.randn(G.t.shape, generator=g).to(DEV))
+    outs = [torch.full_like(m, float("nan")) for m in members]
+    optrs = (C.c_void_p * 4)(*[o.data_ptr() for o in outs])
+    L.check(L.lib().ufr_chunks_to_nchw_cat(L.ptr(G.t), 1, chunks, optrs, chans, first, 4, L.ptr(members[0]), 0.25, 0.025, B, H, W, L.stream()))
+    full = G.to_nchw(chunks * 32, 1, slope=1.0)
+    assert torch.equal(outs[0], full[:, :81] * torch.where(members[0] > 0, 0.25, 0.025))
+    for o, c0 in zip(outs[1:], (81, 83, 96)):
+        assert torch.equal(o, full[:, c0:c0 + o.shape[1]])
+    with pytest.raises(RuntimeError, match="out of order"):
+        L.check(L.lib().ufr_nchw_cat_to_planes(ptrs, chans, (C.c_int * 4)(0, 80, 83, 96), 4, L.ptr(planes.t), planes.plane_stride, 1, chunks,
+                                               B, H, W, L.stream()))
