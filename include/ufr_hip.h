@@ -465,10 +465,11 @@ typedef struct {
   const void* mask; int mask_chunk0;
   void* out_planes; long out_plane_stride; int out_chunk0;
   float* out_f32; int out_f32_chunk0;
-  float* tail; int tail_n0;                    /* optional: output columns >= tail_n0 (a multiple of 32) leave as RAW sums into this fp32
+  float* tail; int tail_n0, tail_accumulate;   /* optional: output columns >= tail_n0 (a multiple of 32) leave as RAW sums into this fp32
                                                   chunk-major tensor [(N - tail_n0) / 32 chunks][B*Ho*Wo][32] instead of passing the epilogue:
                                                   a later layer's partial sum over the same input chunks, which that layer's own launch
-                                                  takes back as `add` (with act = 1: LeakyReLU(acc + add + bias)) */
+                                                  takes back as `add` (with act = 1: LeakyReLU(acc + add + bias)); tail_accumulate != 0
+                                                  adds the sums onto the tensor (a gradient sum with other contributors) */
   int splitk; float* ws;
   int products;                                /* 6: the float32-accurate six-product form (the only one) */
   int variant;                                 /* kernel form: 0 / 2 = single-stage LDS-DMA tiles (128 x 128; 128 x 64 when Npad % 128),

@@ -68,7 +68,7 @@ class IgemmDesc(C.Structure):
                 ("mask", C.c_void_p), ("mask_chunk0", C.c_int),
                 ("out_planes", C.c_void_p), ("out_plane_stride", C.c_long), ("out_chunk0", C.c_int),
                 ("out_f32", C.c_void_p), ("out_f32_chunk0", C.c_int),
-                ("tail", C.c_void_p), ("tail_n0", C.c_int),
+                ("tail", C.c_void_p), ("tail_n0", C.c_int), ("tail_accumulate", C.c_int),
                 ("splitk", C.c_int), ("ws", C.c_void_p),
                 ("products", C.c_int), ("variant", C.c_int), ("k_order", C.c_int)]
 

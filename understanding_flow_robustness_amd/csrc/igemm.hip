@@ -61,14 +61,15 @@ struct Epilogue {
   const __bf16* mask; int mask_chunk0;
   __bf16* out_planes; long out_plane_stride; int out_chunk0;
   float* out_f32; int out_f32_chunk0;
-  float* tail; int tail_n0;           // columns >= tail_n0 (a multiple of 32): raw sums to this fp32 chunk-major tensor (no bias / act)
+  float* tail; int tail_n0, tail_acc; // columns >= tail_n0 (a multiple of 32): raw sums to (tail_acc: added onto) this fp32 chunk-major tensor
   long Mout; int N, Nchunks32;        // channels < Nchunks32*32 are written (zeros beyond N: the chunk's padding)
 };
 
 __device__ __forceinline__ void epilogue_store(const Epilogue& e, long pout, int n, float v) {
   if (n >= e.Nchunks32 * 32) return;
   if (e.tail && n >= e.tail_n0) {
-    e.tail[((long)((n - e.tail_n0) >> 5) * e.Mout + pout) * 32 + (n & 31)] = n < e.N ? v : 0.f;
+    float* tp = e.tail + ((long)((n - e.tail_n0) >> 5) * e.Mout + pout) * 32 + (n & 31);
+    *tp = (n < e.N ? v : 0.f) + (e.tail_acc ? *tp : 0.f);
     return;
   }
   const long cm = ((long)(n >> 5) * e.Mout + pout) * 32 + (n & 31);          // chunk-major element inside a tensor
@@ -107,6 +108,10 @@ __device__ __forceinline__ void epilogue_store8(const Epilogue& e, long pout, in
     for (int j = 0; j < 8; ++j)
       if (n0 + j >= e.N) v[j] = 0.f;
     float* tp = e.tail + ((long)((n0 - e.tail_n0) >> 5) * e.Mout + pout) * 32 + (n0 & 31);
+    if (e.tail_acc) {                    // the tail lives in a running sum (a gradient with other contributors)
+      const float4 o0 = *reinterpret_cast<const float4*>(tp), o1 = *reinterpret_cast<const float4*>(tp + 4);
+      v[0] += o0.x; v[1] += o0.y; v[2] += o0.z; v[3] += o0.w; v[4] += o1.x; v[5] += o1.y; v[6] += o1.z; v[7] += o1.w;
+    }
     *reinterpret_cast<float4*>(tp) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4*>(tp + 4) = make_float4(v[4], v[5], v[6], v[7]);
     return;
@@ -890,7 +895,7 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   a.e.mask = static_cast<const __bf16*>(d->mask); a.e.mask_chunk0 = d->mask_chunk0;
   a.e.out_planes = static_cast<__bf16*>(d->out_planes); a.e.out_plane_stride = d->out_plane_stride; a.e.out_chunk0 = d->out_chunk0;
   a.e.out_f32 = d->out_f32; a.e.out_f32_chunk0 = d->out_f32_chunk0;
-  a.e.tail = d->tail; a.e.tail_n0 = d->tail_n0;
+  a.e.tail = d->tail; a.e.tail_n0 = d->tail_n0; a.e.tail_acc = d->tail_accumulate;
   a.e.Mout = (long)d->B * d->Ho * d->Wo; a.e.N = d->N; a.e.Nchunks32 = (d->N + 31) / 32;
   a.nphase = d->nphase; a.splitk = d->splitk; a.ws = d->ws;
   a.xcd = 1;                              // XCD-aware tile order (off: +0.2 ms per iteration, profiles/r2_bench_engine_v4_no_xcd_order)

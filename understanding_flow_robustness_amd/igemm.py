@@ -279,11 +279,12 @@ def make_launch(wi: WeightImage, x: Planes, in_chunk0: int, rows_hw, out_hw, *, 
                 out_chunk0: int = 0, out_f32: GradSum | None = None, out_f32_chunk0: int = 0, bias: torch.Tensor | None = None,
                 add: GradSum | None = None, add_chunk0: int = 0, mask: Planes | None = None, mask_chunk0: int = 0,
                 slope: float = LEAKY, splitk: int = 1, ws: torch.Tensor | None = None, row_band=None, in_band=None,
-                products: int = 6, variant: int = 0, tail: GradSum | None = None, tail_n0: int = 0) -> Launch:
+                products: int = 6, variant: int = 0, tail: GradSum | None = None, tail_n0: int = 0, tail_chunk0: int = 0,
+                tail_accumulate: bool = False) -> Launch:
     """Descriptor for `wi` applied to the chunks [in_chunk0, in_chunk0 + KC) of `x`.
     rows_hw = (Hr, Wr) row grid; out_hw = (Ho, Wo) output grid.  row_band = (origins int32 tensor, element stride, divisor):
     tail / tail_n0: the launch's output columns >= tail_n0 are a LATER layer's partial sum over these input chunks and leave raw
-    into `tail` (chunk 0 on); that layer's own launch passes it as `add` together with its bias.
+    into `tail` (chunk `tail_chunk0` on; `tail_accumulate`: added onto it); that layer's own launch passes it as `add`.
     the row grid's columns start at origins[b*stride] // divisor.  in_band = (origins, stride, divisor, width): input
     columns outside [origin, origin + width) read as zero.  bias given -> forward epilogue (bias + LeakyReLU)."""
     d = L.IgemmDesc()
@@ -311,9 +312,10 @@ def make_launch(wi: WeightImage, x: Planes, in_chunk0: int, rows_hw, out_hw, *, 
     Mout = x.B * d.Ho * d.Wo
     nch = pad32(wi.N) // 32
     if tail is not None:
-        if tail_n0 % 32 or not 0 < tail_n0 < wi.N or tail.M != Mout or (wi.N - tail_n0 + 31) // 32 > tail.chunks:
+        if tail_n0 % 32 or not 0 < tail_n0 < wi.N or tail.M != Mout or tail_chunk0 + (wi.N - tail_n0 + 31) // 32 > tail.chunks:
             raise RuntimeError("igemm: tail geometry")
-        d.tail, d.tail_n0 = tail.t.data_ptr(), int(tail_n0)
+        d.tail, d.tail_n0 = tail.t.data_ptr() + int(tail_chunk0) * tail.M * 32 * 4, int(tail_n0)
+        d.tail_accumulate = 1 if tail_accumulate else 0
         nch = tail_n0 // 32                                       # chunks that reach the planes / fp32 output
     keep = [wi, x, bias, add, mask, out_planes, out_f32, ws, row_band, in_band, tail]
     if bias is not None:

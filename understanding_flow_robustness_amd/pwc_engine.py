@@ -274,6 +274,24 @@ class PwcHeadEngine:
                 later = [(w, c0) for sid, w, c0 in src if sid == "dc1" or j == "x" or sid > j]      # the convolutions that read segment j
                 if not later:
                     continue                                           # conv_4 of levels 3-6: predict_flow^T and upfeat^T only
+                if k == 2 and j in (4, 3):
+                    # level 2: conv_4 (32 channels) and conv_3 (64) both take dc_conv1's gradient.  ONE 128-column launch over
+                    # dc_conv1's four gradient chunks computes conv_4's whole data gradient (columns 0-31, through the epilogue)
+                    # and conv_3's share (columns 32-95: raw sums ADDED onto G_D's conv_3 chunks, the tail of csrc/igemm.hip);
+                    # conv_3's own launch then reduces over conv_4's gradient chunk only.  (32- and 64-column launches over a
+                    # 36-step reduction ran half-empty tiles: 0.49 ms -> 0.34 ms.)
+                    if j == 4:
+                        wv = self.w_dc1[:, :(SEG[4] + SEG[3])]         # [dc_conv1's 128 outputs, conv_4 | conv_3 channels, 3, 3]
+                        wi = ig.conv_backward_weights(wv, 1, 1)
+                        plan(("dec", 2, 4), "bwd", wi, self.gzD[2], 0, 2, 2, add=self.G_D[2], add_chunk0=A_OFF[4], mask=self.D[2],
+                             mask_chunk0=A_OFF[4], out_planes=self.gzD[2], out_chunk0=gz0 + A_OFF[4], tail=self.G_D[2], tail_n0=SEG[4],
+                             tail_chunk0=A_OFF[3], tail_accumulate=True)
+                    else:
+                        wv = wbuf[4][:, :SEG[3]]                       # conv_4's weights on conv_3's channels (conv_4 reads from chunk 1)
+                        wi = ig.conv_backward_weights(wv, 1, 1)
+                        plan(("dec", 2, 3), "bwd", wi, self.gzD[2], gz0 + A_OFF[4], 2, 2, add=self.G_D[2], add_chunk0=A_OFF[3],
+                             mask=self.D[2], mask_chunk0=A_OFF[3], out_planes=self.gzD[2], out_chunk0=gz0 + A_OFF[3])
+                    continue
                 # stacked like the gradient planes in gzD: [gz channels of the later outputs, segment channels, 3, 3]
                 wv = torch.cat([w[:, (dst0 - c0) * 32:(dst0 - c0) * 32 + width] for w, c0 in later], 0)
                 wi = ig.conv_backward_weights(wv, 1, 1)
