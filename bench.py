@@ -1,6 +1,6 @@
 """bench.py -- headline metric of BASELINE.json on MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W] [--config c2|c4|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 metric   : attack-iters/s = frame pairs x I-FGSM patch iterations per second
@@ -275,21 +275,20 @@ def cpu_baseline():
 
 
 def launch_ranks(n, argv):
-    """One process per GPU through `python -m torch.distributed.run` on 127.0.0.1 (a free port), as a CHILD process: this
-    process has made no HIP call yet and makes none.  Returns the exit code; rank 0's stdout (the one JSON line) is relayed."""
-    import socket
+    """One process per GPU through `python -m torch.distributed.run --standalone` on 127.0.0.1 (the launcher picks and owns
+    its rendezvous port: no bind-then-close race), as a CHILD process: this process has made no HIP call yet and makes none.
+    Returns the exit code; rank 0's stdout (the one JSON line) is relayed, everything else goes to stderr on failure."""
     import subprocess
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n}", os.path.abspath(__file__)] + list(argv)
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
     for ln in lines[-1:]:
         print(ln, flush=True)
+    if proc.returncode != 0:                                # a rank's diagnostic prints must not be lost
+        sys.stderr.write("".join(ln + "\n" for ln in proc.stdout.splitlines() if ln not in lines[-1:]))
     if proc.returncode == 0 and not lines:
         print("bench.py: the ranks exited without a result line", file=sys.stderr)
         return 1
@@ -307,11 +306,128 @@ def cpu_model():
     return None
 
 
+# ------------------------------------------------------------------------------------ the three shardable configs
+# Every config is (step, resident batches, how one attack() call is loaded, iterations per call): SURVEY.md 8e shards the
+# pairs of C2 / C4 eight per rank behind ONE patch (31 KB all-gather per iteration) and the pairs of C5 one per rank behind
+# ONE perturbation (11 MiB all-reduce per iteration).
+CONFIG_WORKLOADS = {
+    "c2": "FlowNetC 384x1280 I-FGSM patch attack (configs[1])",
+    "c4": "PWC-Net 384x1280 I-FGSM patch attack (configs[3]: batch 64 sharded 8 per GPU, patch-gradient exchange)",
+    "c5": "FlowNet2 448x1024 universal-perturbation loop (configs[4]: one pair per GPU, image-sized all-reduce)",
+}
+
+
+def setup_patch_config(opt, rank, world, device, flownet, seed):
+    """C2 / C4: `B_PER_GPU` pairs per rank behind one 51x51 patch in patch coordinates (patch_attacks/main.py:523-613)."""
+    from understanding_flow_robustness_amd.flownets.utils_model import fetch_model, predict_flow
+    from understanding_flow_robustness_amd.patch_attack import PatchAttackStep, ShardedExchange
+    args = Namespace(flownet=flownet, l2=False, alpha=0.0, lr=1000.0, max_count=2)
+    net = fetch_model(args, synthetic_seed=seed).to(device)
+    exchange = ShardedExchange() if world > 1 else None
+    step = PatchAttackStep(net, args, B_PER_GPU, H, W, device=device, shared_patch=True, exchange=exchange,
+                           use_graph=not opt.no_graph, warmup=2, patch_hw=(PATCH, PATCH))
+    # two resident batches (frames AND patch placements differ): consecutive attack() calls never see
+    # the same operands, so nothing cached for one call can serve the next
+    g = torch.Generator().manual_seed(7)
+    patch0 = torch.rand(1, 3, PATCH, PATCH, generator=g).to(device)     # same patch on every rank
+    mask_p = circle_mask(PATCH).expand(1, 3, PATCH, PATCH).contiguous().to(device)
+    batches = []
+    for k in range(2):
+        tgt, ref, origins = synthetic_batch(B_PER_GPU, 1000 + 17 * k + rank, device)
+        with torch.no_grad():
+            target = -torch.cat([predict_flow(net, None, tgt[i:i + 1], ref[i:i + 1], args) for i in range(B_PER_GPU)])   # main.py:395
+        batches.append(dict(args=(tgt, ref, patch0, mask_p, patch0, target), origins=origins))
+    load = lambda call: step.load(*batches[call % 2]["args"], origins=batches[call % 2]["origins"])
+    load(0)
+    step.run(0)                                                  # warm-up + graph capture, reloads operands
+    return dict(net=net, args=args, step=step, batches=batches, load=load, pairs=B_PER_GPU, per_call=max(1, opt.max_count),
+                executed=lambda: step.state[1], overflow=lambda: float(step.state[3]))
+
+
+def setup_universal_config(opt, rank, world, device):
+    """C5: one 448x1024 pair per rank behind ONE perturbation [2,3,H,W]; an attack() call = n_step = 10 sign steps
+    (global_attacks/universal_perturbation.py:452-530, defaults :73-106), new frames per call."""
+    from understanding_flow_robustness_amd.flownets.utils_model import fetch_model, predict_flow
+    from understanding_flow_robustness_amd.patch_attack import ShardedExchange
+    from understanding_flow_robustness_amd.universal_perturbation import UniversalPerturbationStep
+    h, w = 448, 1024
+    args = Namespace(flownet="FlowNet2", n_step=10, learning_rate=2e-3, output_norm=0.02, flow_loss="cossim",
+                     perturb_method="ifgsm", perturb_mode="both", add_gaussian=False)
+    net = fetch_model(args, synthetic_seed=3).to(device)
+    exchange = ShardedExchange() if world > 1 else None
+    step = UniversalPerturbationStep(net, args, 1, h, w, device=device, shared=True, exchange=exchange,
+                                     use_graph=not opt.no_graph)
+    batches = []
+    for k in range(2):
+        g = torch.Generator().manual_seed(2000 + 17 * k + rank)
+        i0, i1 = torch.rand(1, 3, h, w, generator=g).to(device), torch.rand(1, 3, h, w, generator=g).to(device)
+        with torch.no_grad():
+            target = -predict_flow(net, None, i0, i1, args)
+        batches.append((i0, i1, target))
+    # the perturbation is carried from call to call like the reference's (`universal_perturbation_var`, :573-600)
+    load = lambda call: step.load(*batches[call % 2][:2], step.delta, batches[call % 2][2])
+    load(0)
+    step.run(0)
+    done = torch.zeros(1, device=device)       # no early exit in this loop (:464: `for _ in range(n_step)`): every enqueued step runs
+    return dict(net=net, args=args, step=step, batches=batches, load=load, pairs=1, per_call=args.n_step, hw=(h, w),
+                executed=None, overflow=lambda: 0.0, done=done)
+
+
+def cpu_baseline_other(config):
+    """C4 / C5 on the host cores: the CPU oracle (oracle/flow_oracle.py) on one pair, bounded to ~15 s."""
+    from oracle import flow_oracle as fo
+    from oracle import oracle_ops
+    from understanding_flow_robustness_amd.flownets.weights import synthetic_state_dict
+    oracle_ops.lib()
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
+    torch.set_num_threads(cores)
+    oracle_ops.lib().ufr_oracle_set_threads(cores)
+    t0, n = time.time(), 0
+    if config == "c4":
+        from understanding_flow_robustness_amd.flownets.pwcnet import PWCDCNet
+        sd = synthetic_state_dict(PWCDCNet().state_dict(), seed=1)
+        tgt, ref, origins = synthetic_batch(1, 1234, "cpu")
+        mask = fo.place(circle_mask(PATCH).expand(1, 3, PATCH, PATCH), origins, H, W)
+        patch0 = torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(99)) * mask
+        predict = lambda x, y: fo.pwcnet_forward(sd, x, y)
+        with torch.no_grad():
+            target = -predict(tgt, ref)
+        t0 = time.time()
+        while time.time() - t0 < 12.0:
+            n += fo.patch_attack(predict, tgt, ref, patch0.clone(), mask, patch0, target, lr=1e3, max_count=2)[3]
+        what = "attack() calls of 2 iterations, 1 pair 384x1280, PWC-Net fp32"
+    else:
+        from understanding_flow_robustness_amd.flownets.flownet2 import FlowNet2
+        sd = synthetic_state_dict(FlowNet2().state_dict(), seed=3)
+        g = torch.Generator().manual_seed(1234)
+        i0, i1 = torch.rand(1, 3, 448, 1024, generator=g), torch.rand(1, 3, 448, 1024, generator=g)
+        predict = lambda x, y: fo.flownet2_forward(sd, x, y)
+        with torch.no_grad():
+            target = -predict(i0, i1)
+        delta = torch.zeros(1, 2, 3, 448, 1024)
+        t0 = time.time()
+        while time.time() - t0 < 12.0:
+            _, _, delta = fo.universal_attack(predict, i0, i1, delta, target, n_step=1, lr=2e-3, eps=0.02, flow_loss="cossim")
+            n += 1
+        what = "universal-perturbation sign steps, 1 pair 448x1024, FlowNet2 fp32"
+    dt = time.time() - t0
+    return dict(value=round(n / dt, 4), unit="frame-pairs*steps/s", cores=cores, cpu_model=cpu_model(), kind="port",
+                sample=f"{n} {what}, torch-CPU convs + the C oracle's correlation / Resample2d / ChannelNorm, {dt:.1f} s")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=sorted(CONFIG_WORKLOADS), default="c2",
+                    help="c2 = the headline (BASELINE configs[1]); c4 / c5 = the configs BASELINE shards over 8 GPUs")
+    ap.add_argument("--sustained-seconds", type=float, default=2.0,
+                    help="N=1: after the K timed steps, replay the same protocol for at least this long (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-full-frame", action="store_true", help="skip the full-frame side measurement")
@@ -343,42 +459,27 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from understanding_flow_robustness_amd.flownets.utils_model import fetch_model
-    from understanding_flow_robustness_amd.patch_attack import PatchAttackStep, ShardedExchange
-
     torch.backends.cudnn.benchmark = True      # patch_attacks/main.py:276 (MIOpen find mode)
-    args = Namespace(flownet="FlowNetC", l2=False, alpha=0.0, lr=1000.0, max_count=2)
-    net = fetch_model(args, synthetic_seed=0).to(device)
-    exchange = ShardedExchange() if world > 1 else None
-    step = PatchAttackStep(net, args, B_PER_GPU, H, W, device=device, shared_patch=True, exchange=exchange,
-                           use_graph=not opt.no_graph, warmup=2, patch_hw=(PATCH, PATCH))
-
-    # two resident batches (frames AND patch placements differ): consecutive attack() calls never see
-    # the same operands, so nothing cached for one call can serve the next
-    g = torch.Generator().manual_seed(7)
-    patch0 = torch.rand(1, 3, PATCH, PATCH, generator=g).to(device)     # same patch on every rank
-    mask_p = circle_mask(PATCH).expand(1, 3, PATCH, PATCH).contiguous().to(device)
-    batches = []
-    for k in range(2):
-        tgt, ref, origins = synthetic_batch(B_PER_GPU, 1000 + 17 * k + rank, device)
-        with torch.no_grad():
-            target = -torch.cat([net(tgt[i:i + 1], ref[i:i + 1]) for i in range(B_PER_GPU)])   # main.py:395
-        batches.append(dict(args=(tgt, ref, patch0, mask_p, patch0, target), origins=origins))
-    step.load(*batches[0]["args"], origins=batches[0]["origins"])
-    step.run(0)                                                  # warm-up + graph capture, reloads operands
-    mc = max(1, opt.max_count)
+    if opt.config == "c5":
+        ctx = setup_universal_config(opt, rank, world, device)
+    else:
+        ctx = setup_patch_config(opt, rank, world, device, *(("FlowNetC", 0) if opt.config == "c2" else ("PWCNet", 1)))
+    net, args, step, batches, pairs, mc = ctx["net"], ctx["args"], ctx["step"], ctx["batches"], ctx["pairs"], ctx["per_call"]
     executed_acc = torch.zeros(1, device=device)
 
     def attack_calls(iterations, first_call):
-        """`iterations` inner-loop iterations as attack() calls of `max_count` (main.py:79 default 2): every
-        call loads a different batch (new frames, new placement: paste, window placement, full-frame prefix)
+        """`iterations` inner-loop iterations as attack() calls of `per_call` (main.py:79 default 2; universal: n_step 10):
+        every call loads a different batch (new frames, new placement: paste, window placement, full-frame prefix)
         and then replays the captured iteration.  Nothing is read back."""
         call, left = first_call, iterations
         while left > 0:
-            step.load(*batches[call % 2]["args"], origins=batches[call % 2]["origins"])
+            ctx["load"](call)
             n = min(mc, left)
             step.enqueue(n)
-            executed_acc.add_(step.state[1])
+            if ctx["executed"] is not None:
+                executed_acc.add_(ctx["executed"]())
+            else:
+                executed_acc.add_(float(n))
             call, left = call + 1, left - n
         return call
 
@@ -391,7 +492,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    attack_calls(opt.steps, calls_done)
+    calls_done = attack_calls(opt.steps, calls_done)
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
@@ -404,96 +505,149 @@ def main():
     if int(executed) != opt.steps:
         raise SystemExit(f"only {int(executed)} of {opt.steps} iterations took effect (loss gate tripped): "
                          "the timed region would contain skipped work")
-    if float(step.state[3]) != 0.0:
+    if ctx["overflow"]() != 0.0:
         raise SystemExit("a patch window overflowed inside the timed region")
+
+    # a SUSTAINED figure beside the K-step one (N=1): the same calls for >= --sustained-seconds, so that a clock that sags
+    # under a long load shows (the K = 20 region is ~0.1 s)
+    sustained = None
+    if world == 1 and opt.sustained_seconds > 0:
+        ms_est = elapsed * 1e3 / opt.steps
+        n_sus = int(-(-max(opt.sustained_seconds * 1e3 / ms_est, mc) // mc) * mc)
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        attack_calls(n_sus, calls_done)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t1
+        sustained = dict(ms_per_step=round(dt * 1e3 / n_sus, 3), steps=n_sus, seconds=round(dt, 2))
 
     if rank == 0:
         ms = elapsed * 1e3 / opt.steps
-        value = world * B_PER_GPU * opt.steps / elapsed
-        band = getattr(step, "band", None) if step.cone is not None else None
-        gflop = gflop_per_pair_step(step.win_hw if step.cone is not None else None, mc,
-                                    band.width if band is not None and band.width else None,
-                                    bool(band is not None and band.inc_layers))
-        tf = gflop * B_PER_GPU / ms                        # per-GPU TFLOP/s (GFLOP/ms), executed work only
+        value = world * pairs * opt.steps / elapsed
         line = {
             "metric": "attack-iters/s", "value": round(value, 3), "unit": "frame-pairs*steps/s",
             "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "FlowNetC 384x1280 I-FGSM patch attack (configs[1])", "pairs_per_gpu": B_PER_GPU,
-                       "global_pairs": world * B_PER_GPU, "patch": "ONE 51x51 circular patch in patch coordinates, shown by every pair at its own placement",
-                       "calls": f"attack() calls of max_count={mc} iterations, new frames + placement per call",
-                       "prefix": (f"conv1-3 on a {step.win_hw[0]}x{step.win_hw[1]} window per pair"
-                                  if step.cone is not None else "full frame"),
-                       "head_adjoint": (f"conv3_1/4/4_1/5 data gradients on a {band.width}-pixel column band"
-                                        if band is not None else "full width"),
-                       "loss": "cosine", "lr": 1000.0, "weights": "synthetic seeded (no checkpoints offline)",
-                       "graph": not opt.no_graph,
-                       "parallelism": (f"dp{world}: pairs sharded, per-rank crop of the pre-clamp gradient to [3,51,51], "
-                                       f"all-gather of {world} x 31 KB rows + fixed-order sum before the clamp")},
-            "roofline": {"bound": "mfma", "kernel": "attack step = 1 hipGraph launch", "achieved": round(tf, 2),
-                         "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_TFLOPS, 4),
-                         "traffic": step_traffic(), "algorithmic_gflop_per_launch": round(gflop * B_PER_GPU, 1),
-                         "full_frame_gflop_per_launch": round(GFLOP_PER_PAIR_STEP * B_PER_GPU, 1),
-                         "peak_note": "the fp32 VECTOR / fp32-MFMA peak, kept as round 1's yardstick: the convolutions run as "
-                                      "six bf16 MFMA products per float32 product (ceiling 416.7, see the top-level roofline), "
-                                      "so this fraction may pass 1"},
+            "config": {"workload": CONFIG_WORKLOADS[opt.config], "pairs_per_gpu": pairs, "global_pairs": world * pairs,
+                       "weights": "synthetic seeded (no checkpoints offline)", "graph": not opt.no_graph},
         }
-        engine_on = bool(getattr(net, "__dict__", {}).get("_ufr_head_engines"))
-        line["config"]["arithmetic"] = (
-            "float32 end to end; the head's convolutions compute each float32 product on the bf16 matrix cores as three bf16 "
-            "planes per operand and the six leading products, float32 accumulation (csrc/igemm.hip: error vs float64 at "
-            "MIOpen's own fp32 level, tests/test_igemm_gpu.py) -- the head, conv1 / conv2 / conv3 of the full-frame prefix and of "
-            "the window and their data gradients, the cost volume and both of its adjoints, predict_flow; no vendor "
-            "convolution kernel runs in an iteration" if engine_on else
-            "float32 end to end on MIOpen (UFR_ENGINE=0)")
-        if world == 1:
-            kernels, agg = kernel_rooflines(step, device, mc)
-            step_line = line["roofline"]
-            if agg is not None:
-                # the dominant kernel: csrc/igemm.hip over the launches of one average iteration (live HIP-event timings)
-                tf_i = agg["gflop"] / agg["ms"]
-                line["roofline"] = {"bound": "mfma", "kernel": "igemm (csrc/igemm.hip), all launches of one iteration",
-                                    "achieved": round(tf_i, 1), "peak": round(PEAK_SPLIT6_TFLOPS, 1), "unit": "TFLOP/s",
-                                    "frac": round(tf_i / PEAK_SPLIT6_TFLOPS, 3),
-                                    "traffic": _pmc(IGEMM_TRAFFIC).get("per_iteration_bytes"),
-                                    "algorithmic_bytes_per_iteration": round(agg["bytes"]),
-                                    "ms_per_iteration": round(agg["ms"], 3), "algorithmic_gflop_per_iteration": round(agg["gflop"], 1),
-                                    "peak_note": "fp32-equivalent: 2.5 PFLOP/s dense bf16 MFMA / 6 products per float32 product",
-                                    "step": step_line}
-            line["roofline"]["kernels"] = kernels
-            if not opt.no_other_configs:
-                # the other BASELINE configs, one GPU's share each, measured live in this very process (steady-state inner
-                # loop of their own step + the rooflines of their igemm launches): C4 PWC-Net, C3 RAFT with alt_cuda_corr,
-                # C5 FlowNet2's universal-perturbation step (tools/bench_configs.py measures more: all-pairs RAFT, 8-pair RAFT)
-                sys.path.insert(0, os.path.join(ROOT, "tools"))
-                import bench_configs
-                line["config"]["other_configs"] = [bench_configs.measure(w, 6) for w in ("c4", "c3alt", "c5")]
-            if step.cone is not None and not opt.no_full_frame:
-                # the same protocol with every frame-sized shortcut off (UFR_CONE=0): what the windowed prefix,
-                # band and incremental forward are worth, measured in this very process
-                ref_step = PatchAttackStep(net, args, B_PER_GPU, H, W, device=device, shared_patch=True,
-                                           use_graph=not opt.no_graph, warmup=2, use_cone=False, patch_hw=(PATCH, PATCH))
-                ref_load = lambda c: ref_step.load(*batches[c % 2]["args"], origins=batches[c % 2]["origins"])
-                ref_load(0)
-                ref_step.run(0)
-                k = 6
-                for c in range(2):
-                    ref_load(c); ref_step.enqueue(mc)
-                torch.cuda.synchronize(device)
-                t1 = time.perf_counter()
-                done = 0
-                while done < k:
-                    ref_load(done // mc); ref_step.enqueue(min(mc, k - done)); done += mc
-                torch.cuda.synchronize(device)
-                line["config"]["full_frame_attack_iters_per_s"] = round(B_PER_GPU * k / (time.perf_counter() - t1), 2)
-            if not opt.no_cpu_baseline:
-                line["cpu_baseline"] = cpu_baseline()
-                line["config"]["c1_cpu_forward_s"] = line["cpu_baseline"].get("c1_cpu_forward_s")
+        if sustained is not None:
+            line["sustained_ms_per_step"] = sustained["ms_per_step"]
+            line["config"]["sustained"] = sustained
+        if opt.config == "c2":
+            c2_line(line, opt, ctx, world, device, ms, mc)
+        else:
+            other_line(line, opt, ctx, world, ms)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def other_line(line, opt, ctx, world, ms):
+    """C4 / C5: the dominant kernel is the same igemm; its roofline = every prepared launch of the config's engines timed live
+    on the step's own buffers (tools/bench_configs.igemm_roofline)."""
+    cfg = line["config"]
+    if opt.config == "c4":
+        cfg.update(patch="ONE 51x51 circular patch in patch coordinates, shown by every pair at its own placement",
+                   calls=f"attack() calls of max_count={ctx['per_call']} iterations, new frames + placement per call",
+                   loss="cosine", lr=1000.0,
+                   parallelism=f"dp{world}: pairs sharded, per-rank crop of the pre-clamp gradient to [3,51,51], all-gather of "
+                               f"{world} x 31 KB rows + fixed-order sum before the clamp")
+    else:
+        cfg.update(calls="attack() calls of n_step=10 sign steps, new frames per call, the perturbation carried over",
+                   loss="cossim", lr=2e-3, output_norm=0.02,
+                   parallelism=f"dp{world}: one pair per rank, all-reduce(sum) of the [2,3,448,1024] gradient + loss (11 MiB) "
+                               "before the sign")
+    if world == 1:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_configs
+        roof = bench_configs.igemm_roofline(ctx["net"])
+        if roof is not None:
+            line["roofline"] = roof
+        if not opt.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_other(opt.config)
+
+
+def c2_line(line, opt, ctx, world, device, ms, mc):
+    """The headline's own fields: executed-FLOP roofline of the step, the igemm aggregate, per-kernel rooflines, the other
+    configs measured live, the full-frame protocol, the CPU baseline."""
+    from understanding_flow_robustness_amd.patch_attack import PatchAttackStep
+    net, args, step, batches = ctx["net"], ctx["args"], ctx["step"], ctx["batches"]
+    band = getattr(step, "band", None) if step.cone is not None else None
+    gflop = gflop_per_pair_step(step.win_hw if step.cone is not None else None, mc,
+                                band.width if band is not None and band.width else None,
+                                bool(band is not None and band.inc_layers))
+    tf = gflop * B_PER_GPU / ms                        # per-GPU TFLOP/s (GFLOP/ms), executed work only
+    line["config"].update({
+                   "patch": "ONE 51x51 circular patch in patch coordinates, shown by every pair at its own placement",
+                   "calls": f"attack() calls of max_count={mc} iterations, new frames + placement per call",
+                   "prefix": (f"conv1-3 on a {step.win_hw[0]}x{step.win_hw[1]} window per pair"
+                              if step.cone is not None else "full frame"),
+                   "head_adjoint": (f"conv3_1/4/4_1/5 data gradients on a {band.width}-pixel column band"
+                                    if band is not None else "full width"),
+                   "loss": "cosine", "lr": 1000.0,
+                   "parallelism": (f"dp{world}: pairs sharded, per-rank crop of the pre-clamp gradient to [3,51,51], "
+                                   f"all-gather of {world} x 31 KB rows + fixed-order sum before the clamp")})
+    line["roofline"] = {"bound": "mfma", "kernel": "attack step = 1 hipGraph launch", "achieved": round(tf, 2),
+                     "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_TFLOPS, 4),
+                     "traffic": step_traffic(), "algorithmic_gflop_per_launch": round(gflop * B_PER_GPU, 1),
+                     "full_frame_gflop_per_launch": round(GFLOP_PER_PAIR_STEP * B_PER_GPU, 1),
+                     "peak_note": "the fp32 VECTOR / fp32-MFMA peak, kept as round 1's yardstick: the convolutions run as "
+                                  "six bf16 MFMA products per float32 product (ceiling 416.7, see the top-level roofline), "
+                                  "so this fraction may pass 1"}
+    engine_on = bool(getattr(net, "__dict__", {}).get("_ufr_head_engines"))
+    line["config"]["arithmetic"] = (
+        "float32 end to end; the head's convolutions compute each float32 product on the bf16 matrix cores as three bf16 "
+        "planes per operand and the six leading products, float32 accumulation (csrc/igemm.hip: error vs float64 at "
+        "MIOpen's own fp32 level, tests/test_igemm_gpu.py) -- the head, conv1 / conv2 / conv3 of the full-frame prefix and of "
+        "the window and their data gradients, the cost volume and both of its adjoints, predict_flow; no vendor "
+        "convolution kernel runs in an iteration" if engine_on else
+        "float32 end to end on MIOpen (UFR_ENGINE=0)")
+    if world == 1:
+        kernels, agg = kernel_rooflines(step, device, mc)
+        step_line = line["roofline"]
+        if agg is not None:
+            # the dominant kernel: csrc/igemm.hip over the launches of one average iteration (live HIP-event timings)
+            tf_i = agg["gflop"] / agg["ms"]
+            line["roofline"] = {"bound": "mfma", "kernel": "igemm (csrc/igemm.hip), all launches of one iteration",
+                                "achieved": round(tf_i, 1), "peak": round(PEAK_SPLIT6_TFLOPS, 1), "unit": "TFLOP/s",
+                                "frac": round(tf_i / PEAK_SPLIT6_TFLOPS, 3),
+                                "traffic": _pmc(IGEMM_TRAFFIC).get("per_iteration_bytes"),
+                                "algorithmic_bytes_per_iteration": round(agg["bytes"]),
+                                "ms_per_iteration": round(agg["ms"], 3), "algorithmic_gflop_per_iteration": round(agg["gflop"], 1),
+                                "peak_note": "fp32-equivalent: 2.5 PFLOP/s dense bf16 MFMA / 6 products per float32 product",
+                                "step": step_line}
+        line["roofline"]["kernels"] = kernels
+        if not opt.no_other_configs:
+            # the other BASELINE configs, one GPU's share each, measured live in this very process (steady-state inner
+            # loop of their own step + the rooflines of their igemm launches): C4 PWC-Net, C3 RAFT with alt_cuda_corr,
+            # C5 FlowNet2's universal-perturbation step (tools/bench_configs.py measures more: all-pairs RAFT, 8-pair RAFT)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_configs
+            line["config"]["other_configs"] = [bench_configs.measure(w, 6) for w in ("c4", "c3alt", "c5")]
+        if step.cone is not None and not opt.no_full_frame:
+            # the same protocol with every frame-sized shortcut off (UFR_CONE=0): what the windowed prefix,
+            # band and incremental forward are worth, measured in this very process
+            ref_step = PatchAttackStep(net, args, B_PER_GPU, H, W, device=device, shared_patch=True,
+                                       use_graph=not opt.no_graph, warmup=2, use_cone=False, patch_hw=(PATCH, PATCH))
+            ref_load = lambda c: ref_step.load(*batches[c % 2]["args"], origins=batches[c % 2]["origins"])
+            ref_load(0)
+            ref_step.run(0)
+            k = 6
+            for c in range(2):
+                ref_load(c); ref_step.enqueue(mc)
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            done = 0
+            while done < k:
+                ref_load(done // mc); ref_step.enqueue(min(mc, k - done)); done += mc
+            torch.cuda.synchronize(device)
+            line["config"]["full_frame_attack_iters_per_s"] = round(B_PER_GPU * k / (time.perf_counter() - t1), 2)
+        if not opt.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+            line["config"]["c1_cpu_forward_s"] = line["cpu_baseline"].get("c1_cpu_forward_s")
 
 
 if __name__ == "__main__":

@@ -77,8 +77,15 @@ def test_square_patch_train_and_validation_match_reference():
     vt, vr, gt = t(z["val_tgt"], DEV), t(z["val_ref"], DEV), t(z["val_gt"], DEV)
     items = [(vr[i:i + 1], vt[i:i + 1], vr[i:i + 1], gt[i:i + 1]) for i in range(3)]
     np.random.seed(29)
-    avg, names = validate_flow_with_gt(p0.copy(), m0.copy(), sh0, items, net, args)
+    vp, vm = p0.copy(), m0.copy()
+    avg, names = validate_flow_with_gt(vp, vm, sh0, items, net, args)
     for got, want, n in zip(avg, z["val_errors"], names):
         assert abs(got - want) <= 1e-4 * abs(want) + 1e-5, f"{n}: {got} vs {want}"
+    # the reference's square_transform turns the caller's patch in place: the state the next epoch starts from
+    assert np.array_equal(vp, z["val_patch_after"]) and not np.array_equal(vp, p0)
+    np.random.seed(29)
+    dvp, dvm = d64(p0), d64(m0)
+    validate_flow_with_gt(dvp, dvm, sh0, items, net, args)
+    assert np.array_equal(dvp.cpu().numpy(), z["val_patch_after"])
     with pytest.raises(ValueError, match="square or circle"):
         validate_flow_with_gt(p0, m0, sh0, items, net, Namespace(flownet="FlowNetC", patch_type="star"))

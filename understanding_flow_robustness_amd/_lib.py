@@ -239,18 +239,81 @@ def dtype_code(t: torch.Tensor) -> int:
     raise RuntimeError(f"unsupported dtype {t.dtype}: the gfx950 build implements float32, float64 and (correlation only) float16")
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# When a forward leaves the hand-written engines (its convolutions then run as torch operators on the vendor library) it says
+# so: one RuntimeWarning per (module class, reason) and a process-wide counter.  The engines serve the attack's configuration
+# (frozen parameters, eval mode, HIP float32); everything else -- a training-mode module, parameters that want weight
+# gradients -- is the reference's own torch spelling.  Frame sides: FlowNetC / PWC-Net / FlowNet2 need multiples of 64 IN THE
+# REFERENCE TOO (their `torch.cat` of decoder and encoder features raises otherwise, models/FlowNetC.py:167-182,
+# models/PWCNet.py:300-360), so there is no silent size fallback to report for them; RAFT needs multiples of 8 like the reference.
+VENDOR_FALLBACKS: dict = {}
+
+
+def engine_refusal(module, x, multiple: int, spatial_scale: int = 1):
+    """None when the native engines serve `module` on tensor `x` (a feature map at 1/spatial_scale of the frame whose sides
+    must be multiples of `multiple`), else the reason they do not."""
+    import os
+    if os.environ.get("UFR_ENGINE", "1") != "1":
+        return "UFR_ENGINE=0"
+    if not (x.is_cuda and x.dtype == torch.float32):
+        return "not a HIP float32 tensor"
+    if module.training:
+        return "module in training mode"
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        return "parameters require gradients (the engines compute data gradients only)"
+    m = max(1, multiple // spatial_scale)
+    if x.shape[2] % m or x.shape[3] % m:
+        return f"frame sides are not multiples of {multiple}"
+    return None
+
+
+def engine_gate(module, x, multiple: int, spatial_scale: int = 1, extra=None) -> bool:
+    """True = run on the engines.  False = the torch / vendor spelling, reported once per (class, reason) and counted in
+    VENDOR_FALLBACKS (explicit opt-outs -- UFR_ENGINE=0, CPU tensors -- are not reported)."""
+    reason = extra or engine_refusal(module, x, multiple, spatial_scale)
+    if reason is None:
+        return True
+    if reason not in ("UFR_ENGINE=0", "not a HIP float32 tensor"):
+        key = (type(module).__name__, reason)
+        VENDOR_FALLBACKS[key] = VENDOR_FALLBACKS.get(key, 0) + 1
+        if VENDOR_FALLBACKS[key] == 1:
+            import warnings
+            warnings.warn(f"understanding_flow_robustness_amd: {key[0]} runs its convolutions as torch operators on the vendor "
+                          f"library, not on the hand-written engines: {reason} (reported once; _lib.VENDOR_FALLBACKS counts)",
+                          RuntimeWarning, stacklevel=3)
+    return False
+
+
 class EngineCache(dict):
     """Per-module cache of native engines / schedules / captured steps (static device buffers, ctypes descriptors).  It is
     state OF the process, not of the module: `copy.deepcopy(net)`, `pickle` and `torch.save(net)` get an empty one and the copy
     builds its own engines on first use."""
 
     MAX_ENTRIES = 6                     # engines hold GBs of static planes: a validation loop over many frame sizes must not keep them all
+    evictions = 0                       # process-wide count: a loop that thrashes the cache shows here (and warns once per cache)
+
+    def get(self, key, default=None):
+        """A hit makes the entry the most recently USED one."""
+        if key in self:
+            value = super().pop(key)
+            super().__setitem__(key, value)
+            return value
+        return default
 
     def __setitem__(self, key, value):
-        """Least-recently-BUILT eviction.  A step that captured graphs over an evicted engine's buffers holds the engine object
+        """Least-recently-USED eviction.  A step that captured graphs over an evicted engine's buffers holds the engine object
         itself, so its memory stays valid; the cache only stops handing it out."""
-        if key not in self and len(self) >= self.MAX_ENTRIES:
+        if key in self:
+            super().pop(key)
+        elif len(self) >= self.MAX_ENTRIES:
             del self[next(iter(self))]
+            EngineCache.evictions += 1
+            if not getattr(self, "_warned", False):
+                self._warned = True
+                import warnings
+                warnings.warn(f"understanding_flow_robustness_amd: more than {self.MAX_ENTRIES} engine configurations alive on one "
+                              "module; the least recently used one is rebuilt on its next use (EngineCache.evictions counts)",
+                              RuntimeWarning, stacklevel=3)
         super().__setitem__(key, value)
 
     def __deepcopy__(self, memo):

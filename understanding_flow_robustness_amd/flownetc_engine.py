@@ -350,13 +350,24 @@ class FlowNetCHeadEngine:
                  c2_nchw=torch.zeros(B2, 128, h4, w4, **f32), c3_nchw=torch.zeros(B2, 256, h8, w8, **f32))
         P.update(self._conv1_launch(B2, wh, ww, c1))
         self._wprefixes[(wh, ww)] = P
+        self._bound_wprefixes()
         return P
+
+    MAX_WINDOW_PREFIXES = 4
+
+    def _bound_wprefixes(self):
+        """At most MAX_WINDOW_PREFIXES window sizes stay cached (least recently used goes).  A step that captured graphs over a
+        state holds the state itself (PatchAttackStep._wp_hold), so dropping it here never frees memory a graph points into."""
+        while len(self._wprefixes) > self.MAX_WINDOW_PREFIXES:
+            del self._wprefixes[next(iter(self._wprefixes))]
 
     def window_prefix(self, wh: int, ww: int) -> dict:
         """The window-prefix state for a (wh, ww) window; `_wprefix` = the one used last (launch_table, the backward)."""
-        P = self._wprefixes.get((int(wh), int(ww)))
+        P = self._wprefixes.pop((int(wh), int(ww)), None)
         if P is None:
             P = self._build_window_prefix(int(wh), int(ww))
+        else:
+            self._wprefixes[(int(wh), int(ww))] = P          # most recently used last
         self._wprefix = P
         return P
 

@@ -50,13 +50,10 @@ class _Refinement(nn.Module):
             setattr(self, name, FlowUpsample(2, 2, 4, 2, 1, bias=up_bias))
 
     def _engine_ok(self, c2a) -> bool:
-        """Frozen parameters, eval mode, HIP float32 features, frame sides that are multiples of 64 (UFR_ENGINE=0 switches off)."""
-        import os
-        if os.environ.get("UFR_ENGINE", "1") != "1" or self.training:
-            return False
-        frozen = not any(p.requires_grad for p in self.parameters())
-        return (c2a.is_cuda and c2a.dtype == torch.float32 and (frozen or not torch.is_grad_enabled())
-                and c2a.shape[2] % 16 == 0 and c2a.shape[3] % 16 == 0)
+        """Frozen parameters, eval mode, HIP float32 features, frame sides that are multiples of 64 (UFR_ENGINE=0 switches off);
+        a refused forward is reported once (`_lib.engine_gate`)."""
+        from .. import _lib as L
+        return L.engine_gate(self, c2a, 64, 4)
 
     def _refine(self, c6, skips):
         """skips = (conv5, conv4, conv3, conv2) features; returns flow2."""

@@ -160,13 +160,11 @@ class FlowNetC(nn.Module):
 
     def _engine_ok(self, c2a, feats, band):
         """The native head (flownetc_engine.py) serves the attack's configuration: frozen parameters, eval mode, HIP
-        float32 features, frame sides that are multiples of 64."""
-        import os
-        if os.environ.get("UFR_ENGINE", "1") != "1" or feats is not None or self.training:
+        float32 features, frame sides that are multiples of 64; a refused forward is reported once (`_lib.engine_gate`)."""
+        if feats is not None:                  # return_feat_maps: the analysis scripts' torch spelling, by request
             return False
-        frozen = not any(p.requires_grad for p in self.parameters())
-        return (c2a.is_cuda and c2a.dtype == torch.float32 and (frozen or not torch.is_grad_enabled())
-                and c2a.shape[2] % 16 == 0 and c2a.shape[3] % 16 == 0)
+        from .. import _lib as L
+        return L.engine_gate(self, c2a, 64, 4)
 
     def _rest(self, c2a, c3a, c3b, feats, band=None):
         if self._engine_ok(c2a, feats, band):

@@ -170,13 +170,9 @@ class PWCDCNet(nn.Module):
 
     def _engine_ok(self, f2a) -> bool:
         """The native head (pwc_engine.py) serves the attack's configuration: frozen parameters, eval mode, HIP float32
-        features, frame sides that are multiples of 64 (UFR_ENGINE=0 switches it off)."""
-        import os
-        if os.environ.get("UFR_ENGINE", "1") != "1" or self.training:
-            return False
-        frozen = not any(p.requires_grad for p in self.parameters())
-        return (f2a.is_cuda and f2a.dtype == torch.float32 and (frozen or not torch.is_grad_enabled())
-                and f2a.shape[2] % 16 == 0 and f2a.shape[3] % 16 == 0)
+        features, frame sides that are multiples of 64 (UFR_ENGINE=0 switches it off); a refused forward is reported once."""
+        from .. import _lib as L
+        return L.engine_gate(self, f2a, 64, 4)
 
     def head(self, f2a, f2b):
         """Pyramid levels 3-6, the coarse-to-fine decoder and the context network."""

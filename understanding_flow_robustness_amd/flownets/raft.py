@@ -10,6 +10,8 @@ of the reference (so `raft-things.pth` loads unchanged).  Differences, all on pu
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -76,14 +78,10 @@ class BasicEncoder(nn.Module):
                     nn.init.constant_(m.bias, 0)
 
     def _engine_ok(self, x) -> bool:
-        """raft_encoder_engine.py serves the attack's configuration: eval mode, frozen parameters, HIP float32 frames whose sides
-        are multiples of 8, instance or (eval) batch normalisation (UFR_ENGINE=0 switches it off)."""
-        import os
-        if os.environ.get("UFR_ENGINE", "1") != "1" or self.training or self.norm_fn not in ("instance", "batch"):
-            return False
-        frozen = not any(p.requires_grad for p in self.parameters())
-        return (x.is_cuda and x.dtype == torch.float32 and (frozen or not torch.is_grad_enabled()) and x.shape[2] % 8 == 0
-                and x.shape[3] % 8 == 0)
+        """The native encoder (raft_encoder_engine.py): frozen parameters, eval mode, HIP float32, sides multiples of 8; a
+        refused forward is reported once (`_lib.engine_gate`)."""
+        extra = None if self.norm_fn in ("instance", "batch") else f"norm_fn {self.norm_fn!r} is not instance / batch"
+        return L.engine_gate(self, x, 8, extra=extra if os.environ.get("UFR_ENGINE", "1") == "1" and x.is_cuda else None)
 
     def forward(self, x):
         pair = isinstance(x, (tuple, list))
@@ -285,13 +283,12 @@ class RAFT(nn.Module):
 
     def _engine_ok(self, net, H, W) -> bool:
         """The native refinement loop (raft_engine.py) serves the attack's configuration: frozen parameters, eval mode, HIP
-        float32 tensors, the raft-things update block, frame sides that are multiples of 8 (UFR_ENGINE=0 switches it off)."""
-        import os
-        if os.environ.get("UFR_ENGINE", "1") != "1" or self.training or getattr(self.args, "update_no_motion_downsampling", False):
-            return False
-        frozen = not any(p.requires_grad for p in self.parameters())
-        return (net.is_cuda and net.dtype == torch.float32 and (frozen or not torch.is_grad_enabled()) and H % 8 == 0 and W % 8 == 0
-                and self.args.corr_levels == 4 and self.args.corr_radius == 4)
+        float32 tensors, the raft-things update block, frame sides that are multiples of 8 (UFR_ENGINE=0 switches it off);
+        a refused forward is reported once (`_lib.engine_gate`)."""
+        extra = None
+        if getattr(self.args, "update_no_motion_downsampling", False) or self.args.corr_levels != 4 or self.args.corr_radius != 4:
+            extra = "not the raft-things update block (corr_levels 4, corr_radius 4, motion downsampling)"
+        return L.engine_gate(self, net, 8, 8, extra=extra if os.environ.get("UFR_ENGINE", "1") == "1" and net.is_cuda else None)
 
     def freeze_bn(self):
         for m in self.modules():
@@ -317,7 +314,7 @@ class RAFT(nn.Module):
         fmap1, fmap2 = self.fnet([image1, image2])
         fmap1, fmap2 = fmap1.float().contiguous(), fmap2.float().contiguous()
         if self.args.alternate_corr:
-            corr_fn = AlternateCorrBlock(fmap1, fmap2, radius=self.args.corr_radius)
+            corr_fn = AlternateCorrBlock(fmap1, fmap2, radius=self.args.corr_radius, share_grad=True)
         else:
             corr_fn = CorrBlock(fmap1, fmap2, num_levels=self.args.corr_levels, radius=self.args.corr_radius)
         net, inp = torch.split(self.cnet(image1), [128, 128], dim=1)

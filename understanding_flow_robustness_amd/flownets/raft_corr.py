@@ -98,7 +98,10 @@ def corr_lookup(pyramid, coords, radius, shared=None):
 class CorrBlock:
     """models/raft/corr.py:26-106 (all-pairs branch; `compute_spatial` is a visualisation aid)."""
 
-    def __init__(self, fmap1, fmap2, num_levels=4, radius=4, share_grad=True):
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4, share_grad=False):
+        """`share_grad=True` is RAFT's own opt-in (flownets/raft.py): every lookup of its loop reaches the loss and coords are
+        detached (raft.py:190), so the lookups' feature-map adjoints accumulate in one buffer and the last adjoint delivers the
+        sum.  A public caller gets one independent autograd node per lookup (the default)."""
         self.num_levels, self.radius = num_levels, radius
         self._shared = _SharedGrad() if share_grad else None
         corr = CorrBlock.corr(fmap1, fmap2)
@@ -200,7 +203,10 @@ class AlternateCorrBlock:
     256 channels and radius 3 / 4 (both RAFT variants) take the one-launch matrix-core form; anything else the per-level
     drop-in calls."""
 
-    def __init__(self, fmap1, fmap2, num_levels=4, radius=4, share_grad=True):
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4, share_grad=False):
+        """`share_grad=True` is RAFT's own opt-in (flownets/raft.py): every lookup of its loop reaches the loss and coords are
+        detached (raft.py:190), so the lookups' feature-map adjoints accumulate in one buffer and the last adjoint delivers the
+        sum.  A public caller gets one independent autograd node per lookup (the default)."""
         self.num_levels, self.radius = num_levels, radius
         self.pyramid = [(fmap1, fmap2)]
         for _ in range(num_levels):
@@ -217,8 +223,11 @@ class AlternateCorrBlock:
 
     def __call__(self, coords):
         dim = self.pyramid[0][0].shape[1]
-        if self._fused:
+        if self._fused and not (torch.is_grad_enabled() and coords.requires_grad):
+            # (a caller that wants d / d coords takes the per-level drop-in below, which computes it like the reference's op)
             needs_grad = torch.is_grad_enabled() and (self._f1.requires_grad or any(f.requires_grad for f in self._f2))
+            if needs_grad and self._shared is not None and self._shared.pending == 0:
+                self._shared.acc = None          # first lookup after a completed (or abandoned) backward: nothing carries over
             return AltCorrPyramidFunction.apply(self._f1, coords, self.radius, 1.0 / math.sqrt(dim),
                                                 self._shared if needs_grad else None, *self._f2)
         coords = coords.permute(0, 2, 3, 1)

@@ -138,7 +138,10 @@ class PatchAttackStep:
                             and height % 4 == 0 and width % 4 == 0)
         self.g_flow2 = torch.zeros(batch, 2, height // 4, width // 4, **f32)
         self.state = torch.zeros(4, **f32)     # stopped, executed, last loss, (pad)
-        for p in self.net.parameters():        # data gradient only: skips a third of the reference's FLOPs
+        # data gradient only: skips a third of the reference's FLOPs (main.py:573 `loss.backward()` also fills weight
+        # gradients nothing reads).  The caller's flags are remembered: `release(flow_net)` puts them back.
+        self._grad_flags = [(p, p.requires_grad) for p in self.net.parameters()]
+        for p, _ in self._grad_flags:
             p.requires_grad_(False)
         self.net.eval()
         self.graph = self.graph_b = self.graph_next = None
@@ -233,6 +236,7 @@ class PatchAttackStep:
                 from .flownetc_engine import get_engine
             self.eng = get_engine(self.net, B, H, W, self.dev)
             self.eng.flow_out.requires_grad_(True)
+            self._wp_hold = self.eng.window_prefix(wh, ww)     # the captured graphs point into this state: keep it alive
         self.taps = []                         # (level stride, margin, frames, full leaf, window gradient)
         with torch.no_grad():
             feats = self.net.encode(torch.zeros(2, 3, spec.total_stride * 2, spec.total_stride * 2, **f32))
@@ -533,6 +537,21 @@ class PatchAttackStep:
 _STEP_CACHE_ATTR = "_ufr_patch_steps"
 
 
+def release(flow_net):
+    """Drop every cached step of `flow_net` (captured graphs, static buffers) and give its parameters back the
+    `requires_grad` flags they had before the first step froze them -- e.g. before a training phase on the same module."""
+    flags = {}
+    for attr in (_STEP_CACHE_ATTR, "_ufr_universal_steps"):
+        cache = flow_net.__dict__.get(attr)
+        for step in list(cache.values()) if cache else ():
+            for p, flag in getattr(step, "_grad_flags", ()):
+                flags.setdefault(id(p), (p, flag))        # the oldest step saw the caller's own flags
+        if cache:
+            cache.clear()
+    for p, flag in flags.values():
+        p.requires_grad_(flag)
+
+
 def attack(flow_net, tgt_img_var, ref_past_img_var, ref_future_img_var, patch_var, mask_var,
            patch_init_var, target_var, logger=None, args: Namespace | None = None, use_graph=True,
            prefix_features=None, origins=None):
@@ -665,7 +684,7 @@ def validate_flow_with_gt(patch, mask, patch_shape, val_loader, flow_net, args: 
             if patch_d is None:
                 f64 = lambda a: (a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))).to(dev, torch.float64)
                 patch_d, mask_d = f64(patch), f64(mask)
-            if square:                           # main.py:646-654; the turns accumulate on patch / mask like the reference's in-place rot90
+            if square:                           # main.py:646-654; the turns accumulate (written back to the caller's arrays below)
                 patch_t, mask_t, _, _, _, (patch_d, mask_d, _) = square_transform_device(
                     patch_d, mask_d, patch_d, tuple(tgt.shape), patch_shape, norotate=getattr(args, "norotate", False))
             else:
@@ -682,5 +701,13 @@ def validate_flow_with_gt(patch, mask, patch_shape, val_loader, flow_net, args: 
                                 losses.cossim_tensor(flow_gt, flow_fwd), losses.cossim_tensor(flow_gt, adv_flow)])
             sums = vals if sums is None else sums + vals
             count += 1
+    if square and patch_d is not None:
+        # the reference's square_transform turns the CALLER's patch and mask in place (utils_patch.py:793-798, called with the
+        # training state at main.py:647): the accumulated turns are part of the state the next epoch starts from
+        for dst, src in ((patch, patch_d), (mask, mask_d)):
+            if torch.is_tensor(dst):
+                dst.copy_(src.to(dst.dtype))
+            else:
+                np.copyto(dst, src.cpu().numpy().astype(dst.dtype, copy=False))
     avg = (sums / max(count, 1)).tolist() if sums is not None else [0.0] * 4
     return avg, list(ERROR_NAMES)

@@ -304,13 +304,9 @@ def graph_for(module, key, build):
 
 
 def native_ok(module, x) -> bool:
-    """plane_graph.py serves the attack's configuration: frozen parameters, eval mode, HIP float32, sides multiples of 64."""
-    import os
-    if os.environ.get("UFR_ENGINE", "1") != "1" or module.training:
-        return False
-    frozen = not any(p.requires_grad for p in module.parameters())
-    return (x.is_cuda and x.dtype == torch.float32 and (frozen or not torch.is_grad_enabled()) and x.shape[2] % 64 == 0
-            and x.shape[3] % 64 == 0)
+    """plane_graph.py serves the attack's configuration: frozen parameters, eval mode, HIP float32, sides multiples of 64;
+    a forward that is refused says so once (`_lib.engine_gate`)."""
+    return L.engine_gate(module, x, 64)
 
 
 def stem_graph(net, n, H, W, cin, dev):

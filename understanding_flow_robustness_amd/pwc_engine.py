@@ -398,10 +398,14 @@ class PwcHeadEngine:
         self.F[2].load_nchw(self.f2_cache, 0)
 
     def window_prefix(self, wh: int, ww: int) -> _PyramidPrefix:
-        """One state per window size, kept for the engine's life (captured graphs hold raw pointers into it)."""
-        P = self._wprefixes.get((int(wh), int(ww)))
+        """One state per window size, at most four cached (least recently used goes); a step that captured graphs over a
+        state holds the state itself (PatchAttackStep._wp_hold): captured graphs hold raw pointers into it."""
+        P = self._wprefixes.pop((int(wh), int(ww)), None)
         if P is None:
-            P = self._wprefixes[(int(wh), int(ww))] = _PyramidPrefix(self, 2 * self.B, int(wh), int(ww), backward=True)
+            P = _PyramidPrefix(self, 2 * self.B, int(wh), int(ww), backward=True)
+        self._wprefixes[(int(wh), int(ww))] = P
+        while len(self._wprefixes) > 4:
+            del self._wprefixes[next(iter(self._wprefixes))]
         self._wprefix = P
         return P
 

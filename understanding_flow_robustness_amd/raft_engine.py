@@ -322,7 +322,8 @@ class _RaftRefine(torch.autograd.Function):
 
 def get_engine(net, B: int, H: int, W: int, device) -> RaftUpdateEngine:
     from .flownetc_engine import _weights_stamp
-    key = (int(B), int(H), int(W), str(torch.device(device)))
+    a = net.args            # the launch schedule bakes these in: a changed `args.iters` on a live model must rebuild it
+    key = (int(B), int(H), int(W), str(torch.device(device)), int(a.iters), int(a.corr_radius), int(a.corr_levels))
     cache = _engine_cache(net, "_ufr_head_engines")
     stamp = _weights_stamp(net)
     eng = cache.get(key)

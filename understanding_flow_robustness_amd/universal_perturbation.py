@@ -77,7 +77,8 @@ class UniversalPerturbationStep:
         self.loss_cur = self.packed[2 * self.CHW:]
         self.scale_t = torch.ones(1, **f32)     # 1/normaliser of the loss, device-resident
         self.loss_ws = torch.zeros(L.LOSS_PARTIALS, **f32)     # workgroup partials of the fixed-order loss reduction
-        for p in self.model.parameters():
+        self._grad_flags = [(p, p.requires_grad) for p in self.model.parameters()]   # patch_attack.release() restores them
+        for p, _ in self._grad_flags:
             p.requires_grad_(False)
         self.model.eval()
         self.graph = self.graph_b = None
