@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define UFR_ABI_VERSION 4   /* 4: ufr_igemm_desc gained tail / tail_n0 (round 3); 3: k_order (round 2) */
+#define UFR_ABI_VERSION 5   /* 5: ufr_igemm_clock_probe, ufr_conv1_direct (round 4); 4: ufr_igemm_desc gained tail / tail_n0 (round 3); 3: k_order (round 2) */
 
 enum { UFR_F32 = 0, UFR_F64 = 1, UFR_F16 = 2 };   /* UFR_F16: the spatial correlation only (generic kernels, float32 sums) */
 enum {
@@ -481,6 +481,10 @@ typedef struct {
                                                   1 = [KC][taps] (the taps of one channel chunk back to back: L2 reuse of the pixels) */
 } ufr_igemm_desc;
 int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream);
+/* Measurement aid (tools/measure_clock.py): with a device buffer of 4 x capacity_workgroups uint64 set, every workgroup of the
+ * ping-pong kernel (variant 6) records {s_memtime at entry, at exit, s_memrealtime at entry, at exit}: core cycles against the
+ * constant 100 MHz counter = the clock the kernel really ran at.  (NULL, 0) switches it off (the default; synchronous call). */
+int ufr_igemm_clock_probe(unsigned long long* buf, int capacity_workgroups);
 /* Layout passes at the engine's edges.  ufr_nchw_to_planes: planes[chunk0 + c/32] = split(leaky(scale * x[B,C,H,W]))
  * (scale = 1, slope = 1: a plain conversion).  ufr_chunks_to_nchw: out[B,C,H,W] = scale * leaky'(mask) * v, v from planes
  * (p0 + p1 + p2) or from an fp32 chunk-major tensor (exactly one of `planes`, `f32`).  ufr_grad_finalize: gradient planes =

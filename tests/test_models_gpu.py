@@ -312,3 +312,40 @@ def test_flownets_trunk_on_the_engine_vs_float64(monkeypatch):
         scale = float(ref.abs().max())
         err, err_t = float((a.double() - ref).abs().max()) / scale, float((b.double() - ref).abs().max()) / scale
         assert err <= max(3 * err_t, 2e-6), f"{what}: engine {err:.2e} vs torch float32 {err_t:.2e} of the float64 result"
+
+
+def test_leaving_the_engines_is_reported_and_release_restores_the_callers_flags():
+    """A forward that cannot run on the hand-written engines says so once per (class, reason) and is counted
+    (`_lib.VENDOR_FALLBACKS`); the frozen eval-mode forward stays silent.  `PatchAttackStep` freezes the caller's parameters;
+    `patch_attack.release()` drops the cached steps and puts the flags back."""
+    import warnings
+
+    from understanding_flow_robustness_amd import _lib as L
+    from understanding_flow_robustness_amd.patch_attack import _STEP_CACHE_ATTR, attack, release
+    net, args = _fetch("FlowNetC", 0)
+    x = torch.rand(1, 3, 64, 128, device=DEV)
+    assert all(p.requires_grad for p in net.parameters())
+    key = ("FlowNetC", "parameters require gradients (the engines compute data gradients only)")
+    before = L.VENDOR_FALLBACKS.get(key, 0)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        net(x, x)                                          # autograd on + parameters that want gradients: torch operators
+        net(x, x)
+    assert L.VENDOR_FALLBACKS.get(key, 0) >= before + 2
+    if before == 0:
+        assert sum("hand-written engines" in str(m.message) and "FlowNetC" in str(m.message) for m in w) == 1   # once, not per call
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        with torch.no_grad():
+            net(x, x)                                      # no gradients wanted: the engines serve it, silently
+    assert not [m for m in w if "hand-written engines" in str(m.message)]
+    args.l2, args.alpha, args.lr, args.max_count = False, 0.0, 1e4, 1
+    mask = torch.zeros(1, 3, 64, 128, device=DEV)
+    mask[:, :, 20:40, 50:70] = 1
+    patch = torch.rand(1, 3, 64, 128, device=DEV) * mask
+    with torch.no_grad():
+        target = -net(x, x)
+    attack(net, x, None, x, patch.clone(), mask, patch, target, None, args=args)
+    assert not any(p.requires_grad for p in net.parameters()) and len(net.__dict__[_STEP_CACHE_ATTR]) == 1
+    release(net)
+    assert all(p.requires_grad for p in net.parameters()) and len(net.__dict__[_STEP_CACHE_ATTR]) == 0

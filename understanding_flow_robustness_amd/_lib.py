@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libufr_hip.so")
 UFR_F32, UFR_F64, UFR_F16 = 0, 1, 2
-ABI_VERSION = 4            # UFR_ABI_VERSION of include/ufr_hip.h these ctypes mirrors were written against
+ABI_VERSION = 5            # UFR_ABI_VERSION of include/ufr_hip.h these ctypes mirrors were written against
 _lib = None
 
 
@@ -175,6 +175,7 @@ SIGNATURES = {
     "ufr_u8_to_tensor": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
     "ufr_kitti_flow_decode": [_vp, _vp, _i, _i, _vp],
     "ufr_host_png_unfilter": [_vp, _vp, _i, _i, _i],
+    "ufr_igemm_clock_probe": [_vp, _i],
 }
 PLAIN = {"ufr_abi_version": (C.c_int, []), "ufr_last_error": (C.c_char_p, []),
          "ufr_device_count": (C.c_int, []),

@@ -265,6 +265,12 @@ __device__ __forceinline__ void igemm_write_out(const Args& a, const Phase& ph, 
 // fetches 16-byte piece slot ^ ((row >> 1) & 3) of its row).  Rows outside the frame fetch a zero page.
 __device__ __attribute__((aligned(64))) unsigned ufr_zero_page[16];
 
+// Clock probe (tools/measure_clock.py; ufr_igemm_clock_probe): when set, thread 0 of every ping-pong workgroup records the
+// shader-clock counter (s_memtime: core cycles) and the constant 100 MHz counter (s_memrealtime) at its first and last
+// instruction: cycles / real time = the clock the CU actually ran this kernel at.  NULL (the default) costs one scalar load.
+__device__ unsigned long long* ufr_clock_probe_buf = nullptr;
+__device__ int ufr_clock_probe_cap = 0;
+
 // one LDS-DMA: 16 bytes per lane from `src` (per lane) to `lds_wave_base + 16 * lane` (the base must be wave-uniform)
 __device__ __forceinline__ void glds16(const __bf16* src, __bf16* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(src, lds_wave_base, 16, 0, 0);
@@ -495,6 +501,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   constexpr int NPL = 3, MT = BN_ == 128 ? 4 : 2, BPT = BN_ / 64;
   constexpr int PP_IMG_B = NPL * BN_ * BK;
   extern __shared__ __attribute__((aligned(16))) __bf16 lds_pp[];
+  unsigned long long* const probe = ufr_clock_probe_buf;
+  const unsigned long long probe_c0 = probe ? __builtin_amdgcn_s_memtime() : 0, probe_r0 = probe ? __builtin_amdgcn_s_memrealtime() : 0;
   const int tid = threadIdx.x & 255, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // wave-uniform: LDS destinations on the scalar unit
   const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);      // wave-uniform: scalar control flow
@@ -650,6 +658,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (grp == 0) __builtin_amdgcn_s_barrier();                             // group 1's extra barrier at the start
   static_assert(4 * 32 * 68 * 4 <= 2 * PP_IMG * 2, "epilogue staging does not fit a group's activation images");
   igemm_write_out<NPL, MT>(a, ph, acc, reinterpret_cast<float*>(lds_pp + imgA0), z, bm, bn, wrow, wcol, lane, wave);
+  if (probe && threadIdx.x == 0) {
+    const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (wg < ufr_clock_probe_cap) {
+      unsigned long long* o = probe + 4L * wg;
+      o[0] = probe_c0; o[1] = __builtin_amdgcn_s_memtime(); o[2] = probe_r0; o[3] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
 }
 
 // ---- ping-pong with horizontal tap reuse (variant 7) ----------------------------------------------------------------------
@@ -860,6 +875,14 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const Args a) {
 }
 
 }  // namespace
+
+extern "C" int ufr_igemm_clock_probe(unsigned long long* buf, int capacity_workgroups) {
+  UFR_REQUIRE((buf == nullptr) == (capacity_workgroups == 0) && capacity_workgroups >= 0, "igemm clock probe: buffer and capacity disagree");
+  if (hipMemcpyToSymbol(HIP_SYMBOL(ufr_clock_probe_cap), &capacity_workgroups, sizeof(int)) != hipSuccess ||
+      hipMemcpyToSymbol(HIP_SYMBOL(ufr_clock_probe_buf), &buf, sizeof(buf)) != hipSuccess)
+    return ufr::fail(UFR_ELAUNCH, "igemm clock probe: %s", hipGetErrorString(hipGetLastError()));
+  return UFR_OK;
+}
 
 extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   UFR_REQUIRE(d, "igemm: null descriptor");
