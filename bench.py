@@ -422,8 +422,8 @@ def cpu_baseline_other(config):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", choices=sorted(CONFIG_WORKLOADS), default="c2",
                     help="c2 = the headline (BASELINE configs[1]); c4 / c5 = the configs BASELINE shards over 8 GPUs")
     ap.add_argument("--sustained-seconds", type=float, default=2.0,

@@ -191,6 +191,11 @@ int ufr_patch_paste_placed(const float* tgt, const float* ref, const float* patc
                            const int* origins, const int* origins_host, float* adv_tgt, float* adv_ref,
                            float* mask_out, int B, int H, int W, int ph, int pw, int do_clamp, float lo, float hi,
                            const float* gate_state, ufr_stream_t stream);
+/* The same on the B x 3 x ph x pw rectangle pixels only: the re-paste of the second and later iterations of a call, when the
+ * canvas outside the rectangles already holds clamp(frame) from the first iteration's full paste (main.py:585-600). */
+int ufr_patch_paste_placed_rect(const float* tgt, const float* ref, const float* patch_p, const float* mask_p,
+                                const int* origins, float* adv_tgt, float* adv_ref, int B, int H, int W, int ph, int pw,
+                                int do_clamp, float lo, float hi, const float* gate_state, ufr_stream_t stream);
 /* ufr_flow_loss: loss = mean_b,h,w(1 - cos(flow, target))            (kind 0, main.py:564-566)
  *             or mean(sqrt(sum_c (flow-target)^2 + 1e-8))           (kind 1, main.py:557-562)
  *   flow,target: [B,2,H,W].  Writes d loss / d flow (already scaled by `weight`, = 1-alpha) to
@@ -510,6 +515,14 @@ int ufr_chunks_to_nchw_cat(const float* g, int chunk0, int chunks, float* const*
 int ufr_grad_finalize(const float* g, int g_chunk0, const void* mask, int mask_chunk0, void* out, long out_plane_stride,
                       int out_chunk0, long M, int chunks, float slope, ufr_stream_t stream);
 
+/* FlowNetC's conv1 = Conv2d(3, 64, 7, 2, 3) + bias + LeakyReLU (models/FlowNetC.py:100-104, submodules.py:18-46) straight from the
+ * RAW frames (frames_a [Ba,3,H,W], then frames_b [Bb,3,H,W] or NULL) to conv1's activation planes [3][2][(Ba+Bb)*H/2*W/2][32] at
+ * chunk out_chunk0: the float64 mean subtraction of normalize_correctly (FlowNetC.py:73-79), the zero padding, the im2col
+ * (in LDS), the six-product MFMA and the epilogue in ONE kernel (csrc/conv1_direct.hip).  wimg = bf16 [3 planes][7][64][32],
+ * k = (kx >> 1) * 8 + (kx & 1) * 4 + c of kernel row ky (igemm.conv1_direct_weights).  H, W even. */
+int ufr_conv1_direct(const float* frames_a, const float* frames_b, int Ba, int Bb, int H, int W, const double* mean,
+                     const void* wimg, const float* bias, float slope, void* out_planes, long plane_stride, int out_chunk0,
+                     ufr_stream_t stream);
 /* Raw frames [Ba(+Bb), 3, H, W] -> the PACKED planes conv1 = Conv2d(3, 64, 7, 2, 3) (models/FlowNetC.py:22) reads as an
  * 8-tap ufr_igemm launch: planes [3][1][(Ba + Bb) * (H/2 + 3) * (W/2 + 2)][32], channel j*12 + (c*2 + p)*2 + q of packed
  * pixel (yp, xp) = frame[c, 2 (yp - 2) + p, 2 (xp - 2 + j) + q] - mean[c] in float64 (normalize_correctly, FlowNetC.py:73-79),

@@ -134,6 +134,22 @@ def test_attack_fused_kernels_bit_exact_vs_torch(net):
     assert torch.equal(m4, canvas_m)
     assert torch.equal(a4t, torch.clamp(torch.mul(1 - canvas_m, tgt4) + torch.mul(canvas_m, canvas_p), 0, 1))
     assert torch.equal(a4r, torch.clamp(torch.mul(1 - canvas_m, ref4) + torch.mul(canvas_m, canvas_p), 0, 1))
+    # the re-paste of a call's later iterations touches the patch rectangles only: after a full paste, a changed patch and the
+    # rectangle paste must leave the very canvas a second full paste would write (clipped placements included)
+    P3 = (torch.rand(1, 3, ph, pw, generator=g) * 3 - 1).to(DEV)
+    for org_t in (origins, torch.tensor([(-3, -2), (H - 4, W - 5), (5, 12), (10, 3)], dtype=torch.int32, device=DEV)):
+        full_t, full_r, rect_t, rect_r = (torch.empty_like(tgt4) for _ in range(4))
+        for dst_t, dst_r, patch in ((rect_t, rect_r, P), (full_t, full_r, P3)):
+            L.check(L.lib().ufr_patch_paste_placed(L.ptr(tgt4), L.ptr(ref4), L.ptr(patch), L.ptr(Mp), L.ptr(org_t), None, L.ptr(dst_t),
+                                                   L.ptr(dst_r), None, B4, H, W, ph, pw, 1, 0.0, 1.0, None, L.stream()))
+        L.check(L.lib().ufr_patch_paste_placed_rect(L.ptr(tgt4), L.ptr(ref4), L.ptr(P3), L.ptr(Mp), L.ptr(org_t), L.ptr(rect_t),
+                                                    L.ptr(rect_r), B4, H, W, ph, pw, 1, 0.0, 1.0, None, L.stream()))
+        assert torch.equal(rect_t, full_t) and torch.equal(rect_r, full_r)
+    stopped = torch.tensor([1.0, 0, 0, 0], device=DEV)                          # a tripped gate makes it a no-op
+    keep = rect_t.clone()
+    L.check(L.lib().ufr_patch_paste_placed_rect(L.ptr(tgt4), L.ptr(ref4), L.ptr(P), L.ptr(Mp), L.ptr(origins), L.ptr(rect_t),
+                                                L.ptr(rect_r), B4, H, W, ph, pw, 1, 0.0, 1.0, L.ptr(stopped), L.stream()))
+    assert torch.equal(rect_t, keep)
     import numpy as np
     bad = np.array([[0, 0], [20, 31], [5, 12], [10, 3]], dtype=np.int32)       # 20 + 7 > 24: leaves the frame
     rc = L.lib().ufr_patch_paste_placed(L.ptr(tgt4), L.ptr(ref4), L.ptr(P), L.ptr(Mp), L.ptr(origins), bad.ctypes.data,

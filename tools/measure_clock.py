@@ -138,7 +138,7 @@ def main():
     step.load(tgt, ref, patch0, mask_p, patch0, target, origins=origins)
     step.run(2)                                                    # real activations and gradients in every buffer
     eng = step.eng
-    wanted = set(opt.layers.split(","))
+    wanted = set(opt.layers.replace("+", ",").split(","))
     print(json.dumps(dict(sclk_idle=pm_info_sclk() or smi_sclk(), nominal_mhz=NOMINAL_MHZ)), flush=True)
     for name, kind, tag, launch, gflop in eng.launch_table():
         if name not in wanted or tag != "full" or launch.desc.variant != 6:

@@ -115,6 +115,7 @@ SIGNATURES = {
     "ufr_flow2_upsampled_loss": [_vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp],
     "ufr_patch_grad_crop": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "ufr_patch_apply": [_vp, _i, _vp, _vp, _i, _i, _f, _f, _vp, _vp],
+    "ufr_patch_paste_placed_rect": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp],
     "ufr_patch_paste_placed": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp],
     "ufr_cone_window": [_vp, _i, _l, _i, _i, _i, C.POINTER(ConeChain), _i, _i, _vp, _vp, _vp],
     "ufr_window_gather": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -176,6 +177,7 @@ SIGNATURES = {
     "ufr_kitti_flow_decode": [_vp, _vp, _i, _i, _vp],
     "ufr_host_png_unfilter": [_vp, _vp, _i, _i, _i],
     "ufr_igemm_clock_probe": [_vp, _i],
+    "ufr_conv1_direct": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _l, _i, _vp],
 }
 PLAIN = {"ufr_abi_version": (C.c_int, []), "ufr_last_error": (C.c_char_p, []),
          "ufr_device_count": (C.c_int, []),

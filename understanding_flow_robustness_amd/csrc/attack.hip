@@ -189,6 +189,30 @@ __global__ void paste_placed_kernel(const float* __restrict__ tgt, const float* 
   }
 }
 
+// The re-paste of the SECOND and later iterations of an attack() call: the frames outside the patch rectangles already hold
+// clamp(frame) from the first iteration's full-canvas paste and never change again (main.py:585-600 recomputes them to the same
+// values), so only the B x 3 x ph x pw rectangle pixels are rewritten -- 188 MB of canvas traffic per iteration become 0.4 MB.
+__global__ void paste_placed_rect_kernel(const float* __restrict__ tgt, const float* __restrict__ ref,
+                                         const float* __restrict__ patch_p, const float* __restrict__ mask_p,
+                                         const int* __restrict__ origins, float* __restrict__ adv_tgt,
+                                         float* __restrict__ adv_ref, int B, int H, int W, int ph, int pw, int do_clamp, float lo,
+                                         float hi, const float* __restrict__ gate) {
+  if (gate != nullptr && gate[0] != 0.f) return;
+  const int n = 3 * ph * pw;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < B * n; idx += gridDim.x * blockDim.x) {
+    const int b = idx / n, e = idx - b * n;
+    const int c = e / (ph * pw), r = e - c * ph * pw, i = r / pw, j = r - i * pw;
+    const int y = origins[2 * b] + i, x = origins[2 * b + 1] + j;
+    if ((unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W) continue;       // clipped like the full-canvas paste
+    const long o = ((long)b * 3 + c) * H * W + (long)y * W + x;
+    const float m = mask_p[e], mp = m * patch_p[e], om = 1.0f - m;
+    float a = om * tgt[o] + mp, q = om * ref[o] + mp;
+    if (do_clamp) { a = clampf(a, lo, hi); q = clampf(q, lo, hi); }
+    adv_tgt[o] = a;
+    adv_ref[o] = q;
+  }
+}
+
 // models/FlowNetC.py:73-79, :93-94 (`normalize_correctly`): the float64 mean subtraction of both frame stacks, written as
 // ONE float32 stack [Ba + Bb, C, H, W] (first frames, then second frames) -- replaces torch.cat + .double() + sub + .float().
 __global__ void normalize_frames_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
@@ -439,6 +463,18 @@ extern "C" int ufr_patch_paste_placed(const float* tgt, const float* ref, const 
                      ref, patch_p, mask_p, origins, adv_tgt, adv_ref, mask_out, total, H, W, ph, pw, do_clamp, lo, hi,
                      gate_state);
   return ufr::launched("paste_placed_kernel");
+}
+
+extern "C" int ufr_patch_paste_placed_rect(const float* tgt, const float* ref, const float* patch_p, const float* mask_p,
+                                           const int* origins, float* adv_tgt, float* adv_ref, int B, int H, int W, int ph, int pw,
+                                           int do_clamp, float lo, float hi, const float* gate_state, ufr_stream_t stream) {
+  UFR_REQUIRE(tgt && ref && patch_p && mask_p && origins && adv_tgt && adv_ref, "placed rect paste: null pointer argument");
+  UFR_REQUIRE(B > 0 && H > 0 && W > 0 && ph > 0 && pw > 0 && ph <= H && pw <= W, "placed rect paste: bad shape");
+  const long total = (long)B * 3 * ph * pw;
+  UFR_REQUIRE(total < (1L << 30), "placed rect paste: too many patch pixels");
+  hipLaunchKernelGGL(paste_placed_rect_kernel, dim3(ufr::stream_grid(total, 256)), dim3(256), 0, ufr::as_stream(stream), tgt, ref,
+                     patch_p, mask_p, origins, adv_tgt, adv_ref, B, H, W, ph, pw, do_clamp, lo, hi, gate_state);
+  return ufr::launched("paste_placed_rect_kernel");
 }
 
 extern "C" int ufr_normalize_frames(const float* frames_a, const float* frames_b, float* out, int Ba, int Bb, int C, int H, int W,

@@ -246,10 +246,15 @@ class FlowNetCHeadEngine:
         """conv1 = Conv2d(3, 64, 7, 2, 3) + bias + LeakyReLU as an igemm launch over the packed planes of the raw frames
         (csrc/plane_layout.hip `conv1_pack_kernel`: pixel-unshuffle + two columns per chunk -> 8 taps of one chunk, the mean
         subtraction and the zero padding inside the buffer), writing conv1's planes directly."""
+        bias = self._conv("conv1").bias.detach().float().contiguous()
+        if os.environ.get("UFR_CONV1_DIRECT", "1") != "0":
+            # round 4: ONE kernel from the raw frames to conv1's planes (csrc/conv1_direct.hip): no packed buffer, no pack pass
+            conv1 = self._conv("conv1")
+            return dict(direct=dict(wimg=ig.conv1_direct_weights(conv1.weight), bias=bias, c1=c1, n=n, hw=(H, W),
+                                    gflop=2.0 * n * (H // 2) * (W // 2) * 147 * 64 / 1e9))
         packed = ig.Planes(n, H // 2 + 3, W // 2 + 2, 1, self.dev)
         wi = ig.conv1_packed_weights(self._conv("conv1").weight)
-        launch = ig.make_launch(wi, packed, 0, (H // 2, W // 2), (H // 2, W // 2), out_planes=c1,
-                                bias=self._conv("conv1").bias.detach().float().contiguous(), variant=2)
+        launch = ig.make_launch(wi, packed, 0, (H // 2, W // 2), (H // 2, W // 2), out_planes=c1, bias=bias, variant=2)
         return dict(packed=packed, conv1=launch, conv1_wi=wi)
 
     def _conv1(self, P: dict, a: torch.Tensor, b: torch.Tensor | None):
@@ -258,6 +263,13 @@ class FlowNetCHeadEngine:
         L.require_hip(a, "frames")
         nb = 0 if b is None else int(b.shape[0])
         mean = self.net._mean64.reshape(-1).contiguous()
+        D = P.get("direct")
+        if D is not None:
+            c1 = D["c1"]
+            L.check(L.lib().ufr_conv1_direct(L.ptr(a), L.ptr(b.contiguous()) if b is not None else None, int(a.shape[0]), nb,
+                                             int(a.shape[2]), int(a.shape[3]), L.ptr(mean), L.ptr(D["wimg"]), L.ptr(D["bias"]),
+                                             float(ig.LEAKY), L.ptr(c1.t), c1.plane_stride, 0, L.stream()), "conv1 direct")
+            return
         pk = P["packed"]
         L.check(L.lib().ufr_conv1_pack_planes(L.ptr(a), L.ptr(b.contiguous()) if b is not None else None, L.ptr(pk.t),
                                               pk.plane_stride, int(a.shape[0]), nb, int(a.shape[2]), int(a.shape[3]),

@@ -182,6 +182,21 @@ def conv1_packed_weights(weight: torch.Tensor) -> WeightImage:
     return WeightImage(planes, offsets, [(0, 0, taps)], n, npad, KC, dict(in_s=1, out_s=1), C=147.0 / 8.0)   # flops(): 147 real taps x channels
 
 
+def conv1_direct_weights(weight: torch.Tensor) -> torch.Tensor:
+    """Conv2d(3, 64, 7, 2, 3) weight [64,3,7,7] -> the image `ufr_conv1_direct` (csrc/conv1_direct.hip) keeps in registers:
+    bf16 [3 planes][7 ky][64 n][32 k], k = (kx >> 1) * 8 + (kx & 1) * 4 + c -- a K group of 8 = two adjacent input pixels x
+    (3 channels + 1 zero); kx = 7 and c = 3 are zero."""
+    N, Cn, k, _ = weight.shape
+    if (N, Cn, k) != (64, 3, 7):
+        raise ValueError("conv1_direct_weights: Conv2d(3, 64, 7, 2, 3) only")
+    w = weight.detach().float()
+    img = torch.zeros(7, 64, 32, dtype=torch.float32, device=weight.device)
+    for kx in range(7):
+        for c in range(3):
+            img[:, :, (kx >> 1) * 8 + (kx & 1) * 4 + c] = w[:, c, :, kx].t()
+    return _split3(img).view(3, 7, 64, 32).contiguous()
+
+
 def conv1_packed_backward_weights(weight: torch.Tensor) -> WeightImage:
     """Data gradient of `conv1_packed_weights`' launch with respect to the PACKED planes: rows = the packed grid
     (H/2 + 3, W/2 + 2), gP(yp, xp)[n] = sum_t W_t[o, n] gy(yp - a_t, xp - 2 b2_t)[o]; N = 24 packed channels."""

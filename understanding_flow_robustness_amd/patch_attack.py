@@ -144,8 +144,9 @@ class PatchAttackStep:
         for p, _ in self._grad_flags:
             p.requires_grad_(False)
         self.net.eval()
-        self.graph = self.graph_b = self.graph_next = None
+        self.graph = self.graph_b = self.graph_next = self.graph_b_next = None
         self._first = True
+        self._rect_paste = False               # set while the "later iterations" form of the step is captured / run eagerly
         self.use_graph = use_graph
         self._warmup = warmup
         # windowed encoder (cone.py): networks that expose a convolutional prefix as CONE/encode/head
@@ -160,6 +161,13 @@ class PatchAttackStep:
 
     # ------------------------------------------------------------------------------------ C ABI calls
     def _paste(self, do_clamp, gate=False, write_mask=False):
+        if self.placed and self._rect_paste and not write_mask:
+            # second and later iterations of a call: the canvas outside the patch rectangles already holds clamp(frame)
+            L.check(L.lib().ufr_patch_paste_placed_rect(
+                L.ptr(self.tgt), L.ptr(self.ref), L.ptr(self.patch), L.ptr(self.mask_p), L.ptr(self.origins),
+                L.ptr(self.adv_tgt), L.ptr(self.adv_ref), self.B, self.H, self.W, self.ph, self.pw, int(do_clamp), self.lo,
+                self.hi, L.ptr(self.state) if gate else None, L.stream()), "placed rect paste")
+            return
         if self.placed:
             L.check(L.lib().ufr_patch_paste_placed(
                 L.ptr(self.tgt), L.ptr(self.ref), L.ptr(self.patch), L.ptr(self.mask_p), L.ptr(self.origins),
@@ -215,7 +223,7 @@ class PatchAttackStep:
         spec, B, H, W = self.cone, self.B, self.H, self.W
         eh, ew = self._mask_extent()
         wh, ww = spec.window_size(eh, H), spec.window_size(ew, W)
-        self.graph = self.graph_b = self.graph_next = None
+        self.graph = self.graph_b = self.graph_next = self.graph_b_next = None
         if self._warmup < 0:
             self._warmup = 1                   # re-capture after the window grew
         if wh * ww * 2 > H * W:
@@ -413,53 +421,65 @@ class PatchAttackStep:
         band = getattr(self, "band", None)
         return bool(self.cone is not None and band is not None and band.inc_layers and not self._first)
 
+    def _set_later(self, later: bool):
+        """The two forms of an iteration: the FIRST after a load() (full head forward, full-canvas clamped re-paste) and the
+        LATER ones (band-only forward of the head's first blocks where the network has them; re-paste of the patch rectangles only)."""
+        band = getattr(self, "band", None) if self.cone is not None else None
+        if band is not None:
+            band.incremental = bool(later and band.inc_layers)
+        self._rect_paste = bool(later and self.placed and os.environ.get("UFR_RECT_PASTE", "1") != "0")
+
     def _iteration(self):
-        inc = self._incremental_now()
+        later = not self._first
         if self.graph is not None:
-            (self.graph_next if inc else self.graph).replay()
+            (self.graph_next if later else self.graph).replay()
         else:
-            if getattr(self, "band", None) is not None:
-                self.band.incremental = inc
+            self._set_later(later)
             self._part_a()
         self._first = False
         if self.world > 1:
             self.exchange.gather(self.rows_local, self.rows_all)    # RCCL all-gather of [crop | loss] rows, eager, same stream
             if self.graph_b is not None:
-                self.graph_b.replay()
+                (self.graph_b_next if later else self.graph_b).replay()
             else:
                 self._part_b()
+        if self.graph is None:
+            self._set_later(False)
 
     def _capture(self):
-        """Warm up (MIOpen algorithm search, allocator) on a side stream, then capture the iteration:
-        one graph on a single GPU; two graphs around the eager RCCL collective when sharded."""
+        """Warm up (MIOpen algorithm search, allocator) on a side stream, then capture the iteration in its two forms
+        (`_set_later`): one graph each on a single GPU; two graphs each around the eager RCCL collective when sharded."""
         side = torch.cuda.Stream(device=self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(side):
-            for _ in range(max(self._warmup, 2)):      # at least one full and one incremental iteration
+            for _ in range(max(self._warmup, 2)):      # at least one first and one later iteration
                 self._iteration()
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
         if not self.use_graph:
             return
-        band = getattr(self, "band", None) if self.cone is not None else None
-        if band is not None:
-            band.incremental = False
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            self._part_a()
-        self.graph_next = graph
-        if band is not None and band.inc_layers:      # second and later iterations of a call: band-only forward
-            band.incremental = True
-            self.graph_next = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_next):
+        graphs = {}
+        for later in (False, True):
+            self._set_later(later)
+            differs = later and (self._rect_paste or self._incremental_form())
+            if later and not differs:
+                graphs[True] = graphs[False]
+                break
+            ga = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
                 self._part_a()
-            band.incremental = False
-        graph_b = None
-        if self.world > 1:
-            graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph_b):
-                self._part_b()
-        self.graph, self.graph_b = graph, graph_b
+            gb = None
+            if self.world > 1:
+                gb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb):
+                    self._part_b()
+            graphs[later] = (ga, gb)
+        self._set_later(False)
+        (self.graph, self.graph_b), (self.graph_next, self.graph_b_next) = graphs[False], graphs[True]
+
+    def _incremental_form(self):
+        band = getattr(self, "band", None) if self.cone is not None else None
+        return bool(band is not None and band.incremental)
 
     # ------------------------------------------------------------------------------------ public API
     def load(self, tgt, ref, patch, mask, patch_init, target, prefix_features=None, origins=None):
@@ -525,6 +545,7 @@ class PatchAttackStep:
                     self._setup_cone()
                     if self.cone is not None:
                         self._cone_refresh()
+                    self._first = True             # the cached head activations belong to the window that overflowed
                 return self.run(max_count)
         return int(st[1]), float(st[2])
 
