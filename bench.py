@@ -157,6 +157,13 @@ def kernel_rooflines(step, device, max_count):
             g_sum += w * gflop
             b_sum += w * nbytes
         agg = dict(ms=t_sum, gflop=g_sum, bytes=b_sum)
+    # ---- conv1 straight from the raw frames (csrc/conv1_direct.hip): HBM-bound -- frames in, three bf16 planes of conv1 out
+    if eng is not None and hasattr(eng, "conv1_direct_table"):
+        for label, tag, fn, nbytes, gflop in eng.conv1_direct_table():
+            t = event_time(fn, 10)
+            ks.append(dict(kernel=f"{label} ({tag})", ms=round(t, 4), bound="hbm", achieved=round(nbytes / t / 1e6, 1), peak=PEAK_HBM_GBS,
+                           unit="GB/s", frac=round(nbytes / t / 1e6 / PEAK_HBM_GBS, 4), algorithmic_bytes=int(nbytes),
+                           tflops=round(gflop / t, 1), traffic=None))
     # ---- correlation
     a = torch.randn(B, 256, H // 8, W // 8, device=device)
     b = torch.randn(B, 256, H // 8, W // 8, device=device)

