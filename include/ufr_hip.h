@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define UFR_ABI_VERSION 5   /* 5: ufr_igemm_clock_probe, ufr_conv1_direct (round 4); 4: ufr_igemm_desc gained tail / tail_n0 (round 3); 3: k_order (round 2) */
+#define UFR_ABI_VERSION 5   /* 5: ufr_igemm_desc gained out_rowmajor / out_ld; ufr_igemm_clock_probe, ufr_conv1_direct, ufr_patch_paste_placed_rect (round 4); 4: ufr_igemm_desc gained tail / tail_n0 (round 3); 3: k_order (round 2) */
 
 enum { UFR_F32 = 0, UFR_F64 = 1, UFR_F16 = 2 };   /* UFR_F16: the spatial correlation only (generic kernels, float32 sums) */
 enum {
@@ -484,6 +484,9 @@ typedef struct {
                                                       does not cover -- stride 2, fewer than 22 columns -- run as 6 / 2) */
   int k_order;                                 /* order of the K tiles in the weight image of a phase: 0 = [taps][KC] (tap-major),
                                                   1 = [KC][taps] (the taps of one channel chunk back to back: L2 reuse of the pixels) */
+  float* out_rowmajor; long out_ld;            /* optional (ABI 5): the epilogue's result also / instead as ROW-MAJOR fp32 [B*Ho*Wo][out_ld],
+                                                  element (pixel, n) -- RAFT's all-pairs volume corr[p][q] = <fmap1[p], fmap2[q]>
+                                                  (models/raft/corr.py:57-64) is a 1x1 launch whose "weights" are fmap2's planes; N % 8 == 0 */
 } ufr_igemm_desc;
 int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream);
 /* Measurement aid (tools/measure_clock.py): with a device buffer of 4 x capacity_workgroups uint64 set, every workgroup of the

@@ -111,3 +111,29 @@ def test_raft_attack_at_full_size_engine_vs_torch_spelling(raft, monkeypatch, al
           f"{e_torch:.2e}, engines vs torch spelling {e_same:.2e}; loss {lf:.6f} / {le:.6f}")
     assert nf == ne == 1 and abs(lf - le) <= 1e-5 and 0.3 < upd < 1.9
     assert e_eng <= max(1.5 * e_torch, 1e-3) and e_same <= 1e-2
+
+
+@pytest.mark.parametrize("B,C,H,W", [(1, 256, 48, 160), (2, 256, 16, 24), (2, 128, 16, 16)])
+def test_all_pairs_correlation_on_the_igemm(B, C, H, W, monkeypatch):
+    """`CorrBlock.corr` (models/raft/corr.py:57-64: matmul / sqrt(C)) as ONE hand-written igemm launch per pair with fmap2's
+    planes as the weight image (flownets/raft_corr.py `AllPairsCorrFunction`): against a float64 product, judged by the library
+    GEMM's own float32 error; the adjoint against torch autograd through the reference's spelling."""
+    from understanding_flow_robustness_amd.flownets.raft_corr import AllPairsCorrFunction, CorrBlock
+    g = torch.Generator().manual_seed(C + H)
+    f1 = torch.randn(B, C, H, W, generator=g).to(DEV).requires_grad_(True)
+    f2 = torch.randn(B, C, H, W, generator=g).to(DEV).requires_grad_(True)
+    assert AllPairsCorrFunction.supported(f1, f2)
+    got = CorrBlock.corr(f1, f2)
+    assert got.shape == (B, H, W, 1, H, W) and got.grad_fn is not None and "AllPairs" in type(got.grad_fn).__name__
+    monkeypatch.setenv("UFR_ENGINE", "0")
+    lib32 = CorrBlock.corr(f1, f2)                                     # the reference's spelling on the library GEMM
+    monkeypatch.setenv("UFR_ENGINE", "1")
+    want = (torch.matmul(f1.detach().double().view(B, C, -1).transpose(1, 2), f2.detach().double().view(B, C, -1)) / C ** 0.5).view_as(got)
+    rel = lambda a, b: float((a.detach().double() - b).abs().max()) / float(b.abs().max())
+    e_eng, e_lib = rel(got, want), rel(lib32, want)
+    print(f"all-pairs {B}x{C}x{H}x{W}: igemm {e_eng:.2e}, library fp32 {e_lib:.2e} (vs float64)")
+    assert e_eng <= max(3 * e_lib, 2e-6)
+    go = torch.randn(got.shape, generator=g).to(DEV)
+    g1, g2 = torch.autograd.grad(got, (f1, f2), go)
+    r1, r2 = torch.autograd.grad(lib32, (f1, f2), go)
+    assert rel(g1, r1.double()) <= 1e-5 and rel(g2, r2.double()) <= 1e-5

@@ -70,7 +70,8 @@ class IgemmDesc(C.Structure):
                 ("out_f32", C.c_void_p), ("out_f32_chunk0", C.c_int),
                 ("tail", C.c_void_p), ("tail_n0", C.c_int), ("tail_accumulate", C.c_int),
                 ("splitk", C.c_int), ("ws", C.c_void_p),
-                ("products", C.c_int), ("variant", C.c_int), ("k_order", C.c_int)]
+                ("products", C.c_int), ("variant", C.c_int), ("k_order", C.c_int),
+                ("out_rowmajor", C.c_void_p), ("out_ld", C.c_long)]
 
 
 UFR_MAX_CONE_LAYERS = 8

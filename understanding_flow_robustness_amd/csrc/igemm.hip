@@ -61,6 +61,7 @@ struct Epilogue {
   const __bf16* mask; int mask_chunk0;
   __bf16* out_planes; long out_plane_stride; int out_chunk0;
   float* out_f32; int out_f32_chunk0;
+  float* out_rm; long out_ld;         // optional ROW-MAJOR fp32 output [Mout][out_ld] (RAFT's all-pairs volume: a row = one pixel's N sums)
   float* tail; int tail_n0, tail_acc; // columns >= tail_n0 (a multiple of 32): raw sums to (tail_acc: added onto) this fp32 chunk-major tensor
   long Mout; int N, Nchunks32;        // channels < Nchunks32*32 are written (zeros beyond N: the chunk's padding)
 };
@@ -82,6 +83,7 @@ __device__ __forceinline__ void epilogue_store(const Epilogue& e, long pout, int
     if (e.mask) v = ((float)e.mask[(long)e.mask_chunk0 * e.Mout * 32 + cm] > 0.f) ? v : v * e.slope;
   }
   if (n >= e.N) v = 0.f;
+  if (e.out_rm && n < e.N) e.out_rm[pout * e.out_ld + n] = v;
   if (e.out_f32) e.out_f32[(long)e.out_f32_chunk0 * e.Mout * 32 + cm] = v;
   if (e.out_planes) {
     __bf16 a, b, c;
@@ -143,6 +145,11 @@ __device__ __forceinline__ void epilogue_store8(const Epilogue& e, long pout, in
 #pragma unroll
   for (int j = 0; j < 8; ++j)
     if (n0 + j >= e.N) v[j] = 0.f;
+  if (e.out_rm && n0 < e.N) {              // (N is a multiple of 8 there: the host checks it)
+    float* op = e.out_rm + pout * e.out_ld + n0;
+    *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
   if (e.out_f32) {
     float* op = e.out_f32 + (long)e.out_f32_chunk0 * e.Mout * 32 + cm;
     *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
@@ -893,7 +900,8 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   UFR_REQUIRE(d->nphase >= 1 && d->nphase <= 4 && d->splitk >= 1 && d->splitk <= 64, "igemm: bad phase / split count");
   UFR_REQUIRE(d->products == 6 || d->products == 3 || d->products == 1, "igemm: products must be 6, 3 or 1");
   UFR_REQUIRE(d->splitk == 1 || d->ws, "igemm: split-K needs a workspace");
-  UFR_REQUIRE(d->out_planes || d->out_f32, "igemm: no output");
+  UFR_REQUIRE(d->out_planes || d->out_f32 || d->out_rowmajor, "igemm: no output");
+  UFR_REQUIRE(!d->out_rowmajor || (d->out_ld >= d->N && d->N % 8 == 0 && d->out_ld % 4 == 0), "igemm: bad row-major output");
   UFR_REQUIRE(!d->act || d->bias, "igemm: the forward epilogue needs the bias");
   UFR_REQUIRE(!d->tail || (d->tail_n0 > 0 && d->tail_n0 % 32 == 0 && d->tail_n0 < d->N), "igemm: bad tail column");
   UFR_REQUIRE(!d->row_x0 || (d->row_x0_div > 0), "igemm: bad band divisor");
@@ -918,6 +926,7 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   a.e.mask = static_cast<const __bf16*>(d->mask); a.e.mask_chunk0 = d->mask_chunk0;
   a.e.out_planes = static_cast<__bf16*>(d->out_planes); a.e.out_plane_stride = d->out_plane_stride; a.e.out_chunk0 = d->out_chunk0;
   a.e.out_f32 = d->out_f32; a.e.out_f32_chunk0 = d->out_f32_chunk0;
+  a.e.out_rm = d->out_rowmajor; a.e.out_ld = d->out_ld;
   a.e.tail = d->tail; a.e.tail_n0 = d->tail_n0; a.e.tail_acc = d->tail_accumulate;
   a.e.Mout = (long)d->B * d->Ho * d->Wo; a.e.N = d->N; a.e.Nchunks32 = (d->N + 31) / 32;
   a.nphase = d->nphase; a.splitk = d->splitk; a.ws = d->ws;

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -95,6 +96,49 @@ def corr_lookup(pyramid, coords, radius, shared=None):
     return CorrLookupFunction.apply(coords, radius, shared, *pyramid)
 
 
+class AllPairsCorrFunction(torch.autograd.Function):
+    """corr[b, p, q] = <fmap1[b, :, p], fmap2[b, :, q]> / sqrt(C) (models/raft/corr.py:57-64) on the hand-written igemm
+    (csrc/igemm.hip): per frame pair ONE 1x1 launch whose activation is fmap1's planes and whose "weight image" is fmap2's planes
+    (the two layouts coincide, igemm.planes_as_weights), float32-accurate on the bf16 matrix cores, the row-major volume written
+    by the epilogue.  The 1/sqrt(C) goes into fmap1's planes (exact for C = 256: a power of two).
+    Backward = the two products with the volume's gradient (library GEMMs on the 236 MB gradient, as before)."""
+
+    @staticmethod
+    def supported(fmap1, fmap2) -> bool:
+        B, C_, H, W = fmap1.shape
+        return (fmap1.is_cuda and fmap1.dtype == torch.float32 and fmap2.dtype == torch.float32 and fmap1.shape == fmap2.shape
+                and C_ % 32 == 0 and (H * W) % 128 == 0)
+
+    @staticmethod
+    def forward(ctx, fmap1, fmap2):
+        from .. import igemm as ig
+        B, C_, H, W = fmap1.shape
+        HW = H * W
+        scale = 1.0 / math.sqrt(C_)
+        out = torch.empty(B, HW, HW, dtype=torch.float32, device=fmap1.device)
+        f1, f2 = fmap1.detach().contiguous(), fmap2.detach().contiguous()
+        with torch.cuda.device(fmap1.device):
+            for b in range(B):
+                p1 = ig.Planes(1, H, W, C_ // 32, fmap1.device).load_nchw(f1[b:b + 1], 0, scale=scale)
+                p2 = ig.Planes(1, H, W, C_ // 32, fmap1.device).load_nchw(f2[b:b + 1], 0)
+                ig.make_launch(ig.planes_as_weights(p2), p1, 0, (H, W), (H, W), out_rowmajor=(out, b * HW * HW, HW), variant=6)()
+        ctx.save_for_backward(fmap1, fmap2)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        fmap1, fmap2 = ctx.saved_tensors
+        B, C_, H, W = fmap1.shape
+        g = g.reshape(B, H * W, H * W)
+        g1 = g2 = None
+        if ctx.needs_input_grad[0]:
+            g1 = (torch.matmul(fmap2.reshape(B, C_, -1), g.transpose(1, 2)) * ctx.scale).view_as(fmap1)
+        if ctx.needs_input_grad[1]:
+            g2 = (torch.matmul(fmap1.reshape(B, C_, -1), g) * ctx.scale).view_as(fmap2)
+        return g1, g2
+
+
 class CorrBlock:
     """models/raft/corr.py:26-106 (all-pairs branch; `compute_spatial` is a visualisation aid)."""
 
@@ -122,6 +166,8 @@ class CorrBlock:
     @staticmethod
     def corr(fmap1, fmap2):
         batch, dim, ht, wd = fmap1.shape
+        if AllPairsCorrFunction.supported(fmap1, fmap2) and os.environ.get("UFR_ENGINE", "1") == "1":
+            return AllPairsCorrFunction.apply(fmap1, fmap2).view(batch, ht, wd, 1, ht, wd)      # the hand-written igemm
         corr = torch.matmul(fmap1.view(batch, dim, ht * wd).transpose(1, 2), fmap2.view(batch, dim, ht * wd))
         return corr.view(batch, ht, wd, 1, ht, wd) / math.sqrt(dim)
 

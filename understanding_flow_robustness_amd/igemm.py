@@ -182,6 +182,18 @@ def conv1_packed_weights(weight: torch.Tensor) -> WeightImage:
     return WeightImage(planes, offsets, [(0, 0, taps)], n, npad, KC, dict(in_s=1, out_s=1), C=147.0 / 8.0)   # flops(): 147 real taps x channels
 
 
+def planes_as_weights(p: Planes, N: int | None = None) -> WeightImage:
+    """An activation's planes [3][chunks][M][32] ARE a weight image [3][KC][Npad = M][32] of a one-tap launch whose output
+    channel n is pixel n: <x[p], y[q]> over the channels for all pixel pairs = RAFT's all-pairs correlation
+    (models/raft/corr.py:57-64) as ONE igemm launch per frame pair.  M must be a multiple of 64."""
+    if p.M % 64:
+        raise ValueError("planes_as_weights: the pixel count must be a multiple of 64")
+    planes = p.t.view(3, -1)
+    wi = WeightImage(planes, [0], [(0, 0, [(0, 0)])], p.M if N is None else N, p.M, p.chunks, dict(in_s=1, out_s=1), C=p.chunks * 32.0)
+    wi._keep = p
+    return wi
+
+
 def conv1_direct_weights(weight: torch.Tensor) -> torch.Tensor:
     """Conv2d(3, 64, 7, 2, 3) weight [64,3,7,7] -> the image `ufr_conv1_direct` (csrc/conv1_direct.hip) keeps in registers:
     bf16 [3 planes][7 ky][64 n][32 k], k = (kx >> 1) * 8 + (kx & 1) * 4 + c -- a K group of 8 = two adjacent input pixels x
@@ -295,7 +307,7 @@ def make_launch(wi: WeightImage, x: Planes, in_chunk0: int, rows_hw, out_hw, *, 
                 add: GradSum | None = None, add_chunk0: int = 0, mask: Planes | None = None, mask_chunk0: int = 0,
                 slope: float = LEAKY, splitk: int = 1, ws: torch.Tensor | None = None, row_band=None, in_band=None,
                 products: int = 6, variant: int = 0, tail: GradSum | None = None, tail_n0: int = 0, tail_chunk0: int = 0,
-                tail_accumulate: bool = False) -> Launch:
+                tail_accumulate: bool = False, out_rowmajor=None) -> Launch:
     """Descriptor for `wi` applied to the chunks [in_chunk0, in_chunk0 + KC) of `x`.
     rows_hw = (Hr, Wr) row grid; out_hw = (Ho, Wo) output grid.  row_band = (origins int32 tensor, element stride, divisor):
     tail / tail_n0: the launch's output columns >= tail_n0 are a LATER layer's partial sum over these input chunks and leave raw
@@ -352,6 +364,12 @@ def make_launch(wi: WeightImage, x: Planes, in_chunk0: int, rows_hw, out_hw, *, 
         if out_f32.M != Mout or out_f32_chunk0 + nch > out_f32.chunks:
             raise RuntimeError("igemm: fp32 output geometry")
         d.out_f32, d.out_f32_chunk0 = out_f32.t.data_ptr(), int(out_f32_chunk0)
+    if out_rowmajor is not None:               # (tensor, element offset, leading dimension): fp32 [Mout][ld], element (pixel, n)
+        rm, rm_off, ld = out_rowmajor
+        if rm.dtype != torch.float32 or wi.N % 8 or ld < wi.N or ld % 4 or rm_off % 4 or rm.numel() < rm_off + (Mout - 1) * ld + wi.N:
+            raise RuntimeError("igemm: row-major output geometry")
+        d.out_rowmajor, d.out_ld = rm.data_ptr() + 4 * int(rm_off), int(ld)
+        keep.append(rm)
     d.splitk = int(splitk)
     if splitk > 1:
         need = d.nphase * splitk * x.B * d.Hr * d.Wr * wi.Npad
