@@ -130,6 +130,14 @@ int ufr_resample2d_forward(const float* input1, const float* input2, float* outp
 int ufr_resample2d_backward(const float* input1, const float* input2, const float* grad_output,
                             float* grad_input1, float* grad_input2, int B, int C, int Hi, int Wi,
                             int H, int W, int kernel_size, int bilinear, ufr_stream_t stream);
+/* The same adjoint for kernel_size 1 and an image of the flow's size WITHOUT global atomics (csrc/resample2d_owner.hip, round 4):
+ * launch A writes grad_input2 and a table of the output tiles' sampling boxes into `workspace`
+ * (ufr_resample2d_backward_workspace_bytes(B, H, W) bytes, 16-byte aligned), launch B lets every 32 x 64 tile of grad_input1 be
+ * computed and WRITTEN by one owner workgroup (no zero fill needed; C <= 12). */
+long ufr_resample2d_backward_workspace_bytes(int B, int H, int W);
+int ufr_resample2d_backward_owner(const float* input1, const float* input2, const float* grad_output, float* grad_input1,
+                                  float* grad_input2, void* workspace, long workspace_bytes, int B, int C, int H, int W,
+                                  ufr_stream_t stream);
 
 /* ---- ChannelNorm -------------------------------------------------------------------------------
  * replaces channelnorm_cuda.forward / .backward (models/channelnorm_package/channelnorm_cuda.cc:6-25,

@@ -325,10 +325,11 @@ def test_lookup_matches_corrblock_golden_and_oracle(ops, oracle):
 @pytest.mark.parametrize("B,C,H,W,bilinear,spread", [(2, 3, 17, 23, True, 4.0), (1, 3, 448, 1024, True, 4.0), (2, 2, 9, 11, False, 4.0),
                                                       (2, 3, 100, 260, True, 300.0),     # wild flow: the tiles' source boxes exceed LDS -> direct form
                                                       (1, 8, 70, 130, True, 1.5), (1, 3, 64, 96, True, 30.0)])   # mixed: some tiles staged, some not
-@pytest.mark.parametrize("lds_mode", ["1", "2", "0"])   # default (direct forward, LDS adjoint) / both LDS / both direct
+@pytest.mark.parametrize("lds_mode", ["1", "2", "0", "3"])   # default (direct forward, owner-computes adjoint) / both LDS-staged / both direct / direct forward + LDS-privatised adjoint
 def test_resample2d_vs_oracle(ops, oracle, monkeypatch, lds_mode, B, C, H, W, bilinear, spread):
-    """csrc/warp_norm.hip: the LDS-staged forward / privatised image adjoint (kernel_size 1, bilinear) and the direct
-    forms, against the C oracle's literal restatement of resample2d_kernel.cu:15-198."""
+    """csrc/resample2d_owner.hip (the adjoint without global atomics: one owner workgroup per tile of the image gradient) and
+    csrc/warp_norm.hip (the LDS-staged forward / privatised image adjoint and the direct forms), against the C oracle's literal
+    restatement of resample2d_kernel.cu:15-198.  The gradient buffers are handed over UNINITIALISED: every element is written."""
     monkeypatch.setenv("UFR_RESAMPLE_LDS", lds_mode)
     g = torch.Generator().manual_seed(H)
     img = torch.rand(B, C, H, W, generator=g)

@@ -70,7 +70,13 @@ def main():
             emit(f"resample2d_fwd ({kind} flow)", cfg, ms, (img.numel() + flow.numel() + out.numel()) * 4)
             ms = timed(lambda: L.check(lib.ufr_resample2d_backward(L.ptr(img), L.ptr(flow), L.ptr(gout), L.ptr(gimg), L.ptr(gflow), B, 3, H, W,
                                                                    H, W, 1, 1, st())))
-            emit(f"resample2d_bwd (image + flow gradients, {kind} flow)", cfg, ms,
+            emit(f"resample2d_bwd, LDS-privatised scatter (image + flow gradients, {kind} flow)", cfg, ms,
+                 (img.numel() + flow.numel() + gout.numel() + gimg.numel() + gflow.numel()) * 4)
+            nb = int(lib.ufr_resample2d_backward_workspace_bytes(B, H, W))
+            ws = torch.empty((nb + 15) // 16 * 4, dtype=torch.int32, device=DEV)
+            ms = timed(lambda: L.check(lib.ufr_resample2d_backward_owner(L.ptr(img), L.ptr(flow), L.ptr(gout), L.ptr(gimg), L.ptr(gflow), L.ptr(ws),
+                                                                         nb, B, 3, H, W, st())))
+            emit(f"resample2d_bwd, owner-computes (the default; image + flow gradients, {kind} flow)", cfg, ms,
                  (img.numel() + flow.numel() + gout.numel() + gimg.numel() + gflow.numel()) * 4)
         for C in (3, 2):
             x = rnd(B, C, H, W)

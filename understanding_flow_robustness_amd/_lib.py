@@ -99,6 +99,7 @@ SIGNATURES = {
     "ufr_corr_lookup_forward": [C.POINTER(Pyramid), _vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_corr_lookup_backward": [C.POINTER(Pyramid), _vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_resample2d_forward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ufr_resample2d_backward_owner": [_vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp],
     "ufr_resample2d_backward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ufr_channelnorm_forward": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ufr_channelnorm_backward": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
@@ -184,6 +185,7 @@ PLAIN = {"ufr_abi_version": (C.c_int, []), "ufr_last_error": (C.c_char_p, []),
          "ufr_device_count": (C.c_int, []),
          "ufr_conv3x3_c2_workspace_floats": (C.c_long, [_i, _i, _i, _i]),
          "ufr_cm_norm_workspace_doubles": (C.c_long, [_l, _i, _i]),
+         "ufr_resample2d_backward_workspace_bytes": (C.c_long, [_i, _i, _i]),
          "ufr_altcorr_pyramid_workspace_bytes": (C.c_long, [_i, _i, _i, _i, _i, _i])}
 
 

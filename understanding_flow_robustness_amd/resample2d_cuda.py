@@ -3,6 +3,8 @@
 functions return 1, fp32 only (resample2d_kernel.cu:221-234)."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -39,6 +41,15 @@ def backward(input1, input2, gradOutput, gradInput1, gradInput2, kernel_size, bi
             or gradInput2.shape != input2.shape:
         raise RuntimeError("resample2d backward: gradient buffer shapes do not match the inputs")
     with torch.cuda.device(input1.device):
+        if (int(kernel_size) == 1 and (Hi, Wi) == (H, W) and Cc <= 12 and os.environ.get("UFR_RESAMPLE_LDS", "1") == "1"):
+            # the adjoint without global atomics: one owner workgroup per tile of gradInput1 (csrc/resample2d_owner.hip);
+            # UFR_RESAMPLE_LDS=3 keeps round 2's LDS-privatised scatter, 0 the reference's direct scatter
+            nbytes = int(L.lib().ufr_resample2d_backward_workspace_bytes(B, H, W))
+            ws = torch.empty((nbytes + 15) // 16 * 4, dtype=torch.int32, device=input1.device)
+            L.check(L.lib().ufr_resample2d_backward_owner(L.ptr(input1), L.ptr(input2), L.ptr(gradOutput), L.ptr(gradInput1),
+                                                          L.ptr(gradInput2), L.ptr(ws), nbytes, B, Cc, H, W, L.stream()),
+                    "resample2d_cuda.backward")
+            return 1
         L.check(L.lib().ufr_resample2d_backward(L.ptr(input1), L.ptr(input2), L.ptr(gradOutput),
                                                 L.ptr(gradInput1), L.ptr(gradInput2), B, Cc, Hi, Wi, H, W,
                                                 int(kernel_size), int(bool(bilinear)), L.stream()),
