@@ -64,7 +64,9 @@ def main():
         # 0.25 px of noise); 'rough' = independent 4 px noise per pixel (worst case for locality)
         coarse = 16 * torch.randn(B, 2, H // 16, W // 16, generator=g)
         smooth = torch.nn.functional.interpolate(coarse, size=(H, W), mode="bilinear", align_corners=False) + 0.25 * torch.randn(B, 2, H, W, generator=g)
-        for kind, flow in (("smooth", smooth.to(DEV)), ("rough", (4 * torch.randn(B, 2, H, W, generator=g)).to(DEV))):
+        # 'gentle' = a 1/64-resolution field of +-8 px, upsampled: gradients of ~0.2 px per px, what most of a real frame looks like
+        gentle = torch.nn.functional.interpolate(8 * torch.randn(B, 2, H // 64, W // 64, generator=g), size=(H, W), mode="bilinear", align_corners=False)
+        for kind, flow in (("gentle", gentle.to(DEV)), ("smooth", smooth.to(DEV)), ("rough", (4 * torch.randn(B, 2, H, W, generator=g)).to(DEV))):
             gimg, gflow = torch.empty_like(img), torch.empty_like(flow)
             ms = timed(lambda: L.check(lib.ufr_resample2d_forward(L.ptr(img), L.ptr(flow), L.ptr(out), B, 3, H, W, H, W, 1, 1, st())))
             emit(f"resample2d_fwd ({kind} flow)", cfg, ms, (img.numel() + flow.numel() + out.numel()) * 4)

@@ -8,15 +8,13 @@
 //   A  `rs_flow_boxes_kernel`  one workgroup per 16 x 64 tile of OUTPUT pixels: the flow gradient (a gather: flow, C gradient
 //      values and the 4*C image taps of every pixel, as the forward), and the bounding box of the tile's clamped sampling
 //      corners -> a table of boxes [B][tiles] (16 bytes per tile);
-//   B  `rs_image_owner_kernel` one workgroup OWNS a 32 x 64 tile of the IMAGE gradient: it scans the table for the output
-//      tiles whose box meets its tile (smooth flow: ~3 of them), walks their pixels again (flow + C gradient values, 20
-//      bytes per pixel), adds the corners that fall inside its tile into an LDS accumulator (ds_add_f32) and finally WRITES
-//      its tile with plain coalesced stores: every element of grad_input1 is written exactly once, no atomics, no zero fill.
-// Measured (8 x 448x1024, C = 3, profiles/r4_resample_owner_*.txt): launch A 0.03 - 0.07 ms, launch B 0.25 - 0.30 ms = 0.34 - 0.37 ms
-// against 0.50 - 0.52 ms of the privatised scatter.  B's time is its 12 ds_add_f32 per pixel: LDS FLOAT atomics retire at only
-// ~0.2 - 0.7 lanes per clock and CU here (44 M of them in 0.25 ms; the walk without them: 0.014 ms + ~1 us per candidate tile),
-// about six times the rate of global float atomics -- the next step is to add fewer of them (lanes i and i + 1 of a wave share
-// a cell for a smooth flow: merge through a lane shift), not fewer bytes.
+//   B  `rs_image_owner_kernel` one workgroup OWNS a 16 x 64 tile of the IMAGE gradient: it scans the table for the output
+//      tiles whose box meets its tile (smooth flow: ~4 of them), walks their pixels again (flow + C gradient values, 20
+//      bytes per pixel), files the corners that fall inside its tile into per-cell SLOTS in LDS (one integer atomic per corner,
+//      see the kernel) and finally adds the slots and WRITES its tile with plain coalesced stores: every element of
+//      grad_input1 is written exactly once, no global atomics, no zero fill.
+// History (8 x 448x1024, C = 3; profiles/r4_resample_owner_decomposition.txt): the first owner form accumulated with ds_add_f32
+// and took 0.34 - 0.37 ms, 0.25 - 0.30 of them in launch B whatever the flow -- LDS float atomics, not bytes or latency.
 // Algorithmic bytes per pixel (C = 3): 52 (flow 8 + gradient 12 + image 12 in, 12 + 8 out); moved here ~110 (the output tiles are
 // re-read ~3x by kernel B).  Any flow field is handled: a wild one makes more boxes meet a tile (more re-reads), never a
 // wrong result.  Arithmetic identical to warp_norm.hip's kernels (weights with int() truncation for the image gradient,
@@ -28,8 +26,8 @@ namespace {
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
 constexpr int OT_H = 16, OT_W = 64;            // output tiles of kernel A = the table's granularity
-constexpr int RT_H = 32, RT_W = 64;            // owner tiles of kernel B
-constexpr int RS_MAX_LIST = 2048;              // candidate tiles an owner can list in LDS (the rest are walked in further passes)
+constexpr int RT_H = 16, RT_W = 64;            // owner tiles of kernel B
+constexpr int RS_MAX_LIST = 512;               // candidate tiles an owner lists in LDS per pass (more are walked in further passes)
 
 struct Sample {                                // one output pixel's sampling geometry (shared by both kernels)
   int xL, xR, yT, yB;
@@ -103,16 +101,27 @@ __global__ __launch_bounds__(256) void rs_flow_boxes_kernel(const float* __restr
 }
 
 // ---- B: the image gradient, one owner per tile ------------------------------------------------------------------------------
-// Per candidate tile a thread walks four pixels.  Loads never wait on one another: the NEXT tile's flow is fetched while this
-// one is processed, and the gradient values of all pixels that reach the owner's tile are requested together before the first
-// LDS add (round 4's first form loaded them one by one behind the corner tests: 12 dependent latencies per tile, 0.29 ms).
+// LDS FLOAT atomics are the wrong tool on gfx950: ds_add_f32 retires 0.38 lanes per clock and CU, ds_add_rtn_u32 13 (measured,
+// profiles/r4_lds_atomics_probe.txt).  So a contribution RESERVES a slot of its cell with one INTEGER atomic (one per corner,
+// shared by the C channels) and stores its C products there with plain LDS writes; the owner finally adds each cell's slots.
+// A cell of a smooth flow receives four contributions (one per corner role); RS_SLOTS = 5 are kept, anything beyond (flows that
+// compress, clamped frame borders) falls back to float atomics into a small overflow accumulator.
+// Per candidate tile a thread walks RS_PX pixels (512 threads: 16 waves per CU at two owners per CU); loads never wait on one another: the NEXT tile's flow is fetched while this
+// one is processed, and the gradient values of all pixels that reach the owner's tile are requested together.
+constexpr int RS_SLOTS = 5;
+constexpr int RS_NT = 1024, RS_ROWS = RS_NT / 64, RS_PX = OT_H / RS_ROWS;   // threads of an owner; output rows per step; pixels per thread and candidate tile
+
 template <int CT_>
-__global__ __launch_bounds__(256) void rs_image_owner_kernel(const float* __restrict__ flow, const float* __restrict__ gout,
+__global__ __launch_bounds__(RS_NT) void rs_image_owner_kernel(const float* __restrict__ flow, const float* __restrict__ gout,
                                                              const int4* __restrict__ boxes, float* __restrict__ gimg, int B,
                                                              int Crt, int H, int W) {
   constexpr int CR = CT_ ? CT_ : 1;                                            // gradient values kept in registers per pixel
+  constexpr int CELLS = RT_H * RT_W;
   const int C = CT_ ? CT_ : Crt;
-  extern __shared__ __attribute__((aligned(16))) float acc[];                  // [C][RT_H * RT_W]
+  extern __shared__ __attribute__((aligned(16))) float rs_smem[];              // over [C][CELLS] | cnt [CELLS] | slots [CELLS][RS_SLOTS][C]
+  float* over = rs_smem;
+  int* cnt = reinterpret_cast<int*>(rs_smem + C * CELLS);
+  float* slots = rs_smem + C * CELLS + CELLS;
   __shared__ int list[RS_MAX_LIST];
   __shared__ int n_list;
   const int tid = threadIdx.x;
@@ -123,42 +132,43 @@ __global__ __launch_bounds__(256) void rs_image_owner_kernel(const float* __rest
   const size_t plane = (size_t)H * W;
   const float* flow_b = flow + (size_t)b * 2 * plane;
   const float* gout_b = gout + (size_t)b * C * plane;
-  for (int i = tid; i < C * RT_H * RT_W; i += 256) acc[i] = 0.f;
-  auto fetch_flow = [&](int t, float (&dxs)[4], float (&dys)[4]) {
+  for (int i = tid; i < C * CELLS; i += RS_NT) over[i] = 0.f;
+  if (CT_) for (int i = tid; i < CELLS; i += RS_NT) cnt[i] = 0;
+  auto fetch_flow = [&](int t, float (&dxs)[RS_PX], float (&dys)[RS_PX]) {
     const int x = (t % otx) * OT_W + (tid & 63), yb = (t / otx) * OT_H + (tid >> 6);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int y = yb + 4 * k;
+    for (int k = 0; k < RS_PX; ++k) {
+      const int y = yb + RS_ROWS * k;
       const bool live = x < W && y < H;
       const size_t pix = (size_t)(live ? y : 0) * W + (live ? x : 0);
       dxs[k] = live ? flow_b[pix] : 0.f;
       dys[k] = live ? flow_b[plane + pix] : 0.f;
     }
   };
-  for (int t0 = 0; t0 < nT; t0 += RS_MAX_LIST) {                               // (one pass unless > 2048 tiles meet this owner)
+  for (int t0 = 0; t0 < nT; t0 += RS_MAX_LIST) {                               // (one pass unless > RS_MAX_LIST tiles meet this owner)
     if (tid == 0) n_list = 0;
     __syncthreads();
-    for (int t = t0 + tid; t < min(nT, t0 + RS_MAX_LIST); t += 256) {
+    for (int t = t0 + tid; t < min(nT, t0 + RS_MAX_LIST); t += RS_NT) {
       const int4 bx = boxes[(size_t)b * nT + t];
       if (bx.z >= rx0 && bx.x < rx0 + RT_W && bx.w >= ry0 && bx.y < ry0 + RT_H) list[atomicAdd(&n_list, 1)] = t;
     }
     __syncthreads();
     const int n = n_list;
-    float ndx[4], ndy[4];
+    float ndx[RS_PX], ndy[RS_PX];
     if (n > 0) fetch_flow(list[0], ndx, ndy);
     for (int li = 0; li < n; ++li) {
       const int t = list[li];
-      float dxs[4], dys[4];
+      float dxs[RS_PX], dys[RS_PX];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { dxs[k] = ndx[k]; dys[k] = ndy[k]; }
+      for (int k = 0; k < RS_PX; ++k) { dxs[k] = ndx[k]; dys[k] = ndy[k]; }
       if (li + 1 < n) fetch_flow(list[li + 1], ndx, ndy);                      // in flight while this tile is processed
       const int x = (t % otx) * OT_W + (tid & 63), yb = (t / otx) * OT_H + (tid >> 6);
-      int cells[4][4];                                                        // LDS cell of TL, TR, BL, BR, or -1
-      float wts[4][4], g[4][CR];
-      bool any[4];
+      int cells[RS_PX][4];                                                        // LDS cell of TL, TR, BL, BR, or -1
+      float wts[RS_PX][4], g[RS_PX][CR];
+      bool any[RS_PX];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int y = yb + 4 * k;
+      for (int k = 0; k < RS_PX; ++k) {
+        const int y = yb + RS_ROWS * k;
         const Sample s = sample_of(dxs[k], dys[k], x, y, H, W);
         const int cxL = s.xL - rx0, cxR = s.xR - rx0, cyT = s.yT - ry0, cyB = s.yB - ry0;
         const bool live = x < W && y < H;
@@ -174,41 +184,55 @@ __global__ __launch_bounds__(256) void rs_image_owner_kernel(const float* __rest
       }
       if constexpr (CT_ != 0) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)                                            // every needed gradient value requested at once
+        for (int k = 0; k < RS_PX; ++k)                                            // every needed gradient value requested at once
 #pragma unroll
-          for (int c = 0; c < CR; ++c) g[k][c] = any[k] ? gout_b[(size_t)c * plane + (size_t)(yb + 4 * k) * W + x] : 0.f;
+          for (int c = 0; c < CR; ++c) g[k][c] = any[k] ? gout_b[(size_t)c * plane + (size_t)(yb + RS_ROWS * k) * W + x] : 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < RS_PX; ++k) {
           if (!any[k]) continue;
 #pragma unroll
-          for (int c = 0; c < CR; ++c) {
-            float* a = acc + c * (RT_H * RT_W);
+          for (int q = 0; q < 4; ++q) {
+            const int cell = cells[k][q];
+            if (cell < 0) continue;
+            const int slot = atomicAdd(&cnt[cell], 1) & 0x7fffffff;            // ds_add_rtn_u32: the fast kind of LDS atomic
+            if (slot < RS_SLOTS) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (cells[k][q] >= 0) atomicAdd(&a[cells[k][q]], wts[k][q] * g[k][c]);
+              for (int c = 0; c < CR; ++c) slots[(cell * RS_SLOTS + slot) * CR + c] = wts[k][q] * g[k][c];
+            } else {
+              // beyond the slots: float atomics into the overflow sums (slow -- 0.38 lanes per clock -- but rare for a real flow;
+              // a per-cell lock bit + plain read-add-write would be the integer-atomic form, but a spin lock between the lanes of one
+              // wave is a SIMT deadlock hazard under the compiler's control-flow restructuring: not used)
+#pragma unroll
+              for (int c = 0; c < CR; ++c) atomicAdd(&over[c * CELLS + cell], wts[k][q] * g[k][c]);
+            }
           }
         }
-      } else {
+      } else {                                                                 // any channel count: float atomics only
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < RS_PX; ++k) {
           if (!any[k]) continue;
           for (int c = 0; c < C; ++c) {
-            const float gv = gout_b[(size_t)c * plane + (size_t)(yb + 4 * k) * W + x];
-            float* a = acc + c * (RT_H * RT_W);
+            const float gv = gout_b[(size_t)c * plane + (size_t)(yb + RS_ROWS * k) * W + x];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              if (cells[k][q] >= 0) atomicAdd(&a[cells[k][q]], wts[k][q] * gv);
+              if (cells[k][q] >= 0) atomicAdd(&over[c * CELLS + cells[k][q]], wts[k][q] * gv);
           }
         }
       }
     }
     __syncthreads();
   }
-  // the owner writes its tile: every element of grad_input1 exactly once
-  for (int i = tid; i < C * RT_H * RT_W; i += 256) {
-    const int c = i / (RT_H * RT_W), r = i - c * (RT_H * RT_W), ly = r / RT_W, lx = r - ly * RT_W;
+  // the owner adds each cell's slots and writes its tile: every element of grad_input1 exactly once
+  for (int i = tid; i < CELLS; i += RS_NT) {
+    const int ly = i / RT_W, lx = i - ly * RT_W;
     const int y = ry0 + ly, x = rx0 + lx;
-    if (y < H && x < W) gimg[((size_t)b * C + c) * plane + (size_t)y * W + x] = acc[i];
+    if (y >= H || x >= W) continue;
+    const int n = CT_ ? min(cnt[i] & 0x7fffffff, RS_SLOTS) : 0;
+    for (int c = 0; c < C; ++c) {
+      float v = over[c * CELLS + i];
+      for (int sl = 0; sl < n; ++sl) v += slots[(i * RS_SLOTS + sl) * CR + c];
+      gimg[((size_t)b * C + c) * plane + (size_t)y * W + x] = v;
+    }
   }
 }
 
@@ -225,6 +249,7 @@ extern "C" int ufr_resample2d_backward_owner(const float* input1, const float* i
   UFR_REQUIRE(input1 && input2 && grad_output && grad_input1 && grad_input2 && workspace, "resample2d backward (owner): null pointer argument");
   UFR_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && (long)B * H * W < (1L << 31), "resample2d backward (owner): bad shape");
   UFR_REQUIRE((size_t)C * RT_H * RT_W * sizeof(float) <= 96 * 1024, "resample2d backward (owner): at most %d channels", 96 * 1024 / (RT_H * RT_W * 4));
+  const int CT = C <= 4 ? C : 0;
   UFR_REQUIRE(workspace_bytes >= ufr_resample2d_backward_workspace_bytes(B, H, W), "resample2d backward (owner): workspace too small");
   UFR_REQUIRE((reinterpret_cast<size_t>(workspace) & 15) == 0, "resample2d backward (owner): the workspace must be 16-byte aligned");
   hipStream_t st = ufr::as_stream(stream);
@@ -240,21 +265,24 @@ extern "C" int ufr_resample2d_backward_owner(const float* input1, const float* i
   int rc = ufr::launched("rs_flow_boxes_kernel");
   if (rc != UFR_OK) return rc;
   const int rt = B * ((H + RT_H - 1) / RT_H) * ((W + RT_W - 1) / RT_W);
-  const size_t lds = (size_t)C * RT_H * RT_W * sizeof(float);
-  if (lds > 48 * 1024) {
-    static bool raised = false;
-    if (!raised) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(rs_image_owner_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
-        return ufr::fail(UFR_ELAUNCH, "resample2d backward (owner): %s", hipGetErrorString(hipGetLastError()));
-      raised = true;
-    }
+  const size_t cells = (size_t)RT_H * RT_W;
+  const size_t lds = (CT ? (size_t)C * cells + cells + cells * RS_SLOTS * C : (size_t)C * cells) * sizeof(float);
+  static bool raised = false;
+  if (!raised) {
+    hipError_t e = hipSuccess;
+    const void* fns[5] = {reinterpret_cast<const void*>(rs_image_owner_kernel<0>), reinterpret_cast<const void*>(rs_image_owner_kernel<1>),
+                          reinterpret_cast<const void*>(rs_image_owner_kernel<2>), reinterpret_cast<const void*>(rs_image_owner_kernel<3>),
+                          reinterpret_cast<const void*>(rs_image_owner_kernel<4>)};
+    for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "resample2d backward (owner): %s", hipGetErrorString(e));
+    raised = true;
   }
   switch (C) {
-    case 1: rs_image_owner_kernel<1><<<rt, 256, lds, st>>>(input2, grad_output, boxes, grad_input1, B, C, H, W); break;
-    case 2: rs_image_owner_kernel<2><<<rt, 256, lds, st>>>(input2, grad_output, boxes, grad_input1, B, C, H, W); break;
-    case 3: rs_image_owner_kernel<3><<<rt, 256, lds, st>>>(input2, grad_output, boxes, grad_input1, B, C, H, W); break;
-    case 4: rs_image_owner_kernel<4><<<rt, 256, lds, st>>>(input2, grad_output, boxes, grad_input1, B, C, H, W); break;
-    default: rs_image_owner_kernel<0><<<rt, 256, lds, st>>>(input2, grad_output, boxes, grad_input1, B, C, H, W);
+    case 1: rs_image_owner_kernel<1><<<rt, RS_NT, lds, st>>>(input2, grad_output, boxes, grad_input1, B, C, H, W); break;
+    case 2: rs_image_owner_kernel<2><<<rt, RS_NT, lds, st>>>(input2, grad_output, boxes, grad_input1, B, C, H, W); break;
+    case 3: rs_image_owner_kernel<3><<<rt, RS_NT, lds, st>>>(input2, grad_output, boxes, grad_input1, B, C, H, W); break;
+    case 4: rs_image_owner_kernel<4><<<rt, RS_NT, lds, st>>>(input2, grad_output, boxes, grad_input1, B, C, H, W); break;
+    default: rs_image_owner_kernel<0><<<rt, RS_NT, lds, st>>>(input2, grad_output, boxes, grad_input1, B, C, H, W);
   }
   return ufr::launched("rs_image_owner_kernel");
 }
