@@ -103,7 +103,7 @@ def event_time(fn, iters, warm=2):
 
 
 # PMC summaries of the latest passes over this command (tools/gpu_call.sh `traffic` step -> tools/pmc_step_traffic.py)
-IGEMM_TRAFFIC, STEP_TRAFFIC, CORR_TRAFFIC = "r3_igemm_traffic.json", "r3_step_traffic.json", "r3_corr_planes_traffic.json"
+IGEMM_TRAFFIC, STEP_TRAFFIC, CORR_TRAFFIC = "r4_igemm_traffic.json", "r4_step_traffic.json", "r3_corr_planes_traffic.json"
 
 
 def _pmc(name):
@@ -235,7 +235,7 @@ def kernel_rooflines(step, device, max_count):
 
 def step_traffic():
     """HBM-side bytes of one iteration of the windowed step from this round's PMC passes
-    (tools/pmc_step_traffic.py -> profiles/r3_step_traffic.json); counters cannot be read live."""
+    (tools/pmc_step_traffic.py -> profiles/r4_step_traffic.json); counters cannot be read live."""
     try:
         return int(_pmc(STEP_TRAFFIC)["traffic_bytes_per_iteration"])
     except (KeyError, ValueError):

@@ -576,9 +576,56 @@ class FlowNetCHeadEngine:
         self.in31.load_nchw(c3, 0)
         for name in ("conv3_1", "conv4", "conv4_1", "conv5", "conv5_1", "conv6", "conv6_1"):
             self.fwd[name]()
-        # refinement (FlowNetC.py:162-183).  (deconvK beside predict_flow(K+1) -> upsampled_flow(K+1) on a second stream -- they
-        # read cat(K+1) and write disjoint chunks of catK -- was built and measured no faster inside the graph: 5.904 against
-        # 5.874 ms in one call, gpurun r4_call13; one stream.)
+        self._pf_forward(6)
+        for k in (5, 4, 3, 2):
+            self._up_forward(k + 1)
+            self.fwd[f"deconv{k}"]()
+            self._pf_forward(k)
+        return self.flow[2]
+
+    def forward_cached(self, band=None) -> torch.Tensor:
+        """`forward` on the features the engine already holds (prefix_full / load_prefix_features + scatter_window_features)."""
+        return self.forward(None, self._c3a, self._c3b, band)
+
+    def forward(self, c2a: torch.Tensor | None, c3a: torch.Tensor, c3b: torch.Tensor, band=None) -> torch.Tensor:
+        """(conv2 of frame 1 [B,128,H/4,W/4], conv3 of both frames [B,256,H/8,W/8]) -> flow2 [B,2,H/4,W/4].
+        `band` (band_conv.Band) with `incremental` set: the features differ from the previous call's only inside the
+        prefix window, so conv_redir / conv3_1 / conv4 / conv4_1 recompute the band's columns only -- the plane buffers
+        still hold the previous iteration's activations everywhere else."""
+        if not self.siamese:
+            return self._forward_trunk(c2a, c3a)
+        for t, name in ((c3a, "c3a"), (c3b, "c3b")):
+            L.require_hip(t, name)
+        self._c3a, self._c3b = c3a, c3b
+        inc = False
+        if band is not None:
+            self.attach_band(band)
+            inc = bool(band.width and band.incremental and band.inc_layers)
+        if c2a is not None:                      # features handed over in NCHW: convert; None: the planes are up to date
+            L.require_hip(c2a, "c2a")
+            self.cat2.load_nchw(c2a, 0)
+            self.c3a_p.load_nchw(c3a, 0)
+            self.c3b_p.load_nchw(c3b, 0)
+        # submodules.py:124-138 (`correlate`: /C) + FlowNetC.py:139 LeakyReLU fused into the correlation's epilogue:
+        # matrix cores, planes in, conv3_1's input planes out (correlation_planes.hip)
+        if inc and band.cone_win is not None and band.cone_hw[1] // 8 <= 23:
+            # later iterations of a call: only the window's neighbourhood of the volume changes
+            L.check(L.lib().ufr_corr_forward_planes_window(L.ptr(self.c3a_p.t), L.ptr(self.c3b_p.t), self.c3a_p.plane_stride,
+                                                           L.ptr(self.in31.t), self.in31.plane_stride, 1, self.B, 256, *self.grid[8],
+                                                           21, 2, 1.0 / 256.0, ig.LEAKY, L.ptr(band.cone_win), 8,
+                                                           band.cone_hw[1] // 8, L.stream()), "correlation forward (planes, window)")
+        else:
+            L.check(L.lib().ufr_corr_forward_planes(L.ptr(self.c3a_p.t), L.ptr(self.c3b_p.t), self.c3a_p.plane_stride,
+                                                    L.ptr(self.in31.t), self.in31.plane_stride, 1, self.B, 256, *self.grid[8], 21, 2,
+                                                    1.0 / 256.0, ig.LEAKY, L.stream()), "correlation forward (planes)")
+        for name in ("conv_redir", "conv3_1", "conv4", "conv4_1"):
+            (self.fwd_band if inc else self.fwd)[name]()
+        for name in ("conv5", "conv5_1", "conv6", "conv6_1"):
+            self.fwd[name]()
+        # refinement (FlowNetC.py:162-183).  (deconvK beside predict_flow(K+1) -> upsampled_flow(K+1) on a second stream inside the
+        # graph -- they read cat(K+1) and write disjoint chunks of catK -- measured no faster: 5.773 against 5.729 ms in one call,
+        # gpurun r4_call23; the same for the small launches of the backward beside deconvK's data gradient, 5.904 against 5.874,
+        # r4_call13: the ping-pong igemm holds every CU's LDS, the small launches wait for its tail either way.  One stream.)
         self._pf_forward(6)
         for k in (5, 4, 3, 2):
             self._up_forward(k + 1)
