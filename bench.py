@@ -103,7 +103,7 @@ def event_time(fn, iters, warm=2):
 
 
 # PMC summaries of the latest passes over this command (tools/gpu_call.sh `traffic` step -> tools/pmc_step_traffic.py)
-IGEMM_TRAFFIC, STEP_TRAFFIC, CORR_TRAFFIC = "r4_igemm_traffic.json", "r4_step_traffic.json", "r3_corr_planes_traffic.json"
+IGEMM_TRAFFIC, STEP_TRAFFIC, CORR_TRAFFIC = "r4_igemm_traffic.json", "r4_step_traffic.json", "r4_corr_planes_traffic.json"
 
 
 def _pmc(name):
@@ -216,7 +216,7 @@ def kernel_rooflines(step, device, max_count):
     ks.append(dict(kernel=name, ms=round(t_w, 4), bound="hbm",
                    achieved=round(bytes_w / t_w / 1e6, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                    frac=round(bytes_w / t_w / 1e6 / PEAK_HBM_GBS, 4), tflops=round(GFLOP_CORR_BWD_WINDOW * B / t_w, 2),
-                   traffic=_pmc("r3_corr_window_traffic.json").get("traffic_bytes"), algorithmic_bytes=int(bytes_w)))
+                   traffic=_pmc("r4_corr_window_traffic.json").get("traffic_bytes"), algorithmic_bytes=int(bytes_w)))
     # ---- the 2-channel layers of the refinement (HBM-bound: one pass over the concatenation's planes)
     if eng is not None:
         for k in (6, 5, 4, 3, 2):
@@ -435,6 +435,9 @@ def main():
                     help="c2 = the headline (BASELINE configs[1]); c4 / c5 = the configs BASELINE shards over 8 GPUs")
     ap.add_argument("--sustained-seconds", type=float, default=2.0,
                     help="N=1: after the K timed steps, replay the same protocol for at least this long (0 = skip)")
+    ap.add_argument("--precondition-seconds", type=float, default=1.0,
+                    help="before the W warm-up steps: this long of the same attack() calls, untimed, so that the timed region starts from the "
+                         "clock the chip HOLDS under this load (a launch after idle runs ~8 %% slower clocked: profiles/r4_igemm_clock.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-full-frame", action="store_true", help="skip the full-frame side measurement")
@@ -491,7 +494,19 @@ def main():
         return call
 
     # the throughput run must never trip the early exit: an iteration that is skipped is not work done
-    calls_done = attack_calls(opt.warmup, 0)
+    calls_done = 0
+    if opt.precondition_seconds > 0:               # setup, like the graph capture: bring the chip to its steady clock
+        t_pre = time.perf_counter()
+        calls_done = attack_calls(4 * mc, calls_done)
+        torch.cuda.synchronize(device)
+        dt = max(time.perf_counter() - t_pre, 1e-4)
+        more = torch.tensor([int(max(0.0, opt.precondition_seconds - dt) / dt)], device=device)
+        if world > 1:                              # every rank must run the same number of exchanges
+            dist.broadcast(more, src=0)
+        for _ in range(int(more)):
+            calls_done = attack_calls(4 * mc, calls_done)
+        torch.cuda.synchronize(device)
+    calls_done = attack_calls(opt.warmup, calls_done)
     torch.cuda.synchronize(device)
     executed0 = float(executed_acc)
 
@@ -537,6 +552,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": CONFIG_WORKLOADS[opt.config], "pairs_per_gpu": pairs, "global_pairs": world * pairs,
+                       "preconditioning_s": opt.precondition_seconds,
                        "weights": "synthetic seeded (no checkpoints offline)", "graph": not opt.no_graph},
         }
         if sustained is not None:
@@ -633,7 +649,8 @@ def c2_line(line, opt, ctx, world, device, ms, mc):
             # C5 FlowNet2's universal-perturbation step (tools/bench_configs.py measures more: all-pairs RAFT, 8-pair RAFT)
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_configs
-            line["config"]["other_configs"] = [bench_configs.measure(w, 6) for w in ("c4", "c3alt", "c5")]
+            # (C3 at one pair -- the reference's batch size -- and at 8 pairs behind one patch: SURVEY.md 8d "C3 = 1...8")
+            line["config"]["other_configs"] = [bench_configs.measure(w, 6) for w in ("c4", "c3alt", "c3altb8", "c3", "c5")]
         if step.cone is not None and not opt.no_full_frame:
             # the same protocol with every frame-sized shortcut off (UFR_CONE=0): what the windowed prefix,
             # band and incremental forward are worth, measured in this very process

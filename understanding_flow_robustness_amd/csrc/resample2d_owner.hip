@@ -134,7 +134,7 @@ __global__ __launch_bounds__(RS_NT) void rs_image_owner_kernel(const float* __re
   const float* gout_b = gout + (size_t)b * C * plane;
   for (int i = tid; i < C * CELLS; i += RS_NT) over[i] = 0.f;
   if (CT_) for (int i = tid; i < CELLS; i += RS_NT) cnt[i] = 0;
-  auto fetch_flow = [&](int t, float (&dxs)[RS_PX], float (&dys)[RS_PX]) {
+  auto fetch_flow = [&](int t, float (&dxs)[RS_PX], float (&dys)[RS_PX], float (&gs)[RS_PX][CR]) {
     const int x = (t % otx) * OT_W + (tid & 63), yb = (t / otx) * OT_H + (tid >> 6);
 #pragma unroll
     for (int k = 0; k < RS_PX; ++k) {
@@ -143,6 +143,10 @@ __global__ __launch_bounds__(RS_NT) void rs_image_owner_kernel(const float* __re
       const size_t pix = (size_t)(live ? y : 0) * W + (live ? x : 0);
       dxs[k] = live ? flow_b[pix] : 0.f;
       dys[k] = live ? flow_b[plane + pix] : 0.f;
+      if constexpr (CT_ != 0) {                 // the gradient values ride along (12 bytes per pixel more, one latency less per tile)
+#pragma unroll
+        for (int c = 0; c < CR; ++c) gs[k][c] = live ? gout_b[(size_t)c * plane + pix] : 0.f;
+      }
     }
   };
   for (int t0 = 0; t0 < nT; t0 += RS_MAX_LIST) {                               // (one pass unless > RS_MAX_LIST tiles meet this owner)
@@ -154,17 +158,21 @@ __global__ __launch_bounds__(RS_NT) void rs_image_owner_kernel(const float* __re
     }
     __syncthreads();
     const int n = n_list;
-    float ndx[RS_PX], ndy[RS_PX];
-    if (n > 0) fetch_flow(list[0], ndx, ndy);
+    float ndx[RS_PX], ndy[RS_PX], ng[RS_PX][CR];
+    if (n > 0) fetch_flow(list[0], ndx, ndy, ng);
     for (int li = 0; li < n; ++li) {
       const int t = list[li];
-      float dxs[RS_PX], dys[RS_PX];
+      float dxs[RS_PX], dys[RS_PX], g[RS_PX][CR];
 #pragma unroll
-      for (int k = 0; k < RS_PX; ++k) { dxs[k] = ndx[k]; dys[k] = ndy[k]; }
-      if (li + 1 < n) fetch_flow(list[li + 1], ndx, ndy);                      // in flight while this tile is processed
+      for (int k = 0; k < RS_PX; ++k) {
+        dxs[k] = ndx[k]; dys[k] = ndy[k];
+#pragma unroll
+        for (int c = 0; c < CR; ++c) g[k][c] = ng[k][c];
+      }
+      if (li + 1 < n) fetch_flow(list[li + 1], ndx, ndy, ng);                  // in flight while this tile is processed
       const int x = (t % otx) * OT_W + (tid & 63), yb = (t / otx) * OT_H + (tid >> 6);
       int cells[RS_PX][4];                                                        // LDS cell of TL, TR, BL, BR, or -1
-      float wts[RS_PX][4], g[RS_PX][CR];
+      float wts[RS_PX][4];
       bool any[RS_PX];
 #pragma unroll
       for (int k = 0; k < RS_PX; ++k) {
@@ -183,10 +191,6 @@ __global__ __launch_bounds__(RS_NT) void rs_image_owner_kernel(const float* __re
         any[k] = (cells[k][0] & cells[k][1] & cells[k][2] & cells[k][3]) != -1;
       }
       if constexpr (CT_ != 0) {
-#pragma unroll
-        for (int k = 0; k < RS_PX; ++k)                                            // every needed gradient value requested at once
-#pragma unroll
-          for (int c = 0; c < CR; ++c) g[k][c] = any[k] ? gout_b[(size_t)c * plane + (size_t)(yb + RS_ROWS * k) * W + x] : 0.f;
 #pragma unroll
         for (int k = 0; k < RS_PX; ++k) {
           if (!any[k]) continue;
