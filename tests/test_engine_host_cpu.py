@@ -132,3 +132,87 @@ def test_split_k_cost_model_keeps_uniform_launches_and_balances_unequal_phases()
     s = ig.splitk_for(7296, 256, 64, 4, phase_ktiles=pk)             # conv4 backward on the band
     assert s in (2, 4) and -(-max(pk) // s) <= 32
     assert ig.splitk_for(7296, 256, 64, 4, phase_ktiles=[64, 64, 64, 64]) == ig.splitk_for(7296, 256, 64, 4)
+
+
+def test_conv1_direct_weight_image_is_the_7x7_stride2_convolution():
+    """igemm.conv1_direct_weights: the image `ufr_conv1_direct` keeps in registers -- K tile = kernel row ky, K group g = the
+    input pixel pair (2g, 2g + 1) x (3 channels + 1 zero) -- against Conv2d(3, 64, 7, 2, 3) through a plain-torch emulation of
+    the kernel's im2col (the region starts at input column 2 X0 - 3, so output pixel x reads LDS pixels 2 x .. 2 x + 7)."""
+    g = torch.Generator().manual_seed(2)
+    w = torch.randn(64, 3, 7, 7, generator=g)
+    x = torch.randn(2, 3, 10, 14, generator=g, dtype=torch.float64)
+    img = ig.conv1_direct_weights(w)
+    assert img.shape == (3, 7, 64, 32) and img.dtype == torch.bfloat16
+    wv = img.float().sum(0).double()                                       # [7 ky][64 n][32 k], exact
+    assert torch.equal(wv.float().sum(0).sum(0)[torch.tensor([3, 7, 11, 15, 19, 23, 27, 28, 29, 30, 31])], torch.zeros(11))   # channel 3 and kx = 7 carry zeros
+    xp = F.pad(x, (3, 4, 3, 3))                                            # column 2 x0 - 3 ... one extra column for kx = 7
+    Ho, Wo = 5, 7
+    out = torch.zeros(2, 64, Ho, Wo, dtype=torch.float64)
+    for ky in range(7):
+        for gg in range(4):
+            for j in range(2):
+                for c in range(3):
+                    k = gg * 8 + j * 4 + c
+                    patch = xp[:, c, ky:ky + 2 * Ho:2, 2 * gg + j:2 * gg + j + 2 * Wo:2]      # input (2 y - 3 + ky, 2 x - 3 + 2 g + j)
+                    out += wv[ky, :, k].view(1, 64, 1, 1) * patch.unsqueeze(1)
+    want = F.conv2d(x, w.double(), None, 2, 3)
+    assert torch.allclose(out, want, atol=1e-9)
+
+
+def test_planes_as_weights_describe_the_all_pairs_product():
+    """igemm.planes_as_weights: an activation's planes [3][chunks][M][32] read as a one-tap weight image [KC][Npad = M][32]
+    (RAFT's all-pairs correlation, models/raft/corr.py:57-64): geometry only, no launch."""
+    import pytest
+    p = ig.Planes(1, 8, 16, 4, "cpu")                                      # M = 128 pixels, 128 channels
+    wi = ig.planes_as_weights(p)
+    assert (wi.N, wi.Npad, wi.KC, wi.phases, wi.offsets) == (128, 128, 4, [(0, 0, [(0, 0)])], [0])
+    assert wi.planes.shape == (3, p.plane_stride) and wi.planes.data_ptr() == p.t.data_ptr() and wi.k_order == 1
+    assert wi.flops(128) == 2.0 * 128 * 128 * 128
+    with pytest.raises(ValueError):
+        ig.planes_as_weights(ig.Planes(1, 5, 9, 4, "cpu"))                 # 45 pixels: not a multiple of 64
+
+
+def test_engine_cache_is_lru_and_counts_evictions():
+    """_lib.EngineCache: a hit makes an entry the most recently USED one; the seventh configuration evicts the least
+    recently used, counts it and warns once per cache."""
+    import warnings
+
+    from understanding_flow_robustness_amd import _lib as L
+    c = L.EngineCache()
+    before = L.EngineCache.evictions
+    for k in range(6):
+        c[k] = f"engine{k}"
+    assert c.get(0) == "engine0"                                           # 0 is now the most recently used
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        c[6] = "engine6"
+        c[7] = "engine7"
+    assert 0 in c and 1 not in c and 2 not in c and len(c) == 6
+    assert L.EngineCache.evictions == before + 2 and len([m for m in w if "engine configurations" in str(m.message)]) == 1
+    assert c.get("absent", "dflt") == "dflt"
+
+
+def test_engine_refusal_names_the_reason():
+    """_lib.engine_refusal / engine_gate: why a forward leaves the hand-written engines."""
+    from understanding_flow_robustness_amd import _lib as L
+    m = torch.nn.Conv2d(3, 4, 3).eval()
+    assert L.engine_refusal(m, torch.zeros(1, 3, 64, 64), 64) == "not a HIP float32 tensor"
+
+    class FakeHip:                                                         # a stand-in with the fields the gate reads
+        is_cuda, dtype = True, torch.float32
+
+        def __init__(self, h, w):
+            self.shape = (1, 3, h, w)
+    assert "require gradients" in L.engine_refusal(m, FakeHip(64, 64), 64)
+    for p in m.parameters():
+        p.requires_grad_(False)
+    assert L.engine_refusal(m, FakeHip(64, 64), 64) is None
+    assert L.engine_refusal(m, FakeHip(16, 16), 64, spatial_scale=4) is None            # a 1/4-resolution feature of a 64-multiple frame
+    assert "multiples of 64" in L.engine_refusal(m, FakeHip(72, 64), 64)
+    m.train()
+    assert L.engine_refusal(m, FakeHip(64, 64), 64) == "module in training mode"
+    with torch.no_grad():
+        m.eval()
+        for p in m.parameters():
+            p.requires_grad_(True)
+        assert L.engine_refusal(m, FakeHip(64, 64), 64) is None            # no gradients wanted: the engines serve it
