@@ -1,3 +1,5 @@
+// Build and run on the GPU box:  hipcc --offload-arch=gfx950 -O3 tools/probe_lds_atomics.hip -o /tmp/lds_atomics && /tmp/lds_atomics
+// Result of round 4: profiles/r4_lds_atomics_probe.txt (ds_add_f32 0.38 lanes per clock and CU, ds_add_rtn_u32 13, plain read-add-write 7).
 // micro-benchmark: LDS atomic throughput per CU (conflict-free consecutive addresses, one lane per bank)
 #include <hip/hip_runtime.h>
 #include <cstdio>
