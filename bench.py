@@ -429,15 +429,15 @@ def cpu_baseline_other(config):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=sorted(CONFIG_WORKLOADS), default="c2",
                     help="c2 = the headline (BASELINE configs[1]); c4 / c5 = the configs BASELINE shards over 8 GPUs")
     ap.add_argument("--sustained-seconds", type=float, default=2.0,
                     help="N=1: after the K timed steps, replay the same protocol for at least this long (0 = skip)")
-    ap.add_argument("--precondition-seconds", type=float, default=1.0,
-                    help="before the W warm-up steps: this long of the same attack() calls, untimed, so that the timed region starts from the "
-                         "clock the chip HOLDS under this load (a launch after idle runs ~8 %% slower clocked: profiles/r4_igemm_clock.txt)")
+    ap.add_argument("--precondition-seconds", type=float, default=0.0,
+                    help="optional: before the W warm-up steps, this long of the same attack() calls, untimed (a launch after idle runs ~8 %% "
+                         "slower clocked than in a sustained stream, profiles/r4_igemm_clock.txt; off by default: W warm-up steps, then K timed ones)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-full-frame", action="store_true", help="skip the full-frame side measurement")
