@@ -608,6 +608,13 @@ int ufr_deconv_flow_tail_backward_mfma(const void* grad_planes, long plane_strid
                                        float* G, int out_chunk, int B, int H, int W, ufr_stream_t stream);
 int ufr_flow_head_planes_backward(const float* grad_y, const float* wpk, float* G, int chunk0, int chunks, int B, int H,
                                   int W, int accumulate, ufr_stream_t stream);
+/* The same with the finalisation of one segment fused (round 4): for the chunks [fin_chunk0, fin_chunk0 + fin_chunks) of the
+ * tensor the completed sum x LeakyReLU'(mask_planes plane 0; NULL = linear) also leaves as the three gradient planes `out_planes`
+ * (same chunk positions) -- what ufr_grad_finalize did in a launch of its own (FlowNetC's refinement, models/FlowNetC.py:162-183:
+ * predict_flowK's adjoint is the last contributor to deconvK's output gradient). */
+int ufr_flow_head_planes_backward_finalize(const float* grad_y, const float* wpk, float* G, int chunk0, int chunks, int B, int H, int W,
+                                           int accumulate, const void* mask_planes, void* out_planes, long out_plane_stride,
+                                           int fin_chunk0, int fin_chunks, float slope, ufr_stream_t stream);
 /* PWC-Net's `upfeat*` = ConvTranspose2d(C, 2, 4, 2, 1) (models/PWCNet.py:115-143, used at :284,:299,:314,:329) on the engine's planes:
  * forward from `chunks` chunks of the COARSE [B,H,W] planes to out [B,2,2H,2W] (NCHW fp32, + bias) on the matrix cores
  * (wmf: bf16 [chunks][3][2][16][32] with n = 2 (4 ky + kx) + o); backward from grad_y [B,2,2H,2W] into the coarse gradient

@@ -148,6 +148,7 @@ SIGNATURES = {
     "ufr_flow_head_planes_forward_mfma": [_vp, _l, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ufr_deconv_flow_tail_backward_mfma": [_vp, _l, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_flow_head_planes_backward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "ufr_flow_head_planes_backward_finalize": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _l, _i, _i, _f, _vp],
     "ufr_unshuffle_pack_planes": [_vp, _vp, _l, _i, _i, _i, _i, _vp],
     "ufr_unshuffle_unpack_grad": [_vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_cm_norm_stats": [_vp, _vp, _vp, _l, _i, _i, _f, _vp],

@@ -335,9 +335,16 @@ __global__ __launch_bounds__(512) void flow_head_planes_fwd_mfma(const __bf16* _
 
 // G[chunk0 + ch][pix][c] (+)= sum_o sum_k gy[b, o, pix - (k - centre)] * weight[o][32*ch + c][k]
 // thread = (pixel, 8-channel group), blockIdx.y = slice of the chunks (independent outputs: no reduction)
+// Optional fused finalisation (round 4): for the chunks [fin_c0, fin_c0 + fin_n) of the tensor -- the segment a deconvolution
+// produced, whose gradient is COMPLETE once this kernel has added its share -- the sum x LeakyReLU'(mask) also leaves as the
+// three gradient planes the segment's transposed GEMM reads (what ufr_grad_finalize did in a launch of its own).
+struct PfFinalize {
+  const __bf16* mask; __bf16* out; long out_plane_stride; int c0, n; float slope;
+};
+
 __global__ __launch_bounds__(256) void flow_head_planes_bwd(const float* __restrict__ gy, const float* __restrict__ wpk,
                                                             float* __restrict__ G, int chunk0, int chunks, int B, int H, int W,
-                                                            int accumulate, int per) {
+                                                            int accumulate, int per, const PfFinalize fin) {
   extern __shared__ __attribute__((aligned(16))) float lds_w[];          // this slice's [per][9][2][32]
   const long M = (long)B * H * W;
   const int c_lo = blockIdx.y * per, c_hi = min(chunks, c_lo + per);
@@ -384,6 +391,25 @@ __global__ __launch_bounds__(256) void flow_head_planes_bwd(const float* __restr
     }
     dst[0] = lo;
     dst[1] = hi;
+    if (fin.out && ch >= fin.c0 && ch < fin.c0 + fin.n) {
+      const long e = ((long)(chunk0 + ch) * M + pix) * 32 + q * 8;
+      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      if (fin.mask) {
+        const bf16x8 m = *reinterpret_cast<const bf16x8*>(fin.mask + e);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ((float)m[j] > 0.f) ? v[j] : v[j] * fin.slope;
+      }
+      bf16x8 q0, q1, q2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        __bf16 x, y, z;
+        split3(v[j], x, y, z);
+        q0[j] = x; q1[j] = y; q2[j] = z;
+      }
+      *reinterpret_cast<bf16x8*>(fin.out + e) = q0;
+      *reinterpret_cast<bf16x8*>(fin.out + e + fin.out_plane_stride) = q1;
+      *reinterpret_cast<bf16x8*>(fin.out + e + 2 * fin.out_plane_stride) = q2;
+    }
   }
 }
 
@@ -612,11 +638,9 @@ extern "C" int ufr_upfeat_planes_backward(const float* grad_y, const float* wpk,
   return ufr::launched("flow_tail_planes_bwd");
 }
 
-extern "C" int ufr_flow_head_planes_backward(const float* grad_y, const float* wpk, float* G, int chunk0, int chunks, int B,
-                                             int H, int W, int accumulate, ufr_stream_t stream) {
-  UFR_REQUIRE(grad_y && wpk && G, "flow head (planes) backward: null pointer");
-  UFR_REQUIRE(B > 0 && H > 0 && W > 0 && chunks > 0 && chunks <= 48 && chunk0 >= 0 && (long)B * H * W < (1L << 29),
-              "flow head (planes) backward: bad shape");
+namespace {
+int launch_pf_bwd(const float* grad_y, const float* wpk, float* G, int chunk0, int chunks, int B, int H, int W, int accumulate,
+                  const PfFinalize& fin, hipStream_t st) {
   const long threads = (long)B * H * W * 4;
   const int bx = ufr::ceil_div(threads, 256);
   int slices = 1;                             // chunk slices over blockIdx.y: more workgroups on the small grids
@@ -629,9 +653,33 @@ extern "C" int ufr_flow_head_planes_backward(const float* grad_y, const float* w
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flow_head_planes_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 576 * 4);
     attr_set = true;
   }
-  flow_head_planes_bwd<<<dim3(bx, slices), 256, (size_t)per * 576 * 4, ufr::as_stream(stream)>>>(grad_y, wpk, G, chunk0, chunks, B,
-                                                                                                H, W, accumulate, per);
+  flow_head_planes_bwd<<<dim3(bx, slices), 256, (size_t)per * 576 * 4, st>>>(grad_y, wpk, G, chunk0, chunks, B, H, W, accumulate, per, fin);
   return ufr::launched("flow_head_planes_bwd");
+}
+}  // namespace
+
+extern "C" int ufr_flow_head_planes_backward(const float* grad_y, const float* wpk, float* G, int chunk0, int chunks, int B,
+                                             int H, int W, int accumulate, ufr_stream_t stream) {
+  UFR_REQUIRE(grad_y && wpk && G, "flow head (planes) backward: null pointer");
+  UFR_REQUIRE(B > 0 && H > 0 && W > 0 && chunks > 0 && chunks <= 48 && chunk0 >= 0 && (long)B * H * W < (1L << 29),
+              "flow head (planes) backward: bad shape");
+  return launch_pf_bwd(grad_y, wpk, G, chunk0, chunks, B, H, W, accumulate, PfFinalize{nullptr, nullptr, 0, 0, 0, 1.f}, ufr::as_stream(stream));
+}
+
+extern "C" int ufr_flow_head_planes_backward_finalize(const float* grad_y, const float* wpk, float* G, int chunk0, int chunks, int B,
+                                                      int H, int W, int accumulate, const void* mask_planes, void* out_planes,
+                                                      long out_plane_stride, int fin_chunk0, int fin_chunks, float slope,
+                                                      ufr_stream_t stream) {
+  UFR_REQUIRE(grad_y && wpk && G && out_planes, "flow head (planes) backward + finalize: null pointer");
+  UFR_REQUIRE(B > 0 && H > 0 && W > 0 && chunks > 0 && chunks <= 48 && chunk0 >= 0 && (long)B * H * W < (1L << 29),
+              "flow head (planes) backward + finalize: bad shape");
+  UFR_REQUIRE(fin_chunk0 >= 0 && fin_chunks > 0 && fin_chunk0 + fin_chunks <= chunks && out_plane_stride > 0,
+              "flow head (planes) backward + finalize: the finalised segment leaves the tensor");
+  // the mask (plane 0 of the activation) and the gradient planes share the tensor's geometry: element ((chunk0 + ch) * M + pixel) * 32
+  return launch_pf_bwd(grad_y, wpk, G, chunk0, chunks, B, H, W, accumulate,
+                       PfFinalize{static_cast<const __bf16*>(mask_planes), static_cast<__bf16*>(out_planes), out_plane_stride, fin_chunk0,
+                                  fin_chunks, slope},
+                       ufr::as_stream(stream));
 }
 
 extern "C" int ufr_flow_up_planes_forward(const float* x, const float* w, const float* bias, void* planes, long plane_stride,

@@ -539,8 +539,17 @@ class FlowNetCHeadEngine:
                                                           L.ptr(self.pf_b[k]), L.ptr(self.flow[k]), self.B, src.H, src.W,
                                                           L.stream()), "predict_flow forward (mfma)")
 
-    def _pf_backward(self, k, gy, accumulate):
+    def _pf_backward(self, k, gy, accumulate, finalize=None):
+        """predict_flowK^T; `finalize` = (activation planes, gradient planes, first chunk, chunks) of the segment whose gradient
+        sum is complete with this launch (deconvK's output): x LeakyReLU' -> planes in the same kernel (round 4)."""
         src, chunks = self.pf_src[k]
+        if finalize is not None:
+            act, out, c0, n = finalize
+            L.check(L.lib().ufr_flow_head_planes_backward_finalize(L.ptr(gy), L.ptr(self.pf_w[k]), L.ptr(self.pf_G[k].t), 0, chunks, self.B,
+                                                                   src.H, src.W, int(accumulate), L.ptr(act.t), L.ptr(out.t), out.plane_stride,
+                                                                   int(c0), int(n), float(ig.LEAKY), L.stream()),
+                    "predict_flow backward + finalize")
+            return
         L.check(L.lib().ufr_flow_head_planes_backward(L.ptr(gy), L.ptr(self.pf_w[k]), L.ptr(self.pf_G[k].t), 0, chunks, self.B,
                                                       src.H, src.W, int(accumulate), L.stream()), "predict_flow backward")
 
@@ -645,24 +654,31 @@ class FlowNetCHeadEngine:
         if band is not None:
             self.attach_band(band)
         # level 2: predict_flow2 -> gradient of cat2 = [conv2a | deconv2 | flow3_up]
-        self._pf_backward(2, g_flow2, accumulate=False)
+        gz = {2: (self.G_cat2, self.cat2, self.gz_cat2, 4, 2), 3: (self.G_cat3, self.cat3, self.gz_cat3, 8, 4),
+              4: (self.G_cat4, self.cat4, self.gz_cat4, 16, 8), 5: (self.G_cat5, self.cat5, self.gz_cat5, 16, 16)}
+        # predict_flowK's adjoint is the LAST contributor to deconvK's output gradient (deconv(K-1)'s data gradient and its two
+        # flow columns come before it): LeakyReLU' and the split into gradient planes ride in its kernel instead of a
+        # `grad_finalize` launch per level (UFR_FUSE_FINALIZE=0: the separate launches)
+        fuse = os.environ.get("UFR_FUSE_FINALIZE", "1") != "0"
+        fin = lambda k: (gz[k][1], gz[k][2], gz[k][3], gz[k][4]) if fuse else None
+        self._pf_backward(2, g_flow2, accumulate=False, finalize=fin(2))
         eng_window = bool(fused_window and band is not None and getattr(band, "eng_window", False)
                           and getattr(self, "_wprefix", None) is not None)
         if eng_window:                           # the window prefix runs on the engine: its conv2 gradient stays chunk-major
             self.window_gather_conv2_gradient(band.cone_win, band.g2_margin)
         else:
             self.G_cat2.to_nchw(128, 0, out=self.g_c2a)
-        gz = {2: (self.G_cat2, self.cat2, self.gz_cat2, 4, 2), 3: (self.G_cat3, self.cat3, self.gz_cat3, 8, 4),
-              4: (self.G_cat4, self.cat4, self.gz_cat4, 16, 8), 5: (self.G_cat5, self.cat5, self.gz_cat5, 16, 16)}
         for k in (2, 3, 4):
             Gs, act, out, chunk0, chunks = gz[k]
-            self._finalize(Gs, act, out, chunk0, chunks)          # LeakyReLU' of deconvK's output
+            if not fuse:
+                self._finalize(Gs, act, out, chunk0, chunks)      # LeakyReLU' of deconvK's output
             self._up_backward(k + 1)                               # -> d/d flow(K+1)
             self.bwd[f"deconv{k}"]()                               # writes the gradient sum of cat(K+1)
             self._deconv_tail(k)
-            self._pf_backward(k + 1, self.g_flow[k + 1], accumulate=True)
+            self._pf_backward(k + 1, self.g_flow[k + 1], accumulate=True, finalize=fin(k + 1))
         Gs, act, out, chunk0, chunks = gz[5]
-        self._finalize(Gs, act, out, chunk0, chunks)
+        if not fuse:
+            self._finalize(Gs, act, out, chunk0, chunks)
         self._up_backward(6)
         self._pf_backward(6, self.g_flow[6], accumulate=False)      # G_c6 = predict_flow6^T; deconv5's adjoint adds to it
         for name in ("deconv5", "conv6_1", "conv6", "conv5_1"):
