@@ -193,6 +193,11 @@ int ufr_attack_gate(const float* loss_cur, float* state, float threshold, ufr_st
 int ufr_patch_grad_crop(const float* g_tgt, const float* g_ref, const float* mask_p, const int* origins,
                         const int* origins_host, const float* loss_local, float* rows, int B, int H, int W,
                         int ph, int pw, int groups, ufr_stream_t stream);
+/* ufr_patch_grad_crop from the WINDOW gradients of the windowed prefix instead of canvas-sized ones (round 4): gxw [2B,3,wh,ww] =
+ * d loss / d (first frames | second frames) on each pair's window, win[b] = {y0, x0, ...} (8 ints per pair, the table of
+ * ufr_cone_window; origins clamped into the frame as ufr_window_scatter clamps them); zero gradient outside the window. */
+int ufr_patch_grad_crop_window(const float* gxw, const int* win, const float* mask_p, const int* origins, const float* loss_local,
+                               float* rows, int B, int H, int W, int wh, int ww, int ph, int pw, int groups, ufr_stream_t stream);
 int ufr_patch_apply(const float* rows, int n_rows, float* patch_p, float* loss, int ph, int pw, float step,
                     float bound, const float* gate_state, ufr_stream_t stream);
 int ufr_patch_paste_placed(const float* tgt, const float* ref, const float* patch_p, const float* mask_p,

@@ -117,6 +117,7 @@ SIGNATURES = {
     "ufr_flow2_upsampled_loss": [_vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp],
     "ufr_patch_grad_crop": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "ufr_patch_apply": [_vp, _i, _vp, _vp, _i, _i, _f, _f, _vp, _vp],
+    "ufr_patch_grad_crop_window": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ufr_patch_paste_placed_rect": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp],
     "ufr_patch_paste_placed": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp],
     "ufr_cone_window": [_vp, _i, _l, _i, _i, _i, C.POINTER(ConeChain), _i, _i, _vp, _vp, _vp],

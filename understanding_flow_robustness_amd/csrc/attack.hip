@@ -150,6 +150,40 @@ __global__ void patch_grad_crop_kernel(const float* __restrict__ g_tgt, const fl
   }
 }
 
+// The same crop straight from the WINDOW gradients of the windowed prefix (patch_attack.py `_backward_cone`): gxw [2B, 3, wh, ww] holds
+// d loss / d (first frames | second frames) on each pair's window (origin win[b] = {y0, x0, ..}, clamped into the frame exactly as
+// window_copy_kernel clamps it); outside the window the image gradient is zero.  Replaces two window -> canvas scatters (and the two
+// canvas zero fills per call behind them) + the canvas crop.
+__global__ void patch_grad_crop_window_kernel(const float* __restrict__ gxw, const int* __restrict__ win,
+                                              const float* __restrict__ mask_p, const int* __restrict__ origins,
+                                              const float* __restrict__ loss_local, float* __restrict__ rows, int B, int H, int W,
+                                              int wh, int ww, int ph, int pw, int groups) {
+  const int n = 3 * ph * pw, per = B / groups;
+  const long wplane = (long)wh * ww;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e <= n; e += gridDim.x * blockDim.x) {
+    if (e == n) {
+      for (int g = 0; g < groups; ++g) rows[(long)g * (n + 1) + n] = (g == 0) ? *loss_local : 0.f;
+      continue;
+    }
+    const int c = e / (ph * pw), r = e - c * ph * pw, i = r / pw, j = r - i * pw;
+    const bool shown = mask_p[e] != 0.f;
+    for (int g = 0; g < groups; ++g) {
+      float s = 0.f;
+      if (shown)
+        for (int b = g * per; b < (g + 1) * per; ++b) {
+          const int y = origins[2 * b] + i, x = origins[2 * b + 1] + j;
+          if ((unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W) continue;
+          const int y0 = min(max(win[b * 8], 0), H - wh), x0 = min(max(win[b * 8 + 1], 0), W - ww);
+          const int wy = y - y0, wx = x - x0;
+          if ((unsigned)wy >= (unsigned)wh || (unsigned)wx >= (unsigned)ww) continue;     // zero gradient outside the window
+          const long o = (long)c * wplane + (long)wy * ww + wx;
+          s += gxw[(long)b * 3 * wplane + o] + gxw[(long)(B + b) * 3 * wplane + o];
+        }
+      rows[(long)g * (n + 1) + e] = s;
+    }
+  }
+}
+
 __global__ void patch_apply_kernel(const float* __restrict__ rows, int n_rows, float* __restrict__ patch_p,
                                    float* __restrict__ loss, int n, float step, float bound,
                                    const float* __restrict__ gate) {
@@ -439,6 +473,19 @@ extern "C" int ufr_patch_grad_crop(const float* g_tgt, const float* g_ref, const
   hipLaunchKernelGGL(patch_grad_crop_kernel, dim3(ufr::ceil_div(n, 256)), dim3(256), 0, ufr::as_stream(stream), g_tgt,
                      g_ref, mask_p, origins, loss_local, rows, B, H, W, ph, pw, groups);
   return ufr::launched("patch_grad_crop_kernel");
+}
+
+extern "C" int ufr_patch_grad_crop_window(const float* gxw, const int* win, const float* mask_p, const int* origins,
+                                          const float* loss_local, float* rows, int B, int H, int W, int wh, int ww, int ph, int pw,
+                                          int groups, ufr_stream_t stream) {
+  UFR_REQUIRE(gxw && win && mask_p && origins && loss_local && rows, "patch grad crop (window): null pointer argument");
+  UFR_REQUIRE(B > 0 && H > 0 && W > 0 && ph > 0 && pw > 0 && ph <= H && pw <= W && wh > 0 && ww > 0 && wh <= H && ww <= W,
+              "patch grad crop (window): bad shape");
+  UFR_REQUIRE(groups > 0 && B % groups == 0, "patch grad crop (window): the pairs must split evenly into %d groups", groups);
+  const int n = 3 * ph * pw + 1;
+  hipLaunchKernelGGL(patch_grad_crop_window_kernel, dim3(ufr::ceil_div(n, 256)), dim3(256), 0, ufr::as_stream(stream), gxw, win,
+                     mask_p, origins, loss_local, rows, B, H, W, wh, ww, ph, pw, groups);
+  return ufr::launched("patch_grad_crop_window_kernel");
 }
 
 extern "C" int ufr_patch_apply(const float* rows, int n_rows, float* patch_p, float* loss, int ph, int pw, float step,

@@ -254,8 +254,9 @@ class PatchAttackStep:
             full = None if self.eng is not None else torch.zeros(n, f.shape[1], H // ls, W // ls, **f32).requires_grad_(True)
             gwin = torch.zeros(n, f.shape[1], wh // ls, ww // ls, **f32)
             self.taps.append((ls, m, n, full, gwin))
-        self.g_tgt_full = torch.zeros_like(self.tgt)
-        self.g_ref_full = torch.zeros_like(self.tgt)
+        if not self.placed:                    # canvas-sized image gradients: only the reference's canvas form reads them
+            self.g_tgt_full = torch.zeros_like(self.tgt)
+            self.g_ref_full = torch.zeros_like(self.tgt)
         self._chain = spec.to_c()
         # column band for the head's most expensive data gradients (band_conv.py)
         self.band, reach = None, getattr(self.net, "BAND_REACH", None)
@@ -285,7 +286,8 @@ class PatchAttackStep:
         wh, ww = self.win_hw
         L.check(lib.ufr_cone_window(L.ptr(self.mask), self.B, self.CHW, 3, self.H, self.W, C.byref(self._chain),
                                     wh, ww, L.ptr(self.win), L.ptr(self.state[3:]), L.stream()), "cone window")
-        self.g_tgt_full.zero_(); self.g_ref_full.zero_()
+        if not self.placed:                    # (a patch-coordinate step crops from the window gradients: no canvases)
+            self.g_tgt_full.zero_(); self.g_ref_full.zero_()
         if self.band is not None and self.band.width:   # band start: 32-pixel aligned, `reach` left of the window, inside the frame
             start = torch.div(self.win[:, 1] - self._band_reach, 32, rounding_mode="floor") * 32
             self.band.win[:, 1] = start.clamp(0, self.W - self.band.width)
@@ -360,6 +362,8 @@ class PatchAttackStep:
             gxw, = torch.autograd.grad(self._feats_w, (self.xw,), [t[4] for t in self.taps])
         self._feats_w = None
         gxw = gxw.contiguous()
+        if self.placed:                        # the crop reads the window gradients directly (no canvas scatter, no canvas fill)
+            return gxw, None
         self._win_copy(lib.ufr_window_scatter, gxw, self.g_tgt_full, B, 3, H, W, 1, 0)
         self._win_copy(lib.ufr_window_scatter, gxw[B:], self.g_ref_full, B, 3, H, W, 1, 0)
         return self.g_tgt_full, self.g_ref_full
@@ -402,7 +406,13 @@ class PatchAttackStep:
             self._update(g_tgt, g_ref)
             self._gate()
             return
-        self._crop(g_tgt, g_ref)
+        if g_ref is None:                      # windowed prefix: crop from the window gradients [2B,3,wh,ww]
+            wh, ww = self.win_hw
+            L.check(L.lib().ufr_patch_grad_crop_window(L.ptr(g_tgt), L.ptr(self.win), L.ptr(self.mask_p), L.ptr(self.origins),
+                                                       L.ptr(self.loss_local), L.ptr(self.rows_local), self.B, self.H, self.W, wh, ww,
+                                                       self.ph, self.pw, self.groups, L.stream()), "patch grad crop (window)")
+        else:
+            self._crop(g_tgt, g_ref)
         if self.world == 1:
             self._apply()
             self._gate()
