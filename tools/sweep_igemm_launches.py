@@ -38,7 +38,7 @@ def timed(fn, iters=30):
 def sweep(label, wi, x, in_chunk0, rows, out_hw, kw, M, gflop, chosen):
     kw = dict(kw)
     kw.pop("variant", None)
-    variants = (6, 5, 4, 2) if wi.Npad % 128 == 0 else (2,)
+    variants = (6, 5, 4, 2) if wi.Npad % 128 == 0 else (2, 7)      # 7 on 64 columns = the 256 x 64 tap-reuse ping-pong
     res = []
     for v in variants:
         for S in (1, 2, 4, 8, 16):
@@ -99,7 +99,8 @@ def main():
     for name, kind, tag, launch, gflop in eng.launch_table():
         s2 = kind == "bwd" and name in ("conv4", "conv5", "conv6")
         small = name in ("conv5_1", "conv6", "conv6_1", "deconv5", "conv5") and tag == "full"
-        if not (("s2bwd" in which and s2) or ("small" in which and small and not s2)) or tag in ("prefix", "window"):
+        n64 = "n64" in which and name in ("deconv2", "conv_redir") and kind == "fwd"
+        if not (("s2bwd" in which and s2) or ("small" in which and small and not s2) or n64) or tag in ("prefix", "window"):
             continue
         if not hasattr(eng, "replan"):
             break
