@@ -440,3 +440,37 @@ def test_headline_configuration_vs_cpu_oracle(net, sd, oracle, seed, case):
     err = float((step.patch.cpu() - cpu_patch).abs().max())
     assert 0.3 < upd < 1.9
     assert err <= REL * max(upd, 1.0), f"headline configuration: patch err {err:.3e}, update {upd:.3e}"
+
+
+@pytest.mark.parametrize("B,H,W,P,origins", [(1, 256, 256, 51, [(100, 90)]),                       # the reference's training crop size
+                                              (3, 128, 448, 25, [(0, 0), (103, 423), (50, 200)]),  # three pairs, corners + interior
+                                              (2, 320, 192, 33, [(280, 10), (7, 150)])])           # taller than wide
+def test_attack_at_other_frame_sizes_vs_cpu_oracle(net, sd, oracle, B, H, W, P, origins):
+    """The fused step at frame sizes other than the benchmark's (windowed prefix, band or no band as the width allows, conv1 from
+    the raw frames, rectangle re-paste, window crop): two iterations behind one PxP patch against the CPU oracle's
+    `patch_attack_placed`, 1e-4 of the update."""
+    from oracle import flow_oracle as fo
+    from understanding_flow_robustness_amd.patch_attack import PatchAttackStep
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    g = torch.Generator().manual_seed(H + W)
+    tgt, ref = torch.rand(B, 3, H, W, generator=g), torch.rand(B, 3, H, W, generator=g)
+    yy, xx = torch.meshgrid(torch.arange(P), torch.arange(P), indexing="ij")
+    mask_p = (((yy - P // 2) ** 2 + (xx - P // 2) ** 2) <= (P // 2 - 2) ** 2).float().expand(1, 3, P, P).contiguous()
+    patch0 = torch.rand(1, 3, P, P, generator=g)
+    predict = lambda a, b: fo.flownetc_forward(sd, a, b)
+    with torch.no_grad():
+        target = -torch.cat([predict(tgt[i:i + 1], ref[i:i + 1]) for i in range(B)])
+    probe, trace = patch0.clone(), []
+    fo.patch_attack_placed(predict, tgt, ref, probe, mask_p, origins, target, lr=1.0, max_count=1, trace=trace)
+    lr = 0.5 / (0.5 * float(trace[0]["G"].abs().max()))
+    cpu_patch = patch0.clone()
+    fo.patch_attack_placed(predict, tgt, ref, cpu_patch, mask_p, origins, target, lr=lr, max_count=2)
+    args = Namespace(flownet="FlowNetC", l2=False, alpha=0.0, lr=lr, max_count=2)
+    step = PatchAttackStep(net, args, B, H, W, device=DEV, patch_hw=(P, P))
+    step.load(tgt.to(DEV), ref.to(DEV), patch0.to(DEV), mask_p.to(DEV), patch0.to(DEV), target.to(DEV), origins=origins)
+    n, _ = step.run(2)
+    upd = float((cpu_patch - patch0).abs().max())
+    err = float((step.patch.cpu() - cpu_patch).abs().max())
+    print(f"{B} x {H}x{W}, patch {P}: cone {step.cone is not None}, window {step.win_hw}, update {upd:.3e}, step vs oracle {err / upd:.2e}")
+    assert n == 2 and step.graph is not None and 0.2 < upd < 1.9
+    assert err <= REL * max(upd, 1.0), f"{B} x {H}x{W}: patch err {err:.3e}, update {upd:.3e}"
