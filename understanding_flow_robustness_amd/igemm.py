@@ -8,6 +8,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -37,7 +39,8 @@ class Planes:
         self.B, self.H, self.W, self.chunks = int(B), int(H), int(W), int(chunks)
         self.M = self.B * self.H * self.W
         self.t = torch.zeros(3, self.chunks, self.M, 32, dtype=torch.bfloat16, device=device)
-        self.plane_stride = self.chunks * self.M * 32
+        self.plane_stride = self.chunks * self.M * 32       # (padding the planes apart -- 4 KB and 1 MB tried -- changes nothing:
+                                                            #  5.460 / 5.465 / 5.462 ms in one call, gpurun r4_call36)
 
     def load_nchw(self, x: torch.Tensor, chunk0: int = 0, scale: float = 1.0, slope: float = 1.0, bias: torch.Tensor | None = None):
         """planes[chunk0 + c/32] = split(leaky(scale * x + bias[c])); x [B,C,H,W] float32 contiguous."""
@@ -322,7 +325,7 @@ def make_launch(wi: WeightImage, x: Planes, in_chunk0: int, rows_hw, out_hw, *, 
     d.in_sy = d.in_sx = int(wi.geometry["in_s"])
     if in_band is not None:
         d.in_x0, d.in_x0_stride, d.in_x0_div, d.in_xw = in_band[0].data_ptr(), int(in_band[1]), int(in_band[2]), int(in_band[3])
-    d.w, d.w_plane_stride, d.Npad, d.N = wi.planes.data_ptr(), wi.planes.shape[1], wi.Npad, wi.N
+    d.w, d.w_plane_stride, d.Npad, d.N = wi.planes.data_ptr(), wi.planes.stride(0), wi.Npad, wi.N
     d.Hr, d.Wr = int(rows_hw[0]), int(rows_hw[1])
     if row_band is not None:
         d.row_x0, d.row_x0_stride, d.row_x0_div = row_band[0].data_ptr(), int(row_band[1]), int(row_band[2])
