@@ -345,7 +345,15 @@ def test_leaving_the_engines_is_reported_and_release_restores_the_callers_flags(
     patch = torch.rand(1, 3, 64, 128, device=DEV) * mask
     with torch.no_grad():
         target = -net(x, x)
+    counted = dict(L.VENDOR_FALLBACKS)
     attack(net, x, None, x, patch.clone(), mask, patch, target, None, args=args)
     assert not any(p.requires_grad for p in net.parameters()) and len(net.__dict__[_STEP_CACHE_ATTR]) == 1
+    big = torch.rand(1, 3, 256, 384, device=DEV)           # large enough for the windowed prefix: its toy-frame shape probe
+    mask_b = torch.zeros(1, 3, 256, 384, device=DEV)       # (_setup_cone) is not a fallback of the workload and is not reported
+    mask_b[:, :, 100:150, 200:250] = 1
+    with torch.no_grad():
+        target_b = -net(big, big)
+    attack(net, big, None, big, torch.rand_like(big) * mask_b, mask_b, torch.rand_like(big) * mask_b, target_b, None, args=args)
+    assert L.VENDOR_FALLBACKS == counted, "the attack itself left the engines (or its shape probe was counted)"
     release(net)
     assert all(p.requires_grad for p in net.parameters()) and len(net.__dict__[_STEP_CACHE_ATTR]) == 0

@@ -246,7 +246,7 @@ class PatchAttackStep:
             self.eng.flow_out.requires_grad_(True)
             self._wp_hold = self.eng.window_prefix(wh, ww)     # the captured graphs point into this state: keep it alive
         self.taps = []                         # (level stride, margin, frames, full leaf, window gradient)
-        with torch.no_grad():
+        with torch.no_grad(), L.shape_probe():
             feats = self.net.encode(torch.zeros(2, 3, spec.total_stride * 2, spec.total_stride * 2, **f32))
         for t, m, fr, f in zip(spec.taps, spec.tap_margins(), spec.frames, feats):
             ls = spec.level_stride(t)
