@@ -502,9 +502,10 @@ typedef struct {
                                                   (models/raft/corr.py:57-64) is a 1x1 launch whose "weights" are fmap2's planes; N % 8 == 0 */
 } ufr_igemm_desc;
 int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream);
-/* Measurement aid (tools/measure_clock.py): with a device buffer of 4 x capacity_workgroups uint64 set, every workgroup of the
- * ping-pong kernel (variant 6) records {s_memtime at entry, at exit, s_memrealtime at entry, at exit}: core cycles against the
- * constant 100 MHz counter = the clock the kernel really ran at.  (NULL, 0) switches it off (the default; synchronous call). */
+/* Measurement aid (tools/measure_clock.py): with a device buffer of 8 x capacity_workgroups uint64 set, every workgroup of the
+ * ping-pong kernel (variant 6) records {s_memtime at entry, at exit, s_memrealtime at entry, at exit, s_memtime before and after
+ * the K loop, HW_ID, K steps}: core cycles against the constant 100 MHz counter = the clock the kernel really ran at, and the
+ * split of a workgroup's life into set-up / K loop / epilogue.  (NULL, 0) switches it off (the default; synchronous call). */
 int ufr_igemm_clock_probe(unsigned long long* buf, int capacity_workgroups);
 /* Layout passes at the engine's edges.  ufr_nchw_to_planes: planes[chunk0 + c/32] = split(leaky(scale * x[B,C,H,W]))
  * (scale = 1, slope = 1: a plain conversion).  ufr_chunks_to_nchw: out[B,C,H,W] = scale * leaky'(mask) * v, v from planes

@@ -73,7 +73,7 @@ class Sampler(threading.Thread):
 def probe_launch(launch, seconds):
     d = launch.desc
     n_wg = (d.Npad // 128) * ((d.B * d.Hr * d.Wr + 255) // 256) * 64      # upper bound on z (phases x split-K slices)
-    buf = torch.zeros(n_wg, 4, dtype=torch.int64, device=DEV)
+    buf = torch.zeros(n_wg, 8, dtype=torch.int64, device=DEV)
     for _ in range(3):
         launch()
     torch.cuda.synchronize()
@@ -111,8 +111,15 @@ def probe_launch(launch, seconds):
         cyc, real = (t[:, 1] - t[:, 0]).double(), (t[:, 3] - t[:, 2]).double()
         f = (cyc / real * 100.0).sort().values                  # s_memrealtime ticks at 100 MHz
         q = lambda p: round(float(f[min(len(f) - 1, int(p * len(f)))]), 1)
+        med = lambda v: int(v.double().median())
+        t0 = int(t[:, 2].min())
+        starts = ((t[:, 2] - t0).double() / 100.0).sort().values          # us after the launch's first workgroup
         return dict(workgroups=len(f), median=q(0.5), p05=q(0.05), p95=q(0.95),
-                    wg_cycles_median=int(cyc.median()), wg_us_median=round(float(real.median()) / 100.0, 2))
+                    wg_cycles_median=int(cyc.median()), wg_us_median=round(float(real.median()) / 100.0, 2),
+                    k_steps=med(t[:, 7]), setup_cycles=med(t[:, 4] - t[:, 0]), loop_cycles=med(t[:, 5] - t[:, 4]),
+                    epilogue_cycles=med(t[:, 1] - t[:, 5]), epilogue_p05_p95=[int((t[:, 1] - t[:, 5]).double().quantile(p)) for p in (0.05, 0.95)],
+                    launch_span_us=round(float((t[:, 3].max() - t0)) / 100.0, 1),
+                    start_us_quantiles=[round(float(starts[min(len(starts) - 1, int(p * len(starts)))]), 1) for p in (0.25, 0.5, 0.6, 0.75, 0.95)])
     return dict(reps=reps, ms_single=round(one, 4), ms_sustained=round(sustained_ms, 4), clock_hot=mhz(hot), clock_cold=mhz(cold),
                 smi_sclk_samples=sampler.samples[:40])
 

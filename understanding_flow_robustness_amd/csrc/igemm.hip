@@ -214,51 +214,44 @@ struct Args {
   Phase ph[4];
 };
 
-// Accumulators -> memory: split-K slabs, or the fused epilogue through an LDS transpose (a lane owns 8 consecutive
-// channels of one pixel: 16-byte plane / fp32 stores; row stride 68 floats is conflict-free both ways).
+// Accumulators -> memory, straight from the registers.  The kernels multiply with the operands SWAPPED (weights as the MFMA's A,
+// pixels as its B), so the 16x16 result tile is transposed: lane (p = lane & 15, q = lane >> 4) holds pixel p of the m tile and
+// LDS weight rows 4 q .. 4 q + 3 of the n tile.  The weight rows are staged PERMUTED inside every group of 32 (`weight_row`:
+// LDS row 16 h + 4 q + j holds output channel 8 q + 4 h + j), so the lane's two n tiles of a group are 8 CONSECUTIVE channels of
+// its pixel: one 16-byte store per plane (a wave instruction writes 16 pixels x 64 B = 1 KB contiguous), 16-byte slab stores,
+// no LDS transpose, no barrier, and the workgroup is gone while its stores drain.  (The transposing form it replaces -- two
+// passes of 32 ds_writes + 8 ds_reads between four workgroup barriers, each waiting for the previous pass's stores -- cost 31 k
+// cycles per 256 x 128 tile against 3.8 k for the slab writer: profiles/r4_igemm_tile_anatomy.txt.)
+__device__ __forceinline__ int weight_row(int lds_row) {          // source weight row (output channel) of LDS weight row `lds_row`
+  return (lds_row & ~31) | (((lds_row >> 2) & 3) << 3) | (((lds_row >> 4) & 1) << 2) | (lds_row & 3);
+}
+
 template <int NPL, int MT>
-__device__ __forceinline__ void igemm_write_out(const Args& a, const Phase& ph, f32x4 (&acc)[MT][4], float* lds_f32, int z, int bm,
-                                                int bn, int wrow, int wcol, int lane, int wave) {
-  // C/D layout of the 16x16 forms: col = lane & 15, row = (lane >> 4) * 4 + reg
+__device__ __forceinline__ void igemm_write_out(const Args& a, const Phase& ph, f32x4 (&acc)[MT][4], int z, int bm, int bn, int wrow,
+                                                int wcol, int lane) {
+  const int p = lane & 15, q = lane >> 4;
   if (a.splitk > 1) {
-    float* slab = a.ws + (long)z * a.g.M * a.Npad;
+    float* slab = a.ws + (long)z * a.g.M * a.Npad + bn + wcol + q * 8;
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT; ++m) {
+      const int row = bm + wrow + m * 16 + p;
+      if (row < a.g.M) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = bm + wrow + m * 16 + (lane >> 4) * 4 + j;
-        if (row < a.g.M) {
-#pragma unroll
-          for (int n = 0; n < 4; ++n) slab[(long)row * a.Npad + bn + wcol + n * 16 + (lane & 15)] = acc[m][n][j];
-        }
+        for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x4*>(slab + (long)row * a.Npad + (n >> 1) * 32 + (n & 1) * 4) = acc[m][n];
       }
+    }
     return;
   }
-  {
-    // transpose each wave's 32 x 64 accumulator slabs through LDS so that a lane owns 8 consecutive channels of one
-    // pixel: 16-byte plane / fp32 stores instead of 2-byte ones (row stride 68 floats: conflict-free both ways)
-    constexpr int TS = 68;
-    float* tw = lds_f32 + wave * (32 * TS);
 #pragma unroll
-    for (int pass = 0; pass < MT / 2; ++pass) {
-      __syncthreads();                                   // the K loop's (or the previous pass's) LDS reads are done
+  for (int m = 0; m < MT; ++m) {
+    const int row = bm + wrow + m * 16 + p;
+    if (row < a.g.M) {
+      const long pout = out_pixel(a.g, row, ph.oy0, ph.ox0);
 #pragma unroll
-      for (int mm = 0; mm < 2; ++mm)
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            tw[(mm * 16 + (lane >> 4) * 4 + j) * TS + n * 16 + (lane & 15)] = acc[pass * 2 + mm][n][j];
-      __syncthreads();
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int item = it * 64 + lane, r = item >> 3, g8 = item & 7;
-        const int row = bm + wrow + pass * 32 + r;
-        if (row < a.g.M) {
-          const float4 lo = *reinterpret_cast<const float4*>(tw + r * TS + g8 * 8), hi = *reinterpret_cast<const float4*>(tw + r * TS + g8 * 8 + 4);
-          float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-          epilogue_store8(a.e, out_pixel(a.g, row, ph.oy0, ph.ox0), bn + wcol + g8 * 8, v);
-        }
+      for (int g = 0; g < 2; ++g) {
+        float v[8] = {acc[m][2 * g][0], acc[m][2 * g][1], acc[m][2 * g][2], acc[m][2 * g][3],
+                      acc[m][2 * g + 1][0], acc[m][2 * g + 1][1], acc[m][2 * g + 1][2], acc[m][2 * g + 1][3]};
+        epilogue_store8(a.e, pout, bn + wcol + g * 32 + q * 8, v);
       }
     }
   }
@@ -342,7 +335,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE_ ? 2 :
   const __bf16* gx = a.x + (long)a.in_chunk0 * cstride + csw * 8;
   const __bf16* zero = reinterpret_cast<const __bf16*>(ufr_zero_page);
   int tap = a.korder ? kt0 % ph.ntaps : kt0 / KC, kc = a.korder ? kt0 / ph.ntaps : kt0 - tap * KC;
-  const __bf16* wp = a.w + ph.w_off + ((long)kt0 * a.Npad + bn + srow0) * BK + csw * 8;
+  const __bf16* wp = a.w + ph.w_off + ((long)kt0 * a.Npad + bn + weight_row(srow0)) * BK + csw * 8;   // (LDS row srow0 + 64 i: row + 64 i)
   const long wstep = (long)a.Npad * BK;
   const __bf16* xk = gx + (long)kc * cstride;
   bool ok[APT];
@@ -452,7 +445,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE_ ? 2 :
         for (int t = FIRST; t < 6; ++t)
 #pragma unroll
           for (int m = 0; m < MT; ++m)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[t]][m], fb[n][PROD_B[t]], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[n][PROD_B[t]], fa[PROD_A[t]][m], acc[m][n], 0, 0, 0);
     }
   } else
   for (int kt = kt0; kt < kt1; ++kt) {
@@ -474,11 +467,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE_ ? 2 :
       for (int t = FIRST; t < 6; ++t)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[t]][m], fb[PROD_B[t]], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[PROD_B[t]], fa[PROD_A[t]][m], acc[m][n], 0, 0, 0);
     }
   }
-  static_assert(4 * 32 * 68 * 4 <= STAGE * 2, "epilogue staging does not fit");
-  igemm_write_out<NPL, MT>(a, ph, acc, reinterpret_cast<float*>(lds_all), z, bm, bn, wrow, wcol, lane, wave);
+  igemm_write_out<NPL, MT>(a, ph, acc, z, bm, bn, wrow, wcol, lane);
 }
 constexpr int PIPE_LDS_BYTES = (3 * (128 + 128) * BK + 3 * 128 * BK) * 2;     // one stage + the second activation image
 
@@ -551,7 +543,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const __bf16* gx = a.x + (long)a.in_chunk0 * cstride + csw * 8;
   const __bf16* zero = reinterpret_cast<const __bf16*>(ufr_zero_page);
   int tap = a.korder ? kt0 % ph.ntaps : kt0 / KC, kc = a.korder ? kt0 / ph.ntaps : kt0 - tap * KC;
-  const __bf16* wp = a.w + ph.w_off + ((long)kt0 * a.Npad + bn + srow0) * BK + csw * 8;
+  const __bf16* wp = a.w + ph.w_off + ((long)kt0 * a.Npad + bn + weight_row(srow0)) * BK + csw * 8;   // (LDS row srow0 + 64 i: row + 64 i)
   const long wstep = (long)a.Npad * BK;
   const __bf16* xk = gx + (long)kc * cstride;
   bool ok[2];
@@ -630,6 +622,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
+  const unsigned long long probe_c2 = probe ? __builtin_amdgcn_s_memtime() : 0;
   for (int i = 0; i < nk; ++i) {
     const int cur = i & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // my DMAs of the previous READ have landed ...
@@ -660,16 +653,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int t = 0; t < 6; ++t)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[t]][m], fb[n][PROD_B[t]], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[n][PROD_B[t]], fa[PROD_A[t]][m], acc[m][n], 0, 0, 0);
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();                             // group 1's extra barrier at the start
-  static_assert(4 * 32 * 68 * 4 <= 2 * PP_IMG * 2, "epilogue staging does not fit a group's activation images");
-  igemm_write_out<NPL, MT>(a, ph, acc, reinterpret_cast<float*>(lds_pp + imgA0), z, bm, bn, wrow, wcol, lane, wave);
+  const unsigned long long probe_c3 = probe ? __builtin_amdgcn_s_memtime() : 0;
+  igemm_write_out<NPL, MT>(a, ph, acc, z, bm, bn, wrow, wcol, lane);
   if (probe && threadIdx.x == 0) {
     const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    if (wg < ufr_clock_probe_cap) {
-      unsigned long long* o = probe + 4L * wg;
-      o[0] = probe_c0; o[1] = __builtin_amdgcn_s_memtime(); o[2] = probe_r0; o[3] = __builtin_amdgcn_s_memrealtime();
+    if (wg < ufr_clock_probe_cap) {                                       // 8 words per workgroup: cycles at entry / exit, 100 MHz
+      unsigned long long* o = probe + 8L * wg;                            // ticks at entry / exit, cycles at the K loop's two ends,
+      o[0] = probe_c0; o[1] = __builtin_amdgcn_s_memtime(); o[2] = probe_r0; o[3] = __builtin_amdgcn_s_memrealtime();   // HW_ID, K steps
+      o[4] = probe_c2; o[5] = probe_c3; o[6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); o[7] = (unsigned long long)nk;
     }
   }
 }
@@ -745,7 +739,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const __bf16* gx = a.x + (long)a.in_chunk0 * cstride + csw * 8;
   const __bf16* gxx = a.x + (long)a.in_chunk0 * cstride + cswx * 8;
   const __bf16* zero = reinterpret_cast<const __bf16*>(ufr_zero_page);
-  const __bf16* wp = a.w + ph.w_off + ((long)kt0 * a.Npad + bn + srow0) * BK + csw * 8;
+  const __bf16* wp = a.w + ph.w_off + ((long)kt0 * a.Npad + bn + weight_row(srow0)) * BK + csw * 8;   // (LDS row srow0 + 64 i: row + 64 i)
   const long wstep = (long)a.Npad * BK;
 
   const int imgA0 = grp * 2 * PP3_IMG, imgB0 = 4 * PP3_IMG;
@@ -850,15 +844,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int t = 0; t < 6; ++t)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[t]][m], fb[n][PROD_B[t]], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[n][PROD_B[t]], fa[PROD_A[t]][m], acc[m][n], 0, 0, 0);
     // advance (kc, tap); a new run flips the image
     first_of_run = pos == len - 1;
     if (first_of_run) ebuf ^= 1;
     if (++tap == ntaps) { tap = 0; ++kc; }
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
-  static_assert(4 * 32 * 68 * 4 <= 2 * PP3_IMG * 2, "epilogue staging does not fit a group's activation images");
-  igemm_write_out<NPL, MT>(a, ph, acc, reinterpret_cast<float*>(lds_pp + imgA0), z, bm, bn, wrow, wcol, lane, wave);
+  igemm_write_out<NPL, MT>(a, ph, acc, z, bm, bn, wrow, wcol, lane);
 }
 
 // Second stage of split-K: thread = (phase, row, 8 channels); the slabs are added in ascending order.
