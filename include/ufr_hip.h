@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define UFR_ABI_VERSION 5   /* 5: ufr_igemm_desc gained out_rowmajor / out_ld; ufr_igemm_clock_probe, ufr_conv1_direct, ufr_patch_paste_placed_rect (round 4); 4: ufr_igemm_desc gained tail / tail_n0 (round 3); 3: k_order (round 2) */
+#define UFR_ABI_VERSION 6   /* 6: ufr_igemm_desc gained planes_chunks / f32_first_chunk; the clock probe records 8 words (round 4); 5: ufr_igemm_desc gained out_rowmajor / out_ld; ufr_igemm_clock_probe, ufr_conv1_direct, ufr_patch_paste_placed_rect (round 4); 4: ufr_igemm_desc gained tail / tail_n0 (round 3); 3: k_order (round 2) */
 
 enum { UFR_F32 = 0, UFR_F64 = 1, UFR_F16 = 2 };   /* UFR_F16: the spatial correlation only (generic kernels, float32 sums) */
 enum {
@@ -500,6 +500,10 @@ typedef struct {
   float* out_rowmajor; long out_ld;            /* optional (ABI 5): the epilogue's result also / instead as ROW-MAJOR fp32 [B*Ho*Wo][out_ld],
                                                   element (pixel, n) -- RAFT's all-pairs volume corr[p][q] = <fmap1[p], fmap2[q]>
                                                   (models/raft/corr.py:57-64) is a 1x1 launch whose "weights" are fmap2's planes; N % 8 == 0 */
+  int planes_chunks, f32_first_chunk;          /* (ABI 6) with BOTH out_planes and out_f32: only output chunks < planes_chunks reach the planes
+                                                  (0 = all) and only chunks >= f32_first_chunk the fp32 tensor -- conv3_1's data gradient feeds
+                                                  conv_redir's (planes, chunk 0) and the correlation's adjoint (fp32, chunks 1 ..): 4.4 instead
+                                                  of 10 bytes per element leave the tile, and an epilogue is a chip-wide write burst */
 } ufr_igemm_desc;
 int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream);
 /* Measurement aid (tools/measure_clock.py): with a device buffer of 8 x capacity_workgroups uint64 set, every workgroup of the

@@ -12,9 +12,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libufr_hip.so")
+LIB_PATH = os.environ.get("UFR_HIP_LIB") or os.path.join(_HERE, "lib", "libufr_hip.so")   # UFR_HIP_LIB: another BUILD of the same library (same-box A/B of two kernels)
 UFR_F32, UFR_F64, UFR_F16 = 0, 1, 2
-ABI_VERSION = 5            # UFR_ABI_VERSION of include/ufr_hip.h these ctypes mirrors were written against
+ABI_VERSION = 6            # UFR_ABI_VERSION of include/ufr_hip.h these ctypes mirrors were written against
 _lib = None
 
 
@@ -71,7 +71,8 @@ class IgemmDesc(C.Structure):
                 ("tail", C.c_void_p), ("tail_n0", C.c_int), ("tail_accumulate", C.c_int),
                 ("splitk", C.c_int), ("ws", C.c_void_p),
                 ("products", C.c_int), ("variant", C.c_int), ("k_order", C.c_int),
-                ("out_rowmajor", C.c_void_p), ("out_ld", C.c_long)]
+                ("out_rowmajor", C.c_void_p), ("out_ld", C.c_long),
+                ("planes_chunks", C.c_int), ("f32_first_chunk", C.c_int)]
 
 
 UFR_MAX_CONE_LAYERS = 8

@@ -61,6 +61,7 @@ struct Epilogue {
   const __bf16* mask; int mask_chunk0;
   __bf16* out_planes; long out_plane_stride; int out_chunk0;
   float* out_f32; int out_f32_chunk0;
+  int planes_chunks, f32_first_chunk; // planes: output chunks < planes_chunks only; fp32: chunks >= f32_first_chunk only
   float* out_rm; long out_ld;         // optional ROW-MAJOR fp32 output [Mout][out_ld] (RAFT's all-pairs volume: a row = one pixel's N sums)
   float* tail; int tail_n0, tail_acc; // columns >= tail_n0 (a multiple of 32): raw sums to (tail_acc: added onto) this fp32 chunk-major tensor
   long Mout; int N, Nchunks32;        // channels < Nchunks32*32 are written (zeros beyond N: the chunk's padding)
@@ -84,8 +85,8 @@ __device__ __forceinline__ void epilogue_store(const Epilogue& e, long pout, int
   }
   if (n >= e.N) v = 0.f;
   if (e.out_rm && n < e.N) e.out_rm[pout * e.out_ld + n] = v;
-  if (e.out_f32) e.out_f32[(long)e.out_f32_chunk0 * e.Mout * 32 + cm] = v;
-  if (e.out_planes) {
+  if (e.out_f32 && (n >> 5) >= e.f32_first_chunk) e.out_f32[(long)e.out_f32_chunk0 * e.Mout * 32 + cm] = v;
+  if (e.out_planes && (n >> 5) < e.planes_chunks) {
     __bf16 a, b, c;
     split3(v, a, b, c);
     __bf16* o = e.out_planes + (long)e.out_chunk0 * e.Mout * 32 + cm;
@@ -150,12 +151,12 @@ __device__ __forceinline__ void epilogue_store8(const Epilogue& e, long pout, in
     *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
   }
-  if (e.out_f32) {
+  if (e.out_f32 && (n0 >> 5) >= e.f32_first_chunk) {
     float* op = e.out_f32 + (long)e.out_f32_chunk0 * e.Mout * 32 + cm;
     *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
   }
-  if (e.out_planes) {
+  if (e.out_planes && (n0 >> 5) < e.planes_chunks) {
     bf16x8 q0, q1, q2;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -214,44 +215,51 @@ struct Args {
   Phase ph[4];
 };
 
-// Accumulators -> memory, straight from the registers.  The kernels multiply with the operands SWAPPED (weights as the MFMA's A,
-// pixels as its B), so the 16x16 result tile is transposed: lane (p = lane & 15, q = lane >> 4) holds pixel p of the m tile and
-// LDS weight rows 4 q .. 4 q + 3 of the n tile.  The weight rows are staged PERMUTED inside every group of 32 (`weight_row`:
-// LDS row 16 h + 4 q + j holds output channel 8 q + 4 h + j), so the lane's two n tiles of a group are 8 CONSECUTIVE channels of
-// its pixel: one 16-byte store per plane (a wave instruction writes 16 pixels x 64 B = 1 KB contiguous), 16-byte slab stores,
-// no LDS transpose, no barrier, and the workgroup is gone while its stores drain.  (The transposing form it replaces -- two
-// passes of 32 ds_writes + 8 ds_reads between four workgroup barriers, each waiting for the previous pass's stores -- cost 31 k
-// cycles per 256 x 128 tile against 3.8 k for the slab writer: profiles/r4_igemm_tile_anatomy.txt.)
-__device__ __forceinline__ int weight_row(int lds_row) {          // source weight row (output channel) of LDS weight row `lds_row`
-  return (lds_row & ~31) | (((lds_row >> 2) & 3) << 3) | (((lds_row >> 4) & 1) << 2) | (lds_row & 3);
-}
-
+// Accumulators -> memory: split-K slabs, or the fused epilogue through an LDS transpose (a lane owns 8 consecutive
+// channels of one pixel: 16-byte plane / fp32 stores; row stride 68 floats is conflict-free both ways).
 template <int NPL, int MT>
-__device__ __forceinline__ void igemm_write_out(const Args& a, const Phase& ph, f32x4 (&acc)[MT][4], int z, int bm, int bn, int wrow,
-                                                int wcol, int lane) {
-  const int p = lane & 15, q = lane >> 4;
+__device__ __forceinline__ void igemm_write_out(const Args& a, const Phase& ph, f32x4 (&acc)[MT][4], float* lds_f32, int z, int bm,
+                                                int bn, int wrow, int wcol, int lane, int wave) {
+  // C/D layout of the 16x16 forms: col = lane & 15, row = (lane >> 4) * 4 + reg
   if (a.splitk > 1) {
-    float* slab = a.ws + (long)z * a.g.M * a.Npad + bn + wcol + q * 8;
+    float* slab = a.ws + (long)z * a.g.M * a.Npad;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int row = bm + wrow + m * 16 + p;
-      if (row < a.g.M) {
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x4*>(slab + (long)row * a.Npad + (n >> 1) * 32 + (n & 1) * 4) = acc[m][n];
+      for (int j = 0; j < 4; ++j) {
+        const int row = bm + wrow + m * 16 + (lane >> 4) * 4 + j;
+        if (row < a.g.M) {
+#pragma unroll
+          for (int n = 0; n < 4; ++n) slab[(long)row * a.Npad + bn + wcol + n * 16 + (lane & 15)] = acc[m][n][j];
+        }
       }
-    }
     return;
   }
+  {
+    // transpose each wave's 32 x 64 accumulator slabs through LDS so that a lane owns 8 consecutive channels of one
+    // pixel: 16-byte plane / fp32 stores instead of 2-byte ones (row stride 68 floats: conflict-free both ways)
+    constexpr int TS = 68;
+    float* tw = lds_f32 + wave * (32 * TS);
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int row = bm + wrow + m * 16 + p;
-    if (row < a.g.M) {
-      const long pout = out_pixel(a.g, row, ph.oy0, ph.ox0);
+    for (int pass = 0; pass < MT / 2; ++pass) {
+      __syncthreads();                                   // the K loop's (or the previous pass's) LDS reads are done
 #pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        float v[8] = {acc[m][2 * g][0], acc[m][2 * g][1], acc[m][2 * g][2], acc[m][2 * g][3],
-                      acc[m][2 * g + 1][0], acc[m][2 * g + 1][1], acc[m][2 * g + 1][2], acc[m][2 * g + 1][3]};
-        epilogue_store8(a.e, pout, bn + wcol + g * 32 + q * 8, v);
+      for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            tw[(mm * 16 + (lane >> 4) * 4 + j) * TS + n * 16 + (lane & 15)] = acc[pass * 2 + mm][n][j];
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int item = it * 64 + lane, r = item >> 3, g8 = item & 7;
+        const int row = bm + wrow + pass * 32 + r;
+        if (row < a.g.M) {
+          const float4 lo = *reinterpret_cast<const float4*>(tw + r * TS + g8 * 8), hi = *reinterpret_cast<const float4*>(tw + r * TS + g8 * 8 + 4);
+          float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          epilogue_store8(a.e, out_pixel(a.g, row, ph.oy0, ph.ox0), bn + wcol + g8 * 8, v);
+        }
       }
     }
   }
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE_ ? 2 :
   const __bf16* gx = a.x + (long)a.in_chunk0 * cstride + csw * 8;
   const __bf16* zero = reinterpret_cast<const __bf16*>(ufr_zero_page);
   int tap = a.korder ? kt0 % ph.ntaps : kt0 / KC, kc = a.korder ? kt0 / ph.ntaps : kt0 - tap * KC;
-  const __bf16* wp = a.w + ph.w_off + ((long)kt0 * a.Npad + bn + weight_row(srow0)) * BK + csw * 8;   // (LDS row srow0 + 64 i: row + 64 i)
+  const __bf16* wp = a.w + ph.w_off + ((long)kt0 * a.Npad + bn + srow0) * BK + csw * 8;
   const long wstep = (long)a.Npad * BK;
   const __bf16* xk = gx + (long)kc * cstride;
   bool ok[APT];
@@ -445,7 +453,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE_ ? 2 :
         for (int t = FIRST; t < 6; ++t)
 #pragma unroll
           for (int m = 0; m < MT; ++m)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[n][PROD_B[t]], fa[PROD_A[t]][m], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[t]][m], fb[n][PROD_B[t]], acc[m][n], 0, 0, 0);
     }
   } else
   for (int kt = kt0; kt < kt1; ++kt) {
@@ -467,10 +475,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE_ ? 2 :
       for (int t = FIRST; t < 6; ++t)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[PROD_B[t]], fa[PROD_A[t]][m], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[t]][m], fb[PROD_B[t]], acc[m][n], 0, 0, 0);
     }
   }
-  igemm_write_out<NPL, MT>(a, ph, acc, z, bm, bn, wrow, wcol, lane);
+  static_assert(4 * 32 * 68 * 4 <= STAGE * 2, "epilogue staging does not fit");
+  igemm_write_out<NPL, MT>(a, ph, acc, reinterpret_cast<float*>(lds_all), z, bm, bn, wrow, wcol, lane, wave);
 }
 constexpr int PIPE_LDS_BYTES = (3 * (128 + 128) * BK + 3 * 128 * BK) * 2;     // one stage + the second activation image
 
@@ -543,7 +552,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const __bf16* gx = a.x + (long)a.in_chunk0 * cstride + csw * 8;
   const __bf16* zero = reinterpret_cast<const __bf16*>(ufr_zero_page);
   int tap = a.korder ? kt0 % ph.ntaps : kt0 / KC, kc = a.korder ? kt0 / ph.ntaps : kt0 - tap * KC;
-  const __bf16* wp = a.w + ph.w_off + ((long)kt0 * a.Npad + bn + weight_row(srow0)) * BK + csw * 8;   // (LDS row srow0 + 64 i: row + 64 i)
+  const __bf16* wp = a.w + ph.w_off + ((long)kt0 * a.Npad + bn + srow0) * BK + csw * 8;
   const long wstep = (long)a.Npad * BK;
   const __bf16* xk = gx + (long)kc * cstride;
   bool ok[2];
@@ -653,11 +662,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int t = 0; t < 6; ++t)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[n][PROD_B[t]], fa[PROD_A[t]][m], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[t]][m], fb[n][PROD_B[t]], acc[m][n], 0, 0, 0);
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();                             // group 1's extra barrier at the start
   const unsigned long long probe_c3 = probe ? __builtin_amdgcn_s_memtime() : 0;
-  igemm_write_out<NPL, MT>(a, ph, acc, z, bm, bn, wrow, wcol, lane);
+  static_assert(4 * 32 * 68 * 4 <= 2 * PP_IMG * 2, "epilogue staging does not fit a group's activation images");
+  igemm_write_out<NPL, MT>(a, ph, acc, reinterpret_cast<float*>(lds_pp + imgA0), z, bm, bn, wrow, wcol, lane, wave);
   if (probe && threadIdx.x == 0) {
     const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     if (wg < ufr_clock_probe_cap) {                                       // 8 words per workgroup: cycles at entry / exit, 100 MHz
@@ -739,7 +749,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const __bf16* gx = a.x + (long)a.in_chunk0 * cstride + csw * 8;
   const __bf16* gxx = a.x + (long)a.in_chunk0 * cstride + cswx * 8;
   const __bf16* zero = reinterpret_cast<const __bf16*>(ufr_zero_page);
-  const __bf16* wp = a.w + ph.w_off + ((long)kt0 * a.Npad + bn + weight_row(srow0)) * BK + csw * 8;   // (LDS row srow0 + 64 i: row + 64 i)
+  const __bf16* wp = a.w + ph.w_off + ((long)kt0 * a.Npad + bn + srow0) * BK + csw * 8;
   const long wstep = (long)a.Npad * BK;
 
   const int imgA0 = grp * 2 * PP3_IMG, imgB0 = 4 * PP3_IMG;
@@ -844,14 +854,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int t = 0; t < 6; ++t)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[n][PROD_B[t]], fa[PROD_A[t]][m], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[t]][m], fb[n][PROD_B[t]], acc[m][n], 0, 0, 0);
     // advance (kc, tap); a new run flips the image
     first_of_run = pos == len - 1;
     if (first_of_run) ebuf ^= 1;
     if (++tap == ntaps) { tap = 0; ++kc; }
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
-  igemm_write_out<NPL, MT>(a, ph, acc, z, bm, bn, wrow, wcol, lane);
+  static_assert(4 * 32 * 68 * 4 <= 2 * PP3_IMG * 2, "epilogue staging does not fit a group's activation images");
+  igemm_write_out<NPL, MT>(a, ph, acc, reinterpret_cast<float*>(lds_pp + imgA0), z, bm, bn, wrow, wcol, lane, wave);
 }
 
 // Second stage of split-K: thread = (phase, row, 8 channels); the slabs are added in ascending order.
@@ -896,6 +907,8 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   UFR_REQUIRE(d->out_planes || d->out_f32 || d->out_rowmajor, "igemm: no output");
   UFR_REQUIRE(!d->out_rowmajor || (d->out_ld >= d->N && d->N % 8 == 0 && d->out_ld % 4 == 0), "igemm: bad row-major output");
   UFR_REQUIRE(!d->act || d->bias, "igemm: the forward epilogue needs the bias");
+  UFR_REQUIRE(d->planes_chunks >= 0 && d->f32_first_chunk >= 0 && ((d->planes_chunks == 0 && d->f32_first_chunk == 0) || (d->out_planes && d->out_f32)),
+              "igemm: planes_chunks / f32_first_chunk need both outputs");
   UFR_REQUIRE(!d->tail || (d->tail_n0 > 0 && d->tail_n0 % 32 == 0 && d->tail_n0 < d->N), "igemm: bad tail column");
   UFR_REQUIRE(!d->row_x0 || (d->row_x0_div > 0), "igemm: bad band divisor");
   UFR_REQUIRE(!d->in_x0 || (d->in_x0_div > 0 && d->in_xw > 0), "igemm: bad input band");
@@ -920,6 +933,7 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   a.e.out_planes = static_cast<__bf16*>(d->out_planes); a.e.out_plane_stride = d->out_plane_stride; a.e.out_chunk0 = d->out_chunk0;
   a.e.out_f32 = d->out_f32; a.e.out_f32_chunk0 = d->out_f32_chunk0;
   a.e.out_rm = d->out_rowmajor; a.e.out_ld = d->out_ld;
+  a.e.planes_chunks = d->planes_chunks > 0 ? d->planes_chunks : (1 << 30); a.e.f32_first_chunk = d->f32_first_chunk;
   a.e.tail = d->tail; a.e.tail_n0 = d->tail_n0; a.e.tail_acc = d->tail_accumulate;
   a.e.Mout = (long)d->B * d->Ho * d->Wo; a.e.N = d->N; a.e.Nchunks32 = (d->N + 31) / 32;
   a.nphase = d->nphase; a.splitk = d->splitk; a.ws = d->ws;

@@ -170,8 +170,10 @@ class FlowNetCHeadEngine:
         bwd["conv4_1"] = plan(cb("conv4_1", 1, 1), self.gz_cat4, 0, g[16], g[16], mask=self.c4a, out_planes=self.gz_c4a)
         bwd["conv4"] = plan(cb("conv4", 2, 1), self.gz_c4a, 0, g[16], g[8], add=self.G_cat3, mask=self.cat3, out_planes=self.gz_cat3)
         if self.siamese:
+            # its 473 columns: chunk 0 (conv_redir's output) is read as planes by conv_redir's adjoint, chunks 1 .. (the cost volume)
+            # as fp32 by the correlation's: each leaves the tile once, in the form its reader wants (4.4 instead of 10 B per element)
             bwd["conv3_1"] = plan(cb("conv3_1", 1, 1), self.gz_cat3, 0, g[8], g[8], mask=self.in31, out_planes=self.gz_in31,
-                                  out_f32=self.G_in31)
+                                  out_f32=self.G_in31, planes_chunks=1, f32_first_chunk=1)
             bwd["conv_redir"] = plan(cb("conv_redir", 1, 0), self.gz_in31, 0, g[8], g[8], out_f32=self.G_c3a)
         else:                                   # the trunk's input IS conv3's activation: its gradient leaves unmasked
             bwd["conv3_1"] = plan(cb("conv3_1", 1, 1), self.gz_cat3, 0, g[8], g[8], out_f32=self.G_in31)

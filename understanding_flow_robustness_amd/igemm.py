@@ -299,7 +299,10 @@ class Launch:
         taps = sum(d.phase[z].ntaps for z in range(d.nphase))
         out_el = rows * d.nphase * ((d.tail_n0 if d.tail else d.N) + 31) // 32 * 32
         b = pix_in * d.KC * 32 * 6 + taps * d.KC * d.Npad * 32 * 6
-        b += out_el * ((6 if d.out_planes else 0) + (4 if d.out_f32 else 0) + (4 if d.add else 0) + (2 if d.mask else 0))
+        b += out_el * ((4 if d.add else 0) + (2 if d.mask else 0))
+        nch = out_el // (rows * d.nphase * 32)                  # output chunks; planes / fp32 may each cover a part of them
+        pl = min(nch, d.planes_chunks) if d.planes_chunks else nch
+        b += rows * d.nphase * 32 * ((6 * pl if d.out_planes else 0) + (4 * (nch - min(nch, d.f32_first_chunk)) if d.out_f32 else 0))
         if d.tail:
             b += rows * (d.N - d.tail_n0) * 4
         return float(b)
@@ -310,7 +313,7 @@ def make_launch(wi: WeightImage, x: Planes, in_chunk0: int, rows_hw, out_hw, *, 
                 add: GradSum | None = None, add_chunk0: int = 0, mask: Planes | None = None, mask_chunk0: int = 0,
                 slope: float = LEAKY, splitk: int = 1, ws: torch.Tensor | None = None, row_band=None, in_band=None,
                 products: int = 6, variant: int = 0, tail: GradSum | None = None, tail_n0: int = 0, tail_chunk0: int = 0,
-                tail_accumulate: bool = False, out_rowmajor=None) -> Launch:
+                tail_accumulate: bool = False, out_rowmajor=None, planes_chunks: int = 0, f32_first_chunk: int = 0) -> Launch:
     """Descriptor for `wi` applied to the chunks [in_chunk0, in_chunk0 + KC) of `x`.
     rows_hw = (Hr, Wr) row grid; out_hw = (Ho, Wo) output grid.  row_band = (origins int32 tensor, element stride, divisor):
     tail / tail_n0: the launch's output columns >= tail_n0 are a LATER layer's partial sum over these input chunks and leave raw
@@ -373,6 +376,10 @@ def make_launch(wi: WeightImage, x: Planes, in_chunk0: int, rows_hw, out_hw, *, 
             raise RuntimeError("igemm: row-major output geometry")
         d.out_rowmajor, d.out_ld = rm.data_ptr() + 4 * int(rm_off), int(ld)
         keep.append(rm)
+    if planes_chunks or f32_first_chunk:       # with both outputs: planes for the chunks < planes_chunks, fp32 from f32_first_chunk on
+        if out_planes is None or out_f32 is None:
+            raise RuntimeError("igemm: planes_chunks / f32_first_chunk need both outputs")
+        d.planes_chunks, d.f32_first_chunk = int(planes_chunks), int(f32_first_chunk)
     d.splitk = int(splitk)
     if splitk > 1:
         need = d.nphase * splitk * x.B * d.Hr * d.Wr * wi.Npad
