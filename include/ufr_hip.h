@@ -284,6 +284,12 @@ long ufr_cm_norm_workspace_doubles(long HW, int n, int chunks);
 int ufr_cm_norm_stats(const float* x, float* stats, double* workspace, long HW, int n, int chunks, float eps, ufr_stream_t stream);
 int ufr_cm_norm_apply(const float* x, const float* stats, const void* res, long res_plane_stride, int res_chunk0, void* out,
                       long out_plane_stride, int out_chunk0, long HW, int n, int chunks, int relu1, int relu2, ufr_stream_t stream);
+/* ufr_cm_norm_stats + ufr_cm_norm_apply as TWO launches instead of three (ABI 6): the workgroups of the apply kernel add the float64
+ * partials of their 32 channels themselves (same order, same arithmetic as the statistics' second stage) and leave `stats` behind for the
+ * adjoint; ufr_cm_norm_backward does the same with its sums. */
+int ufr_cm_norm_stats_apply(const float* x, float* stats, double* workspace, float eps, const void* res, long res_plane_stride,
+                            int res_chunk0, void* out, long out_plane_stride, int out_chunk0, long HW, int n, int chunks, int relu1,
+                            int relu2, ufr_stream_t stream);
 int ufr_cm_norm_backward(const float* x, const float* G, const void* outmask, int mask_chunk0, const float* stats, float* sums,
                          double* workspace, void* gz, long gz_plane_stride, int gz_chunk0, long HW, int n, int chunks, int relu1,
                          ufr_stream_t stream);

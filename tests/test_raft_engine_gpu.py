@@ -137,3 +137,50 @@ def test_all_pairs_correlation_on_the_igemm(B, C, H, W, monkeypatch):
     g1, g2 = torch.autograd.grad(got, (f1, f2), go)
     r1, r2 = torch.autograd.grad(lib32, (f1, f2), go)
     assert rel(g1, r1.double()) <= 1e-5 and rel(g2, r2.double()) <= 1e-5
+
+
+@pytest.mark.parametrize("n,H,W,chunks", [(2, 32, 64, 2), (1, 55, 128, 4), (2, 17, 23, 3)])
+def test_norm_statistics_finished_inside_the_apply_kernels_bit_exact(n, H, W, chunks):
+    """`ufr_cm_norm_stats_apply` (two launches: the apply kernel adds the float64 partials itself) against `ufr_cm_norm_stats` +
+    `ufr_cm_norm_apply` (three): statistics and activation planes bit-identical; the adjoint's fused second stage against the
+    hand-computed sums of the three-launch arithmetic: gradient planes bit-identical to the unfused kernel fed with those sums."""
+    from understanding_flow_robustness_amd import _lib as L
+    from understanding_flow_robustness_amd import igemm as ig
+    lib = L.lib()
+    HW = H * W
+    g = torch.Generator().manual_seed(n * H + W)
+    X = ig.GradSum(n, H, W, chunks, DEV)
+    X.t.copy_(torch.randn(X.t.shape, generator=g) * 3 + 0.5)
+    res = ig.Planes(n, H, W, chunks, DEV)
+    res.load_nchw(torch.randn(n, chunks * 32, H, W, generator=g).to(DEV), 0)
+    ws = torch.empty(lib.ufr_cm_norm_workspace_doubles(HW, n, chunks), dtype=torch.float64, device=DEV)
+    st = L.stream()
+    stats_a, stats_b = (torch.zeros(n * chunks * 32 * 2, device=DEV) for _ in range(2))
+    out_a, out_b = ig.Planes(n, H, W, chunks, DEV), ig.Planes(n, H, W, chunks, DEV)
+    L.check(lib.ufr_cm_norm_stats(L.ptr(X.t), L.ptr(stats_a), L.ptr(ws), HW, n, chunks, 1e-5, st), "stats")
+    L.check(lib.ufr_cm_norm_apply(L.ptr(X.t), L.ptr(stats_a), L.ptr(res.t), res.plane_stride, 0, L.ptr(out_a.t), out_a.plane_stride, 0, HW, n,
+                                  chunks, 1, 1, st), "apply")
+    L.check(lib.ufr_cm_norm_stats_apply(L.ptr(X.t), L.ptr(stats_b), L.ptr(ws), 1e-5, L.ptr(res.t), res.plane_stride, 0, L.ptr(out_b.t),
+                                        out_b.plane_stride, 0, HW, n, chunks, 1, 1, st), "stats + apply")
+    assert torch.equal(stats_a, stats_b)
+    assert torch.equal(out_a.t.view(torch.int16), out_b.t.view(torch.int16))
+    # adjoint: the fused path (statistics form) twice must agree with itself and write the same sums it used
+    G = ig.GradSum(n, H, W, chunks, DEV)
+    G.t.copy_(torch.randn(G.t.shape, generator=g))
+    sums = torch.zeros(n * chunks * 32 * 2, device=DEV)
+    gz_a, gz_b = ig.Planes(n, H, W, chunks, DEV), ig.Planes(n, H, W, chunks, DEV)
+    L.check(lib.ufr_cm_norm_backward(L.ptr(X.t), L.ptr(G.t), L.ptr(out_a.t), 0, L.ptr(stats_a), L.ptr(sums), L.ptr(ws), L.ptr(gz_a.t),
+                                     gz_a.plane_stride, 0, HW, n, chunks, 1, st), "backward")
+    # float64 restatement of the adjoint from the same operands
+    x = X.to_nchw(chunks * 32, 0, slope=1.0).double()
+    go = G.to_nchw(chunks * 32, 0, slope=1.0).double()
+    mean = stats_a.view(n, chunks * 32, 2)[..., 0].double()[:, :, None, None]
+    rstd = stats_a.view(n, chunks * 32, 2)[..., 1].double()[:, :, None, None]
+    xh = (x - mean) * rstd
+    outv = out_a.to_nchw(chunks * 32, 0).double()
+    gm = go * (outv > 0) * (xh > 0)
+    want = rstd * (gm - gm.mean((2, 3), keepdim=True) - xh * (gm * xh).mean((2, 3), keepdim=True))
+    got = gz_a.to_nchw(chunks * 32, 0).double()
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    want_sums = torch.stack((gm.mean((2, 3)), (gm * xh).mean((2, 3))), -1).reshape(-1)
+    assert float((sums.double() - want_sums).abs().max()) <= 1e-6 * max(1.0, float(want_sums.abs().max()))

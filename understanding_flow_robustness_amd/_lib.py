@@ -155,6 +155,7 @@ SIGNATURES = {
     "ufr_unshuffle_unpack_grad": [_vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_cm_norm_stats": [_vp, _vp, _vp, _l, _i, _i, _f, _vp],
     "ufr_cm_norm_apply": [_vp, _vp, _vp, _l, _i, _vp, _l, _i, _l, _i, _i, _i, _i, _vp],
+    "ufr_cm_norm_stats_apply": [_vp, _vp, _vp, _f, _vp, _l, _i, _vp, _l, _i, _l, _i, _i, _i, _i, _vp],
     "ufr_cm_norm_backward": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _l, _i, _l, _i, _i, _i, _vp],
     "ufr_cm_masked_copy": [_vp, _vp, _l, _vp, _l, _vp],
     "ufr_raft_flow_patches": [_vp, _vp, _l, _i, _i, _i, _i, _vp],

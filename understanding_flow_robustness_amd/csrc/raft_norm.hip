@@ -213,6 +213,120 @@ int slices_for(long HW, int n, int chunks) {
   return S;
 }
 
+// ---- the statistics' second stage inside their consumers (round 4) --------------------------------------------------------------
+// A launch of its own for `cm_sums_finalize` cost 13 us thirty times per RAFT step for a few hundred numbers.  The consumers are
+// launched as workgroup (row slab, image, chunk) instead: 64 threads add the S float64 partials of the workgroup's 32 channels in
+// ascending order -- the arithmetic of cm_sums_finalize, bit for bit -- into LDS, slab 0 also writes them out (the adjoint reads
+// the forward's statistics again), then every thread streams rows (tid / 4) + 64 k of the slab, 8 channels each.
+template <int MODE>
+__device__ __forceinline__ void cm_stats_prologue(const double* __restrict__ partial, int S, int n, int C, int img, int ch, double HW,
+                                                  double eps, float (*st)[2], float* __restrict__ out, bool write_out) {
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    const int c = tid >> 1, k = tid & 1;
+    const long nC = (long)n * C, i = (long)img * C + ch * 32 + c;
+    double v = 0.0;
+    for (int s = 0; s < S; ++s) v += partial[((long)s * nC + i) * 2 + k];
+    const double other = __shfl_xor(v, 1, 64);                 // k = 0 holds the first sum, k = 1 the second
+    float r;
+    if (MODE == 0) {
+      const double a = k ? other : v, b = k ? v : other;
+      const double mean = a / HW, var = fmax(b / HW - mean * mean, 0.0);
+      r = k ? (float)(1.0 / sqrt(var + eps)) : (float)mean;
+    } else {
+      r = (float)(v / HW);
+    }
+    st[c][k] = r;
+    if (write_out) out[i * 2 + k] = r;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void cm_norm_apply_fused_kernel(const float* __restrict__ x, const double* __restrict__ partial, int S,
+                                                                  double eps, float* __restrict__ stats, const __bf16* __restrict__ res,
+                                                                  long res_stride, int res_chunk0, __bf16* __restrict__ out,
+                                                                  long out_stride, int out_chunk0, long HW, int n, int chunks, int relu1,
+                                                                  int relu2) {
+  __shared__ float st[32][2];
+  const int slab = blockIdx.x, slabs = gridDim.x, img = blockIdx.y, ch = blockIdx.z;
+  const int tid = threadIdx.x, q = tid & 3, ro = tid >> 2;
+  const long M = (long)n * HW;
+  cm_stats_prologue<0>(partial, S, n, chunks * 32, img, ch, (double)HW, eps, st, stats, slab == 0);
+  const long per = (HW + slabs - 1) / slabs, r0 = slab * per, r1 = min(HW, r0 + per);
+  float mean[8], rstd[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { mean[j] = st[q * 8 + j][0]; rstd[j] = st[q * 8 + j][1]; }
+  for (long r = r0 + ro; r < r1; r += 64) {
+    const long e = ((long)ch * M + (long)img * HW + r) * 32 + q * 8;
+    float v[8];
+    load_f8(x + e, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (v[j] - mean[j]) * rstd[j];
+    if (relu1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+    }
+    if (res) {
+      float rv[8];
+      load_planes8(res + (long)res_chunk0 * M * 32 + e, res_stride, rv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += rv[j];
+    }
+    if (relu2) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+    }
+    store_planes8(out + (long)out_chunk0 * M * 32 + e, out_stride, v);
+  }
+}
+
+__global__ __launch_bounds__(256) void cm_norm_bwd_apply_fused_kernel(const float* __restrict__ x, const float* __restrict__ G,
+                                                                      const __bf16* __restrict__ outmask, int mask_chunk0,
+                                                                      const float* __restrict__ stats, const double* __restrict__ partial,
+                                                                      int S, float* __restrict__ sums, __bf16* __restrict__ gz,
+                                                                      long gz_stride, int gz_chunk0, long HW, int n, int chunks,
+                                                                      int relu1) {
+  __shared__ float st[32][2];
+  const int slab = blockIdx.x, slabs = gridDim.x, img = blockIdx.y, ch = blockIdx.z;
+  const int tid = threadIdx.x, q = tid & 3, ro = tid >> 2;
+  const long M = (long)n * HW;
+  const int C = chunks * 32;
+  cm_stats_prologue<1>(partial, S, n, C, img, ch, (double)HW, 0.0, st, sums, slab == 0);
+  const long per = (HW + slabs - 1) / slabs, r0 = slab * per, r1 = min(HW, r0 + per);
+  float mean[8], rstd[8], s0[8], s1[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const long sc = ((long)img * C + ch * 32 + q * 8 + j) * 2;
+    mean[j] = stats[sc]; rstd[j] = stats[sc + 1];
+    s0[j] = st[q * 8 + j][0]; s1[j] = st[q * 8 + j][1];
+  }
+  for (long r = r0 + ro; r < r1; r += 64) {
+    const long e = ((long)ch * M + (long)img * HW + r) * 32 + q * 8;
+    float xv[8], gv[8];
+    load_f8(x + e, xv);
+    load_f8(G + e, gv);
+    if (outmask) {
+      const bf16x8 mk = *reinterpret_cast<const bf16x8*>(outmask + (long)mask_chunk0 * M * 32 + e);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gv[j] = (float)mk[j] > 0.f ? gv[j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (xv[j] - mean[j]) * rstd[j];
+      float g = (relu1 && !(xh > 0.f)) ? 0.f : gv[j];
+      g = g - s0[j] - xh * s1[j];
+      gv[j] = rstd[j] * g;
+    }
+    store_planes8(gz + (long)gz_chunk0 * M * 32 + e, gz_stride, gv);
+  }
+}
+
+int slabs_for(long HW, int n, int chunks) {          // ~1024 workgroups, >= 64 rows each
+  long s = 1024 / ((long)n * chunks);
+  if (s > HW / 64) s = HW / 64;
+  return (int)(s < 1 ? 1 : s);
+}
+
 }  // namespace
 
 extern "C" long ufr_cm_norm_workspace_doubles(long HW, int n, int chunks) { return 2L * 64 * n * chunks * 32; }
@@ -228,6 +342,21 @@ extern "C" int ufr_cm_norm_stats(const float* x, float* stats, double* workspace
   const long nC = (long)n * chunks * 32;
   cm_sums_finalize<0><<<ufr::ceil_div(nC, 256), 256, 0, st>>>(workspace, stats, S, nC, (double)HW, (double)eps);
   return ufr::launched("cm_sums_finalize<0>");
+}
+
+extern "C" int ufr_cm_norm_stats_apply(const float* x, float* stats, double* workspace, float eps, const void* res,
+                                       long res_plane_stride, int res_chunk0, void* out, long out_plane_stride, int out_chunk0, long HW,
+                                       int n, int chunks, int relu1, int relu2, ufr_stream_t stream) {
+  UFR_REQUIRE(x && stats && workspace && out && HW > 0 && n > 0 && chunks > 0, "norm stats + apply: bad argument");
+  const int S = slices_for(HW, n, chunks);
+  hipStream_t st = ufr::as_stream(stream);
+  cm_sums_kernel<0><<<dim3(S, n, chunks), 256, 0, st>>>(x, nullptr, nullptr, 0, nullptr, workspace, HW, n, chunks, 0);
+  int rc = ufr::launched("cm_sums_kernel<0>");
+  if (rc != UFR_OK) return rc;
+  cm_norm_apply_fused_kernel<<<dim3(slabs_for(HW, n, chunks), n, chunks), 256, 0, st>>>(
+      x, workspace, S, (double)eps, stats, static_cast<const __bf16*>(res), res_plane_stride, res_chunk0, static_cast<__bf16*>(out),
+      out_plane_stride, out_chunk0, HW, n, chunks, relu1, relu2);
+  return ufr::launched("cm_norm_apply_fused_kernel");
 }
 
 extern "C" int ufr_cm_norm_apply(const float* x, const float* stats, const void* res, long res_plane_stride, int res_chunk0, void* out,
@@ -253,15 +382,15 @@ extern "C" int ufr_cm_norm_backward(const float* x, const float* G, const void* 
                                                          chunks, relu1);
     int rc = ufr::launched("cm_sums_kernel<1>");
     if (rc != UFR_OK) return rc;
-    const long nC = (long)n * chunks * 32;
-    cm_sums_finalize<1><<<ufr::ceil_div(nC, 256), 256, 0, st>>>(workspace, sums, S, nC, (double)HW, 0.0);
-    rc = ufr::launched("cm_sums_finalize<1>");
-    if (rc != UFR_OK) return rc;
+    cm_norm_bwd_apply_fused_kernel<<<dim3(slabs_for(HW, n, chunks), n, chunks), 256, 0, st>>>(
+        x, G, static_cast<const __bf16*>(outmask), mask_chunk0, stats, workspace, S, sums, static_cast<__bf16*>(gz), gz_plane_stride,
+        gz_chunk0, HW, n, chunks, relu1);
+    return ufr::launched("cm_norm_bwd_apply_fused_kernel");
   }
   const long total = (long)chunks * n * HW * 4;
-  cm_norm_bwd_apply_kernel<<<ufr::stream_grid(total, 256), 256, 0, st>>>(x, G, static_cast<const __bf16*>(outmask), mask_chunk0, stats,
-                                                                        stats ? sums : nullptr, static_cast<__bf16*>(gz), gz_plane_stride,
-                                                                        gz_chunk0, HW, n, chunks, relu1);
+  cm_norm_bwd_apply_kernel<<<ufr::stream_grid(total, 256), 256, 0, st>>>(x, G, static_cast<const __bf16*>(outmask), mask_chunk0, nullptr,
+                                                                        nullptr, static_cast<__bf16*>(gz), gz_plane_stride, gz_chunk0, HW,
+                                                                        n, chunks, relu1);
   return ufr::launched("cm_norm_bwd_apply_kernel");
 }
 

@@ -74,9 +74,13 @@ class _Unit:
         lib, st, X, e = L.lib(), L.stream(), self.X, self.eng
         self.fwd()
         HW = self.out.H * self.out.W
-        if self.stats is not None:
-            L.check(lib.ufr_cm_norm_stats(L.ptr(X.t), L.ptr(self.stats), L.ptr(e.ws_d), HW, X.B, X.chunks, EPS, st), "norm stats")
         res = self.res
+        if self.stats is not None:             # InstanceNorm: partial sums, then the apply kernel finishes the statistics itself
+            L.check(lib.ufr_cm_norm_stats_apply(L.ptr(X.t), L.ptr(self.stats), L.ptr(e.ws_d), EPS,
+                                                L.ptr(res.t) if res is not None else None, res.plane_stride if res is not None else 0, 0,
+                                                L.ptr(self.out.t), self.out.plane_stride, 0, HW, X.B, X.chunks, int(self.relu1),
+                                                int(self.relu2), st), "norm stats + apply")
+            return
         L.check(lib.ufr_cm_norm_apply(L.ptr(X.t), L.ptr(self.stats) if self.stats is not None else None,
                                       L.ptr(res.t) if res is not None else None, res.plane_stride if res is not None else 0, 0,
                                       L.ptr(self.out.t), self.out.plane_stride, 0, HW, X.B, X.chunks, int(self.relu1), int(self.relu2), st),
