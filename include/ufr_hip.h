@@ -261,6 +261,13 @@ int ufr_raft_motion_finish(void* p1, long plane_stride1, void* p2, long plane_st
                            int W, ufr_stream_t stream);
 int ufr_gru_gates_cm_forward(float* zr, const void* h, long h_plane_stride, int h_chunk0, void* rh, long rh_plane_stride,
                              int rh_chunk0, long M, int chunks, ufr_stream_t stream);
+/* The same two kernels reading the pre-activations straight from a `no_reduce` split-K launch's slabs (columns [z | r] resp. q; the
+ * float32 pre-activation tensor is then only written -- sigmoid / tanh values for the adjoint -- never read). */
+int ufr_gru_gates_cm_forward_slabs(const float* ws, int splitk, int Npad, const float* bias, float* zr, const void* h, long h_plane_stride,
+                                   int h_chunk0, void* rh, long rh_plane_stride, int rh_chunk0, long M, int chunks, ufr_stream_t stream);
+int ufr_gru_blend_cm_forward_slabs(const float* ws, int splitk, int Npad, const float* bias, float* q, const float* z, const void* h,
+                                   long h_plane_stride, int h_chunk0, void* out, long out_plane_stride, int out_chunk0, long M, int chunks,
+                                   ufr_stream_t stream);
 int ufr_gru_blend_cm_forward(float* q, const float* z, const void* h, long h_plane_stride, int h_chunk0, void* out,
                              long out_plane_stride, int out_chunk0, long M, int chunks, ufr_stream_t stream);
 int ufr_gru_blend_cm_backward(const float* q, const float* z, const void* h, long h_plane_stride, int h_chunk0, const float* g,
@@ -510,6 +517,10 @@ typedef struct {
                                                   (0 = all) and only chunks >= f32_first_chunk the fp32 tensor -- conv3_1's data gradient feeds
                                                   conv_redir's (planes, chunk 0) and the correlation's adjoint (fp32, chunks 1 ..): 4.4 instead
                                                   of 10 bytes per element leave the tile, and an epilogue is a chip-wide write burst */
+  int no_reduce;                               /* (ABI 6) split-K launch of one phase: stop after the slab kernel; `ws` then holds the raw sums
+                                                  [splitk][B*Hr*Wr][Npad] for a consumer that adds them itself in ascending order and then
+                                                  the bias (ufr_gru_gates_cm_forward_slabs / ufr_gru_blend_cm_forward_slabs): the epilogue
+                                                  fields are not used */
 } ufr_igemm_desc;
 int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream);
 /* Measurement aid (tools/measure_clock.py): with a device buffer of 8 x capacity_workgroups uint64 set, every workgroup of the

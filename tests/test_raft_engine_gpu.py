@@ -184,3 +184,36 @@ def test_norm_statistics_finished_inside_the_apply_kernels_bit_exact(n, H, W, ch
     assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
     want_sums = torch.stack((gm.mean((2, 3)), (gm * xh).mean((2, 3))), -1).reshape(-1)
     assert float((sums.double() - want_sums).abs().max()) <= 1e-6 * max(1.0, float(want_sums.abs().max()))
+
+
+def test_gate_arithmetic_reading_the_split_k_slabs_is_bit_identical(raft, monkeypatch):
+    """The GRU's gate / candidate convolutions leave their raw split-K slabs to the gate kernels (`no_reduce`,
+    ufr_gru_gates_cm_forward_slabs / ufr_gru_blend_cm_forward_slabs): flow, mask and the context gradients must equal the
+    three-launch form (convolution, reduce, gate arithmetic) bit for bit -- same order of additions."""
+    from understanding_flow_robustness_amd.raft_engine import RaftUpdateEngine
+    net, _ = raft
+    B, H, W = 1, 128, 192
+    h, w = H // 8, W // 8
+    g = torch.Generator().manual_seed(5)
+    net0 = torch.tanh(torch.randn(B, 128, h, w, generator=g)).to(DEV)
+    inp = torch.relu(torch.randn(B, 128, h, w, generator=g)).to(DEV)
+    f1 = torch.randn(B, h, w, 256, generator=g).to(DEV)
+    f2 = [torch.randn(B, h >> l, w >> l, 256, generator=g).to(DEV) for l in range(4)]
+    gf, gm = torch.randn(B, 2, h, w, generator=g).to(DEV), torch.randn(B, 576, h, w, generator=g).to(DEV) * 0.01
+    res = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("UFR_RAFT_FUSE_REDUCE", knob)
+        eng = RaftUpdateEngine(net, B, H, W, DEV)
+        fused = [bool(l.desc.no_reduce) for k, l in eng.launch.items() if k[0] in ("zr1", "q1", "zr2", "q2")]
+        assert any(fused) == (knob == "1"), "no launch of this grid is split: pick a size whose gate convolutions are"
+        src = dict(alt=True, f1=f1, f2=f2, scale=1.0 / 16.0)
+        flow, mask = eng.forward(net0, inp, src)
+        flow, mask = flow.clone(), mask.clone()
+        src["g_f1"], src["g_f2"] = torch.empty_like(f1), [torch.empty_like(f) for f in f2]
+        nbytes = __import__("understanding_flow_robustness_amd._lib", fromlist=["lib"]).lib().ufr_altcorr_pyramid_workspace_bytes(
+            B, h, w, 256, eng.radius, len(f2))
+        src["ws"] = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+        g_net0, g_inp = eng.backward(gf, gm)
+        res[knob] = (flow, mask, g_net0.clone(), g_inp.clone())
+    for a, b in zip(res["1"], res["0"]):
+        assert torch.equal(a, b)

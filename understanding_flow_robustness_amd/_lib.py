@@ -72,7 +72,7 @@ class IgemmDesc(C.Structure):
                 ("splitk", C.c_int), ("ws", C.c_void_p),
                 ("products", C.c_int), ("variant", C.c_int), ("k_order", C.c_int),
                 ("out_rowmajor", C.c_void_p), ("out_ld", C.c_long),
-                ("planes_chunks", C.c_int), ("f32_first_chunk", C.c_int)]
+                ("planes_chunks", C.c_int), ("f32_first_chunk", C.c_int), ("no_reduce", C.c_int)]
 
 
 UFR_MAX_CONE_LAYERS = 8
@@ -161,6 +161,8 @@ SIGNATURES = {
     "ufr_raft_flow_patches": [_vp, _vp, _l, _i, _i, _i, _i, _vp],
     "ufr_raft_motion_finish": [_vp, _l, _vp, _l, _i, _vp, _i, _i, _i, _vp],
     "ufr_gru_gates_cm_forward": [_vp, _vp, _l, _i, _vp, _l, _i, _l, _i, _vp],
+    "ufr_gru_gates_cm_forward_slabs": [_vp, _i, _i, _vp, _vp, _vp, _l, _i, _vp, _l, _i, _l, _i, _vp],
+    "ufr_gru_blend_cm_forward_slabs": [_vp, _i, _i, _vp, _vp, _vp, _vp, _l, _i, _vp, _l, _i, _l, _i, _vp],
     "ufr_gru_blend_cm_forward": [_vp, _vp, _vp, _l, _i, _vp, _l, _i, _l, _i, _vp],
     "ufr_gru_blend_cm_backward": [_vp, _vp, _vp, _l, _i, _vp, _vp, _l, _i, _vp, _vp, _l, _i, _vp],
     "ufr_gru_gates_cm_backward": [_vp, _vp, _l, _i, _vp, _vp, _vp, _l, _i, _vp, _l, _i, _i, _vp],

@@ -904,6 +904,7 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   UFR_REQUIRE(d->nphase >= 1 && d->nphase <= 4 && d->splitk >= 1 && d->splitk <= 64, "igemm: bad phase / split count");
   UFR_REQUIRE(d->products == 6 || d->products == 3 || d->products == 1, "igemm: products must be 6, 3 or 1");
   UFR_REQUIRE(d->splitk == 1 || d->ws, "igemm: split-K needs a workspace");
+  UFR_REQUIRE(!d->no_reduce || (d->splitk > 1 && d->nphase == 1), "igemm: no_reduce is for single-phase split-K launches");
   UFR_REQUIRE(d->out_planes || d->out_f32 || d->out_rowmajor, "igemm: no output");
   UFR_REQUIRE(!d->out_rowmajor || (d->out_ld >= d->N && d->N % 8 == 0 && d->out_ld % 4 == 0), "igemm: bad row-major output");
   UFR_REQUIRE(!d->act || d->bias, "igemm: the forward epilogue needs the bias");
@@ -1028,7 +1029,7 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
     else igemm_glds_kernel<128, 64><<<grid, 256, 0, st>>>(a);
   }
   int rc = ufr::launched("igemm_kernel");
-  if (rc != UFR_OK || d->splitk == 1) return rc;
+  if (rc != UFR_OK || d->splitk == 1 || d->no_reduce) return rc;     // no_reduce: the caller's next kernel adds the slabs itself
   const long total = (long)d->nphase * M * (d->Npad / 8);
   igemm_reduce_kernel<<<ufr::stream_grid(total, 256), 256, 0, st>>>(a);
   return ufr::launched("igemm_reduce_kernel");

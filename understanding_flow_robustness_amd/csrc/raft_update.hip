@@ -100,15 +100,40 @@ __global__ void motion_finish_kernel(__bf16* __restrict__ p1, long ps1, __bf16* 
   }
 }
 
+// The pre-activation of 8 consecutive output channels of pixel m straight from a split-K launch's raw slabs [S][M][Npad] (ufr_igemm
+// with `no_reduce`): the slabs are added in ascending order from zero, then the bias -- the arithmetic of igemm_reduce_kernel + its
+// linear epilogue, bit for bit -- so the launch of that kernel between the convolution and the gate arithmetic disappears.
+struct SlabSrc {
+  const float* ws; const float* bias; long slab_stride; int S, Npad;
+};
+__device__ __forceinline__ void load_slabs8(const SlabSrc& k, long m, int col, float v[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = 0.f;
+  const float* src = k.ws + m * k.Npad + col;
+  for (int s = 0; s < k.S; ++s) {
+    const float4 lo = *reinterpret_cast<const float4*>(src + s * k.slab_stride), hi = *reinterpret_cast<const float4*>(src + s * k.slab_stride + 4);
+    v[0] += lo.x; v[1] += lo.y; v[2] += lo.z; v[3] += lo.w; v[4] += hi.x; v[5] += hi.y; v[6] += hi.z; v[7] += hi.w;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] += k.bias[col + j];
+}
+
 // zr [2 chunks_h][M][32] float32 pre-activations -> sigmoid values in place; rh planes = r * h
 __global__ void gates_fwd_kernel(float* __restrict__ zr, const __bf16* __restrict__ h, long hs, int h_chunk0,
-                                 __bf16* __restrict__ rh, long rs, int rh_chunk0, long M, int chunks) {
+                                 __bf16* __restrict__ rh, long rs, int rh_chunk0, long M, int chunks, SlabSrc slabs) {
   const long n8 = (long)chunks * M * 4;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n8; t += (long)gridDim.x * blockDim.x) {
     const long e = t * 8;                                 // element inside a [chunks][M][32] tensor
     float z[8], r[8], hv[8];
-    load_f8(zr + e, z);
-    load_f8(zr + (long)chunks * M * 32 + e, r);
+    if (slabs.ws) {                                       // columns [z | r] of the gate convolution
+      const int ch = (int)(e / (M * 32)), col = ch * 32 + (int)(e & 31);
+      const long m = (e >> 5) - (long)ch * M;
+      load_slabs8(slabs, m, col, z);
+      load_slabs8(slabs, m, chunks * 32 + col, r);
+    } else {
+      load_f8(zr + e, z);
+      load_f8(zr + (long)chunks * M * 32 + e, r);
+    }
     load_planes8(h + (long)h_chunk0 * M * 32 + e, hs, hv);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -124,12 +149,17 @@ __global__ void gates_fwd_kernel(float* __restrict__ zr, const __bf16* __restric
 
 // q [chunks][M][32] pre-activation -> tanh in place; out planes = (1 - z) h + z q
 __global__ void blend_fwd_kernel(float* __restrict__ q, const float* __restrict__ z, const __bf16* __restrict__ h, long hs,
-                                 int h_chunk0, __bf16* __restrict__ out, long os, int out_chunk0, long M, int chunks) {
+                                 int h_chunk0, __bf16* __restrict__ out, long os, int out_chunk0, long M, int chunks, SlabSrc slabs) {
   const long n8 = (long)chunks * M * 4;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n8; t += (long)gridDim.x * blockDim.x) {
     const long e = t * 8;
     float qv[8], zv[8], hv[8];
-    load_f8(q + e, qv);
+    if (slabs.ws) {
+      const int ch = (int)(e / (M * 32));
+      load_slabs8(slabs, (e >> 5) - (long)ch * M, ch * 32 + (int)(e & 31), qv);
+    } else {
+      load_f8(q + e, qv);
+    }
     load_f8(z + e, zv);
     load_planes8(h + (long)h_chunk0 * M * 32 + e, hs, hv);
 #pragma unroll
@@ -220,16 +250,40 @@ extern "C" int ufr_gru_gates_cm_forward(float* zr, const void* h, long h_plane_s
                                         int rh_chunk0, long M, int chunks, ufr_stream_t stream) {
   UFR_REQUIRE(zr && h && rh && M > 0 && chunks > 0, "gru gates (chunk-major) forward: bad argument");
   gates_fwd_kernel<<<ufr::stream_grid((long)chunks * M * 4, 256), 256, 0, ufr::as_stream(stream)>>>(
-      zr, static_cast<const __bf16*>(h), h_plane_stride, h_chunk0, static_cast<__bf16*>(rh), rh_plane_stride, rh_chunk0, M, chunks);
+      zr, static_cast<const __bf16*>(h), h_plane_stride, h_chunk0, static_cast<__bf16*>(rh), rh_plane_stride, rh_chunk0, M, chunks,
+      SlabSrc{nullptr, nullptr, 0, 0, 0});
   return ufr::launched("gates_fwd_kernel");
+}
+
+extern "C" int ufr_gru_gates_cm_forward_slabs(const float* ws, int splitk, int Npad, const float* bias, float* zr, const void* h,
+                                              long h_plane_stride, int h_chunk0, void* rh, long rh_plane_stride, int rh_chunk0, long M,
+                                              int chunks, ufr_stream_t stream) {
+  UFR_REQUIRE(ws && bias && zr && h && rh && M > 0 && chunks > 0 && splitk >= 1 && Npad >= 2 * chunks * 32 && Npad % 8 == 0,
+              "gru gates (chunk-major, from slabs) forward: bad argument");
+  gates_fwd_kernel<<<ufr::stream_grid((long)chunks * M * 4, 256), 256, 0, ufr::as_stream(stream)>>>(
+      zr, static_cast<const __bf16*>(h), h_plane_stride, h_chunk0, static_cast<__bf16*>(rh), rh_plane_stride, rh_chunk0, M, chunks,
+      SlabSrc{ws, bias, M * Npad, splitk, Npad});
+  return ufr::launched("gates_fwd_kernel (slabs)");
 }
 
 extern "C" int ufr_gru_blend_cm_forward(float* q, const float* z, const void* h, long h_plane_stride, int h_chunk0, void* out,
                                         long out_plane_stride, int out_chunk0, long M, int chunks, ufr_stream_t stream) {
   UFR_REQUIRE(q && z && h && out && M > 0 && chunks > 0, "gru blend (chunk-major) forward: bad argument");
   blend_fwd_kernel<<<ufr::stream_grid((long)chunks * M * 4, 256), 256, 0, ufr::as_stream(stream)>>>(
-      q, z, static_cast<const __bf16*>(h), h_plane_stride, h_chunk0, static_cast<__bf16*>(out), out_plane_stride, out_chunk0, M, chunks);
+      q, z, static_cast<const __bf16*>(h), h_plane_stride, h_chunk0, static_cast<__bf16*>(out), out_plane_stride, out_chunk0, M, chunks,
+      SlabSrc{nullptr, nullptr, 0, 0, 0});
   return ufr::launched("blend_fwd_kernel");
+}
+
+extern "C" int ufr_gru_blend_cm_forward_slabs(const float* ws, int splitk, int Npad, const float* bias, float* q, const float* z,
+                                              const void* h, long h_plane_stride, int h_chunk0, void* out, long out_plane_stride,
+                                              int out_chunk0, long M, int chunks, ufr_stream_t stream) {
+  UFR_REQUIRE(ws && bias && q && z && h && out && M > 0 && chunks > 0 && splitk >= 1 && Npad >= chunks * 32 && Npad % 8 == 0,
+              "gru blend (chunk-major, from slabs) forward: bad argument");
+  blend_fwd_kernel<<<ufr::stream_grid((long)chunks * M * 4, 256), 256, 0, ufr::as_stream(stream)>>>(
+      q, z, static_cast<const __bf16*>(h), h_plane_stride, h_chunk0, static_cast<__bf16*>(out), out_plane_stride, out_chunk0, M, chunks,
+      SlabSrc{ws, bias, M * Npad, splitk, Npad});
+  return ufr::launched("blend_fwd_kernel (slabs)");
 }
 
 extern "C" int ufr_gru_blend_cm_backward(const float* q, const float* z, const void* h, long h_plane_stride, int h_chunk0,

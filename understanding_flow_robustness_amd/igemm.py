@@ -313,7 +313,8 @@ def make_launch(wi: WeightImage, x: Planes, in_chunk0: int, rows_hw, out_hw, *, 
                 add: GradSum | None = None, add_chunk0: int = 0, mask: Planes | None = None, mask_chunk0: int = 0,
                 slope: float = LEAKY, splitk: int = 1, ws: torch.Tensor | None = None, row_band=None, in_band=None,
                 products: int = 6, variant: int = 0, tail: GradSum | None = None, tail_n0: int = 0, tail_chunk0: int = 0,
-                tail_accumulate: bool = False, out_rowmajor=None, planes_chunks: int = 0, f32_first_chunk: int = 0) -> Launch:
+                tail_accumulate: bool = False, out_rowmajor=None, planes_chunks: int = 0, f32_first_chunk: int = 0,
+                no_reduce: bool = False) -> Launch:
     """Descriptor for `wi` applied to the chunks [in_chunk0, in_chunk0 + KC) of `x`.
     rows_hw = (Hr, Wr) row grid; out_hw = (Ho, Wo) output grid.  row_band = (origins int32 tensor, element stride, divisor):
     tail / tail_n0: the launch's output columns >= tail_n0 are a LATER layer's partial sum over these input chunks and leave raw
@@ -386,6 +387,7 @@ def make_launch(wi: WeightImage, x: Planes, in_chunk0: int, rows_hw, out_hw, *, 
         if ws is None or ws.numel() < need or ws.dtype != torch.float32:
             raise RuntimeError(f"igemm: split-K workspace of {need} floats needed")
         d.ws = ws.data_ptr()
+    d.no_reduce = 1 if (no_reduce and splitk > 1) else 0      # the consumer adds the slabs (single-phase launches)
     d.products = int(products)
     d.k_order = int(wi.k_order)
     d.variant = int(variant)               # 0 / 2 = single-stage tiles, 4 = 64 x 128, 5 = pipelined, 6 = ping-pong (csrc/igemm.hip)

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import torch
 from ._lib import engine_cache as _engine_cache
@@ -123,6 +124,9 @@ class RaftUpdateEngine:
             W["zr" + tag], W["q" + tag] = cw(w_zr[tag], self._pads[tag]), cw(w_q[tag], self._pads[tag])
             Wb["zr" + tag], Wb["q" + tag] = bw(w_zr[tag], self._pads[tag]), bw(w_q[tag], self._pads[tag])
         relu, lin = dict(slope=0.0), dict(slope=1.0)
+        b_q = {tag: bias(getattr(gru, "convq" + tag)) for tag in ("1", "2")}
+        self._gate_bias = {**{"zr" + t: b_zr[t] for t in ("1", "2")}, **{"q" + t: b_q[t] for t in ("1", "2")}}
+        fuse = os.environ.get("UFR_RAFT_FUSE_REDUCE", "1") != "0"
         for it in range(IT):
             P1, P2 = self.P1[it], self.P2[it]
             plan(("convc1", it), W["convc1"], self.corr_p[it], 0, out_planes=self.cor1[it], bias=bias(enc.convc1), **relu)
@@ -131,8 +135,9 @@ class RaftUpdateEngine:
             plan(("convf2", it), W["convf2"], self.flo1, 0, out_planes=self.CF[it], out_chunk0=6, bias=bias(enc.convf2), **relu)
             plan(("conv", it), W["conv"], self.CF[it], 0, out_planes=P1, out_chunk0=2 * HC, bias=bias(enc.conv), **relu)
             for half, (tag, buf, nxt) in enumerate((("1", P1, P2), ("2", P2, self.P1[it + 1]))):
-                plan(("zr" + tag, it), W["zr" + tag], buf, 0, out_f32=self.ZR[half][it], bias=b_zr[tag], **lin)
-                plan(("q" + tag, it), W["q" + tag], buf, HC, out_f32=self.Q[half][it], bias=bias(getattr(gru, "convq" + tag)), **lin)
+                # the gate / candidate convolutions leave their split-K slabs to the gate arithmetic (no reduce launch in between)
+                plan(("zr" + tag, it), W["zr" + tag], buf, 0, out_f32=self.ZR[half][it], bias=b_zr[tag], no_reduce=fuse, **lin)
+                plan(("q" + tag, it), W["q" + tag], buf, HC, out_f32=self.Q[half][it], bias=b_q[tag], no_reduce=fuse, **lin)
                 # adjoints: d / d [inp | motion | r*h] of q, d / d [h | inp | motion] of the gates
                 src, dst = (self.TA, self.TB) if tag == "2" else (self.TB, self.TA)    # the backward walks half-step 2 first
                 plan(("q" + tag + "^T", it), Wb["q" + tag], self.gzq, 0, add=src, add_chunk0=HC, out_f32=dst, out_f32_chunk0=HC)
@@ -157,6 +162,14 @@ class RaftUpdateEngine:
         fh2 = ub.flow_head.conv2
         self.fh2_w, self.fh2_wm = _pack_flow_head(fh2.weight), _pack_flow_head_mfma(fh2.weight)
         self.fh2_b = fh2.bias.detach().float().contiguous()
+
+    @staticmethod
+    def _slices(launch) -> int:
+        """Slabs a single-phase split-K launch writes: ufr_igemm cuts the K tiles into ceil(KT / splitk)-sized slices."""
+        d = launch.desc
+        kt = d.phase[0].ntaps * d.KC
+        per = -(-kt // d.splitk)
+        return -(-kt // per)
 
     def launch_table(self):
         rows = []
@@ -227,12 +240,24 @@ class RaftUpdateEngine:
                                                B, h, w, st()), "motion finish")
             for half, (tag, buf, nxt) in enumerate((("1", P1, P2), ("2", P2, self.P1[it + 1]))):
                 ZR, Q = self.ZR[half][it], self.Q[half][it]
-                self.launch[("zr" + tag, it)]()
-                L.check(lib.ufr_gru_gates_cm_forward(L.ptr(ZR.t), L.ptr(buf.t), buf.plane_stride, 0, L.ptr(buf.t), buf.plane_stride,
-                                                     3 * HC, M, HC, st()), "gru gates forward")
-                self.launch[("q" + tag, it)]()
-                L.check(lib.ufr_gru_blend_cm_forward(L.ptr(Q.t), L.ptr(ZR.t), L.ptr(buf.t), buf.plane_stride, 0, L.ptr(nxt.t),
-                                                     nxt.plane_stride, 0, M, HC, st()), "gru blend forward")
+                lz = self.launch[("zr" + tag, it)]
+                lz()
+                if lz.desc.no_reduce:
+                    L.check(lib.ufr_gru_gates_cm_forward_slabs(L.ptr(self.ws), self._slices(lz), lz.desc.Npad, L.ptr(self._gate_bias["zr" + tag]),
+                                                               L.ptr(ZR.t), L.ptr(buf.t), buf.plane_stride, 0, L.ptr(buf.t), buf.plane_stride,
+                                                               3 * HC, M, HC, st()), "gru gates forward (slabs)")
+                else:
+                    L.check(lib.ufr_gru_gates_cm_forward(L.ptr(ZR.t), L.ptr(buf.t), buf.plane_stride, 0, L.ptr(buf.t), buf.plane_stride,
+                                                         3 * HC, M, HC, st()), "gru gates forward")
+                lq = self.launch[("q" + tag, it)]
+                lq()
+                if lq.desc.no_reduce:
+                    L.check(lib.ufr_gru_blend_cm_forward_slabs(L.ptr(self.ws), self._slices(lq), lq.desc.Npad, L.ptr(self._gate_bias["q" + tag]),
+                                                               L.ptr(Q.t), L.ptr(ZR.t), L.ptr(buf.t), buf.plane_stride, 0, L.ptr(nxt.t),
+                                                               nxt.plane_stride, 0, M, HC, st()), "gru blend forward (slabs)")
+                else:
+                    L.check(lib.ufr_gru_blend_cm_forward(L.ptr(Q.t), L.ptr(ZR.t), L.ptr(buf.t), buf.plane_stride, 0, L.ptr(nxt.t),
+                                                         nxt.plane_stride, 0, M, HC, st()), "gru blend forward")
             self.launch[("fh1", it)]()
             L.check(lib.ufr_flow_head_planes_forward_mfma(L.ptr(self.FH.t), self.FH.plane_stride, 0, 8, L.ptr(self.fh2_wm), L.ptr(self.fh2_b),
                                                           L.ptr(self.delta), B, h, w, st()), "delta_flow")
