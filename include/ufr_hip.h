@@ -259,6 +259,10 @@ int ufr_gru_blend_backward(const float* q_pre, const float* z, const float* h, c
 int ufr_raft_flow_patches(const float* flow, void* planes, long plane_stride, int chunk0, int B, int H, int W, ufr_stream_t stream);
 int ufr_raft_motion_finish(void* p1, long plane_stride1, void* p2, long plane_stride2, int chunk0, const float* flow, int B, int H,
                            int W, ufr_stream_t stream);
+/* ufr_raft_motion_finish for a motion encoder whose last convolution was a `no_reduce` split-K launch (N <= 126 outputs, Npad 128): the
+ * planes of BOTH GRU buffers come straight from the slabs (ascending sum, bias, LeakyReLU(slope), zeros in the padding, flow in 126 / 127). */
+int ufr_raft_motion_finish_slabs(const float* ws, int splitk, int Npad, int N, const float* bias, float slope, void* p1, long plane_stride1,
+                                 void* p2, long plane_stride2, int chunk0, const float* flow, int B, int H, int W, ufr_stream_t stream);
 int ufr_gru_gates_cm_forward(float* zr, const void* h, long h_plane_stride, int h_chunk0, void* rh, long rh_plane_stride,
                              int rh_chunk0, long M, int chunks, ufr_stream_t stream);
 /* The same two kernels reading the pre-activations straight from a `no_reduce` split-K launch's slabs (columns [z | r] resp. q; the

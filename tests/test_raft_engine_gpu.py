@@ -204,7 +204,7 @@ def test_gate_arithmetic_reading_the_split_k_slabs_is_bit_identical(raft, monkey
     for knob in ("1", "0"):
         monkeypatch.setenv("UFR_RAFT_FUSE_REDUCE", knob)
         eng = RaftUpdateEngine(net, B, H, W, DEV)
-        fused = [bool(l.desc.no_reduce) for k, l in eng.launch.items() if k[0] in ("zr1", "q1", "zr2", "q2")]
+        fused = [bool(l.desc.no_reduce) for k, l in eng.launch.items() if k[0] in ("zr1", "q1", "zr2", "q2", "conv")]
         assert any(fused) == (knob == "1"), "no launch of this grid is split: pick a size whose gate convolutions are"
         src = dict(alt=True, f1=f1, f2=f2, scale=1.0 / 16.0)
         flow, mask = eng.forward(net0, inp, src)

@@ -159,6 +159,7 @@ SIGNATURES = {
     "ufr_cm_norm_backward": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _l, _i, _l, _i, _i, _i, _vp],
     "ufr_cm_masked_copy": [_vp, _vp, _l, _vp, _l, _vp],
     "ufr_raft_flow_patches": [_vp, _vp, _l, _i, _i, _i, _i, _vp],
+    "ufr_raft_motion_finish_slabs": [_vp, _i, _i, _i, _vp, _f, _vp, _l, _vp, _l, _i, _vp, _i, _i, _i, _vp],
     "ufr_raft_motion_finish": [_vp, _l, _vp, _l, _i, _vp, _i, _i, _i, _vp],
     "ufr_gru_gates_cm_forward": [_vp, _vp, _l, _i, _vp, _l, _i, _l, _i, _vp],
     "ufr_gru_gates_cm_forward_slabs": [_vp, _i, _i, _vp, _vp, _vp, _l, _i, _vp, _l, _i, _l, _i, _vp],

@@ -118,6 +118,40 @@ __device__ __forceinline__ void load_slabs8(const SlabSrc& k, long m, int col, f
   for (int j = 0; j < 8; ++j) v[j] += k.bias[col + j];
 }
 
+// motion_finish_kernel reading the motion encoder's last convolution (126 outputs, ReLU) from its split-K slabs: p1 = p2 =
+// split(relu(sum + bias)) with the flow in channels 126, 127 -- the reduce launch and the read-back of p1 disappear
+__global__ void motion_finish_slabs_kernel(SlabSrc slabs, int N, float slope, __bf16* __restrict__ p1, long ps1, __bf16* __restrict__ p2,
+                                           long ps2, int chunk0, const float* __restrict__ flow, long M, long HW) {
+  const long total = M * 16;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int g8 = (int)(t & 15);
+    const long m = t >> 4;
+    const long e = ((long)(chunk0 + (g8 >> 2)) * M + m) * 32 + (g8 & 3) * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    const float* src = slabs.ws + m * slabs.Npad + g8 * 8;
+    for (int s = 0; s < slabs.S; ++s) {
+      const float4 lo = *reinterpret_cast<const float4*>(src + s * slabs.slab_stride), hi = *reinterpret_cast<const float4*>(src + s * slabs.slab_stride + 4);
+      v[0] += lo.x; v[1] += lo.y; v[2] += lo.z; v[3] += lo.w; v[4] += hi.x; v[5] += hi.y; v[6] += hi.z; v[7] += hi.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                          // igemm's forward epilogue: bias, LeakyReLU(slope), zeros in the padding
+      const int n = g8 * 8 + j;
+      v[j] += n < N ? slabs.bias[n] : 0.f;
+      v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
+      if (n >= N) v[j] = 0.f;
+    }
+    if (g8 == 15) {
+      const long b = m / HW, pix = m - b * HW;
+      v[6] = flow[(b * 2 + 0) * HW + pix];
+      v[7] = flow[(b * 2 + 1) * HW + pix];
+    }
+    store_planes8(p1 + e, ps1, v);
+    store_planes8(p2 + e, ps2, v);
+  }
+}
+
 // zr [2 chunks_h][M][32] float32 pre-activations -> sigmoid values in place; rh planes = r * h
 __global__ void gates_fwd_kernel(float* __restrict__ zr, const __bf16* __restrict__ h, long hs, int h_chunk0,
                                  __bf16* __restrict__ rh, long rs, int rh_chunk0, long M, int chunks, SlabSrc slabs) {
@@ -244,6 +278,18 @@ extern "C" int ufr_raft_motion_finish(void* p1, long plane_stride1, void* p2, lo
   motion_finish_kernel<<<ufr::stream_grid(M * 16, 256), 256, 0, ufr::as_stream(stream)>>>(
       static_cast<__bf16*>(p1), plane_stride1, static_cast<__bf16*>(p2), plane_stride2, chunk0, flow, M, (long)H * W);
   return ufr::launched("motion_finish_kernel");
+}
+
+extern "C" int ufr_raft_motion_finish_slabs(const float* ws, int splitk, int Npad, int N, const float* bias, float slope, void* p1,
+                                            long plane_stride1, void* p2, long plane_stride2, int chunk0, const float* flow, int B, int H,
+                                            int W, ufr_stream_t stream) {
+  UFR_REQUIRE(ws && bias && p1 && p2 && flow && B > 0 && H > 0 && W > 0 && chunk0 >= 0 && splitk >= 1 && Npad == 128 && N > 0 && N <= 126,
+              "raft motion finish (slabs): bad argument");
+  const long M = (long)B * H * W;
+  motion_finish_slabs_kernel<<<ufr::stream_grid(M * 16, 256), 256, 0, ufr::as_stream(stream)>>>(
+      SlabSrc{ws, bias, M * Npad, splitk, Npad}, N, slope, static_cast<__bf16*>(p1), plane_stride1, static_cast<__bf16*>(p2), plane_stride2,
+      chunk0, flow, M, (long)H * W);
+  return ufr::launched("motion_finish_slabs_kernel");
 }
 
 extern "C" int ufr_gru_gates_cm_forward(float* zr, const void* h, long h_plane_stride, int h_chunk0, void* rh, long rh_plane_stride,

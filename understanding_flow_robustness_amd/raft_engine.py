@@ -125,6 +125,7 @@ class RaftUpdateEngine:
             Wb["zr" + tag], Wb["q" + tag] = bw(w_zr[tag], self._pads[tag]), bw(w_q[tag], self._pads[tag])
         relu, lin = dict(slope=0.0), dict(slope=1.0)
         b_q = {tag: bias(getattr(gru, "convq" + tag)) for tag in ("1", "2")}
+        b_conv = self._conv_bias = bias(enc.conv)
         self._gate_bias = {**{"zr" + t: b_zr[t] for t in ("1", "2")}, **{"q" + t: b_q[t] for t in ("1", "2")}}
         fuse = os.environ.get("UFR_RAFT_FUSE_REDUCE", "1") != "0"
         for it in range(IT):
@@ -133,7 +134,7 @@ class RaftUpdateEngine:
             plan(("convc2", it), W["convc2"], self.cor1[it], 0, out_planes=self.CF[it], out_chunk0=0, bias=bias(enc.convc2), **relu)
             plan(("convf1", it), W["convf1"], self.fpat, 0, out_planes=self.flo1, bias=bias(enc.convf1), **relu)
             plan(("convf2", it), W["convf2"], self.flo1, 0, out_planes=self.CF[it], out_chunk0=6, bias=bias(enc.convf2), **relu)
-            plan(("conv", it), W["conv"], self.CF[it], 0, out_planes=P1, out_chunk0=2 * HC, bias=bias(enc.conv), **relu)
+            plan(("conv", it), W["conv"], self.CF[it], 0, out_planes=P1, out_chunk0=2 * HC, bias=b_conv, no_reduce=fuse, **relu)
             for half, (tag, buf, nxt) in enumerate((("1", P1, P2), ("2", P2, self.P1[it + 1]))):
                 # the gate / candidate convolutions leave their split-K slabs to the gate arithmetic (no reduce launch in between)
                 plan(("zr" + tag, it), W["zr" + tag], buf, 0, out_f32=self.ZR[half][it], bias=b_zr[tag], no_reduce=fuse, **lin)
@@ -236,8 +237,14 @@ class RaftUpdateEngine:
             for name in ("convc1", "convc2", "convf1", "convf2", "conv"):
                 self.launch[(name, it)]()
             P1, P2 = self.P1[it], self.P2[it]
-            L.check(lib.ufr_raft_motion_finish(L.ptr(P1.t), P1.plane_stride, L.ptr(P2.t), P2.plane_stride, 2 * HC, L.ptr(self.flows[it]),
-                                               B, h, w, st()), "motion finish")
+            lc = self.launch[("conv", it)]
+            if lc.desc.no_reduce:                                    # its slabs -> both GRU buffers' motion chunks (+ the flow channels)
+                L.check(lib.ufr_raft_motion_finish_slabs(L.ptr(self.ws), self._slices(lc), lc.desc.Npad, lc.desc.N, L.ptr(self._conv_bias), 0.0,
+                                                         L.ptr(P1.t), P1.plane_stride, L.ptr(P2.t), P2.plane_stride, 2 * HC,
+                                                         L.ptr(self.flows[it]), B, h, w, st()), "motion finish (slabs)")
+            else:
+                L.check(lib.ufr_raft_motion_finish(L.ptr(P1.t), P1.plane_stride, L.ptr(P2.t), P2.plane_stride, 2 * HC, L.ptr(self.flows[it]),
+                                                   B, h, w, st()), "motion finish")
             for half, (tag, buf, nxt) in enumerate((("1", P1, P2), ("2", P2, self.P1[it + 1]))):
                 ZR, Q = self.ZR[half][it], self.Q[half][it]
                 lz = self.launch[("zr" + tag, it)]
