@@ -105,7 +105,7 @@ class PlaneGraph:
         gz = ig.Planes(self.B, db.H, db.W, nch, self.dev)
         fwd = self._launch(wi, sb.planes, s0, rows, rows, out_planes=db.planes, out_chunk0=d0, bias=bias.detach().float().contiguous(), slope=slope)
         bwd = self._launch(wib, gz, 0, rows, (sb.H, sb.W), add=sb.grad, add_chunk0=s0, out_f32=sb.grad, out_f32_chunk0=s0)
-        self.ops.append(dict(kind="conv", fwd=fwd, bwd=bwd, gz=gz, db=db, d0=d0, nch=nch, slope=slope, wi=wi, wib=wib))
+        self.ops.append(dict(kind="conv", fwd=fwd, bwd=bwd, gz=gz, db=db, d0=d0, nch=nch, slope=slope, wi=wi, wib=wib, sb=sb, s0=s0, sk=sk))
 
     def deconv(self, weight, bias, src, dst, slope=ig.LEAKY, in_segments=None):
         """ConvTranspose2d(Cin, Cout, 4, 2, 1) + bias + LeakyReLU (submodules.py:75-82)."""
@@ -121,7 +121,7 @@ class PlaneGraph:
         fwd = self._launch(wi, sb.planes, s0, (sb.H, sb.W), (db.H, db.W), out_planes=db.planes, out_chunk0=d0,
                            bias=bias.detach().float().contiguous(), slope=slope)
         bwd = self._launch(wib, gz, 0, (sb.H, sb.W), (sb.H, sb.W), add=sb.grad, add_chunk0=s0, out_f32=sb.grad, out_f32_chunk0=s0)
-        self.ops.append(dict(kind="conv", fwd=fwd, bwd=bwd, gz=gz, db=db, d0=d0, nch=nch, slope=slope, wi=wi, wib=wib))
+        self.ops.append(dict(kind="conv", fwd=fwd, bwd=bwd, gz=gz, db=db, d0=d0, nch=nch, slope=slope, wi=wi, wib=wib, sb=sb, s0=s0, sk=sk))
 
     def predict_flow(self, conv, src, name, in_segments=None):
         """Conv2d(C, 2, 3, 1, 1) on a buffer's chunks -> flow `name` [B, 2, H, W] (NCHW float32)."""
@@ -150,8 +150,38 @@ class PlaneGraph:
         self.tensor_outputs.append(dict(buf=b, C=channels, chunk0=chunk0,
                                         t=torch.zeros(self.B, channels, b.H, b.W, dtype=torch.float32, device=self.dev)))
 
+    def _fuse_single_reader_segments(self):
+        """A produced segment that exactly ONE later convolution reads (conv3 -> conv3_1, conv0 -> conv1, ...) needs no gradient
+        sum: that convolution's transposed launch writes LeakyReLU'(segment) x its result straight into the producer's gradient
+        planes (igemm epilogue `mask` + `out_planes`), instead of adding onto the float32 sum for a `grad_finalize` launch to
+        convert.  Segments with several readers (the concatenations) keep the sum."""
+        plans = {id(p[0]): p for p in self._plans}
+        overlap = lambda a0, an, b0, bn: a0 < b0 + bn and b0 < a0 + an
+        for P in self.ops:
+            if P["kind"] != "conv":
+                continue
+            db, d0, nch = P["db"], P["d0"], P["nch"]
+            readers = []
+            for Q in self.ops:
+                if Q["kind"] in ("conv", "pf") and Q["sb"] is db and overlap(Q["s0"], Q["sk"], d0, nch):
+                    readers.append(Q)
+                elif Q["kind"] == "up" and Q["db"] is db and overlap(Q["chunk"], 1, d0, nch):
+                    readers.append(Q)
+            if any(t["buf"] is db and overlap(t["chunk0"], -(-t["C"] // 32), d0, nch) for t in self.tensor_outputs):
+                continue
+            if len(readers) != 1 or readers[0]["kind"] != "conv" or (readers[0]["s0"], readers[0]["sk"]) != (d0, nch):
+                continue
+            kw = plans[id(readers[0]["bwd"])][6]
+            kw.pop("add", None); kw.pop("add_chunk0", None); kw.pop("out_f32", None); kw.pop("out_f32_chunk0", None)
+            kw.update(out_planes=P["gz"], out_chunk0=0, slope=float(P["slope"]))
+            if P["slope"] != 1.0:
+                kw.update(mask=db.planes, mask_chunk0=d0)
+            P["finalized"] = True
+
     def build(self):
         B = self.B
+        if __import__("os").environ.get("UFR_GRAPH_FUSE_FINALIZE", "1") != "0":
+            self._fuse_single_reader_segments()
         # every gradient sum and flow gradient in one arena: a backward starts with ONE fill instead of one per buffer
         r64 = lambda n: (n + 63) // 64 * 64                   # keep every member 256-byte aligned
         sizes = [b.grad.t.numel() for b in self.bufs.values()] + [r64(g.numel()) for g in self.g_flows.values()]
@@ -231,9 +261,10 @@ class PlaneGraph:
         for op in reversed(self.ops):
             if op["kind"] == "conv":
                 db, gz = op["db"], op["gz"]
-                mask = db.planes if op["slope"] != 1.0 else None
-                L.check(lib.ufr_grad_finalize(L.ptr(db.grad.t), op["d0"], L.ptr(mask.t) if mask is not None else None, op["d0"], L.ptr(gz.t),
-                                              gz.plane_stride, 0, db.grad.M, op["nch"], float(op["slope"]), st()), "gradient finalize")
+                if not op.get("finalized"):                      # (else its single reader's transposed launch wrote gz already)
+                    mask = db.planes if op["slope"] != 1.0 else None
+                    L.check(lib.ufr_grad_finalize(L.ptr(db.grad.t), op["d0"], L.ptr(mask.t) if mask is not None else None, op["d0"], L.ptr(gz.t),
+                                                  gz.plane_stride, 0, db.grad.M, op["nch"], float(op["slope"]), st()), "gradient finalize")
                 op["bwd"]()
             elif op["kind"] == "pf":
                 sb = op["sb"]
