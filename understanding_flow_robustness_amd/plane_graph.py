@@ -151,10 +151,10 @@ class PlaneGraph:
                                         t=torch.zeros(self.B, channels, b.H, b.W, dtype=torch.float32, device=self.dev)))
 
     def _fuse_single_reader_segments(self):
-        """A produced segment that exactly ONE later convolution reads (conv3 -> conv3_1, conv0 -> conv1, ...) needs no gradient
-        sum: that convolution's transposed launch writes LeakyReLU'(segment) x its result straight into the producer's gradient
-        planes (igemm epilogue `mask` + `out_planes`), instead of adding onto the float32 sum for a `grad_finalize` launch to
-        convert.  Segments with several readers (the concatenations) keep the sum."""
+        """A produced segment whose FIRST reader is a convolution over exactly that segment (conv3 -> conv3_1, conv0 -> conv1,
+        convK_1 -> conv(K+1) in front of a concatenation, ...) needs no `grad_finalize` launch: that convolution's transposed launch
+        -- the last contribution to arrive in the backward -- writes LeakyReLU'(segment) x (its result + what the other readers
+        left in the float32 sum) straight into the producer's gradient planes (igemm epilogue `add` + `mask` + `out_planes`)."""
         plans = {id(p[0]): p for p in self._plans}
         overlap = lambda a0, an, b0, bn: a0 < b0 + bn and b0 < a0 + an
         for P in self.ops:
@@ -169,10 +169,14 @@ class PlaneGraph:
                     readers.append(Q)
             if any(t["buf"] is db and overlap(t["chunk0"], -(-t["C"] // 32), d0, nch) for t in self.tensor_outputs):
                 continue
-            if len(readers) != 1 or readers[0]["kind"] != "conv" or (readers[0]["s0"], readers[0]["sk"]) != (d0, nch):
+            # the reader that comes FIRST in the forward order runs LAST in the backward: when it is a convolution over exactly
+            # this segment, its transposed launch completes the sum (epilogue `add` = what the other readers left) and finalises
+            if not readers or readers[0]["kind"] != "conv" or (readers[0]["s0"], readers[0]["sk"]) != (d0, nch):
                 continue
             kw = plans[id(readers[0]["bwd"])][6]
-            kw.pop("add", None); kw.pop("add_chunk0", None); kw.pop("out_f32", None); kw.pop("out_f32_chunk0", None)
+            kw.pop("out_f32", None); kw.pop("out_f32_chunk0", None)
+            if len(readers) == 1:
+                kw.pop("add", None); kw.pop("add_chunk0", None)
             kw.update(out_planes=P["gz"], out_chunk0=0, slope=float(P["slope"]))
             if P["slope"] != 1.0:
                 kw.update(mask=db.planes, mask_chunk0=d0)
