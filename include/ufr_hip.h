@@ -657,7 +657,7 @@ int ufr_upfeat_planes_backward(const float* grad_y, const float* wpk, float* G, 
 int ufr_flow_up_planes_forward(const float* x, const float* w, const float* bias, void* planes, long plane_stride,
                                int chunk, int B, int H, int W, ufr_stream_t stream);
 int ufr_flow_up_planes_backward(const float* G, int chunk, const float* w, float* grad_x, int B, int H, int W,
-                                ufr_stream_t stream);
+                                int accumulate /* ABI 6: grad_x += (1) or = (0) */, ufr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -172,7 +172,7 @@ SIGNATURES = {
     "ufr_upfeat_planes_forward_mfma": [_vp, _l, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ufr_upfeat_planes_backward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "ufr_flow_up_planes_forward": [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp],
-    "ufr_flow_up_planes_backward": [_vp, _i, _vp, _vp, _i, _i, _i, _vp],
+    "ufr_flow_up_planes_backward": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_corr_forward_planes_window": [_vp, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _i, _i, _vp],
     "ufr_corr_forward_planes": [_vp, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp],
     "ufr_convex_upsample_forward": [_vp, _vp, _vp, _i, _i, _i, _vp],

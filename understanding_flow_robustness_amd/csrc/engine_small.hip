@@ -506,7 +506,7 @@ __global__ void flow_up_planes_fwd(const float* __restrict__ x, const float* __r
 
 // gx[b,i,y,x] = sum_o sum_{ky,kx} G[chunk][(b,2y-1+ky,2x-1+kx)][o] * w[i,o,ky,kx]
 __global__ void flow_up_planes_bwd(const float* __restrict__ G, int chunk, const float* __restrict__ w, float* __restrict__ gx,
-                                   int B, int H, int W) {
+                                   int B, int H, int W, int accumulate) {
   const int Ho = 2 * H, Wo = 2 * W;
   const long total = (long)B * H * W, Mf = (long)B * Ho * Wo;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -527,8 +527,10 @@ __global__ void flow_up_planes_bwd(const float* __restrict__ G, int chunk, const
         a1 = fmaf(g.y, w[((1 * 2 + 1) * 4 + ky) * 4 + kx], a1);
       }
     }
-    gx[((size_t)b * 2 + 0) * H * W + (size_t)yy * W + xx] = a0;
-    gx[((size_t)b * 2 + 1) * H * W + (size_t)yy * W + xx] = a1;
+    float* o0 = gx + ((size_t)b * 2 + 0) * H * W + (size_t)yy * W + xx;
+    float* o1 = gx + ((size_t)b * 2 + 1) * H * W + (size_t)yy * W + xx;
+    *o0 = accumulate ? *o0 + a0 : a0;
+    *o1 = accumulate ? *o1 + a1 : a1;
   }
 }
 
@@ -692,9 +694,9 @@ extern "C" int ufr_flow_up_planes_forward(const float* x, const float* w, const 
 }
 
 extern "C" int ufr_flow_up_planes_backward(const float* G, int chunk, const float* w, float* grad_x, int B, int H, int W,
-                                           ufr_stream_t stream) {
+                                           int accumulate, ufr_stream_t stream) {
   UFR_REQUIRE(G && w && grad_x, "flow upsample (planes) backward: null pointer");
   UFR_REQUIRE(B > 0 && H > 0 && W > 0 && chunk >= 0, "flow upsample (planes) backward: bad shape");
-  flow_up_planes_bwd<<<ufr::stream_grid((long)B * H * W, 256), 256, 0, ufr::as_stream(stream)>>>(G, chunk, w, grad_x, B, H, W);
+  flow_up_planes_bwd<<<ufr::stream_grid((long)B * H * W, 256), 256, 0, ufr::as_stream(stream)>>>(G, chunk, w, grad_x, B, H, W, accumulate);
   return ufr::launched("flow_up_planes_bwd");
 }

@@ -572,7 +572,7 @@ class FlowNetCHeadEngine:
         G, chunk = self.up_G[k]
         f = self.g_flow[k]
         L.check(L.lib().ufr_flow_up_planes_backward(L.ptr(G.t), chunk, L.ptr(self.up_w[k]), L.ptr(f), self.B, f.shape[2],
-                                                    f.shape[3], L.stream()), "upsampled_flow backward")
+                                                    f.shape[3], 0, L.stream()), "upsampled_flow backward")
 
     def _finalize(self, Gs, mask, out, chunk0, chunks):
         L.check(L.lib().ufr_grad_finalize(L.ptr(Gs.t), chunk0, L.ptr(mask.t), chunk0, L.ptr(out.t), out.plane_stride, chunk0,

@@ -276,9 +276,8 @@ class PlaneGraph:
                                                           self.B, sb.H, sb.W, 1, st()), "predict_flow backward")
             else:
                 gf, db = self.g_flows[op["flow"]], op["db"]
-                L.check(lib.ufr_flow_up_planes_backward(L.ptr(db.grad.t), op["chunk"], L.ptr(op["w"]), L.ptr(self._tmp_like(gf)), self.B,
-                                                        gf.shape[2], gf.shape[3], st()), "upsampled_flow backward")
-                gf.add_(self._tmp_like(gf))
+                L.check(lib.ufr_flow_up_planes_backward(L.ptr(db.grad.t), op["chunk"], L.ptr(op["w"]), L.ptr(gf), self.B, gf.shape[2], gf.shape[3],
+                                                        1, st()), "upsampled_flow backward")      # += : an output flow already holds its gradient
         outs = []
         for spec in self.inputs:
             b = spec["buf"]
@@ -288,13 +287,6 @@ class PlaneGraph:
                 b.grad.to_nchw(spec["C"], spec["chunk0"], slope=1.0, out=spec["g"])
             outs.append(spec["g"])
         return outs
-
-    def _tmp_like(self, t):
-        key = tuple(t.shape)
-        tmp = self.__dict__.setdefault("_tmps", {})
-        if key not in tmp:
-            tmp[key] = torch.zeros_like(t)
-        return tmp[key]
 
 
 class _Deferred:
