@@ -197,7 +197,11 @@ constexpr int PFM_MAXT = 6;                        // m-tiles per wave
 //         T[p, n = 2 (4 ky + kx) + o] = sum_c x[p, c] w[c, o, ky, kx] (N = 32), then fine pixel (Y, X) adds its <= 4 (pixel, tap)
 //         pairs: ky = (Y + 1) mod 2 (+ 2), y = (Y + 1 - ky) / 2.  tile = TH x 16 coarse pixels, staged = the tile + halo
 //         (TH + 2) x 18; out = NCHW [B, 2, 2H, 2W] + bias.  H, W = the COARSE (input) grid.
-template <int MODE>
+// WPS_ = waves per chunk slice.  4 (the default): the slice's m-tiles are dealt to four waves, each of which fetches the slice's
+// 6 KB weight image per chunk.  1 (the small grids, <= 12 m-tiles): ONE wave holds all m-tiles of a slice and eight slices share the
+// workgroup -- the weights are fetched once per chunk and workgroup instead of four times (a workgroup of these grids is bound by
+// its CU's vector-memory port: 51 -> 33 KB per chunk, profiles/r4_predict_flow_small_grids.jsonl)
+template <int MODE, int WPS_ = 4, int MAXT_ = PFM_MAXT>
 __global__ __launch_bounds__(512) void flow_head_planes_fwd_mfma(const __bf16* __restrict__ x, long plane_stride, int chunk0,
                                                                  int chunks, const __bf16* __restrict__ wmf,
                                                                  const float* __restrict__ bias, float* __restrict__ out,
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(512) void flow_head_planes_fwd_mfma(const __bf16* _
   extern __shared__ __attribute__((aligned(16))) float pfm_T[];            // [S][mt * 16][TS]
   const int Hs = MODE == 1 ? 2 * H : H, Ws = MODE == 1 ? 2 * W : W;        // the staged (input) grid
   const long M = (long)B * Hs * Ws;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, slice = wave >> 2, tw = wave & 3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, slice = wave / WPS_, tw = wave % WPS_;
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
   const int b = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x - b * tiles_x * tiles_y;
   const int y0 = (tr / tiles_x) * TH, x0 = (tr % tiles_x) * TW;
@@ -215,20 +219,20 @@ __global__ __launch_bounds__(512) void flow_head_planes_fwd_mfma(const __bf16* _
   const int nh = (MODE == 1 ? 2 * TH + 2 : TH + 2) * PFM_HW, mt = (nh + 15) >> 4;
   const __bf16* zero = reinterpret_cast<const __bf16*>(pf_zero_page);
   // this lane's staged pixel in each of its m-tiles
-  const __bf16* abase[PFM_MAXT];
+  const __bf16* abase[MAXT_];
   unsigned okmask = 0;
 #pragma unroll
-  for (int s = 0; s < PFM_MAXT; ++s) {
-    const int hp = (tw + 4 * s) * 16 + (lane & 15);
+  for (int s = 0; s < MAXT_; ++s) {
+    const int hp = (tw + WPS_ * s) * 16 + (lane & 15);
     const int hy = hp / PFM_HW, hx = hp - hy * PFM_HW;
     const int yy = sy0 + hy, xx = sx0 + hx;
-    const bool ok = tw + 4 * s < mt && hp < nh && yy >= 0 && yy < Hs && xx >= 0 && xx < Ws;
+    const bool ok = tw + WPS_ * s < mt && hp < nh && yy >= 0 && yy < Hs && xx >= 0 && xx < Ws;
     abase[s] = ok ? x + ((long)chunk0 * M + ((long)b * Hs + yy) * Ws + xx) * 32 + (lane >> 4) * 8 : zero;
     okmask |= ok ? 1u << s : 0u;
   }
-  f32x4 acc[PFM_MAXT][2];
+  f32x4 acc[MAXT_][2];
 #pragma unroll
-  for (int s = 0; s < PFM_MAXT; ++s) acc[s][0] = acc[s][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < MAXT_; ++s) acc[s][0] = acc[s][1] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int per = (chunks + S - 1) / S, c_lo = slice * per, c_hi = min(chunks, c_lo + per);
   const __bf16* wl = wmf + (lane & 15) * 32 + (lane >> 4) * 8;
   for (int ch = c_lo; ch < c_hi; ++ch) {
@@ -237,34 +241,37 @@ __global__ __launch_bounds__(512) void flow_head_planes_fwd_mfma(const __bf16* _
     for (int p = 0; p < 3; ++p)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) fb[nt][p] = *reinterpret_cast<const bf16x8*>(wl + (((long)ch * 3 + p) * 2 + nt) * 512);
-    bf16x8 fa[PFM_MAXT][3];
 #pragma unroll
-    for (int s = 0; s < PFM_MAXT; ++s)
-      if (tw + 4 * s < mt) {
+    for (int h = 0; h < MAXT_; h += 6) {         // six m-tiles' fragments at a time (WPS_ = 1: twelve tiles in two halves)
+      bf16x8 fa[6][3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          const long off = (okmask >> s & 1u) ? (long)ch * M * 32 + p * plane_stride : 0;   // the zero page does not move
-          fa[s][p] = *reinterpret_cast<const bf16x8*>(abase[s] + off);
+      for (int s = 0; s < 6; ++s)
+        if (tw + WPS_ * (h + s) < mt) {
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            const long off = (okmask >> (h + s) & 1u) ? (long)ch * M * 32 + p * plane_stride : 0;   // the zero page does not move
+            fa[s][p] = *reinterpret_cast<const bf16x8*>(abase[h + s] + off);
+          }
         }
-      }
 #pragma unroll
-    for (int s = 0; s < PFM_MAXT; ++s)
-      if (tw + 4 * s < mt) {
+      for (int s = 0; s < 6; ++s)
+        if (tw + WPS_ * (h + s) < mt) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+          for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-          for (int q = 0; q < 6; ++q)
-            acc[s][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s][PFM_A[q]], fb[nt][PFM_B[q]], acc[s][nt], 0, 0, 0);
-      }
+            for (int q = 0; q < 6; ++q)
+              acc[h + s][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s][PFM_A[q]], fb[nt][PFM_B[q]], acc[h + s][nt], 0, 0, 0);
+        }
+    }
   }
   // T: lane holds D[m = 4 (lane >> 4) + r][n = lane & 15]
   float* T = pfm_T + (long)slice * mt * 16 * TS;
 #pragma unroll
-  for (int s = 0; s < PFM_MAXT; ++s)
-    if (tw + 4 * s < mt) {
+  for (int s = 0; s < MAXT_; ++s)
+    if (tw + WPS_ * s < mt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float* row = T + ((tw + 4 * s) * 16 + (lane >> 4) * 4 + r) * TS;
+        float* row = T + ((tw + WPS_ * s) * 16 + (lane >> 4) * 4 + r) * TS;
         row[lane & 15] = acc[s][0][r];
         if (MODE != 0 || (lane & 15) < 2) row[16 + (lane & 15)] = acc[s][1][r];
       }
@@ -588,6 +595,19 @@ int launch_pf_mfma(const void* planes, long plane_stride, int chunk0, int chunks
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
     lds_allowed = lds;
+  }
+  if constexpr (MODE == 0) if (mt <= 12 && S == 2 && chunks >= 16 && blocks <= 256) {    // small grids (at most one workgroup per CU): eight one-wave slices
+    const size_t lds8 = (size_t)8 * mt * 16 * TS * sizeof(float);
+    static bool raised8 = false;
+    if (!raised8) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flow_head_planes_fwd_mfma<MODE, 1, 12>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 12 * 16 * TS * (int)sizeof(float));
+      if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+      raised8 = true;
+    }
+    flow_head_planes_fwd_mfma<MODE, 1, 12><<<blocks, 512, lds8, st>>>(static_cast<const __bf16*>(planes), plane_stride, chunk0, chunks,
+                                                                      static_cast<const __bf16*>(wmf), bias, out, out_chunk, B, H, W, TH, 8);
+    return ufr::launched(what);
   }
   flow_head_planes_fwd_mfma<MODE><<<blocks, 256 * S, lds, st>>>(static_cast<const __bf16*>(planes), plane_stride, chunk0, chunks,
                                                                 static_cast<const __bf16*>(wmf), bias, out, out_chunk, B, H, W, TH, S);
