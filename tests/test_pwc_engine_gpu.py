@@ -107,7 +107,7 @@ def test_pwc_engine_head_forward_and_gradient_match_the_torch_head(net, monkeypa
 def test_pwc_engine_step_equals_full_frame_torch_step(net, monkeypatch):
     """Config C4's step (windowed pyramid levels 1-2 on the igemm, cached level-2 features in the engine's planes, fused
     loss, one HIP graph) against the full-frame torch / MIOpen step (UFR_ENGINE=0, no window, eager) after ONE iteration:
-    4 pairs behind one 51x51 patch at 384x1280, placements at a corner, two edges and the interior -- 1e-4 of the update."""
+    4 pairs behind one 51x51 patch at 384x1280, placements at a corner, two edges and the interior -- 2.5e-4 of the update (see the assertion)."""
     from understanding_flow_robustness_amd.patch_attack import PatchAttackStep
     B, H, W = 4, 384, 1280
     g = torch.Generator().manual_seed(11)
@@ -139,7 +139,10 @@ def test_pwc_engine_step_equals_full_frame_torch_step(net, monkeypatch):
         err = float((pf - pe).abs().max())
         print(f"update {upd:.3e}, engine step vs torch step {err / upd:.2e} of it; loss {lf:.6f} / {le:.6f}")
         assert nf == ne == 1 and abs(lf - le) <= 1e-5
-        assert 1e-3 < upd < 1.9 and err <= 1e-4 * upd, f"{err / upd:.2e} of the update"
+        # 2.5e-4: the yardstick here is the torch / MIOpen step, whose convolution algorithms are chosen per box (find mode) -- the
+        # same tree measured 1.6e-5 .. 5.3e-5 on one box and 1.16e-4 on another (gpurun r4_call65 / r4_final_d).  The engine's own
+        # error is pinned by `test_pwc_step_at_full_size_vs_cpu_oracle`: 1e-4 of the update against the CPU oracle (6e-6 measured).
+        assert 1e-3 < upd < 1.9 and err <= 2.5e-4 * upd, f"{err / upd:.2e} of the update"
 
 
 @pytest.mark.timeout(900)
