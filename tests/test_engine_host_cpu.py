@@ -216,3 +216,49 @@ def test_engine_refusal_names_the_reason():
         for p in m.parameters():
             p.requires_grad_(True)
         assert L.engine_refusal(m, FakeHip(64, 64), 64) is None            # no gradients wanted: the engines serve it
+
+
+def test_plane_graph_lets_the_first_reader_finalise_a_segment(monkeypatch):
+    """PlaneGraph._fuse_single_reader_segments on descriptors only (CPU tensors, nothing is launched): a produced segment whose
+    FIRST reader is a convolution over exactly that segment gets its gradient planes from that reader's transposed launch
+    (`mask` + `out_planes`, and `add` = the float32 sum when other readers contributed before it); a concatenation read as a
+    whole by its first reader, a segment that feeds predict_flow first, and a linear segment keep / lose what they should."""
+    from understanding_flow_robustness_amd.plane_graph import PlaneGraph
+    conv = lambda cin, cout, k=3: (torch.randn(cout, cin, k, k) * 0.1, torch.zeros(cout))
+    monkeypatch.setenv("UFR_GRAPH_FUSE_FINALIZE", "1")
+    g = PlaneGraph(1, "cpu")
+    for name, s, chunks in (("in0", 0, 1), ("a", 0, 2), ("cat", 1, 5), ("b", 2, 4), ("ic", 1, 1)):
+        g.buffer(name, 32 >> s, 64 >> s, chunks)
+    g.input("in0", 6)
+    g.conv(*conv(6, 64), ("in0", 0, 1), ("a", 0))                          # 0: a <- in0           (one reader: conv 1)
+    g.conv(*conv(64, 64), ("a", 0, 2), ("cat", 0), stride=2)               # 1: cat[0:2] <- a      (readers: conv 2 exact, then conv 4 whole)
+    g.conv(*conv(64, 128), ("cat", 0, 2), ("b", 0), stride=2)              # 2: b <- cat[0:2]      (first reader of b: predict_flow)
+    g.predict_flow(torch.nn.Conv2d(128, 2, 3, 1, 1), ("b", 0, 4), "flow2")
+    g.up_flow(torch.nn.ConvTranspose2d(2, 2, 4, 2, 1, bias=False), "flow2", ("cat", 4))
+    dw = torch.randn(128, 64, 4, 4) * 0.1
+    g.deconv(dw, torch.zeros(64), ("b", 0, 4), ("cat", 2))                 # 3: cat[2:4] <- b      (first reader: conv 4 over the WHOLE cat)
+    g.conv(*conv(162, 32), ("cat", 0, 5), ("ic", 0), slope=1.0,            # 4: ic <- cat          (linear; read by predict_flow only)
+           in_segments=[(0, 64, 0), (64, 64, 64), (128, 2, 128)])
+    g.predict_flow(torch.nn.Conv2d(32, 2, 3, 1, 1), ("ic", 0, 1), "flow1")
+    g.output("flow1")
+    g.build()
+    convs = [op for op in g.ops if op["kind"] == "conv"]
+    assert [bool(op.get("finalized")) for op in convs] == [True, True, False, False, False]
+    d1, d2 = convs[1]["bwd"].launch.desc, convs[2]["bwd"].launch.desc
+    # conv 1's transposed launch is `a`'s only contribution: planes + mask, no sum
+    assert d1.out_planes == convs[0]["gz"].t.data_ptr() and d1.mask == g.bufs["a"].planes.t.data_ptr() and not d1.add and not d1.out_f32
+    # conv 2's is the LAST of two contributions to cat[0:2] (conv 4's came first in the backward): it adds the sum and finalises
+    assert d2.out_planes == convs[1]["gz"].t.data_ptr() and d2.add == g.bufs["cat"].grad.t.data_ptr() and not d2.out_f32
+    assert d2.mask == g.bufs["cat"].planes.t.data_ptr() and d2.mask_chunk0 == 0
+    # the others still accumulate into their source's float32 sum
+    for op in (convs[0], convs[3], convs[4]):
+        d = op["bwd"].launch.desc
+        assert d.out_f32 and not d.out_planes
+    monkeypatch.setenv("UFR_GRAPH_FUSE_FINALIZE", "0")
+    g0 = PlaneGraph(1, "cpu")
+    g0.buffer("in0", 8, 8, 1); g0.buffer("a", 8, 8, 2); g0.buffer("b", 8, 8, 2)
+    g0.input("in0", 6)
+    g0.conv(*conv(6, 64), ("in0", 0, 1), ("a", 0))
+    g0.conv(*conv(64, 64), ("a", 0, 2), ("b", 0))
+    g0.build()
+    assert not any(op.get("finalized") for op in g0.ops)
