@@ -306,6 +306,14 @@ int ufr_cm_norm_backward(const float* x, const float* G, const void* outmask, in
                          ufr_stream_t stream);
 int ufr_cm_masked_copy(const float* G, const void* outmask, long mask_elem_offset, float* out, long elems, ufr_stream_t stream);
 
+/* ---- PWC-Net conv1a straight from the raw frames (csrc/small_cin_conv.hip) ---------------------------------------------------
+ * replaces Conv2d(3, N <= 32, 3, stride 2, padding 1) + LeakyReLU(slope) of models/PWCNet.py:55-60, :235 on NCHW float32 frames
+ * [n, 3, H, W] (H, W even): out planes chunk `out_chunk0` = split(leaky(conv + bias)) at [n, H/2, W/2]; weight [N][3][3][3] float32 (the
+ * caller folds the RGB -> BGR flip of PWCNet.py:230-231 into it).  The chunk's channels >= 8 ceil(N / 8) are NOT written: the planes
+ * must hold zeros there (as allocated). */
+int ufr_conv3x3s2_c3_planes(const float* frames, const float* weight, const float* bias, float slope, void* out_planes,
+                            long plane_stride, int out_chunk0, int n, int N, int H, int W, ufr_stream_t stream);
+
 /* ---- PWC-Net backward warp ----------------------------------------------------------------------
  * replaces PWCDCNet.warp (models/PWCNet.py:164-204): grid from the flow (normalised with W-1, sampled with
  * align_corners=False, as the reference does), bilinear grid_sample with zero padding, times the validity mask

@@ -216,3 +216,27 @@ def test_stage_input_cat_kernels(B, F, H, W):
     with pytest.raises(RuntimeError, match="out of order"):
         L.check(L.lib().ufr_nchw_cat_to_planes(ptrs, chans, (C.c_int * 4)(0, 80, 83, 96), 4, L.ptr(planes.t), planes.plane_stride, 1, chunks,
                                                B, H, W, L.stream()))
+
+
+@pytest.mark.parametrize("n,N,H,W", [(2, 16, 64, 128), (16, 16, 384, 1280), (3, 16, 34, 70), (1, 24, 16, 18)])
+def test_conv1a_direct_kernel_vs_float64(n, N, H, W):
+    """`ufr_conv3x3s2_c3_planes` (PWC-Net's conv1a from the raw frames, csrc/small_cin_conv.hip) against float64
+    conv2d + LeakyReLU: within 3x torch-float32's own error; the chunk's padding channels stay zero."""
+    import torch.nn.functional as F
+    from understanding_flow_robustness_amd import _lib as L
+    from understanding_flow_robustness_amd import igemm as ig
+    g = torch.Generator().manual_seed(n * H + W)
+    x = (torch.rand(n, 3, H, W, generator=g) * 2 - 1).to(DEV)
+    w = (torch.randn(N, 3, 3, 3, generator=g) * 0.3).to(DEV)
+    b = (torch.randn(N, generator=g) * 0.1).to(DEV)
+    out = ig.Planes(n, H // 2, W // 2, 1, DEV)
+    L.check(L.lib().ufr_conv3x3s2_c3_planes(L.ptr(x), L.ptr(w), L.ptr(b), 0.1, L.ptr(out.t), out.plane_stride, 0, n, N, H, W, L.stream()),
+            "conv1a direct")
+    got = out.to_nchw(32, 0).double()
+    want = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1), 0.1)
+    t32 = F.leaky_relu(F.conv2d(x, w, b, stride=2, padding=1), 0.1).double()
+    scale = float(want.abs().max())
+    err, err_t = float((got[:, :N] - want).abs().max()) / scale, float((t32 - want).abs().max()) / scale
+    print(f"conv1a direct {n}x{H}x{W} -> {N}: kernel {err:.2e}, torch fp32 {err_t:.2e} (vs float64)")
+    assert err <= max(3 * err_t, 2e-6)
+    assert float(got[:, N:].abs().max()) == 0.0

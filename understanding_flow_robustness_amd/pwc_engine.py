@@ -22,6 +22,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import os
+
 import torch
 from ._lib import engine_cache as _engine_cache
 
@@ -98,6 +100,10 @@ class _PyramidPrefix:
                 stride = 2 if i in (0, 3) else 1
                 kw = dict(out_f32=self.G_x) if i == 0 else dict(out_planes=self.gz[i], mask=acts[i])
                 plans.append(("bwd", i, ig.conv_backward_weights(wgt, stride, 1), self.gz[i + 1], dims[lv[i + 1]], dims[lv[i]], kw))
+        conv1a = getattr(net, names[0])[0]
+        self._w1a = conv1a.weight.detach().flip(1).float().contiguous()              # [16, 3 (BGR order folded), 3, 3]
+        self._b1a = conv1a.bias.detach().float().contiguous()
+        self._direct1a = os.environ.get("UFR_PWC_CONV1A_DIRECT", "1") != "0" and h % 2 == 0 and w % 2 == 0 and self._w1a.shape[0] <= 32
         sized = []
         for kind, i, wi, x, rows, out_hw, kw in plans:
             kw["variant"] = eng._variant_for(wi)
@@ -116,8 +122,14 @@ class _PyramidPrefix:
     @torch.no_grad()
     def forward(self, frames: torch.Tensor) -> ig.Planes:
         """Level-2 features (planes) of the frame stack [n, 3, h, w]."""
-        self.x.load_nchw(frames.contiguous(), 0)
-        for i in range(6):
+        if self._direct1a:            # conv1a straight from the raw frames (3 of 32 K channels and 16 of 64 columns are real on the igemm)
+            L.check(L.lib().ufr_conv3x3s2_c3_planes(L.ptr(frames.contiguous()), L.ptr(self._w1a), L.ptr(self._b1a), ig.LEAKY, L.ptr(self.a1.t),
+                                                    self.a1.plane_stride, 0, self.n, self._w1a.shape[0], self.h, self.w, L.stream()),
+                    "conv1a (direct)")
+        else:
+            self.x.load_nchw(frames.contiguous(), 0)
+            self.fwd[0]()
+        for i in range(1, 6):
             self.fwd[i]()
         return self.f2
 
