@@ -314,6 +314,12 @@ int ufr_cm_masked_copy(const float* G, const void* outmask, long mask_elem_offse
 int ufr_conv3x3s2_c3_planes(const float* frames, const float* weight, const float* bias, float slope, void* out_planes,
                             long plane_stride, int out_chunk0, int n, int N, int H, int W, ufr_stream_t stream);
 
+/* conv1aa / conv1b: Conv2d(16, 16, 3, 1, 1) + LeakyReLU(slope) on activation planes (channels 0-15 of chunk in_chunk0 -> channels 0-15 of
+ * chunk out_chunk0 at the same [n, H, W]; channels 16-31 of the output chunk are NOT written).  weight_ct16 = the weight permuted to
+ * [16 input channels][9 taps][16 outputs] float32 (PWCNet.py:56-57). */
+int ufr_conv3x3_c16_planes(const void* in_planes, long in_plane_stride, int in_chunk0, const float* weight_ct16, const float* bias,
+                           float slope, void* out_planes, long out_plane_stride, int out_chunk0, int n, int H, int W, ufr_stream_t stream);
+
 /* ---- PWC-Net backward warp ----------------------------------------------------------------------
  * replaces PWCDCNet.warp (models/PWCNet.py:164-204): grid from the flow (normalised with W-1, sampled with
  * align_corners=False, as the reference does), bilinear grid_sample with zero padding, times the validity mask

@@ -240,3 +240,29 @@ def test_conv1a_direct_kernel_vs_float64(n, N, H, W):
     print(f"conv1a direct {n}x{H}x{W} -> {N}: kernel {err:.2e}, torch fp32 {err_t:.2e} (vs float64)")
     assert err <= max(3 * err_t, 2e-6)
     assert float(got[:, N:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n,H,W", [(2, 32, 64), (16, 192, 640), (3, 17, 35), (1, 8, 33)])
+def test_conv16_direct_kernel_vs_float64(n, H, W):
+    """`ufr_conv3x3_c16_planes` (conv1aa / conv1b of PWC-Net's pyramid on planes) against float64 conv2d + LeakyReLU: within 3x
+    torch-float32's own error; the output chunk's channels 16-31 are left as they were (zeros)."""
+    import torch.nn.functional as F
+    from understanding_flow_robustness_amd import _lib as L
+    from understanding_flow_robustness_amd import igemm as ig
+    g = torch.Generator().manual_seed(n * H + W)
+    x = (torch.randn(n, 16, H, W, generator=g)).to(DEV)
+    w = (torch.randn(16, 16, 3, 3, generator=g) * 0.1).to(DEV)
+    b = (torch.randn(16, generator=g) * 0.1).to(DEV)
+    src, dst = ig.Planes(n, H, W, 1, DEV), ig.Planes(n, H, W, 1, DEV)
+    src.load_nchw(x, 0)
+    wt = w.permute(1, 2, 3, 0).reshape(16, 9, 16).contiguous()
+    L.check(L.lib().ufr_conv3x3_c16_planes(L.ptr(src.t), src.plane_stride, 0, L.ptr(wt), L.ptr(b), 0.1, L.ptr(dst.t), dst.plane_stride, 0,
+                                           n, H, W, L.stream()), "conv16 direct")
+    got = dst.to_nchw(32, 0).double()
+    want = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=1), 0.1)
+    t32 = F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.1).double()
+    scale = float(want.abs().max())
+    err, err_t = float((got[:, :16] - want).abs().max()) / scale, float((t32 - want).abs().max()) / scale
+    print(f"conv 16 -> 16 direct {n}x{H}x{W}: kernel {err:.2e}, torch fp32 {err_t:.2e} (vs float64)")
+    assert err <= max(3 * err_t, 2e-6)
+    assert float(got[:, 16:].abs().max()) == 0.0

@@ -154,6 +154,7 @@ SIGNATURES = {
     "ufr_unshuffle_pack_planes": [_vp, _vp, _l, _i, _i, _i, _i, _vp],
     "ufr_unshuffle_unpack_grad": [_vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_conv3x3s2_c3_planes": [_vp, _vp, _vp, _f, _vp, _l, _i, _i, _i, _i, _i, _vp],
+    "ufr_conv3x3_c16_planes": [_vp, _l, _i, _vp, _vp, _f, _vp, _l, _i, _i, _i, _i, _vp],
     "ufr_cm_norm_stats": [_vp, _vp, _vp, _l, _i, _i, _f, _vp],
     "ufr_cm_norm_apply": [_vp, _vp, _vp, _l, _i, _vp, _l, _i, _l, _i, _i, _i, _i, _vp],
     "ufr_cm_norm_stats_apply": [_vp, _vp, _vp, _f, _vp, _l, _i, _vp, _l, _i, _l, _i, _i, _i, _i, _vp],

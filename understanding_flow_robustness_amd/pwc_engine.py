@@ -103,7 +103,15 @@ class _PyramidPrefix:
         conv1a = getattr(net, names[0])[0]
         self._w1a = conv1a.weight.detach().flip(1).float().contiguous()              # [16, 3 (BGR order folded), 3, 3]
         self._b1a = conv1a.bias.detach().float().contiguous()
-        self._direct1a = os.environ.get("UFR_PWC_CONV1A_DIRECT", "1") != "0" and h % 2 == 0 and w % 2 == 0 and self._w1a.shape[0] <= 32
+        direct = os.environ.get("UFR_PWC_PYRAMID_DIRECT", "1") != "0"
+        self._direct1a = direct and h % 2 == 0 and w % 2 == 0 and self._w1a.shape[0] <= 32
+        # conv1aa / conv1b (16 -> 16 at half resolution: 12 % of their implicit GEMM is real work): [16 c][9 taps][16 o] weights
+        self._direct16 = {}
+        for i in (1, 2):
+            c16 = getattr(net, names[i])[0]
+            if direct and tuple(c16.weight.shape) == (16, 16, 3, 3):
+                self._direct16[i] = (c16.weight.detach().float().permute(1, 2, 3, 0).reshape(16, 9, 16).contiguous(),
+                                     c16.bias.detach().float().contiguous())
         sized = []
         for kind, i, wi, x, rows, out_hw, kw in plans:
             kw["variant"] = eng._variant_for(wi)
@@ -129,8 +137,15 @@ class _PyramidPrefix:
         else:
             self.x.load_nchw(frames.contiguous(), 0)
             self.fwd[0]()
+        acts = (self.x, self.a1, self.aa1, self.b1)
         for i in range(1, 6):
-            self.fwd[i]()
+            if i in self._direct16:
+                wt, b = self._direct16[i]
+                src, dst = acts[i], acts[i + 1]
+                L.check(L.lib().ufr_conv3x3_c16_planes(L.ptr(src.t), src.plane_stride, 0, L.ptr(wt), L.ptr(b), ig.LEAKY, L.ptr(dst.t),
+                                                       dst.plane_stride, 0, self.n, src.H, src.W, L.stream()), "conv 16 -> 16 (direct)")
+            else:
+                self.fwd[i]()
         return self.f2
 
     @torch.no_grad()
