@@ -83,8 +83,9 @@ int ufr_altcorr_backward(const float* fmap1, const float* fmap2, const float* co
  * (csrc/raft_altcorr_mfma.hip).  coords: [B,2,H1,W1] planar (x, y) as RAFT holds them; level l uses coords * coord_scale[l];
  * out / grad_out: [B, L*(2r+1)^2, H1, W1] = scale * the stacked per-level volumes.  C in {128, 256}, radius in {3, 4}, N = 1.
  * backward: fmap1_grad [B,H1,W1,C] and every fmap2_grad[l] [B,H2,W2,C]; accumulate != 0 adds onto the buffers (RAFT's 12
- * lookups share them).  fmap2_grad of a level whose segments are split over workgroups is added with float atomics (the
- * coarse levels); everything else has one writer per element.  workspace: ufr_altcorr_pyramid_workspace_bytes() bytes of
+ * lookups share them).  fmap2_grad of a level whose segments are split over workgroups (the coarse levels) is the fixed-order sum of
+ * the parts' slabs in the workspace (round 4: no float atomics, bit-reproducible); everything else has one writer per element.
+ * The levels must be no larger than RAFT's pooled pyramid (H2[l] <= ceil(H1 / 2^l)): the workspace is sized for that.  workspace: ufr_altcorr_pyramid_workspace_bytes() bytes of
  * device memory (per-pixel window origins and blend adjoints, the tiles' boxes, per-level partial sums). */
 typedef struct {
   int num_levels;

@@ -15,6 +15,7 @@
 //             tiles' boxes for the tiles that reach them and accumulates gs^T fmap1 in registers
 // (the reference's kernels do one 4 x 8 pixel block per workgroup with a serial channel loop; round 2's form here was one
 // workgroup per pixel on the vector ALU: 0.026 of the fp32 peak, 43x the algorithmic bytes through L2).
+#include <cstdlib>
 #include <climits>
 #include <cstdint>
 
@@ -33,6 +34,7 @@ struct AcLevels {                            // by value in the kernel arguments
   float cscale[4];                           // coords are multiplied by this (1 / 2^l, corr.py:126)
   int tile0[5];                              // d/d fmap2: first workgroup of each level's fmap2 tiles
   int split[4];                              // d/d fmap2: workgroups per fmap2 tile (each scans a slice of the pixel tiles)
+  float* p2[4];                              // d/d fmap2 of a split level: its parts' sums [split][B, H2, W2, C] (workspace)
 };
 
 struct PixelWindow {
@@ -303,7 +305,9 @@ __global__ void altcorr_sum_levels(const float* __restrict__ part, float* __rest
 // A workgroup owns fmap2 pixels (hy, xq0 .. xq0 + 15) of one level and (a slice of) the pixel tiles; wave = channel quarter.
 // For every pixel tile whose box contains the segment: acc[q, c] += sum_p gs[p, q] fmap1[p, c].  split == 1: one writer per
 // element (read-add-store: deterministic); split > 1 (the coarse levels, where 12-36 segments would otherwise serialise all
-// of the tiles): float atomics for the final add.
+// of the tiles): every part stores ITS sum into its own slab of the workspace (one writer per element, no atomics -- float atomics
+// retire at ~28 G lanes/s on this chip and made finer splits SLOWER, gpurun r4_call70), `altcorr_sum_parts` adds the slabs in
+// ascending order afterwards: the gradient is bit-reproducible and the coarse levels can be cut as fine as their balance asks.
 template <int R, int CPG>
 __global__ __launch_bounds__(256) void altcorr_mfma_bwd2(const float* __restrict__ f1, const AcLevels lv,
                                                          const float* __restrict__ gs_all, const int* __restrict__ win,
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(256) void altcorr_mfma_bwd2(const float* __restrict
         for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bvv[kk][nt], acc[nt], 0, 0, 0);
     }
   }
-  float* g2 = lv.g2[l];
+  float* g2 = split > 1 ? lv.p2[l] + (size_t)part * B * H2 * W2 * C : lv.g2[l];
 #pragma unroll
   for (int r4 = 0; r4 < 4; ++r4) {
     const int q = xq0 + 4 * g + r4;
@@ -373,8 +377,30 @@ __global__ __launch_bounds__(256) void altcorr_mfma_bwd2(const float* __restrict
     float* op = g2 + (((size_t)b * H2 + hy) * W2 + q) * C + wave * CPG + pi * NT;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      if (split > 1) atomicAdd(op + nt, acc[nt][r4]);          // (the buffer was zeroed or holds the running sum)
+      if (split > 1) op[nt] = acc[nt][r4];                     // this part's slab: summed by altcorr_sum_parts
       else op[nt] = (accumulate ? op[nt] : 0.f) + acc[nt][r4];
+    }
+  }
+}
+
+// g2 (+)= parts[0] + parts[1] + ... in ascending order, for every level whose segments were split
+__global__ void altcorr_sum_parts(const AcLevels lv, int B, int C4, int accumulate) {
+  for (int l = 0; l < lv.n; ++l) {
+    const int S = lv.split[l];
+    if (S <= 1) continue;
+    const long n4 = (long)B * lv.H2[l] * lv.W2[l] * C4;
+    const float4* parts = reinterpret_cast<const float4*>(lv.p2[l]);
+    float4* g = reinterpret_cast<float4*>(lv.g2[l]);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+      float4 v = accumulate ? g[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int p0 = 0; p0 < S; p0 += 8) {                      // eight slabs in flight, added in ascending order
+        float4 a[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = p0 + k < S ? parts[(long)(p0 + k) * n4 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v.x += a[k].x; v.y += a[k].y; v.z += a[k].z; v.w += a[k].w; }
+      }
+      g[i] = v;
     }
   }
 }
@@ -387,12 +413,34 @@ int launch_fwd(const float* f1, const AcLevels& lv, const float* coords, int pla
   return ufr::launched("altcorr_mfma_fwd");
 }
 
-// workspace layout (bytes): gs_all f32 [L][npix][npt] | part f32 [L][npix][C] | win i32 [L][npix][2] | boxes i32 [L][ntiles][4]
+// workspace layout (bytes): gs_all f32 [L][npix][npt] | part f32 [L][npix][C] | win i32 [L][npix][2] | boxes i32 [L][ntiles][4] |
+// per split level: the parts' slabs f32 [split][B, H2, W2, C]
 struct AcWorkspace { float* gs_all; float* part; int* win; int* boxes; };
+
+// d/d fmap2: workgroups per 16-pixel segment of level l.  First fill the chip (a segment of level l is reached by ~4^l times as
+// many pixel tiles as one of level 0); then, since the kernel lasts as long as its busiest workgroup -- a level-l segment collects
+// ~4^l x 25 tile hits of ~1 us each, a dependent window -> gradient gather per hit -- the coarse levels are cut finer still,
+// up to 2 x 4^l parts while the launch stays below 2048 workgroups per level.
+int want_split(int l) { return l > 0 ? min(64, 2 << (2 * l)) : 1; }
+int split_for(int l, int segs, int tiles_b) {
+  int split = 1;
+  while (segs * split < 256 && split * 2 <= tiles_b / 8 && split < 64) split *= 2;
+  while (split < want_split(l) && segs * split < 2048 && split * 2 <= tiles_b) split *= 2;
+  return split;
+}
+
+// upper bound of the parts' slabs of level l (pixels): H2 <= ceil(H1 / 2^l) for RAFT's average-pooled pyramid
+long parts_pixels_bound(int l, int B, int H1, int W1) {
+  const long H2 = (H1 + (1 << l) - 1) >> l, W2 = (W1 + (1 << l) - 1) >> l;
+  const long by_want = want_split(l) > 1 ? min((long)want_split(l) * B * H2 * W2, 2L * 2048 * 16) : 0;   // split * segs < 2 * 2048 under the second rule
+  return max(512L * 16, by_want) + 64;                                              // split * segs < 512 under the first
+}
 
 long workspace_bytes(int B, int H1, int W1, int C, int radius, int levels) {
   const long npix = (long)B * H1 * W1, ntiles = (long)B * H1 * ((W1 + AC_TP - 1) / AC_TP), npt = (2L * radius + 2) * (2 * radius + 2);
-  return 4 * (levels * npix * npt + levels * npix * C + levels * npix * 2 + levels * ntiles * 4 + 64);
+  long parts = 0;
+  for (int l = 0; l < levels; ++l) parts += parts_pixels_bound(l, B, H1, W1) * C;
+  return 4 * (levels * npix * npt + levels * npix * C + levels * npix * 2 + levels * ntiles * 4 + 256 + parts);
 }
 
 template <int R, int CPG>
@@ -419,23 +467,34 @@ int launch_bwd(const float* f1, AcLevels lv, const float* coords, int planar, co
   rc = ufr::launched("altcorr_sum_levels");
   if (rc != UFR_OK) return rc;
   int total = 0;
+  float* parts = reinterpret_cast<float*>(ws.boxes + (long)lv.n * B * tiles_b * 4 + 16);     // behind the boxes [L][B * tiles_b][4]
+  parts += (4 - ((reinterpret_cast<uintptr_t>(parts) / 4) & 3)) & 3;                  // 16-byte aligned slabs
+  long max_n4 = 0;
+  bool any_split = false;
   for (int l = 0; l < lv.n; ++l) {
     const int segs = B * lv.H2[l] * ((lv.W2[l] + 15) / 16);
-    // a segment of level l is reached by ~4^l times as many pixel tiles as one of level 0: spread them over workgroups
-    int split = 1;
-    while (segs * split < 256 && split * 2 <= tiles_b / 8 && split < 64) split *= 2;
+    const int split = split_for(l, segs, tiles_b);
     lv.tile0[l] = total;
     lv.split[l] = split;
+    lv.p2[l] = nullptr;
     total += segs * split;
-    if (split > 1 && !accumulate) {               // atomics add onto the buffer: start from zero
-      hipError_t e = hipMemsetAsync(lv.g2[l], 0, sizeof(float) * (size_t)B * lv.H2[l] * lv.W2[l] * C, st);
-      if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "altcorr backward: memset: %s", hipGetErrorString(e));
+    if (split > 1) {
+      const long px = (long)B * lv.H2[l] * lv.W2[l];
+      UFR_REQUIRE((long)split * px <= parts_pixels_bound(l, B, H1, W1), "altcorr backward: level %d (%d x %d) is larger than a pooled level of a %d x %d map",
+                  l, lv.H2[l], lv.W2[l], H1, W1);
+      lv.p2[l] = parts;
+      parts += (long)split * px * C;
+      max_n4 = max(max_n4, px * (C / 4));
+      any_split = true;
     }
   }
   lv.tile0[lv.n] = total;
   for (int l = lv.n + 1; l < 5; ++l) lv.tile0[l] = total;
   altcorr_mfma_bwd2<R, CPG><<<total, 256, 0, st>>>(f1, lv, ws.gs_all, ws.win, ws.boxes, B, H1, W1, accumulate);
-  return ufr::launched("altcorr_mfma_bwd2");
+  rc = ufr::launched("altcorr_mfma_bwd2");
+  if (rc != UFR_OK || !any_split) return rc;
+  altcorr_sum_parts<<<ufr::stream_grid(max_n4, 256), 256, 0, st>>>(lv, B, C / 4, accumulate);
+  return ufr::launched("altcorr_sum_parts");
 }
 
 bool mfma_form_serves(int C, int radius) { return (C == 256 || C == 128) && (radius == 4 || radius == 3); }
