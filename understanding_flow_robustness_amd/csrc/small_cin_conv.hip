@@ -12,6 +12,7 @@
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 __device__ __forceinline__ void split3(float v, __bf16& a, __bf16& b, __bf16& c) {
   a = (__bf16)v;
@@ -114,18 +115,22 @@ __global__ __launch_bounds__(256) void conv3x3_c16_planes_kernel(const __bf16* _
   __syncthreads();
   const int ly = threadIdx.x >> 5, lx = threadIdx.x & 31;
   const int yo = y0 + ly, xo = x0 + lx;
-  float acc[16];
+  f32x2 acc2[8];                                                    // packed FMAs (v_pk_fma_f32): two output channels per instruction
 #pragma unroll
-  for (int o = 0; o < 16; ++o) acc[o] = 0.f;
+  for (int o = 0; o < 8; ++o) acc2[o] = f32x2{0.f, 0.f};
   for (int c = 0; c < 16; ++c) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const float v = tile[c][(ly + t / 3) * (SC_TW + 2) + lx + t % 3];
-      const float* w = wt + (c * 9 + t) * 16;                       // wave-uniform: scalar loads
+      const f32x2 vv = {v, v};
+      const f32x2* w = reinterpret_cast<const f32x2*>(wt + (c * 9 + t) * 16);      // wave-uniform: scalar loads
 #pragma unroll
-      for (int o = 0; o < 16; ++o) acc[o] = fmaf(v, w[o], acc[o]);
+      for (int o = 0; o < 8; ++o) acc2[o] = __builtin_elementwise_fma(vv, w[o], acc2[o]);
     }
   }
+  float acc[16];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) { acc[2 * o] = acc2[o][0]; acc[2 * o + 1] = acc2[o][1]; }
   if (yo < H && xo < W) {
     const long m = ((long)b * H + yo) * W + xo;
 #pragma unroll
