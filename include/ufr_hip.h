@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define UFR_ABI_VERSION 6   /* 6: ufr_igemm_desc gained planes_chunks / f32_first_chunk; the clock probe records 8 words (round 4); 5: ufr_igemm_desc gained out_rowmajor / out_ld; ufr_igemm_clock_probe, ufr_conv1_direct, ufr_patch_paste_placed_rect (round 4); 4: ufr_igemm_desc gained tail / tail_n0 (round 3); 3: k_order (round 2) */
+#define UFR_ABI_VERSION 7   /* 7: the chunk-range entries of csrc/engine_small.hip take the extents of what they walk (w_chunks / g_chunks) and refuse a range that leaves it (round 5); 6: ufr_igemm_desc gained planes_chunks / f32_first_chunk; the clock probe records 8 words (round 4); 5: ufr_igemm_desc gained out_rowmajor / out_ld; ufr_igemm_clock_probe, ufr_conv1_direct, ufr_patch_paste_placed_rect (round 4); 4: ufr_igemm_desc gained tail / tail_n0 (round 3); 3: k_order (round 2) */
 
 enum { UFR_F32 = 0, UFR_F64 = 1, UFR_F16 = 2 };   /* UFR_F16: the spatial correlation only (generic kernels, float32 sums) */
 enum {
@@ -639,36 +639,41 @@ int ufr_corr_forward_planes(const void* f1_planes, const void* f2_planes, long i
  * to) the fp32 gradient sum G [.. chunks][B*H*W][32].  upsampled_flow* = ConvTranspose2d(2,2,4,2,1) (:48-50) writes its
  * two channels (+ 30 zeros) into chunk `chunk` of the concatenation at twice the resolution; its data gradient reads
  * channels 0-1 of that chunk of the fp32 gradient sum. */
-int ufr_flow_head_planes_forward(const void* planes, long plane_stride, int chunk0, int chunks, const float* wpk,
+/* ABI 7: every entry of this group that walks a chunk range knows the extent of what it walks and REFUSES (UFR_EINVAL +
+ * ufr_last_error) a range that leaves it, instead of reading or writing past the end: a planes operand holds
+ * plane_stride / (pixels * 32) chunks per plane, so chunk0 + chunks must fit in plane_stride; `w_chunks` = the chunks the packed
+ * weights hold (chunks <= w_chunks: the weights are indexed by the position inside the range); `g_chunks` = the chunks of the
+ * float32 gradient sum G (chunk0 + chunks <= g_chunks, out_chunk < g_chunks). */
+int ufr_flow_head_planes_forward(const void* planes, long plane_stride, int chunk0, int chunks, const float* wpk, int w_chunks,
                                  const float* bias, float* out, int B, int H, int W, ufr_stream_t stream);
 /* The same convolution on the matrix cores: a per-pixel GEMM T[p, 2k + o] = sum_c x[p, c] w[o, c, k] (float32 = six bf16
  * products, as ufr_igemm) whose A operand is the plane layout as it lies in HBM, then the 9-tap gather through LDS.
  * wmf: bf16 [chunks][3][2][16][32] (plane p of w[o][32 ch + c][k] at n = 2k + o, zeros for n >= 18). */
-int ufr_flow_head_planes_forward_mfma(const void* planes, long plane_stride, int chunk0, int chunks, const void* wmf,
+int ufr_flow_head_planes_forward_mfma(const void* planes, long plane_stride, int chunk0, int chunks, const void* wmf, int w_chunks,
                                       const float* bias, float* out, int B, int H, int W, ufr_stream_t stream);
 /* The two flow channels of a ConvTranspose2d(Cin, Cout, 4, 2, 1) data gradient (models/FlowNetC.py:162-183: the last two
  * input channels of deconvK are the upsampled flow), same per-pixel GEMM + gather: grad_planes = the masked output gradient
  * on the fine grid [2H, 2W] (chunks chunk0 .. chunk0 + chunks), wmf as above with n = 2 (4 ky + kx) + o for the weights
  * w[Cin - 2 + o][c][ky][kx]; writes lanes 0-1 of chunk `out_chunk` of the coarse grid's [H, W] float32 gradient sum G. */
 int ufr_deconv_flow_tail_backward_mfma(const void* grad_planes, long plane_stride, int chunk0, int chunks, const void* wmf,
-                                       float* G, int out_chunk, int B, int H, int W, ufr_stream_t stream);
-int ufr_flow_head_planes_backward(const float* grad_y, const float* wpk, float* G, int chunk0, int chunks, int B, int H,
-                                  int W, int accumulate, ufr_stream_t stream);
+                                       int w_chunks, float* G, int g_chunks, int out_chunk, int B, int H, int W, ufr_stream_t stream);
+int ufr_flow_head_planes_backward(const float* grad_y, const float* wpk, int w_chunks, float* G, int g_chunks, int chunk0, int chunks,
+                                  int B, int H, int W, int accumulate, ufr_stream_t stream);
 /* The same with the finalisation of one segment fused (round 4): for the chunks [fin_chunk0, fin_chunk0 + fin_chunks) of the
  * tensor the completed sum x LeakyReLU'(mask_planes plane 0; NULL = linear) also leaves as the three gradient planes `out_planes`
  * (same chunk positions) -- what ufr_grad_finalize did in a launch of its own (FlowNetC's refinement, models/FlowNetC.py:162-183:
  * predict_flowK's adjoint is the last contributor to deconvK's output gradient). */
-int ufr_flow_head_planes_backward_finalize(const float* grad_y, const float* wpk, float* G, int chunk0, int chunks, int B, int H, int W,
-                                           int accumulate, const void* mask_planes, void* out_planes, long out_plane_stride,
-                                           int fin_chunk0, int fin_chunks, float slope, ufr_stream_t stream);
+int ufr_flow_head_planes_backward_finalize(const float* grad_y, const float* wpk, int w_chunks, float* G, int g_chunks, int chunk0,
+                                           int chunks, int B, int H, int W, int accumulate, const void* mask_planes, void* out_planes,
+                                           long out_plane_stride, int fin_chunk0, int fin_chunks, float slope, ufr_stream_t stream);
 /* PWC-Net's `upfeat*` = ConvTranspose2d(C, 2, 4, 2, 1) (models/PWCNet.py:115-143, used at :284,:299,:314,:329) on the engine's planes:
  * forward from `chunks` chunks of the COARSE [B,H,W] planes to out [B,2,2H,2W] (NCHW fp32, + bias) on the matrix cores
  * (wmf: bf16 [chunks][3][2][16][32] with n = 2 (4 ky + kx) + o); backward from grad_y [B,2,2H,2W] into the coarse gradient
  * sum G[chunk0 ..][B*H*W][32] (wpk: fp32 [chunks][16][2][32]; accumulate != 0 adds). */
-int ufr_upfeat_planes_forward_mfma(const void* planes, long plane_stride, int chunk0, int chunks, const void* wmf,
+int ufr_upfeat_planes_forward_mfma(const void* planes, long plane_stride, int chunk0, int chunks, const void* wmf, int w_chunks,
                                    const float* bias, float* out, int B, int H, int W, ufr_stream_t stream);
-int ufr_upfeat_planes_backward(const float* grad_y, const float* wpk, float* G, int chunk0, int chunks, int B, int H, int W,
-                               int accumulate, ufr_stream_t stream);
+int ufr_upfeat_planes_backward(const float* grad_y, const float* wpk, int w_chunks, float* G, int g_chunks, int chunk0, int chunks,
+                               int B, int H, int W, int accumulate, ufr_stream_t stream);
 int ufr_flow_up_planes_forward(const float* x, const float* w, const float* bias, void* planes, long plane_stride,
                                int chunk, int B, int H, int W, ufr_stream_t stream);
 int ufr_flow_up_planes_backward(const float* G, int chunk, const float* w, float* grad_x, int B, int H, int W,

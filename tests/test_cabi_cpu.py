@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_error_channel():
     from understanding_flow_robustness_amd import _lib as L
     lib = L.lib()
-    assert lib.ufr_abi_version() == 6 == L.ABI_VERSION
+    assert lib.ufr_abi_version() == 7 == L.ABI_VERSION
     assert lib.ufr_device_count() >= 0
     # argument validation happens before any HIP call: usable without a GPU
     p = L.CorrParams(1, 1, 3, 3, 0, 0, 1, 1, 1, 1, 1, 1)
@@ -45,6 +45,36 @@ def test_abi_version_and_error_channel():
     assert rc == -1
     rc = lib.ufr_flow_loss(None, None, None, None, 1, 1, 0, 1.0, None, None)
     assert rc == -1
+
+
+def test_chunk_ranges_that_leave_their_buffers_are_refused_before_any_launch():
+    """ABI 7 (tools/bench_pf.py launched 16 chunks on a 13-chunk planes buffer and the kernel read past its end, a GPU
+    memory-access fault): the chunk-range entries of csrc/engine_small.hip know the extents of what they walk -- the planes
+    operand (plane_stride / (pixels * 32) chunks per plane), the packed weights (w_chunks), the float32 gradient sum (g_chunks) --
+    and refuse a range that leaves any of them.  Validation precedes every HIP call, so this runs without a GPU; the pointers are
+    never dereferenced."""
+    from understanding_flow_robustness_amd import _lib as L
+    lib = L.lib()
+    p = ctypes.c_void_p(4096)
+    B, H, W, total = 8, 48, 160, 13                      # the faulting launch: 13-chunk buffer of the 48 x 160 grid, 8 frames
+    stride = total * B * H * W * 32
+    refused = [
+        lib.ufr_flow_head_planes_forward_mfma(p, stride, 0, 16, p, 16, p, p, B, H, W, None),       # the planes hold 13
+        lib.ufr_flow_head_planes_forward_mfma(p, stride, 3, 11, p, 16, p, p, B, H, W, None),       # [3, 14) of 13
+        lib.ufr_flow_head_planes_forward_mfma(p, stride, 0, 13, p, 12, p, p, B, H, W, None),       # the weights hold 12
+        lib.ufr_flow_head_planes_forward(p, stride, 0, 16, p, 16, p, p, B, H, W, None),
+        lib.ufr_upfeat_planes_forward_mfma(p, stride, 0, 16, p, 16, p, p, B, H, W, None),
+        lib.ufr_deconv_flow_tail_backward_mfma(p, stride, 0, 14, p, 14, p, 4, 0, B, H // 2, W // 2, None),   # fine grid = 48 x 160
+        lib.ufr_deconv_flow_tail_backward_mfma(p, stride, 0, 13, p, 13, p, 4, 4, B, H // 2, W // 2, None),   # out_chunk 4 of 4
+        lib.ufr_flow_head_planes_backward(p, p, 13, p, 13, 1, 13, B, H, W, 0, None),               # [1, 14) of a 13-chunk sum
+        lib.ufr_flow_head_planes_backward(p, p, 12, p, 13, 0, 13, B, H, W, 0, None),
+        lib.ufr_flow_head_planes_backward_finalize(p, p, 13, p, 13, 1, 13, B, H, W, 0, p, p, stride, 0, 1, 0.1, None),
+        lib.ufr_upfeat_planes_backward(p, p, 13, p, 13, 1, 13, B, H, W, 0, None),
+    ]
+    assert refused == [-1] * len(refused), refused
+    assert b"chunks" in lib.ufr_last_error() or b"chunk" in lib.ufr_last_error()
+    rc = lib.ufr_flow_head_planes_forward_mfma(p, stride, 0, 16, p, 16, p, p, B, H, W, None)
+    assert rc == -1 and b"leave the planes operand (13 chunks per plane)" in lib.ufr_last_error()
 
 
 def test_mirrors_keep_reference_names_and_signatures():

@@ -151,13 +151,13 @@ def test_flow_head_planes_kernels_vs_torch(B, C, H, W):
     pl = ig.Planes(B, H, W, chunks + 1, DEV).load_nchw(x, chunk0=1)
     wpk = _pack_flow_head(w)
     out = torch.empty(B, 2, H, W, device=DEV)
-    L.check(L.lib().ufr_flow_head_planes_forward(L.ptr(pl.t), pl.plane_stride, 1, chunks, L.ptr(wpk), L.ptr(b), L.ptr(out), B, H, W,
+    L.check(L.lib().ufr_flow_head_planes_forward(L.ptr(pl.t), pl.plane_stride, 1, chunks, L.ptr(wpk), chunks, L.ptr(b), L.ptr(out), B, H, W,
                                                  L.stream()))
     want = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
     assert _rel(out, want) <= 1e-5, f"forward {_rel(out, want):.2e}"
     # the matrix-core form (per-pixel GEMM + 9-tap gather): tile heights 8 / 4 / 2, one and two chunk slices
     out_m = torch.full((B, 2, H, W), float("nan"), device=DEV)
-    L.check(L.lib().ufr_flow_head_planes_forward_mfma(L.ptr(pl.t), pl.plane_stride, 1, chunks, L.ptr(_pack_flow_head_mfma(w)), L.ptr(b),
+    L.check(L.lib().ufr_flow_head_planes_forward_mfma(L.ptr(pl.t), pl.plane_stride, 1, chunks, L.ptr(_pack_flow_head_mfma(w)), chunks, L.ptr(b),
                                                       L.ptr(out_m), B, H, W, L.stream()))
     assert _rel(out_m, want) <= 1e-5, f"forward (mfma) {_rel(out_m, want):.2e}"
     gy = torch.randn(B, 2, H, W, generator=g).to(DEV)
@@ -165,10 +165,20 @@ def test_flow_head_planes_kernels_vs_torch(B, C, H, W):
     (gx,) = torch.autograd.grad(F.conv2d(x0, w.double(), None, 1, 1), x0, gy.double())
     G = ig.GradSum(B, H, W, chunks + 1, DEV)
     G.t.fill_(0.5)
-    L.check(L.lib().ufr_flow_head_planes_backward(L.ptr(gy), L.ptr(wpk), L.ptr(G.t), 1, chunks, B, H, W, 0, L.stream()))
+    L.check(L.lib().ufr_flow_head_planes_backward(L.ptr(gy), L.ptr(wpk), chunks, L.ptr(G.t), G.chunks, 1, chunks, B, H, W, 0, L.stream()))
     assert _rel(G.to_nchw(C, 1), gx) <= 1e-5
     assert bool((G.t[0] == 0.5).all())                                   # the neighbouring chunk is untouched
-    L.check(L.lib().ufr_flow_head_planes_backward(L.ptr(gy), L.ptr(wpk), L.ptr(G.t), 1, chunks, B, H, W, 1, L.stream()))
+    L.check(L.lib().ufr_flow_head_planes_backward(L.ptr(gy), L.ptr(wpk), chunks, L.ptr(G.t), G.chunks, 1, chunks, B, H, W, 1, L.stream()))
+    # ABI 7: a chunk range that leaves the planes / the packed weights / the gradient sum is refused, nothing is launched
+    lib = L.lib()
+    for rc in (lib.ufr_flow_head_planes_forward_mfma(L.ptr(pl.t), pl.plane_stride, 2, chunks, L.ptr(_pack_flow_head_mfma(w)), chunks,
+                                                     L.ptr(b), L.ptr(out_m), B, H, W, L.stream()),
+               lib.ufr_flow_head_planes_forward_mfma(L.ptr(pl.t), pl.plane_stride, 0, chunks + 1, L.ptr(_pack_flow_head_mfma(w)), chunks,
+                                                     L.ptr(b), L.ptr(out_m), B, H, W, L.stream()),
+               lib.ufr_flow_head_planes_forward(L.ptr(pl.t), pl.plane_stride, 2, chunks, L.ptr(wpk), chunks, L.ptr(b), L.ptr(out), B, H, W,
+                                                L.stream()),
+               lib.ufr_flow_head_planes_backward(L.ptr(gy), L.ptr(wpk), chunks, L.ptr(G.t), G.chunks, 2, chunks, B, H, W, 0, L.stream())):
+        assert rc == -1 and b"chunks" in lib.ufr_last_error()
     assert _rel(G.to_nchw(C, 1), 2 * gx) <= 1e-5
 
 
@@ -341,7 +351,7 @@ def test_deconv_flow_tail_kernel_vs_torch(B, Cout, H, W):
     G = ig.GradSum(B, H, W, 3, DEV)
     G.t.fill_(0.25)
     L.check(L.lib().ufr_deconv_flow_tail_backward_mfma(L.ptr(pl.t), pl.plane_stride, 1, chunks, L.ptr(_pack_flow_tail_mfma(w2)),
-                                                       L.ptr(G.t), 1, B, H, W, L.stream()))
+                                                       chunks, L.ptr(G.t), G.chunks, 1, B, H, W, L.stream()))
     x0 = torch.zeros(B, 2, H, W, device=DEV, dtype=torch.float64, requires_grad=True)
     (want,) = torch.autograd.grad(F.conv_transpose2d(x0, w2.double(), None, 2, 1), x0, gy.double())
     got = G.t[1].view(B, H, W, 32)

@@ -18,6 +18,30 @@ def _fetch(name, seed, **extra):
     return fetch_model(args, synthetic_seed=seed).to(DEV), args
 
 
+class _on_the_engines:
+    """The frozen leg of a golden test: the caller's parameters are frozen (as `attack()` freezes them), so every convolution
+    must run on the hand-written engines -- any route to the vendor library inside the block fails the test.  The unfrozen leg
+    (parameters that want weight gradients) is the reference's own torch spelling on MIOpen and says so once per class."""
+    def __init__(self, net, frozen):
+        self.net, self.frozen = net, frozen
+
+    def __enter__(self):
+        from understanding_flow_robustness_amd import _lib as L
+        if self.frozen:
+            self.net.requires_grad_(False)
+        self.before = dict(L.VENDOR_FALLBACKS)
+        return self
+
+    def __exit__(self, *exc):
+        from understanding_flow_robustness_amd import _lib as L
+        if self.frozen and exc[0] is None:
+            grown = {k: v - self.before.get(k, 0) for k, v in L.VENDOR_FALLBACKS.items() if v != self.before.get(k, 0)}
+            assert not grown, f"the frozen leg left the engines: {grown}"
+
+
+FROZEN = pytest.mark.parametrize("frozen", [False, True], ids=["torch_spelling", "engines"])
+
+
 def _check(z, net, args, gtol=1e-3, g_atol=3e-4):
     from understanding_flow_robustness_amd.flownets.utils_model import predict_flow
     x1, x2 = t(z["x1"], DEV).requires_grad_(True), t(z["x2"], DEV).requires_grad_(True)
@@ -47,15 +71,18 @@ def _attack_check(z, net, args, key, lr, iters, tol=1e-4):
     assert err <= tol * max(upd, 1.0), f"patch err {err:.3e} vs update {upd:.3e}"
 
 
-def test_pwcnet_vs_reference():
+@FROZEN
+def test_pwcnet_vs_reference(frozen):
     z = load_golden("pwcnet_128x192")
     net, args = _fetch("PWCNet", 1)
-    _check(z, net, args)
+    with _on_the_engines(net, frozen):
+        _check(z, net, args)
     _attack_check(z, net, args, "attack_it2_patch", 1e4, 2)
 
 
+@FROZEN
 @pytest.mark.parametrize("alternate", [False, True])
-def test_raft_vs_reference(alternate):
+def test_raft_vs_reference(alternate, frozen):
     z = load_golden("raft_128x192")
     net, args = _fetch("RAFT", 2, alternate_corr=alternate)
     args.mixed_precision = False
@@ -64,17 +91,20 @@ def test_raft_vs_reference(alternate):
     # evaluation orders on the same CPU already differ by 1e-3 and fp32 vs fp64 by 3e-4
     # (profiles/r2_raft_f64_diag.txt); MIOpen vs oneDNN lands at ~2e-2 of the gradient's max.  The HIP lookup
     # itself matches torch's grid_sample formulation to 6e-6 on the same device (profiles/r2_raft_f64_diag.txt).
-    _check(z, net, args, gtol=5e-2, g_atol=5e-2)
+    with _on_the_engines(net, frozen):
+        _check(z, net, args, gtol=5e-2, g_atol=5e-2)
     _attack_check(z, net, args, "attack_it2_patch", 1e4, 2, tol=5e-2)
 
 
-def test_flownet2_vs_reference_wiring():
+@FROZEN
+def test_flownet2_vs_reference_wiring(frozen):
     z = load_golden("flownet2_64x128")
     net, args = _fetch("FlowNet2", 3)
     # flow / EPE: 1e-4.  The image gradient runs through four Resample2d warps whose floor() makes
     # it piecewise: a flow value within rounding of an integer lands in another cell on another
     # platform, so ~1% of the pixels move by up to 1% of the gradient's max (measured 5.5e-3).
-    _check(z, net, args, gtol=2e-2, g_atol=1e-2)
+    with _on_the_engines(net, frozen):
+        _check(z, net, args, gtol=2e-2, g_atol=1e-2)
 
 
 @pytest.mark.parametrize("use_graph", [True, False])
@@ -131,17 +161,19 @@ def test_raft_full_resolution_smoke():
     assert bool(torch.isfinite(flow).all()) and bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0
 
 
-def test_flownet2s_matches_reference_golden():
+@FROZEN
+def test_flownet2s_matches_reference_golden(frozen):
     """`--flownet FlowNetS` (models/__init__.py:2 -> models/FlowNet2S.py:62-108) through fetch_model + predict_flow."""
     from understanding_flow_robustness_amd.flownets.utils_model import fetch_model, predict_flow
     z = load_golden("flownet2s_64x128")
     args = Namespace(flownet="FlowNetS")
     net = fetch_model(args, synthetic_seed=4).to(DEV)
     x1, x2 = t(z["x1"], DEV).requires_grad_(True), t(z["x2"], DEV).requires_grad_(True)
-    flow = predict_flow(net, None, x1, x2, args)
-    assert_close(flow, t(z["flow"]), rtol=1e-4, atol_scale=1e-5, what="FlowNet2S flow")
-    loss = (1 - torch.nn.functional.cosine_similarity(flow, t(z["target"], DEV))).mean()
-    g1, g2 = torch.autograd.grad(loss, (x1, x2))
+    with _on_the_engines(net, frozen):
+        flow = predict_flow(net, None, x1, x2, args)
+        assert_close(flow, t(z["flow"]), rtol=1e-4, atol_scale=1e-5, what="FlowNet2S flow")
+        loss = (1 - torch.nn.functional.cosine_similarity(flow, t(z["target"], DEV))).mean()
+        g1, g2 = torch.autograd.grad(loss, (x1, x2))
     assert_close(g1, t(z["g1"]), rtol=1e-3, atol_scale=1e-3, what="FlowNet2S grad 1")
     assert_close(g2, t(z["g2"]), rtol=1e-3, atol_scale=1e-3, what="FlowNet2S grad 2")
 
@@ -215,8 +247,9 @@ def test_config_c5_flownet2_universal_step_at_448x1024(oracle):
     print(f"C5: free-running, after {n_step} steps {float(((state - d).abs() > 1e-6).float().mean()):.2e} of the entries differ")
 
 
+@FROZEN
 @pytest.mark.parametrize("alternate", [False, True])
-def test_raft_gradient_against_float64_truth(alternate, oracle):
+def test_raft_gradient_against_float64_truth(alternate, frozen, oracle):
     """RAFT's image gradient and 2-iteration patch against a float64 evaluation (the CPU oracle in double: pinned to
     the reference operation for operation in fp32, so its float64 run is the conditioning-free truth).  Gates:
     the product's error is at most a small multiple of the error the reference's own CPU fp32 run (the golden) has,
@@ -247,9 +280,10 @@ def test_raft_gradient_against_float64_truth(alternate, oracle):
         same_dev = oracle_run(DEV, torch.float32)
         gpu64 = oracle_run(DEV, torch.float64)
         x1, x2 = t(z["x1"], DEV).requires_grad_(True), t(z["x2"], DEV).requires_grad_(True)
-        flow = predict_flow(net, None, x1, x2, args)
-        loss = (1 - torch.nn.functional.cosine_similarity(flow, t(z["target"], DEV))).mean()
-        g1, g2 = torch.autograd.grad(loss, (x1, x2))
+        with _on_the_engines(net, frozen):
+            flow = predict_flow(net, None, x1, x2, args)
+            loss = (1 - torch.nn.functional.cosine_similarity(flow, t(z["target"], DEV))).mean()
+            g1, g2 = torch.autograd.grad(loss, (x1, x2))
     finally:
         torch.backends.cudnn.benchmark = bench_mode
     mine = (flow.detach().double().cpu(), g1.double().cpu(), g2.double().cpu())
@@ -261,7 +295,7 @@ def test_raft_gradient_against_float64_truth(alternate, oracle):
     for name, i in (("flow", 0), ("grad frame 1", 1), ("grad frame 2", 2)):
         e_mine, e_cpu, e_torch = rel(mine, truth, i), rel(cpu32, truth, i), rel(same_dev, truth, i)
         e_same, e_64 = rel(mine, same_dev, i), rel(gpu64, truth, i)
-        print(f"RAFT alt={alternate} {name}: product {e_mine:.2e}, reference cpu fp32 {e_cpu:.2e}, torch spelling fp32 on "
+        print(f"RAFT alt={alternate} frozen={frozen} {name}: product {e_mine:.2e}, reference cpu fp32 {e_cpu:.2e}, torch spelling fp32 on "
               f"this device {e_torch:.2e} (float64: {e_64:.1e}), product vs torch spelling {e_same:.2e}")
         assert e_64 <= 1e-10                                  # the formulation itself is exact on this device
         if not alternate:
@@ -355,5 +389,17 @@ def test_leaving_the_engines_is_reported_and_release_restores_the_callers_flags(
         target_b = -net(big, big)
     attack(net, big, None, big, torch.rand_like(big) * mask_b, mask_b, torch.rand_like(big) * mask_b, target_b, None, args=args)
     assert L.VENDOR_FALLBACKS == counted, "the attack itself left the engines (or its shape probe was counted)"
+    # two step configurations on one module, the FIRST one hit again: the LRU cache now iterates the later step first, which saw
+    # parameters that were already frozen -- release() must still restore the caller's flags (recorded once per module)
+    assert len(net.__dict__[_STEP_CACHE_ATTR]) == 2
+    attack(net, x, None, x, patch.clone(), mask, patch, target, None, args=args)
+    assert len(net.__dict__[_STEP_CACHE_ATTR]) == 2 and not any(p.requires_grad for p in net.parameters())
     release(net)
     assert all(p.requires_grad for p in net.parameters()) and len(net.__dict__[_STEP_CACHE_ATTR]) == 0
+    # a caller that froze some parameters itself gets exactly those back
+    some = list(net.parameters())[:3]
+    for p in some:
+        p.requires_grad_(False)
+    attack(net, x, None, x, patch.clone(), mask, patch, target, None, args=args)
+    release(net)
+    assert [p.requires_grad for p in net.parameters()] == [False] * 3 + [True] * (len(list(net.parameters())) - 3)

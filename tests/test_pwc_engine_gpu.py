@@ -42,7 +42,7 @@ def test_upfeat_kernels_match_conv_transpose(C, H, W):
     wbuf[:C] = w
     out = torch.full((B, 2, 2 * H, 2 * W), float("nan"), device=DEV)
     L.check(L.lib().ufr_upfeat_planes_forward_mfma(L.ptr(planes.t), planes.plane_stride, 1, chunks,
-                                                   L.ptr(_pack_flow_tail_mfma(wbuf.permute(1, 0, 2, 3).contiguous())), L.ptr(b), L.ptr(out),
+                                                   L.ptr(_pack_flow_tail_mfma(wbuf.permute(1, 0, 2, 3).contiguous())), chunks, L.ptr(b), L.ptr(out),
                                                    B, H, W, L.stream()))
     want = torch.nn.functional.conv_transpose2d(x.double(), w.double(), b.double(), 2, 1)
     assert _rel(out, want) <= 2e-6
@@ -51,7 +51,7 @@ def test_upfeat_kernels_match_conv_transpose(C, H, W):
     base = torch.randn_like(Gs.t)
     for accumulate in (0, 1):
         Gs.t.copy_(base)
-        L.check(L.lib().ufr_upfeat_planes_backward(L.ptr(gy), L.ptr(_pack_tail_bwd(wbuf)), L.ptr(Gs.t), 1, chunks, B, H, W, accumulate,
+        L.check(L.lib().ufr_upfeat_planes_backward(L.ptr(gy), L.ptr(_pack_tail_bwd(wbuf)), chunks, L.ptr(Gs.t), Gs.chunks, 1, chunks, B, H, W, accumulate,
                                                    L.stream()))
         xg = x.double().requires_grad_(True)
         (gx,) = torch.autograd.grad(torch.nn.functional.conv_transpose2d(xg, w.double(), None, 2, 1), xg, gy.double())
@@ -107,7 +107,7 @@ def test_pwc_engine_head_forward_and_gradient_match_the_torch_head(net, monkeypa
 def test_pwc_engine_step_equals_full_frame_torch_step(net, monkeypatch):
     """Config C4's step (windowed pyramid levels 1-2 on the igemm, cached level-2 features in the engine's planes, fused
     loss, one HIP graph) against the full-frame torch / MIOpen step (UFR_ENGINE=0, no window, eager) after ONE iteration:
-    4 pairs behind one 51x51 patch at 384x1280, placements at a corner, two edges and the interior -- 2.5e-4 of the update (see the assertion)."""
+    4 pairs behind one 51x51 patch at 384x1280, placements at a corner, two edges and the interior -- 1e-4 of the update, with MIOpen's find step off (see the assertion)."""
     from understanding_flow_robustness_amd.patch_attack import PatchAttackStep
     B, H, W = 4, 384, 1280
     g = torch.Generator().manual_seed(11)
@@ -129,9 +129,18 @@ def test_pwc_engine_step_equals_full_frame_torch_step(net, monkeypatch):
             outs.append((step.patch.clone(), n, loss))
         return step, outs
 
-    _, probe = run(False, False, 1.0, False)
-    lr = 0.5 / float((probe[0][0] - patch0).abs().max())          # first update peaks at 0.5: the +-2 clamp stays inactive
-    _, full = run(False, False, lr, False)
+    # the yardstick is the torch / MIOpen step: with the find step on (cudnn.benchmark, switched on by earlier tests of this
+    # process) MIOpen picks its fp32 convolution algorithms per box and per call shape -- the same tree measured 1.6e-5 .. 5.3e-5
+    # of the update on one box and 1.16e-4 on another (gpurun r4_call65 / r4_final_d); with it off the yardstick is the same
+    # kernels everywhere (as in test_models_gpu.py::test_raft_gradient_against_float64_truth)
+    bench_mode = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = False
+    try:
+        _, probe = run(False, False, 1.0, False)
+        lr = 0.5 / float((probe[0][0] - patch0).abs().max())          # first update peaks at 0.5: the +-2 clamp stays inactive
+        _, full = run(False, False, lr, False)
+    finally:
+        torch.backends.cudnn.benchmark = bench_mode
     step, eng = run(True, True, lr, True)
     assert step.cone is not None and step.eng is not None and step.eng_kind == "pwc" and step.graph is not None
     for (pf, nf, lf), (pe, ne, le) in zip(full, eng):
@@ -139,10 +148,9 @@ def test_pwc_engine_step_equals_full_frame_torch_step(net, monkeypatch):
         err = float((pf - pe).abs().max())
         print(f"update {upd:.3e}, engine step vs torch step {err / upd:.2e} of it; loss {lf:.6f} / {le:.6f}")
         assert nf == ne == 1 and abs(lf - le) <= 1e-5
-        # 2.5e-4: the yardstick here is the torch / MIOpen step, whose convolution algorithms are chosen per box (find mode) -- the
-        # same tree measured 1.6e-5 .. 5.3e-5 on one box and 1.16e-4 on another (gpurun r4_call65 / r4_final_d).  The engine's own
-        # error is pinned by `test_pwc_step_at_full_size_vs_cpu_oracle`: 1e-4 of the update against the CPU oracle (6e-6 measured).
-        assert 1e-3 < upd < 1.9 and err <= 2.5e-4 * upd, f"{err / upd:.2e} of the update"
+        # the engine's own error is also pinned by `test_pwc_step_at_full_size_vs_cpu_oracle`: 1e-4 of the update against the CPU
+        # oracle (6e-6 measured)
+        assert 1e-3 < upd < 1.9 and err <= 1e-4 * upd, f"{err / upd:.2e} of the update"
 
 
 @pytest.mark.timeout(900)

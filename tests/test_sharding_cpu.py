@@ -5,7 +5,6 @@ the 31-KB-class rows [crop | loss]; every rank adds the rows in rank order and a
 the single-process batch with the same summation groups BIT FOR BIT, and a patch pixel must carry both ranks'
 gradients."""
 import os
-import socket
 
 import pytest
 import torch
@@ -17,10 +16,9 @@ ORIGINS = [(10, 20), (30, 80), (5, 100), (40, 8)]          # four pairs, four di
 LR = 5e4
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+def _rendezvous(tmp_path):
+    """A file-store rendezvous in the test's own directory: no TCP port to pick, nothing to resolve."""
+    return f"file://{tmp_path}/rendezvous"
 
 
 def _inputs():
@@ -33,10 +31,9 @@ def _inputs():
     return tgt, ref, mask_p, patch0, target
 
 
-def _rank_main(rank, world, port, out_dir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _rank_main(rank, world, rdzv, out_dir):
     torch.set_num_threads(2)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=rdzv, rank=rank, world_size=world)
     from oracle import flow_oracle as fo
     from understanding_flow_robustness_amd.flownets.flownetc import FlowNetC
     from understanding_flow_robustness_amd.flownets.weights import synthetic_state_dict
@@ -80,8 +77,7 @@ def test_two_rank_sharded_patch_update_equals_single_process_batch(oracle, tmp_p
     from oracle import flow_oracle as fo
     from understanding_flow_robustness_amd.flownets.flownetc import FlowNetC
     from understanding_flow_robustness_amd.flownets.weights import synthetic_state_dict
-    port = _free_port()
-    mp.spawn(_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_rank_main, args=(2, _rendezvous(tmp_path), str(tmp_path)), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     assert torch.equal(r0["patch"], r1["patch"]), "ranks must hold bit-identical patches after the exchange"
     assert torch.equal(r0["loss"], r1["loss"]) and torch.equal(r0["rows"], r1["rows"])
@@ -114,13 +110,12 @@ def _universal_inputs():
     return img0, img1, target
 
 
-def _universal_rank_main(rank, world, port, out_dir):
+def _universal_rank_main(rank, world, rdzv, out_dir):
     """UniversalPerturbationStep's N>1 protocol (universal_perturbation.py::_part_a / _update modes 1 and 2):
     local loss scaled by 1/(B*world*H*W), local sum of the two image gradients packed as [2,3,H,W | loss],
     one all-reduce, then sign / clamp(+-eps) applied identically by every rank."""
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(2)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=rdzv, rank=rank, world_size=world)
     from oracle import flow_oracle as fo
     from understanding_flow_robustness_amd.flownets.flownetc import FlowNetC
     from understanding_flow_robustness_amd.flownets.weights import synthetic_state_dict
@@ -149,8 +144,7 @@ def test_two_rank_sharded_universal_update_equals_single_process_batch(oracle, t
     from oracle import flow_oracle as fo
     from understanding_flow_robustness_amd.flownets.flownetc import FlowNetC
     from understanding_flow_robustness_amd.flownets.weights import synthetic_state_dict
-    port = _free_port()
-    mp.spawn(_universal_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_universal_rank_main, args=(2, _rendezvous(tmp_path), str(tmp_path)), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "u_rank0.pt"), torch.load(tmp_path / "u_rank1.pt")
     assert torch.equal(r0["delta"], r1["delta"]), "ranks must hold bit-identical perturbations after the exchange"
     sd = synthetic_state_dict(FlowNetC().state_dict(), seed=0)

@@ -5,7 +5,6 @@ on the one-GPU test box they share the device and gloo moves the rows.  Both ran
 that equal the single-process step run with the same two summation groups."""
 import json
 import os
-import socket
 import subprocess
 import sys
 
@@ -22,10 +21,10 @@ PH = PW = 20
 ORIGINS = [(10, 20), (30, 80), (5, 100), (40, 8)]
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+def _rendezvous(tmp_path):
+    """A file-store rendezvous in the test's own directory: no TCP port to pick (bind-then-close races with every other
+    process on the box), nothing to resolve."""
+    return f"file://{tmp_path}/rendezvous"
 
 
 def _inputs():
@@ -47,23 +46,22 @@ def _make_step(batch, exchange, dev, groups=1, flownet="FlowNetC"):
     return PatchAttackStep(net, args, batch, 64, 128, device=dev, exchange=exchange, patch_hw=(PH, PW), sum_groups=groups)
 
 
-def _init_ranks(rank, world, port):
+def _init_ranks(rank, world, rdzv):
     """One device per rank over RCCL when the box has them; on the one-GPU test box the ranks share cuda:0 and gloo moves the
     rows (the product code is the same: ShardedExchange calls torch.distributed)."""
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
     two_devices = torch.cuda.device_count() >= world
     dev = f"cuda:{rank}" if two_devices else DEV
     torch.cuda.set_device(dev)
     if two_devices:                                    # RCCL over xGMI: the production transport
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        dist.init_process_group("nccl", init_method=rdzv, rank=rank, world_size=world, device_id=torch.device(dev))
     else:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", init_method=rdzv, rank=rank, world_size=world)
     return dev
 
 
-def _rank_main(rank, world, port, out_dir, flownet="FlowNetC"):
-    dev = _init_ranks(rank, world, port)
+def _rank_main(rank, world, rdzv, out_dir, flownet="FlowNetC"):
+    dev = _init_ranks(rank, world, rdzv)
     from understanding_flow_robustness_amd.patch_attack import ShardedExchange
     tgt, ref, mask_p, patch0, target = _inputs()
     sl = slice(2 * rank, 2 * rank + 2)
@@ -83,7 +81,7 @@ def test_two_ranks_match_single_process_batch(tmp_path, flownet):
     """FlowNetC = config C2's step, PWCNet = config C4's (PWC-Net behind the exchange: SURVEY.md 8e, "C4: 64 -> 8 x 8"):
     the product's own sharded PatchAttackStep on two ranks against its single-process form with the same two summation
     groups."""
-    mp.spawn(_rank_main, args=(2, _free_port(), str(tmp_path), flownet), nprocs=2, join=True)
+    mp.spawn(_rank_main, args=(2, _rendezvous(tmp_path), str(tmp_path), flownet), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     assert r0["graphs"] == (True, True) and r0["n"] == r1["n"] == 2
     assert r0["backend"] == ("nccl" if torch.cuda.device_count() >= 2 else "gloo")
@@ -116,23 +114,32 @@ def _universal_inputs(gt_channels):
     return img0, img1, target
 
 
-def _universal_step(batch, exchange, dev, flow_loss, gt_channels):
+def _universal_delta0(flownet):
+    """FlowNetC starts from zeros like the reference (universal_perturbation.py:314); FlowNet2's four floor() warps make its
+    gradient piecewise, so its case starts from a perturbation "as after earlier samples" (as the C5 test does) where the
+    gradient is well away from zero."""
+    if flownet != "FlowNet2":
+        return torch.zeros(2, 3, 64, 128)
+    return (torch.rand(2, 3, 64, 128, generator=torch.Generator().manual_seed(92)) * 2 - 1) * 0.5 * U_EPS
+
+
+def _universal_step(batch, exchange, dev, flow_loss, gt_channels, flownet="FlowNetC"):
     from argparse import Namespace
     from understanding_flow_robustness_amd.flownets.utils_model import fetch_model
     from understanding_flow_robustness_amd.universal_perturbation import UniversalPerturbationStep
-    args = Namespace(flownet="FlowNetC", n_step=U_STEPS, learning_rate=U_LR, output_norm=U_EPS, flow_loss=flow_loss,
+    args = Namespace(flownet=flownet, n_step=U_STEPS, learning_rate=U_LR, output_norm=U_EPS, flow_loss=flow_loss,
                      perturb_method="ifgsm", perturb_mode="both", add_gaussian=False)
-    net = fetch_model(args, synthetic_seed=0).to(dev)
+    net = fetch_model(args, synthetic_seed=3 if flownet == "FlowNet2" else 0).to(dev)
     return UniversalPerturbationStep(net, args, batch, 64, 128, gt_channels=gt_channels, device=dev, shared=True,
                                      exchange=exchange)
 
 
-def _universal_rank_main(rank, world, port, out_dir, flow_loss, gt_channels):
-    dev = _init_ranks(rank, world, port)
+def _universal_rank_main(rank, world, rdzv, out_dir, flow_loss, gt_channels, flownet):
+    dev = _init_ranks(rank, world, rdzv)
     from understanding_flow_robustness_amd.patch_attack import ShardedExchange
     img0, img1, target = (x[rank:rank + 1].to(dev) for x in _universal_inputs(gt_channels))
-    step = _universal_step(1, ShardedExchange(), dev, flow_loss, gt_channels)
-    step.load(img0, img1, torch.zeros(2, 3, 64, 128, device=dev), target)
+    step = _universal_step(1, ShardedExchange(), dev, flow_loss, gt_channels, flownet)
+    step.load(img0, img1, _universal_delta0(flownet).to(dev), target)
     step.run(U_STEPS)
     torch.cuda.synchronize()
     torch.save(dict(delta=step.delta.cpu(), loss=float(step.loss_cur), scale=float(step.scale_t),
@@ -143,21 +150,24 @@ def _universal_rank_main(rank, world, port, out_dir, flow_loss, gt_channels):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("flow_loss,gt_channels", [("cossim", 2), ("l2", 3)])
-def test_two_rank_universal_step_matches_single_process(tmp_path, flow_loss, gt_channels):
+@pytest.mark.parametrize("flow_loss,gt_channels,flownet", [("cossim", 2, "FlowNetC"), ("l2", 3, "FlowNetC"),
+                                                           ("cossim", 2, "FlowNet2")])
+def test_two_rank_universal_step_matches_single_process(tmp_path, flow_loss, gt_channels, flownet):
     """The product's own sharded UniversalPerturbationStep (universal_perturbation.py `world > 1`: `_update` modes 1 / 2
     around the packed all-reduce, the `valid` all-reduce of a 3-channel target) on two ranks of one pair each: bit-identical
     perturbations on both ranks, and the single-process `shared=True` step over the same two pairs up to sign flips where the
-    summed gradient is ~0 ("universal: [2,3,H,W] fp32 all-reduced, then sign")."""
-    mp.spawn(_universal_rank_main, args=(2, _free_port(), str(tmp_path), flow_loss, gt_channels), nprocs=2, join=True)
+    summed gradient is ~0 ("universal: [2,3,H,W] fp32 all-reduced, then sign").  The FlowNet2 case is config
+    C5's own network (Correlation + 4 Resample2d + 6 ChannelNorm, models/flownet2_models.py:122-205) behind the exchange."""
+    mp.spawn(_universal_rank_main, args=(2, _rendezvous(tmp_path), str(tmp_path), flow_loss, gt_channels, flownet), nprocs=2,
+             join=True)
     r0, r1 = torch.load(tmp_path / "u_rank0.pt"), torch.load(tmp_path / "u_rank1.pt")
     assert r0["graphs"] == (True, True)
     assert r0["backend"] == ("nccl" if torch.cuda.device_count() >= 2 else "gloo")
     assert torch.equal(r0["delta"], r1["delta"]), "ranks must hold bit-identical perturbations after the exchange"
     assert r0["loss"] == r1["loss"] and r0["scale"] == r1["scale"]
     img0, img1, target = (x.to(DEV) for x in _universal_inputs(gt_channels))
-    step = _universal_step(2, None, DEV, flow_loss, gt_channels)
-    step.load(img0, img1, torch.zeros(2, 3, 64, 128, device=DEV), target)
+    step = _universal_step(2, None, DEV, flow_loss, gt_channels, flownet)
+    step.load(img0, img1, _universal_delta0(flownet).to(DEV), target)
     step.run(U_STEPS)
     d = step.delta.cpu()
     assert float(d.abs().max()) > 0.5 * U_EPS                       # the steps did move the perturbation
@@ -196,11 +206,11 @@ def test_bench_two_rank_rehearsal(ranks, config):
     assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
 
 
-def _rccl_rank(rank, port, out_dir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _rccl_rank(rank, rdzv, out_dir):
+    os.environ.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
     sys.path.insert(0, ROOT)
     torch.cuda.set_device(DEV)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    dist.init_process_group("nccl", init_method=rdzv, rank=0, world_size=1, device_id=torch.device(DEV))
     rows_local = torch.arange(2 * 7, dtype=torch.float32, device=DEV).view(2, 7)
     rows_all = torch.full((2, 7), -1.0, device=DEV)
     dist.all_gather_into_tensor(rows_all, rows_local)              # the call ShardedExchange.gather makes for world > 1
@@ -217,7 +227,7 @@ def _rccl_rank(rank, port, out_dir):
 def test_rccl_initialises_and_runs_the_exchange_collectives(tmp_path):
     """The one-GPU box cannot run two RCCL ranks, so the N > 1 tests above move their rows over gloo.  This one brings RCCL
     itself up on the MI355X (backend "nccl", one rank) and issues the two collectives the exchange uses on HIP tensors."""
-    mp.spawn(_rccl_rank, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_rccl_rank, args=(_rendezvous(tmp_path), str(tmp_path)), nprocs=1, join=True)
     r = torch.load(tmp_path / "rccl.pt")
     assert r["backend"] == "nccl"
     assert torch.equal(r["gathered"], torch.arange(14, dtype=torch.float32).view(2, 7)) and r["reduced"] == float(1 << 20)

@@ -38,9 +38,12 @@ def main():
             wm = _pack_flow_head_mfma(w)
             bias = torch.zeros(2, device=DEV)
             out = torch.zeros(B, 2, H, W, device=DEV)
-            for chunks in sorted({1, 4, 8, 16, cmax}):
-                fn = lambda: L.check(lib.ufr_flow_head_planes_forward_mfma(L.ptr(planes.t), planes.plane_stride, 0, chunks, L.ptr(wm), L.ptr(bias),
-                                                                           L.ptr(out), B, H, W, L.stream()), "pf")
+            # never more chunks than the buffer and the packed weights hold: round 4's form of this loop launched 16 chunks on
+            # the 13-chunk buffer of the 48 x 160 grid and the kernel read past its end -- a GPU memory-access fault at 8 frames
+            # (DESIGN.md 6.5); since ABI 7 the C entry refuses such a range as well
+            for chunks in sorted(c for c in {1, 4, 8, 16, cmax} if c <= cmax):
+                fn = lambda: L.check(lib.ufr_flow_head_planes_forward_mfma(L.ptr(planes.t), planes.plane_stride, 0, chunks, L.ptr(wm),
+                                                                           wm.shape[0], L.ptr(bias), L.ptr(out), B, H, W, L.stream()), "pf")
                 print(json.dumps(dict(grid=[H, W], frames=B, chunks=chunks, us=round(timed(fn), 2))), flush=True)
     # the floor: an empty-ish kernel of torch
     x = torch.zeros(64, device=DEV)

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UFR_HIP_LIB") or os.path.join(_HERE, "lib", "libufr_hip.so")   # UFR_HIP_LIB: another BUILD of the same library (same-box A/B of two kernels)
 UFR_F32, UFR_F64, UFR_F16 = 0, 1, 2
-ABI_VERSION = 6            # UFR_ABI_VERSION of include/ufr_hip.h these ctypes mirrors were written against
+ABI_VERSION = 7            # UFR_ABI_VERSION of include/ufr_hip.h these ctypes mirrors were written against
 _lib = None
 
 
@@ -146,11 +146,11 @@ SIGNATURES = {
     "ufr_nchw_cat_to_planes": [_vp, _vp, _vp, _i, _vp, _l, _i, _i, _i, _i, _i, _vp],
     "ufr_chunks_to_nchw_cat": [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _f, _f, _i, _i, _i, _vp],
     "ufr_grad_finalize": [_vp, _i, _vp, _i, _vp, _l, _i, _l, _i, _f, _vp],
-    "ufr_flow_head_planes_forward": [_vp, _l, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "ufr_flow_head_planes_forward_mfma": [_vp, _l, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "ufr_deconv_flow_tail_backward_mfma": [_vp, _l, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp],
-    "ufr_flow_head_planes_backward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
-    "ufr_flow_head_planes_backward_finalize": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _l, _i, _i, _f, _vp],
+    "ufr_flow_head_planes_forward": [_vp, _l, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
+    "ufr_flow_head_planes_forward_mfma": [_vp, _l, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
+    "ufr_deconv_flow_tail_backward_mfma": [_vp, _l, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "ufr_flow_head_planes_backward": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ufr_flow_head_planes_backward_finalize": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _l, _i, _i, _f, _vp],
     "ufr_unshuffle_pack_planes": [_vp, _vp, _l, _i, _i, _i, _i, _vp],
     "ufr_unshuffle_unpack_grad": [_vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_conv3x3s2_c3_planes": [_vp, _vp, _vp, _f, _vp, _l, _i, _i, _i, _i, _i, _vp],
@@ -171,8 +171,8 @@ SIGNATURES = {
     "ufr_gru_gates_cm_backward": [_vp, _vp, _l, _i, _vp, _vp, _vp, _l, _i, _vp, _l, _i, _i, _vp],
     "ufr_altcorr_pyramid_forward": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
     "ufr_altcorr_pyramid_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
-    "ufr_upfeat_planes_forward_mfma": [_vp, _l, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "ufr_upfeat_planes_backward": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "ufr_upfeat_planes_forward_mfma": [_vp, _l, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
+    "ufr_upfeat_planes_backward": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ufr_flow_up_planes_forward": [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp],
     "ufr_flow_up_planes_backward": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_corr_forward_planes_window": [_vp, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _i, _i, _vp],
@@ -347,6 +347,34 @@ class EngineCache(dict):
 
     def __reduce__(self):
         return (EngineCache, ())
+
+
+_GRAD_FLAGS_ATTR = "_ufr_grad_flags"
+
+
+def freeze_parameters(module) -> None:
+    """The fused steps compute data gradients only: they freeze the caller's parameters.  The flags the CALLER had are
+    recorded ONCE per module (`module.__dict__[_GRAD_FLAGS_ATTR]`, an EngineCache-like dict that copies / pickles empty), at the
+    first freeze -- a later step sees parameters that are already frozen and must not overwrite the record, and the record must
+    not depend on which step the LRU step cache happens to hold or to iterate first."""
+    flags = module.__dict__.setdefault(_GRAD_FLAGS_ATTR, _GradFlags())
+    for p in module.parameters():
+        flags.setdefault(id(p), (p, p.requires_grad))
+        p.requires_grad_(False)
+
+
+def restore_parameters(module) -> None:
+    """Give the parameters back the `requires_grad` flags they had before the first `freeze_parameters(module)`."""
+    for p, flag in module.__dict__.pop(_GRAD_FLAGS_ATTR, {}).values():
+        p.requires_grad_(flag)
+
+
+class _GradFlags(dict):
+    def __deepcopy__(self, memo):
+        return _GradFlags()
+
+    def __reduce__(self):
+        return (_GradFlags, ())
 
 
 def engine_cache(module, attr: str) -> EngineCache:

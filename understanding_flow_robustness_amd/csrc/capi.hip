@@ -1,5 +1,8 @@
 // capi.hip -- error channel and introspection entry points of libufr_hip.so.
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "ufr_common.h"
 
@@ -14,6 +17,19 @@ int fail(int code, const char* fmt, ...) {
   vsnprintf(err_buf(), 512, fmt, ap);
   va_end(ap);
   return code;
+}
+hipError_t ensure_dynamic_lds(const void* fn, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> raised;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = raised[{fn, dev}];
+  if (bytes <= have) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) have = bytes;
+  return e;
 }
 }  // namespace ufr
 

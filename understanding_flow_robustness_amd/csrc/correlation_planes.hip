@@ -225,12 +225,9 @@ template <int NW>
 int launch_corr_planes(const __bf16* a, const __bf16* b, long in_plane_stride, __bf16* o, long out_plane_stride, int out_chunk0,
                        int B, int H, int W, int ni, float scale, float slope, hipStream_t st, const int* win = nullptr,
                        int win_div = 1) {
-  static bool raised = false;                    // above the default dynamic-LDS limit
-  if (!raised) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_fwd_planes_k2_kernel<NW>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, corr_planes_k2_lds_bytes<NW>());
+  {                                              // above the default dynamic-LDS limit
+    hipError_t e = ufr::ensure_dynamic_lds(reinterpret_cast<const void*>(corr_fwd_planes_k2_kernel<NW>), corr_planes_k2_lds_bytes<NW>());
     if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "correlation (planes): %s", hipGetErrorString(e));
-    raised = true;
   }
   corr_fwd_planes_k2_kernel<NW><<<dim3(win ? 1 : ufr::ceil_div(ni, 16 * NW), 2, B * H), 128 * NW, corr_planes_k2_lds_bytes<NW>(), st>>>(
       a, b, in_plane_stride, o, out_plane_stride, out_chunk0, B, H, W, scale, slope, win, win_div);

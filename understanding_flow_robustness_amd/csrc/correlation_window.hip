@@ -82,12 +82,9 @@ __global__ __launch_bounds__(256 * CG / CT) void corr_bwd_window_kernel(
 template <int CG, int P, int DP>
 int launch_window(const float* in1, const float* in2, const float* go, float* g1, float* g2, int B, int C, int H,
                   int W, const int* win, int ls, int wh, int ww, size_t lds, hipStream_t st) {
-  static size_t lds_allowed = 64 * 1024;     // raised once per size class, not on every (captured) launch
-  if (lds > lds_allowed) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_bwd_window_kernel<CG, P, DP>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > 64 * 1024) {                     // raised once per size class and device, not on every (captured) launch
+    hipError_t e = ufr::ensure_dynamic_lds(reinterpret_cast<const void*>(corr_bwd_window_kernel<CG, P, DP>), lds);
     if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "corr backward window: %s", hipGetErrorString(e));
-    lds_allowed = lds;
   }
   corr_bwd_window_kernel<CG, P, DP><<<dim3(B, ufr::ceil_div(C, CG), 2), 256 * CG / CT, lds, st>>>(in1, in2, go, g1, g2, C, H, W,
                                                                                          win, ls, wh, ww);

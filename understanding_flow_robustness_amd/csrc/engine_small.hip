@@ -541,23 +541,41 @@ __global__ void flow_up_planes_bwd(const float* __restrict__ G, int chunk, const
   }
 }
 
+// ABI 7: a chunk range [chunk0, chunk0 + chunks) must stay inside what it walks.  A planes operand whose planes lie
+// plane_stride elements apart holds plane_stride / (pixels * 32) chunks per plane; the packed weights hold w_chunks (indexed by the
+// position inside the range); a float32 gradient sum holds g_chunks.  (tools/bench_pf.py launched 16 chunks on a 13-chunk buffer in
+// round 4 and the kernel read 3 x 8 x 48 x 160 x 32 bf16 per plane past the end: a GPU memory-access fault)
+bool planes_hold(long plane_stride, long pixels, int chunk0, int chunks) {
+  return plane_stride > 0 && (long)(chunk0 + chunks) * pixels * 32 <= plane_stride;
+}
+#define UFR_REQUIRE_RANGE(what, plane_stride, pixels, chunk0, chunks, w_chunks)                                                       \
+  do {                                                                                                                                \
+    if (!planes_hold(plane_stride, pixels, chunk0, chunks))                                                                           \
+      return ufr::fail(UFR_EINVAL, "%s: chunks [%d, %d) leave the planes operand (%ld chunks per plane)", what, chunk0,               \
+                       chunk0 + chunks, (long)(plane_stride) / ((long)(pixels) * 32));                                               \
+    if ((chunks) > (w_chunks))                                                                                                        \
+      return ufr::fail(UFR_EINVAL, "%s: %d chunks asked of packed weights that hold %d", what, chunks, w_chunks);                     \
+  } while (0)
+#define UFR_REQUIRE_GRANGE(what, chunk0, chunks, w_chunks, g_chunks)                                                                  \
+  do {                                                                                                                                \
+    if ((chunk0) + (chunks) > (g_chunks))                                                                                             \
+      return ufr::fail(UFR_EINVAL, "%s: chunks [%d, %d) leave the gradient sum (%d chunks)", what, chunk0, chunk0 + chunks, g_chunks); \
+    if ((chunks) > (w_chunks))                                                                                                        \
+      return ufr::fail(UFR_EINVAL, "%s: %d chunks asked of packed weights that hold %d", what, chunks, w_chunks);                     \
+  } while (0)
+
 }  // namespace
 
-extern "C" int ufr_flow_head_planes_forward(const void* planes, long plane_stride, int chunk0, int chunks, const float* wpk,
+extern "C" int ufr_flow_head_planes_forward(const void* planes, long plane_stride, int chunk0, int chunks, const float* wpk, int w_chunks,
                                             const float* bias, float* out, int B, int H, int W, ufr_stream_t stream) {
   UFR_REQUIRE(planes && wpk && bias && out, "flow head (planes) forward: null pointer");
   UFR_REQUIRE(B > 0 && H > 0 && W > 0 && chunks > 0 && chunks <= 48 && chunk0 >= 0 && (long)B * H * W < (1L << 29),
               "flow head (planes) forward: bad shape");
+  UFR_REQUIRE_RANGE("flow head (planes) forward", plane_stride, (long)B * H * W, chunk0, chunks, w_chunks);
   const int blocks = B * ufr::ceil_div(H, PF_TH) * ufr::ceil_div(W, PF_TW);
   hipStream_t st = ufr::as_stream(stream);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flow_head_planes_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (2 * (PF_HH * PF_HW * PF_CS + 576) + 2 * 256 * 2) * 4);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flow_head_planes_fwd_small), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              48 * 576 * 4 + 4 * 64 * 2 * 4);
-    attr_set = true;
-  }
+  (void)ufr::ensure_dynamic_lds(reinterpret_cast<const void*>(flow_head_planes_fwd), (2 * (PF_HH * PF_HW * PF_CS + 576) + 2 * 256 * 2) * 4);
+  (void)ufr::ensure_dynamic_lds(reinterpret_cast<const void*>(flow_head_planes_fwd_small), 48 * 576 * 4 + 4 * 64 * 2 * 4);
   if (blocks >= 192) {                        // big grids: LDS-tiled kernel, the planes are fetched once
     const int S = (blocks < 512 && chunks >= 8) ? 2 : 1;
     const size_t lds = ((size_t)S * (PF_HH * PF_HW * PF_CS + 576) + (size_t)S * 256 * 2) * 4;
@@ -589,22 +607,15 @@ int launch_pf_mfma(const void* planes, long plane_stride, int chunk0, int chunks
   const int S = (blocks >= 512 || chunks < 4) ? 1 : 2;
   const int mt = ((MODE == 1 ? 2 * TH + 2 : TH + 2) * HWs + 15) / 16;
   const size_t lds = (size_t)S * mt * 16 * TS * sizeof(float);
-  static size_t lds_allowed = 64 * 1024;
-  if (lds > lds_allowed) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flow_head_planes_fwd_mfma<MODE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > 64 * 1024) {
+    hipError_t e = ufr::ensure_dynamic_lds(reinterpret_cast<const void*>(flow_head_planes_fwd_mfma<MODE>), lds);
     if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
-    lds_allowed = lds;
   }
   if constexpr (MODE == 0) if (mt <= 12 && S == 2 && chunks >= 16 && blocks <= 256) {    // small grids (at most one workgroup per CU): eight one-wave slices
     const size_t lds8 = (size_t)8 * mt * 16 * TS * sizeof(float);
-    static bool raised8 = false;
-    if (!raised8) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flow_head_planes_fwd_mfma<MODE, 1, 12>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 12 * 16 * TS * (int)sizeof(float));
-      if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
-      raised8 = true;
-    }
+    hipError_t e = ufr::ensure_dynamic_lds(reinterpret_cast<const void*>(flow_head_planes_fwd_mfma<MODE, 1, 12>),
+                                           8 * 12 * 16 * TS * sizeof(float));
+    if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
     flow_head_planes_fwd_mfma<MODE, 1, 12><<<blocks, 512, lds8, st>>>(static_cast<const __bf16*>(planes), plane_stride, chunk0, chunks,
                                                                       static_cast<const __bf16*>(wmf), bias, out, out_chunk, B, H, W, TH, 8);
     return ufr::launched(what);
@@ -616,37 +627,43 @@ int launch_pf_mfma(const void* planes, long plane_stride, int chunk0, int chunks
 }  // namespace
 
 extern "C" int ufr_flow_head_planes_forward_mfma(const void* planes, long plane_stride, int chunk0, int chunks, const void* wmf,
-                                                 const float* bias, float* out, int B, int H, int W, ufr_stream_t stream) {
+                                                 int w_chunks, const float* bias, float* out, int B, int H, int W, ufr_stream_t stream) {
   UFR_REQUIRE(planes && wmf && bias && out, "flow head (planes, mfma) forward: null pointer");
   UFR_REQUIRE(B > 0 && H > 0 && W > 0 && chunks > 0 && chunks <= 48 && chunk0 >= 0 && (long)B * H * W < (1L << 29),
               "flow head (planes, mfma) forward: bad shape");
+  UFR_REQUIRE_RANGE("flow head (planes, mfma) forward", plane_stride, (long)B * H * W, chunk0, chunks, w_chunks);
   return launch_pf_mfma<0>(planes, plane_stride, chunk0, chunks, wmf, bias, out, 0, B, H, W, ufr::as_stream(stream),
                            "flow_head_planes_fwd_mfma");
 }
 
 extern "C" int ufr_deconv_flow_tail_backward_mfma(const void* grad_planes, long plane_stride, int chunk0, int chunks, const void* wmf,
-                                                  float* G, int out_chunk, int B, int H, int W, ufr_stream_t stream) {
+                                                  int w_chunks, float* G, int g_chunks, int out_chunk, int B, int H, int W,
+                                                  ufr_stream_t stream) {
   UFR_REQUIRE(grad_planes && wmf && G, "deconv flow tail backward: null pointer");
   UFR_REQUIRE(B > 0 && H > 0 && W > 0 && chunks > 0 && chunks <= 48 && chunk0 >= 0 && out_chunk >= 0 &&
                   (long)B * H * W < (1L << 27), "deconv flow tail backward: bad shape");
+  UFR_REQUIRE_RANGE("deconv flow tail backward", plane_stride, (long)B * H * W * 4, chunk0, chunks, w_chunks);   // planes on the fine grid
+  UFR_REQUIRE(out_chunk < g_chunks, "deconv flow tail backward: chunk %d is not in the gradient sum (%d chunks)", out_chunk, g_chunks);
   return launch_pf_mfma<1>(grad_planes, plane_stride, chunk0, chunks, wmf, nullptr, G, out_chunk, B, H, W, ufr::as_stream(stream),
                            "deconv_flow_tail_bwd_mfma");
 }
 
 extern "C" int ufr_upfeat_planes_forward_mfma(const void* planes, long plane_stride, int chunk0, int chunks, const void* wmf,
-                                              const float* bias, float* out, int B, int H, int W, ufr_stream_t stream) {
+                                              int w_chunks, const float* bias, float* out, int B, int H, int W, ufr_stream_t stream) {
   UFR_REQUIRE(planes && wmf && bias && out, "upfeat (planes, mfma) forward: null pointer");
   UFR_REQUIRE(B > 0 && H > 0 && W > 0 && chunks > 0 && chunks <= 48 && chunk0 >= 0 && (long)B * H * W < (1L << 27),
               "upfeat (planes, mfma) forward: bad shape");
+  UFR_REQUIRE_RANGE("upfeat (planes, mfma) forward", plane_stride, (long)B * H * W, chunk0, chunks, w_chunks);
   return launch_pf_mfma<2>(planes, plane_stride, chunk0, chunks, wmf, bias, out, 0, B, H, W, ufr::as_stream(stream),
                            "upfeat_planes_fwd_mfma");
 }
 
-extern "C" int ufr_upfeat_planes_backward(const float* grad_y, const float* wpk, float* G, int chunk0, int chunks, int B, int H,
-                                          int W, int accumulate, ufr_stream_t stream) {
+extern "C" int ufr_upfeat_planes_backward(const float* grad_y, const float* wpk, int w_chunks, float* G, int g_chunks, int chunk0,
+                                          int chunks, int B, int H, int W, int accumulate, ufr_stream_t stream) {
   UFR_REQUIRE(grad_y && wpk && G, "upfeat (planes) backward: null pointer");
   UFR_REQUIRE(B > 0 && H > 0 && W > 0 && chunks > 0 && chunks <= 48 && chunk0 >= 0 && (long)B * H * W < (1L << 27),
               "upfeat (planes) backward: bad shape");
+  UFR_REQUIRE_GRANGE("upfeat (planes) backward", chunk0, chunks, w_chunks, g_chunks);
   const long threads = (long)B * H * W * 4;
   const int bx = ufr::ceil_div(threads, 256);
   int slices = 1;
@@ -670,31 +687,31 @@ int launch_pf_bwd(const float* grad_y, const float* wpk, float* G, int chunk0, i
   if (slices > chunks) slices = chunks;
   const int per = ufr::ceil_div(chunks, slices);
   slices = ufr::ceil_div(chunks, per);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flow_head_planes_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 576 * 4);
-    attr_set = true;
-  }
+  (void)ufr::ensure_dynamic_lds(reinterpret_cast<const void*>(flow_head_planes_bwd), 48 * 576 * 4);
   flow_head_planes_bwd<<<dim3(bx, slices), 256, (size_t)per * 576 * 4, st>>>(grad_y, wpk, G, chunk0, chunks, B, H, W, accumulate, per, fin);
   return ufr::launched("flow_head_planes_bwd");
 }
 }  // namespace
 
-extern "C" int ufr_flow_head_planes_backward(const float* grad_y, const float* wpk, float* G, int chunk0, int chunks, int B,
-                                             int H, int W, int accumulate, ufr_stream_t stream) {
+extern "C" int ufr_flow_head_planes_backward(const float* grad_y, const float* wpk, int w_chunks, float* G, int g_chunks, int chunk0,
+                                             int chunks, int B, int H, int W, int accumulate, ufr_stream_t stream) {
   UFR_REQUIRE(grad_y && wpk && G, "flow head (planes) backward: null pointer");
   UFR_REQUIRE(B > 0 && H > 0 && W > 0 && chunks > 0 && chunks <= 48 && chunk0 >= 0 && (long)B * H * W < (1L << 29),
               "flow head (planes) backward: bad shape");
+  UFR_REQUIRE_GRANGE("flow head (planes) backward", chunk0, chunks, w_chunks, g_chunks);
   return launch_pf_bwd(grad_y, wpk, G, chunk0, chunks, B, H, W, accumulate, PfFinalize{nullptr, nullptr, 0, 0, 0, 1.f}, ufr::as_stream(stream));
 }
 
-extern "C" int ufr_flow_head_planes_backward_finalize(const float* grad_y, const float* wpk, float* G, int chunk0, int chunks, int B,
-                                                      int H, int W, int accumulate, const void* mask_planes, void* out_planes,
-                                                      long out_plane_stride, int fin_chunk0, int fin_chunks, float slope,
-                                                      ufr_stream_t stream) {
+extern "C" int ufr_flow_head_planes_backward_finalize(const float* grad_y, const float* wpk, int w_chunks, float* G, int g_chunks,
+                                                      int chunk0, int chunks, int B, int H, int W, int accumulate,
+                                                      const void* mask_planes, void* out_planes, long out_plane_stride, int fin_chunk0,
+                                                      int fin_chunks, float slope, ufr_stream_t stream) {
   UFR_REQUIRE(grad_y && wpk && G && out_planes, "flow head (planes) backward + finalize: null pointer");
   UFR_REQUIRE(B > 0 && H > 0 && W > 0 && chunks > 0 && chunks <= 48 && chunk0 >= 0 && (long)B * H * W < (1L << 29),
               "flow head (planes) backward + finalize: bad shape");
+  UFR_REQUIRE_GRANGE("flow head (planes) backward + finalize", chunk0, chunks, w_chunks, g_chunks);
+  UFR_REQUIRE(planes_hold(out_plane_stride, (long)B * H * W, chunk0 + fin_chunk0, fin_chunks),
+              "flow head (planes) backward + finalize: the finalised segment leaves the gradient planes");
   UFR_REQUIRE(fin_chunk0 >= 0 && fin_chunks > 0 && fin_chunk0 + fin_chunks <= chunks && out_plane_stride > 0,
               "flow head (planes) backward + finalize: the finalised segment leaves the tensor");
   // the mask (plane 0 of the activation) and the gradient planes share the tensor's geometry: element ((chunk0 + ch) * M + pixel) * 32

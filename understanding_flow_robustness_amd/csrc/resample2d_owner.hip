@@ -271,15 +271,12 @@ extern "C" int ufr_resample2d_backward_owner(const float* input1, const float* i
   const int rt = B * ((H + RT_H - 1) / RT_H) * ((W + RT_W - 1) / RT_W);
   const size_t cells = (size_t)RT_H * RT_W;
   const size_t lds = (CT ? (size_t)C * cells + cells + cells * RS_SLOTS * C : (size_t)C * cells) * sizeof(float);
-  static bool raised = false;
-  if (!raised) {
-    hipError_t e = hipSuccess;
+  {
     const void* fns[5] = {reinterpret_cast<const void*>(rs_image_owner_kernel<0>), reinterpret_cast<const void*>(rs_image_owner_kernel<1>),
                           reinterpret_cast<const void*>(rs_image_owner_kernel<2>), reinterpret_cast<const void*>(rs_image_owner_kernel<3>),
                           reinterpret_cast<const void*>(rs_image_owner_kernel<4>)};
-    for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    hipError_t e = ufr::ensure_dynamic_lds(fns[C <= 4 ? C : 0], 120 * 1024);      // per device
     if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "resample2d backward (owner): %s", hipGetErrorString(e));
-    raised = true;
   }
   switch (C) {
     case 1: rs_image_owner_kernel<1><<<rt, RS_NT, lds, st>>>(input2, grad_output, boxes, grad_input1, B, C, H, W); break;

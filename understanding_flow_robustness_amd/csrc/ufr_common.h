@@ -15,6 +15,11 @@ int fail(int code, const char* fmt, ...);
 
 inline hipStream_t as_stream(ufr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize of `fn` raised to >= `bytes` on the CURRENT device: remembered per (kernel,
+// device) under a mutex -- a process may drive several devices and several host threads (capi.hip).  hipSuccess when nothing
+// had to be done.
+hipError_t ensure_dynamic_lds(const void* fn, size_t bytes);
+
 // Post-launch check: launch-configuration errors surface here; nothing is synchronised.
 inline int launched(const char* what) {
   hipError_t e = hipGetLastError();

@@ -342,12 +342,8 @@ int rs_lds_mode() {
 }
 
 void rs_raise_lds() {
-  static bool done = false;
-  if (!done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resample2d_fwd_lds), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resample2d_bwd_lds), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS_BYTES);
-    done = true;
-  }
+  (void)ufr::ensure_dynamic_lds(reinterpret_cast<const void*>(resample2d_fwd_lds), RS_LDS_BYTES);
+  (void)ufr::ensure_dynamic_lds(reinterpret_cast<const void*>(resample2d_bwd_lds), RS_LDS_BYTES);
 }
 
 }  // namespace

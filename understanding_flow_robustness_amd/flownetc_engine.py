@@ -538,7 +538,7 @@ class FlowNetCHeadEngine:
     def _pf_forward(self, k):
         src, chunks = self.pf_src[k]
         L.check(L.lib().ufr_flow_head_planes_forward_mfma(L.ptr(src.t), src.plane_stride, 0, chunks, L.ptr(self.pf_wm[k]),
-                                                          L.ptr(self.pf_b[k]), L.ptr(self.flow[k]), self.B, src.H, src.W,
+                                                          self.pf_wm[k].shape[0], L.ptr(self.pf_b[k]), L.ptr(self.flow[k]), self.B, src.H, src.W,
                                                           L.stream()), "predict_flow forward (mfma)")
 
     def _pf_backward(self, k, gy, accumulate, finalize=None):
@@ -547,12 +547,14 @@ class FlowNetCHeadEngine:
         src, chunks = self.pf_src[k]
         if finalize is not None:
             act, out, c0, n = finalize
-            L.check(L.lib().ufr_flow_head_planes_backward_finalize(L.ptr(gy), L.ptr(self.pf_w[k]), L.ptr(self.pf_G[k].t), 0, chunks, self.B,
+            L.check(L.lib().ufr_flow_head_planes_backward_finalize(L.ptr(gy), L.ptr(self.pf_w[k]), self.pf_w[k].shape[0], L.ptr(self.pf_G[k].t),
+                                                                   self.pf_G[k].chunks, 0, chunks, self.B,
                                                                    src.H, src.W, int(accumulate), L.ptr(act.t), L.ptr(out.t), out.plane_stride,
                                                                    int(c0), int(n), float(ig.LEAKY), L.stream()),
                     "predict_flow backward + finalize")
             return
-        L.check(L.lib().ufr_flow_head_planes_backward(L.ptr(gy), L.ptr(self.pf_w[k]), L.ptr(self.pf_G[k].t), 0, chunks, self.B,
+        L.check(L.lib().ufr_flow_head_planes_backward(L.ptr(gy), L.ptr(self.pf_w[k]), self.pf_w[k].shape[0], L.ptr(self.pf_G[k].t),
+                                                      self.pf_G[k].chunks, 0, chunks, self.B,
                                                       src.H, src.W, int(accumulate), L.stream()), "predict_flow backward")
 
     def _up_forward(self, k):
@@ -565,7 +567,7 @@ class FlowNetCHeadEngine:
     def _deconv_tail(self, k):
         src, chunk0, chunks, Gd, out_chunk, (h, w) = self.tail_args[k]
         L.check(L.lib().ufr_deconv_flow_tail_backward_mfma(L.ptr(src.t), src.plane_stride, chunk0, chunks, L.ptr(self.tail_w[k]),
-                                                           L.ptr(Gd.t), out_chunk, self.B, h, w, L.stream()),
+                                                           self.tail_w[k].shape[0], L.ptr(Gd.t), Gd.chunks, out_chunk, self.B, h, w, L.stream()),
                 "deconv data gradient, flow channels")
 
     def _up_backward(self, k):

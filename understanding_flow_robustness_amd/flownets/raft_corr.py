@@ -96,6 +96,21 @@ def corr_lookup(pyramid, coords, radius, shared=None):
     return CorrLookupFunction.apply(coords, radius, shared, *pyramid)
 
 
+_ALL_PAIRS_PLANES: dict = {}
+
+
+def _all_pairs_planes(device, H, W, chunks):
+    """The two operand buffers of the all-pairs launch, one pair per shape (stream-ordered reuse: a launch reads them before the
+    next load overwrites them)."""
+    from .. import igemm as ig
+    key = (device, H, W, chunks)
+    if key not in _ALL_PAIRS_PLANES:
+        if len(_ALL_PAIRS_PLANES) >= 8:
+            _ALL_PAIRS_PLANES.clear()
+        _ALL_PAIRS_PLANES[key] = (ig.Planes(1, H, W, chunks, device), ig.Planes(1, H, W, chunks, device))
+    return _ALL_PAIRS_PLANES[key]
+
+
 class AllPairsCorrFunction(torch.autograd.Function):
     """corr[b, p, q] = <fmap1[b, :, p], fmap2[b, :, q]> / sqrt(C) (models/raft/corr.py:57-64) on the hand-written igemm
     (csrc/igemm.hip): per frame pair ONE 1x1 launch whose activation is fmap1's planes and whose "weight image" is fmap2's planes
@@ -106,8 +121,8 @@ class AllPairsCorrFunction(torch.autograd.Function):
     @staticmethod
     def supported(fmap1, fmap2) -> bool:
         B, C_, H, W = fmap1.shape
-        return (fmap1.is_cuda and fmap1.dtype == torch.float32 and fmap2.dtype == torch.float32 and fmap1.shape == fmap2.shape
-                and C_ % 32 == 0 and (H * W) % 128 == 0)
+        return (fmap1.is_cuda and fmap2.is_cuda and fmap1.device == fmap2.device and fmap1.dtype == torch.float32
+                and fmap2.dtype == torch.float32 and fmap1.shape == fmap2.shape and C_ % 32 == 0 and (H * W) % 128 == 0)
 
     @staticmethod
     def forward(ctx, fmap1, fmap2):
@@ -115,13 +130,19 @@ class AllPairsCorrFunction(torch.autograd.Function):
         B, C_, H, W = fmap1.shape
         HW = H * W
         scale = 1.0 / math.sqrt(C_)
+        # folded into fmap1 BEFORE the three-way bf16 split only where that is exact (a power of two: C = 64, 256, ...); for
+        # raft-small's C = 128 the volume is scaled afterwards, like the reference's matmul(...) / sqrt(dim) (corr.py:63)
+        fold = math.frexp(scale)[0] == 0.5
         out = torch.empty(B, HW, HW, dtype=torch.float32, device=fmap1.device)
         f1, f2 = fmap1.detach().contiguous(), fmap2.detach().contiguous()
         with torch.cuda.device(fmap1.device):
+            p1, p2 = _all_pairs_planes(fmap1.device, H, W, C_ // 32)         # load_nchw writes every chunk: no zero fill per call
             for b in range(B):
-                p1 = ig.Planes(1, H, W, C_ // 32, fmap1.device).load_nchw(f1[b:b + 1], 0, scale=scale)
-                p2 = ig.Planes(1, H, W, C_ // 32, fmap1.device).load_nchw(f2[b:b + 1], 0)
+                p1.load_nchw(f1[b:b + 1], 0, scale=scale if fold else 1.0)
+                p2.load_nchw(f2[b:b + 1], 0)
                 ig.make_launch(ig.planes_as_weights(p2), p1, 0, (H, W), (H, W), out_rowmajor=(out, b * HW * HW, HW), variant=6)()
+            if not fold:
+                out.mul_(scale)
         ctx.save_for_backward(fmap1, fmap2)
         ctx.scale = scale
         return out

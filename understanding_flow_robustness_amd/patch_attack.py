@@ -140,9 +140,7 @@ class PatchAttackStep:
         self.state = torch.zeros(4, **f32)     # stopped, executed, last loss, (pad)
         # data gradient only: skips a third of the reference's FLOPs (main.py:573 `loss.backward()` also fills weight
         # gradients nothing reads).  The caller's flags are remembered: `release(flow_net)` puts them back.
-        self._grad_flags = [(p, p.requires_grad) for p in self.net.parameters()]
-        for p, _ in self._grad_flags:
-            p.requires_grad_(False)
+        L.freeze_parameters(self.net)
         self.net.eval()
         self.graph = self.graph_b = self.graph_next = self.graph_b_next = None
         self._first = True
@@ -571,16 +569,13 @@ _STEP_CACHE_ATTR = "_ufr_patch_steps"
 def release(flow_net):
     """Drop every cached step of `flow_net` (captured graphs, static buffers) and give its parameters back the
     `requires_grad` flags they had before the first step froze them -- e.g. before a training phase on the same module."""
-    flags = {}
     for attr in (_STEP_CACHE_ATTR, "_ufr_universal_steps"):
         cache = flow_net.__dict__.get(attr)
-        for step in list(cache.values()) if cache else ():
-            for p, flag in getattr(step, "_grad_flags", ()):
-                flags.setdefault(id(p), (p, flag))        # the oldest step saw the caller's own flags
         if cache:
             cache.clear()
-    for p, flag in flags.values():
-        p.requires_grad_(flag)
+    # the caller's flags were recorded once per module at the first freeze (`_lib.freeze_parameters`), not per step: the step
+    # cache is LRU, so neither its iteration order nor an eviction may decide what is restored
+    L.restore_parameters(flow_net)
 
 
 def attack(flow_net, tgt_img_var, ref_past_img_var, ref_future_img_var, patch_var, mask_var,

@@ -71,6 +71,7 @@ def adversarial_training_batch(model, image1, image2, flow, valid, gt_full, args
     finally:
         for p, f in zip(model.parameters(), flags):
             p.requires_grad_(f)
+        model.__dict__.pop(L._GRAD_FLAGS_ATTR, None)          # the caller's flags are back: a later freeze records afresh
         model.train(was_training)
     return (torch.cat((image1, image1_adv)), torch.cat((image2, image2_adv)), torch.cat((flow, flow)),
             torch.cat((valid, valid)), epe_attacked)

@@ -161,12 +161,17 @@ class PlaneGraph:
             if P["kind"] != "conv":
                 continue
             db, d0, nch = P["db"], P["d0"], P["nch"]
-            readers = []
+            # (an "up" op PRODUCES its chunk of db in the forward and only reads db.grad in the backward: it is a writer, below)
+            readers = [Q for Q in self.ops if Q["kind"] in ("conv", "pf") and Q["sb"] is db and overlap(Q["s0"], Q["sk"], d0, nch)]
+            # the fusion rests on single assignment: every reader comes AFTER its producer in the forward order and nothing else
+            # writes the segment -- a reused segment would hand P's gradient planes to the wrong launch without any error
+            at = self.ops.index(P)
+            if any(self.ops.index(Q) <= at for Q in readers):
+                raise RuntimeError(f"PlaneGraph: a reader of {P.get('name', 'a convolution')}'s output segment runs before it (segment reused?)")
             for Q in self.ops:
-                if Q["kind"] in ("conv", "pf") and Q["sb"] is db and overlap(Q["s0"], Q["sk"], d0, nch):
-                    readers.append(Q)
-                elif Q["kind"] == "up" and Q["db"] is db and overlap(Q["chunk"], 1, d0, nch):
-                    readers.append(Q)
+                if Q is not P and ((Q["kind"] == "conv" and Q["db"] is db and overlap(Q["d0"], Q["nch"], d0, nch)) or
+                                   (Q["kind"] == "up" and Q["db"] is db and overlap(Q["chunk"], 1, d0, nch))):
+                    raise RuntimeError(f"PlaneGraph: two producers write chunks [{d0}, {d0 + nch}) of one buffer")
             if any(t["buf"] is db and overlap(t["chunk0"], -(-t["C"] // 32), d0, nch) for t in self.tensor_outputs):
                 continue
             # the reader that comes FIRST in the forward order runs LAST in the backward: when it is a convolution over exactly
@@ -238,7 +243,7 @@ class PlaneGraph:
             elif op["kind"] == "pf":
                 sb = op["sb"]
                 L.check(lib.ufr_flow_head_planes_forward_mfma(L.ptr(sb.planes.t), sb.planes.plane_stride, op["s0"], op["sk"], L.ptr(op["wm"]),
-                                                              L.ptr(op["b"]), L.ptr(self.flows[op["name"]]), self.B, sb.H, sb.W, st()),
+                                                              op["wm"].shape[0], L.ptr(op["b"]), L.ptr(self.flows[op["name"]]), self.B, sb.H, sb.W, st()),
                         "predict_flow forward")
             else:
                 f, db = self.flows[op["flow"]], op["db"]
@@ -272,7 +277,8 @@ class PlaneGraph:
                 op["bwd"]()
             elif op["kind"] == "pf":
                 sb = op["sb"]
-                L.check(lib.ufr_flow_head_planes_backward(L.ptr(self.g_flows[op["name"]]), L.ptr(op["wb"]), L.ptr(sb.grad.t), op["s0"], op["sk"],
+                L.check(lib.ufr_flow_head_planes_backward(L.ptr(self.g_flows[op["name"]]), L.ptr(op["wb"]), op["wb"].shape[0], L.ptr(sb.grad.t),
+                                                          sb.grad.chunks, op["s0"], op["sk"],
                                                           self.B, sb.H, sb.W, 1, st()), "predict_flow backward")
             else:
                 gf, db = self.g_flows[op["flow"]], op["db"]

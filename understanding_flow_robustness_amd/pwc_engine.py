@@ -373,11 +373,11 @@ class PwcHeadEngine:
 
     # ------------------------------------------------------------------------------------------------ small launches
     def _pf_forward(self, src, chunks, wm, b, out):
-        L.check(L.lib().ufr_flow_head_planes_forward_mfma(L.ptr(src.t), src.plane_stride, 0, chunks, L.ptr(wm), L.ptr(b), L.ptr(out),
+        L.check(L.lib().ufr_flow_head_planes_forward_mfma(L.ptr(src.t), src.plane_stride, 0, chunks, L.ptr(wm), wm.shape[0], L.ptr(b), L.ptr(out),
                                                           src.B, src.H, src.W, L.stream()), "predict_flow forward (mfma)")
 
     def _pf_backward(self, gy, w, Gs, chunks, accumulate=False):
-        L.check(L.lib().ufr_flow_head_planes_backward(L.ptr(gy), L.ptr(w), L.ptr(Gs.t), 0, chunks, Gs.B, Gs.H, Gs.W, int(accumulate),
+        L.check(L.lib().ufr_flow_head_planes_backward(L.ptr(gy), L.ptr(w), w.shape[0], L.ptr(Gs.t), Gs.chunks, 0, chunks, Gs.B, Gs.H, Gs.W, int(accumulate),
                                                       L.stream()), "predict_flow backward")
 
     def _finalize(self, Gs, g_chunk0, mask, mask_chunk0, out, out_chunk0, chunks):
@@ -495,7 +495,7 @@ class PwcHeadEngine:
                                                        L.ptr(self.up_flow[k]), B, h, w, st()), "deconv forward")
                 Dc = self.D[k + 1]
                 L.check(lib.ufr_upfeat_planes_forward_mfma(L.ptr(Dc.t), Dc.plane_stride, 0, Dc.chunks, L.ptr(self.uf_wm[k + 1]),
-                                                           L.ptr(self.uf_b[k + 1]), L.ptr(self.up_feat[k]), B, h, w, st()), "upfeat forward")
+                                                           self.uf_wm[k + 1].shape[0], L.ptr(self.uf_b[k + 1]), L.ptr(self.up_feat[k]), B, h, w, st()), "upfeat forward")
                 torch.mul(self.up_flow[k], FLOW_SCALE[k], out=self.up_flow_s[k])
                 L.check(lib.ufr_pwc_warp_forward(L.ptr(c2), L.ptr(self.up_flow_s[k]), L.ptr(self.warped[k]), B, FEAT[k], *self.grid[k], st()),
                         "warp forward")
@@ -527,7 +527,7 @@ class PwcHeadEngine:
             D, Gd, gz = self.D[k], self.G_D[k], self.gzD[k]
             self._pf_backward(g_flow, self.pf_w[k], Gd, D.chunks)
             if k > 2:                                                  # + upfeat^T of the finer level's up_feat gradient
-                L.check(lib.ufr_upfeat_planes_backward(L.ptr(self.g_upfeat[k - 1]), L.ptr(self.uf_wb[k]), L.ptr(Gd.t), 0, D.chunks, B,
+                L.check(lib.ufr_upfeat_planes_backward(L.ptr(self.g_upfeat[k - 1]), L.ptr(self.uf_wb[k]), self.uf_wb[k].shape[0], L.ptr(Gd.t), Gd.chunks, 0, D.chunks, B,
                                                        *self.grid[k], 1, st()), "upfeat backward")
                 self._finalize(Gd, 0, D, 0, gz, 0, 1)                  # conv_4: no later convolution reads it
             for j in ((4, 3, 2, 1, 0) if k == 2 else (3, 2, 1, 0)):

@@ -266,7 +266,8 @@ class RaftUpdateEngine:
                     L.check(lib.ufr_gru_blend_cm_forward(L.ptr(Q.t), L.ptr(ZR.t), L.ptr(buf.t), buf.plane_stride, 0, L.ptr(nxt.t),
                                                          nxt.plane_stride, 0, M, HC, st()), "gru blend forward")
             self.launch[("fh1", it)]()
-            L.check(lib.ufr_flow_head_planes_forward_mfma(L.ptr(self.FH.t), self.FH.plane_stride, 0, 8, L.ptr(self.fh2_wm), L.ptr(self.fh2_b),
+            L.check(lib.ufr_flow_head_planes_forward_mfma(L.ptr(self.FH.t), self.FH.plane_stride, 0, 8, L.ptr(self.fh2_wm), self.fh2_wm.shape[0],
+                                                          L.ptr(self.fh2_b),
                                                           L.ptr(self.delta), B, h, w, st()), "delta_flow")
             self.coords1.add_(self.delta)
         self.launch[("mask1",)]()
@@ -288,7 +289,8 @@ class RaftUpdateEngine:
             self.launch[("mask1^T",)]()
         else:
             self.TA.t[:HC].zero_()
-        L.check(lib.ufr_flow_head_planes_backward(L.ptr(g_flow.contiguous()), L.ptr(self.fh2_w), L.ptr(self.G_fh.t), 0, 8, B, h, w, 0,
+        L.check(lib.ufr_flow_head_planes_backward(L.ptr(g_flow.contiguous()), L.ptr(self.fh2_w), self.fh2_w.shape[0], L.ptr(self.G_fh.t),
+                                                  self.G_fh.chunks, 0, 8, B, h, w, 0,
                                                   st()), "delta_flow backward")
         L.check(lib.ufr_grad_finalize(L.ptr(self.G_fh.t), 0, L.ptr(self.FH.t), 0, L.ptr(self.gz_fh.t), self.gz_fh.plane_stride, 0, M, 8,
                                       0.0, st()), "flow head finalize")

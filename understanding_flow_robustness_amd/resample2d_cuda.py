@@ -1,6 +1,12 @@
 """Drop-in for the reference's pybind module `resample2d_cuda`
 (models/resample2d_package/resample2d_cuda.cc:6-31): the CALLER allocates every output buffer,
-functions return 1, fp32 only (resample2d_kernel.cu:221-234)."""
+functions return 1, fp32 only (resample2d_kernel.cu:221-234).
+
+Contract of `backward` (both kernels behind it, whatever C and UFR_RESAMPLE_LDS): gradInput1 and gradInput2 are OVERWRITTEN with
+the gradients -- what the reference computes into the zero-filled buffers its only caller hands over
+(models/resample2d_package/resample2d.py:31-43).  The reference kernel itself atomically ADDS onto gradInput1
+(resample2d_kernel.cu:118-121); a caller that relied on accumulating into a non-zero buffer must add the result itself
+(INTEGRATION.md 3)."""
 from __future__ import annotations
 
 import os
@@ -17,6 +23,20 @@ def _check(**tensors):
             raise RuntimeError(f"{n} must be float32 (resample2d is fp32 only)")
         if t.dim() != 4:
             raise RuntimeError(f"{n} must be 4-D")
+
+
+_WORKSPACES: dict = {}            # (device, B, H, W) -> int32 workspace of the owner-computes adjoint (sampling boxes per tile)
+
+
+def _workspace(device, B, H, W):
+    key = (device, B, H, W)
+    ws = _WORKSPACES.get(key)
+    if ws is None:
+        if len(_WORKSPACES) >= 16:
+            _WORKSPACES.clear()
+        nbytes = int(L.lib().ufr_resample2d_backward_workspace_bytes(B, H, W))
+        ws = _WORKSPACES[key] = (torch.empty((nbytes + 15) // 16 * 4, dtype=torch.int32, device=device), nbytes)
+    return ws
 
 
 def forward(input1, input2, output, kernel_size, bilinear):
@@ -44,8 +64,8 @@ def backward(input1, input2, gradOutput, gradInput1, gradInput2, kernel_size, bi
         if (int(kernel_size) == 1 and (Hi, Wi) == (H, W) and Cc <= 12 and os.environ.get("UFR_RESAMPLE_LDS", "1") == "1"):
             # the adjoint without global atomics: one owner workgroup per tile of gradInput1 (csrc/resample2d_owner.hip);
             # UFR_RESAMPLE_LDS=3 keeps round 2's LDS-privatised scatter, 0 the reference's direct scatter
-            nbytes = int(L.lib().ufr_resample2d_backward_workspace_bytes(B, H, W))
-            ws = torch.empty((nbytes + 15) // 16 * 4, dtype=torch.int32, device=input1.device)
+            # (the workspace is written by launch A and read by launch B of the same call, in stream order: one per shape)
+            ws, nbytes = _workspace(input1.device, B, H, W)
             L.check(L.lib().ufr_resample2d_backward_owner(L.ptr(input1), L.ptr(input2), L.ptr(gradOutput), L.ptr(gradInput1),
                                                           L.ptr(gradInput2), L.ptr(ws), nbytes, B, Cc, H, W, L.stream()),
                     "resample2d_cuda.backward")

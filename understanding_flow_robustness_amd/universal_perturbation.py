@@ -77,9 +77,7 @@ class UniversalPerturbationStep:
         self.loss_cur = self.packed[2 * self.CHW:]
         self.scale_t = torch.ones(1, **f32)     # 1/normaliser of the loss, device-resident
         self.loss_ws = torch.zeros(L.LOSS_PARTIALS, **f32)     # workgroup partials of the fixed-order loss reduction
-        self._grad_flags = [(p, p.requires_grad) for p in self.model.parameters()]   # patch_attack.release() restores them
-        for p, _ in self._grad_flags:
-            p.requires_grad_(False)
+        L.freeze_parameters(self.model)                         # patch_attack.release() restores the caller's flags
         self.model.eval()
         self.graph = self.graph_b = None
         self.use_graph, self._warmup, self._captured = use_graph, warmup, False
