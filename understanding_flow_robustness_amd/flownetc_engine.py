@@ -115,6 +115,7 @@ class FlowNetCHeadEngine:
             kw.setdefault("variant", self._variant_for(wi))
             bm, target = self._tile_rows_and_slots(wi, kw)
             S = ig.splitk_for(M, wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target)
+            kw["variant"], S = ig.tuned(wi, M, kw, kw["variant"], S)
             plans.append((wi, x, in_chunk0, rows, out_hw, S, kw))
             return len(plans) - 1
 

@@ -308,6 +308,42 @@ class Launch:
         return float(b)
 
 
+# ---- per-launch tuning (round 5) ------------------------------------------------------------------------------------------
+# Every engine picks a launch's kernel form and split-K factor by a rule of thumb (`splitk_for` + its own default variant); on the
+# small grids of the one-pair configs (RAFT's 48 x 160 update block, FlowNet2's sub-networks at 448 x 1024) the best pair
+# depends on the launch.  `tools/sweep_engine_launches.py` times every distinct launch of a config with every (variant, split-K)
+# pair on the step's own buffers and writes the winners to `igemm_tuning.json`, keyed by `launch_signature`; `tuned()` is asked
+# by every engine right after its rule of thumb.  UFR_IGEMM_TUNING=0 switches the table off (the sweep tool does, to see the rule).
+_TUNING = None
+RECORD = None            # a list while tools/sweep_engine_launches.py builds a step: every make_launch() appends its arguments
+
+
+def launch_signature(wi: "WeightImage", M: int, kw: dict) -> str:
+    """What decides a launch's best form: rows, padded columns, K chunks, taps per phase, strides, and how the result leaves."""
+    out = ("slabs" if kw.get("no_reduce") else "rowmajor" if kw.get("out_rowmajor") is not None else
+           ("planes" if kw.get("out_planes") is not None else "") + ("f32" if kw.get("out_f32") is not None else ""))
+    out += ("+add" if kw.get("add") is not None else "") + ("+mask" if kw.get("mask") is not None else "") + ("+tail" if kw.get("tail") is not None else "")
+    taps = "-".join(str(len(t)) for _, _, t in wi.phases)
+    return f"M{M}_N{wi.Npad}_KC{wi.KC}_t{taps}_s{wi.geometry['in_s']}{wi.geometry['out_s']}_{out}"
+
+
+def _tuning_table() -> dict:
+    global _TUNING
+    if _TUNING is None:
+        _TUNING = {}
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "igemm_tuning.json")
+        if os.environ.get("UFR_IGEMM_TUNING", "1") != "0" and os.path.exists(path):
+            import json
+            with open(path) as f:
+                _TUNING = {k: tuple(v) for k, v in json.load(f).items() if not k.startswith("_")}
+    return _TUNING
+
+
+def tuned(wi: "WeightImage", M: int, kw: dict, variant: int, splitk: int):
+    """(variant, splitk) of the tuning table for this launch, else the engine's own choice."""
+    return _tuning_table().get(launch_signature(wi, M, kw), (variant, splitk))
+
+
 def make_launch(wi: WeightImage, x: Planes, in_chunk0: int, rows_hw, out_hw, *, out_planes: Planes | None = None,
                 out_chunk0: int = 0, out_f32: GradSum | None = None, out_f32_chunk0: int = 0, bias: torch.Tensor | None = None,
                 add: GradSum | None = None, add_chunk0: int = 0, mask: Planes | None = None, mask_chunk0: int = 0,
@@ -321,6 +357,13 @@ def make_launch(wi: WeightImage, x: Planes, in_chunk0: int, rows_hw, out_hw, *, 
     into `tail` (chunk `tail_chunk0` on; `tail_accumulate`: added onto it); that layer's own launch passes it as `add`.
     the row grid's columns start at origins[b*stride] // divisor.  in_band = (origins, stride, divisor, width): input
     columns outside [origin, origin + width) read as zero.  bias given -> forward epilogue (bias + LeakyReLU)."""
+    if RECORD is not None:
+        RECORD.append(dict(wi=wi, x=x, in_chunk0=in_chunk0, rows=tuple(rows_hw), out_hw=tuple(out_hw), splitk=splitk, variant=variant,
+                           kw=dict(out_planes=out_planes, out_chunk0=out_chunk0, out_f32=out_f32, out_f32_chunk0=out_f32_chunk0, bias=bias,
+                                   add=add, add_chunk0=add_chunk0, mask=mask, mask_chunk0=mask_chunk0, slope=slope, row_band=row_band,
+                                   in_band=in_band, tail=tail, tail_n0=tail_n0, tail_chunk0=tail_chunk0, tail_accumulate=tail_accumulate,
+                                   out_rowmajor=out_rowmajor, planes_chunks=planes_chunks, f32_first_chunk=f32_first_chunk,
+                                   no_reduce=no_reduce)))
     d = L.IgemmDesc()
     d.x, d.x_plane_stride, d.in_chunk0, d.KC = x.t.data_ptr(), x.plane_stride, int(in_chunk0), wi.KC
     if in_chunk0 + wi.KC > x.chunks:

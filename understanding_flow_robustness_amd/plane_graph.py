@@ -208,8 +208,9 @@ class PlaneGraph:
         for holder, wi, x, c0, rows, out_hw, kw in self._plans:
             pk = [len(t) * wi.KC for _, _, t in wi.phases]
             bm, target = (256, 256) if kw["variant"] in (6, 7) else (128, 768)
-            sized.append(ig.splitk_for(B * rows[0] * rows[1], wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target,
-                                       min_ktiles=4))
+            S = ig.splitk_for(B * rows[0] * rows[1], wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target, min_ktiles=4)
+            kw["variant"], S = ig.tuned(wi, B * rows[0] * rows[1], kw, kw["variant"], S)
+            sized.append(S)
         need = max([len(p[1].phases) * S * B * p[4][0] * p[4][1] * p[1].Npad for p, S in zip(self._plans, sized) if S > 1] + [1])
         self.ws = torch.empty(need, dtype=torch.float32, device=self.dev)
         for (holder, wi, x, c0, rows, out_hw, kw), S in zip(self._plans, sized):

@@ -167,8 +167,9 @@ class RaftEncoderEngine:
             pk = [len(t) * wi.KC for _, _, t in wi.phases]
             v = kw["variant"]
             bm, target = (256, 256) if v in (6, 7) else (128, 768)
-            sized.append(ig.splitk_for(n * rows[0] * rows[1], wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target,
-                                       min_ktiles=4))
+            S = ig.splitk_for(n * rows[0] * rows[1], wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target, min_ktiles=4)
+            kw["variant"], S = ig.tuned(wi, n * rows[0] * rows[1], kw, v, S)
+            sized.append(S)
         need = max([len(p[1].phases) * S * n * p[3][0] * p[3][1] * p[1].Npad for p, S in zip(self._plans, sized) if S > 1] + [1])
         self.ws = torch.empty(need, dtype=torch.float32, device=dev)
         for (holder, wi, xin, rows, out_hw, kw), S in zip(self._plans, sized):

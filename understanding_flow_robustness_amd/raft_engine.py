@@ -114,6 +114,7 @@ class RaftUpdateEngine:
             kw.setdefault("variant", 6 if wi.Npad % 128 == 0 else 2)
             bm, target = (256, 256) if kw["variant"] == 6 else (128, 768)
             S = ig.splitk_for(self.M, wi.Npad, max(pk), 1, phase_ktiles=pk, bm=bm, target=target, min_ktiles=4)
+            kw["variant"], S = ig.tuned(wi, self.M, kw, kw["variant"], S)
             plans.append((key, wi, x, in_chunk0, S, kw))
 
         W = dict(convc1=cw(enc.convc1, 0), convc2=cw(enc.convc2, 1), convf1=cw(wf1, 0), convf2=cw(enc.convf2, 1), conv=cw(enc.conv, 1),
