@@ -551,6 +551,12 @@ int ufr_igemm_clock_probe(unsigned long long* buf, int capacity_workgroups);
  * (scale = 1, slope = 1: a plain conversion).  ufr_chunks_to_nchw: out[B,C,H,W] = scale * leaky'(mask) * v, v from planes
  * (p0 + p1 + p2) or from an fp32 chunk-major tensor (exactly one of `planes`, `f32`).  ufr_grad_finalize: gradient planes =
  * split(g * leaky'(mask)) for `chunks` chunks of M pixels. */
+/* A row-major float32 matrix src [rows][ld] (first `cols` columns) as the operand of a GEMM reduced over its COLUMNS:
+ * planes[chunk0 + k/32][m][k%32] = split(scale * src[m][k]) in a buffer of `plane_rows` rows per chunk (round 5: the adjoint of RAFT's
+ * all-pairs correlation, models/raft/corr.py:57-64 -- the volume's gradient and the feature maps as igemm operands; the reduction
+ * over the ROWS of the same matrix is ufr_nchw_to_planes with channels = rows). */
+int ufr_rowmajor_to_planes(const float* src, long ld, long rows, int cols, float scale, void* planes, long plane_stride, int chunk0,
+                           long plane_rows, ufr_stream_t stream);
 int ufr_nchw_to_planes(const float* x, void* planes, long plane_stride, int chunk0, int B, int C, int H, int W,
                        float scale, float slope, const float* bias, ufr_stream_t stream);
 /* The windowed prefix's results patched into cached full-frame features that live in the plane layout: as

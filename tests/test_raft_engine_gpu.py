@@ -113,6 +113,30 @@ def test_raft_attack_at_full_size_engine_vs_torch_spelling(raft, monkeypatch, al
     assert e_eng <= max(1.5 * e_torch, 1e-3) and e_same <= 1e-2
 
 
+@pytest.mark.parametrize("rows_hw,cols,chunk0,scale", [((10, 10), 70, 1, 1.0), ((16, 24), 384, 0, 0.0625), ((1, 256), 7680, 0, 1.0)])
+def test_rowmajor_matrix_to_planes_is_the_exact_three_way_split(rows_hw, cols, chunk0, scale):
+    """`ufr_rowmajor_to_planes` (the column-reduced operand of the all-pairs adjoint): planes[chunk0 + k/32][m][k%32] holds the three
+    bf16 planes of scale * src[m][k] bit for bit (igemm._split3: round to nearest at every step), zeros in the padding columns,
+    neighbouring chunks untouched; a strided source (ld > cols) and a range that leaves the buffer is refused."""
+    from understanding_flow_robustness_amd import _lib as L
+    from understanding_flow_robustness_amd import igemm as ig
+    H, W = rows_hw
+    M, kc = H * W, (cols + 31) // 32
+    g = torch.Generator().manual_seed(cols)
+    wide = torch.randn(M, cols + 8, generator=g).to(DEV)
+    src = wide[:, :cols]                                                # ld = cols + 8
+    pl = ig.Planes(1, H, W, chunk0 + kc + 1, DEV)
+    pl.t.fill_(7.0)
+    pl.load_rowmajor(src, chunk0, scale=scale)
+    want = torch.zeros(M, kc * 32, device=DEV)
+    want[:, :cols] = src * scale
+    want = ig._split3(want.view(M, kc, 32).permute(1, 0, 2).contiguous()).view(3, kc, M, 32)
+    assert torch.equal(pl.t[:, chunk0:chunk0 + kc], want)
+    assert bool((pl.t[:, chunk0 + kc:] == 7.0).all()) and bool((pl.t[:, :chunk0] == 7.0).all())
+    rc = L.lib().ufr_rowmajor_to_planes(L.ptr(src), src.stride(0), M, cols, 1.0, L.ptr(pl.t), pl.plane_stride, chunk0 + 2, M, L.stream())
+    assert rc == -1 and b"leave the planes operand" in L.lib().ufr_last_error()
+
+
 @pytest.mark.parametrize("B,C,H,W", [(1, 256, 48, 160), (2, 256, 16, 24), (2, 128, 16, 16)])
 def test_all_pairs_correlation_on_the_igemm(B, C, H, W, monkeypatch):
     """`CorrBlock.corr` (models/raft/corr.py:57-64: matmul / sqrt(C)) as ONE hand-written igemm launch per pair with fmap2's
@@ -133,10 +157,21 @@ def test_all_pairs_correlation_on_the_igemm(B, C, H, W, monkeypatch):
     e_eng, e_lib = rel(got, want), rel(lib32, want)
     print(f"all-pairs {B}x{C}x{H}x{W}: igemm {e_eng:.2e}, library fp32 {e_lib:.2e} (vs float64)")
     assert e_eng <= max(3 * e_lib, 2e-6)
+    # the adjoint (round 5: both products on the igemm, the volume's gradient as the activation, the feature maps as the weight
+    # image) against float64, judged by the library GEMM's own float32 error like the forward
     go = torch.randn(got.shape, generator=g).to(DEV)
     g1, g2 = torch.autograd.grad(got, (f1, f2), go)
     r1, r2 = torch.autograd.grad(lib32, (f1, f2), go)
-    assert rel(g1, r1.double()) <= 1e-5 and rel(g2, r2.double()) <= 1e-5
+    go64 = go.double().view(B, H * W, H * W)
+    w1 = (torch.matmul(f2.detach().double().view(B, C, -1), go64.transpose(1, 2)) / C ** 0.5).view_as(f1)
+    w2 = (torch.matmul(f1.detach().double().view(B, C, -1), go64) / C ** 0.5).view_as(f2)
+    for name, mine, lib_, want_ in (("d fmap1", g1, r1, w1), ("d fmap2", g2, r2, w2)):
+        e_eng, e_lib = rel(mine, want_), rel(lib_, want_)
+        print(f"all-pairs adjoint {name} {B}x{C}x{H}x{W}: igemm {e_eng:.2e}, library fp32 {e_lib:.2e} (vs float64)")
+        assert e_eng <= max(3 * e_lib, 2e-6), f"{name}: {e_eng:.2e} (library {e_lib:.2e})"
+    monkeypatch.setenv("UFR_ALLPAIRS_ADJOINT", "0")                    # the library-GEMM form stays available for A/B runs
+    k1, k2 = torch.autograd.grad(CorrBlock.corr(f1, f2), (f1, f2), go)
+    assert rel(k1, r1.double()) <= 1e-5 and rel(k2, r2.double()) <= 1e-5
 
 
 @pytest.mark.parametrize("n,H,W,chunks", [(2, 32, 64, 2), (1, 55, 128, 4), (2, 17, 23, 3)])

@@ -99,8 +99,7 @@ def sweep(config, out_dir):
     # the largest batch of each signature family is the step's (the clean forward runs pair by pair on its own engines): keep all,
     # the table is keyed by M anyway
     for sig, r in seen.items():
-        wi, kw, M = r["wi"], {k: v for k, v in r["kw"].items() if v is not None and v is not False and v != 0 or k == "slope"}, r["M"]
-        kw["slope"] = r["kw"]["slope"]
+        wi, kw, M = r["wi"], dict(r["kw"]), r["M"]
         gflop = wi.flops(M) / 1e9
         chosen = (r["variant"] if r["variant"] else 2, r["splitk"])
         variants = (6, 7, 5, 4, 2) if wi.Npad % 128 == 0 else (2, 7)

@@ -140,6 +140,7 @@ SIGNATURES = {
     "ufr_pwc_warp_forward": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_pwc_warp_backward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_igemm": [C.POINTER(IgemmDesc), _vp],
+    "ufr_rowmajor_to_planes": [_vp, _l, _l, _i, _f, _vp, _l, _i, _l, _vp],
     "ufr_nchw_to_planes": [_vp, _vp, _l, _i, _i, _i, _i, _i, _f, _f, _vp, _vp],
     "ufr_window_scatter_planes": [_vp, _vp, _l, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ufr_chunks_to_nchw": [_vp, _l, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _f, _vp],

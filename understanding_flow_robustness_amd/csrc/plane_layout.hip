@@ -62,6 +62,40 @@ __global__ __launch_bounds__(256) void nchw_to_planes_kernel(const float* __rest
   *reinterpret_cast<bf16x8*>(dst + 2 * plane_stride) = q2;
 }
 
+// A ROW-MAJOR float32 matrix src [rows][ld] (its first `cols` columns) -> planes[chunk0 + k / 32][m][k % 32] = split(scale * src[m][k]):
+// the operand layout of a GEMM whose reduction runs over the matrix's COLUMNS (RAFT's all-pairs adjoint: the volume's gradient
+// g[p][q] reduced over q, the feature maps [C][HW] as weight images reduced over the pixels).  The reduction over the ROWS is
+// nchw_to_planes_kernel on the same matrix read as [channels = rows][pixels = columns].  Workgroup = 64 rows x one chunk: a row's
+// 128 bytes in, 4 KB contiguous per plane out; columns >= cols of the last chunk are written as zeros.
+__global__ __launch_bounds__(256) void rowmajor_to_planes_kernel(const float* __restrict__ src, long ld, long rows, int cols, float scale,
+                                                                 __bf16* __restrict__ planes, long plane_stride, int chunk0,
+                                                                 long plane_rows) {
+  const int tid = threadIdx.x, p = tid >> 2, ch = tid & 3;
+  const long m = (long)blockIdx.y * 64 + p;
+  if (m >= rows) return;
+  const int k0 = blockIdx.x * 32 + ch * 8;
+  const float* s = src + m * ld + k0;
+  float v[8];
+  if (k0 + 8 <= cols && ((reinterpret_cast<size_t>(s) & 15) == 0)) {
+    const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = k0 + j < cols ? s[j] : 0.f;
+  }
+  bf16x8 q0, q1, q2;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    __bf16 a, b, c;
+    split3(v[j] * scale, a, b, c);
+    q0[j] = a; q1[j] = b; q2[j] = c;
+  }
+  __bf16* dst = planes + (((size_t)chunk0 + blockIdx.x) * plane_rows + m) * 32 + ch * 8;
+  *reinterpret_cast<bf16x8*>(dst) = q0;
+  *reinterpret_cast<bf16x8*>(dst + plane_stride) = q1;
+  *reinterpret_cast<bf16x8*>(dst + 2 * plane_stride) = q2;
+}
+
 // ---- conv1 (Conv2d(3, 64, 7, 2, 3), models/FlowNetC.py:22) as an igemm launch --------------------------------------------
 // A 3-channel pixel would leave 29 of a chunk's 32 channels empty.  The frames are therefore written as PACKED planes: the
 // 2 x 2 pixel-unshuffle turns the stride-2 7 x 7 convolution into a stride-1 4 x 4 one over 12 channels on the half grid,
@@ -370,6 +404,20 @@ extern "C" int ufr_nchw_to_planes(const float* x, void* planes, long plane_strid
   nchw_to_planes_kernel<<<grid, 256, 0, ufr::as_stream(stream)>>>(x, static_cast<__bf16*>(planes), plane_stride, chunk0, B, C,
                                                                    H * W, scale, slope, bias, nullptr);
   return ufr::launched("nchw_to_planes_kernel");
+}
+
+extern "C" int ufr_rowmajor_to_planes(const float* src, long ld, long rows, int cols, float scale, void* planes, long plane_stride,
+                                      int chunk0, long plane_rows, ufr_stream_t stream) {
+  UFR_REQUIRE(src && planes, "row-major -> planes: null pointer");
+  UFR_REQUIRE(rows > 0 && cols > 0 && ld >= cols && chunk0 >= 0 && plane_rows >= rows && rows < (1L << 31) * 64, "row-major -> planes: bad shape");
+  const int chunks = (cols + 31) / 32;
+  UFR_REQUIRE((long)(chunk0 + chunks) * plane_rows * 32 <= plane_stride, "row-major -> planes: chunks [%d, %d) leave the planes operand",
+              chunk0, chunk0 + chunks);
+  const dim3 grid(chunks, (unsigned)((rows + 63) / 64));
+  UFR_REQUIRE(grid.y < 65536, "row-major -> planes: too many rows for one launch (%ld)", rows);
+  rowmajor_to_planes_kernel<<<grid, 256, 0, ufr::as_stream(stream)>>>(src, ld, rows, cols, scale, static_cast<__bf16*>(planes),
+                                                                       plane_stride, chunk0, plane_rows);
+  return ufr::launched("rowmajor_to_planes_kernel");
 }
 
 extern "C" int ufr_nchw_grad_to_planes(const float* grad, const float* act, void* planes, long plane_stride, int chunk0, int B, int C,

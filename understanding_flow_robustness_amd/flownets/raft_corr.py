@@ -111,12 +111,56 @@ def _all_pairs_planes(device, H, W, chunks):
     return _ALL_PAIRS_PLANES[key]
 
 
+_ALL_PAIRS_ADJOINT: dict = {}
+
+
+def _all_pairs_adjoint(fmap1, fmap2, g, scale, needs):
+    """Both adjoint products of the all-pairs correlation on the igemm (see AllPairsCorrFunction); g [B, HW, HW] contiguous."""
+    from .. import igemm as ig
+    B, C_, H, W = fmap1.shape
+    HW, dev = H * W, fmap1.device
+    key = (dev, H, W, C_)
+    st = _ALL_PAIRS_ADJOINT.get(key)
+    if st is None:
+        if len(_ALL_PAIRS_ADJOINT) >= 4:
+            _ALL_PAIRS_ADJOINT.clear()
+        st = _ALL_PAIRS_ADJOINT[key] = dict(A=ig.Planes(1, H, W, HW // 32, dev),            # the gradient as the activation
+                                            Wf=ig.Planes(1, 1, C_, HW // 32, dev),           # a feature map [C, HW] as the weights
+                                            out=ig.GradSum(1, H, W, C_ // 32, dev))
+        wi = ig.planes_as_weights(st["Wf"])
+        S = ig.splitk_for(HW, wi.Npad, wi.KC, 1, bm=256, target=256, min_ktiles=4)
+        wi_variant, S = ig.tuned(wi, HW, dict(out_f32=st["out"]), 6, S)
+        st["ws"] = torch.empty(max(1, S * HW * wi.Npad), dtype=torch.float32, device=dev) if S > 1 else None
+        st["launch"] = ig.make_launch(wi, st["A"], 0, (H, W), (H, W), out_f32=st["out"], splitk=S, ws=st["ws"], variant=wi_variant)
+    A, Wf, out, launch = st["A"], st["Wf"], st["out"], st["launch"]
+    f1, f2 = fmap1.detach().contiguous().view(B, C_, HW), fmap2.detach().contiguous().view(B, C_, HW)
+    g1 = torch.empty_like(fmap1) if needs[0] else None
+    g2 = torch.empty_like(fmap2) if needs[1] else None
+    with torch.cuda.device(dev):
+        for b in range(B):
+            if needs[0]:
+                A.load_rowmajor(g[b])                                  # A[p][q] = g[p, q]
+                Wf.load_rowmajor(f2[b])                                # W[c][q] = fmap2[c, q]
+                launch()
+                out.to_nchw(C_, 0, scale=scale, slope=1.0, out=g1[b:b + 1])
+            if needs[1]:
+                A.load_nchw(g[b].view(1, HW, H, W))                    # A[q][p] = g[p, q]: channels = g's rows
+                Wf.load_rowmajor(f1[b])                                # W[c][p] = fmap1[c, p]
+                launch()
+                out.to_nchw(C_, 0, scale=scale, slope=1.0, out=g2[b:b + 1])
+    return g1, g2
+
+
 class AllPairsCorrFunction(torch.autograd.Function):
     """corr[b, p, q] = <fmap1[b, :, p], fmap2[b, :, q]> / sqrt(C) (models/raft/corr.py:57-64) on the hand-written igemm
     (csrc/igemm.hip): per frame pair ONE 1x1 launch whose activation is fmap1's planes and whose "weight image" is fmap2's planes
     (the two layouts coincide, igemm.planes_as_weights), float32-accurate on the bf16 matrix cores, the row-major volume written
     by the epilogue.  The 1/sqrt(C) goes into fmap1's planes (exact for C = 256: a power of two).
-    Backward = the two products with the volume's gradient (library GEMMs on the 236 MB gradient, as before)."""
+    Backward (round 5) = the two products with the volume's gradient g[p, q] on the same kernel, per frame pair:
+        d fmap1[c, p] = scale * sum_q g[p, q] fmap2[c, q]    rows p, reduction over g's COLUMNS: g through `Planes.load_rowmajor`,
+        d fmap2[c, q] = scale * sum_p g[p, q] fmap1[c, p]    rows q, reduction over g's ROWS: g read as [channels p][pixels q],
+    the feature maps [C, HW] as the weight image (row-major -> planes with C "pixels": the layouts coincide, planes_as_weights),
+    float32 sums out, split-K with the fixed-order reduction.  UFR_ALLPAIRS_ADJOINT=0 keeps the library GEMMs (A/B only)."""
 
     @staticmethod
     def supported(fmap1, fmap2) -> bool:
@@ -153,6 +197,9 @@ class AllPairsCorrFunction(torch.autograd.Function):
         B, C_, H, W = fmap1.shape
         g = g.reshape(B, H * W, H * W)
         g1 = g2 = None
+        if (AllPairsCorrFunction.supported(fmap1, fmap2) and g.is_cuda and g.dtype == torch.float32
+                and os.environ.get("UFR_ALLPAIRS_ADJOINT", "1") != "0"):
+            return _all_pairs_adjoint(fmap1, fmap2, g.contiguous(), ctx.scale, ctx.needs_input_grad)
         if ctx.needs_input_grad[0]:
             g1 = (torch.matmul(fmap2.reshape(B, C_, -1), g.transpose(1, 2)) * ctx.scale).view_as(fmap1)
         if ctx.needs_input_grad[1]:

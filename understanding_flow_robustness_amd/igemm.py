@@ -53,6 +53,16 @@ class Planes:
                 "nchw -> planes")
         return self
 
+    def load_rowmajor(self, src: torch.Tensor, chunk0: int = 0, scale: float = 1.0):
+        """planes[chunk0 + k/32][m][k%32] = split(scale * src[m][k]) for a row-major float32 matrix src [M, K] (the operand of a
+        GEMM reduced over the matrix's columns; rows = this buffer's pixels)."""
+        L.require_hip(src, "src", contiguous=False)
+        if src.dim() != 2 or src.stride(1) != 1 or src.dtype != torch.float32 or src.shape[0] != self.M or chunk0 + pad32(src.shape[1]) // 32 > self.chunks:
+            raise RuntimeError("Planes.load_rowmajor: shape mismatch")
+        L.check(L.lib().ufr_rowmajor_to_planes(L.ptr(src), src.stride(0), src.shape[0], src.shape[1], float(scale), L.ptr(self.t),
+                                               self.plane_stride, int(chunk0), self.M, L.stream()), "row-major -> planes")
+        return self
+
     def to_nchw(self, Cn: int, chunk0: int = 0, out: torch.Tensor | None = None) -> torch.Tensor:
         if out is None:
             out = torch.empty(self.B, Cn, self.H, self.W, dtype=torch.float32, device=self.t.device)
