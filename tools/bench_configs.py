@@ -41,12 +41,16 @@ def igemm_roofline(net):
     """The dominant kernel of a config = csrc/igemm.hip: every prepared launch of every native engine the network's step ran
     on, timed live with HIP events on the step's own buffers (they hold the last iteration's real activations: zero operands
     draw less power and clock higher), algorithmic FLOPs 2 * rows * taps * Cin * Cout / the six-product ceiling."""
-    engines = [eng for mod in net.modules() for attr in ("_ufr_head_engines", "_ufr_encoder_engines")
+    engines = [eng for mod in net.modules() for attr in ("_ufr_head_engines", "_ufr_encoder_engines", "_ufr_plane_graphs")
                for eng in mod.__dict__.get(attr, {}).values()]
     batch = lambda e: getattr(e, "B", None) or getattr(e, "n", 1)
-    top = max([batch(e) for e in engines] + [1])
-    # (the clean forward that makes the target runs pair by pair on its own one-pair engines: not the step's)
-    tables = [e.launch_table() for e in engines if batch(e) * 2 > top]
+    # the step's batch = the largest `B` of a head / update / graph engine (an encoder engine's `n` counts FRAMES: 2 per pair for
+    # RAFT's feature encoder).  With more than one pair per step the clean forward that makes the target ran pair by pair on its
+    # own one-pair engines: those are not the step's.  (Round 4 compared `n` and `B` directly and thereby dropped RAFT's whole
+    # update block at one pair, and never looked at the PlaneGraph sub-networks of FlowNet2: its C3 / C5 fractions covered the
+    # encoders / the three heads only.)
+    top = max([e.B for e in engines if hasattr(e, "B")] + [1])
+    tables = [e.launch_table() for e in engines if top == 1 or batch(e) >= top]
     ms = gflop = 0.0
     n = 0
     for table in tables:
