@@ -267,20 +267,26 @@ int ufr_raft_motion_finish_slabs(const float* ws, int splitk, int Npad, int N, c
 int ufr_gru_gates_cm_forward(float* zr, const void* h, long h_plane_stride, int h_chunk0, void* rh, long rh_plane_stride,
                              int rh_chunk0, long M, int chunks, ufr_stream_t stream);
 /* The same two kernels reading the pre-activations straight from a `no_reduce` split-K launch's slabs (columns [z | r] resp. q; the
- * float32 pre-activation tensor is then only written -- sigmoid / tanh values for the adjoint -- never read). */
-int ufr_gru_gates_cm_forward_slabs(const float* ws, int splitk, int Npad, const float* bias, float* zr, const void* h, long h_plane_stride,
-                                   int h_chunk0, void* rh, long rh_plane_stride, int rh_chunk0, long M, int chunks, ufr_stream_t stream);
-int ufr_gru_blend_cm_forward_slabs(const float* ws, int splitk, int Npad, const float* bias, float* q, const float* z, const void* h,
-                                   long h_plane_stride, int h_chunk0, void* out, long out_plane_stride, int out_chunk0, long M, int chunks,
+ * float32 pre-activation tensor is then only written -- sigmoid / tanh values for the adjoint -- never read).  `addend` (ABI 7,
+ * may be NULL): a float32 tensor in the layout of zr / q added behind the bias -- the share of the pre-activation that does not
+ * change between RAFT's iterations (the context features `inp`, models/raft/raft.py:176-180: the same tensor enters the GRU of all
+ * 12 iterations, update.py:50-66; its convolution is computed once per forward instead of 24 times). */
+int ufr_gru_gates_cm_forward_slabs(const float* ws, int splitk, int Npad, const float* bias, const float* addend, float* zr, const void* h,
+                                   long h_plane_stride, int h_chunk0, void* rh, long rh_plane_stride, int rh_chunk0, long M, int chunks,
                                    ufr_stream_t stream);
+int ufr_gru_blend_cm_forward_slabs(const float* ws, int splitk, int Npad, const float* bias, const float* addend, float* q, const float* z,
+                                   const void* h, long h_plane_stride, int h_chunk0, void* out, long out_plane_stride, int out_chunk0,
+                                   long M, int chunks, ufr_stream_t stream);
 int ufr_gru_blend_cm_forward(float* q, const float* z, const void* h, long h_plane_stride, int h_chunk0, void* out,
                              long out_plane_stride, int out_chunk0, long M, int chunks, ufr_stream_t stream);
+/* acc_gq / acc_gzr (ABI 7, may be NULL): float32 running sums in the layout of q / zr onto which the pre-activation gradients are
+ * ADDED -- the adjoint of the iteration-invariant share runs once per backward on the sum over the iterations. */
 int ufr_gru_blend_cm_backward(const float* q, const float* z, const void* h, long h_plane_stride, int h_chunk0, const float* g,
                               void* gq, long gq_plane_stride, int gq_chunk0, float* g_z, float* g_h, long M, int chunks,
-                              ufr_stream_t stream);
+                              float* acc_gq, ufr_stream_t stream);
 int ufr_gru_gates_cm_backward(const float* zr, const void* h, long h_plane_stride, int h_chunk0, const float* g_z, float* g_rh,
                               void* gzr, long gzr_plane_stride, int gzr_chunk0, float* g_h, long M, int chunks, int consume_g_rh,
-                              ufr_stream_t stream);
+                              float* acc_gzr, ufr_stream_t stream);
 
 /* ---- RAFT BasicEncoder: normalisation / ReLU / residual arithmetic between the convolutions (csrc/raft_norm.hip) -----------
  * replaces nn.InstanceNorm2d / nn.BatchNorm2d (eval) + ReLU + the residual add of models/raft/extractor.py:5-78, :142-215 on

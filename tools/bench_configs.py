@@ -49,7 +49,8 @@ def igemm_roofline(net):
     # own one-pair engines: those are not the step's.  (Round 4 compared `n` and `B` directly and thereby dropped RAFT's whole
     # update block at one pair, and never looked at the PlaneGraph sub-networks of FlowNet2: its C3 / C5 fractions covered the
     # encoders / the three heads only.)
-    top = max([e.B for e in engines if hasattr(e, "B")] + [1])
+    heads = [eng for mod in net.modules() for eng in mod.__dict__.get("_ufr_head_engines", {}).values() if hasattr(eng, "B")]
+    top = max([e.B for e in heads] + [1])              # pairs per step (a stem PlaneGraph's `B` counts frames, like an encoder's `n`)
     tables = [e.launch_table() for e in engines if top == 1 or batch(e) >= top]
     ms = gflop = 0.0
     n = 0

@@ -167,10 +167,10 @@ def main():
                                                             4, st())))
     emit("blend_fwd_kernel (chunk-major)", cfg, ms, M * 128 * (4 + 4 + 4 + 6 + 6))
     ms = timed(lambda: L.check(lib.ufr_gru_blend_cm_backward(L.ptr(Q.t), L.ptr(ZR.t), L.ptr(Pb.t), Pb.plane_stride, 0, L.ptr(Gh.t), L.ptr(gzq.t),
-                                                             gzq.plane_stride, 0, L.ptr(Gz.t), L.ptr(Grh.t), M, 4, st())))
+                                                             gzq.plane_stride, 0, L.ptr(Gz.t), L.ptr(Grh.t), M, 4, None, st())))
     emit("blend_bwd_kernel (chunk-major)", cfg, ms, M * 128 * (4 + 4 + 6 + 4 + 6 + 4 + 4))
     ms = timed(lambda: L.check(lib.ufr_gru_gates_cm_backward(L.ptr(ZR.t), L.ptr(Pb.t), Pb.plane_stride, 0, L.ptr(Gz.t), L.ptr(Grh.t), L.ptr(gzrp.t),
-                                                             gzrp.plane_stride, 0, L.ptr(Gh.t), M, 4, 0, st())))
+                                                             gzrp.plane_stride, 0, L.ptr(Gh.t), M, 4, 0, None, st())))
     emit("gates_bwd_kernel (chunk-major)", cfg, ms, M * 128 * (8 + 6 + 4 + 4 + 12 + 8))
     fl, mk = rnd(B, 2, H, W), rnd(B, 576, H, W)
     up = torch.empty(B, 2, 8 * H, 8 * W, device=DEV)

@@ -165,11 +165,11 @@ SIGNATURES = {
     "ufr_raft_motion_finish_slabs": [_vp, _i, _i, _i, _vp, _f, _vp, _l, _vp, _l, _i, _vp, _i, _i, _i, _vp],
     "ufr_raft_motion_finish": [_vp, _l, _vp, _l, _i, _vp, _i, _i, _i, _vp],
     "ufr_gru_gates_cm_forward": [_vp, _vp, _l, _i, _vp, _l, _i, _l, _i, _vp],
-    "ufr_gru_gates_cm_forward_slabs": [_vp, _i, _i, _vp, _vp, _vp, _l, _i, _vp, _l, _i, _l, _i, _vp],
-    "ufr_gru_blend_cm_forward_slabs": [_vp, _i, _i, _vp, _vp, _vp, _vp, _l, _i, _vp, _l, _i, _l, _i, _vp],
+    "ufr_gru_gates_cm_forward_slabs": [_vp, _i, _i, _vp, _vp, _vp, _vp, _l, _i, _vp, _l, _i, _l, _i, _vp],
+    "ufr_gru_blend_cm_forward_slabs": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp, _l, _i, _l, _i, _vp],
     "ufr_gru_blend_cm_forward": [_vp, _vp, _vp, _l, _i, _vp, _l, _i, _l, _i, _vp],
-    "ufr_gru_blend_cm_backward": [_vp, _vp, _vp, _l, _i, _vp, _vp, _l, _i, _vp, _vp, _l, _i, _vp],
-    "ufr_gru_gates_cm_backward": [_vp, _vp, _l, _i, _vp, _vp, _vp, _l, _i, _vp, _l, _i, _i, _vp],
+    "ufr_gru_blend_cm_backward": [_vp, _vp, _vp, _l, _i, _vp, _vp, _l, _i, _vp, _vp, _l, _i, _vp, _vp],
+    "ufr_gru_gates_cm_backward": [_vp, _vp, _l, _i, _vp, _vp, _vp, _l, _i, _vp, _l, _i, _i, _vp, _vp],
     "ufr_altcorr_pyramid_forward": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
     "ufr_altcorr_pyramid_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "ufr_upfeat_planes_forward_mfma": [_vp, _l, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp],

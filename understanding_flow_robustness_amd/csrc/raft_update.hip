@@ -105,14 +105,24 @@ __global__ void motion_finish_kernel(__bf16* __restrict__ p1, long ps1, __bf16* 
 // linear epilogue, bit for bit -- so the launch of that kernel between the convolution and the gate arithmetic disappears.
 struct SlabSrc {
   const float* ws; const float* bias; long slab_stride; int S, Npad;
+  const float* addend;     // optional [chunks][M][32] float32 in the OUTPUT tensor's layout, added behind the bias: the part of the
+                           // pre-activation that is the same in every iteration (the context features' share, raft_engine.py)
 };
-__device__ __forceinline__ void load_slabs8(const SlabSrc& k, long m, int col, float v[8]) {
+// (addp: the 8 addend values of these channels or nullptr -- added between the slab sum and the bias, the order of igemm's own
+// forward epilogue with an `add` tensor, so that the slab form and the launch + reduce form stay bit-identical)
+__device__ __forceinline__ void load_slabs8(const SlabSrc& k, long m, int col, float v[8], const float* addp = nullptr) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) v[j] = 0.f;
   const float* src = k.ws + m * k.Npad + col;
   for (int s = 0; s < k.S; ++s) {
     const float4 lo = *reinterpret_cast<const float4*>(src + s * k.slab_stride), hi = *reinterpret_cast<const float4*>(src + s * k.slab_stride + 4);
     v[0] += lo.x; v[1] += lo.y; v[2] += lo.z; v[3] += lo.w; v[4] += hi.x; v[5] += hi.y; v[6] += hi.z; v[7] += hi.w;
+  }
+  if (addp) {
+    float a[8];
+    load_f8(addp, a);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += a[j];
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) v[j] += k.bias[col + j];
@@ -162,8 +172,8 @@ __global__ void gates_fwd_kernel(float* __restrict__ zr, const __bf16* __restric
     if (slabs.ws) {                                       // columns [z | r] of the gate convolution
       const int ch = (int)(e / (M * 32)), col = ch * 32 + (int)(e & 31);
       const long m = (e >> 5) - (long)ch * M;
-      load_slabs8(slabs, m, col, z);
-      load_slabs8(slabs, m, chunks * 32 + col, r);
+      load_slabs8(slabs, m, col, z, slabs.addend ? slabs.addend + e : nullptr);
+      load_slabs8(slabs, m, chunks * 32 + col, r, slabs.addend ? slabs.addend + (long)chunks * M * 32 + e : nullptr);
     } else {
       load_f8(zr + e, z);
       load_f8(zr + (long)chunks * M * 32 + e, r);
@@ -190,7 +200,7 @@ __global__ void blend_fwd_kernel(float* __restrict__ q, const float* __restrict_
     float qv[8], zv[8], hv[8];
     if (slabs.ws) {
       const int ch = (int)(e / (M * 32));
-      load_slabs8(slabs, (e >> 5) - (long)ch * M, ch * 32 + (int)(e & 31), qv);
+      load_slabs8(slabs, (e >> 5) - (long)ch * M, ch * 32 + (int)(e & 31), qv, slabs.addend ? slabs.addend + e : nullptr);
     } else {
       load_f8(q + e, qv);
     }
@@ -209,7 +219,7 @@ __global__ void blend_fwd_kernel(float* __restrict__ q, const float* __restrict_
 // g_q_pre planes = g z (1 - q^2);  g_z = g q - g h;  g_h = g (1 - z)      (q = tanh value, z = sigmoid value)
 __global__ void blend_bwd_kernel(const float* __restrict__ q, const float* __restrict__ z, const __bf16* __restrict__ h, long hs,
                                  int h_chunk0, const float* __restrict__ g, __bf16* __restrict__ gq, long gqs, int gq_chunk0,
-                                 float* __restrict__ g_z, float* __restrict__ g_h, long M, int chunks) {
+                                 float* __restrict__ g_z, float* __restrict__ g_h, long M, int chunks, float* __restrict__ acc) {
   const long n8 = (long)chunks * M * 4;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n8; t += (long)gridDim.x * blockDim.x) {
     const long e = t * 8;
@@ -227,13 +237,20 @@ __global__ void blend_bwd_kernel(const float* __restrict__ q, const float* __res
     store_planes8(gq + (long)gq_chunk0 * M * 32 + e, gqs, a);
     store_f8(g_z + e, bz);
     store_f8(g_h + e, bh);
+    if (acc) {                           // running sum of g_q_pre over the iterations (the context features' adjoint runs once, on it)
+      float s[8];
+      load_f8(acc + e, s);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += a[j];
+      store_f8(acc + e, s);
+    }
   }
 }
 
 // g_zr planes [2 chunks]: [g_z z (1 - z) | g_rh h r (1 - r)];  g_h += g_rh r   (zr holds the sigmoid values)
 __global__ void gates_bwd_kernel(const float* __restrict__ zr, const __bf16* __restrict__ h, long hs, int h_chunk0,
                                  const float* __restrict__ g_z, float* __restrict__ g_rh, __bf16* __restrict__ gzr, long gs,
-                                 int gzr_chunk0, float* __restrict__ g_h, long M, int chunks, int consume) {
+                                 int gzr_chunk0, float* __restrict__ g_h, long M, int chunks, int consume, float* __restrict__ acc) {
   const long n8 = (long)chunks * M * 4;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n8; t += (long)gridDim.x * blockDim.x) {
     const long e = t * 8;
@@ -253,6 +270,15 @@ __global__ void gates_bwd_kernel(const float* __restrict__ zr, const __bf16* __r
     store_planes8(gzr + (long)gzr_chunk0 * M * 32 + e, gs, a);
     store_planes8(gzr + ((long)gzr_chunk0 + chunks) * M * 32 + e, gs, b);
     store_f8(g_h + e, gh);
+    if (acc) {                           // running sums of [g_z_pre | g_r_pre] over the iterations
+      float sa[8], sb[8];
+      load_f8(acc + e, sa);
+      load_f8(acc + (long)chunks * M * 32 + e, sb);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { sa[j] += a[j]; sb[j] += b[j]; }
+      store_f8(acc + e, sa);
+      store_f8(acc + (long)chunks * M * 32 + e, sb);
+    }
     if (consume) {                       // g_rh sits in a running-sum buffer whose next writer ADDS: leave zeros behind
       const float zero[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       store_f8(g_rh + e, zero);
@@ -287,7 +313,7 @@ extern "C" int ufr_raft_motion_finish_slabs(const float* ws, int splitk, int Npa
               "raft motion finish (slabs): bad argument");
   const long M = (long)B * H * W;
   motion_finish_slabs_kernel<<<ufr::stream_grid(M * 16, 256), 256, 0, ufr::as_stream(stream)>>>(
-      SlabSrc{ws, bias, M * Npad, splitk, Npad}, N, slope, static_cast<__bf16*>(p1), plane_stride1, static_cast<__bf16*>(p2), plane_stride2,
+      SlabSrc{ws, bias, M * Npad, splitk, Npad, nullptr}, N, slope, static_cast<__bf16*>(p1), plane_stride1, static_cast<__bf16*>(p2), plane_stride2,
       chunk0, flow, M, (long)H * W);
   return ufr::launched("motion_finish_slabs_kernel");
 }
@@ -297,18 +323,18 @@ extern "C" int ufr_gru_gates_cm_forward(float* zr, const void* h, long h_plane_s
   UFR_REQUIRE(zr && h && rh && M > 0 && chunks > 0, "gru gates (chunk-major) forward: bad argument");
   gates_fwd_kernel<<<ufr::stream_grid((long)chunks * M * 4, 256), 256, 0, ufr::as_stream(stream)>>>(
       zr, static_cast<const __bf16*>(h), h_plane_stride, h_chunk0, static_cast<__bf16*>(rh), rh_plane_stride, rh_chunk0, M, chunks,
-      SlabSrc{nullptr, nullptr, 0, 0, 0});
+      SlabSrc{nullptr, nullptr, 0, 0, 0, nullptr});
   return ufr::launched("gates_fwd_kernel");
 }
 
-extern "C" int ufr_gru_gates_cm_forward_slabs(const float* ws, int splitk, int Npad, const float* bias, float* zr, const void* h,
+extern "C" int ufr_gru_gates_cm_forward_slabs(const float* ws, int splitk, int Npad, const float* bias, const float* addend, float* zr, const void* h,
                                               long h_plane_stride, int h_chunk0, void* rh, long rh_plane_stride, int rh_chunk0, long M,
                                               int chunks, ufr_stream_t stream) {
   UFR_REQUIRE(ws && bias && zr && h && rh && M > 0 && chunks > 0 && splitk >= 1 && Npad >= 2 * chunks * 32 && Npad % 8 == 0,
               "gru gates (chunk-major, from slabs) forward: bad argument");
   gates_fwd_kernel<<<ufr::stream_grid((long)chunks * M * 4, 256), 256, 0, ufr::as_stream(stream)>>>(
       zr, static_cast<const __bf16*>(h), h_plane_stride, h_chunk0, static_cast<__bf16*>(rh), rh_plane_stride, rh_chunk0, M, chunks,
-      SlabSrc{ws, bias, M * Npad, splitk, Npad});
+      SlabSrc{ws, bias, M * Npad, splitk, Npad, addend});
   return ufr::launched("gates_fwd_kernel (slabs)");
 }
 
@@ -317,37 +343,37 @@ extern "C" int ufr_gru_blend_cm_forward(float* q, const float* z, const void* h,
   UFR_REQUIRE(q && z && h && out && M > 0 && chunks > 0, "gru blend (chunk-major) forward: bad argument");
   blend_fwd_kernel<<<ufr::stream_grid((long)chunks * M * 4, 256), 256, 0, ufr::as_stream(stream)>>>(
       q, z, static_cast<const __bf16*>(h), h_plane_stride, h_chunk0, static_cast<__bf16*>(out), out_plane_stride, out_chunk0, M, chunks,
-      SlabSrc{nullptr, nullptr, 0, 0, 0});
+      SlabSrc{nullptr, nullptr, 0, 0, 0, nullptr});
   return ufr::launched("blend_fwd_kernel");
 }
 
-extern "C" int ufr_gru_blend_cm_forward_slabs(const float* ws, int splitk, int Npad, const float* bias, float* q, const float* z,
+extern "C" int ufr_gru_blend_cm_forward_slabs(const float* ws, int splitk, int Npad, const float* bias, const float* addend, float* q, const float* z,
                                               const void* h, long h_plane_stride, int h_chunk0, void* out, long out_plane_stride,
                                               int out_chunk0, long M, int chunks, ufr_stream_t stream) {
   UFR_REQUIRE(ws && bias && q && z && h && out && M > 0 && chunks > 0 && splitk >= 1 && Npad >= chunks * 32 && Npad % 8 == 0,
               "gru blend (chunk-major, from slabs) forward: bad argument");
   blend_fwd_kernel<<<ufr::stream_grid((long)chunks * M * 4, 256), 256, 0, ufr::as_stream(stream)>>>(
       q, z, static_cast<const __bf16*>(h), h_plane_stride, h_chunk0, static_cast<__bf16*>(out), out_plane_stride, out_chunk0, M, chunks,
-      SlabSrc{ws, bias, M * Npad, splitk, Npad});
+      SlabSrc{ws, bias, M * Npad, splitk, Npad, addend});
   return ufr::launched("blend_fwd_kernel (slabs)");
 }
 
 extern "C" int ufr_gru_blend_cm_backward(const float* q, const float* z, const void* h, long h_plane_stride, int h_chunk0,
                                          const float* g, void* gq, long gq_plane_stride, int gq_chunk0, float* g_z, float* g_h, long M,
-                                         int chunks, ufr_stream_t stream) {
+                                         int chunks, float* acc_gq, ufr_stream_t stream) {
   UFR_REQUIRE(q && z && h && g && gq && g_z && g_h && M > 0 && chunks > 0, "gru blend (chunk-major) backward: bad argument");
   blend_bwd_kernel<<<ufr::stream_grid((long)chunks * M * 4, 256), 256, 0, ufr::as_stream(stream)>>>(
       q, z, static_cast<const __bf16*>(h), h_plane_stride, h_chunk0, g, static_cast<__bf16*>(gq), gq_plane_stride, gq_chunk0, g_z, g_h, M,
-      chunks);
+      chunks, acc_gq);
   return ufr::launched("blend_bwd_kernel");
 }
 
 extern "C" int ufr_gru_gates_cm_backward(const float* zr, const void* h, long h_plane_stride, int h_chunk0, const float* g_z,
                                          float* g_rh, void* gzr, long gzr_plane_stride, int gzr_chunk0, float* g_h, long M,
-                                         int chunks, int consume_g_rh, ufr_stream_t stream) {
+                                         int chunks, int consume_g_rh, float* acc_gzr, ufr_stream_t stream) {
   UFR_REQUIRE(zr && h && g_z && g_rh && gzr && g_h && M > 0 && chunks > 0, "gru gates (chunk-major) backward: bad argument");
   gates_bwd_kernel<<<ufr::stream_grid((long)chunks * M * 4, 256), 256, 0, ufr::as_stream(stream)>>>(
       zr, static_cast<const __bf16*>(h), h_plane_stride, h_chunk0, g_z, g_rh, static_cast<__bf16*>(gzr), gzr_plane_stride, gzr_chunk0, g_h,
-      M, chunks, consume_g_rh);
+      M, chunks, consume_g_rh, acc_gzr);
   return ufr::launched("gates_bwd_kernel");
 }

@@ -8,7 +8,10 @@ flows are upsampled with `nearest`, FlowNetS's flow up-convolutions have no bias
 """
 from __future__ import annotations
 
+import os
+
 import torch
+from .. import _lib as _L
 from ..plane_graph import graph_for as _graph_for, native_ok as _native_ok, stem_graph as _prefix_graph
 import torch.nn as nn
 import torch.nn.functional as F
@@ -324,6 +327,16 @@ def _fusion_graph(net, B, H, W, dev):
     return g.build()
 
 
+_BRANCH_STREAMS: dict = {}
+
+
+def _branch_stream(device):
+    key = torch.device(device)
+    if key not in _BRANCH_STREAMS:
+        _BRANCH_STREAMS[key] = torch.cuda.Stream(device=key)
+    return _BRANCH_STREAMS[key]
+
+
 class FlowNet2(nn.Module):
     def __init__(self, batchNorm=False, div_flow=20.0, return_feat_maps: bool = False):
         super().__init__()
@@ -354,15 +367,34 @@ class FlowNet2(nn.Module):
         up_bl = lambda f: F.interpolate(f, scale_factor=4, mode="bilinear", align_corners=False)
         up_nn = lambda f: F.interpolate(f, scale_factor=4, mode="nearest")
 
+        def small_displacement_branch():
+            flow_sd = up_nn(self.flownets_d(x)[0] / self.div_flow)     # sic: divided (:176)
+            return flow_sd, self.channelnorm(flow_sd), self.channelnorm(x[:, :3] - self.resample3(x[:, 3:], flow_sd))
+
+        # FlowNet-SD reads the frames only (flownet2_models.py:174-181): it does not depend on the FlowNetC -> FlowNetS -> FlowNetS
+        # chain, and at one pair per GPU most launches of either cover a fraction of the 256 CUs (1/16 .. 1/64 grids).  On the
+        # native path the branch runs on a second HIP stream -- forward here, its adjoint wherever autograd replays these nodes
+        # (the stream they were recorded on) -- and the two meet again at the fusion network's input.  Inside a HIP-graph capture
+        # the fork / join become graph edges.  UFR_FN2_BRANCH_STREAM=0: one stream (the A/B switch).
+        fork = x.is_cuda and _L.engine_refusal(self.flownets_d, x, 64) is None and os.environ.get("UFR_FN2_BRANCH_STREAM", "1") != "0"
+        if fork:
+            main, side = torch.cuda.current_stream(x.device), _branch_stream(x.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                flow_sd, norm_sd, err_sd = small_displacement_branch()
+
         flow_c = up_bl(self.flownetc(x)[0] * self.div_flow)
         flow_s1 = up_bl(self.flownets_1(self._warp_stage(x, flow_c))[0] * self.div_flow)
         flow_s2 = up_nn(self.flownets_2(self._warp_stage(x, flow_s1))[0] * self.div_flow)
         norm_s2 = self.channelnorm(flow_s2)
         err_s2 = self.channelnorm(x[:, :3] - self.resample4(x[:, 3:], flow_s2))
 
-        flow_sd = up_nn(self.flownets_d(x)[0] / self.div_flow)     # sic: divided (:176)
-        norm_sd = self.channelnorm(flow_sd)
-        err_sd = self.channelnorm(x[:, :3] - self.resample3(x[:, 3:], flow_sd))
+        if fork:
+            main.wait_stream(side)
+            for t_ in (flow_sd, norm_sd, err_sd):
+                t_.record_stream(main)
+        else:
+            flow_sd, norm_sd, err_sd = small_displacement_branch()
 
         fused_in = torch.cat((x[:, :3], flow_sd, flow_s2, norm_sd, norm_s2, err_sd, err_s2), dim=1)
         return self.flownetfusion(fused_in)

@@ -9,8 +9,16 @@ explicit schedule of hand-written gfx950 kernels, one autograd Function around t
     delta_flow = Conv2d(256, 2, 3)                                      csrc/engine_small.hip (per-pixel GEMM + gather)
 
 Layout.  A GRU half-step's two concatenations -- cat([h, x]) for the z / r gates and cat([r*h, x]) for q, x = cat([inp, motion])
-(update.py:50-66) -- are ONE 16-chunk plane buffer [h 4 | inp 4 | motion 4 | r*h 4]: the gate convolution reads chunks 0-11, the
-q convolution chunks 4-15 (its weights re-indexed once).  motion = cat([out 126, flow 2]) is exactly four chunks.
+(update.py:50-66) -- are ONE 12-chunk plane buffer [h 4 | motion 4 | r*h 4]: the gate convolution reads chunks 0-7, the
+q convolution chunks 4-11 (its weights re-indexed once).  motion = cat([out 126, flow 2]) is exactly four chunks.
+
+The context features `inp` are not in that buffer (round 5).  They are the SAME tensor in all 12 iterations (raft.py:176-180), and a
+convolution is linear in its input channels: conv(W, [h | inp | motion]) = conv(W_h,m, [h | motion]) + conv(W_inp, inp).  The
+second term of the four gate / candidate convolutions is computed ONCE per forward (float32 [M][256 | 128], `Cctx`) and added to
+the pre-activations by the gate kernels (`addend` of the slab-reading forms; igemm's `add` epilogue otherwise): the 48 GRU
+convolutions of a forward reduce over 256 instead of 384 channels.  Its adjoint is linear too: the pre-activation gradients of the
+12 iterations are summed (the gate adjoint kernels add into `Azr` / `Aq`) and d / d inp is four transposed launches on the sums,
+while the 48 per-iteration adjoint launches produce 256 instead of 384 columns.
 
 What the loop's structure allows (raft.py:190: coords1 is detached at the top of every iteration): the flow head runs its
 adjoint for the LAST iteration only, the whole flow branch of the motion encoder (convf1, convf2) has no adjoint at all, and the
@@ -63,8 +71,11 @@ class RaftUpdateEngine:
         self.corr_p = [P(self.cor_chunks) for _ in range(IT)]
         self.cor1 = [P(8) for _ in range(IT)]
         self.CF = [P(8) for _ in range(IT)]                           # [cor2 192 | flo2 64] = cat([cor, flo]) (update.py:118)
-        self.P1 = [P(4 * HC) for _ in range(IT)] + [P(HC)]            # [h | inp | motion | r*h]; the extra one holds the final h
-        self.P2 = [P(4 * HC) for _ in range(IT)]
+        self.P1 = [P(3 * HC) for _ in range(IT)] + [P(HC)]            # [h | motion | r*h]; the extra one holds the final h
+        self.P2 = [P(3 * HC) for _ in range(IT)]
+        self.INP = P(HC)                                              # the context features: one buffer, loaded once per forward
+        # their share of the four gate / candidate pre-activations (raw sums, no bias), computed once per forward
+        self.Cctx = {"zr1": G(2 * HC), "q1": G(HC), "zr2": G(2 * HC), "q2": G(HC)}
         self.ZR = [[G(2 * HC) for _ in range(IT)] for _ in range(2)]  # sigmoid(z) | sigmoid(r) of the two half-steps
         self.Q = [[G(HC) for _ in range(IT)] for _ in range(2)]       # tanh(q)
         self.fpat, self.flo1 = P(4), P(4)                             # flow branch: no adjoint, one buffer serves every iteration
@@ -80,10 +91,22 @@ class RaftUpdateEngine:
         self.flow_lr = torch.zeros(B, 2, h, w, **f32)
         self.up_mask = torch.zeros(B, 576, h, w, **f32)
         # ---- gradients
-        # two running-sum buffers in the GRU buffer's own order [h | inp | motion | r*h]: a half-step's adjoint launches ADD into
-        # them in their epilogues (q^T: chunks 4-15 of the other buffer + its result -> this one; zr^T: chunks 0-11 in place),
-        # so d / d h, the running d / d inp and the iteration's d / d motion need no separate add kernels (7 per iteration before)
-        self.TA, self.TB, self.G_z = G(4 * HC), G(4 * HC), G(HC)
+        # two running-sum buffers in the GRU buffer's own order [h | motion | r*h]: a half-step's adjoint launches ADD into
+        # them in their epilogues (q^T: chunks 4-11 of the other buffer + its result -> this one; zr^T: chunks 0-7 in place),
+        # so d / d h and the iteration's d / d motion need no separate add kernels (7 per iteration before)
+        self.TA, self.TB, self.G_z = G(3 * HC), G(3 * HC), G(HC)
+        # the pre-activation gradients summed over the iterations ([g_z | g_r] and g_q of the two half-steps: one arena, one fill),
+        # their planes, and d / d inp
+        self._acc_arena = torch.zeros(2 * (2 * HC + HC) * self.M * 32, **f32)
+        self.Azr, self.Aq, off = [], [], 0
+        for _ in range(2):
+            for lst, ch in ((self.Azr, 2 * HC), (self.Aq, HC)):
+                gs = G(1)
+                gs.chunks, gs.t = ch, self._acc_arena[off:off + ch * self.M * 32].view(ch, self.M, 32)
+                off += ch * self.M * 32
+                lst.append(gs)
+        self.gz_ctx = {"zr1": P(2 * HC), "q1": P(HC), "zr2": P(2 * HC), "q2": P(HC)}
+        self.G_inp = G(HC)
         self.gzq, self.gzr, self.gz_mot = P(HC), P(2 * HC), P(HC)
         self.gz_cor2, self.gz_cor1 = P(6), P(8)
         self.G_corr = G(self.cor_chunks)
@@ -97,17 +120,20 @@ class RaftUpdateEngine:
         bias = lambda conv: conv.bias.detach().float().contiguous()
         wf1 = torch.zeros(128, 128, 1, 1, **f32)                      # convf1 over the gathered 7x7x2 patches: k = (ky*7 + kx)*2 + c
         wf1[:, :98, 0, 0] = enc.convf1.weight.detach().float().permute(0, 2, 3, 1).reshape(128, 98)
-        w_zr, b_zr, w_q = {}, {}, {}
+        w_zr, b_zr, w_q, w_zr_ctx, w_q_ctx = {}, {}, {}, {}, {}
         for tag in ("1", "2"):
             convz, convr, convq = (getattr(gru, f"conv{g}{tag}") for g in "zrq")
-            w_zr[tag] = torch.cat([convz.weight, convr.weight]).detach().float()          # [256, 384 = h | inp | motion, kh, kw]
+            wzr = torch.cat([convz.weight, convr.weight]).detach().float()                # [256, 384 = h | inp | motion, kh, kw]
+            w_zr[tag] = torch.cat([wzr[:, :128], wzr[:, 256:]], 1).contiguous()           # buffer: [h | motion]
+            w_zr_ctx[tag] = wzr[:, 128:256].contiguous()                                   # the context features' columns
             b_zr[tag] = torch.cat([convz.bias, convr.bias]).detach().float().contiguous()
             wq = convq.weight.detach().float()                                             # reference input: [r*h | inp | motion]
-            w_q[tag] = torch.cat([wq[:, 128:], wq[:, :128]], 1).contiguous()              # buffer: [inp | motion | r*h]
+            w_q[tag] = torch.cat([wq[:, 256:], wq[:, :128]], 1).contiguous()              # buffer: [motion | r*h]
+            w_q_ctx[tag] = wq[:, 128:256].contiguous()
         self._pads = {"1": (0, 2), "2": (2, 0)}
         plans = []
 
-        def plan(key, wi, x, in_chunk0, **kw):
+        def plan(key, wi, x, in_chunk0, ctx=None, **kw):
             pk = [len(t) * wi.KC for _, _, t in wi.phases]
             # ping-pong tiles with a deep split (>= 4 K tiles per slice) measured best on these 48 x 160 grids: 18.1 ms per
             # iteration against 18.4 (>= 8), 19.8 (>= 16), 18.4 with 64 x 128 tiles and 18.6 with single-stage 128 x 128 tiles
@@ -115,6 +141,8 @@ class RaftUpdateEngine:
             bm, target = (256, 256) if kw["variant"] == 6 else (128, 768)
             S = ig.splitk_for(self.M, wi.Npad, max(pk), 1, phase_ktiles=pk, bm=bm, target=target, min_ktiles=4)
             kw["variant"], S = ig.tuned(wi, self.M, kw, kw["variant"], S)
+            if ctx is not None and not (kw.get("no_reduce") and S > 1):
+                kw["add"] = ctx            # no slabs for the gate kernel to read: the context share rides in igemm's own epilogue
             plans.append((key, wi, x, in_chunk0, S, kw))
 
         W = dict(convc1=cw(enc.convc1, 0), convc2=cw(enc.convc2, 1), convf1=cw(wf1, 0), convf2=cw(enc.convf2, 1), conv=cw(enc.conv, 1),
@@ -124,23 +152,32 @@ class RaftUpdateEngine:
         for tag in ("1", "2"):
             W["zr" + tag], W["q" + tag] = cw(w_zr[tag], self._pads[tag]), cw(w_q[tag], self._pads[tag])
             Wb["zr" + tag], Wb["q" + tag] = bw(w_zr[tag], self._pads[tag]), bw(w_q[tag], self._pads[tag])
+            W["ctx_zr" + tag], W["ctx_q" + tag] = cw(w_zr_ctx[tag], self._pads[tag]), cw(w_q_ctx[tag], self._pads[tag])
+            Wb["ctx_zr" + tag], Wb["ctx_q" + tag] = bw(w_zr_ctx[tag], self._pads[tag]), bw(w_q_ctx[tag], self._pads[tag])
         relu, lin = dict(slope=0.0), dict(slope=1.0)
         b_q = {tag: bias(getattr(gru, "convq" + tag)) for tag in ("1", "2")}
         b_conv = self._conv_bias = bias(enc.conv)
         self._gate_bias = {**{"zr" + t: b_zr[t] for t in ("1", "2")}, **{"q" + t: b_q[t] for t in ("1", "2")}}
         fuse = os.environ.get("UFR_RAFT_FUSE_REDUCE", "1") != "0"
+        # once per forward / backward: the context features' share of the gate convolutions and its adjoint (a chain of adds)
+        for i, name in enumerate(("zr1", "q1", "zr2", "q2")):
+            plan(("ctx_" + name,), W["ctx_" + name], self.INP, 0, out_f32=self.Cctx[name])
+            plan(("ctx_" + name + "^T",), Wb["ctx_" + name], self.gz_ctx[name], 0, out_f32=self.G_inp,
+                 **(dict(add=self.G_inp) if i else {}))
         for it in range(IT):
             P1, P2 = self.P1[it], self.P2[it]
             plan(("convc1", it), W["convc1"], self.corr_p[it], 0, out_planes=self.cor1[it], bias=bias(enc.convc1), **relu)
             plan(("convc2", it), W["convc2"], self.cor1[it], 0, out_planes=self.CF[it], out_chunk0=0, bias=bias(enc.convc2), **relu)
             plan(("convf1", it), W["convf1"], self.fpat, 0, out_planes=self.flo1, bias=bias(enc.convf1), **relu)
             plan(("convf2", it), W["convf2"], self.flo1, 0, out_planes=self.CF[it], out_chunk0=6, bias=bias(enc.convf2), **relu)
-            plan(("conv", it), W["conv"], self.CF[it], 0, out_planes=P1, out_chunk0=2 * HC, bias=b_conv, no_reduce=fuse, **relu)
+            plan(("conv", it), W["conv"], self.CF[it], 0, out_planes=P1, out_chunk0=HC, bias=b_conv, no_reduce=fuse, **relu)
             for half, (tag, buf, nxt) in enumerate((("1", P1, P2), ("2", P2, self.P1[it + 1]))):
                 # the gate / candidate convolutions leave their split-K slabs to the gate arithmetic (no reduce launch in between)
-                plan(("zr" + tag, it), W["zr" + tag], buf, 0, out_f32=self.ZR[half][it], bias=b_zr[tag], no_reduce=fuse, **lin)
-                plan(("q" + tag, it), W["q" + tag], buf, HC, out_f32=self.Q[half][it], bias=b_q[tag], no_reduce=fuse, **lin)
-                # adjoints: d / d [inp | motion | r*h] of q, d / d [h | inp | motion] of the gates
+                plan(("zr" + tag, it), W["zr" + tag], buf, 0, ctx=self.Cctx["zr" + tag], out_f32=self.ZR[half][it], bias=b_zr[tag],
+                     no_reduce=fuse, **lin)
+                plan(("q" + tag, it), W["q" + tag], buf, HC, ctx=self.Cctx["q" + tag], out_f32=self.Q[half][it], bias=b_q[tag],
+                     no_reduce=fuse, **lin)
+                # adjoints: d / d [motion | r*h] of q, d / d [h | motion] of the gates
                 src, dst = (self.TA, self.TB) if tag == "2" else (self.TB, self.TA)    # the backward walks half-step 2 first
                 plan(("q" + tag + "^T", it), Wb["q" + tag], self.gzq, 0, add=src, add_chunk0=HC, out_f32=dst, out_f32_chunk0=HC)
                 plan(("zr" + tag + "^T", it), Wb["zr" + tag], self.gzr, 0, add=dst, add_chunk0=0, out_f32=dst, out_f32_chunk0=0)
@@ -219,10 +256,9 @@ class RaftUpdateEngine:
         self.generation += 1
         self._src = src
         self.P1[0].load_nchw(net0.contiguous(), 0)
-        inp = inp.contiguous()
-        for it in range(IT):                                          # the context features are the same in every iteration
-            self.P1[it].load_nchw(inp, HC)
-            self.P2[it].load_nchw(inp, HC)
+        self.INP.load_nchw(inp.contiguous(), 0)                       # the context features are the same in every iteration:
+        for name in ("zr1", "q1", "zr2", "q2"):                       # their share of the gate convolutions, once
+            self.launch[("ctx_" + name,)]()
         self.coords1.copy_(self.coords0)
         if flow_init is not None:
             self.coords1.add_(flow_init)
@@ -241,10 +277,10 @@ class RaftUpdateEngine:
             lc = self.launch[("conv", it)]
             if lc.desc.no_reduce:                                    # its slabs -> both GRU buffers' motion chunks (+ the flow channels)
                 L.check(lib.ufr_raft_motion_finish_slabs(L.ptr(self.ws), self._slices(lc), lc.desc.Npad, lc.desc.N, L.ptr(self._conv_bias), 0.0,
-                                                         L.ptr(P1.t), P1.plane_stride, L.ptr(P2.t), P2.plane_stride, 2 * HC,
+                                                         L.ptr(P1.t), P1.plane_stride, L.ptr(P2.t), P2.plane_stride, HC,
                                                          L.ptr(self.flows[it]), B, h, w, st()), "motion finish (slabs)")
             else:
-                L.check(lib.ufr_raft_motion_finish(L.ptr(P1.t), P1.plane_stride, L.ptr(P2.t), P2.plane_stride, 2 * HC, L.ptr(self.flows[it]),
+                L.check(lib.ufr_raft_motion_finish(L.ptr(P1.t), P1.plane_stride, L.ptr(P2.t), P2.plane_stride, HC, L.ptr(self.flows[it]),
                                                    B, h, w, st()), "motion finish")
             for half, (tag, buf, nxt) in enumerate((("1", P1, P2), ("2", P2, self.P1[it + 1]))):
                 ZR, Q = self.ZR[half][it], self.Q[half][it]
@@ -252,17 +288,18 @@ class RaftUpdateEngine:
                 lz()
                 if lz.desc.no_reduce:
                     L.check(lib.ufr_gru_gates_cm_forward_slabs(L.ptr(self.ws), self._slices(lz), lz.desc.Npad, L.ptr(self._gate_bias["zr" + tag]),
-                                                               L.ptr(ZR.t), L.ptr(buf.t), buf.plane_stride, 0, L.ptr(buf.t), buf.plane_stride,
-                                                               3 * HC, M, HC, st()), "gru gates forward (slabs)")
+                                                               L.ptr(self.Cctx["zr" + tag].t), L.ptr(ZR.t), L.ptr(buf.t), buf.plane_stride, 0,
+                                                               L.ptr(buf.t), buf.plane_stride, 2 * HC, M, HC, st()), "gru gates forward (slabs)")
                 else:
                     L.check(lib.ufr_gru_gates_cm_forward(L.ptr(ZR.t), L.ptr(buf.t), buf.plane_stride, 0, L.ptr(buf.t), buf.plane_stride,
-                                                         3 * HC, M, HC, st()), "gru gates forward")
+                                                         2 * HC, M, HC, st()), "gru gates forward")
                 lq = self.launch[("q" + tag, it)]
                 lq()
                 if lq.desc.no_reduce:
                     L.check(lib.ufr_gru_blend_cm_forward_slabs(L.ptr(self.ws), self._slices(lq), lq.desc.Npad, L.ptr(self._gate_bias["q" + tag]),
-                                                               L.ptr(Q.t), L.ptr(ZR.t), L.ptr(buf.t), buf.plane_stride, 0, L.ptr(nxt.t),
-                                                               nxt.plane_stride, 0, M, HC, st()), "gru blend forward (slabs)")
+                                                               L.ptr(self.Cctx["q" + tag].t), L.ptr(Q.t), L.ptr(ZR.t), L.ptr(buf.t),
+                                                               buf.plane_stride, 0, L.ptr(nxt.t), nxt.plane_stride, 0, M, HC, st()),
+                            "gru blend forward (slabs)")
                 else:
                     L.check(lib.ufr_gru_blend_cm_forward(L.ptr(Q.t), L.ptr(ZR.t), L.ptr(buf.t), buf.plane_stride, 0, L.ptr(nxt.t),
                                                          nxt.plane_stride, 0, M, HC, st()), "gru blend forward")
@@ -296,30 +333,40 @@ class RaftUpdateEngine:
         L.check(lib.ufr_grad_finalize(L.ptr(self.G_fh.t), 0, L.ptr(self.FH.t), 0, L.ptr(self.gz_fh.t), self.gz_fh.plane_stride, 0, M, 8,
                                       0.0, st()), "flow head finalize")
         self.launch[("fh1^T",)]()
-        self.TA.t[HC:].zero_()                                        # running d / d inp, d / d motion; r*h slots start at zero
-        self.TB.t[3 * HC:].zero_()
+        self.TA.t[HC:].zero_()                                        # d / d motion; the r*h slots start at zero
+        self.TB.t[2 * HC:].zero_()
+        self._acc_arena.zero_()                                       # the pre-activation gradients' sums over the iterations
         for it in range(IT - 1, -1, -1):
             # cur = chunks 0-3 of `gin` (d / d the half-step's output h), prev = chunks 0-3 of `gout` (d / d its input h)
             for half, (tag, buf, gin, gout) in ((1, ("2", self.P2[it], self.TA, self.TB)), (0, ("1", self.P1[it], self.TB, self.TA))):
                 ZR, Q = self.ZR[half][it], self.Q[half][it]
                 L.check(lib.ufr_gru_blend_cm_backward(L.ptr(Q.t), L.ptr(ZR.t), L.ptr(buf.t), buf.plane_stride, 0, L.ptr(gin.t),
                                                       L.ptr(self.gzq.t), self.gzq.plane_stride, 0, L.ptr(self.G_z.t), L.ptr(gout.t), M,
-                                                      HC, st()), "gru blend backward")
-                self.launch[("q" + tag + "^T", it)]()                 # gout[inp | motion | r*h] = gin[...] + d / d [inp | motion | r*h]
-                L.check(lib.ufr_gru_gates_cm_backward(L.ptr(ZR.t), L.ptr(buf.t), buf.plane_stride, 0, L.ptr(self.G_z.t), _ptr(gout, 3 * HC),
-                                                      L.ptr(self.gzr.t), self.gzr.plane_stride, 0, L.ptr(gout.t), M, HC, 1, st()),
+                                                      HC, L.ptr(self.Aq[half].t), st()), "gru blend backward")
+                self.launch[("q" + tag + "^T", it)]()                 # gout[motion | r*h] = gin[...] + d / d [motion | r*h]
+                L.check(lib.ufr_gru_gates_cm_backward(L.ptr(ZR.t), L.ptr(buf.t), buf.plane_stride, 0, L.ptr(self.G_z.t), _ptr(gout, 2 * HC),
+                                                      L.ptr(self.gzr.t), self.gzr.plane_stride, 0, L.ptr(gout.t), M, HC, 1,
+                                                      L.ptr(self.Azr[half].t), st()),
                         "gru gates backward")                         # (consumes the r*h slot: zeros for the next adder)
-                self.launch[("zr" + tag + "^T", it)]()                # gout[h | inp | motion] += d / d [h | inp | motion]
+                self.launch[("zr" + tag + "^T", it)]()                # gout[h | motion] += d / d [h | motion]
             # motion features -> ReLU' -> conv^T (correlation branch) -> convc2^T -> convc1^T -> the lookup's adjoint
-            L.check(lib.ufr_grad_finalize(_ptr(self.TA, 2 * HC), 0, L.ptr(self.P1[it].t), 2 * HC, L.ptr(self.gz_mot.t), self.gz_mot.plane_stride,
+            L.check(lib.ufr_grad_finalize(_ptr(self.TA, HC), 0, L.ptr(self.P1[it].t), HC, L.ptr(self.gz_mot.t), self.gz_mot.plane_stride,
                                           0, M, HC, 0.0, st()), "motion finalize")
-            self.TA.t[2 * HC:3 * HC].zero_()                           # the next iteration's motion gradient starts from zero
+            self.TA.t[HC:2 * HC].zero_()                               # the next iteration's motion gradient starts from zero
             for name in ("conv^T", "convc2^T", "convc1^T"):
                 self.launch[(name, it)]()
             self.G_corr.to_nchw(self.cor_planes, 0, slope=1.0, out=self.g_corr)
             self._lookup_backward(src, self._coords[it], first=(it == IT - 1))
         self.TA.to_nchw(128, 0, slope=1.0, out=self.g_net0)          # (an even number of half-steps: TA holds d / d net0)
-        self.TA.to_nchw(128, HC, slope=1.0, out=self.g_inp)
+        # d / d inp: the adjoint of the context share, once, on the pre-activation gradients summed over the iterations
+        for half, tag in enumerate(("1", "2")):
+            for name, acc in (("zr" + tag, self.Azr[half]), ("q" + tag, self.Aq[half])):
+                gz = self.gz_ctx[name]
+                L.check(lib.ufr_grad_finalize(L.ptr(acc.t), 0, None, 0, L.ptr(gz.t), gz.plane_stride, 0, M, acc.chunks, 1.0, st()),
+                        "context share: gradient sums -> planes")
+        for name in ("zr1", "q1", "zr2", "q2"):
+            self.launch[("ctx_" + name + "^T",)]()
+        self.G_inp.to_nchw(128, 0, slope=1.0, out=self.g_inp)
         return self.g_net0, self.g_inp
 
 
