@@ -140,6 +140,38 @@ int ufr_resample2d_backward_owner(const float* input1, const float* input2, cons
                                   float* grad_input2, void* workspace, long workspace_bytes, int B, int C, int H, int W,
                                   ufr_stream_t stream);
 
+/* ---- FlowNet2's glue between its sub-networks (csrc/fn2_glue.hip, round 5) --------------------------------------------------
+ * models/flownet2_models.py:122-205 strings FlowNetC, two FlowNetS, FlowNetSD and FlowNetFusion together with ~20 elementwise
+ * torch operators per stage (mul / interpolate, slice, sub, div, cat around Resample2d and ChannelNorm, and their adjoints).  These
+ * entries are those operators as streaming kernels; Resample2d itself stays ufr_resample2d_*.  All tensors NCHW float32, dense.
+ *   ufr_flow_upscale4_*: out [B,2,4h,4w] = upsample_x4(flow * scale) (divide = 0) or (flow / scale) (divide != 0), bilinear with
+ *     torch's align_corners = False weights (`upsample1`, flownet2_models.py:133) or nearest (`upsample3/4`, :160, :176); the
+ *     adjoint gathers (no atomics, overwrites grad_flow).
+ *   ufr_fn2_stage_pack: out [B,12,H,W] = cat(x [B,6], resampled [B,3], flow [B,2] / div_flow, ChannelNorm(x[:, :3] - resampled))
+ *     (:138-145, :150-157).  ufr_fn2_stage_unpack_grad: grad_x[:, 0:3] (complete) and grad_resampled [B,3,H,W] = what enters
+ *     Resample2d's adjoint, from grad_out [B,12,H,W] and the packed tensor.  ufr_fn2_stage_finish_grad: grad_x[:, 3:6] =
+ *     grad_out[:, 3:6] + Resample2d's image gradient; grad_flow = Resample2d's flow gradient + grad_out[:, 9:11] / div_flow.
+ *   ufr_fn2_fusion_*: the same three steps for FlowNetFusion's input (:183-205):
+ *     out [B,11,H,W] = cat(x[:, :3], flow_sd, flow_s2, |flow_sd|, |flow_s2|, |x1 - res_sd|, |x1 - res_s2|). */
+int ufr_flow_upscale4_forward(const float* flow, float* out, int B, int h, int w, int bilinear, float scale, int divide,
+                              ufr_stream_t stream);
+int ufr_flow_upscale4_backward(const float* grad_out, float* grad_flow, int B, int h, int w, int bilinear, float scale, int divide,
+                               ufr_stream_t stream);
+int ufr_fn2_stage_pack(const float* x, const float* resampled, const float* flow, float* out, int B, int H, int W, float div_flow,
+                       ufr_stream_t stream);
+int ufr_fn2_stage_unpack_grad(const float* grad_out, const float* packed, float* grad_x, float* grad_resampled, int B, int H, int W,
+                              ufr_stream_t stream);
+int ufr_fn2_stage_finish_grad(const float* grad_out, const float* grad_image, const float* grad_flow_rs, float* grad_x, float* grad_flow,
+                              int B, int H, int W, float div_flow, ufr_stream_t stream);
+int ufr_fn2_fusion_pack(const float* x, const float* flow_sd, const float* flow_s2, const float* res_sd, const float* res_s2, float* out,
+                        int B, int H, int W, ufr_stream_t stream);
+int ufr_fn2_fusion_unpack_grad(const float* grad_out, const float* packed, const float* res_sd, const float* res_s2, float* grad_x,
+                               float* grad_res_sd, float* grad_res_s2, float* grad_flow_sd, float* grad_flow_s2, int B, int H, int W,
+                               ufr_stream_t stream);
+int ufr_fn2_fusion_finish_grad(const float* grad_image_sd, const float* grad_image_s2, const float* grad_flow_rs_sd,
+                               const float* grad_flow_rs_s2, float* grad_x, float* grad_flow_sd, float* grad_flow_s2, int B, int H, int W,
+                               ufr_stream_t stream);
+
 /* ---- ChannelNorm -------------------------------------------------------------------------------
  * replaces channelnorm_cuda.forward / .backward (models/channelnorm_package/channelnorm_cuda.cc:6-25,
  *   kernels channelnorm_kernel.cu:18-60, :63-96); norm_deg accepted and ignored like the reference.

@@ -140,6 +140,14 @@ SIGNATURES = {
     "ufr_pwc_warp_forward": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_pwc_warp_backward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_igemm": [C.POINTER(IgemmDesc), _vp],
+    "ufr_flow_upscale4_forward": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
+    "ufr_flow_upscale4_backward": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
+    "ufr_fn2_stage_pack": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
+    "ufr_fn2_stage_unpack_grad": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "ufr_fn2_stage_finish_grad": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
+    "ufr_fn2_fusion_pack": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "ufr_fn2_fusion_unpack_grad": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "ufr_fn2_fusion_finish_grad": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ufr_rowmajor_to_planes": [_vp, _l, _l, _i, _f, _vp, _l, _i, _l, _vp],
     "ufr_nchw_to_planes": [_vp, _vp, _l, _i, _i, _i, _i, _i, _f, _f, _vp, _vp],
     "ufr_window_scatter_planes": [_vp, _vp, _l, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

@@ -367,6 +367,28 @@ class FlowNet2(nn.Module):
         up_bl = lambda f: F.interpolate(f, scale_factor=4, mode="bilinear", align_corners=False)
         up_nn = lambda f: F.interpolate(f, scale_factor=4, mode="nearest")
 
+        # the native path strings the sub-networks together with three fused Functions (fn2_glue.py / csrc/fn2_glue.hip) instead of
+        # ~20 torch operators per stage; UFR_FN2_GLUE=0 keeps the torch spelling below (the yardstick of tests/test_fn2_glue_gpu.py)
+        glue = x.is_cuda and _L.engine_refusal(self, x, 64) is None and os.environ.get("UFR_FN2_GLUE", "1") != "0"
+        if glue:
+            from ..fn2_glue import fusion_input, upscale4, warp_stage
+            up_bl = lambda f: upscale4(f, True, self.div_flow)             # == interpolate(f * div_flow, 4, bilinear)
+            main, side = torch.cuda.current_stream(x.device), _branch_stream(x.device)
+            fork = os.environ.get("UFR_FN2_BRANCH_STREAM", "1") != "0"
+            if fork:                                                       # FlowNet-SD on the second stream (see below)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    flow_sd = upscale4(self.flownets_d(x)[0], False, self.div_flow, divide=True)
+            flow_c = up_bl(self.flownetc(x)[0])
+            flow_s1 = up_bl(self.flownets_1(warp_stage(x, flow_c, self.div_flow))[0])
+            flow_s2 = upscale4(self.flownets_2(warp_stage(x, flow_s1, self.div_flow))[0], False, self.div_flow)
+            if fork:
+                main.wait_stream(side)
+                flow_sd.record_stream(main)
+            else:
+                flow_sd = upscale4(self.flownets_d(x)[0], False, self.div_flow, divide=True)
+            return self.flownetfusion(fusion_input(x, flow_sd, flow_s2))
+
         def small_displacement_branch():
             flow_sd = up_nn(self.flownets_d(x)[0] / self.div_flow)     # sic: divided (:176)
             return flow_sd, self.channelnorm(flow_sd), self.channelnorm(x[:, :3] - self.resample3(x[:, 3:], flow_sd))

@@ -25,11 +25,13 @@ def _check(**tensors):
             raise RuntimeError(f"{n} must be 4-D")
 
 
-_WORKSPACES: dict = {}            # (device, B, H, W) -> int32 workspace of the owner-computes adjoint (sampling boxes per tile)
+_WORKSPACES: dict = {}            # (device, stream, B, H, W) -> int32 workspace of the owner-computes adjoint (sampling boxes per tile)
 
 
 def _workspace(device, B, H, W):
-    key = (device, B, H, W)
+    # per STREAM: launch A writes it and launch B of the same call reads it, in stream order; FlowNet2's small-displacement branch
+    # runs its Resample2d on a second stream (flownets/flownet2.py) at the same shape
+    key = (device, torch.cuda.current_stream(device).cuda_stream, B, H, W)
     ws = _WORKSPACES.get(key)
     if ws is None:
         if len(_WORKSPACES) >= 16:
