@@ -24,7 +24,9 @@ __device__ __forceinline__ void bil4(int d, int n, int& i0, int& i1, float& l0, 
   l0 = 1.0f - l1;
 }
 
-__device__ __forceinline__ float scaled(float v, float scale, int divide) { return divide ? v / scale : v * scale; }
+// torch divides a tensor by a Python scalar as a multiplication by the float reciprocal (div_true_kernel_cuda: `a * (1 / b)` when
+// the divisor is a CPU scalar): `flow / self.div_flow` (flownet2_models.py:143, :176) is reproduced bit for bit that way
+__device__ __forceinline__ float scaled(float v, float scale, int divide) { return divide ? v * (1.0f / scale) : v * scale; }
 
 // out [B,2,4h,4w] = upsample(scaled(flow [B,2,h,w])): the scaling first, as `interpolate(flow * div_flow)` does
 __global__ void flow_upscale4_fwd(const float* __restrict__ flow, float* __restrict__ out, int B, int h, int w, int bilinear,
@@ -116,8 +118,8 @@ __global__ void stage_pack(const float* __restrict__ x, const float* __restrict_
       ob[(6 + c) * HW] = r;
       d[c] = xb[c * HW] - r;
     }
-    ob[9 * HW] = fb[0] / div;
-    ob[10 * HW] = fb[HW] / div;
+    ob[9 * HW] = fb[0] * (1.0f / div);                       // (torch's tensor / scalar: see `scaled`)
+    ob[10 * HW] = fb[HW] * (1.0f / div);
     ob[11 * HW] = norm3(d[0], d[1], d[2]);
   }
 }
@@ -150,7 +152,7 @@ __global__ void stage_finish_grad(const float* __restrict__ g, const float* __re
 #pragma unroll
     for (int c = 0; c < 3; ++c) gx[b * 6 * HW + (3 + c) * HW + p] = gb[(3 + c) * HW] + gimg[b * 3 * HW + c * HW + p];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) gflow[b * 2 * HW + c * HW + p] = gflow_rs[b * 2 * HW + c * HW + p] + gb[(9 + c) * HW] / div;
+    for (int c = 0; c < 2; ++c) gflow[b * 2 * HW + c * HW + p] = gflow_rs[b * 2 * HW + c * HW + p] + gb[(9 + c) * HW] * (1.0f / div);
   }
 }
 

@@ -45,6 +45,39 @@ def _ptr(gs: ig.GradSum, chunk0: int) -> C.c_void_p:
     return C.c_void_p(gs.t.data_ptr() + chunk0 * gs.M * 32 * 4)
 
 
+class _Fork:
+    """Work on the engine's second stream between a fork from and a join with the caller's stream.  Two ways to use it:
+        with fork as on_side:            # joins at the end of the block
+            with on_side: ...side work...
+            ...main work...
+        fork.start() as a context for the side work, fork.join() later (the backward's one-iteration lag).
+    Without a side stream (UFR_RAFT_STREAMS=0) everything runs in program order on the caller's stream."""
+
+    def __init__(self, side):
+        self.side = side
+        self.main = torch.cuda.current_stream(side.device) if side is not None else None
+        self.used = False
+
+    def start(self):
+        import contextlib
+        if self.side is None:
+            return contextlib.nullcontext()
+        self.side.wait_stream(self.main)
+        self.used = True
+        return torch.cuda.stream(self.side)
+
+    def join(self):
+        if self.used:
+            self.main.wait_stream(self.side)
+            self.used = False
+
+    def __enter__(self):
+        return self.start()
+
+    def __exit__(self, *exc):
+        self.join()
+
+
 class RaftUpdateEngine:
     def __init__(self, net, B: int, H: int, W: int, device):
         if H % 8 or W % 8:
@@ -192,12 +225,26 @@ class RaftUpdateEngine:
         plan(("mask2^T",), Wb["mask2"], self.gz_mask, 0, mask=self.MH, out_planes=self.gz_mh, **relu)
         plan(("mask1^T",), Wb["mask1"], self.gz_mh, 0, out_f32=self.TA, out_f32_chunk0=0)
         plan(("fh1^T",), Wb["fh1"], self.gz_fh, 0, add=self.TA, add_chunk0=0, out_f32=self.TA, out_f32_chunk0=0)
-        need = max([S * self.M * wi.Npad for _, wi, _, _, S, _ in plans if S > 1] + [1])
-        self.ws = torch.empty(need, **f32)
+        # Two streams (round 5).  At one pair (48 x 160 = 7,680 rows) no launch of the update block fills the 256 CUs, and two parts
+        # of an iteration do not depend on the chain that carries the hidden state:
+        #   forward   the flow branch of the motion encoder (flow patches, convf1, convf2) next to lookup -> convc1 -> convc2;
+        #   backward  the motion encoder's adjoint and the lookup's adjoint of iteration i (conv^T .. convc1^T, alt_corr / lookup
+        #             backward: they end in the feature maps' gradients, coords are detached, raft.py:190) next to the GRU adjoint
+        #             of iteration i - 1.
+        # The side stream's launches split K into their own workspace.  Inside a HIP-graph capture the fork / join events become
+        # graph edges.  UFR_RAFT_STREAMS=0: everything on the caller's stream (the A/B switch).
+        self._side_keys = {"convf1", "convf2", "conv^T", "convc2^T", "convc1^T"}
+        side = lambda key: key[0] in self._side_keys
+        need = max([S * self.M * wi.Npad for key, wi, _, _, S, _ in plans if S > 1 and not side(key)] + [1])
+        need_side = max([S * self.M * wi.Npad for key, wi, _, _, S, _ in plans if S > 1 and side(key)] + [1])
+        self.ws, self.ws_side = torch.empty(need, **f32), torch.empty(need_side, **f32)
         self.launch, self._wi = {}, {}
         for key, wi, x, c0, S, kw in plans:
-            self.launch[key] = ig.make_launch(wi, x, c0, (h, w), (h, w), splitk=S, ws=self.ws if S > 1 else None, **kw)
+            ws = (self.ws_side if side(key) else self.ws) if S > 1 else None
+            self.launch[key] = ig.make_launch(wi, x, c0, (h, w), (h, w), splitk=S, ws=ws, **kw)
             self._wi[key] = wi
+        self._two_streams = os.environ.get("UFR_RAFT_STREAMS", "1") != "0"
+        self._side_stream = torch.cuda.Stream(device=dev) if self._two_streams else None
         fh2 = ub.flow_head.conv2
         self.fh2_w, self.fh2_wm = _pack_flow_head(fh2.weight), _pack_flow_head_mfma(fh2.weight)
         self.fh2_b = fh2.bias.detach().float().contiguous()
@@ -216,6 +263,9 @@ class RaftUpdateEngine:
             d = launch.desc
             rows.append(("_".join(str(v) for v in key), launch, self._wi[key].flops(d.B * d.Hr * d.Wr) / 1e9))
         return rows
+
+    def _fork(self):
+        return _Fork(self._side_stream)
 
     # ------------------------------------------------------------------------------------------------ lookups
     def _alt_levels(self, f2s, grads=None):
@@ -266,13 +316,18 @@ class RaftUpdateEngine:
         for it in range(IT):
             coords = self.coords1.clone()                             # (the adjoint of this iteration's lookup reads them)
             self._coords.append(coords)
-            self._lookup_forward(src, coords)
-            self.corr_p[it].load_nchw(self.corr, 0)
             torch.sub(coords, self.coords0, out=self.flows[it])
-            L.check(lib.ufr_raft_flow_patches(L.ptr(self.flows[it]), L.ptr(self.fpat.t), self.fpat.plane_stride, 0, B, h, w, st()),
-                    "flow patches")
-            for name in ("convc1", "convc2", "convf1", "convf2", "conv"):
-                self.launch[(name, it)]()
+            with self._fork() as on_side:                             # the flow branch: no adjoint, nothing of the lookup in it
+                with on_side:
+                    L.check(lib.ufr_raft_flow_patches(L.ptr(self.flows[it]), L.ptr(self.fpat.t), self.fpat.plane_stride, 0, B, h, w, st()),
+                            "flow patches")
+                    self.launch[("convf1", it)]()
+                    self.launch[("convf2", it)]()
+                self._lookup_forward(src, coords)
+                self.corr_p[it].load_nchw(self.corr, 0)
+                self.launch[("convc1", it)]()
+                self.launch[("convc2", it)]()
+            self.launch[("conv", it)]()
             P1, P2 = self.P1[it], self.P2[it]
             lc = self.launch[("conv", it)]
             if lc.desc.no_reduce:                                    # its slabs -> both GRU buffers' motion chunks (+ the flow channels)
@@ -336,6 +391,7 @@ class RaftUpdateEngine:
         self.TA.t[HC:].zero_()                                        # d / d motion; the r*h slots start at zero
         self.TB.t[2 * HC:].zero_()
         self._acc_arena.zero_()                                       # the pre-activation gradients' sums over the iterations
+        pending = None                                                # the side stream's work of the previous iteration
         for it in range(IT - 1, -1, -1):
             # cur = chunks 0-3 of `gin` (d / d the half-step's output h), prev = chunks 0-3 of `gout` (d / d its input h)
             for half, (tag, buf, gin, gout) in ((1, ("2", self.P2[it], self.TA, self.TB)), (0, ("1", self.P1[it], self.TB, self.TA))):
@@ -349,14 +405,21 @@ class RaftUpdateEngine:
                                                       L.ptr(self.Azr[half].t), st()),
                         "gru gates backward")                         # (consumes the r*h slot: zeros for the next adder)
                 self.launch[("zr" + tag + "^T", it)]()                # gout[h | motion] += d / d [h | motion]
-            # motion features -> ReLU' -> conv^T (correlation branch) -> convc2^T -> convc1^T -> the lookup's adjoint
+            # motion features -> ReLU' -> conv^T (correlation branch) -> convc2^T -> convc1^T -> the lookup's adjoint: this chain
+            # ends in the feature maps' gradients, the GRU adjoint of the next (earlier) iteration does not wait for it
+            if pending is not None:
+                pending.join()                                         # (its buffers -- gz_mot .. g_corr -- are about to be rewritten)
             L.check(lib.ufr_grad_finalize(_ptr(self.TA, HC), 0, L.ptr(self.P1[it].t), HC, L.ptr(self.gz_mot.t), self.gz_mot.plane_stride,
                                           0, M, HC, 0.0, st()), "motion finalize")
             self.TA.t[HC:2 * HC].zero_()                               # the next iteration's motion gradient starts from zero
-            for name in ("conv^T", "convc2^T", "convc1^T"):
-                self.launch[(name, it)]()
-            self.G_corr.to_nchw(self.cor_planes, 0, slope=1.0, out=self.g_corr)
-            self._lookup_backward(src, self._coords[it], first=(it == IT - 1))
+            pending = self._fork()
+            with pending.start():
+                for name in ("conv^T", "convc2^T", "convc1^T"):
+                    self.launch[(name, it)]()
+                self.G_corr.to_nchw(self.cor_planes, 0, slope=1.0, out=self.g_corr)
+                self._lookup_backward(src, self._coords[it], first=(it == IT - 1))
+        if pending is not None:
+            pending.join()
         self.TA.to_nchw(128, 0, slope=1.0, out=self.g_net0)          # (an even number of half-steps: TA holds d / d net0)
         # d / d inp: the adjoint of the context share, once, on the pre-activation gradients summed over the iterations
         for half, tag in enumerate(("1", "2")):
