@@ -257,6 +257,16 @@ class BasicUpdateBlock(nn.Module):
         return net, mask, delta_flow
 
 
+_CONTEXT_STREAMS: dict = {}
+
+
+def _context_stream(device):
+    key = torch.device(device)
+    if key not in _CONTEXT_STREAMS:
+        _CONTEXT_STREAMS[key] = torch.cuda.Stream(device=key)
+    return _CONTEXT_STREAMS[key]
+
+
 def coords_grid(batch, ht, wd, device):
     """utils/utils.py:80-83: channel 0 = x, channel 1 = y."""
     ys, xs = torch.meshgrid(torch.arange(ht, device=device), torch.arange(wd, device=device), indexing="ij")
@@ -311,14 +321,32 @@ class RAFT(nn.Module):
         iters = self.args.iters                                        # raft.py:126 (argument ignored)
         image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
         image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
+        def context():
+            net, inp = torch.split(self.cnet(image1), [128, 128], dim=1)
+            return torch.tanh(net), torch.relu(inp)
+
+        # The context encoder reads frame 1 only and meets the feature encoder's results in the update block (raft.py:176-184).  On
+        # the native path it runs on a second HIP stream: its normalisation kernels are HBM-bound, the feature encoder's
+        # convolutions MFMA-bound, and the adjoints (autograd replays a node on the stream it was recorded on) run side by side
+        # as well.  UFR_RAFT_STREAMS=0: one stream.
+        fork = (image1.is_cuda and L.engine_refusal(self, image1, 8) is None and os.environ.get("UFR_ENGINE", "1") == "1"
+                and os.environ.get("UFR_RAFT_STREAMS", "1") != "0")
+        if fork:
+            main, side = torch.cuda.current_stream(image1.device), _context_stream(image1.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                net, inp = context()
         fmap1, fmap2 = self.fnet([image1, image2])
         fmap1, fmap2 = fmap1.float().contiguous(), fmap2.float().contiguous()
         if self.args.alternate_corr:
             corr_fn = AlternateCorrBlock(fmap1, fmap2, radius=self.args.corr_radius, share_grad=True)
         else:
             corr_fn = CorrBlock(fmap1, fmap2, num_levels=self.args.corr_levels, radius=self.args.corr_radius)
-        net, inp = torch.split(self.cnet(image1), [128, 128], dim=1)
-        net, inp = torch.tanh(net), torch.relu(inp)
+        if fork:
+            main.wait_stream(side)
+            net.record_stream(main), inp.record_stream(main)
+        else:
+            net, inp = context()
 
         N, _, H, W = image1.shape
         if test_mode and flow_init is None and self._engine_ok(net, H, W):
