@@ -877,7 +877,23 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const Args a) {
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float* src = a.ws + ((long)a.zoff[phase] * a.g.M + row) * a.Npad + n0;
     const long sstride = (long)a.g.M * a.Npad;
-    for (int s = 0; s < a.sk[phase]; ++s) {
+    // (the slabs of four slices are requested before the first is added: a deep split on a tiny grid -- 16 .. 32 slabs of a 7 x 16
+    // grid -- was a chain of dependent loads, ~0.5 us each; the order of the additions, and with it every bit of the sum, stays)
+    const int S = a.sk[phase];
+    int s = 0;
+    for (; s + 4 <= S; s += 4) {
+      float4 lo[4], hi[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        lo[u] = *reinterpret_cast<const float4*>(src + (s + u) * sstride);
+        hi[u] = *reinterpret_cast<const float4*>(src + (s + u) * sstride + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[0] += lo[u].x; v[1] += lo[u].y; v[2] += lo[u].z; v[3] += lo[u].w; v[4] += hi[u].x; v[5] += hi[u].y; v[6] += hi[u].z; v[7] += hi[u].w;
+      }
+    }
+    for (; s < S; ++s) {
       const float4 lo = *reinterpret_cast<const float4*>(src + s * sstride), hi = *reinterpret_cast<const float4*>(src + s * sstride + 4);
       v[0] += lo.x; v[1] += lo.y; v[2] += lo.z; v[3] += lo.w; v[4] += hi.x; v[5] += hi.y; v[6] += hi.z; v[7] += hi.w;
     }

@@ -174,7 +174,8 @@ class RaftUpdateEngine:
             bm, target = (256, 256) if kw["variant"] == 6 else (128, 768)
             S = ig.splitk_for(self.M, wi.Npad, max(pk), 1, phase_ktiles=pk, bm=bm, target=target, min_ktiles=4)
             kw["variant"], S = ig.tuned(wi, self.M, kw, kw["variant"], S)
-            S = min(S, int(os.environ.get("UFR_RAFT_SPLITK_CAP", "64")))       # (experiment: with two streams a launch need not fill the chip)
+            # (capping the split because a second stream fills the chip anyway measured SLOWER: 16.02 ms -> 16.47 at <= 2 slices, 20.16
+            # without split-K, gpurun r5_call11: a lone ping-pong workgroup per CU is latency-bound, short slices are the cure)
             if ctx is not None and not (kw.get("no_reduce") and S > 1):
                 kw["add"] = ctx            # no slabs for the gate kernel to read: the context share rides in igemm's own epilogue
             plans.append((key, wi, x, in_chunk0, S, kw))
