@@ -358,6 +358,26 @@ class EngineCache(dict):
         return (EngineCache, ())
 
 
+# The engines keep their results and input gradients in STATIC buffers; their autograd Functions hand autograd CLONES, because a
+# caller may keep a flow or a `.grad` across the next forward.  A composition whose every consumer reads the tensor at once and
+# keeps nothing (FlowNet2's native path: fn2_glue.py Functions and engine Functions feeding each other) says so with
+# `with static_handoff():` around its sub-network calls; the Functions then pass aliases of the static buffers, forward and
+# (the choice is remembered in ctx) backward -- ~30 copy kernels per FlowNet2 iteration less.
+_STATIC_HANDOFF = [0]
+
+
+class static_handoff:
+    def __enter__(self):
+        _STATIC_HANDOFF[0] += 1
+
+    def __exit__(self, *exc):
+        _STATIC_HANDOFF[0] -= 1
+
+
+def static_ok() -> bool:
+    return _STATIC_HANDOFF[0] > 0
+
+
 _GRAD_FLAGS_ATTR = "_ufr_grad_flags"
 
 

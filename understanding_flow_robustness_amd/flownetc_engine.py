@@ -737,8 +737,11 @@ class _EngineHead(torch.autograd.Function):
     def forward(ctx, c2a, c3a, c3b, engine, band):
         ctx.engine, ctx.band = engine, band
         engine.generation = ctx.generation = getattr(engine, "generation", 0) + 1
-        # the engine's flow2 is a static buffer: hand autograd its own (2-channel, tiny) tensor
-        return engine.forward(c2a.contiguous(), c3a.contiguous(), c3b.contiguous() if c3b is not None else None, band).clone()
+        # the engine's flow2 is a static buffer: hand autograd its own (2-channel, tiny) tensor -- or, inside a composition that
+        # declared every consumer immediate (`_lib.static_handoff`), an alias of it
+        ctx.static = L.static_ok()
+        flow2 = engine.forward(c2a.contiguous(), c3a.contiguous(), c3b.contiguous() if c3b is not None else None, band)
+        return flow2.detach() if ctx.static else flow2.clone()
 
     @staticmethod
     def backward(ctx, g_flow2):
@@ -747,6 +750,8 @@ class _EngineHead(torch.autograd.Function):
                                "backward; its activations are gone.  Call backward() before the next forward, or set "
                                "UFR_ENGINE=0 for interleaved forwards")
         g2a, g3a, g3b = ctx.engine.backward(g_flow2.contiguous(), ctx.band, fused_window=False)
+        if ctx.static:
+            return g2a, g3a, g3b, None, None
         # static buffers as well: autograd (and a caller who retains .grad) gets its own copies
         return (g2a.clone() if g2a is not None else None, g3a.clone() if g3a is not None else None,
                 g3b.clone() if g3b is not None else None, None, None)

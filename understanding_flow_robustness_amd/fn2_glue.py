@@ -25,6 +25,34 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
+class _NormalizePair(torch.autograd.Function):
+    """x = cat(x1 - mean, x2 - mean) with the subtraction in float64 (flownet2_models.py:93-96, :124-125; FlowNetC.py:73-79) in
+    ONE pass (`ufr_normalize_frames`, bit-exact) instead of two casts up, two subtractions, two casts down and a cat; the adjoint
+    is the split of the gradient."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, mean64):
+        x1, x2 = _f32c(x1, "x1"), _f32c(x2, "x2")
+        B, C, H, W = x1.shape
+        if x2.shape != x1.shape or mean64.dtype != torch.float64 or mean64.numel() != C:
+            raise RuntimeError("normalize_pair: two [B,C,H,W] frames and C float64 means expected")
+        stack = x1.new_empty(2 * B, C, H, W)
+        with torch.cuda.device(x1.device):
+            L.check(L.lib().ufr_normalize_frames(L.ptr(x1), L.ptr(x2), L.ptr(stack), B, B, C, H, W, L.ptr(mean64.contiguous()), L.stream()),
+                    "normalize frames")
+        ctx.C = C
+        # [x1 stack | x2 stack] IS cat(x1n, x2n, dim=1) for one pair; more pairs interleave with one cat
+        return stack.view(1, 2 * C, H, W) if B == 1 else torch.cat((stack[:B], stack[B:]), dim=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :ctx.C], g[:, ctx.C:], None
+
+
+def normalize_pair(x1, x2, mean64):
+    return _NormalizePair.apply(x1, x2, mean64)
+
+
 class _Upscale4(torch.autograd.Function):
     @staticmethod
     def forward(ctx, flow, bilinear, scale, divide):

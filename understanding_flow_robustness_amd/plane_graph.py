@@ -308,7 +308,8 @@ class _GraphFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, graph, *inputs):
-        outs = [o.clone() for o in graph.forward(*inputs)]
+        ctx.static = L.static_ok()            # (`_lib.static_handoff`: every consumer reads at once -> aliases instead of clones)
+        outs = [o.detach() if ctx.static else o.clone() for o in graph.forward(*inputs)]
         ctx.graph, ctx.generation = graph, graph.generation
         return tuple(outs)
 
@@ -318,7 +319,7 @@ class _GraphFunction(torch.autograd.Function):
             raise RuntimeError("native sub-network: another forward (same batch and frame size) ran before this backward; its "
                                "activations are gone.  Call backward() before the next forward, or set UFR_ENGINE=0")
         gs = ctx.graph.backward(*[g.contiguous() for g in grads])
-        return (None, *[g.clone() for g in gs])
+        return (None, *[g if ctx.static else g.clone() for g in gs])
 
 
 def run(graph: PlaneGraph, *inputs):
