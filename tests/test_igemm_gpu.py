@@ -16,7 +16,8 @@ VARIANT = {"v": 0}
 
 class _Ig:
     """The igemm host module with `make_launch` pinned to one kernel form (csrc/igemm.hip: 2 = single-stage, 4 = 64 x 128
-    tiles, 5 = pipelined, 6 = ping-pong, 7 = ping-pong with horizontal runs of taps staged once)."""
+    tiles, 5 = pipelined, 6 = ping-pong, 7 = ping-pong with horizontal runs of taps staged once, 8 = the direct 3 x 3 form: a
+    launch it does not cover -- other kernels, strides, more than 128 columns -- falls through to the plain forms)."""
 
     def __getattr__(self, name):
         from understanding_flow_robustness_amd import igemm
@@ -25,7 +26,8 @@ class _Ig:
         return getattr(igemm, name)
 
 
-@pytest.fixture(autouse=True, params=[2, 4, 5, 6, 7], ids=["single-stage", "tile-64x128", "pipelined", "ping-pong", "ping-pong-tap-reuse"])
+@pytest.fixture(autouse=True, params=[2, 4, 5, 6, 7, 8],
+                ids=["single-stage", "tile-64x128", "pipelined", "ping-pong", "ping-pong-tap-reuse", "direct-3x3"])
 def _variant(request):
     VARIANT["v"] = request.param
     yield
@@ -54,6 +56,9 @@ def _rand(*shape, seed=0, scale=1.0):
     (1, 64, 128, 20, 36, 5, 2, 2),        # conv2 / conv3 shape (25 taps)
     (2, 160, 64, 24, 40, 3, 1, 1),        # PWC-Net's decoder: 64 outputs behind a long K (256 x 64 tiles in the tap-reuse form)
     (3, 117, 32, 13, 29, 3, 1, 1),        # ... 32 outputs, a row grid that ends inside a tile row, odd width
+    (1, 6, 64, 40, 72, 3, 1, 1),          # FlowNetSD's conv0: 6 -> 64 at full resolution (one input chunk; the direct 3 x 3 form's case)
+    (2, 11, 64, 17, 35, 3, 1, 1),         # FlowNetFusion's conv0, ragged tiles
+    (1, 82, 16, 21, 70, 3, 1, 1),         # inter_conv0: 82 -> 16 (one column tile of 16)
 ])
 def test_forward_convolution_with_bias_and_leaky(B, Cin, Cout, H, W, k, s, p):
     ig = _mods()
@@ -98,7 +103,8 @@ def test_deconv_forward_phases(B, Cin, Cout, H, W):
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,k,s,p", [(2, 96, 160, 24, 40, 3, 1, 1), (2, 70, 130, 24, 40, 3, 2, 1),
                                                    (1, 256, 32, 12, 20, 1, 1, 0), (2, 64, 224, 24, 40, 3, 1, 1),
-                                                   (3, 32, 160, 13, 29, 3, 1, 1)])
+                                                   (3, 32, 160, 13, 29, 3, 1, 1), (1, 6, 64, 40, 72, 3, 1, 1),
+                                                   (2, 82, 16, 21, 70, 3, 1, 1)])
 def test_data_gradient_with_addend_and_mask(B, Cin, Cout, H, W, k, s, p):
     """gx = (conv^T(gy) + addend) * LeakyReLU'(activation): planes and fp32 outputs of the gradient epilogue."""
     ig = _mods()

@@ -119,7 +119,7 @@ def sweep(config, out_dir):
         wi, kw, M = r["wi"], dict(r["kw"]), r["M"]
         gflop = wi.flops(M) / 1e9
         chosen = (r["variant"] if r["variant"] else 2, r["splitk"])
-        variants = (6, 7, 5, 4, 2) if wi.Npad % 128 == 0 else (2, 7)
+        variants = (6, 7, 5, 4, 2, 8) if wi.Npad % 128 == 0 else (2, 7, 8)
         kt = max(len(t) for _, _, t in wi.phases) * wi.KC
         res = {}
         for v in variants:

@@ -865,6 +865,159 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   igemm_write_out<NPL, MT>(a, ph, acc, reinterpret_cast<float*>(lds_pp + imgA0), z, bm, bn, wrow, wcol, lane, wave);
 }
 
+// ---- direct 3 x 3 form (variant 8, round 5): stride-1 3 x 3 convolutions over FEW input chunks (KC <= 8) and / or few output
+// columns -- the full- and half-resolution layers of FlowNetFusion / FlowNetSD (6 -> 64, 11 -> 64, 82 -> 16, 64 -> 6 ... channels at
+// 448 x 1024).  On the tile forms above such a launch pads its columns to 64 and streams every activation row once per TAP from
+// L2 (nine times per chunk); with K of 9 - 36 steps it is bound by that delivery and by its own latency, not by the matrix pipe
+// (0.12 - 0.38 of the ceiling, profiles/r5_engine_launch_sweep_cold_c5.jsonl).  Here a workgroup owns a TH x 32 tile of output pixels,
+// stages the tile's (TH + 2) x 34 halo of ONE input chunk once (three planes, LDS-DMA, the same XOR swizzle keyed by the halo pixel),
+// takes all nine taps from LDS, and stages the weights three taps at a time ([3][NT * 16][32] per plane: only the column tiles the
+// launch really has, NT = 1, 2, 4 or 8 tiles of 16).  Epilogue = epilogue_store8 through an LDS transpose, as everywhere.
+template <int NT, int TH>
+__global__ __launch_bounds__(256) void igemm_d33_kernel(const Args a) {
+  constexpr int TW = 32, HW_ = TW + 2, HPIX = (TH + 2) * HW_, HBLK = (HPIX + 15) / 16, HROWS = HBLK * 16;
+  constexpr int MT = TH / 2, RPW = TH / 4;                          // m-tiles per wave; tile rows per wave
+  constexpr int TG = 3;                                             // taps per weight staging (NT >= 2; one column tile keeps its
+  constexpr int WROWS = NT == 1 ? 0 : TG * NT * 16;                 //  weights in registers: 27 fragments per lane, LDS = the halo only)
+  extern __shared__ __attribute__((aligned(16))) __bf16 lds_d33[];
+  __bf16* const sH = lds_d33;                                       // [3 planes][HROWS][32]
+  __bf16* const sW = lds_d33 + 3 * HROWS * BK;                      // [3 planes][WROWS][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = a.Hi, W = a.Wi;
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  int t;
+  {                                                                   // XCD k owns one contiguous run of tiles (xcd_tile's 1-D form)
+    const int n = gridDim.x, orig = blockIdx.x, q = n / 8, r = n % 8, xcd = orig % 8, idx = orig / 8;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int b = t / (tiles_x * tiles_y), rem = t - b * tiles_x * tiles_y, y0 = (rem / tiles_x) * TH, x0 = (rem % tiles_x) * TW;
+  const Phase& ph = a.ph[0];
+  const long Min = (long)a.g.B * H * W;
+  const __bf16* zero = reinterpret_cast<const __bf16*>(ufr_zero_page);
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment geometry: m-tile m of this wave = 16 pixels of tile row wave * RPW + m / 2 starting at column 16 * (m & 1)
+  const int pi = lane & 15, kgrp = lane >> 4;
+  for (int kc = 0; kc < a.KC; ++kc) {
+    __syncthreads();                                                  // the previous chunk's fragment reads are done
+    for (int blk = wave; blk < 3 * HBLK; blk += 4) {                  // halo of chunk kc: 16 pixels x 4 pieces per DMA
+      const int p = blk / HBLK, hb = blk - p * HBLK;
+      const int hp = hb * 16 + (lane >> 2), slot = lane & 3;
+      const int hy = hp / HW_, hx = hp - hy * HW_;
+      const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+      const bool ok = hp < HPIX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const int piece = slot ^ ((hp >> 1) & 3);
+      const __bf16* src = ok ? a.x + (long)p * a.x_plane_stride + ((long)(a.in_chunk0 + kc) * Min + ((long)b * H + gy) * W + gx) * BK + piece * 8 : zero;
+      glds16(src, sH + ((long)p * HROWS + hb * 16) * BK);
+    }
+    if constexpr (NT == 1) {
+      // one column tile: the chunk's weights go straight from L2 to registers (lane = (column n, 8-channel group): one 16-byte load
+      // per tap and plane) while the halo's DMA is in flight; with 40 KB of LDS three to four workgroups share a CU and cover each
+      // other's waits -- a halo + weights image of 68 KB (two per CU) ran 0.176 ms on FlowNetFusion's 82 -> 16 layer, gpurun r5_call18
+      bf16x8 wr[9][3];
+      const __bf16* wl = a.w + ph.w_off + ((long)kc * 9 * a.Npad + pi) * BK + kgrp * 8;
+#pragma unroll
+      for (int tt = 0; tt < 9; ++tt)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wr[tt][p] = *reinterpret_cast<const bf16x8*>(wl + (long)p * a.w_plane_stride + (long)tt * a.Npad * BK);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+#pragma unroll
+      for (int tt = 0; tt < 9; ++tt) {
+        const int dyx = ph.dyx[tt], dy = (int)(short)(dyx & 0xffff), dx = dyx >> 16;
+        bf16x8 fa[3][MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int hp = (wave * RPW + (m >> 1) + dy + 1) * HW_ + 16 * (m & 1) + pi + dx + 1;
+          const int off = hp * BK + ((kgrp ^ ((hp >> 1) & 3)) << 3);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) fa[p][m] = *reinterpret_cast<const bf16x8*>(sH + p * (HROWS * BK) + off);
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[q]][m], wr[tt][PROD_B[q]], acc[m][0], 0, 0, 0);
+      }
+    } else
+    for (int j = 0; j < 9 / TG; ++j) {                                // taps TG j .. TG j + TG - 1 of this chunk
+      if (j) __syncthreads();                                         // the previous group's weight reads are done
+      for (int blk = wave; blk < 3 * TG * NT; blk += 4) {             // [plane][tap][column tile]: 16 weight rows x 4 pieces per DMA
+        const int p = blk / (TG * NT), r3 = blk - p * TG * NT, tt = r3 / NT, nb = r3 - tt * NT;
+        const int row = tt * NT * 16 + nb * 16 + (lane >> 2), slot = lane & 3;
+        const int piece = slot ^ ((row >> 1) & 3);
+        const __bf16* src = a.w + ph.w_off + (long)p * a.w_plane_stride + ((long)(kc * 9 + TG * j + tt) * a.Npad + nb * 16 + (lane >> 2)) * BK + piece * 8;
+        glds16(src, sW + ((long)p * WROWS + tt * NT * 16 + nb * 16) * BK);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+#pragma unroll
+      for (int tt = 0; tt < TG; ++tt) {
+        const int dyx = ph.dyx[TG * j + tt], dy = (int)(short)(dyx & 0xffff), dx = dyx >> 16;
+        bf16x8 fa[3][MT], fb[NT][3];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int hp = (wave * RPW + (m >> 1) + dy + 1) * HW_ + 16 * (m & 1) + pi + dx + 1;
+          const int off = hp * BK + ((kgrp ^ ((hp >> 1) & 3)) << 3);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) fa[p][m] = *reinterpret_cast<const bf16x8*>(sH + p * (HROWS * BK) + off);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int row = tt * NT * 16 + n * 16 + pi;
+          const int off = row * BK + ((kgrp ^ ((row >> 1) & 3)) << 3);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) fb[n][p] = *reinterpret_cast<const bf16x8*>(sW + p * (WROWS * BK) + off);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[q]][m], fb[n][PROD_B[q]], acc[m][n], 0, 0, 0);
+      }
+    }
+  }
+  // ---- epilogue: the wave's MT x 16 pixels x NT x 16 columns through LDS, a lane then owns 8 consecutive channels of one pixel
+  constexpr int TS = NT * 16 + 4;
+  __syncthreads();
+  float* tw = reinterpret_cast<float*>(lds_d33) + wave * (MT * 16 * TS);
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tw[(m * 16 + kgrp * 4 + j) * TS + n * 16 + pi] = acc[m][n][j];
+  __syncthreads();
+  // (the launch writes whole 32-channel chunks: the groups behind the last computed column tile leave as zeros)
+  const int G8 = max(NT * 2, a.e.Nchunks32 * 4);
+  for (int it = lane; it < MT * 16 * G8; it += 64) {
+    const int r = it / G8, g8 = it - r * G8, m = r >> 4;
+    const int y = y0 + wave * RPW + (m >> 1), x = x0 + 16 * (m & 1) + (r & 15);
+    if (y < H && x < W) {
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (g8 < NT * 2) {
+        const float4 lo = *reinterpret_cast<const float4*>(tw + r * TS + g8 * 8), hi = *reinterpret_cast<const float4*>(tw + r * TS + g8 * 8 + 4);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+      }
+      epilogue_store8(a.e, ((long)b * H + y) * W + x, g8 * 8, v);
+    }
+  }
+}
+
+template <int NT, int TH>
+constexpr int d33_lds_bytes() {
+  constexpr int HROWS = (((TH + 2) * 34 + 15) / 16) * 16, stage = (3 * HROWS + (NT == 1 ? 0 : 3 * 3 * NT * 16)) * BK * 2;
+  constexpr int epi = 4 * (TH / 2) * 16 * (NT * 16 + 4) * 4;
+  return stage > epi ? stage : epi;
+}
+
 // Second stage of split-K: thread = (phase, row, 8 channels); the slabs are added in ascending order.
 __global__ __launch_bounds__(256) void igemm_reduce_kernel(const Args a) {
   const int n8 = a.Npad / 8;
@@ -997,7 +1150,8 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   // the 64-column ones run the single-stage 128 x 64 tile, which measured faster there), 7 = ping-pong with horizontal runs of
   // taps staged once (256 x 128 or 256 x 64: stride-1 launches with >= 22 columns, the narrow-N / long-K layers of PWC-Net)
   const int variant = d->variant ? d->variant : 2;
-  UFR_REQUIRE(variant == 2 || variant == 4 || variant == 5 || variant == 6 || variant == 7, "igemm: unknown kernel variant %d", variant);
+  UFR_REQUIRE(variant == 2 || variant == 4 || variant == 5 || variant == 6 || variant == 7 || variant == 8, "igemm: unknown kernel variant %d",
+              variant);
   UFR_REQUIRE(d->products == 6, "igemm: six products only (float32-accurate); the 3- and 1-product forms were removed");
   // activation rows through a raw buffer resource (hardware zeros outside the frame) while the planes stay below 2 GB
   const bool use_buf = 6L * d->x_plane_stride < 0x7fffffffL;
@@ -1021,6 +1175,26 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
                               pp3_lds_bytes(64));
     if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "igemm: %s", hipGetErrorString(e));
     raised[dev] = true;
+  }
+  // 8 = the direct 3 x 3 form: one phase of nine taps within +-1, stride 1 in and out, row grid = input grid = output grid, no band,
+  // no split, no tail / row-major output, chunk-major K order, <= 8 input chunks, <= 128 columns (anything else falls through)
+  bool d33 = variant == 8 && d->nphase == 1 && d->phase[0].ntaps == 9 && d->in_sx == 1 && d->in_sy == 1 && d->out_sx == 1 && d->out_sy == 1 &&
+             d->Hr == d->Hi && d->Wr == d->Wi && d->Ho == d->Hi && d->Wo == d->Wi && !d->row_x0 && !d->in_x0 && d->splitk == 1 && !d->tail &&
+             !d->out_rowmajor && d->k_order && d->KC <= 8 && d->N <= 128;
+  for (int t = 0; d33 && t < 9; ++t)
+    d33 = d->phase[0].dy[t] >= -1 && d->phase[0].dy[t] <= 1 && d->phase[0].dx[t] >= -1 && d->phase[0].dx[t] <= 1;
+  if (d33) {
+    const int nt = d->N <= 16 ? 1 : (d->N <= 32 ? 2 : (d->N <= 64 ? 4 : 8));
+    const int th = 4;                        // 4 x 32 tiles: halo + weights <= 80 KB for <= 64 columns, two workgroups per CU
+    const int tiles = d->B * ((d->Hi + th - 1) / th) * ((d->Wi + 31) / 32);
+    hipError_t e = hipSuccess;
+#define UFR_D33(NT_, TH_)                                                                                                       \
+    e = ufr::ensure_dynamic_lds(reinterpret_cast<const void*>(igemm_d33_kernel<NT_, TH_>), d33_lds_bytes<NT_, TH_>());          \
+    if (e == hipSuccess) igemm_d33_kernel<NT_, TH_><<<tiles, 256, d33_lds_bytes<NT_, TH_>(), st>>>(a)
+    if (nt == 1) { UFR_D33(1, 4); } else if (nt == 2) { UFR_D33(2, 4); } else if (nt == 4) { UFR_D33(4, 4); } else { UFR_D33(8, 4); }
+#undef UFR_D33
+    if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "igemm (direct 3 x 3): %s", hipGetErrorString(e));
+    return ufr::launched("igemm_d33_kernel");
   }
   if (variant == 7 && d->k_order && d->in_sx == 1 && d->Wr >= 22) {
     // ping-pong + horizontal runs of taps staged once (launches it does not cover fall through to the plain forms)
