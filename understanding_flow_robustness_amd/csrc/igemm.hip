@@ -755,7 +755,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int imgA0 = grp * 2 * PP3_IMG, imgB0 = 4 * PP3_IMG;
   // one run's pixels of channel chunk kc -> activation image at element `img`
   auto stage_A = [&](int img, int kc, int tap) {
-    const int dyx = ph.dyx[tap], dyo = (int)(short)(dyx & 0xffff), dxo = (dyx >> 16) - (ph.run[tap] & 3);
+    const int dyx = ph.dyx[tap], dyo = (int)(short)(dyx & 0xffff), dxo = (dyx >> 16) - (ph.run[tap] & 3) * a.in_sx;   // the run's first pixel
     const long coff = (long)kc * cstride;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -1118,17 +1118,19 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
     for (int t = 0; t < UFR_IGEMM_MAX_TAPS; ++t)
       a.ph[z].dyx[t] = t < p.ntaps ? (((int)p.dy[t] & 0xffff) | ((int)p.dx[t] << 16)) : 0;
     for (int t = 0; t < UFR_IGEMM_MAX_TAPS; ++t) a.ph[z].run[t] = 1 << 4;         // default: every tap its own run
-    for (int t = 0; t < p.ntaps;) {                // maximal runs of <= 3 taps with equal dy and dx stepping by +1 or -1
+    // maximal runs of <= 3 taps with equal dy whose dx step by one CELL of the row grid (+-in_sx input pixels: a stride-2 launch
+    // pairs the taps of one parity, igemm.py orders them so); shift = cells behind the run's first pixel
+    for (int t = 0; t < p.ntaps;) {
       int len = 1, dir = 0;
       while (len < 3 && t + len < p.ntaps && p.dy[t + len] == p.dy[t]) {
         const int step = p.dx[t + len] - p.dx[t + len - 1];
-        if ((step != 1 && step != -1) || (dir && step != dir)) break;
+        if ((step != d->in_sx && step != -d->in_sx) || (dir && step != dir)) break;
         dir = step;
         ++len;
       }
       int dmin = p.dx[t];
       for (int i = 1; i < len; ++i) dmin = p.dx[t + i] < dmin ? p.dx[t + i] : dmin;
-      for (int i = 0; i < len; ++i) a.ph[z].run[t + i] = (p.dx[t + i] - dmin) | (i << 2) | (len << 4);
+      for (int i = 0; i < len; ++i) a.ph[z].run[t + i] = ((p.dx[t + i] - dmin) / d->in_sx) | (i << 2) | (len << 4);
       t += len;
     }
   }
@@ -1196,7 +1198,7 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
     if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "igemm (direct 3 x 3): %s", hipGetErrorString(e));
     return ufr::launched("igemm_d33_kernel");
   }
-  if (variant == 7 && d->k_order && d->in_sx == 1 && d->Wr >= 22) {
+  if (variant == 7 && d->k_order && (d->in_sx == 1 || d->in_sx == 2) && d->Wr >= 22) {
     // ping-pong + horizontal runs of taps staged once (launches it does not cover fall through to the plain forms)
     const dim3 gpp(d->Npad / bn, (unsigned)((M + 255) / 256), nz);
     if (bn == BN) igemm_pp3_kernel<128><<<gpp, 512, pp3_lds_bytes(128), st>>>(a);

@@ -168,6 +168,12 @@ def conv_forward_weights(weight: torch.Tensor, stride: int, padding, dilation: i
     w = weight.detach().float()
     mat = w.permute(0, 2, 3, 1).reshape(N, kh * kw, Cn)
     taps = [(ky * dilation - ph, kx * dilation - pw) for ky in range(kh) for kx in range(kw)]
+    if stride == 2 and dilation == 1 and kw >= 3:
+        # a stride-2 row reads every other input pixel: the taps of one kernel row whose dx have the same parity read the SAME
+        # pixel sequence shifted by whole cells, so they sit next to each other in K (dx = -2, 0, 2 | -1, 1 for a 5 x 5) and the
+        # tap-reuse form (csrc/igemm.hip variant 7) stages each parity's pixels once per kernel row
+        order = [ky * kw + kx for ky in range(kh) for par in (0, 1) for kx in range(kw) if (kx - pw) % 2 == par]
+        mat, taps = mat[:, order], [taps[i] for i in order]
     planes, offsets, N, npad, KC, cr = _pack([mat], weight.device)
     return WeightImage(planes, offsets, [(0, 0, taps)], N, npad, KC, dict(in_s=stride, out_s=1), cr)
 
