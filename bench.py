@@ -103,7 +103,7 @@ def event_time(fn, iters, warm=2):
 
 
 # PMC summaries of the latest passes over this command (tools/gpu_call.sh `traffic` step -> tools/pmc_step_traffic.py)
-IGEMM_TRAFFIC, STEP_TRAFFIC, CORR_TRAFFIC = "r4_igemm_traffic.json", "r4_step_traffic.json", "r4_corr_planes_traffic.json"
+IGEMM_TRAFFIC, STEP_TRAFFIC, CORR_TRAFFIC = "r5_igemm_traffic.json", "r5_step_traffic.json", "r4_corr_planes_traffic.json"
 
 
 def _pmc(name):
