@@ -216,7 +216,7 @@ def kernel_rooflines(step, device, max_count):
     ks.append(dict(kernel=name, ms=round(t_w, 4), bound="hbm",
                    achieved=round(bytes_w / t_w / 1e6, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                    frac=round(bytes_w / t_w / 1e6 / PEAK_HBM_GBS, 4), tflops=round(GFLOP_CORR_BWD_WINDOW * B / t_w, 2),
-                   traffic=_pmc("r4_corr_window_traffic.json").get("traffic_bytes"), algorithmic_bytes=int(bytes_w)))
+                   traffic=_pmc("r5_corr_window_traffic.json").get("traffic_bytes"), algorithmic_bytes=int(bytes_w)))
     # ---- the 2-channel layers of the refinement (HBM-bound: one pass over the concatenation's planes)
     if eng is not None:
         for k in (6, 5, 4, 3, 2):

@@ -45,8 +45,14 @@ __global__ __launch_bounds__(256) void corr_bwd_window_mfma_kernel(
   constexpr int CS = 16 / (4 * TPW);              // channel splits over blockIdx.y
   __shared__ __attribute__((aligned(16))) __bf16 As[2][NR][3][16 * AST];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = blockIdx.z, adj = blockIdx.y / CS, cs = blockIdx.y - adj * CS;
-  const int pr = blockIdx.x & 1, ly0 = pr + 2 * (blockIdx.x >> 1) * NR;         // window rows ly0 + 2 r
+  // The 64 workgroups of one frame pair (8 row groups x 2 adjoints x 4 channel quarters) read the same 56 x 64 feature region and the same
+  // band of cost-volume gradients.  In launch order (x fastest) consecutive workgroups go round-robin to the 8 XCDs, so EVERY XCD's L2
+  // fetched EVERY pair's region: 214 MB of HBM traffic for 72 MB of operands (profiles/r4_corr_window_traffic.json).  The launch index is
+  // re-dealt pair-fastest instead: with 8 pairs, pair n lives on XCD n and its region crosses the fabric once.
+  const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int n = lin % B, rest = lin / B, bx = rest % (int)gridDim.x, by = rest / (int)gridDim.x;
+  const int adj = by / CS, cs = by - adj * CS;
+  const int pr = bx & 1, ly0 = pr + 2 * (bx >> 1) * NR;                         // window rows ly0 + 2 r
   const int* w = win + n * 8;
   const int y0 = min(max(w[0] / level_stride, 0), H - wh), x0 = min(max(w[1] / level_stride, 0), W - ww);
   const int xb = ((x0 - 2 * WR) >> 2) << 2;       // first source column of the K range (floor to 4; may be negative)
