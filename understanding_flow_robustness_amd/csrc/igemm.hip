@@ -1145,7 +1145,11 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
     nz += a.sk[z];
   }
   hipStream_t st = ufr::as_stream(stream);
-  const int bn = d->Npad % BN == 0 ? BN : 64;        // 64-column tiles where a 128-column tile would be mostly padding
+  // 64-column tiles where a 128-column tile would be mostly padding.  (64-column tiles ON REQUEST for launches whose columns are a
+  // multiple of 128 -- twice the workgroups per split-K slice, so half the slabs on RAFT's 48 x 160 grids -- won the cold per-launch
+  // sweep on the four GRU launches by 3 - 15 % and LOST inside the step: 16.18 ms against 16.02 / 16.02 with the table without them,
+  // same call, gpurun r5_call30.  Removed.)
+  const int bn = d->Npad % BN == 0 ? BN : 64;
   const dim3 grid(d->Npad / bn, (unsigned)((M + BM - 1) / BM), nz);
   // kernel forms: 0 / 2 = single-stage LDS-DMA tiles (128 x 128, or 128 x 64 where Npad is not a multiple of 128),
   // 4 = 64 x 128 tiles (four workgroups per CU), 5 = pipelined 128 x 128, 6 = ping-pong 256 x 128 (128-column launches only;
@@ -1153,7 +1157,7 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   // taps staged once (256 x 128 or 256 x 64: stride-1 launches with >= 22 columns, the narrow-N / long-K layers of PWC-Net)
   const int variant = d->variant ? d->variant : 2;
   UFR_REQUIRE(variant == 2 || variant == 4 || variant == 5 || variant == 6 || variant == 7 || variant == 8, "igemm: unknown kernel variant %d",
-              variant);
+              d->variant);
   UFR_REQUIRE(d->products == 6, "igemm: six products only (float32-accurate); the 3- and 1-product forms were removed");
   // activation rows through a raw buffer resource (hardware zeros outside the frame) while the planes stay below 2 GB
   const bool use_buf = 6L * d->x_plane_stride < 0x7fffffffL;

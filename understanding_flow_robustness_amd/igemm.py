@@ -347,7 +347,8 @@ def _tuning_table() -> dict:
     global _TUNING
     if _TUNING is None:
         _TUNING = {}
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "igemm_tuning.json")
+        # (UFR_IGEMM_TUNING_FILE: another table for a same-call A/B of two candidate tables)
+        path = os.environ.get("UFR_IGEMM_TUNING_FILE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "igemm_tuning.json")
         if os.environ.get("UFR_IGEMM_TUNING", "1") != "0" and os.path.exists(path):
             import json
             with open(path) as f:
