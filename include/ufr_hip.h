@@ -296,6 +296,13 @@ int ufr_raft_motion_finish(void* p1, long plane_stride1, void* p2, long plane_st
  * planes of BOTH GRU buffers come straight from the slabs (ascending sum, bias, LeakyReLU(slope), zeros in the padding, flow in 126 / 127). */
 int ufr_raft_motion_finish_slabs(const float* ws, int splitk, int Npad, int N, const float* bias, float slope, void* p1, long plane_stride1,
                                  void* p2, long plane_stride2, int chunk0, const float* flow, int B, int H, int W, ufr_stream_t stream);
+/* Round 5, the loop's small change: ufr_raft_coords_step = `coords1 += delta` (delta NULL at the loop's entry) + the copy the next
+ * lookup's adjoint reads + `flow = coords1 - coords0` (raft.py:190-228) in one kernel of n floats; ufr_grad_finalize_consume =
+ * ufr_grad_finalize on `chunks` chunks of a running sum g [chunks][M][32] that is zeroed behind the read (pointers AT the first chunk:
+ * g, plane 0 of the mask activation, plane 0 of the output planes). */
+int ufr_raft_coords_step(float* coords1, const float* delta, const float* coords0, float* saved, float* flow, long n, ufr_stream_t stream);
+int ufr_grad_finalize_consume(float* g, const void* mask_plane0, void* out, long out_plane_stride, long M, int chunks, float slope,
+                              ufr_stream_t stream);
 int ufr_gru_gates_cm_forward(float* zr, const void* h, long h_plane_stride, int h_chunk0, void* rh, long rh_plane_stride,
                              int rh_chunk0, long M, int chunks, ufr_stream_t stream);
 /* The same two kernels reading the pre-activations straight from a `no_reduce` split-K launch's slabs (columns [z | r] resp. q; the

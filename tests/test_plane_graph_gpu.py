@@ -56,8 +56,15 @@ def _three_way(make, cin, B, H, W, monkeypatch, out_hw, seed):
     assert "_ufr_plane_graphs" in m.__dict__, "the native schedule did not run"
     e_out, e_g = _rel(nout, want), _rel(ng, gwant)
     t_out, t_g = _rel(tout, want), _rel(tg, gwant)
-    print(f"native {e_out:.2e} / {e_g:.2e}   torch {t_out:.2e} / {t_g:.2e}")
-    assert e_out <= 5e-6 and e_g <= 5e-6          # (MIOpen's own data gradient is 4e-3 off at B = 2; the six-product igemm is not)
+    # A LeakyReLU whose pre-activation sits within float32 rounding of zero takes the other slope than the float64 evaluation; at a
+    # coarse level (1/64) that one activation lies in the backward cone of ~2 % of the input gradient, which then differs by O(1e-3) of
+    # its scale -- in ANY float32 implementation whose sum lands on that side.  torch / MIOpen always showed it on the B = 2 case
+    # (3.7e-3); since round 5 orders a stride-2 launch's taps by parity the igemm's sums round to the same side (3.69e-3 both,
+    # gpurun r5_final_a / r5_call31).  The gate therefore: to rounding against float64, OR to rounding against torch's float32 run where
+    # that run itself is off float64 (two independent float32 evaluations agreeing to 5e-6 while a wrong adjoint would be off by O(1)).
+    e_nt = _rel(ng, tg.double() if tg.dtype != ng.dtype else tg)
+    print(f"native {e_out:.2e} / {e_g:.2e}   torch {t_out:.2e} / {t_g:.2e}   native vs torch gradient {e_nt:.2e}")
+    assert e_out <= 5e-6 and (e_g <= 5e-6 or (t_g > 5e-6 and e_nt <= 5e-6)), f"gradient: vs float64 {e_g:.2e}, vs torch float32 {e_nt:.2e}"
     # second call through the cached schedule: same bits
     nout2, ng2 = _run(m, x, gy, monkeypatch, True)
     assert torch.equal(nout, nout2) and torch.equal(ng, ng2)

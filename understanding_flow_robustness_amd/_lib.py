@@ -172,6 +172,8 @@ SIGNATURES = {
     "ufr_raft_flow_patches": [_vp, _vp, _l, _i, _i, _i, _i, _vp],
     "ufr_raft_motion_finish_slabs": [_vp, _i, _i, _i, _vp, _f, _vp, _l, _vp, _l, _i, _vp, _i, _i, _i, _vp],
     "ufr_raft_motion_finish": [_vp, _l, _vp, _l, _i, _vp, _i, _i, _i, _vp],
+    "ufr_raft_coords_step": [_vp, _vp, _vp, _vp, _vp, _l, _vp],
+    "ufr_grad_finalize_consume": [_vp, _vp, _vp, _l, _l, _i, _f, _vp],
     "ufr_gru_gates_cm_forward": [_vp, _vp, _l, _i, _vp, _l, _i, _l, _i, _vp],
     "ufr_gru_gates_cm_forward_slabs": [_vp, _i, _i, _vp, _vp, _vp, _vp, _l, _i, _vp, _l, _i, _l, _i, _vp],
     "ufr_gru_blend_cm_forward_slabs": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp, _l, _i, _l, _i, _vp],

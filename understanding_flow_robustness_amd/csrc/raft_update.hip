@@ -299,7 +299,55 @@ __global__ void gates_bwd_kernel(const float* __restrict__ zr, const __bf16* __r
   }
 }
 
+// coords1 (+)= delta; the copy the lookup's adjoint of the NEXT iteration reads; flow = coords1 - coords0 (raft.py:190-228: `coords1 =
+// coords1 + delta_flow`, then `coords1.detach()` and `flow = coords1 - coords0` at the top of the next iteration): three torch kernels
+// (add_, clone, sub) in one.  delta == nullptr: the loop's entry (coords1 as it stands).
+__global__ void coords_step_kernel(float* __restrict__ coords1, const float* __restrict__ delta, const float* __restrict__ coords0,
+                                   float* __restrict__ saved, float* __restrict__ flow, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float c = coords1[i];
+    if (delta) {
+      c += delta[i];
+      coords1[i] = c;
+    }
+    saved[i] = c;
+    flow[i] = c - coords0[i];
+  }
+}
+
+// grad_finalize (plane_layout.hip) on a running sum that is CONSUMED: planes = split(g * ReLU'(mask)) and g := 0 for the next adder
+__global__ void finalize_consume_kernel(float* __restrict__ g, const __bf16* __restrict__ mask, long ms, __bf16* __restrict__ out, long os,
+                                        long n8, float slope) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n8; t += (long)gridDim.x * blockDim.x) {
+    const long e = t * 8;
+    float v[8];
+    load_f8(g + e, v);
+    const bf16x8 m = *reinterpret_cast<const bf16x8*>(mask + e);
+    (void)ms;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = ((float)m[j] > 0.f) ? v[j] : v[j] * slope;
+    store_planes8(out + e, os, v);
+    const float zero[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    store_f8(g + e, zero);
+  }
+}
+
 }  // namespace
+
+extern "C" int ufr_raft_coords_step(float* coords1, const float* delta, const float* coords0, float* saved, float* flow, long n,
+                                    ufr_stream_t stream) {
+  UFR_REQUIRE(coords1 && coords0 && saved && flow && n > 0, "raft coords step: bad argument");
+  coords_step_kernel<<<ufr::stream_grid(n, 256), 256, 0, ufr::as_stream(stream)>>>(coords1, delta, coords0, saved, flow, n);
+  return ufr::launched("coords_step_kernel");
+}
+
+extern "C" int ufr_grad_finalize_consume(float* g, const void* mask_plane0, void* out, long out_plane_stride, long M, int chunks, float slope,
+                                         ufr_stream_t stream) {
+  UFR_REQUIRE(g && mask_plane0 && out && M > 0 && chunks > 0 && out_plane_stride > 0, "grad finalize (consume): bad argument");
+  finalize_consume_kernel<<<ufr::stream_grid((long)chunks * M * 4, 256), 256, 0, ufr::as_stream(stream)>>>(
+      g, static_cast<const __bf16*>(mask_plane0), 0, static_cast<__bf16*>(out), out_plane_stride, (long)chunks * M * 4, slope);
+  return ufr::launched("finalize_consume_kernel");
+}
 
 extern "C" int ufr_raft_flow_patches(const float* flow, void* planes, long plane_stride, int chunk0, int B, int H, int W,
                                      ufr_stream_t stream) {

@@ -121,6 +121,7 @@ class RaftUpdateEngine:
         ys, xs = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing="ij")
         self.coords0.copy_(torch.stack((xs, ys), dim=0).float()[None].expand(B, -1, -1, -1))     # utils/utils.py:80-83
         self.coords1 = torch.zeros(B, 2, h, w, **f32)
+        self.coords_it = [torch.zeros(B, 2, h, w, **f32) for _ in range(IT + 1)]   # coords1 at the top of iteration it (the lookups' adjoints read them)
         self.flow_lr = torch.zeros(B, 2, h, w, **f32)
         self.up_mask = torch.zeros(B, 576, h, w, **f32)
         # ---- gradients
@@ -314,11 +315,12 @@ class RaftUpdateEngine:
         self.coords1.copy_(self.coords0)
         if flow_init is not None:
             self.coords1.add_(flow_init)
-        self._coords = []
+        self._coords = self.coords_it
+        n_coords = self.coords1.numel()
+        L.check(lib.ufr_raft_coords_step(L.ptr(self.coords1), None, L.ptr(self.coords0), L.ptr(self.coords_it[0]), L.ptr(self.flows[0]),
+                                         n_coords, st()), "coords step")
         for it in range(IT):
-            coords = self.coords1.clone()                             # (the adjoint of this iteration's lookup reads them)
-            self._coords.append(coords)
-            torch.sub(coords, self.coords0, out=self.flows[it])
+            coords = self.coords_it[it]                               # (the adjoint of this iteration's lookup reads them)
             with self._fork() as on_side:                             # the flow branch: no adjoint, nothing of the lookup in it
                 with on_side:
                     L.check(lib.ufr_raft_flow_patches(L.ptr(self.flows[it]), L.ptr(self.fpat.t), self.fpat.plane_stride, 0, B, h, w, st()),
@@ -364,12 +366,14 @@ class RaftUpdateEngine:
             L.check(lib.ufr_flow_head_planes_forward_mfma(L.ptr(self.FH.t), self.FH.plane_stride, 0, 8, L.ptr(self.fh2_wm), self.fh2_wm.shape[0],
                                                           L.ptr(self.fh2_b),
                                                           L.ptr(self.delta), B, h, w, st()), "delta_flow")
-            self.coords1.add_(self.delta)
+            # coords1 += delta_flow, the next iteration's copy and flow = coords1 - coords0 in one kernel (it == IT - 1: into the spare slot)
+            nxt_flow = self.flows[it + 1] if it + 1 < IT else self.flow_lr
+            L.check(lib.ufr_raft_coords_step(L.ptr(self.coords1), L.ptr(self.delta), L.ptr(self.coords0), L.ptr(self.coords_it[it + 1]),
+                                             L.ptr(nxt_flow), n_coords, st()), "coords step")
         self.launch[("mask1",)]()
         self.launch[("mask2",)]()
         self.mask_f32.to_nchw(576, 0, scale=0.25, slope=1.0, out=self.up_mask)
-        torch.sub(self.coords1, self.coords0, out=self.flow_lr)
-        return self.flow_lr, self.up_mask
+        return self.flow_lr, self.up_mask                             # (flow_lr = coords1 - coords0: the last coords step wrote it)
 
     @torch.no_grad()
     def backward(self, g_flow: torch.Tensor, g_mask: torch.Tensor | None):
@@ -411,9 +415,9 @@ class RaftUpdateEngine:
             # ends in the feature maps' gradients, the GRU adjoint of the next (earlier) iteration does not wait for it
             if pending is not None:
                 pending.join()                                         # (its buffers -- gz_mot .. g_corr -- are about to be rewritten)
-            L.check(lib.ufr_grad_finalize(_ptr(self.TA, HC), 0, L.ptr(self.P1[it].t), HC, L.ptr(self.gz_mot.t), self.gz_mot.plane_stride,
-                                          0, M, HC, 0.0, st()), "motion finalize")
-            self.TA.t[HC:2 * HC].zero_()                               # the next iteration's motion gradient starts from zero
+            # (the next iteration's motion gradient starts from zero: the finalize kernel leaves zeros behind its read)
+            L.check(lib.ufr_grad_finalize_consume(_ptr(self.TA, HC), C.c_void_p(self.P1[it].t.data_ptr() + HC * M * 32 * 2), L.ptr(self.gz_mot.t),
+                                                  self.gz_mot.plane_stride, M, HC, 0.0, st()), "motion finalize")
             pending = self._fork()
             with pending.start():
                 for name in ("conv^T", "convc2^T", "convc1^T"):
