@@ -99,6 +99,12 @@ int ufr_altcorr_pyramid_forward(const float* fmap1, const ufr_altcorr_levels* le
 int ufr_altcorr_pyramid_backward(const float* fmap1, const ufr_altcorr_levels* levels, const float* coords, const float* grad_out,
                                  float* fmap1_grad, void* workspace, int B, int H1, int W1, int C, int radius, float scale,
                                  int accumulate, ufr_stream_t stream);
+/* The same with the cost volume's gradient as the update engine holds it (round 5): chunk-major float32 [chunks][B*H1*W1][32], channel
+ * o = level * (2r+1)^2 + window point at chunk o / 32, lane o % 32 -- no conversion pass to NCHW between the motion encoder's adjoint and
+ * the lookup's. */
+int ufr_altcorr_pyramid_backward_cm(const float* fmap1, const ufr_altcorr_levels* levels, const float* coords, const float* grad_out_cm,
+                                    float* fmap1_grad, void* workspace, int B, int H1, int W1, int C, int radius, float scale,
+                                    int accumulate, ufr_stream_t stream);
 long ufr_altcorr_pyramid_workspace_bytes(int B, int H1, int W1, int C, int radius, int num_levels);
 
 /* ---- RAFT all-pairs pyramid lookup -----------------------------------------------------------

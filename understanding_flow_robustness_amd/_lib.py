@@ -182,6 +182,7 @@ SIGNATURES = {
     "ufr_gru_gates_cm_backward": [_vp, _vp, _l, _i, _vp, _vp, _vp, _l, _i, _vp, _l, _i, _i, _vp, _vp],
     "ufr_altcorr_pyramid_forward": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
     "ufr_altcorr_pyramid_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "ufr_altcorr_pyramid_backward_cm": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "ufr_upfeat_planes_forward_mfma": [_vp, _l, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
     "ufr_upfeat_planes_backward": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ufr_flow_up_planes_forward": [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp],

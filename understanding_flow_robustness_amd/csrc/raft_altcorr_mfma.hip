@@ -175,7 +175,7 @@ template <int R>
 __global__ __launch_bounds__(64) void altcorr_prepass(const AcLevels lv, const float* __restrict__ coords, int planar,
                                                       const float* __restrict__ gout, float* __restrict__ gs_all,
                                                       int* __restrict__ win, int* __restrict__ boxes, int B, int H1, int W1,
-                                                      float scale) {
+                                                      float scale, int gout_cm) {
   constexpr int rd = 2 * R + 1, gd = rd + 1, npt = gd * gd;
   __shared__ float dxs[AC_TP], dys[AC_TP];
   const int tiles_x = (W1 + AC_TP - 1) / AC_TP, ntiles = B * H1 * tiles_x;
@@ -208,17 +208,25 @@ __global__ __launch_bounds__(64) void altcorr_prepass(const AcLevels lv, const f
     }
   }
   __syncthreads();
+  // the cost volume's gradient: NCHW [B, L * rd * rd, H1, W1], or (gout_cm: the update engine's gradient sum as it lies, no
+  // conversion pass in between) chunk-major float32 [chunks][B * H1 * W1][32] with channel o at chunk o / 32, lane o % 32
   const size_t gbase = (((size_t)b * lv.n + l) * rd * rd) * plane + (size_t)h1 * W1;
+  const size_t prow = (size_t)b * plane + (size_t)h1 * W1;
   for (int t = tid; t < AC_TP * npt; t += 64) {
     const int i = t & 15, pt = t >> 4, iy = pt / gd, ix = pt - iy * gd;
     if (w0 + i >= W1) continue;
     const float* gp = gout + gbase + w0 + i;
+    auto G = [&](int ol) -> float {
+      if (!gout_cm) return gp[plane * ol];
+      const int o = l * rd * rd + ol;
+      return gout[((size_t)(o >> 5) * npix + prow + w0 + i) * 32 + (o & 31)];
+    };
     const float dx = dxs[i], dy = dys[i];
     float g = 0.f;
-    if (iy > 0 && ix > 0)   g += gp[plane * ((iy - 1) + rd * (ix - 1))] * dy * dx;
-    if (iy > 0 && ix < rd)  g += gp[plane * ((iy - 1) + rd * ix)] * dy * (1 - dx);
-    if (iy < rd && ix > 0)  g += gp[plane * (iy + rd * (ix - 1))] * (1 - dy) * dx;
-    if (iy < rd && ix < rd) g += gp[plane * (iy + rd * ix)] * (1 - dy) * (1 - dx);
+    if (iy > 0 && ix > 0)   g += G((iy - 1) + rd * (ix - 1)) * dy * dx;
+    if (iy > 0 && ix < rd)  g += G((iy - 1) + rd * ix) * dy * (1 - dx);
+    if (iy < rd && ix > 0)  g += G(iy + rd * (ix - 1)) * (1 - dy) * dx;
+    if (iy < rd && ix < rd) g += G(iy + rd * ix) * (1 - dy) * (1 - dx);
     gs_all[((size_t)l * npix + (size_t)b * plane + (size_t)h1 * W1 + w0 + i) * npt + pt] = g * scale;
   }
 }
@@ -445,7 +453,7 @@ long workspace_bytes(int B, int H1, int W1, int C, int radius, int levels) {
 
 template <int R, int CPG>
 int launch_bwd(const float* f1, AcLevels lv, const float* coords, int planar, const float* gout, float* g1, void* workspace, int B,
-               int H1, int W1, float scale, int accumulate, hipStream_t st) {
+               int H1, int W1, float scale, int accumulate, hipStream_t st, int gout_cm = 0) {
   constexpr int C = 4 * CPG, npt = (2 * R + 2) * (2 * R + 2);
   const int tiles_b = H1 * ((W1 + AC_TP - 1) / AC_TP);
   const long npix = (long)B * H1 * W1;
@@ -456,7 +464,7 @@ int launch_bwd(const float* f1, AcLevels lv, const float* coords, int planar, co
   ws.boxes = ws.win + (long)lv.n * npix * 2;
   ws.boxes += (4 - ((reinterpret_cast<uintptr_t>(ws.boxes) / 4) & 3)) & 3;            // 16-byte aligned rows
   const int tiles_pad = (B * H1 + 7) / 8 * 8 * (tiles_b / H1);                 // rows padded to a multiple of 8: see xcd_row_tile
-  altcorr_prepass<R><<<dim3(tiles_pad, lv.n), 64, 0, st>>>(lv, coords, planar, gout, ws.gs_all, ws.win, ws.boxes, B, H1, W1, scale);
+  altcorr_prepass<R><<<dim3(tiles_pad, lv.n), 64, 0, st>>>(lv, coords, planar, gout, ws.gs_all, ws.win, ws.boxes, B, H1, W1, scale, gout_cm);
   int rc = ufr::launched("altcorr_prepass");
   if (rc != UFR_OK) return rc;
   altcorr_mfma_bwd1<R, CPG><<<dim3(tiles_pad, lv.n), 256, 0, st>>>(lv, ws.gs_all, ws.win, ws.boxes, ws.part, B, H1, W1);
@@ -517,17 +525,17 @@ int ufr_altcorr_mfma_forward(const float* f1, const ufr_altcorr_levels* lv_in, c
 
 int ufr_altcorr_mfma_backward(const float* f1, const ufr_altcorr_levels* lv_in, const float* coords, int planar, const float* gout,
                               float* g1, void* workspace, int B, int H1, int W1, int C, int radius, float scale, int accumulate,
-                              hipStream_t st) {
+                              hipStream_t st, int gout_cm) {
   AcLevels lv{};
   lv.n = lv_in->num_levels;
   for (int l = 0; l < lv.n; ++l) {
     lv.f2[l] = lv_in->fmap2[l]; lv.g2[l] = lv_in->fmap2_grad[l]; lv.H2[l] = lv_in->H2[l]; lv.W2[l] = lv_in->W2[l];
     lv.cscale[l] = lv_in->coord_scale[l];
   }
-  if (C == 256 && radius == 4) return launch_bwd<4, 64>(f1, lv, coords, planar, gout, g1, workspace, B, H1, W1, scale, accumulate, st);
-  if (C == 128 && radius == 4) return launch_bwd<4, 32>(f1, lv, coords, planar, gout, g1, workspace, B, H1, W1, scale, accumulate, st);
-  if (C == 256 && radius == 3) return launch_bwd<3, 64>(f1, lv, coords, planar, gout, g1, workspace, B, H1, W1, scale, accumulate, st);
-  return launch_bwd<3, 32>(f1, lv, coords, planar, gout, g1, workspace, B, H1, W1, scale, accumulate, st);
+  if (C == 256 && radius == 4) return launch_bwd<4, 64>(f1, lv, coords, planar, gout, g1, workspace, B, H1, W1, scale, accumulate, st, gout_cm);
+  if (C == 128 && radius == 4) return launch_bwd<4, 32>(f1, lv, coords, planar, gout, g1, workspace, B, H1, W1, scale, accumulate, st, gout_cm);
+  if (C == 256 && radius == 3) return launch_bwd<3, 64>(f1, lv, coords, planar, gout, g1, workspace, B, H1, W1, scale, accumulate, st, gout_cm);
+  return launch_bwd<3, 32>(f1, lv, coords, planar, gout, g1, workspace, B, H1, W1, scale, accumulate, st, gout_cm);
 }
 
 bool ufr_altcorr_mfma_serves(int C, int radius) { return mfma_form_serves(C, radius); }
@@ -551,7 +559,19 @@ extern "C" int ufr_altcorr_pyramid_backward(const float* fmap1, const ufr_altcor
   for (int l = 0; l < levels->num_levels; ++l)
     UFR_REQUIRE(levels->fmap2[l] && levels->fmap2_grad[l] && levels->H2[l] > 0 && levels->W2[l] > 0, "altcorr pyramid backward: bad level %d", l);
   return ufr_altcorr_mfma_backward(fmap1, levels, coords, 1, grad_out, fmap1_grad, workspace, B, H1, W1, C, radius, scale, accumulate,
-                                   ufr::as_stream(stream));
+                                   ufr::as_stream(stream), 0);
+}
+
+extern "C" int ufr_altcorr_pyramid_backward_cm(const float* fmap1, const ufr_altcorr_levels* levels, const float* coords,
+                                               const float* grad_out_cm, float* fmap1_grad, void* workspace, int B, int H1, int W1, int C,
+                                               int radius, float scale, int accumulate, ufr_stream_t stream) {
+  UFR_REQUIRE(fmap1 && levels && coords && grad_out_cm && fmap1_grad && workspace, "altcorr pyramid backward (chunk-major): null pointer");
+  UFR_REQUIRE(B > 0 && H1 > 0 && W1 > 0 && levels->num_levels >= 1 && levels->num_levels <= 4, "altcorr pyramid backward (chunk-major): bad shape");
+  UFR_REQUIRE(mfma_form_serves(C, radius), "altcorr pyramid backward (chunk-major): C must be 128 or 256 and the radius 3 or 4 (got %d, %d)", C, radius);
+  for (int l = 0; l < levels->num_levels; ++l)
+    UFR_REQUIRE(levels->fmap2[l] && levels->fmap2_grad[l] && levels->H2[l] > 0 && levels->W2[l] > 0, "altcorr pyramid backward (chunk-major): bad level %d", l);
+  return ufr_altcorr_mfma_backward(fmap1, levels, coords, 1, grad_out_cm, fmap1_grad, workspace, B, H1, W1, C, radius, scale, accumulate,
+                                   ufr::as_stream(stream), 1);
 }
 
 extern "C" long ufr_altcorr_pyramid_workspace_bytes(int B, int H1, int W1, int C, int radius, int num_levels) {

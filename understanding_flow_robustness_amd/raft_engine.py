@@ -291,7 +291,8 @@ class RaftUpdateEngine:
         lib, B, h, w = L.lib(), self.B, self.h, self.w
         if src["alt"]:
             lv = self._alt_levels(src["f2"], src["g_f2"])
-            L.check(lib.ufr_altcorr_pyramid_backward(L.ptr(src["f1"]), C.byref(lv), L.ptr(coords), L.ptr(self.g_corr), L.ptr(src["g_f1"]),
+            # (the cost volume's gradient is read as convc1^T left it, chunk-major: no NCHW copy in between)
+            L.check(lib.ufr_altcorr_pyramid_backward_cm(L.ptr(src["f1"]), C.byref(lv), L.ptr(coords), L.ptr(self.G_corr.t), L.ptr(src["g_f1"]),
                                                      L.ptr(src["ws"]), B, h, w, src["f1"].shape[3], self.radius, src["scale"],
                                                      0 if first else 1, L.stream()), "alt_corr backward")
         else:
@@ -422,7 +423,8 @@ class RaftUpdateEngine:
             with pending.start():
                 for name in ("conv^T", "convc2^T", "convc1^T"):
                     self.launch[(name, it)]()
-                self.G_corr.to_nchw(self.cor_planes, 0, slope=1.0, out=self.g_corr)
+                if not src["alt"]:                                     # (alt_corr's adjoint reads the chunk-major sum itself)
+                    self.G_corr.to_nchw(self.cor_planes, 0, slope=1.0, out=self.g_corr)
                 self._lookup_backward(src, self._coords[it], first=(it == IT - 1))
         if pending is not None:
             pending.join()
