@@ -360,42 +360,43 @@ class FlowNet2(nn.Module):
         diff = x[:, :3] - resampled
         return torch.cat((x, resampled, flow / self.div_flow, self.channelnorm(diff)), dim=1)
 
+    def _forward_fused(self, x1, x2):
+        """The native path (frozen parameters, HIP float32, sides multiples of 64): the sub-networks strung together by the fused
+        Functions of fn2_glue.py / csrc/fn2_glue.hip instead of ~20 torch operators per stage, FlowNet-SD on a second HIP stream."""
+        from ..fn2_glue import fusion_input, normalize_pair, upscale4, warp_stage
+        x = normalize_pair(x1, x2, self._mean64.reshape(-1))               # :93-96, :124-125 in one pass (bit-exact)
+        fork = os.environ.get("UFR_FN2_BRANCH_STREAM", "1") != "0"
+        main, side = torch.cuda.current_stream(x.device), _branch_stream(x.device)
+        sd = lambda: upscale4(self.flownets_d(x)[0], False, self.div_flow, divide=True)     # sic: divided (:176); nearest x4
+        # every sub-network's flow is read at once by `upscale4` / the next stage and kept by nobody: the engines hand over aliases
+        # of their static buffers instead of clones (`_lib.static_handoff`); the fusion network's result goes to the caller and is
+        # cloned as ever
+        with _L.static_handoff():
+            if fork:                                                       # (why a second stream: see forward())
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    flow_sd = sd()
+            flow_c = upscale4(self.flownetc(x)[0], True, self.div_flow)    # == interpolate(flow * div_flow, x4, bilinear)
+            flow_s1 = upscale4(self.flownets_1(warp_stage(x, flow_c, self.div_flow))[0], True, self.div_flow)
+            flow_s2 = upscale4(self.flownets_2(warp_stage(x, flow_s1, self.div_flow))[0], False, self.div_flow)
+            if fork:
+                main.wait_stream(side)
+                flow_sd.record_stream(main)
+            else:
+                flow_sd = sd()
+        return self.flownetfusion(fusion_input(x, flow_sd, flow_s2))
+
     def forward(self, x1, x2):
-        if x1.is_cuda and x1.dtype == torch.float32 and _L.engine_refusal(self, x1, 64) is None and os.environ.get("UFR_FN2_GLUE", "1") != "0":
-            from ..fn2_glue import normalize_pair
-            x = normalize_pair(x1, x2, self._mean64.reshape(-1))   # :93-96, :124-125 in one pass (bit-exact)
-        else:
-            x1 = (x1.double() - self._mean64).float()              # :93-96, :124-125
-            x2 = (x2.double() - self._mean64).float()
-            x = torch.cat((x1, x2), dim=1)
+        if (x1.is_cuda and x1.dtype == torch.float32 and _L.engine_refusal(self, x1, 64) is None
+                and os.environ.get("UFR_FN2_GLUE", "1") != "0"):
+            return self._forward_fused(x1, x2)
+        # the torch spelling of flownet2_models.py:122-205 (UFR_FN2_GLUE=0 keeps it on the native path too: the yardstick of
+        # tests/test_fn2_glue_gpu.py)
+        x1 = (x1.double() - self._mean64).float()                  # :93-96, :124-125
+        x2 = (x2.double() - self._mean64).float()
+        x = torch.cat((x1, x2), dim=1)
         up_bl = lambda f: F.interpolate(f, scale_factor=4, mode="bilinear", align_corners=False)
         up_nn = lambda f: F.interpolate(f, scale_factor=4, mode="nearest")
-
-        # the native path strings the sub-networks together with three fused Functions (fn2_glue.py / csrc/fn2_glue.hip) instead of
-        # ~20 torch operators per stage; UFR_FN2_GLUE=0 keeps the torch spelling below (the yardstick of tests/test_fn2_glue_gpu.py)
-        glue = x.is_cuda and _L.engine_refusal(self, x, 64) is None and os.environ.get("UFR_FN2_GLUE", "1") != "0"
-        if glue:
-            from ..fn2_glue import fusion_input, upscale4, warp_stage
-            up_bl = lambda f: upscale4(f, True, self.div_flow)             # == interpolate(f * div_flow, 4, bilinear)
-            main, side = torch.cuda.current_stream(x.device), _branch_stream(x.device)
-            fork = os.environ.get("UFR_FN2_BRANCH_STREAM", "1") != "0"
-            # every sub-network's flow is read at once by `upscale4` / the next stage and kept by nobody: the engines hand over
-            # aliases of their static buffers instead of clones (`_lib.static_handoff`); the fusion network's result goes to the
-            # caller and is cloned as ever
-            with _L.static_handoff():
-                if fork:                                                   # FlowNet-SD on the second stream (see below)
-                    side.wait_stream(main)
-                    with torch.cuda.stream(side):
-                        flow_sd = upscale4(self.flownets_d(x)[0], False, self.div_flow, divide=True)
-                flow_c = up_bl(self.flownetc(x)[0])
-                flow_s1 = up_bl(self.flownets_1(warp_stage(x, flow_c, self.div_flow))[0])
-                flow_s2 = upscale4(self.flownets_2(warp_stage(x, flow_s1, self.div_flow))[0], False, self.div_flow)
-                if fork:
-                    main.wait_stream(side)
-                    flow_sd.record_stream(main)
-                else:
-                    flow_sd = upscale4(self.flownets_d(x)[0], False, self.div_flow, divide=True)
-            return self.flownetfusion(fusion_input(x, flow_sd, flow_s2))
 
         def small_displacement_branch():
             flow_sd = up_nn(self.flownets_d(x)[0] / self.div_flow)     # sic: divided (:176)
