@@ -865,24 +865,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   igemm_write_out<NPL, MT>(a, ph, acc, reinterpret_cast<float*>(lds_pp + imgA0), z, bm, bn, wrow, wcol, lane, wave);
 }
 
-// ---- direct 3 x 3 form (variant 8, round 5): stride-1 3 x 3 convolutions over FEW input chunks (KC <= 8) and / or few output
-// columns -- the full- and half-resolution layers of FlowNetFusion / FlowNetSD (6 -> 64, 11 -> 64, 82 -> 16, 64 -> 6 ... channels at
-// 448 x 1024).  On the tile forms above such a launch pads its columns to 64 and streams every activation row once per TAP from
-// L2 (nine times per chunk); with K of 9 - 36 steps it is bound by that delivery and by its own latency, not by the matrix pipe
-// (0.12 - 0.38 of the ceiling, profiles/r5_engine_launch_sweep_cold_c5.jsonl).  Here a workgroup owns a TH x 32 tile of output pixels,
-// stages the tile's (TH + 2) x 34 halo of ONE input chunk once (three planes, LDS-DMA, the same XOR swizzle keyed by the halo pixel),
-// takes all nine taps from LDS, and stages the weights three taps at a time ([3][NT * 16][32] per plane: only the column tiles the
-// launch really has, NT = 1, 2, 4 or 8 tiles of 16).  Epilogue = epilogue_store8 through an LDS transpose, as everywhere.
-template <int NT, int TH>
+// ---- direct 3 x 3 form (variant 8, round 5): stride-1 3 x 3 convolutions with at most 64 output columns -- the full- and
+// half-resolution layers of FlowNetFusion / FlowNetSD (6 -> 64, 11 -> 64, 82 -> 16, 64 -> 6 ... channels at 448 x 1024), the 64-channel
+// stage of RAFT's encoders, the 64- / 32-output convolutions of PWC-Net's decoders.  On the tile forms above such a launch pads its
+// columns to 64 and streams every activation row once per TAP from L2 (nine times per chunk); it is bound by that delivery and by its own
+// latency, not by the matrix pipe (0.12 - 0.45 of the ceiling, profiles/r5_engine_launch_sweep_cold_*.jsonl).  Here a workgroup owns a
+// 4 x 32 tile of output pixels (8 m-tiles of 16), stages the tile's 6 x 34 halo of ONE input chunk once (three planes, LDS-DMA, the same
+// XOR swizzle keyed by the halo pixel) and takes all nine taps from LDS; the WEIGHTS never touch LDS: a wave owns ONE column tile of 16
+// and keeps its nine taps x three planes of the chunk in registers (27 fragments, straight from L2), the 4 / NT waves that share a
+// column tile split the m-tiles.  LDS = the halo (40 KB): two to three workgroups per CU cover each other's waits.  Epilogue =
+// epilogue_store8 through an LDS transpose, as everywhere.  (A first form that staged the weights in LDS three taps at a time lost to
+// the tile forms at 64 columns -- its waits were exposed at one workgroup per CU -- gpurun r5_call17 - r5_call19.)
+template <int NT>
 __global__ __launch_bounds__(256) void igemm_d33_kernel(const Args a) {
-  constexpr int TW = 32, HW_ = TW + 2, HPIX = (TH + 2) * HW_, HBLK = (HPIX + 15) / 16, HROWS = HBLK * 16;
-  constexpr int MT = TH / 2, RPW = TH / 4;                          // m-tiles per wave; tile rows per wave
-  constexpr int TG = 3;                                             // taps per weight staging (NT >= 2; one column tile keeps its
-  constexpr int WROWS = NT == 1 ? 0 : TG * NT * 16;                 //  weights in registers: 27 fragments per lane, LDS = the halo only)
+  constexpr int TH = 4, TW = 32, HW_ = TW + 2, HPIX = (TH + 2) * HW_, HBLK = (HPIX + 15) / 16, HROWS = HBLK * 16;
+  constexpr int MTW = 2 * NT;                                       // m-tiles per wave: 8 per tile, dealt to the 4 / NT waves of a column tile
   extern __shared__ __attribute__((aligned(16))) __bf16 lds_d33[];
   __bf16* const sH = lds_d33;                                       // [3 planes][HROWS][32]
-  __bf16* const sW = lds_d33 + 3 * HROWS * BK;                      // [3 planes][WROWS][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nt = wave % NT, pg = wave / NT;                         // this wave's column tile and its share of the m-tiles
   const int H = a.Hi, W = a.Wi;
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
   int t;
@@ -895,13 +896,9 @@ __global__ __launch_bounds__(256) void igemm_d33_kernel(const Args a) {
   const long Min = (long)a.g.B * H * W;
   const __bf16* zero = reinterpret_cast<const __bf16*>(ufr_zero_page);
 
-  f32x4 acc[MT][NT];
+  f32x4 acc[MTW];
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // fragment geometry: m-tile m of this wave = 16 pixels of tile row wave * RPW + m / 2 starting at column 16 * (m & 1)
+  for (int m = 0; m < MTW; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int pi = lane & 15, kgrp = lane >> 4;
   for (int kc = 0; kc < a.KC; ++kc) {
     __syncthreads();                                                  // the previous chunk's fragment reads are done
@@ -915,106 +912,59 @@ __global__ __launch_bounds__(256) void igemm_d33_kernel(const Args a) {
       const __bf16* src = ok ? a.x + (long)p * a.x_plane_stride + ((long)(a.in_chunk0 + kc) * Min + ((long)b * H + gy) * W + gx) * BK + piece * 8 : zero;
       glds16(src, sH + ((long)p * HROWS + hb * 16) * BK);
     }
-    if constexpr (NT == 1) {
-      // one column tile: the chunk's weights go straight from L2 to registers (lane = (column n, 8-channel group): one 16-byte load
-      // per tap and plane) while the halo's DMA is in flight; with 40 KB of LDS three to four workgroups share a CU and cover each
-      // other's waits -- a halo + weights image of 68 KB (two per CU) ran 0.176 ms on FlowNetFusion's 82 -> 16 layer, gpurun r5_call18
-      bf16x8 wr[9][3];
-      const __bf16* wl = a.w + ph.w_off + ((long)kc * 9 * a.Npad + pi) * BK + kgrp * 8;
+    // this wave's column tile of the chunk's weights: lane = (column, 8-channel group), one 16-byte load per tap and plane
+    bf16x8 wr[9][3];
+    const __bf16* wl = a.w + ph.w_off + ((long)kc * 9 * a.Npad + nt * 16 + pi) * BK + kgrp * 8;
 #pragma unroll
-      for (int tt = 0; tt < 9; ++tt)
+    for (int tt = 0; tt < 9; ++tt)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) wr[tt][p] = *reinterpret_cast<const bf16x8*>(wl + (long)p * a.w_plane_stride + (long)tt * a.Npad * BK);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      for (int p = 0; p < 3; ++p) wr[tt][p] = *reinterpret_cast<const bf16x8*>(wl + (long)p * a.w_plane_stride + (long)tt * a.Npad * BK);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 #pragma unroll
-      for (int tt = 0; tt < 9; ++tt) {
-        const int dyx = ph.dyx[tt], dy = (int)(short)(dyx & 0xffff), dx = dyx >> 16;
-        bf16x8 fa[3][MT];
+    for (int tt = 0; tt < 9; ++tt) {
+      const int dyx = ph.dyx[tt], dy = (int)(short)(dyx & 0xffff), dx = dyx >> 16;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const int hp = (wave * RPW + (m >> 1) + dy + 1) * HW_ + 16 * (m & 1) + pi + dx + 1;
-          const int off = hp * BK + ((kgrp ^ ((hp >> 1) & 3)) << 3);
+      for (int m = 0; m < MTW; ++m) {
+        const int g = pg * MTW + m;                                   // m-tile g: tile row g >> 1, columns 16 (g & 1) ..
+        const int hp = ((g >> 1) + dy + 1) * HW_ + 16 * (g & 1) + pi + dx + 1;
+        const int off = hp * BK + ((kgrp ^ ((hp >> 1) & 3)) << 3);
+        bf16x8 fa[3];
 #pragma unroll
-          for (int p = 0; p < 3; ++p) fa[p][m] = *reinterpret_cast<const bf16x8*>(sH + p * (HROWS * BK) + off);
-        }
+        for (int p = 0; p < 3; ++p) fa[p] = *reinterpret_cast<const bf16x8*>(sH + p * (HROWS * BK) + off);
 #pragma unroll
-        for (int q = 0; q < 6; ++q)
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[q]][m], wr[tt][PROD_B[q]], acc[m][0], 0, 0, 0);
-      }
-    } else
-    for (int j = 0; j < 9 / TG; ++j) {                                // taps TG j .. TG j + TG - 1 of this chunk
-      if (j) __syncthreads();                                         // the previous group's weight reads are done
-      for (int blk = wave; blk < 3 * TG * NT; blk += 4) {             // [plane][tap][column tile]: 16 weight rows x 4 pieces per DMA
-        const int p = blk / (TG * NT), r3 = blk - p * TG * NT, tt = r3 / NT, nb = r3 - tt * NT;
-        const int row = tt * NT * 16 + nb * 16 + (lane >> 2), slot = lane & 3;
-        const int piece = slot ^ ((row >> 1) & 3);
-        const __bf16* src = a.w + ph.w_off + (long)p * a.w_plane_stride + ((long)(kc * 9 + TG * j + tt) * a.Npad + nb * 16 + (lane >> 2)) * BK + piece * 8;
-        glds16(src, sW + ((long)p * WROWS + tt * NT * 16 + nb * 16) * BK);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-#pragma unroll
-      for (int tt = 0; tt < TG; ++tt) {
-        const int dyx = ph.dyx[TG * j + tt], dy = (int)(short)(dyx & 0xffff), dx = dyx >> 16;
-        bf16x8 fa[3][MT], fb[NT][3];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const int hp = (wave * RPW + (m >> 1) + dy + 1) * HW_ + 16 * (m & 1) + pi + dx + 1;
-          const int off = hp * BK + ((kgrp ^ ((hp >> 1) & 3)) << 3);
-#pragma unroll
-          for (int p = 0; p < 3; ++p) fa[p][m] = *reinterpret_cast<const bf16x8*>(sH + p * (HROWS * BK) + off);
-        }
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const int row = tt * NT * 16 + n * 16 + pi;
-          const int off = row * BK + ((kgrp ^ ((row >> 1) & 3)) << 3);
-#pragma unroll
-          for (int p = 0; p < 3; ++p) fb[n][p] = *reinterpret_cast<const bf16x8*>(sW + p * (WROWS * BK) + off);
-        }
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-          for (int q = 0; q < 6; ++q)
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[q]][m], fb[n][PROD_B[q]], acc[m][n], 0, 0, 0);
+        for (int q = 0; q < 6; ++q) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[q]], wr[tt][PROD_B[q]], acc[m], 0, 0, 0);
       }
     }
   }
-  // ---- epilogue: the wave's MT x 16 pixels x NT x 16 columns through LDS, a lane then owns 8 consecutive channels of one pixel
-  constexpr int TS = NT * 16 + 4;
+  // ---- epilogue: the wave's MTW x 16 pixels x 16 columns through LDS, a lane then owns 8 consecutive channels of one pixel
+  constexpr int TS = 20;
   __syncthreads();
-  float* tw = reinterpret_cast<float*>(lds_d33) + wave * (MT * 16 * TS);
+  float* tw = reinterpret_cast<float*>(lds_d33) + wave * (MTW * 16 * TS);
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+  for (int m = 0; m < MTW; ++m)
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) tw[(m * 16 + kgrp * 4 + j) * TS + n * 16 + pi] = acc[m][n][j];
+    for (int j = 0; j < 4; ++j) tw[(m * 16 + kgrp * 4 + j) * TS + pi] = acc[m][j];
   __syncthreads();
-  // (the launch writes whole 32-channel chunks: the groups behind the last computed column tile leave as zeros)
-  const int G8 = max(NT * 2, a.e.Nchunks32 * 4);
-  for (int it = lane; it < MT * 16 * G8; it += 64) {
-    const int r = it / G8, g8 = it - r * G8, m = r >> 4;
-    const int y = y0 + wave * RPW + (m >> 1), x = x0 + 16 * (m & 1) + (r & 15);
+  // (the launch writes whole 32-channel chunks: with one column tile the groups behind it leave as zeros, from the same wave)
+  const int G8 = NT == 1 ? max(2, a.e.Nchunks32 * 4) : 2;
+  for (int it = lane; it < MTW * 16 * G8; it += 64) {
+    const int r = it / G8, g8 = it - r * G8, g = pg * MTW + (r >> 4);
+    const int y = y0 + (g >> 1), x = x0 + 16 * (g & 1) + (r & 15);
     if (y < H && x < W) {
       float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (g8 < NT * 2) {
+      if (g8 < 2) {
         const float4 lo = *reinterpret_cast<const float4*>(tw + r * TS + g8 * 8), hi = *reinterpret_cast<const float4*>(tw + r * TS + g8 * 8 + 4);
         v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
       }
-      epilogue_store8(a.e, ((long)b * H + y) * W + x, g8 * 8, v);
+      epilogue_store8(a.e, ((long)b * H + y) * W + x, nt * 16 + g8 * 8, v);
     }
   }
 }
 
-template <int NT, int TH>
+template <int NT>
 constexpr int d33_lds_bytes() {
-  constexpr int HROWS = (((TH + 2) * 34 + 15) / 16) * 16, stage = (3 * HROWS + (NT == 1 ? 0 : 3 * 3 * NT * 16)) * BK * 2;
-  constexpr int epi = 4 * (TH / 2) * 16 * (NT * 16 + 4) * 4;
+  constexpr int HROWS = ((6 * 34 + 15) / 16) * 16, stage = 3 * HROWS * BK * 2, epi = 4 * (2 * NT) * 16 * 20 * 4;
   return stage > epi ? stage : epi;
 }
 
@@ -1183,21 +1133,20 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
     raised[dev] = true;
   }
   // 8 = the direct 3 x 3 form: one phase of nine taps within +-1, stride 1 in and out, row grid = input grid = output grid, no band,
-  // no split, no tail / row-major output, chunk-major K order, <= 8 input chunks, <= 128 columns (anything else falls through)
+  // no split, no tail / row-major output, chunk-major K order, <= 64 columns (anything else falls through to the tile forms)
   bool d33 = variant == 8 && d->nphase == 1 && d->phase[0].ntaps == 9 && d->in_sx == 1 && d->in_sy == 1 && d->out_sx == 1 && d->out_sy == 1 &&
              d->Hr == d->Hi && d->Wr == d->Wi && d->Ho == d->Hi && d->Wo == d->Wi && !d->row_x0 && !d->in_x0 && d->splitk == 1 && !d->tail &&
-             !d->out_rowmajor && d->k_order && d->KC <= 8 && d->N <= 128;
+             !d->out_rowmajor && d->k_order && d->N <= 64;
   for (int t = 0; d33 && t < 9; ++t)
     d33 = d->phase[0].dy[t] >= -1 && d->phase[0].dy[t] <= 1 && d->phase[0].dx[t] >= -1 && d->phase[0].dx[t] <= 1;
   if (d33) {
-    const int nt = d->N <= 16 ? 1 : (d->N <= 32 ? 2 : (d->N <= 64 ? 4 : 8));
-    const int th = 4;                        // 4 x 32 tiles: halo + weights <= 80 KB for <= 64 columns, two workgroups per CU
-    const int tiles = d->B * ((d->Hi + th - 1) / th) * ((d->Wi + 31) / 32);
+    const int nt = d->N <= 16 ? 1 : (d->N <= 32 ? 2 : 4);
+    const int tiles = d->B * ((d->Hi + 3) / 4) * ((d->Wi + 31) / 32);
     hipError_t e = hipSuccess;
-#define UFR_D33(NT_, TH_)                                                                                                       \
-    e = ufr::ensure_dynamic_lds(reinterpret_cast<const void*>(igemm_d33_kernel<NT_, TH_>), d33_lds_bytes<NT_, TH_>());          \
-    if (e == hipSuccess) igemm_d33_kernel<NT_, TH_><<<tiles, 256, d33_lds_bytes<NT_, TH_>(), st>>>(a)
-    if (nt == 1) { UFR_D33(1, 4); } else if (nt == 2) { UFR_D33(2, 4); } else if (nt == 4) { UFR_D33(4, 4); } else { UFR_D33(8, 4); }
+#define UFR_D33(NT_)                                                                                                  \
+    e = ufr::ensure_dynamic_lds(reinterpret_cast<const void*>(igemm_d33_kernel<NT_>), d33_lds_bytes<NT_>());          \
+    if (e == hipSuccess) igemm_d33_kernel<NT_><<<tiles, 256, d33_lds_bytes<NT_>(), st>>>(a)
+    if (nt == 1) { UFR_D33(1); } else if (nt == 2) { UFR_D33(2); } else { UFR_D33(4); }
 #undef UFR_D33
     if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "igemm (direct 3 x 3): %s", hipGetErrorString(e));
     return ufr::launched("igemm_d33_kernel");
