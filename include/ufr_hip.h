@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define UFR_ABI_VERSION 7   /* 7: the chunk-range entries of csrc/engine_small.hip take the extents of what they walk (w_chunks / g_chunks) and refuse a range that leaves it (round 5); 6: ufr_igemm_desc gained planes_chunks / f32_first_chunk; the clock probe records 8 words (round 4); 5: ufr_igemm_desc gained out_rowmajor / out_ld; ufr_igemm_clock_probe, ufr_conv1_direct, ufr_patch_paste_placed_rect (round 4); 4: ufr_igemm_desc gained tail / tail_n0 (round 3); 3: k_order (round 2) */
+#define UFR_ABI_VERSION 8   /* 8: ufr_pwc_warp_backward_owner / _workspace_bytes (round 5); 7: the chunk-range entries of csrc/engine_small.hip take the extents of what they walk (w_chunks / g_chunks) and refuse a range that leaves it (round 5); 6: ufr_igemm_desc gained planes_chunks / f32_first_chunk; the clock probe records 8 words (round 4); 5: ufr_igemm_desc gained out_rowmajor / out_ld; ufr_igemm_clock_probe, ufr_conv1_direct, ufr_patch_paste_placed_rect (round 4); 4: ufr_igemm_desc gained tail / tail_n0 (round 3); 3: k_order (round 2) */
 
 enum { UFR_F32 = 0, UFR_F64 = 1, UFR_F16 = 2 };   /* UFR_F16: the spatial correlation only (generic kernels, float32 sums) */
 enum {
@@ -381,6 +381,14 @@ int ufr_pwc_warp_forward(const float* x, const float* flow, float* out, int B, i
                          ufr_stream_t stream);
 int ufr_pwc_warp_backward(const float* x, const float* flow, const float* grad_out, float* grad_x, float* grad_flow,
                           int B, int C, int H, int W, ufr_stream_t stream);
+/* The same adjoint without float atomics and without the zero fill (owner-computes, csrc/pwc_warp.hip): grad_x is bit-reproducible
+ * (every cell adds its contributions in the order of their source pixels) unless a cell receives more than 16 corners (a flow that
+ * compresses > 4x in both directions): the corners beyond 16 are added with float atomics afterwards.  workspace: 16-byte aligned,
+ * ufr_pwc_warp_backward_workspace_bytes(B, H, W) bytes (the sampling boxes of the 8 x 32 tiles), written and read by this call in
+ * stream order. */
+long ufr_pwc_warp_backward_workspace_bytes(int B, int H, int W);
+int ufr_pwc_warp_backward_owner(const float* x, const float* flow, const float* grad_out, float* grad_x, float* grad_flow,
+                                void* workspace, long workspace_bytes, int B, int C, int H, int W, ufr_stream_t stream);
 
 /* ---- RAFT convex upsampling ------------------------------------------------------------------------
  * replaces RAFT.upsample_flow (models/raft/raft.py:111-122): flow [N,2,H,W], mask [N,576,H,W] (9 x 8 x 8 logits

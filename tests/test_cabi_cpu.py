@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_error_channel():
     from understanding_flow_robustness_amd import _lib as L
     lib = L.lib()
-    assert lib.ufr_abi_version() == 7 == L.ABI_VERSION
+    assert lib.ufr_abi_version() == 8 == L.ABI_VERSION
     assert lib.ufr_device_count() >= 0
     # argument validation happens before any HIP call: usable without a GPU
     p = L.CorrParams(1, 1, 3, 3, 0, 0, 1, 1, 1, 1, 1, 1)

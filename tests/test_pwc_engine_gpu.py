@@ -148,9 +148,11 @@ def test_pwc_engine_step_equals_full_frame_torch_step(net, monkeypatch):
         err = float((pf - pe).abs().max())
         print(f"update {upd:.3e}, engine step vs torch step {err / upd:.2e} of it; loss {lf:.6f} / {le:.6f}")
         assert nf == ne == 1 and abs(lf - le) <= 1e-5
-        # the engine's own error is also pinned by `test_pwc_step_at_full_size_vs_cpu_oracle`: 1e-4 of the update against the CPU
-        # oracle (6e-6 measured)
-        assert 1e-3 < upd < 1.9 and err <= 1e-4 * upd, f"{err / upd:.2e} of the update"
+        # The engine's own error is pinned by `test_pwc_step_at_full_size_vs_cpu_oracle`: 1e-4 of the update against the CPU oracle
+        # (6e-6 measured).  HERE the yardstick is torch's float32 step, whose own distance from the truth is what is seen: measured
+        # 1.6e-5 .. 1.16e-4 of the update across boxes and call orders (its grid_sample adjoint scatters with float atomics), 1.02e-4
+        # once in round 5 (gpurun r5_warp2) against 8e-5 on the next box with the same engine.  2e-4: a consistency gate, not the pin.
+        assert 1e-3 < upd < 1.9 and err <= 2e-4 * upd, f"{err / upd:.2e} of the update"
 
 
 @pytest.mark.timeout(900)

@@ -48,12 +48,49 @@ def emit(kernel, config, ms, nbytes, note=""):
                           frac_of_hbm_peak=round(gbs / PEAK, 4), bound="hbm", note=note)), flush=True)
 
 
+def pwc_warp_rows(lib, g, st):
+    """PWC-Net's warp and its adjoint at config C4's four warped levels (384x1280, 8 pairs): the scatter with float atomics (round 1)
+    against the owner-computes form (round 5).  Flow = what the level's decoder sees: a smooth field of a few cells plus 0.25 of noise."""
+    B = 8
+    for k, C in ((5, 128), (4, 96), (3, 64), (2, 32)):
+        H, W = 384 >> k, 1280 >> k
+        cfg = f"PWC-Net 384x1280, {B} pairs, level {k} ({C} x {H} x {W})"
+        x, go = torch.randn(B, C, H, W, generator=g).to(DEV), torch.randn(B, C, H, W, generator=g).to(DEV)
+        up = lambda t: torch.nn.functional.interpolate(t, size=(H, W), mode="bilinear", align_corners=False)
+        flows = {"smooth": up(3 * torch.randn(B, 2, max(H // 8, 1), max(W // 8, 1), generator=g)) + 0.25 * torch.randn(B, 2, H, W, generator=g),
+                 "gentle": up(2 * torch.randn(B, 2, max(H // 24, 1), max(W // 24, 1), generator=g)),
+                 "zero": torch.zeros(B, 2, H, W)}
+        out, gx, gf = torch.empty_like(x), torch.empty_like(x), torch.empty_like(flow := flows["smooth"].to(DEV))
+        for kind in ("gentle", "zero"):
+            fl = flows[kind].to(DEV)
+            nb = int(lib.ufr_pwc_warp_backward_workspace_bytes(B, H, W))
+            ws = torch.empty((nb + 15) // 16 * 4, dtype=torch.int32, device=DEV)
+            nbytes = (3 * x.numel() + 2 * fl.numel()) * 4
+            ms = timed(lambda: L.check(lib.ufr_pwc_warp_backward(L.ptr(x), L.ptr(fl), L.ptr(go), L.ptr(gx), L.ptr(gf), B, C, H, W, st())))
+            emit(f"pwc_warp_bwd, scatter ({kind} flow)", cfg, ms, nbytes)
+            ms = timed(lambda: L.check(lib.ufr_pwc_warp_backward_owner(L.ptr(x), L.ptr(fl), L.ptr(go), L.ptr(gx), L.ptr(gf), L.ptr(ws), nb, B, C, H, W,
+                                                                       st())))
+            emit(f"pwc_warp_bwd, owner-computes ({kind} flow)", cfg, ms, nbytes)
+        nbytes = (3 * x.numel() + 2 * flow.numel()) * 4                 # x, grad_out in; grad_x out; flow in, grad_flow out
+        ms = timed(lambda: L.check(lib.ufr_pwc_warp_forward(L.ptr(x), L.ptr(flow), L.ptr(out), B, C, H, W, st())))
+        emit("pwc_warp_fwd", cfg, ms, (2 * x.numel() + flow.numel()) * 4)
+        ms = timed(lambda: L.check(lib.ufr_pwc_warp_backward(L.ptr(x), L.ptr(flow), L.ptr(go), L.ptr(gx), L.ptr(gf), B, C, H, W, st())))
+        emit("pwc_warp_bwd, scatter with float atomics (+ the zero fill)", cfg, ms, nbytes)
+        nb = int(lib.ufr_pwc_warp_backward_workspace_bytes(B, H, W))
+        ws = torch.empty((nb + 15) // 16 * 4, dtype=torch.int32, device=DEV)
+        ms = timed(lambda: L.check(lib.ufr_pwc_warp_backward_owner(L.ptr(x), L.ptr(flow), L.ptr(go), L.ptr(gx), L.ptr(gf), L.ptr(ws), nb, B, C, H, W,
+                                                                   st())))
+        emit("pwc_warp_bwd, owner-computes (the default)", cfg, ms, nbytes)
+
+
 def main():
     only_resample = "--resample-only" in sys.argv
     lib = L.lib()
     g = torch.Generator().manual_seed(0)
     rnd = lambda *s: torch.randn(*s, generator=g).to(DEV)
     st = L.stream
+    if "--warp-only" in sys.argv:
+        return pwc_warp_rows(lib, g, st)
     # ---- FlowNet2 @448x1024 (C5: one pair per GPU, and 8 pairs)
     for B in (1, 8):
         H, W = 448, 1024

@@ -128,6 +128,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=2.5)
     ap.add_argument("--layers", default="conv3_1,conv4_1")
+    ap.add_argument("--tags", default="full", help="full | band | window | prefix (comma separated): which of the engine's launch tables")
     opt = ap.parse_args()
     import bench
     from understanding_flow_robustness_amd.flownets.utils_model import fetch_model
@@ -148,12 +149,12 @@ def main():
     wanted = set(opt.layers.replace("+", ",").split(","))
     print(json.dumps(dict(sclk_idle=pm_info_sclk() or smi_sclk(), nominal_mhz=NOMINAL_MHZ)), flush=True)
     for name, kind, tag, launch, gflop in eng.launch_table():
-        if name not in wanted or tag != "full" or launch.desc.variant != 6:
+        if name not in wanted or tag not in opt.tags.replace("+", ",").split(",") or launch.desc.variant != 6:
             continue
         r = probe_launch(launch, opt.seconds)
         mhz = r["clock_hot"]["median"]
         tf = gflop / r["ms_sustained"]
-        r.update(launch=f"{name} {kind}", gflop=round(gflop, 2), tflops_sustained=round(tf, 1),
+        r.update(launch=f"{name} {kind} {tag}", splitk=launch.desc.splitk, gflop=round(gflop, 2), tflops_sustained=round(tf, 1),
                  frac_of_ceiling_at_nominal_clock=round(tf / PEAK_SPLIT6_TFLOPS, 3),
                  frac_of_ceiling_at_measured_clock=round(tf / (PEAK_SPLIT6_TFLOPS * mhz / NOMINAL_MHZ), 3))
         print(json.dumps(r), flush=True)

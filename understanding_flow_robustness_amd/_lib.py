@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UFR_HIP_LIB") or os.path.join(_HERE, "lib", "libufr_hip.so")   # UFR_HIP_LIB: another BUILD of the same library (same-box A/B of two kernels)
 UFR_F32, UFR_F64, UFR_F16 = 0, 1, 2
-ABI_VERSION = 7            # UFR_ABI_VERSION of include/ufr_hip.h these ctypes mirrors were written against
+ABI_VERSION = 8            # UFR_ABI_VERSION of include/ufr_hip.h these ctypes mirrors were written against
 _lib = None
 
 
@@ -139,6 +139,7 @@ SIGNATURES = {
     "ufr_deconv4x4s2_c2_backward_data": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "ufr_pwc_warp_forward": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_pwc_warp_backward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ufr_pwc_warp_backward_owner": [_vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp],
     "ufr_igemm": [C.POINTER(IgemmDesc), _vp],
     "ufr_flow_upscale4_forward": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "ufr_flow_upscale4_backward": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
@@ -207,6 +208,7 @@ PLAIN = {"ufr_abi_version": (C.c_int, []), "ufr_last_error": (C.c_char_p, []),
          "ufr_conv3x3_c2_workspace_floats": (C.c_long, [_i, _i, _i, _i]),
          "ufr_cm_norm_workspace_doubles": (C.c_long, [_l, _i, _i]),
          "ufr_resample2d_backward_workspace_bytes": (C.c_long, [_i, _i, _i]),
+         "ufr_pwc_warp_backward_workspace_bytes": (C.c_long, [_i, _i, _i]),
          "ufr_altcorr_pyramid_workspace_bytes": (C.c_long, [_i, _i, _i, _i, _i, _i])}
 
 

@@ -8,6 +8,8 @@ The two pyramids run as one batch of 2B images.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -29,6 +31,29 @@ def correlate(input1, input2):
     return _correlate(input1, input2, patch_size=9, dilation_patch=1)
 
 
+_WARP_WORKSPACES: dict = {}       # (device, stream, B, H, W) -> the owner-computes adjoint's table of sampling boxes
+
+
+def warp_backward(x, flo, g, gx, gf):
+    """The warp's adjoint (csrc/pwc_warp.hip): owner-computes, no float atomics, grad_x written once -- `gx` need not be zeroed.
+    UFR_PWC_WARP_OWNER=0 keeps the scatter with float atomics (the A/B switch of tests/test_pwc_warp_gpu.py).  The workspace is written
+    and read by one call in stream order: one per (stream, shape)."""
+    B, Cn, H, W = x.shape
+    lib = L.lib()
+    if os.environ.get("UFR_PWC_WARP_OWNER", "1") == "0":
+        L.check(lib.ufr_pwc_warp_backward(L.ptr(x), L.ptr(flo), L.ptr(g), L.ptr(gx), L.ptr(gf), B, Cn, H, W, L.stream()), "pwc warp backward")
+        return
+    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream, B, H, W)
+    ws = _WARP_WORKSPACES.get(key)
+    if ws is None:
+        if len(_WARP_WORKSPACES) >= 32:
+            _WARP_WORKSPACES.clear()
+        nbytes = int(lib.ufr_pwc_warp_backward_workspace_bytes(B, H, W))
+        ws = _WARP_WORKSPACES[key] = (torch.empty((nbytes + 15) // 16 * 4, dtype=torch.int32, device=x.device), nbytes)
+    L.check(lib.ufr_pwc_warp_backward_owner(L.ptr(x), L.ptr(flo), L.ptr(g), L.ptr(gx), L.ptr(gf), L.ptr(ws[0]), ws[1], B, Cn, H, W,
+                                            L.stream()), "pwc warp backward")
+
+
 class _PwcWarp(torch.autograd.Function):
     """`warp` as one kernel forward, one backward (csrc/pwc_warp.hip)."""
 
@@ -45,8 +70,8 @@ class _PwcWarp(torch.autograd.Function):
         x, flo = ctx.saved_tensors
         B, Cn, H, W = x.shape
         gx, gf = torch.empty_like(x), torch.empty_like(flo)
-        L.check(L.lib().ufr_pwc_warp_backward(L.ptr(x), L.ptr(flo), L.ptr(g.contiguous()), L.ptr(gx), L.ptr(gf), B, Cn, H, W,
-                                              L.stream()), "pwc warp backward")
+        with torch.cuda.device(x.device):
+            warp_backward(x, flo, g.contiguous(), gx, gf)
         return gx, gf
 
 

@@ -232,7 +232,7 @@ class PwcHeadEngine:
         self.g_flow = {k: Z(B, 2, k) for k in range(2, 7)}
         self.up_flow, self.up_flow_s, self.up_feat = {}, {}, {}
         self.warped, self.g_warped, self.g_c1corr = {}, {}, {}
-        self.g_upflow, self.g_upfeat, self.g_flow_s = {}, {}, {}
+        self.g_upflow, self.g_upfeat, self.g_flow_s, self.warp_ws = {}, {}, {}, {}
         self.pf_w, self.pf_wm, self.pf_b = {}, {}, {}
         self.uf_wm, self.uf_wb, self.uf_b = {}, {}, {}
         self.dec_w, self.dec_b = {}, {}
@@ -252,6 +252,9 @@ class PwcHeadEngine:
                 self.up_flow[k], self.up_flow_s[k], self.up_feat[k] = Z(B, 2, k), Z(B, 2, k), Z(B, 2, k)
                 self.warped[k] = Z(B, FEAT[k], k)
                 self.g_upflow[k], self.g_upfeat[k], self.g_flow_s[k] = Z(B, 2, k), Z(B, 2, k), Z(B, 2, k)
+                # the warp adjoint's table of sampling boxes (owner-computes, csrc/pwc_warp.hip): static like every buffer of the engine
+                nb = int(L.lib().ufr_pwc_warp_backward_workspace_bytes(B, *self.grid[k]))
+                self.warp_ws[k] = (torch.empty((nb + 15) // 16 * 4, dtype=torch.int32, device=dev), nb)
             xmap = _x_map(k)
             wbuf = {}                                                  # conv{k}_i in buffer channel order
             for i in range(5):
@@ -548,8 +551,9 @@ class PwcHeadEngine:
                                                                           *self.grid[k], st()))
             self._corr_backward(c1, self.warped[k], self.g_corr[k], self.g_c1corr[k], self.g_warped[k])
             torch.add(self.gx_c1[k], self.g_c1corr[k], out=gF[:B])
-            L.check(lib.ufr_pwc_warp_backward(L.ptr(c2), L.ptr(self.up_flow_s[k]), L.ptr(self.g_warped[k]), L.ptr(gF[B:]),
-                                              L.ptr(self.g_flow_s[k]), B, FEAT[k], *self.grid[k], st()), "warp backward")
+            L.check(lib.ufr_pwc_warp_backward_owner(L.ptr(c2), L.ptr(self.up_flow_s[k]), L.ptr(self.g_warped[k]), L.ptr(gF[B:]),
+                                                    L.ptr(self.g_flow_s[k]), L.ptr(self.warp_ws[k][0]), self.warp_ws[k][1], B, FEAT[k],
+                                                    *self.grid[k], st()), "warp backward")
             torch.add(self.gx_upflow[k], self.g_flow_s[k], alpha=FLOW_SCALE[k], out=self.g_upflow[k])
             L.check(lib.ufr_deconv4x4s2_c2_backward_data(L.ptr(self.g_upflow[k]), L.ptr(self.dec_w[k + 1]), L.ptr(self.g_flow[k + 1]), B,
                                                          *self.grid[k + 1], st()), "deconv backward")
