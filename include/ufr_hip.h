@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define UFR_ABI_VERSION 8   /* 8: ufr_pwc_warp_backward_owner / _workspace_bytes (round 5); 7: the chunk-range entries of csrc/engine_small.hip take the extents of what they walk (w_chunks / g_chunks) and refuse a range that leaves it (round 5); 6: ufr_igemm_desc gained planes_chunks / f32_first_chunk; the clock probe records 8 words (round 4); 5: ufr_igemm_desc gained out_rowmajor / out_ld; ufr_igemm_clock_probe, ufr_conv1_direct, ufr_patch_paste_placed_rect (round 4); 4: ufr_igemm_desc gained tail / tail_n0 (round 3); 3: k_order (round 2) */
+#define UFR_ABI_VERSION 8   /* 8: ufr_pwc_warp_backward_owner / _workspace_bytes, ufr_raft_normalize_pair*, ufr_raft_fmap_pyramid_* (round 5); 7: the chunk-range entries of csrc/engine_small.hip take the extents of what they walk (w_chunks / g_chunks) and refuse a range that leaves it (round 5); 6: ufr_igemm_desc gained planes_chunks / f32_first_chunk; the clock probe records 8 words (round 4); 5: ufr_igemm_desc gained out_rowmajor / out_ld; ufr_igemm_clock_probe, ufr_conv1_direct, ufr_patch_paste_placed_rect (round 4); 4: ufr_igemm_desc gained tail / tail_n0 (round 3); 3: k_order (round 2) */
 
 enum { UFR_F32 = 0, UFR_F64 = 1, UFR_F16 = 2 };   /* UFR_F16: the spatial correlation only (generic kernels, float32 sums) */
 enum {
@@ -389,6 +389,20 @@ int ufr_pwc_warp_backward(const float* x, const float* flow, const float* grad_o
 long ufr_pwc_warp_backward_workspace_bytes(int B, int H, int W);
 int ufr_pwc_warp_backward_owner(const float* x, const float* flow, const float* grad_out, float* grad_x, float* grad_flow,
                                 void* workspace, long workspace_bytes, int B, int C, int H, int W, ufr_stream_t stream);
+
+/* ---- RAFT's glue in front of the encoders and the on-the-fly correlation (csrc/raft_glue.hip) -------------------------------------
+ * ufr_raft_normalize_pair: models/raft/raft.py:128-129 `image = 2 * (image / 255.0) - 1.0` for both frames in one pass, written as the
+ * stack [2B,3,H,W] the feature encoder concatenates them to (raft.py:141); bit for bit torch's three operators.  n_each = elements of
+ * one frame tensor (a multiple of 4; 16-byte aligned tensors).  _backward: grad1 = grad_stack[:B] * 2 / 255, grad2 likewise (may be NULL).
+ * ufr_raft_fmap_pyramid_forward: models/raft/corr.py:97-105, :128-129 (AlternateCorrBlock): levels_nhwc[0] = fmap permuted to
+ * [B,H,W,C]; levels_nhwc[l] = avg_pool2d(2, 2) of level l - 1 ([B, H >> l, W >> l, C]), bit for bit torch's; 1 <= levels <= 4.
+ * _backward: grad_fmap [B,C,H,W] = the levels' gradients (NULL entries: none) through the poolings' and permutations' adjoints. */
+int ufr_raft_normalize_pair(const float* image1, const float* image2, float* stack, long n_each, ufr_stream_t stream);
+int ufr_raft_normalize_pair_backward(const float* grad_stack, float* grad1, float* grad2, long n_each, ufr_stream_t stream);
+int ufr_raft_fmap_pyramid_forward(const float* fmap, float* const* levels_nhwc, int levels, int B, int C, int H, int W,
+                                  ufr_stream_t stream);
+int ufr_raft_fmap_pyramid_backward(const float* const* grad_levels_nhwc, int levels, float* grad_fmap, int B, int C, int H, int W,
+                                   ufr_stream_t stream);
 
 /* ---- RAFT convex upsampling ------------------------------------------------------------------------
  * replaces RAFT.upsample_flow (models/raft/raft.py:111-122): flow [N,2,H,W], mask [N,576,H,W] (9 x 8 x 8 logits

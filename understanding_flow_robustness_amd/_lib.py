@@ -140,6 +140,10 @@ SIGNATURES = {
     "ufr_pwc_warp_forward": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_pwc_warp_backward": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ufr_pwc_warp_backward_owner": [_vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp],
+    "ufr_raft_normalize_pair": [_vp, _vp, _vp, _l, _vp],
+    "ufr_raft_normalize_pair_backward": [_vp, _vp, _vp, _l, _vp],
+    "ufr_raft_fmap_pyramid_forward": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "ufr_raft_fmap_pyramid_backward": [_vp, _i, _vp, _i, _i, _i, _i, _vp],
     "ufr_igemm": [C.POINTER(IgemmDesc), _vp],
     "ufr_flow_upscale4_forward": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "ufr_flow_upscale4_backward": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp],

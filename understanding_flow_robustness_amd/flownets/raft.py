@@ -83,11 +83,12 @@ class BasicEncoder(nn.Module):
         extra = None if self.norm_fn in ("instance", "batch") else f"norm_fn {self.norm_fn!r} is not instance / batch"
         return L.engine_gate(self, x, 8, extra=extra if os.environ.get("UFR_ENGINE", "1") == "1" and x.is_cuda else None)
 
-    def forward(self, x):
+    def forward(self, x, stacked=None):
+        """`stacked`: the pair already concatenated along the batch (RAFT.forward's normalised stack), instead of a torch.cat here."""
         pair = isinstance(x, (tuple, list))
         if pair:
             n = x[0].shape[0]
-            x = torch.cat(x, dim=0)
+            x = stacked if stacked is not None else torch.cat(x, dim=0)
         if self._engine_ok(x):
             from ..raft_encoder_engine import encode      # stem, residual stages and head on the native engine
             x = encode(self, x)
@@ -319,8 +320,13 @@ class RAFT(nn.Module):
 
     def forward(self, image1, image2, iters=12, flow_init=None, test_mode=False):
         iters = self.args.iters                                        # raft.py:126 (argument ignored)
-        image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
-        image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
+        from ..raft_glue import normalize_pair
+        stack = normalize_pair(image1, image2)                         # both frames in one pass, as the stack the feature encoder takes
+        if stack is not None:
+            image1, image2 = stack[:image1.shape[0]], stack[image1.shape[0]:]
+        else:
+            image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
+            image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
         def context():
             net, inp = torch.split(self.cnet(image1), [128, 128], dim=1)
             return torch.tanh(net), torch.relu(inp)
@@ -336,7 +342,7 @@ class RAFT(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 net, inp = context()
-        fmap1, fmap2 = self.fnet([image1, image2])
+        fmap1, fmap2 = self.fnet([image1, image2], stacked=stack)
         fmap1, fmap2 = fmap1.float().contiguous(), fmap2.float().contiguous()
         if self.args.alternate_corr:
             corr_fn = AlternateCorrBlock(fmap1, fmap2, radius=self.args.corr_radius, share_grad=True)

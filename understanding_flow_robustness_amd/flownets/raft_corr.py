@@ -322,21 +322,37 @@ class AlternateCorrBlock:
         detached (raft.py:190), so the lookups' feature-map adjoints accumulate in one buffer and the last adjoint delivers the
         sum.  A public caller gets one independent autograd node per lookup (the default)."""
         self.num_levels, self.radius = num_levels, radius
-        self.pyramid = [(fmap1, fmap2)]
-        for _ in range(num_levels):
-            fmap1 = F.avg_pool2d(fmap1, 2, stride=2)
-            fmap2 = F.avg_pool2d(fmap2, 2, stride=2)
-            self.pyramid.append((fmap1, fmap2))
-        # NHWC copies made once, not once per lookup as in the reference (:128-129)
-        self._f1 = self.pyramid[0][0].permute(0, 2, 3, 1).contiguous()
-        self._f2 = [self.pyramid[i][1].permute(0, 2, 3, 1).contiguous() for i in range(num_levels)]
+        self._maps, self._pyramid = (fmap1, fmap2), None
+        # NHWC copies made once, not once per lookup as in the reference (:128-129).  The reference pools BOTH maps num_levels times
+        # (:97-105) and reads fmap1's level 0 and fmap2's levels 0 .. num_levels - 1 only: those are what one launch per map makes
+        # (raft_glue.fmap_pyramid, bit for bit the torch operators below it replaces).
+        from ..raft_glue import fmap_pyramid
+        p1 = fmap_pyramid(fmap1, 1)
+        p2 = fmap_pyramid(fmap2, num_levels) if p1 is not None else None
+        if p2 is not None:
+            self._f1, self._f2 = p1[0], list(p2)
+        else:
+            self._f1 = self.pyramid[0][0].permute(0, 2, 3, 1).contiguous()
+            self._f2 = [self.pyramid[i][1].permute(0, 2, 3, 1).contiguous() for i in range(num_levels)]
         self._shared = _SharedGrad() if share_grad else None
-        dim = self.pyramid[0][0].shape[1]
+        dim = fmap1.shape[1]
         self._fused = (self._f1.is_cuda and self._f1.dtype == torch.float32 and dim in (128, 256) and radius in (3, 4)
                        and 1 <= num_levels <= 4)
 
+    @property
+    def pyramid(self):
+        """The reference's list of (fmap1, fmap2) levels (corr.py:97-105), built when somebody asks for it."""
+        if self._pyramid is None:
+            fmap1, fmap2 = self._maps
+            self._pyramid = [(fmap1, fmap2)]
+            for _ in range(self.num_levels):
+                fmap1 = F.avg_pool2d(fmap1, 2, stride=2)
+                fmap2 = F.avg_pool2d(fmap2, 2, stride=2)
+                self._pyramid.append((fmap1, fmap2))
+        return self._pyramid
+
     def __call__(self, coords):
-        dim = self.pyramid[0][0].shape[1]
+        dim = self._maps[0].shape[1]
         if self._fused and not (torch.is_grad_enabled() and coords.requires_grad):
             # (a caller that wants d / d coords takes the per-level drop-in below, which computes it like the reference's op)
             needs_grad = torch.is_grad_enabled() and (self._f1.requires_grad or any(f.requires_grad for f in self._f2))
