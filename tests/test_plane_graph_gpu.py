@@ -121,3 +121,31 @@ def test_stale_schedule_backward_raises(monkeypatch):
     m(x.detach().clone().requires_grad_(True))
     with pytest.raises(RuntimeError, match="another forward"):
         a.sum().backward()
+
+
+@pytest.mark.parametrize("which", ["sd", "fusion"])
+def test_first_writers_replace_the_zero_fill(which, monkeypatch):
+    """`PlaneGraph._plan_first_writers`: the first adjoint launch to reach a gradient segment writes `=`, the later ones `+=`, and the
+    backward no longer starts with a fill of every gradient sum.  Against the same schedule built with the fill (UFR_GRAPH_ZERO_ARENA=1),
+    bit for bit, over two passes with different inputs (a segment that nobody overwrote would carry the first pass into the second)."""
+    from understanding_flow_robustness_amd.flownets.flownet2 import FlowNetFusion, FlowNetSD
+    make, cin, out_div = (FlowNetSD, 6, 4) if which == "sd" else (FlowNetFusion, 11, 1)
+    B, H, W = 2, 128, 192
+    m_new = _frozen(_realistic(make(), 11))
+    m_old = copy.deepcopy(m_new)
+    g = torch.Generator().manual_seed(12)
+    passes = [(torch.randn(B, cin, H, W, generator=g).to(DEV), torch.randn(B, 2, H // out_div, W // out_div, generator=g).to(DEV)) for _ in range(2)]
+    res = {}
+    for name, m, knob in (("first writers", m_new, "0"), ("zero fill", m_old, "1")):
+        monkeypatch.setenv("UFR_GRAPH_ZERO_ARENA", knob)
+        res[name] = [_run(m, x, gy, monkeypatch, True) for x, gy in passes]
+        graphs = list(m.__dict__["_ufr_plane_graphs"].values())
+        assert graphs and all((gr._zero_list is None) == (knob == "1") for gr in graphs)
+        if knob == "0":
+            fills = sum(len(gr._zero_list) for gr in graphs)
+            elems = sum(t.numel() for gr in graphs for t in gr._zero_list)
+            total = sum(gr._zero_arena.numel() for gr in graphs)
+            print(f"{which}: {fills} fills of {elems} elements left of an arena of {total}")
+            assert elems <= 0.1 * total
+    for (o1, g1), (o2, g2) in zip(res["first writers"], res["zero fill"]):
+        assert torch.equal(o1, o2) and torch.equal(g1, g2)

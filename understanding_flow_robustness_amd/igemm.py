@@ -357,8 +357,16 @@ def _tuning_table() -> dict:
 
 
 def tuned(wi: "WeightImage", M: int, kw: dict, variant: int, splitk: int):
-    """(variant, splitk) of the tuning table for this launch, else the engine's own choice."""
-    return _tuning_table().get(launch_signature(wi, M, kw), (variant, splitk))
+    """(variant, splitk) of the tuning table for this launch, else the engine's own choice.  A launch whose twin with (without) the
+    epilogue's `add` was swept takes the twin's entry: the addend is one more 32-byte read per output row of the epilogue, nothing
+    the choice of form depends on (PlaneGraph drops the `add` of a segment's first writer: plane_graph._plan_first_writers)."""
+    table, sig = _tuning_table(), launch_signature(wi, M, kw)
+    if sig in table:
+        return table[sig]
+    head, _, out = sig.rpartition("_")
+    twin = out.replace("+add", "") if "+add" in out else (out.replace("+mask", "+add+mask") if "+mask" in out else
+                                                         (out.replace("+tail", "+add+tail") if "+tail" in out else out + "+add"))
+    return table.get(f"{head}_{twin}", (variant, splitk))
 
 
 def make_launch(wi: WeightImage, x: Planes, in_chunk0: int, rows_hw, out_hw, *, out_planes: Planes | None = None,

@@ -8,9 +8,10 @@ the plane layout between layers.
     7x7 stride-2 stem on 12 channels      pixel-unshuffle pack (csrc/plane_layout.hip) + a 16-tap stride-1 launch over 48 channels
 
 A `torch.cat` of the reference is a chunk offset into one buffer (a segment list says where each member sits; weights are
-re-indexed once).  Adjoint: every buffer has a float32 gradient sum of the same layout, zero-filled at the start of a
-backward; each operator's adjoint ADDS its share (igemm epilogue `add` = its own output, the 2-channel kernels with
-accumulate), then LeakyReLU' and the split into gradient planes happen once per produced segment.  Parameters are frozen.
+re-indexed once).  Adjoint: every buffer has a float32 gradient sum of the same layout; the first operator adjoint to reach a
+segment writes its share, the later ones ADD theirs (igemm epilogue `add` = its own output, the 2-channel kernels with
+accumulate; `_plan_first_writers` -- round 4 zero-filled every sum at the start of a backward), then LeakyReLU' and the split
+into gradient planes happen once per produced segment.  Parameters are frozen.
 """
 from __future__ import annotations
 
@@ -187,10 +188,76 @@ class PlaneGraph:
                 kw.update(mask=db.planes, mask_chunk0=d0)
             P["finalized"] = True
 
+    def _plan_first_writers(self):
+        """Which adjoint launch WRITES a gradient segment first.  The backward used to start with one fill of every gradient sum of
+        the graph (~90 MB per FlowNet2 sub-network at 448 x 1024, 11 fills = 0.2 ms of a C5 iteration); instead the first launch that
+        reaches a chunk range writes `=` (the igemm epilogue without `add`, the 2-channel kernels without accumulate) and the later
+        ones `+=`.  Walks the backward in its own order with the set of chunks written so far per buffer; a range that is partly
+        written when a launch reaches it, or read before anything wrote it (a produced segment nobody reads), stays on the list of
+        zero fills.  Returns that list (tensor views)."""
+        written = {id(b): set() for b in self.bufs.values()}
+        zero = {id(b): set() for b in self.bufs.values()}
+        plans = {id(p[0]): p for p in self._plans}
+
+        def write(buf, c0, n) -> bool:
+            R, w = set(range(c0, c0 + n)), written[id(buf)]
+            fresh = not (R & w)
+            if not fresh:
+                zero[id(buf)] |= R - w
+            w |= R
+            return fresh
+
+        def read(buf, c0, n):
+            missing = set(range(c0, c0 + n)) - written[id(buf)]
+            zero[id(buf)] |= missing
+            written[id(buf)] |= missing
+
+        flows_written, zero_flows = set(self.outputs), []
+        for spec in self.tensor_outputs:
+            spec["overwrite"] = write(spec["buf"], spec["chunk0"], spec["C"] // 32)
+        for op in reversed(self.ops):
+            if op["kind"] == "conv":
+                if not op.get("finalized"):
+                    read(op["db"], op["d0"], op["nch"])
+                kw = plans[id(op["bwd"])][6]
+                if "out_f32" in kw:                               # (else: a fused finalize, which writes its producer's gradient planes)
+                    if write(op["sb"], op["s0"], op["sk"]):
+                        kw.pop("add", None); kw.pop("add_chunk0", None)
+                elif "add" in kw:
+                    read(op["sb"], op["s0"], op["sk"])
+            elif op["kind"] == "pf":
+                if op["name"] not in flows_written:               # a flow nobody consumes: its gradient is zero
+                    zero_flows.append(op["name"])
+                    flows_written.add(op["name"])
+                op["acc"] = 0 if write(op["sb"], op["s0"], op["sk"]) else 1
+            else:
+                read(op["db"], op["chunk"], 1)
+                op["acc"] = 1 if op["flow"] in flows_written else 0
+                flows_written.add(op["flow"])
+        for spec in self.inputs:
+            read(spec["buf"], spec["chunk0"], (4 * spec["C"] + 31) // 32 if spec.get("packed") else -(-spec["C"] // 32))
+        fills = []
+        for b in self.bufs.values():
+            chunks = sorted(zero[id(b)])
+            while chunks:                                          # maximal runs of chunks: one fill each
+                c0 = c1 = chunks.pop(0)
+                while chunks and chunks[0] == c1 + 1:
+                    c1 = chunks.pop(0)
+                fills.append((b, c0, c1 + 1))
+        return fills, zero_flows
+
     def build(self):
         B = self.B
         if __import__("os").environ.get("UFR_GRAPH_FUSE_FINALIZE", "1") != "0":
             self._fuse_single_reader_segments()
+        if __import__("os").environ.get("UFR_GRAPH_ZERO_ARENA", "0") == "1":          # round 4's form: one fill of everything
+            fills, zero_flows = None, None
+            for spec in self.tensor_outputs:
+                spec["overwrite"] = False
+            for op in self.ops:
+                op["acc"] = 1
+        else:
+            fills, zero_flows = self._plan_first_writers()
         # every gradient sum and flow gradient in one arena: a backward starts with ONE fill instead of one per buffer
         r64 = lambda n: (n + 63) // 64 * 64                   # keep every member 256-byte aligned
         sizes = [b.grad.t.numel() for b in self.bufs.values()] + [r64(g.numel()) for g in self.g_flows.values()]
@@ -204,6 +271,8 @@ class PlaneGraph:
             n = self.g_flows[k].numel()
             self.g_flows[k] = self._zero_arena[off:off + n].view_as(self.g_flows[k])
             off += r64(n)
+        # what a backward still has to zero before its first launch (None: everything, as one fill)
+        self._zero_list = None if fills is None else ([b.grad.t[c0:c1] for b, c0, c1 in fills] + [self.g_flows[k] for k in zero_flows])
         sized = []
         for holder, wi, x, c0, rows, out_hw, kw in self._plans:
             pk = [len(t) * wi.KC for _, _, t in wi.phases]
@@ -259,15 +328,23 @@ class PlaneGraph:
     @torch.no_grad()
     def backward(self, *grads):
         lib, st = L.lib(), L.stream
-        self._zero_arena.zero_()
+        if self._zero_list is None:
+            self._zero_arena.zero_()
+        else:
+            for t in self._zero_list:                                   # (what no adjoint launch overwrites first: `_plan_first_writers`)
+                t.zero_()
         for name, g in zip(self.outputs, grads):
             self.g_flows[name].copy_(g)
         for spec, g in zip(self.tensor_outputs, grads[len(self.outputs):]):
-            b, C_, c0 = spec["buf"], spec["C"], spec["chunk0"]          # NCHW -> chunk-major float32, added to the buffer's sum
+            b, C_, c0 = spec["buf"], spec["C"], spec["chunk0"]          # NCHW -> chunk-major float32, the first share of the buffer's sum
             n = C_ // 32
             if C_ % 32:
                 raise NotImplementedError("tensor outputs are whole chunks")
-            b.grad.t[c0:c0 + n].add_(g.view(self.B, n, 32, b.H, b.W).permute(1, 0, 3, 4, 2).reshape(n, -1, 32))
+            src = g.view(self.B, n, 32, b.H, b.W).permute(1, 0, 3, 4, 2)
+            if spec["overwrite"]:
+                b.grad.t[c0:c0 + n].view(n, self.B, b.H, b.W, 32).copy_(src)
+            else:
+                b.grad.t[c0:c0 + n].add_(src.reshape(n, -1, 32))
         for op in reversed(self.ops):
             if op["kind"] == "conv":
                 db, gz = op["db"], op["gz"]
@@ -280,11 +357,11 @@ class PlaneGraph:
                 sb = op["sb"]
                 L.check(lib.ufr_flow_head_planes_backward(L.ptr(self.g_flows[op["name"]]), L.ptr(op["wb"]), op["wb"].shape[0], L.ptr(sb.grad.t),
                                                           sb.grad.chunks, op["s0"], op["sk"],
-                                                          self.B, sb.H, sb.W, 1, st()), "predict_flow backward")
+                                                          self.B, sb.H, sb.W, op["acc"], st()), "predict_flow backward")
             else:
                 gf, db = self.g_flows[op["flow"]], op["db"]
                 L.check(lib.ufr_flow_up_planes_backward(L.ptr(db.grad.t), op["chunk"], L.ptr(op["w"]), L.ptr(gf), self.B, gf.shape[2], gf.shape[3],
-                                                        1, st()), "upsampled_flow backward")      # += : an output flow already holds its gradient
+                                                        op["acc"], st()), "upsampled_flow backward")      # += : an output flow already holds its gradient
         outs = []
         for spec in self.inputs:
             b = spec["buf"]
