@@ -63,7 +63,8 @@ for step in "$@"; do
              python tools/pmc_summary.py $fc $pat > $out/${tag}_counters.txt; rc=$?
              [ $rc -ne 0 ] && exit $rc
              cat $out/${tag}_counters.txt ;;
-    configs) timeout -k 10 1100 python tools/bench_configs.py $arg > $out/configs.log 2>&1; rc=$?; tail -n 12 $out/configs.log
+    configs) nc=$((${nc:-0} + 1)); cl=$out/configs$([ $nc -gt 1 ] && echo _$nc).log     # a second configs step of a call: configs_2.log
+             timeout -k 10 1100 python tools/bench_configs.py $arg > $cl 2>&1; rc=$?; tail -n 12 $cl
              [ $rc -ne 0 ] && exit $rc ;;
     env)     export $arg ;;                      # env:NAME=VALUE for the steps behind it
     py)      timeout -k 10 1100 python $arg > $out/py.log 2>&1; rc=$?; tail -n 40 $out/py.log
