@@ -42,7 +42,7 @@ class _on_the_engines:
 FROZEN = pytest.mark.parametrize("frozen", [False, True], ids=["torch_spelling", "engines"])
 
 
-def _check(z, net, args, gtol=1e-3, g_atol=3e-4):
+def _check(z, net, args, gtol=1e-3, g_atol=3e-4, bulk=None):
     from understanding_flow_robustness_amd.flownets.utils_model import predict_flow
     x1, x2 = t(z["x1"], DEV).requires_grad_(True), t(z["x2"], DEV).requires_grad_(True)
     flow = predict_flow(net, None, x1, x2, args)
@@ -53,8 +53,15 @@ def _check(z, net, args, gtol=1e-3, g_atol=3e-4):
     loss = (1 - torch.nn.functional.cosine_similarity(flow, t(z["target"], DEV))).mean()
     assert abs(float(loss.detach()) - float(z["loss"])) < 2e-5
     g1, g2 = torch.autograd.grad(loss, (x1, x2))
-    assert_close(g1, t(z["g1"]), rtol=gtol, atol_scale=g_atol, what="grad frame 1")
-    assert_close(g2, t(z["g2"]), rtol=gtol, atol_scale=g_atol, what="grad frame 2")
+    for name, g, ref_g in (("grad frame 1", g1, t(z["g1"])), ("grad frame 2", g2, t(z["g2"]))):
+        assert_close(g, ref_g, rtol=gtol, atol_scale=g_atol, what=name)
+        # the gate above bounds the WORST entry (ill-conditioned for RAFT and FlowNet2, see the callers); the bulk is held much tighter:
+        # a wrong tap, weight or mask moves most of the gradient by O(1) of its scale
+        err = (g.detach().double().cpu() - ref_g.double()).abs().flatten() / float(ref_g.abs().max())
+        q50, q90 = float(torch.quantile(err, 0.5)), float(torch.quantile(err, 0.9))
+        print(f"{name}: median {q50:.2e}, 90 % within {q90:.2e}, max {float(err.max()):.2e} of the gradient's scale")
+        if bulk is not None:
+            assert q50 <= bulk[0] and q90 <= bulk[1], f"{name}: median {q50:.2e}, 90 % within {q90:.2e} of the scale"
 
 
 def _attack_check(z, net, args, key, lr, iters, tol=1e-4):
@@ -297,6 +304,12 @@ def test_raft_gradient_against_float64_truth(alternate, frozen, oracle):
         e_same, e_64 = rel(mine, same_dev, i), rel(gpu64, truth, i)
         print(f"RAFT alt={alternate} frozen={frozen} {name}: product {e_mine:.2e}, reference cpu fp32 {e_cpu:.2e}, torch spelling fp32 on "
               f"this device {e_torch:.2e} (float64: {e_64:.1e}), product vs torch spelling {e_same:.2e}")
+        bulk = lambda a: [float(torch.quantile(((a[i] - truth[i]).abs() / truth[i].abs().max()).flatten(), q)) for q in (0.5, 0.9, 0.99)]
+        # (the bulk, not the worst entry, says whether an adjoint is right: on the golden's frames the alt_corr + engines leg sits at a
+        # median of 1.3e-4 of the scale where every other leg has 1e-6 .. 3e-5 -- one ReLU flip whose cone, after 12 iterations, is the
+        # whole frame: the same leg measures 2.7e-7 on the frames rolled by 7 pixels and 3e-6 with another seed, below torch's own
+        # float32 on both, gpurun r5_f64e)
+        print(f"    bulk against float64 (median / 90 % / 99 %): product {bulk(mine)}, reference cpu fp32 {bulk(cpu32)}, torch spelling {bulk(same_dev)}")
         assert e_64 <= 1e-10                                  # the formulation itself is exact on this device
         if not alternate:
             # same device, same lookups; the convolutions differ in shape (the product stacks the GRU's z | r

@@ -24,8 +24,9 @@ for step in "$@"; do
   case $kind in
     suite)   timeout -k 10 1500 python -m pytest tests -m gpu -q -x -rs > $out/gpu_suite.log 2>&1; rc=$?; tail -n 6 $out/gpu_suite.log
              [ $rc -ne 0 ] && { grep -E "^E |FAILED|Error" $out/gpu_suite.log | head -n 20; exit $rc; } ;;
-    tests)   timeout -k 10 1100 python -m pytest $arg -q -x > $out/tests.log 2>&1; rc=$?; tail -n 4 $out/tests.log
-             [ $rc -ne 0 ] && { grep -E "^E |FAILED|Error" $out/tests.log | head -n 30; exit $rc; } ;;
+    tests)   nt=$((${nt:-0} + 1)); tl=$out/tests$([ $nt -gt 1 ] && echo _$nt).log     # a second tests step of a call: tests_2.log
+             timeout -k 10 1100 python -m pytest $arg -q -x > $tl 2>&1; rc=$?; tail -n 4 $tl
+             [ $rc -ne 0 ] && { grep -E "^E |FAILED|Error" $tl | head -n 30; exit $rc; } ;;
     bench)   nb=$((${nb:-0} + 1)); bj=$out/bench$([ $nb -gt 1 ] && echo _$nb).json      # a second bench step of a call: bench_2.json
              timeout -k 10 900 python bench.py $arg > $bj 2> $out/bench.err; rc=$?
              [ $rc -ne 0 ] && { tail -n 20 $out/bench.err; exit $rc; }
