@@ -83,7 +83,7 @@ def test_pwcnet_vs_reference(frozen):
     z = load_golden("pwcnet_128x192")
     net, args = _fetch("PWCNet", 1)
     with _on_the_engines(net, frozen):
-        _check(z, net, args)
+        _check(z, net, args, bulk=(2e-5, 2e-4))               # (measured: median 9e-7, 90 % within 2.3e-5 on both legs)
     _attack_check(z, net, args, "attack_it2_patch", 1e4, 2)
 
 
@@ -99,7 +99,9 @@ def test_raft_vs_reference(alternate, frozen):
     # (profiles/r2_raft_f64_diag.txt); MIOpen vs oneDNN lands at ~2e-2 of the gradient's max.  The HIP lookup
     # itself matches torch's grid_sample formulation to 6e-6 on the same device (profiles/r2_raft_f64_diag.txt).
     with _on_the_engines(net, frozen):
-        _check(z, net, args, gtol=5e-2, g_atol=5e-2)
+        # the worst entry is the conditioning's (5e-2); the bulk is gated 30x tighter (measured: median 8e-6 .. 2.3e-4, 90 % within
+        # 4e-5 .. 1.2e-3 over the four legs -- the largest is the alt_corr + engines leg's ReLU flip, test_raft_gradient_against_float64_truth)
+        _check(z, net, args, gtol=5e-2, g_atol=5e-2, bulk=(1e-3, 5e-3))
     _attack_check(z, net, args, "attack_it2_patch", 1e4, 2, tol=5e-2)
 
 
@@ -111,7 +113,7 @@ def test_flownet2_vs_reference_wiring(frozen):
     # it piecewise: a flow value within rounding of an integer lands in another cell on another
     # platform, so ~1% of the pixels move by up to 1% of the gradient's max (measured 5.5e-3).
     with _on_the_engines(net, frozen):
-        _check(z, net, args, gtol=2e-2, g_atol=1e-2)
+        _check(z, net, args, gtol=2e-2, g_atol=1e-2, bulk=(1e-4, 5e-4))     # (measured: median 6 - 8e-6, 90 % within 4.7e-5)
 
 
 @pytest.mark.parametrize("use_graph", [True, False])
