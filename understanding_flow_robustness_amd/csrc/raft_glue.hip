@@ -37,87 +37,115 @@ __global__ void raft_normalize_pair_bwd_kernel(const float* __restrict__ gy, flo
 
 struct PyrLevels { float* p[4]; };                 // NHWC levels 0..3 (forward: outputs; backward: the gradients, NULL = none)
 
-// Workgroup = one 8 x 8 block of level-0 pixels, thread = channel (looped past 256): the 64 values of a channel's block are read
-// as rows of 8 (NCHW), every level's pixels written [pixel][channel] with the channels of a pixel side by side (coalesced).
-// A map of 256 x 48 x 160 is 7.9 MB: the launch replaces 8 pooling + 5 permute-copy launches of ~6 us each.
+// Workgroup = an 8 x 32 block of level-0 pixels x 32 channels, staged through LDS: the NCHW side moves as rows of 32 pixels (128 bytes),
+// the NHWC side as 32 channels of one pixel (128 bytes); the pooled levels (4 x 16, 2 x 8, 1 x 4 pixels of the block) are made in LDS.
+// (The first form -- thread = channel, 32-byte rows of NCHW -- took 25 / 40 us per 7.9 MB map.)
+constexpr int PY_BH = 8, PY_BW = 32, PY_C = 32;
+constexpr int PY_S0 = PY_BH * (PY_BW + 1) + 1;      // channel stride of the level-0 tile (odd: the 32 channels of a pixel hit 32 banks)
+constexpr int PY_S1 = 4 * 17 + 1, PY_S2 = 2 * 9 + 1, PY_S3 = 5;
+
 __global__ __launch_bounds__(256) void raft_fmap_pyramid_fwd_kernel(const float* __restrict__ f, PyrLevels out, int B, int C, int H, int W,
                                                                     int levels) {
-  const int bx = (W + 7) >> 3, by = (H + 7) >> 3;
-  const int b = blockIdx.x / (bx * by), r = blockIdx.x - b * bx * by, y0 = (r / bx) * 8, x0 = (r % bx) * 8;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float* src = f + ((size_t)b * C + c) * H * W;
-    float v0[8][8];
-#pragma unroll
-    for (int y = 0; y < 8; ++y)
-#pragma unroll
-      for (int x = 0; x < 8; ++x) v0[y][x] = (y0 + y < H && x0 + x < W) ? src[(size_t)(y0 + y) * W + x0 + x] : 0.f;
-#pragma unroll
-    for (int y = 0; y < 8; ++y)
-#pragma unroll
-      for (int x = 0; x < 8; ++x)
-        if (y0 + y < H && x0 + x < W) out.p[0][(((size_t)b * H + y0 + y) * W + x0 + x) * C + c] = v0[y][x];
-    if (levels < 2) continue;
-    float v1[4][4], v2[2][2];
-    const int H1 = H >> 1, W1 = W >> 1, H2 = H >> 2, W2 = W >> 2, H3 = H >> 3, W3 = W >> 3;
-#pragma unroll
-    for (int y = 0; y < 4; ++y)
-#pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        v1[y][x] = (((v0[2 * y][2 * x] + v0[2 * y][2 * x + 1]) + v0[2 * y + 1][2 * x]) + v0[2 * y + 1][2 * x + 1]) * 0.25f;
-        const int yy = (y0 >> 1) + y, xx = (x0 >> 1) + x;
-        if (yy < H1 && xx < W1) out.p[1][(((size_t)b * H1 + yy) * W1 + xx) * C + c] = v1[y][x];
-      }
-    if (levels < 3) continue;
-#pragma unroll
-    for (int y = 0; y < 2; ++y)
-#pragma unroll
-      for (int x = 0; x < 2; ++x) {
-        v2[y][x] = (((v1[2 * y][2 * x] + v1[2 * y][2 * x + 1]) + v1[2 * y + 1][2 * x]) + v1[2 * y + 1][2 * x + 1]) * 0.25f;
-        const int yy = (y0 >> 2) + y, xx = (x0 >> 2) + x;
-        if (yy < H2 && xx < W2) out.p[2][(((size_t)b * H2 + yy) * W2 + xx) * C + c] = v2[y][x];
-      }
-    if (levels < 4) continue;
-    const float v3 = (((v2[0][0] + v2[0][1]) + v2[1][0]) + v2[1][1]) * 0.25f;
-    if ((y0 >> 3) < H3 && (x0 >> 3) < W3) out.p[3][(((size_t)b * H3 + (y0 >> 3)) * W3 + (x0 >> 3)) * C + c] = v3;
+  __shared__ float t0[PY_C * PY_S0], t1[PY_C * PY_S1], t2[PY_C * PY_S2];
+  const int bx = (W + PY_BW - 1) / PY_BW, by = (H + PY_BH - 1) / PY_BH, bc = (C + PY_C - 1) / PY_C;
+  int r = blockIdx.x;
+  const int cb = r % bc; r /= bc;
+  const int x0 = (r % bx) * PY_BW; r /= bx;
+  const int y0 = (r % by) * PY_BH, b = r / by, c0 = cb * PY_C;
+  const int tid = threadIdx.x;
+  {                                                  // NCHW rows -> t0[c][y][x]
+    const int x = tid & 31, y = tid >> 5;
+    const bool in = y0 + y < H && x0 + x < W;
+    for (int c = 0; c < PY_C; ++c)
+      t0[c * PY_S0 + y * (PY_BW + 1) + x] = (in && c0 + c < C) ? f[((size_t)b * C + c0 + c) * H * W + (size_t)(y0 + y) * W + x0 + x] : 0.f;
+  }
+  __syncthreads();
+  const int c = tid & 31, q = tid >> 5;             // NHWC side: 32 channels of a pixel side by side, 8 pixels per pass
+  const bool cin = c0 + c < C;
+  for (int p = q; p < PY_BH * PY_BW; p += 8) {
+    const int y = p >> 5, x = p & 31;
+    if (cin && y0 + y < H && x0 + x < W) out.p[0][(((size_t)b * H + y0 + y) * W + x0 + x) * C + c0 + c] = t0[c * PY_S0 + y * (PY_BW + 1) + x];
+  }
+  if (levels < 2) return;
+  const int H1 = H >> 1, W1 = W >> 1, H2 = H >> 2, W2 = W >> 2, H3 = H >> 3, W3 = W >> 3;
+  for (int p = q; p < 4 * 16; p += 8) {
+    const int y = p >> 4, x = p & 15;
+    const float* s = t0 + c * PY_S0 + (2 * y) * (PY_BW + 1) + 2 * x;
+    const float v = (((s[0] + s[1]) + s[PY_BW + 1]) + s[PY_BW + 2]) * 0.25f;
+    t1[c * PY_S1 + y * 17 + x] = v;
+    const int yy = (y0 >> 1) + y, xx = (x0 >> 1) + x;
+    if (cin && yy < H1 && xx < W1) out.p[1][(((size_t)b * H1 + yy) * W1 + xx) * C + c0 + c] = v;
+  }
+  if (levels < 3) return;
+  __syncthreads();
+  for (int p = q; p < 2 * 8; p += 8) {
+    const int y = p >> 3, x = p & 7;
+    const float* s = t1 + c * PY_S1 + (2 * y) * 17 + 2 * x;
+    const float v = (((s[0] + s[1]) + s[17]) + s[18]) * 0.25f;
+    t2[c * PY_S2 + y * 9 + x] = v;
+    const int yy = (y0 >> 2) + y, xx = (x0 >> 2) + x;
+    if (cin && yy < H2 && xx < W2) out.p[2][(((size_t)b * H2 + yy) * W2 + xx) * C + c0 + c] = v;
+  }
+  if (levels < 4) return;
+  __syncthreads();
+  if (q < 4) {
+    const float* s = t2 + c * PY_S2 + 2 * q;
+    const float v = (((s[0] + s[1]) + s[9]) + s[10]) * 0.25f;
+    const int yy = y0 >> 3, xx = (x0 >> 3) + q;
+    if (cin && yy < H3 && xx < W3) out.p[3][(((size_t)b * H3 + yy) * W3 + xx) * C + c0 + c] = v;
   }
 }
 
 // d f[NCHW] = g0 + (g1 + (g2 + g3 / 4) / 4) / 4, every level's total rounded as autograd's accumulation rounds it
 __global__ __launch_bounds__(256) void raft_fmap_pyramid_bwd_kernel(PyrLevels g, float* __restrict__ gf, int B, int C, int H, int W,
                                                                     int levels) {
-  const int bx = (W + 7) >> 3, by = (H + 7) >> 3;
-  const int b = blockIdx.x / (bx * by), r = blockIdx.x - b * bx * by, y0 = (r / bx) * 8, x0 = (r % bx) * 8;
+  __shared__ float t0[PY_C * PY_S0], t1[PY_C * PY_S1], t2[PY_C * PY_S2], t3[PY_C * PY_S3];
+  const int bx = (W + PY_BW - 1) / PY_BW, by = (H + PY_BH - 1) / PY_BH, bc = (C + PY_C - 1) / PY_C;
+  int r = blockIdx.x;
+  const int cb = r % bc; r /= bc;
+  const int x0 = (r % bx) * PY_BW; r /= bx;
+  const int y0 = (r % by) * PY_BH, b = r / by, c0 = cb * PY_C;
   const int H1 = H >> 1, W1 = W >> 1, H2 = H >> 2, W2 = W >> 2, H3 = H >> 3, W3 = W >> 3;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float t3 = 0.f, t2[2][2], t1[4][4];
-    if (levels >= 4 && g.p[3] && (y0 >> 3) < H3 && (x0 >> 3) < W3) t3 = g.p[3][(((size_t)b * H3 + (y0 >> 3)) * W3 + (x0 >> 3)) * C + c];
-#pragma unroll
-    for (int y = 0; y < 2; ++y)
-#pragma unroll
-      for (int x = 0; x < 2; ++x) {
-        const int yy = (y0 >> 2) + y, xx = (x0 >> 2) + x;
-        const float own = (levels >= 3 && g.p[2] && yy < H2 && xx < W2) ? g.p[2][(((size_t)b * H2 + yy) * W2 + xx) * C + c] : 0.f;
-        t2[y][x] = own + t3 * 0.25f;
-      }
-#pragma unroll
-    for (int y = 0; y < 4; ++y)
-#pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        const int yy = (y0 >> 1) + y, xx = (x0 >> 1) + x;
-        const float own = (levels >= 2 && g.p[1] && yy < H1 && xx < W1) ? g.p[1][(((size_t)b * H1 + yy) * W1 + xx) * C + c] : 0.f;
-        // (a level-1 pixel past floor(H / 4) * 2 has no parent: its parent's slot above was read as 0)
-        t1[y][x] = own + (((y0 >> 2) + (y >> 1) < H2 && (x0 >> 2) + (x >> 1) < W2) ? t2[y >> 1][x >> 1] * 0.25f : 0.f);
-      }
-    float* dst = gf + ((size_t)b * C + c) * H * W;
-#pragma unroll
-    for (int y = 0; y < 8; ++y)
-#pragma unroll
-      for (int x = 0; x < 8; ++x) {
-        if (y0 + y >= H || x0 + x >= W) continue;
-        const float own = g.p[0] ? g.p[0][(((size_t)b * H + y0 + y) * W + x0 + x) * C + c] : 0.f;
-        const bool parent = (y0 >> 1) + (y >> 1) < H1 && (x0 >> 1) + (x >> 1) < W1;
-        dst[(size_t)(y0 + y) * W + x0 + x] = own + (parent ? t1[y >> 1][x >> 1] * 0.25f : 0.f);
-      }
+  const int tid = threadIdx.x, c = tid & 31, q = tid >> 5;
+  const bool cin = c0 + c < C;
+  // every level's own gradient -> LDS (0 where a level has none or the pixel does not exist)
+  for (int p = q; p < PY_BH * PY_BW; p += 8) {
+    const int y = p >> 5, x = p & 31;
+    t0[c * PY_S0 + y * (PY_BW + 1) + x] = (g.p[0] && cin && y0 + y < H && x0 + x < W) ? g.p[0][(((size_t)b * H + y0 + y) * W + x0 + x) * C + c0 + c] : 0.f;
+  }
+  for (int p = q; p < 4 * 16; p += 8) {
+    const int y = p >> 4, x = p & 15, yy = (y0 >> 1) + y, xx = (x0 >> 1) + x;
+    t1[c * PY_S1 + y * 17 + x] = (levels >= 2 && g.p[1] && cin && yy < H1 && xx < W1) ? g.p[1][(((size_t)b * H1 + yy) * W1 + xx) * C + c0 + c] : 0.f;
+  }
+  for (int p = q; p < 2 * 8; p += 8) {
+    const int y = p >> 3, x = p & 7, yy = (y0 >> 2) + y, xx = (x0 >> 2) + x;
+    t2[c * PY_S2 + y * 9 + x] = (levels >= 3 && g.p[2] && cin && yy < H2 && xx < W2) ? g.p[2][(((size_t)b * H2 + yy) * W2 + xx) * C + c0 + c] : 0.f;
+  }
+  if (q < 4) {
+    const int yy = y0 >> 3, xx = (x0 >> 3) + q;
+    t3[c * PY_S3 + q] = (levels >= 4 && g.p[3] && cin && yy < H3 && xx < W3) ? g.p[3][(((size_t)b * H3 + yy) * W3 + xx) * C + c0 + c] : 0.f;
+  }
+  __syncthreads();
+  // totals, coarse to fine: own + parent's total / 4 (a pixel past the floor of the halved size has no parent: its slot holds 0)
+  for (int p = q; p < 2 * 8; p += 8) {
+    const int y = p >> 3, x = p & 7;
+    t2[c * PY_S2 + y * 9 + x] += t3[c * PY_S3 + (x >> 1)] * 0.25f;
+  }
+  __syncthreads();
+  for (int p = q; p < 4 * 16; p += 8) {
+    const int y = p >> 4, x = p & 15;
+    const bool parent = (y0 >> 2) + (y >> 1) < H2 && (x0 >> 2) + (x >> 1) < W2;
+    t1[c * PY_S1 + y * 17 + x] += parent ? t2[c * PY_S2 + (y >> 1) * 9 + (x >> 1)] * 0.25f : 0.f;
+  }
+  __syncthreads();
+  {                                                  // NCHW rows out
+    const int x = tid & 31, y = tid >> 5;
+    if (y0 + y < H && x0 + x < W) {
+      const bool parent = (y0 >> 1) + (y >> 1) < H1 && (x0 >> 1) + (x >> 1) < W1;
+      for (int cc = 0; cc < PY_C && c0 + cc < C; ++cc)
+        gf[((size_t)b * C + c0 + cc) * H * W + (size_t)(y0 + y) * W + x0 + x] =
+            t0[cc * PY_S0 + y * (PY_BW + 1) + x] + (parent ? t1[cc * PY_S1 + (y >> 1) * 17 + (x >> 1)] * 0.25f : 0.f);
+    }
   }
 }
 
@@ -151,7 +179,7 @@ extern "C" int ufr_raft_fmap_pyramid_forward(const float* fmap, float* const* le
     UFR_REQUIRE(levels_nhwc[l], "raft fmap pyramid: level %d is null", l);
     out.p[l] = levels_nhwc[l];
   }
-  const long blocks = (long)B * ((H + 7) / 8) * ((W + 7) / 8);
+  const long blocks = (long)B * ((H + PY_BH - 1) / PY_BH) * ((W + PY_BW - 1) / PY_BW) * ((C + PY_C - 1) / PY_C);
   UFR_REQUIRE(blocks < (1L << 31), "raft fmap pyramid: too many pixels");
   raft_fmap_pyramid_fwd_kernel<<<(unsigned)blocks, 256, 0, ufr::as_stream(stream)>>>(fmap, out, B, C, H, W, levels);
   return ufr::launched("raft_fmap_pyramid_fwd_kernel");
@@ -163,7 +191,7 @@ extern "C" int ufr_raft_fmap_pyramid_backward(const float* const* grad_levels_nh
   UFR_REQUIRE(levels >= 1 && levels <= 4 && B > 0 && C > 0 && H > 0 && W > 0, "raft fmap pyramid backward: bad shape (1 - 4 levels)");
   PyrLevels g{};
   for (int l = 0; l < levels; ++l) g.p[l] = const_cast<float*>(grad_levels_nhwc[l]);      // NULL: that level has no gradient
-  const long blocks = (long)B * ((H + 7) / 8) * ((W + 7) / 8);
+  const long blocks = (long)B * ((H + PY_BH - 1) / PY_BH) * ((W + PY_BW - 1) / PY_BW) * ((C + PY_C - 1) / PY_C);
   UFR_REQUIRE(blocks < (1L << 31), "raft fmap pyramid backward: too many pixels");
   raft_fmap_pyramid_bwd_kernel<<<(unsigned)blocks, 256, 0, ufr::as_stream(stream)>>>(g, grad_fmap, B, C, H, W, levels);
   return ufr::launched("raft_fmap_pyramid_bwd_kernel");
