@@ -980,10 +980,37 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const Args a) {
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float* src = a.ws + ((long)a.zoff[phase] * a.g.M + row) * a.Npad + n0;
     const long sstride = (long)a.g.M * a.Npad;
-    // (the slabs of four slices are requested before the first is added: a deep split on a tiny grid -- 16 .. 32 slabs of a 7 x 16
+    // (the slabs of up to eight slices are requested before the first is added: a deep split on a tiny grid -- 16 .. 32 slabs of a 7 x 16
     // grid -- was a chain of dependent loads, ~0.5 us each; the order of the additions, and with it every bit of the sum, stays)
     const int S = a.sk[phase];
     int s = 0;
+    for (; s + 8 <= S; s += 8) {       // (eight where the split has them: a split of 6 - 8 on RAFT's 48 x 160 grids was two round trips)
+      float4 lo[8], hi[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        lo[u] = *reinterpret_cast<const float4*>(src + (s + u) * sstride);
+        hi[u] = *reinterpret_cast<const float4*>(src + (s + u) * sstride + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        v[0] += lo[u].x; v[1] += lo[u].y; v[2] += lo[u].z; v[3] += lo[u].w; v[4] += hi[u].x; v[5] += hi[u].y; v[6] += hi[u].z; v[7] += hi[u].w;
+      }
+    }
+    if (S - s >= 5) {                  // 5 .. 7 left: all of them together (the loads past the last slice repeat it, their values are not added)
+      float4 lo[7], hi[7];
+#pragma unroll
+      for (int u = 0; u < 7; ++u) {
+        const int su = min(s + u, S - 1);
+        lo[u] = *reinterpret_cast<const float4*>(src + su * sstride);
+        hi[u] = *reinterpret_cast<const float4*>(src + su * sstride + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 7; ++u)
+        if (s + u < S) {
+          v[0] += lo[u].x; v[1] += lo[u].y; v[2] += lo[u].z; v[3] += lo[u].w; v[4] += hi[u].x; v[5] += hi[u].y; v[6] += hi[u].z; v[7] += hi[u].w;
+        }
+      s = S;
+    }
     for (; s + 4 <= S; s += 4) {
       float4 lo[4], hi[4];
 #pragma unroll

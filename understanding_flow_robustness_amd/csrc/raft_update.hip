@@ -115,6 +115,21 @@ __device__ __forceinline__ void load_slabs8(const SlabSrc& k, long m, int col, f
   for (int j = 0; j < 8; ++j) v[j] = 0.f;
   const float* src = k.ws + m * k.Npad + col;
   int s = 0;
+  if (k.S >= 5 && k.S <= 8) {                  // the usual splits of the 48 x 160 grids: every slab in flight at once (one round trip)
+    float4 lo[8], hi[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int su = min(u, k.S - 1);          // (the loads past the last slice repeat it, their values are not added)
+      lo[u] = *reinterpret_cast<const float4*>(src + su * k.slab_stride);
+      hi[u] = *reinterpret_cast<const float4*>(src + su * k.slab_stride + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (u < k.S) {
+        v[0] += lo[u].x; v[1] += lo[u].y; v[2] += lo[u].z; v[3] += lo[u].w; v[4] += hi[u].x; v[5] += hi[u].y; v[6] += hi[u].z; v[7] += hi[u].w;
+      }
+    s = k.S;
+  }
   for (; s + 4 <= k.S; s += 4) {               // four slabs in flight, added in the same ascending order
     float4 lo[4], hi[4];
 #pragma unroll
