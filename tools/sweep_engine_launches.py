@@ -28,6 +28,7 @@ CEIL = 2500.0 / 6
 SPLITS = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32)
 
 
+OPTS = {}
 COLD = [None]           # a 1 GiB tensor rewritten between timed launches (--cold): the launch then finds its operands where the
                         # step's previous kernels left them -- in HBM -- not in the L2 / MALL its own previous run filled
 
@@ -120,11 +121,15 @@ def sweep(config, out_dir):
         gflop = wi.flops(M) / 1e9
         chosen = (r["variant"] if r["variant"] else 2, r["splitk"])
         variants = (6, 7, 5, 4, 2, 8) if wi.Npad % 128 == 0 else (2, 7, 8)
+        if OPTS.get("variants"):                                # --variants 8: only these forms (beside the engine's own choice)
+            variants = tuple(v for v in variants if v in OPTS["variants"] or v == chosen[0])
+        if OPTS.get("max_n") and wi.N > OPTS["max_n"]:          # --max-n 64: only the narrow launches
+            continue
         kt = max(len(t) for _, _, t in wi.phases) * wi.KC
         res = {}
         for v in variants:
             for S in SPLITS:
-                if S > 1 and (kt // S < 2 or len(wi.phases) * S * M * wi.Npad * 4 > (2 << 30)):
+                if S > 1 and (v == 8 or kt // S < 2 or len(wi.phases) * S * M * wi.Npad * 4 > (2 << 30)):     # (the direct form does not split)
                     continue
                 ws = torch.empty(len(wi.phases) * S * M * wi.Npad, device=DEV) if S > 1 else None
                 try:
@@ -167,11 +172,14 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--keep-table", action="store_true", help="leave igemm_tuning.json in force (default: sweep against the rule of thumb)")
     ap.add_argument("--cold", action="store_true", help="rewrite 1 GiB between timed launches: operands come from HBM, as inside a step")
+    ap.add_argument("--variants", default="", help="comma / plus separated kernel forms to sweep beside the engine's choice (default: all)")
+    ap.add_argument("--max-n", type=int, default=0, help="only launches with at most this many output columns")
     opt = ap.parse_args()
     if opt.cold:
         COLD[0] = torch.zeros(1 << 28, device=DEV)
     if not opt.keep_table:
         os.environ["UFR_IGEMM_TUNING"] = "0"
+    OPTS.update(variants=[int(v) for v in opt.variants.replace("+", ",").split(",") if v], max_n=opt.max_n)
     for c in opt.configs:
         sweep(c, opt.out)
 
