@@ -2,7 +2,7 @@
 
     python tools/sweep_engine_launches.py CONFIG [CONFIG ...] [--out DIR] [--keep-table]
 
-CONFIG: c3alt | c3 (RAFT at one pair, alt_cuda_corr / all-pairs), c5 (FlowNet2 448x1024 universal step), c4 (PWC-Net, 8 pairs),
+CONFIG: c3alt | c3 (RAFT at one pair, alt_cuda_corr / all-pairs), c3altb8 (8 pairs), c5 (FlowNet2 448x1024 universal step), c4 (PWC-Net, 8 pairs),
 c2b1 (FlowNetC at one pair), c2 (the headline: FlowNetC, 8 pairs; its band / window launches are skipped).  The config's step is built with `igemm.RECORD` switched on, so EVERY `make_launch` of every engine
 the step uses (update block, encoders, PlaneGraph sub-networks, the FlowNetC / FlowNetS heads) is captured with its operands; the
 step runs twice (the buffers then hold real activations), and every DISTINCT launch (igemm.launch_signature) is rebuilt with every
@@ -76,6 +76,7 @@ def build_step(config):
         step.run(2)
         return step
     flownet, seed, B, extra = {"c3alt": ("RAFT", 2, 1, dict(alternate_corr=True)), "c3": ("RAFT", 2, 1, {}),
+                               "c3altb8": ("RAFT", 2, 8, dict(alternate_corr=True)),
                                "c4": ("PWCNet", 1, 8, {}), "c2b1": ("FlowNetC", 0, 1, {}), "c2": ("FlowNetC", 0, 8, {})}[config]
     H, W = 384, 1280
     args = Namespace(flownet=flownet, l2=False, alpha=0.0, lr=1000.0, max_count=2, **extra)
