@@ -4,6 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 make -s -j8 -C understanding_flow_robustness_amd/csrc
+md5sum understanding_flow_robustness_amd/lib/libufr_hip.so          # (which library travels: see the Makefile's note on stale objects)
 make -s -C oracle all >/dev/null
 t=$1; shift
 exec /usr/local/graft/bin/gpurun --timeout $t -- "bash tools/gpu_call.sh $*"
