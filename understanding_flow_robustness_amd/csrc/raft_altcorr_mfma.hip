@@ -168,11 +168,11 @@ __global__ __launch_bounds__(256) void altcorr_mfma_fwd(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------ backward, pre-pass
-// One workgroup (64 threads) per (pixel tile, level): every pixel's window origin, gs = the adjoint of the bilinear blend
+// One workgroup (256 threads) per (pixel tile, level): every pixel's window origin, gs = the adjoint of the bilinear blend
 // (correlation_kernel.cu:196-214) times `scale`, and the tile's box.  Both adjoints read these instead of recomputing them
 // per (tile, segment) pair.   gs_all [L][npix][npt] | win [L][npix][2] | boxes [L][ntiles][4]: {y0, y1, x0, x1}, empty = 0s
 template <int R>
-__global__ __launch_bounds__(64) void altcorr_prepass(const AcLevels lv, const float* __restrict__ coords, int planar,
+__global__ __launch_bounds__(256) void altcorr_prepass(const AcLevels lv, const float* __restrict__ coords, int planar,
                                                       const float* __restrict__ gout, float* __restrict__ gs_all,
                                                       int* __restrict__ win, int* __restrict__ boxes, int B, int H1, int W1,
                                                       float scale, int gout_cm) {
@@ -212,8 +212,10 @@ __global__ __launch_bounds__(64) void altcorr_prepass(const AcLevels lv, const f
   // conversion pass in between) chunk-major float32 [chunks][B * H1 * W1][32] with channel o at chunk o / 32, lane o % 32
   const size_t gbase = (((size_t)b * lv.n + l) * rd * rd) * plane + (size_t)h1 * W1;
   const size_t prow = (size_t)b * plane + (size_t)h1 * W1;
-  for (int t = tid; t < AC_TP * npt; t += 64) {
-    const int i = t & 15, pt = t >> 4, iy = pt / gd, ix = pt - iy * gd;
+  for (int t = tid; t < AC_TP * npt; t += blockDim.x) {
+    // chunk-major gradient: a pixel's 81 channels of a level lie in three 128-byte lines, and its 100 results are 400 contiguous bytes --
+    // consecutive lanes take consecutive window points of ONE pixel; NCHW: consecutive lanes take consecutive pixels of one channel
+    const int i = gout_cm ? t / npt : t & 15, pt = gout_cm ? t - i * npt : t >> 4, iy = pt / gd, ix = pt - iy * gd;
     if (w0 + i >= W1) continue;
     const float* gp = gout + gbase + w0 + i;
     auto G = [&](int ol) -> float {
@@ -464,7 +466,9 @@ int launch_bwd(const float* f1, AcLevels lv, const float* coords, int planar, co
   ws.boxes = ws.win + (long)lv.n * npix * 2;
   ws.boxes += (4 - ((reinterpret_cast<uintptr_t>(ws.boxes) / 4) & 3)) & 3;            // 16-byte aligned rows
   const int tiles_pad = (B * H1 + 7) / 8 * 8 * (tiles_b / H1);                 // rows padded to a multiple of 8: see xcd_row_tile
-  altcorr_prepass<R><<<dim3(tiles_pad, lv.n), 64, 0, st>>>(lv, coords, planar, gout, ws.gs_all, ws.win, ws.boxes, B, H1, W1, scale, gout_cm);
+  // 256 threads per (tile, level): 1,600 window points of 16 pixels, 4 gathers each -- one wave walked them as 25 dependent round trips
+  // (74 us per lookup in the C3 step; 128 / 256 / 512 threads: 51 / 39 / 49 us, c3alt 15.40 / 15.51 -> 15.17 / 15.28 ms, gpurun r5_pp3 / r5_pp4)
+  altcorr_prepass<R><<<dim3(tiles_pad, lv.n), 256, 0, st>>>(lv, coords, planar, gout, ws.gs_all, ws.win, ws.boxes, B, H1, W1, scale, gout_cm);
   int rc = ufr::launched("altcorr_prepass");
   if (rc != UFR_OK) return rc;
   altcorr_mfma_bwd1<R, CPG><<<dim3(tiles_pad, lv.n), 256, 0, st>>>(lv, ws.gs_all, ws.win, ws.boxes, ws.part, B, H1, W1);
