@@ -69,6 +69,7 @@ GFLOP_PER_PAIR_STEP = gflop_per_pair_step(None, 2)
 PEAK_FP32_TFLOPS = 157.3        # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
 PEAK_SPLIT6_TFLOPS = 2500.0 / 6   # bf16 dense MFMA peak / six products per float32 product (csrc/igemm.hip)
 PEAK_HBM_GBS = 8000.0
+NOMINAL_MHZ = 2400.0             # the clock the 2.5 PFLOP/s ceiling is priced at
 CORR_FWD = dict(gflop=1.734, mbytes=29.3)   # per [1,256,48,160] pair
 CORR_BWD = dict(gflop=3.468, mbytes=44.9)
 
@@ -240,6 +241,37 @@ def step_traffic():
         return int(_pmc(STEP_TRAFFIC)["traffic_bytes_per_iteration"])
     except (KeyError, ValueError):
         return None
+
+
+def measured_clock(eng, device, seconds=0.4):
+    """The shader clock the dominant kernel really runs at, measured in THIS process: conv3_1's forward launch
+    (ping-pong igemm, csrc/igemm.hip) replayed back to back for `seconds`, then one probed launch in which every workgroup records
+    s_memtime (core cycles) and s_memrealtime (constant 100 MHz) at entry and exit (`ufr_igemm_clock_probe`): cycles / real time.
+    Returns (median MHz over the workgroups, that launch's sustained TFLOP/s) or (None, None)."""
+    from understanding_flow_robustness_amd import _lib as L
+    row = next((r for r in eng.launch_table() if r[0] == "conv3_1" and r[1] == "fwd" and r[2] == "full" and r[3].desc.variant == 6), None)
+    if row is None:
+        return None, None
+    launch, gflop = row[3], row[4]
+    d = launch.desc
+    n_wg = (d.Npad // 128) * ((d.B * d.Hr * d.Wr + 255) // 256) * 64
+    buf = torch.zeros(n_wg, 8, dtype=torch.int64, device=device)
+    one = event_time(launch, 5)
+    reps = max(10, int(seconds * 1e3 / max(one, 1e-3)))
+    sustained = event_time(launch, reps, warm=0)
+    L.check(L.lib().ufr_igemm_clock_probe(L.ptr(buf), n_wg), "clock probe on")
+    try:
+        for _ in range(4):
+            launch()
+        torch.cuda.synchronize(device)
+    finally:
+        L.check(L.lib().ufr_igemm_clock_probe(None, 0), "clock probe off")
+    t = buf.cpu()
+    t = t[t[:, 3] > t[:, 2]]
+    if not len(t):
+        return None, None
+    mhz = ((t[:, 1] - t[:, 0]).double() / (t[:, 3] - t[:, 2]).double() * 100.0).median()
+    return round(float(mhz), 1), round(gflop / sustained, 1)
 
 
 def cpu_baseline():
@@ -557,6 +589,8 @@ def main():
         }
         if sustained is not None:
             line["sustained_ms_per_step"] = sustained["ms_per_step"]
+            line["config"]["sustained_ms_per_step"] = sustained["ms_per_step"]      # flat scalars: the driver's parser drops nested values
+            line["config"]["sustained_steps"] = sustained["steps"]
             line["config"]["sustained"] = sustained
         if opt.config == "c2":
             c2_line(line, opt, ctx, world, device, ms, mc)
@@ -642,6 +676,16 @@ def c2_line(line, opt, ctx, world, device, ms, mc):
                                 "ms_per_iteration": round(agg["ms"], 3), "algorithmic_gflop_per_iteration": round(agg["gflop"], 1),
                                 "peak_note": "fp32-equivalent: 2.5 PFLOP/s dense bf16 MFMA / 6 products per float32 product",
                                 "step": step_line}
+        # the clock the igemm ran at, in this process: a slow box and a slow build can be told apart from this one line
+        eng = next((e for e in getattr(net, "__dict__", {}).get("_ufr_head_engines", {}).values()
+                    if e.B == B_PER_GPU and e.H == H and e.W == W), None)
+        if eng is not None and agg is not None:
+            mhz, tf_probe = measured_clock(eng, device)
+            if mhz:
+                line["roofline"]["clock_mhz"] = mhz
+                line["roofline"]["nominal_clock_mhz"] = NOMINAL_MHZ
+                line["roofline"]["frac_at_measured_clock"] = round(line["roofline"]["frac"] * NOMINAL_MHZ / mhz, 3)
+                line["roofline"]["conv3_1_fwd_sustained_tflops"] = tf_probe
         line["roofline"]["kernels"] = kernels
         if not opt.no_other_configs:
             # the other BASELINE configs, one GPU's share each, measured live in this very process (steady-state inner
@@ -650,7 +694,12 @@ def c2_line(line, opt, ctx, world, device, ms, mc):
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_configs
             # (C3 at one pair -- the reference's batch size -- and at 8 pairs behind one patch: SURVEY.md 8d "C3 = 1...8")
-            line["config"]["other_configs"] = [bench_configs.measure(w, 6) for w in ("c4", "c3alt", "c3altb8", "c3", "c5")]
+            others = [(w, bench_configs.measure(w, 6)) for w in ("c4", "c3alt", "c3altb8", "c3", "c5")]
+            for w, r in others:            # flat scalars first (the driver's parser keeps scalars in `config`, not nested values)
+                line["config"][f"{w}_ms"] = r["ms_per_iteration"]
+                if r.get("roofline"):
+                    line["config"][f"{w}_igemm_frac"] = r["roofline"]["frac"]
+            line["config"]["other_configs"] = [r for _, r in others]
         if step.cone is not None and not opt.no_full_frame:
             # the same protocol with every frame-sized shortcut off (UFR_CONE=0): what the windowed prefix,
             # band and incremental forward are worth, measured in this very process

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define UFR_ABI_VERSION 8   /* 8: ufr_pwc_warp_backward_owner / _workspace_bytes, ufr_raft_normalize_pair*, ufr_raft_fmap_pyramid_* (round 5); 7: the chunk-range entries of csrc/engine_small.hip take the extents of what they walk (w_chunks / g_chunks) and refuse a range that leaves it (round 5); 6: ufr_igemm_desc gained planes_chunks / f32_first_chunk; the clock probe records 8 words (round 4); 5: ufr_igemm_desc gained out_rowmajor / out_ld; ufr_igemm_clock_probe, ufr_conv1_direct, ufr_patch_paste_placed_rect (round 4); 4: ufr_igemm_desc gained tail / tail_n0 (round 3); 3: k_order (round 2) */
+#define UFR_ABI_VERSION 9   /* 9: ufr_build_manifest; ufr_igemm_desc: `products` 1 / 3 are served again (RAFT's opt-in reduced precision), `fuse_reduce` (split-K summed by the last workgroup of a tile, no second launch) (round 6); 8: ufr_pwc_warp_backward_owner / _workspace_bytes, ufr_raft_normalize_pair*, ufr_raft_fmap_pyramid_* (round 5); 7: the chunk-range entries of csrc/engine_small.hip take the extents of what they walk (w_chunks / g_chunks) and refuse a range that leaves it (round 5); 6: ufr_igemm_desc gained planes_chunks / f32_first_chunk; the clock probe records 8 words (round 4); 5: ufr_igemm_desc gained out_rowmajor / out_ld; ufr_igemm_clock_probe, ufr_conv1_direct, ufr_patch_paste_placed_rect (round 4); 4: ufr_igemm_desc gained tail / tail_n0 (round 3); 3: k_order (round 2) */
 
 enum { UFR_F32 = 0, UFR_F64 = 1, UFR_F16 = 2 };   /* UFR_F16: the spatial correlation only (generic kernels, float32 sums) */
 enum {
@@ -40,6 +40,11 @@ int ufr_abi_version(void);
 const char* ufr_last_error(void);
 /* Number of HIP devices visible to the library (0 when there is no GPU); never throws. */
 int ufr_device_count(void);
+/* Build manifest: one line "<translation unit> <md5>\n" per object of the library, where md5 is the checksum of the sources the
+ * object was COMPILED FROM (csrc/<unit>.hip + csrc/ufr_common.h + include/ufr_hip.h, concatenated in that order).  The Python
+ * binding recomputes the checksums from the tree at load and refuses a library holding an object built from other sources (round 5
+ * lost two full-suite runs to a library that differed from a clean build of the same tree without anyone being able to say where). */
+const char* ufr_build_manifest(void);
 
 /* ---- spatial correlation sampler ------------------------------------------------------------
  * replaces spatial_correlation_sampler_backend.forward / .backward

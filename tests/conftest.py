@@ -24,6 +24,33 @@ def pytest_sessionstart(session):
         __graft_entry__.build()
 
 
+_RESOURCE_LOG = [None, None]          # (file object, last test file)
+
+
+def pytest_runtest_teardown(item, nextitem):
+    """On a GPU box: one line per finished test FILE with the process's host RSS high-water and the device memory torch holds /
+    has held, appended to gpurun_out/suite_resources.log -- so that a suite that dies late (round 5: SIGABRT after 454 green tests)
+    leaves the state it had built up by then on record."""
+    if not torch.cuda.is_available():
+        return
+    this = item.fspath.basename
+    nxt = nextitem.fspath.basename if nextitem is not None else None
+    if nxt == this:
+        return
+    import resource
+    try:
+        if _RESOURCE_LOG[0] is None:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            _RESOURCE_LOG[0] = open(os.path.join(ROOT, "gpurun_out", "suite_resources.log"), "a")
+        free, total = torch.cuda.mem_get_info()
+        _RESOURCE_LOG[0].write(f"{this}: host max RSS {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2 ** 20:.2f} GiB, "
+                               f"device in use {(total - free) / 2 ** 30:.2f} GiB, torch reserved {torch.cuda.memory_reserved() / 2 ** 30:.2f} "
+                               f"(max {torch.cuda.max_memory_reserved() / 2 ** 30:.2f}) GiB\n")
+        _RESOURCE_LOG[0].flush()
+    except (OSError, RuntimeError):
+        pass
+
+
 def pytest_collection_modifyitems(config, items):
     """-m gpu tests never run without a device; nothing else may touch one."""
     if torch.cuda.is_available():

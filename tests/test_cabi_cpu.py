@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_error_channel():
     from understanding_flow_robustness_amd import _lib as L
     lib = L.lib()
-    assert lib.ufr_abi_version() == 8 == L.ABI_VERSION
+    assert lib.ufr_abi_version() == 9 == L.ABI_VERSION
     assert lib.ufr_device_count() >= 0
     # argument validation happens before any HIP call: usable without a GPU
     p = L.CorrParams(1, 1, 3, 3, 0, 0, 1, 1, 1, 1, 1, 1)
@@ -228,6 +228,42 @@ def test_engine_cache_is_bounded():
     assert len(c) == EngineCache.MAX_ENTRIES and 0 not in c and EngineCache.MAX_ENTRIES + 2 in c
     c[EngineCache.MAX_ENTRIES + 2] = "replaced"          # an existing key never evicts
     assert len(c) == EngineCache.MAX_ENTRIES
+
+
+def test_build_manifest_matches_the_tree_and_a_stale_object_is_refused(tmp_path):
+    """every object of libufr_hip.so embeds the checksum of the sources it was compiled from, `_lib.lib()`
+    recomputes them from the tree at load and refuses a library that holds an object built from other sources -- naming it.
+    (Round 5: two full-suite runs aborted on a library whose md5 differed from a clean build's; nothing could say which object.)"""
+    import shutil
+    from understanding_flow_robustness_amd import _lib as L
+    manifest = L.lib().ufr_build_manifest().decode()
+    built = dict(ln.split() for ln in manifest.splitlines())
+    want = L.source_checksums()
+    assert built == want and len(built) >= 30 and "igemm" in built and "capi" in built
+    L.verify_build(manifest)                                          # the loaded library is this tree's
+    # a tree that differs from what the library was built from: one source edited, one deleted, one added
+    csrc = tmp_path / "csrc"
+    shutil.copytree(os.path.join(ROOT, "understanding_flow_robustness_amd", "csrc"), csrc,
+                    ignore=shutil.ignore_patterns("build", "build_san"))
+    with open(csrc / "igemm.hip", "a") as f:
+        f.write("\n// an edit after the build\n")
+    with pytest.raises(RuntimeError, match=r"built from other sources: igemm\)"):
+        L.verify_build(manifest, str(csrc))
+    os.remove(csrc / "gru.hip")
+    (csrc / "new_kernel.hip").write_text("// not built yet\n")
+    with pytest.raises(RuntimeError) as e:
+        L.verify_build(manifest, str(csrc))
+    msg = str(e.value)
+    assert "built from other sources: igemm" in msg and "not in the library: new_kernel" in msg and "no longer exist: gru" in msg
+    # a shared header edit invalidates EVERY object
+    csrc2 = tmp_path / "csrc2"
+    shutil.copytree(os.path.join(ROOT, "understanding_flow_robustness_amd", "csrc"), csrc2,
+                    ignore=shutil.ignore_patterns("build", "build_san"))
+    with open(csrc2 / "ufr_common.h", "a") as f:
+        f.write("\n// changed\n")
+    with pytest.raises(RuntimeError) as e:
+        L.verify_build(manifest, str(csrc2))
+    assert all(n in str(e.value) for n in ("attack", "igemm", "window"))
 
 
 def test_graft_entry_build_runs():

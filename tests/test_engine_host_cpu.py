@@ -262,3 +262,61 @@ def test_plane_graph_lets_the_first_reader_finalise_a_segment(monkeypatch):
     g0.conv(*conv(64, 64), ("a", 0, 2), ("b", 0))
     g0.build()
     assert not any(op.get("finalized") for op in g0.ops)
+
+
+def test_igemm_host_arithmetic_runs_up_to_the_launch_without_a_device():
+    """`ufr_igemm`'s host side -- descriptor checks, the phase / tap-run tables, the split-K slicing -- on REAL descriptors of every
+    geometry the engines build (stride-1 and stride-2 convolutions, their data gradients with 1 + 2 + 2 + 4-tap phases and split-K,
+    both deconvolution launches), on a box without a GPU: the call must get as far as asking for the device and fail THERE
+    (UFR_ELAUNCH), never earlier and never by touching an operand.  This is the test `make -C csrc sanitize` (host ASan / UBSan
+    build of the library) is pointed at: a descriptor field read past its struct, a tap table overrun or an overflowing extent
+    computation aborts it."""
+    import ctypes as C
+
+    import pytest
+
+    from understanding_flow_robustness_amd import _lib as L
+    lib = L.lib()
+    if lib.ufr_device_count() > 0:
+        pytest.skip("a HIP device is present: these descriptors point at host memory and must not be launched")
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 2, 12, 20
+    x = ig.Planes(B, H, W, 4, "cpu")                                        # 128 channels
+    w3 = torch.randn(96, 128, 3, 3, generator=g)
+    w3s2 = torch.randn(128, 128, 3, 3, generator=g)
+    wd = torch.randn(128, 64, 4, 4, generator=g)
+    cases = []
+    # Conv2d(128, 96, 3, 1, 1) forward, single pass and split-K with the reduce launch behind it
+    wi = ig.conv_forward_weights(w3, 1, 1)
+    out = ig.Planes(B, H, W, 3, "cpu")
+    bias = torch.zeros(wi.Npad)
+    for variant in (2, 4, 5, 6, 7, 8):
+        cases.append(ig.make_launch(wi, x, 0, (H, W), (H, W), out_planes=out, bias=bias, variant=variant))
+    ws = torch.empty(4 * B * H * W * wi.Npad)
+    cases.append(ig.make_launch(wi, x, 0, (H, W), (H, W), out_planes=out, bias=bias, splitk=4, ws=ws, variant=6))
+    # its data gradient (stride 1) with an addend and a mask
+    wb = ig.conv_backward_weights(w3, 1, 1)
+    gy, gx = ig.Planes(B, H, W, 3, "cpu"), ig.GradSum(B, H, W, 4, "cpu")
+    cases.append(ig.make_launch(wb, gy, 0, (H, W), (H, W), out_f32=gx, add=gx, mask=x, variant=6))
+    # Conv2d(128, 128, 3, 2, 1): forward on the half grid, data gradient as four phases of 1 + 2 + 2 + 4 taps, split 3 ways
+    wf2, wb2 = ig.conv_forward_weights(w3s2, 2, 1), ig.conv_backward_weights(w3s2, 2, 1)
+    half = ig.Planes(B, H // 2, W // 2, 4, "cpu")
+    cases.append(ig.make_launch(wf2, x, 0, (H // 2, W // 2), (H // 2, W // 2), out_planes=half, bias=torch.zeros(wf2.Npad), variant=6))
+    assert sorted(len(t) for _, _, t in wb2.phases) == [1, 2, 2, 4]
+    ws2 = torch.empty(4 * 3 * B * (H // 2) * (W // 2) * wb2.Npad)
+    cases.append(ig.make_launch(wb2, half, 0, (H // 2, W // 2), (H, W), out_f32=gx, splitk=3, ws=ws2, variant=6))
+    # ConvTranspose2d(128, 64, 4, 2, 1): forward (four phases onto the fine grid) and its data gradient (16 taps, stride-2 reads)
+    wdf, wdb = ig.deconv_forward_weights(wd, 1), ig.deconv_backward_weights(wd, 1)
+    fine = ig.Planes(B, 2 * H, 2 * W, 2, "cpu")
+    cases.append(ig.make_launch(wdf, x, 0, (H, W), (2 * H, 2 * W), out_planes=fine, bias=torch.zeros(wdf.Npad), variant=2))
+    cases.append(ig.make_launch(wdb, fine, 0, (H, W), (H, W), out_f32=gx, variant=2))
+    for launch in cases:
+        rc = lib.ufr_igemm(C.byref(launch.desc), None)
+        assert rc == -3, (rc, lib.ufr_last_error())
+        assert b"no current device" in lib.ufr_last_error() or b"igemm" in lib.ufr_last_error()
+    # and the refusals in front of it
+    bad = cases[0].desc
+    keep = bad.splitk
+    bad.splitk = 65
+    assert lib.ufr_igemm(C.byref(bad), None) == -1 and b"split" in lib.ufr_last_error()
+    bad.splitk = keep

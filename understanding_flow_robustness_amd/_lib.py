@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UFR_HIP_LIB") or os.path.join(_HERE, "lib", "libufr_hip.so")   # UFR_HIP_LIB: another BUILD of the same library (same-box A/B of two kernels)
 UFR_F32, UFR_F64, UFR_F16 = 0, 1, 2
-ABI_VERSION = 8            # UFR_ABI_VERSION of include/ufr_hip.h these ctypes mirrors were written against
+ABI_VERSION = 9            # UFR_ABI_VERSION of include/ufr_hip.h these ctypes mirrors were written against
 _lib = None
 
 
@@ -208,7 +208,7 @@ SIGNATURES = {
     "ufr_conv1_direct": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _l, _i, _vp],
 }
 PLAIN = {"ufr_abi_version": (C.c_int, []), "ufr_last_error": (C.c_char_p, []),
-         "ufr_device_count": (C.c_int, []),
+         "ufr_device_count": (C.c_int, []), "ufr_build_manifest": (C.c_char_p, []),
          "ufr_conv3x3_c2_workspace_floats": (C.c_long, [_i, _i, _i, _i]),
          "ufr_cm_norm_workspace_doubles": (C.c_long, [_l, _i, _i]),
          "ufr_resample2d_backward_workspace_bytes": (C.c_long, [_i, _i, _i]),
@@ -235,8 +235,50 @@ def lib():
         if handle.ufr_abi_version() != ABI_VERSION:      # a stale .so with another ufr_igemm_desc layout would read garbage
             raise RuntimeError(f"{LIB_PATH} has ABI version {handle.ufr_abi_version()}, these bindings are written for "
                                f"{ABI_VERSION}: rebuild it (`make -C understanding_flow_robustness_amd/csrc`)")
+        verify_build(handle.ufr_build_manifest().decode("ascii", "replace"))
         _lib = handle
     return _lib
+
+
+_CSRC = os.path.join(_HERE, "csrc")
+_HEADER = os.path.join(os.path.dirname(_HERE), "include", "ufr_hip.h")
+
+
+def source_checksums(csrc: str = _CSRC, header: str = _HEADER) -> dict:
+    """{translation unit: md5 of csrc/<unit>.hip + csrc/ufr_common.h + include/ufr_hip.h}: what csrc/Makefile embeds in each object."""
+    import hashlib
+    with open(os.path.join(csrc, "ufr_common.h"), "rb") as f:
+        shared = f.read()
+    with open(header, "rb") as f:
+        shared += f.read()
+    sums = {}
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith(".hip"):
+            with open(os.path.join(csrc, name), "rb") as f:
+                sums[name[:-4]] = hashlib.md5(f.read() + shared).hexdigest()
+    return sums
+
+
+def verify_build(manifest: str, csrc: str = _CSRC, header: str = _HEADER) -> None:
+    """Refuse a library whose objects were not built from THIS tree's sources (`ufr_build_manifest`, include/ufr_hip.h): every
+    object embeds the checksum of what it was compiled from.  A stale object, a missing one or one of a deleted source raises and
+    is named.  Skipped when the sources are not there (an installed library without its tree), and when `UFR_HIP_LIB` points at
+    another build on purpose (same-box A/B of two kernels) unless UFR_HIP_LIB_VERIFY=1."""
+    if os.environ.get("UFR_HIP_LIB") and os.environ.get("UFR_HIP_LIB_VERIFY") != "1":
+        return
+    if not (os.path.isdir(csrc) and os.path.exists(header) and os.path.exists(os.path.join(csrc, "ufr_common.h"))):
+        return
+    built = dict(ln.split() for ln in manifest.splitlines() if ln.strip())
+    want = source_checksums(csrc, header)
+    stale = sorted(n for n in want if n in built and built[n] != want[n])
+    missing = sorted(n for n in want if n not in built)
+    extra = sorted(n for n in built if n not in want)
+    if stale or missing or extra:
+        what = "; ".join(s for s in (stale and f"built from other sources: {', '.join(stale)}",
+                                     missing and f"not in the library: {', '.join(missing)}",
+                                     extra and f"objects of sources that no longer exist: {', '.join(extra)}") if s)
+        raise RuntimeError(f"{LIB_PATH} does not match the sources under {csrc} ({what}): rebuild it "
+                           "(`make -C understanding_flow_robustness_amd/csrc`) before running anything on it")
 
 
 def check(rc: int, what: str = "") -> None:

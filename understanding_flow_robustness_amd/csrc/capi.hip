@@ -2,6 +2,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <string>
 #include <utility>
 
 #include "ufr_common.h"
@@ -31,7 +32,24 @@ hipError_t ensure_dynamic_lds(const void* fn, size_t bytes) {
   if (e == hipSuccess) have = bytes;
   return e;
 }
+namespace {
+std::map<std::string, std::string>& tu_table() {      // function-local: constructed before the first registrar runs
+  static std::map<std::string, std::string> t;
+  return t;
+}
+}  // namespace
+void register_tu(const char* name, const char* sum) { tu_table()[name] = sum; }
 }  // namespace ufr
+
+// "<translation unit> <md5 of its .hip + ufr_common.h + include/ufr_hip.h at compile time>\n" per object, sorted by name
+extern "C" const char* ufr_build_manifest(void) {
+  static std::string text;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const auto& kv : ufr::tu_table()) text += kv.first + " " + kv.second + "\n";
+  });
+  return text.c_str();
+}
 
 extern "C" int ufr_abi_version(void) { return UFR_ABI_VERSION; }
 extern "C" const char* ufr_last_error(void) { return ufr::err_buf(); }

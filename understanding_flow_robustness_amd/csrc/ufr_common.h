@@ -20,6 +20,14 @@ inline hipStream_t as_stream(ufr_stream_t s) { return reinterpret_cast<hipStream
 // had to be done.
 hipError_t ensure_dynamic_lds(const void* fn, size_t bytes);
 
+// Build manifest (capi.hip, `ufr_build_manifest()`): every translation unit registers, at load, the checksum of the sources it was
+// COMPILED FROM (its .hip + this header + include/ufr_hip.h; the Makefile passes it as -DUFR_TU_SUM).  _lib.py recomputes the
+// checksums from the tree and refuses a library that holds an object built from other sources.
+void register_tu(const char* name, const char* sum);
+struct TuRegistrar {
+  TuRegistrar(const char* name, const char* sum) { register_tu(name, sum); }
+};
+
 // Post-launch check: launch-configuration errors surface here; nothing is synchronised.
 inline int launched(const char* what) {
   hipError_t e = hipGetLastError();
@@ -56,6 +64,12 @@ int corr_bwd_mfma_launch(const float* in1, const float* in2, const float* gout, 
 void loss_finalize_launch(const float* partials, int n, float* loss, hipStream_t st);
 
 }  // namespace ufr
+
+#if defined(UFR_TU_NAME) && defined(UFR_TU_SUM)
+namespace {
+const ufr::TuRegistrar ufr_tu_registrar(UFR_TU_NAME, UFR_TU_SUM);
+}
+#endif
 
 #define UFR_REQUIRE(cond, ...) \
   do {                         \
