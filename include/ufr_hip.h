@@ -111,6 +111,23 @@ int ufr_altcorr_pyramid_backward_cm(const float* fmap1, const ufr_altcorr_levels
                                     float* fmap1_grad, void* workspace, int B, int H1, int W1, int C, int radius, float scale,
                                     int accumulate, ufr_stream_t stream);
 long ufr_altcorr_pyramid_workspace_bytes(int B, int H1, int W1, int C, int radius, int num_levels);
+/* The lookup on the bf16 matrix cores with float32 accuracy (ABI 9, csrc/raft_altcorr_planes.hip; same values as
+ * ufr_altcorr_pyramid_forward to float32 summation order): the feature maps as bf16 split planes [3][C / 32][pixels][32] (the igemm's
+ * activation layout, v = p0 + p1 + p2 exactly), made ONCE per forward by ufr_altcorr_planes_prepare from the NHWC float32 maps
+ * [pixels][C] (they are constant over RAFT's 12 lookups, models/raft/corr.py:111-119); a workgroup owns 8 x 16 pixels of one level and
+ * stages the bounding box of their windows through LDS once (any coordinate field is handled; a discontinuous one walks a larger box).
+ * coords: planar [B, 2, H1, W1]; out: [B, L (2r+1)^2, H1, W1] = scale * the stacked per-level volumes.  C in {128, 256}, radius in {3, 4}. */
+typedef struct {
+  int num_levels;
+  const void* planes[4];                       /* fmap2 level l: bf16 [3][C / 32][B * H2 * W2][32] */
+  long plane_stride[4];                        /* elements between two planes of level l */
+  int H2[4], W2[4];
+  float coord_scale[4];
+} ufr_altcorr_plane_levels;
+int ufr_altcorr_planes_prepare(const float* fmap_nhwc, void* planes, long plane_stride, long npix, int C, ufr_stream_t stream);
+int ufr_altcorr_planes_forward(const void* fmap1_planes, long fmap1_plane_stride, const ufr_altcorr_plane_levels* levels,
+                               const float* coords, float* out, int B, int H1, int W1, int C, int radius, float scale,
+                               ufr_stream_t stream);
 
 /* ---- RAFT all-pairs pyramid lookup -----------------------------------------------------------
  * replaces CorrBlock.__call__ (models/raft/corr.py:72-96): per level a (2r+1)^2 bilinear window
@@ -599,7 +616,11 @@ typedef struct {
                                                   takes back as `add` (with act = 1: LeakyReLU(acc + add + bias)); tail_accumulate != 0
                                                   adds the sums onto the tensor (a gradient sum with other contributors) */
   int splitk; float* ws;
-  int products;                                /* 6: the float32-accurate six-product form (the only one) */
+  int products;                                /* 6: the float32-accurate six-product form (the default everywhere); (ABI 9) 3 / 1: the leading three
+                                                  products a0b0 + a0b1 + a1b0 (two planes per operand, ~16 significand bits) / the single product
+                                                  a0b0 (one bf16 plane per operand: what an autocast to bfloat16 computes) -- RAFT's opt-in reduced
+                                                  precision (models/utils_model.py:51 `mixed_precision`, models/raft/raft.py:140,168,195), served
+                                                  by the single-stage, 64 x 128 and ping-pong tile forms (variants 5 / 7 / 8 run as 6 / 2) */
   int variant;                                 /* kernel form: 0 / 2 = single-stage LDS-DMA tiles (128 x 128; 128 x 64 when Npad % 128),
                                                   4 = 64 x 128 tiles, 5 = pipelined 128 x 128 (register-held fragments),
                                                   6 = ping-pong: 256 x 128 tiles, two wave groups half a step apart,
@@ -618,6 +639,12 @@ typedef struct {
                                                   [splitk][B*Hr*Wr][Npad] for a consumer that adds them itself in ascending order and then
                                                   the bias (ufr_gru_gates_cm_forward_slabs / ufr_gru_blend_cm_forward_slabs): the epilogue
                                                   fields are not used */
+  int* tickets;                                /* (ABI 9) split-K without the second launch: one zero-initialised int per (phase, row tile, column tile)
+                                                  -- at least nphase * ceil(B*Hr*Wr / 64) * (Npad / 64) of them, owned by THIS launch (two launches
+                                                  in flight on two streams must not share them).  Every slice's workgroup writes its slab, publishes
+                                                  it (agent-scope release) and draws a ticket; the workgroup that draws the last one of its tile adds
+                                                  the tile's slabs in ascending slice order -- the reduce kernel's arithmetic bit for bit -- runs the
+                                                  epilogue and leaves the counter at zero for the next launch.  NULL: the reduce kernel follows. */
 } ufr_igemm_desc;
 int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream);
 /* Measurement aid (tools/measure_clock.py): with a device buffer of 8 x capacity_workgroups uint64 set, every workgroup of the

@@ -269,3 +269,105 @@ def test_accuracy_matches_fp32_against_float64():
     e_fp32 = float((fp32.double() - truth).abs().max()) / scale
     print(f"six-product split {e_mine:.2e}, torch fp32 {e_fp32:.2e} of max |out|")
     assert e_mine <= max(3 * e_fp32, 3e-6)
+
+
+@pytest.mark.parametrize("case", ["conv6_1 forward", "stride-2 data gradient", "gru gates at 48x160"])
+def test_fused_split_k_reduction_is_bit_identical_to_the_reduce_launch(case):
+    """Round 6: with `tickets` the last workgroup to arrive at a tile adds the tile's slabs in ascending slice
+    order and runs the epilogue -- no second launch.  Same slabs, same order, same epilogue code (`sum_slabs`, `epilogue_store8`):
+    every bit of the result equals the slab kernel + `igemm_reduce_kernel` form, on every replay (the last arriver leaves the counters
+    at zero), for a forward launch with bias + LeakyReLU -> planes, a four-phase stride-2 data gradient with unequal slices per
+    phase + addend + mask -> fp32, and the GRU's 1 x 5 gate convolution on RAFT's 48 x 160 grid (30 - 120 tiles of 4 - 8 slices)."""
+    ig = _mods()
+    if case == "conv6_1 forward":
+        B, Cn, H, W = 2, 512, 6, 20
+        x, w, b = _rand(B, Cn, H, W, seed=1), _rand(Cn, Cn, 3, 3, seed=2, scale=0.02), _rand(Cn, seed=3)
+        xin = ig.Planes(B, H, W, Cn // 32, DEV).load_nchw(x)
+        wi = ig.conv_forward_weights(w, 1, 1)
+        S = max(4, ig.splitk_for(B * H * W, wi.Npad, 9 * wi.KC))
+        mk = lambda fuse, ws: (lambda out: (ig.make_launch(wi, xin, 0, (H, W), (H, W), out_planes=out, bias=b, splitk=S, ws=ws, fuse_reduce=fuse), out))(
+            ig.Planes(B, H, W, Cn // 32, DEV))
+        read = lambda out: out.t.clone()
+        rows, nph = B * H * W, 1
+        want = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), 1, 1), 0.1)
+        check = lambda out: _close(out.to_nchw(Cn), want, case)
+    elif case == "stride-2 data gradient":
+        B, Cin, Cout, H, W, S = 2, 70, 130, 24, 40, 3
+        w, gy = _rand(Cout, Cin, 3, 3, seed=2, scale=0.05), _rand(B, Cout, H // 2, W // 2, seed=4)
+        act, addv = _rand(B, Cin, H, W, seed=5), _rand(B, Cin, H, W, seed=6)
+        gyp = ig.Planes(B, H // 2, W // 2, ig.pad32(Cout) // 32, DEV).load_nchw(gy)
+        maskp = ig.Planes(B, H, W, ig.pad32(Cin) // 32, DEV).load_nchw(act)
+        wi = ig.conv_backward_weights(w, 2, 1)
+        nch = ig.pad32(Cin) // 32
+
+        addcm = ig.Planes(B, H, W, nch, DEV).load_nchw(addv).t.float().sum(0)
+
+        def mk(fuse, ws):          # the addend IS the output (an in-place accumulation, as RAFT's encoder and GRU adjoints run it):
+            out = ig.GradSum(B, H, W, nch, DEV)     # a reduction that ran twice would add it twice
+            return ig.make_launch(wi, gyp, 0, (H // 2, W // 2), (H, W), out_f32=out, add=out, mask=maskp, splitk=S, ws=ws, fuse_reduce=fuse), out
+        reset = lambda out: out.t.copy_(addcm.view_as(out.t))
+        read = lambda out: out.t.clone()
+        rows, nph = B * (H // 2) * (W // 2), 4
+        x0 = torch.zeros(B, Cin, H, W, device=DEV, dtype=torch.float64, requires_grad=True)
+        (gx,) = torch.autograd.grad(F.conv2d(x0, w.double(), None, 2, 1), x0, gy.double())
+        want = (gx + addv.double()) * torch.where(act > 0, 1.0, 0.1).double()
+        check = lambda out: _close(out.to_nchw(Cin), want, case)
+    else:
+        B, Cn, H, W, S = 1, 256, 48, 160, 5
+        x, w, b = _rand(B, Cn, H, W, seed=1), _rand(256, Cn, 1, 5, seed=2, scale=0.03), _rand(256, seed=3)
+        xin = ig.Planes(B, H, W, Cn // 32, DEV).load_nchw(x)
+        wi = ig.conv_forward_weights(w, 1, (0, 2))
+        mk = lambda fuse, ws: (lambda out: (ig.make_launch(wi, xin, 0, (H, W), (H, W), out_f32=out, bias=b, slope=1.0, splitk=S, ws=ws, fuse_reduce=fuse), out))(
+            ig.GradSum(B, H, W, 8, DEV))
+        read = lambda out: out.t.clone()
+        rows, nph = B * H * W, 1
+        want = F.conv2d(x.double(), w.double(), b.double(), 1, (0, 2))
+        check = lambda out: _close(out.to_nchw(256, slope=1.0), want, case)
+    ws_a = torch.empty(nph * S * rows * wi.Npad, device=DEV)
+    ws_b = torch.empty_like(ws_a)
+    two_launches, out_two = mk(False, ws_a)
+    fused, out_fused = mk(True, ws_b)
+    assert two_launches.desc.tickets is None and fused.desc.tickets
+    if case != "stride-2 data gradient":
+        reset = lambda out: out.t.zero_()
+    reset(out_two)
+    two_launches()
+    ref = read(out_two)
+    check(out_two)
+    tickets = next(t for t in fused._keep if torch.is_tensor(t) and t.dtype == torch.int32)
+    for replay in range(3):
+        reset(out_fused)
+        ws_b.fill_(float("nan"))                                  # nothing stale can pass for a slab
+        fused()
+        assert torch.equal(read(out_fused), ref), f"{case}: replay {replay} differs from the slab kernel + reduce launch"
+        assert int(tickets.abs().sum()) == 0, "the last arrivers left their counters non-zero"
+
+
+@pytest.mark.parametrize("products", [3, 1])
+def test_reduced_products_are_exactly_the_leading_bf16_products(products):
+    """RAFT's opt-in reduced precision (`products` 1 / 3, ABI 9; models/utils_model.py:51, models/raft/raft.py:140,168,195 run the
+    reference's convolutions under fp16 autocast): ONE product = the convolution of the bf16-ROUNDED operands with float32
+    accumulation (what a bfloat16 autocast computes); THREE = a0b0 + a0b1 + a1b0 = (a0 + a1)(b0 + b1) - a1 b1.  Both pinned against
+    float64 evaluations of exactly those expressions (so the form cannot silently drop or add a product), and their distance from
+    the float32 convolution printed: ~2^-9 and ~2^-17 of the result's scale."""
+    ig = _mods()
+    B, Cin, Cout, H, W = 1, 256, 128, 24, 40
+    x, w, b = _rand(B, Cin, H, W, seed=1), _rand(Cout, Cin, 3, 3, seed=2, scale=0.03), _rand(Cout, seed=3)
+    xin = ig.Planes(B, H, W, Cin // 32, DEV).load_nchw(x)
+    out = ig.GradSum(B, H, W, Cout // 32, DEV)
+    S = 2
+    ws = torch.empty(S * B * H * W * 128, device=DEV)
+    for kw in ({}, dict(splitk=S, ws=ws)):
+        ig.make_launch(ig.conv_forward_weights(w, 1, 1), xin, 0, (H, W), (H, W), out_f32=out, bias=b, slope=1.0, products=products, **kw)()
+        got = out.to_nchw(Cout, slope=1.0).double()
+        conv = lambda a, c: F.conv2d(a.double(), c.double(), None, 1, 1)
+        x0, w0 = x.bfloat16().float(), w.bfloat16().float()
+        x1, w1 = (x - x0).bfloat16().float(), (w - w0).bfloat16().float()
+        want = conv(x0, w0) if products == 1 else conv(x0 + x1, w0 + w1) - conv(x1, w1)
+        want = want + b.double().view(1, -1, 1, 1)
+        full = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+        scale = float(full.abs().max())
+        e_form, e_full = float((got - want).abs().max()) / scale, float((got - full).abs().max()) / scale
+        print(f"{products} product(s): {e_form:.2e} from its own expression, {e_full:.2e} from the float32 convolution (of max |out|)")
+        assert e_form <= 3e-6
+        assert e_full <= (2e-2 if products == 1 else 1e-4)

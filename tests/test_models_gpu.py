@@ -75,6 +75,7 @@ def _attack_check(z, net, args, key, lr, iters, tol=1e-4):
     ref, shown = t(z[key]), (t(z["mask"]) != 0).float()
     upd = float(((ref - t(z["patch0"])) * shown).abs().max())
     err = float(((patch.cpu() - ref) * shown).abs().max())
+    print(f"{args.flownet} attack golden ({key}): patch error {err:.3e} at an update of {upd:.3e} = {err / max(upd, 1.0):.2e} (gate {tol:.0e})")
     assert err <= tol * max(upd, 1.0), f"patch err {err:.3e} vs update {upd:.3e}"
 
 
@@ -102,7 +103,7 @@ def test_raft_vs_reference(alternate, frozen):
         # the worst entry is the conditioning's (5e-2); the bulk is gated 30x tighter (measured: median 8e-6 .. 2.3e-4, 90 % within
         # 4e-5 .. 1.2e-3 over the four legs -- the largest is the alt_corr + engines leg's ReLU flip, test_raft_gradient_against_float64_truth)
         _check(z, net, args, gtol=5e-2, g_atol=5e-2, bulk=(1e-3, 5e-3))
-    _attack_check(z, net, args, "attack_it2_patch", 1e4, 2, tol=5e-2)
+    _attack_check(z, net, args, "attack_it2_patch", 1e4, 2, tol=5e-3)     # (round 6: 5e-2 -> 5e-3; the measured value is printed)
 
 
 @FROZEN

@@ -284,6 +284,50 @@ def test_altcorr_pyramid_on_the_matrix_cores_vs_oracle(oracle, B, H, W, C, r, sp
         assert_close(f2d[i].grad, want2[i], rtol=1e-4, atol_scale=1e-5, what=f"d / d fmap2 level {i}")
 
 
+@pytest.mark.parametrize("B,H,W,C,r,spread", [(1, 48, 160, 256, 4, 3.0), (2, 24, 40, 128, 3, 0.4), (1, 16, 40, 256, 4, 40.0),
+                                                (1, 8, 21, 128, 4, 3.0), (2, 21, 37, 256, 3, 12.0), (1, 48, 160, 256, 4, 0.0)])
+def test_altcorr_lookup_on_split_planes_vs_oracle(oracle, B, H, W, C, r, spread):
+    """Round 6: the lookup on the bf16 matrix cores with float32 accuracy (csrc/raft_altcorr_planes.hip: three bf16 planes per
+    operand, six products, an 8 x 16 pixel tile sharing the bounding box of its windows through LDS) against the CPU oracle level by
+    level AND against round 3's exact-fp32 matrix-core kernel -- smooth, wild (multi-strip boxes, windows far outside the image),
+    zero flow, sides that are not multiples of the 8 x 16 tile, two samples, both channel counts and radii; then coordinates that
+    are not finite (the reference's kernel reads garbage there; this kernel returns zeros for such a pixel and leaves every other
+    pixel untouched)."""
+    import math
+    from understanding_flow_robustness_amd import _lib as L
+    from understanding_flow_robustness_amd.flownets.raft_corr import AltCorrPlanes, AltCorrPyramidFunction
+    g = torch.Generator().manual_seed(B * 1000 + H + int(spread))
+    nl = 4 if H % 8 == 0 else 2
+    f1 = torch.randn(B, H, W, C, generator=g)
+    f2s = [torch.randn(B, max(H >> i, 1), max(W >> i, 1), C, generator=g) for i in range(nl)]
+    xs = torch.arange(W).float().view(1, 1, 1, W).expand(B, 1, H, W)
+    ys = torch.arange(H).float().view(1, 1, H, 1).expand(B, 1, H, W)
+    coords = (torch.cat([xs, ys], 1) + spread * torch.randn(B, 2, H, W, generator=g)).contiguous()
+    scale, rd = 1.0 / math.sqrt(C), 2 * r + 1
+    f1d, f2d = f1.to(DEV), [f.to(DEV) for f in f2s]
+    assert AltCorrPlanes.served(f1d, f2d, r)
+    planes = AltCorrPlanes(f1d, f2d)
+    # the planes ARE the maps: p0 + p1 + p2 == v exactly, in the igemm's chunk-major layout
+    p0 = planes.maps[0][0].float().sum(0).view(C // 32, B * H * W, 32).permute(1, 0, 2).reshape(B, H, W, C)
+    assert torch.equal(p0, f1d)
+    out = planes.forward(coords.to(DEV), r, scale)
+    old = AltCorrPyramidFunction.apply(f1d, coords.to(DEV), r, scale, None, *f2d)
+    for i in range(nl):
+        ci = (coords.permute(0, 2, 3, 1) / 2 ** i).reshape(B, 1, H, W, 2).contiguous()
+        (ref,) = oracle.altcorr_forward(f1, f2s[i], ci, r)
+        assert_close(out[:, i * rd * rd:(i + 1) * rd * rd], ref.squeeze(1) * scale, rtol=1e-4, atol_scale=2e-6, what=f"level {i} forward (split planes)")
+    assert_close(out, old, rtol=1e-4, atol_scale=2e-6, what="split planes vs the exact-fp32 matrix-core kernel")
+    bad = coords.clone().to(DEV)
+    bad[0, 0, 0, 0], bad[0, 1, H - 1, W - 1], bad[-1, 0, H // 2, W // 2] = float("nan"), float("inf"), -float("inf")
+    o2, old2 = planes.forward(bad, r, scale), AltCorrPyramidFunction.apply(f1d, bad, r, scale, None, *f2d)
+    assert bool(torch.isfinite(o2).all())
+    ok = torch.ones(B, 1, H, W, dtype=torch.bool, device=DEV)
+    for bb, yy, xx in ((0, 0, 0), (0, H - 1, W - 1), (B - 1, H // 2, W // 2)):
+        assert float(o2[bb, :, yy, xx].abs().max()) == 0.0
+        ok[bb, 0, yy, xx] = False
+    assert_close(o2 * ok, torch.where(ok, old2, torch.zeros_like(old2)), rtol=1e-4, atol_scale=2e-6, what="non-finite coordinates: the other pixels")
+
+
 # ---------------------------------------------------------------------------- CorrBlock lookup
 def test_lookup_matches_corrblock_golden_and_oracle(ops, oracle):
     from understanding_flow_robustness_amd.flownets.raft_corr import corr_lookup

@@ -110,7 +110,58 @@ def test_raft_attack_at_full_size_engine_vs_torch_spelling(raft, monkeypatch, al
     print(f"RAFT alt={alternate} 384x1280, one iteration, of the update: engines vs float64 {e_eng:.2e}, torch spelling vs float64 "
           f"{e_torch:.2e}, engines vs torch spelling {e_same:.2e}; loss {lf:.6f} / {le:.6f}")
     assert nf == ne == 1 and abs(lf - le) <= 1e-5 and 0.3 < upd < 1.9
-    assert e_eng <= max(1.5 * e_torch, 1e-3) and e_same <= 1e-2
+    # round 6: the gates at what is measured (engines vs float64 4.8e-5 all-pairs / 1.4e-4 alt_corr, torch spelling 1.4e-3;
+    # engines vs torch spelling 1.4e-3) instead of round 5's 1e-3 / 1e-2
+    assert e_eng <= max(1.5 * e_torch, 3e-4) and e_same <= 3e-3
+
+
+@pytest.mark.parametrize("mode,products", [("bf16", 1), ("bf16x3", 3)])
+def test_raft_reduced_precision_is_an_explicit_opt_in(raft, monkeypatch, mode, products):
+    """The reference runs RAFT's encoders and update block under fp16 autocast whenever `args.mixed_precision` is set
+    (models/utils_model.py:51, models/raft/raft.py:140,168,195).  Here the flag ALONE changes nothing (float32, bit for bit);
+    together with UFR_RAFT_PRECISION=bf16 the engines' convolutions take ONE bf16 product per float32 product (bf16x3: three), the
+    correlation stays float32.  Gate of the reduced forms against the float32 engines: flow within 3e-2 of max |flow| for one product
+    (measured 1.5e-2 at 256 x 512 with random-init weights: bfloat16 keeps 8 significand bits where the reference's float16 autocast
+    keeps 11, so its ~1e-2 becomes ~1.5e-2 through 12 iterations), 1e-4 for three; the image gradient is reported."""
+    import copy as _copy
+    net, _ = raft
+    net = _copy.deepcopy(net)
+    H, W = 256, 512
+    g = torch.Generator().manual_seed(23)
+    i1, i2 = (torch.rand(1, 3, H, W, generator=g) * 255).to(DEV), (torch.rand(1, 3, H, W, generator=g) * 255).to(DEV)
+    go = torch.randn(1, 2, H, W, generator=g).to(DEV)
+
+    def run():
+        a, b = i1.clone().requires_grad_(True), i2.clone().requires_grad_(True)
+        flow = net(a, b, test_mode=True)[1]
+        ga, gb = torch.autograd.grad(flow, (a, b), go)
+        return flow.detach().clone(), ga.clone(), gb.clone()
+
+    monkeypatch.delenv("UFR_RAFT_PRECISION", raising=False)
+    net.args.mixed_precision = False
+    assert net.products() == 6
+    f32 = run()
+    net.args.mixed_precision = True                                   # the flag alone: still float32, the very same engines
+    assert net.products() == 6
+    flag_only = run()
+    assert all(torch.equal(x, y) for x, y in zip(f32, flag_only))
+    monkeypatch.setenv("UFR_RAFT_PRECISION", mode)
+    assert net.products() == products
+    low = run()
+    net.args.mixed_precision = False                                  # the environment alone: float32 as well
+    assert net.products() == 6
+    assert all(torch.equal(x, y) for x, y in zip(f32, run()))
+    keys = [k for m in net.modules() for a in ("_ufr_head_engines", "_ufr_encoder_engines") for k in m.__dict__.get(a, {})]
+    assert {k[-1] for k in keys} == {6, products}, "the reduced-precision forward did not build its own engines"
+    e_flow, e_g = _rel(low[0], f32[0]), max(_rel(low[1], f32[1]), _rel(low[2], f32[2]))
+    print(f"RAFT {H}x{W}, UFR_RAFT_PRECISION={mode} ({products} product(s)) against the float32 engines: flow {e_flow:.2e} of max |flow|, "
+          f"image gradient {e_g:.2e} of its maximum")
+    assert e_flow <= (3e-2 if products == 1 else 1e-4)
+    assert e_flow > 1e-7, "the reduced form computed the float32 result: the switch did nothing"
+    monkeypatch.setenv("UFR_RAFT_PRECISION", "fp16")
+    net.args.mixed_precision = True
+    with pytest.raises(ValueError):
+        net.products()
 
 
 @pytest.mark.parametrize("rows_hw,cols,chunk0,scale", [((10, 10), 70, 1, 1.0), ((16, 24), 384, 0, 0.0625), ((1, 256), 7680, 0, 1.0)])

@@ -79,7 +79,8 @@ def timed(step, steps):
 def patch_case(name, flownet, seed, B, H, W, steps, **extra):
     args = Namespace(flownet=flownet, l2=False, alpha=0.0, lr=1000.0, max_count=2, **extra)
     net = fetch_model(args, synthetic_seed=seed).to(DEV)
-    args.mixed_precision = False
+    # float32 unless the caller opts into RAFT's reduced precision with UFR_RAFT_PRECISION=bf16 | bf16x3 (flownets/raft.py)
+    args.mixed_precision = os.environ.get("UFR_RAFT_PRECISION", "fp32").lower() not in ("fp32", "float32")
     g = torch.Generator().manual_seed(0)
     tgt, ref = torch.rand(B, 3, H, W, generator=g).to(DEV), torch.rand(B, 3, H, W, generator=g).to(DEV)
     if B > 1:          # one patch in patch coordinates behind the B pairs
@@ -98,6 +99,8 @@ def patch_case(name, flownet, seed, B, H, W, steps, **extra):
     step.run(0)
     ms = timed(step, steps)
     mem = torch.cuda.max_memory_allocated() / 2 ** 30
+    if flownet == "RAFT":
+        name += f" [{net.products()} product(s) per float32 product]" if net.products() != 6 else ""
     return dict(config=name, pairs=B, ms_per_iteration=round(ms, 3), attack_iters_per_s=round(B * 1e3 / ms, 2),
                 peak_mem_gib=round(mem, 2), roofline=igemm_roofline(net))
 

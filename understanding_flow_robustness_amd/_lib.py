@@ -43,6 +43,12 @@ class AltCorrLevels(C.Structure):
                 ("H2", C.c_int * 4), ("W2", C.c_int * 4), ("coord_scale", C.c_float * 4)]
 
 
+class AltCorrPlaneLevels(C.Structure):
+    """ufr_altcorr_plane_levels (include/ufr_hip.h)."""
+    _fields_ = [("num_levels", C.c_int), ("planes", C.c_void_p * 4), ("plane_stride", C.c_long * 4),
+                ("H2", C.c_int * 4), ("W2", C.c_int * 4), ("coord_scale", C.c_float * 4)]
+
+
 UFR_IGEMM_MAX_TAPS = 25
 
 
@@ -72,7 +78,8 @@ class IgemmDesc(C.Structure):
                 ("splitk", C.c_int), ("ws", C.c_void_p),
                 ("products", C.c_int), ("variant", C.c_int), ("k_order", C.c_int),
                 ("out_rowmajor", C.c_void_p), ("out_ld", C.c_long),
-                ("planes_chunks", C.c_int), ("f32_first_chunk", C.c_int), ("no_reduce", C.c_int)]
+                ("planes_chunks", C.c_int), ("f32_first_chunk", C.c_int), ("no_reduce", C.c_int),
+                ("tickets", C.c_void_p)]
 
 
 UFR_MAX_CONE_LAYERS = 8
@@ -205,6 +212,8 @@ SIGNATURES = {
     "ufr_kitti_flow_decode": [_vp, _vp, _i, _i, _vp],
     "ufr_host_png_unfilter": [_vp, _vp, _i, _i, _i],
     "ufr_igemm_clock_probe": [_vp, _i],
+    "ufr_altcorr_planes_prepare": [_vp, _vp, _l, _l, _i, _vp],
+    "ufr_altcorr_planes_forward": [_vp, _l, C.POINTER(AltCorrPlaneLevels), _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
     "ufr_conv1_direct": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _l, _i, _vp],
 }
 PLAIN = {"ufr_abi_version": (C.c_int, []), "ufr_last_error": (C.c_char_p, []),

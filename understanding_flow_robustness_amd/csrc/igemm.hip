@@ -212,14 +212,77 @@ struct Args {
   int korder;                        // K tile kt = tap * KC + chunk (0) or chunk * ntaps + tap (1: a pixel's taps back to back)
   int per_k, sk[4], zoff[4];         // K tiles per slice; slices of each phase; first slice (z) of each phase
   float* ws;                         // split-K slabs [sum of sk][M][Npad]
+  int* tickets;                      // fused split-K reduction: one arrival counter per (phase, row tile, column tile), zero between launches
   Phase ph[4];
 };
 
+// The split-K sum of eight consecutive columns of one row: slabs `src + s * sstride`, s = 0 .. S - 1, added in ASCENDING order onto
+// zero (the slabs of up to eight slices are requested before the first is added: a deep split on a tiny grid -- 16 .. 32 slabs of a
+// 7 x 16 grid -- was a chain of dependent loads, ~0.5 us each; the order of the additions, and with it every bit of the sum, stays).
+// Shared by igemm_reduce_kernel and the fused reduction of igemm_write_out: the two forms are bit-identical by construction.
+__device__ __forceinline__ void sum_slabs(const float* src, long sstride, int S, float (&v)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = 0.f;
+  int s = 0;
+  for (; s + 8 <= S; s += 8) {       // (eight where the split has them: a split of 6 - 8 on RAFT's 48 x 160 grids was two round trips)
+    float4 lo[8], hi[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      lo[u] = *reinterpret_cast<const float4*>(src + (s + u) * sstride);
+      hi[u] = *reinterpret_cast<const float4*>(src + (s + u) * sstride + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      v[0] += lo[u].x; v[1] += lo[u].y; v[2] += lo[u].z; v[3] += lo[u].w; v[4] += hi[u].x; v[5] += hi[u].y; v[6] += hi[u].z; v[7] += hi[u].w;
+    }
+  }
+  if (S - s >= 5) {                  // 5 .. 7 left: all of them together (the loads past the last slice repeat it, their values are not added)
+    float4 lo[7], hi[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int su = min(s + u, S - 1);
+      lo[u] = *reinterpret_cast<const float4*>(src + su * sstride);
+      hi[u] = *reinterpret_cast<const float4*>(src + su * sstride + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 7; ++u)
+      if (s + u < S) {
+        v[0] += lo[u].x; v[1] += lo[u].y; v[2] += lo[u].z; v[3] += lo[u].w; v[4] += hi[u].x; v[5] += hi[u].y; v[6] += hi[u].z; v[7] += hi[u].w;
+      }
+    s = S;
+  }
+  for (; s + 4 <= S; s += 4) {
+    float4 lo[4], hi[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      lo[u] = *reinterpret_cast<const float4*>(src + (s + u) * sstride);
+      hi[u] = *reinterpret_cast<const float4*>(src + (s + u) * sstride + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v[0] += lo[u].x; v[1] += lo[u].y; v[2] += lo[u].z; v[3] += lo[u].w; v[4] += hi[u].x; v[5] += hi[u].y; v[6] += hi[u].z; v[7] += hi[u].w;
+    }
+  }
+  for (; s < S; ++s) {
+    const float4 lo = *reinterpret_cast<const float4*>(src + s * sstride), hi = *reinterpret_cast<const float4*>(src + s * sstride + 4);
+    v[0] += lo.x; v[1] += lo.y; v[2] += lo.z; v[3] += lo.w; v[4] += hi.x; v[5] += hi.y; v[6] += hi.z; v[7] += hi.w;
+  }
+}
+
 // Accumulators -> memory: split-K slabs, or the fused epilogue through an LDS transpose (a lane owns 8 consecutive
 // channels of one pixel: 16-byte plane / fp32 stores; row stride 68 floats is conflict-free both ways).
-template <int NPL, int MT>
-__device__ __forceinline__ void igemm_write_out(const Args& a, const Phase& ph, f32x4 (&acc)[MT][4], float* lds_f32, int z, int bm,
-                                                int bn, int wrow, int wcol, int lane, int wave) {
+//
+// Split-K WITHOUT a second launch (a.tickets, round 6; the recipe of cdna_hip_programming.md 5 "in-launch split-K reduction"): every
+// slice's workgroup stores its slab with plain stores, drains them, and after the workgroup's barrier ONE lane publishes them with an
+// agent-scope release and draws a ticket of the tile's counter; the workgroup that draws the LAST ticket of its (phase, tile) acquires
+// (one lane, agent scope), and all of its waves add the tile's slabs in ascending slice order through `sum_slabs` -- the reduce kernel's
+// arithmetic, bit for bit -- and run the epilogue.  Correct for any placement of a tile's slices over CUs / XCDs; xcd_tile keeps them on one
+// XCD (speed only).  The last arriver leaves the counter at zero: the next launch of this descriptor (a graph replay) starts clean.
+// WGR = rows of the workgroup's tile (the ping-pong forms: 256 = both groups), bm0 = its first row, `flag` = an int of the EXISTING
+// LDS array (a second __shared__ object beside an LDS-DMA staging array can de-pipeline the K loop).
+template <int NPL, int MT, int WGR, int BNT>
+__device__ __forceinline__ void igemm_write_out(const Args& a, const Phase& ph, f32x4 (&acc)[MT][4], float* lds_f32, int* flag, int z, int phase,
+                                                int tile_id, int bm0, int bm, int bn0, int bn, int wrow, int wcol, int lane, int wave) {
   // C/D layout of the 16x16 forms: col = lane & 15, row = (lane >> 4) * 4 + reg
   if (a.splitk > 1) {
     float* slab = a.ws + (long)z * a.g.M * a.Npad;
@@ -233,6 +296,35 @@ __device__ __forceinline__ void igemm_write_out(const Args& a, const Phase& ph, 
           for (int n = 0; n < 4; ++n) slab[(long)row * a.Npad + bn + wcol + n * 16 + (lane & 15)] = acc[m][n][j];
         }
       }
+    if (!a.tickets) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every wave: its slab stores have left
+    __syncthreads();                                                // (also: every wave is done with the K loop's LDS images)
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");            // publish the workgroup's slab (writes back this XCD's L2)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (keep: ROCm 7.2 can drop the fence's own wait)
+      const int S = a.sk[phase];
+      const int t = __hip_atomic_fetch_add(a.tickets + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = t == S - 1;
+      if (last) {
+        __hip_atomic_store(a.tickets + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every slice has arrived: clean for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    // the last arriver: rows [bm0, bm0 + WGR) x columns [bn0, bn0 + BNT) of this phase, a thread = (row, 8 columns)
+    const float* base = a.ws + (long)a.zoff[phase] * a.g.M * a.Npad;
+    const long sstride = (long)a.g.M * a.Npad;
+    const int S = a.sk[phase];
+    for (int it = threadIdx.x; it < WGR * (BNT / 8); it += blockDim.x) {
+      const int r = it / (BNT / 8), n0 = bn0 + (it - r * (BNT / 8)) * 8, row = bm0 + r;
+      if (row >= a.g.M || n0 >= a.e.Nchunks32 * 32) continue;
+      float v[8];
+      sum_slabs(base + (long)row * a.Npad + n0, sstride, S, v);
+      epilogue_store8(a.e, out_pixel(a.g, row, ph.oy0, ph.ox0), n0, v);
+    }
     return;
   }
   {
@@ -293,14 +385,18 @@ __device__ __forceinline__ void glds16(const __bf16* src, __bf16* lds_wave_base)
 // workgroups to cover it.  A second activation image (72 KB of LDS) gives the operand that misses L2 a whole step to
 // arrive.  ~210 VGPRs: two workgroups per CU.  Measured on one box (profiles/r2_igemm_layers_v5_*.txt): 8-17 % per layer.
 // BUF_: activation rows through a raw buffer resource (see igemm_pp_kernel)
-template <int BM_, int BN_, bool PIPE_ = false, bool BUF_ = false>
+// NP_ = products per float32 product: 6 (three planes per operand, float32-accurate), 3 (a0b0 + a0b1 + a1b0: two planes) or 1 (a0b0: one
+// bf16 plane per operand -- RAFT's opt-in reduced precision); the planes a form does not multiply are not staged either.
+template <int BM_, int BN_, bool PIPE_ = false, bool BUF_ = false, int NP_ = 6>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE_ ? 2 : (BM_ == 64 ? 4 : 3), PIPE_ ? 2 : (BM_ == 64 ? 4 : 3)))) void igemm_glds_kernel(const Args a) {
   static_assert(!(PIPE_ && BUF_), "the buffer-resource form exists for the single-stage kernel");
-  constexpr int NPL = 3, FIRST = 0;
+  static_assert(NP_ == 6 || NP_ == 3 || NP_ == 1, "six, three or one product");
+  constexpr int NPL = NP_ == 6 ? 3 : (NP_ == 3 ? 2 : 1), FIRST = 6 - NP_;
   constexpr int MT = (BN_ == 128 && BM_ == 128) ? 4 : 2;
   constexpr int BPT = BN_ / 64, APT = BM_ / 64;
   constexpr int STAGE = NPL * (BM_ + BN_) * BK;       // elements of one (A, B) stage; PIPE_ appends a second A image
-  __shared__ __attribute__((aligned(16))) __bf16 lds_static[PIPE_ ? 8 : STAGE];
+  constexpr int EPI = 4 * 32 * 68 * 2;                // elements the epilogue's transpose needs (one- / two-plane stages are smaller)
+  __shared__ __attribute__((aligned(16))) __bf16 lds_static[PIPE_ ? 8 : (STAGE > EPI ? STAGE : EPI)];
   extern __shared__ __attribute__((aligned(16))) __bf16 lds_dynamic[];
   __bf16* lds_all = PIPE_ ? lds_dynamic : lds_static;
   __bf16 (*ldsA)[BM_ * BK] = reinterpret_cast<__bf16 (*)[BM_ * BK]>(lds_all);
@@ -478,8 +574,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE_ ? 2 :
           acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[t]][m], fb[PROD_B[t]], acc[m][n], 0, 0, 0);
     }
   }
-  static_assert(4 * 32 * 68 * 4 <= STAGE * 2, "epilogue staging does not fit");
-  igemm_write_out<NPL, MT>(a, ph, acc, reinterpret_cast<float*>(lds_all), z, bm, bn, wrow, wcol, lane, wave);
+  static_assert(PIPE_ ? 4 * 32 * 68 * 4 <= STAGE * 2 : true, "epilogue staging does not fit");
+  igemm_write_out<NPL, MT, BM_, BN_>(a, ph, acc, reinterpret_cast<float*>(lds_all), reinterpret_cast<int*>(lds_all), z, phase,
+                                     (phase * gridDim.y + ty) * gridDim.x + tx, bm, bm, bn, bn, wrow, wcol, lane, wave);
 }
 constexpr int PIPE_LDS_BYTES = (3 * (128 + 128) * BK + 3 * 128 * BK) * 2;     // one stage + the second activation image
 
@@ -504,10 +601,12 @@ constexpr int pp_lds_bytes(int bn) { return (4 * PP_IMG + 2 * 3 * bn * BK) * 2; 
 // band gets an out-of-range offset and the hardware writes zeros -- no zero page, no 64-bit pointer select per plane, the
 // plane / chunk displacement in the scalar offset: ~20 instead of ~70 vector instructions per K step in the READ half-step,
 // which shares the SIMD's issue port with the other group's MFMA stream.
-template <int BN_, bool BUF_ = false>
+template <int BN_, bool BUF_ = false, int NP_ = 6>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm_pp_kernel(const Args a) {
-  constexpr int NPL = 3, MT = BN_ == 128 ? 4 : 2, BPT = BN_ / 64;
-  constexpr int PP_IMG_B = NPL * BN_ * BK;
+  static_assert(NP_ == 6 || NP_ == 3 || NP_ == 1, "six, three or one product");
+  constexpr int NPL = NP_ == 6 ? 3 : (NP_ == 3 ? 2 : 1), FIRST = 6 - NP_;      // (the images keep their three-plane size: one workgroup per CU)
+  constexpr int MT = BN_ == 128 ? 4 : 2, BPT = BN_ / 64;
+  constexpr int PP_IMG_B = 3 * BN_ * BK;
   extern __shared__ __attribute__((aligned(16))) __bf16 lds_pp[];
   unsigned long long* const probe = ufr_clock_probe_buf;
   const unsigned long long probe_c0 = probe ? __builtin_amdgcn_s_memtime() : 0, probe_r0 = probe ? __builtin_amdgcn_s_memrealtime() : 0;
@@ -659,7 +758,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll
-      for (int t = 0; t < 6; ++t)
+      for (int t = FIRST; t < 6; ++t)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
           acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PROD_A[t]][m], fb[n][PROD_B[t]], acc[m][n], 0, 0, 0);
@@ -667,7 +766,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (grp == 0) __builtin_amdgcn_s_barrier();                             // group 1's extra barrier at the start
   const unsigned long long probe_c3 = probe ? __builtin_amdgcn_s_memtime() : 0;
   static_assert(4 * 32 * 68 * 4 <= 2 * PP_IMG * 2, "epilogue staging does not fit a group's activation images");
-  igemm_write_out<NPL, MT>(a, ph, acc, reinterpret_cast<float*>(lds_pp + imgA0), z, bm, bn, wrow, wcol, lane, wave);
+  igemm_write_out<NPL, MT, 256, BN_>(a, ph, acc, reinterpret_cast<float*>(lds_pp + imgA0), reinterpret_cast<int*>(lds_pp), z, phase,
+                                     (phase * gridDim.y + ty) * gridDim.x + tx, ty * 256, bm, bn, bn, wrow, wcol, lane, wave);
   if (probe && threadIdx.x == 0) {
     const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     if (wg < ufr_clock_probe_cap) {                                       // 8 words per workgroup: cycles at entry / exit, 100 MHz
@@ -862,7 +962,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
   static_assert(4 * 32 * 68 * 4 <= 2 * PP3_IMG * 2, "epilogue staging does not fit a group's activation images");
-  igemm_write_out<NPL, MT>(a, ph, acc, reinterpret_cast<float*>(lds_pp + imgA0), z, bm, bn, wrow, wcol, lane, wave);
+  igemm_write_out<NPL, MT, 256, BN_>(a, ph, acc, reinterpret_cast<float*>(lds_pp + imgA0), reinterpret_cast<int*>(lds_pp), z, phase,
+                                     (phase * gridDim.y + ty) * gridDim.x + tx, ty * 256, bm, bn, bn, wrow, wcol, lane, wave);
 }
 
 // ---- direct 3 x 3 form (variant 8, round 5): stride-1 3 x 3 convolutions with at most 64 output columns -- the full- and
@@ -977,56 +1078,8 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const Args a) {
     const long rest = i / n8;
     const int row = (int)(rest % a.g.M), phase = (int)(rest / a.g.M);
     if (n0 >= a.e.Nchunks32 * 32) continue;
-    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const float* src = a.ws + ((long)a.zoff[phase] * a.g.M + row) * a.Npad + n0;
-    const long sstride = (long)a.g.M * a.Npad;
-    // (the slabs of up to eight slices are requested before the first is added: a deep split on a tiny grid -- 16 .. 32 slabs of a 7 x 16
-    // grid -- was a chain of dependent loads, ~0.5 us each; the order of the additions, and with it every bit of the sum, stays)
-    const int S = a.sk[phase];
-    int s = 0;
-    for (; s + 8 <= S; s += 8) {       // (eight where the split has them: a split of 6 - 8 on RAFT's 48 x 160 grids was two round trips)
-      float4 lo[8], hi[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        lo[u] = *reinterpret_cast<const float4*>(src + (s + u) * sstride);
-        hi[u] = *reinterpret_cast<const float4*>(src + (s + u) * sstride + 4);
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        v[0] += lo[u].x; v[1] += lo[u].y; v[2] += lo[u].z; v[3] += lo[u].w; v[4] += hi[u].x; v[5] += hi[u].y; v[6] += hi[u].z; v[7] += hi[u].w;
-      }
-    }
-    if (S - s >= 5) {                  // 5 .. 7 left: all of them together (the loads past the last slice repeat it, their values are not added)
-      float4 lo[7], hi[7];
-#pragma unroll
-      for (int u = 0; u < 7; ++u) {
-        const int su = min(s + u, S - 1);
-        lo[u] = *reinterpret_cast<const float4*>(src + su * sstride);
-        hi[u] = *reinterpret_cast<const float4*>(src + su * sstride + 4);
-      }
-#pragma unroll
-      for (int u = 0; u < 7; ++u)
-        if (s + u < S) {
-          v[0] += lo[u].x; v[1] += lo[u].y; v[2] += lo[u].z; v[3] += lo[u].w; v[4] += hi[u].x; v[5] += hi[u].y; v[6] += hi[u].z; v[7] += hi[u].w;
-        }
-      s = S;
-    }
-    for (; s + 4 <= S; s += 4) {
-      float4 lo[4], hi[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        lo[u] = *reinterpret_cast<const float4*>(src + (s + u) * sstride);
-        hi[u] = *reinterpret_cast<const float4*>(src + (s + u) * sstride + 4);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        v[0] += lo[u].x; v[1] += lo[u].y; v[2] += lo[u].z; v[3] += lo[u].w; v[4] += hi[u].x; v[5] += hi[u].y; v[6] += hi[u].z; v[7] += hi[u].w;
-      }
-    }
-    for (; s < S; ++s) {
-      const float4 lo = *reinterpret_cast<const float4*>(src + s * sstride), hi = *reinterpret_cast<const float4*>(src + s * sstride + 4);
-      v[0] += lo.x; v[1] += lo.y; v[2] += lo.z; v[3] += lo.w; v[4] += hi.x; v[5] += hi.y; v[6] += hi.z; v[7] += hi.w;
-    }
+    float v[8];
+    sum_slabs(a.ws + ((long)a.zoff[phase] * a.g.M + row) * a.Npad + n0, (long)a.g.M * a.Npad, a.sk[phase], v);
     epilogue_store8(a.e, out_pixel(a.g, row, a.ph[phase].oy0, a.ph[phase].ox0), n0, v);
   }
 }
@@ -1084,6 +1137,7 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   a.e.tail = d->tail; a.e.tail_n0 = d->tail_n0; a.e.tail_acc = d->tail_accumulate;
   a.e.Mout = (long)d->B * d->Ho * d->Wo; a.e.N = d->N; a.e.Nchunks32 = (d->N + 31) / 32;
   a.nphase = d->nphase; a.splitk = d->splitk; a.ws = d->ws;
+  a.tickets = (d->splitk > 1 && !d->no_reduce) ? d->tickets : nullptr;
   a.xcd = 1;                              // XCD-aware tile order (off: +0.2 ms per iteration, profiles/r2_bench_engine_v4_no_xcd_order)
   a.korder = d->k_order ? 1 : 0;
   for (int z = 0; z < 4; ++z) {
@@ -1135,7 +1189,6 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   const int variant = d->variant ? d->variant : 2;
   UFR_REQUIRE(variant == 2 || variant == 4 || variant == 5 || variant == 6 || variant == 7 || variant == 8, "igemm: unknown kernel variant %d",
               d->variant);
-  UFR_REQUIRE(d->products == 6, "igemm: six products only (float32-accurate); the 3- and 1-product forms were removed");
   // activation rows through a raw buffer resource (hardware zeros outside the frame) while the planes stay below 2 GB
   const bool use_buf = 6L * d->x_plane_stride < 0x7fffffffL;
   int dev = 0;
@@ -1163,7 +1216,7 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   // no split, no tail / row-major output, chunk-major K order, <= 64 columns (anything else falls through to the tile forms)
   bool d33 = variant == 8 && d->nphase == 1 && d->phase[0].ntaps == 9 && d->in_sx == 1 && d->in_sy == 1 && d->out_sx == 1 && d->out_sy == 1 &&
              d->Hr == d->Hi && d->Wr == d->Wi && d->Ho == d->Hi && d->Wo == d->Wi && !d->row_x0 && !d->in_x0 && d->splitk == 1 && !d->tail &&
-             !d->out_rowmajor && d->k_order && d->N <= 64;
+             !d->out_rowmajor && d->k_order && d->N <= 64 && d->products == 6;
   for (int t = 0; d33 && t < 9; ++t)
     d33 = d->phase[0].dy[t] >= -1 && d->phase[0].dy[t] <= 1 && d->phase[0].dx[t] >= -1 && d->phase[0].dx[t] <= 1;
   if (d33) {
@@ -1178,6 +1231,27 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
     if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "igemm (direct 3 x 3): %s", hipGetErrorString(e));
     return ufr::launched("igemm_d33_kernel");
   }
+  if (d->products != 6) {
+    // reduced products (RAFT's opt-in bf16 arithmetic): the single-stage tiles, the 64 x 128 tiles and the ping-pong tiles, activation rows
+    // through the buffer resource; the pipelined / tap-reuse / direct forms run as their plain twins
+    UFR_REQUIRE(use_buf, "igemm: the reduced-product forms need activation planes below 2 GB");
+#define UFR_NP_LAUNCH(NP_)                                                                                                    \
+    if ((variant == 6 || variant == 7 || variant == 5) && bn == BN) {                                                          \
+      const dim3 gpp(d->Npad / BN, (unsigned)((M + 255) / 256), nz);                                                           \
+      hipError_t e = ufr::ensure_dynamic_lds(reinterpret_cast<const void*>(igemm_pp_kernel<128, true, NP_>), pp_lds_bytes(128)); \
+      if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "igemm: %s", hipGetErrorString(e));                                   \
+      igemm_pp_kernel<128, true, NP_><<<gpp, 512, pp_lds_bytes(128), st>>>(a);                                                 \
+    } else if (variant == 4 && bn == BN) {                                                                                     \
+      const dim3 g64(d->Npad / BN, (unsigned)((M + 63) / 64), nz);                                                             \
+      igemm_glds_kernel<64, 128, false, true, NP_><<<g64, 256, 0, st>>>(a);                                                    \
+    } else if (bn == BN) {                                                                                                     \
+      igemm_glds_kernel<128, 128, false, true, NP_><<<grid, 256, 0, st>>>(a);                                                  \
+    } else {                                                                                                                   \
+      igemm_glds_kernel<128, 64, false, true, NP_><<<grid, 256, 0, st>>>(a);                                                   \
+    }
+    if (d->products == 3) { UFR_NP_LAUNCH(3) } else { UFR_NP_LAUNCH(1) }
+#undef UFR_NP_LAUNCH
+  } else
   if (variant == 7 && d->k_order && (d->in_sx == 1 || d->in_sx == 2) && d->Wr >= 22) {
     // ping-pong + horizontal runs of taps staged once (launches it does not cover fall through to the plain forms)
     const dim3 gpp(d->Npad / bn, (unsigned)((M + 255) / 256), nz);
@@ -1201,7 +1275,8 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
     else igemm_glds_kernel<128, 64><<<grid, 256, 0, st>>>(a);
   }
   int rc = ufr::launched("igemm_kernel");
-  if (rc != UFR_OK || d->splitk == 1 || d->no_reduce) return rc;     // no_reduce: the caller's next kernel adds the slabs itself
+  if (rc != UFR_OK || d->splitk == 1 || d->no_reduce || a.tickets) return rc;     // no_reduce: the caller's next kernel adds the slabs itself;
+                                                                                  // tickets: the last workgroup of every tile already has
   const long total = (long)d->nphase * M * (d->Npad / 8);
   igemm_reduce_kernel<<<ufr::stream_grid(total, 256), 256, 0, st>>>(a);
   return ufr::launched("igemm_reduce_kernel");

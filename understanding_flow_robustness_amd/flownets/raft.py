@@ -5,8 +5,16 @@ Behavioural mirror of models/raft/raft.py:26-233, update.py, extractor.py:1-215 
 of the reference (so `raft-things.pth` loads unchanged).  Differences, all on purpose:
   * the per-iteration lookup is ONE fused kernel (flownets/raft_corr.py) instead of 4 grid_samples;
   * `alternate_corr=True` is differentiable (the reference calls alt_cuda_corr's raw forward);
-  * fp32 throughout: `args.mixed_precision` is honoured only as an opt-in bf16 autocast, because the
-    1e-4 EPE gate is defined against the fp32 path ("RAFT precision").
+  * float32 by DEFAULT, whatever `args.mixed_precision` says: the reference's registry sets that flag for every non-"adv" RAFT
+    (models/utils_model.py:51) and then runs both encoders and the update block under fp16 autocast on a GPU
+    (models/raft/raft.py:140,168,195); the 1e-4 EPE / patch gates of this build are defined against the float32 path
+    ("RAFT precision"), so the flag ALONE changes nothing here.  Reduced precision is an explicit opt-in on top of
+    the flag: `args.mixed_precision` AND the environment's `UFR_RAFT_PRECISION=bf16` make the native engines' convolutions (both
+    encoders, the update block; the correlation stays float32 like the reference's `.float()` operands, corr.py:128-129,
+    raft.py:147-148) compute ONE bf16 product per float32 product (csrc/igemm.hip `products = 1`: bf16-rounded operands, float32
+    accumulation -- what a bfloat16 autocast computes, 1/6 of the matrix work); `UFR_RAFT_PRECISION=bf16x3` the three leading
+    products (~16 significand bits, 1/2 of the work).  `RAFT.products()` says which form a forward will take.  The torch
+    fallback path (training mode, parameters that want gradients) ignores the switch and stays float32.
 """
 from __future__ import annotations
 
@@ -292,6 +300,16 @@ class RAFT(nn.Module):
         self.cnet = BasicEncoder(output_dim=256, norm_fn=args.cnorm, dropout=args.dropout)
         self.update_block = BasicUpdateBlock(args, hidden_dim=128)
 
+    def products(self) -> int:
+        """bf16 products per float32 product of the engines' convolutions: 6 unless the caller opted into reduced precision with
+        BOTH `args.mixed_precision` (the reference's flag, models/utils_model.py:51) and UFR_RAFT_PRECISION=bf16 | bf16x3."""
+        want = os.environ.get("UFR_RAFT_PRECISION", "fp32").lower()
+        if want not in ("fp32", "float32", "bf16", "bf16x3"):
+            raise ValueError(f"UFR_RAFT_PRECISION={want!r}: fp32, bf16 or bf16x3")
+        if not getattr(self.args, "mixed_precision", False) or want in ("fp32", "float32"):
+            return 6
+        return 1 if want == "bf16" else 3
+
     def _engine_ok(self, net, H, W) -> bool:
         """The native refinement loop (raft_engine.py) serves the attack's configuration: frozen parameters, eval mode, HIP
         float32 tensors, the raft-things update block, frame sides that are multiples of 8 (UFR_ENGINE=0 switches it off);
@@ -327,8 +345,12 @@ class RAFT(nn.Module):
         else:
             image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
             image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
+        from .. import igemm as _ig
+        prec = _ig.products(self.products())      # the engines built / looked up inside take this many products (6 = float32-accurate)
+
         def context():
-            net, inp = torch.split(self.cnet(image1), [128, 128], dim=1)
+            with prec:
+                net, inp = torch.split(self.cnet(image1), [128, 128], dim=1)
             return torch.tanh(net), torch.relu(inp)
 
         # The context encoder reads frame 1 only and meets the feature encoder's results in the update block (raft.py:176-184).  On
@@ -342,7 +364,8 @@ class RAFT(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 net, inp = context()
-        fmap1, fmap2 = self.fnet([image1, image2], stacked=stack)
+        with prec:
+            fmap1, fmap2 = self.fnet([image1, image2], stacked=stack)
         fmap1, fmap2 = fmap1.float().contiguous(), fmap2.float().contiguous()
         if self.args.alternate_corr:
             corr_fn = AlternateCorrBlock(fmap1, fmap2, radius=self.args.corr_radius, share_grad=True)
@@ -358,7 +381,8 @@ class RAFT(nn.Module):
         if test_mode and flow_init is None and self._engine_ok(net, H, W):
             # the 12 iterations as one explicit schedule on the native engine (raft_engine.py): same operands, same result
             from ..raft_engine import refine
-            flow_lr, up_mask = refine(self, net.contiguous(), inp.contiguous(), corr_fn, H, W)
+            with prec:
+                flow_lr, up_mask = refine(self, net.contiguous(), inp.contiguous(), corr_fn, H, W)
             return flow_lr, self.upsample_flow(flow_lr, up_mask)
         coords0 = coords_grid(N, H // 8, W // 8, image1.device)
         coords1 = coords0.clone()

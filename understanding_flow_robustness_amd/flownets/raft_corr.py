@@ -251,6 +251,48 @@ def _levels_struct(f2s, grads=None) -> L.AltCorrLevels:
     return lv
 
 
+class AltCorrPlanes:
+    """fmap1 and the fmap2 pyramid of one AlternateCorrBlock as bf16 split planes [3][C / 32][pixels][32] (csrc/igemm.hip's
+    activation layout), made ONCE -- the maps are constant over RAFT's 12 lookups (models/raft/corr.py:111-119) -- for the lookup
+    on the bf16 matrix cores with float32 accuracy (csrc/raft_altcorr_planes.hip, round 6).  `served()` says whether the kernel
+    takes the shape (C 128 / 256, radius 3 / 4, at most four levels)."""
+
+    @staticmethod
+    def served(f1, f2s, radius) -> bool:
+        return (f1.is_cuda and f1.dtype == torch.float32 and f1.shape[3] in (128, 256) and int(radius) in (3, 4)
+                and 1 <= len(f2s) <= 4 and os.environ.get("UFR_ALTCORR_PLANES", "1") != "0")
+
+    def __init__(self, f1: torch.Tensor, f2s):
+        self.B, self.H1, self.W1, self.C = (int(v) for v in f1.shape)
+        self.maps = []
+        with torch.cuda.device(f1.device):
+            for f in (f1, *f2s):
+                L.require_hip(f, "feature map")
+                if f.dim() != 4 or f.shape[0] != self.B or f.shape[3] != self.C or f.dtype != torch.float32:
+                    raise RuntimeError("alt_corr planes: every map must be [B,H,W,C] float32 with fmap1's batch and channels")
+                npix = f.shape[0] * f.shape[1] * f.shape[2]
+                planes = torch.empty(3, npix * self.C, dtype=torch.bfloat16, device=f.device)
+                L.check(L.lib().ufr_altcorr_planes_prepare(L.ptr(f), L.ptr(planes), planes.stride(0), npix, self.C, L.stream()),
+                        "alt_corr planes prepare")
+                self.maps.append((planes, int(f.shape[1]), int(f.shape[2])))
+        self.levels = L.AltCorrPlaneLevels()
+        self.levels.num_levels = len(f2s)
+        for i, (planes, h2, w2) in enumerate(self.maps[1:]):
+            self.levels.planes[i], self.levels.plane_stride[i] = planes.data_ptr(), planes.stride(0)
+            self.levels.H2[i], self.levels.W2[i] = h2, w2
+            self.levels.coord_scale[i] = 1.0 / 2 ** i                # corr.py:126
+
+    def forward(self, coords: torch.Tensor, radius: int, scale: float, out: torch.Tensor | None = None) -> torch.Tensor:
+        """coords [B, 2, H1, W1] -> [B, L (2r+1)^2, H1, W1] = scale * the stacked per-level windows."""
+        rd = 2 * int(radius) + 1
+        if out is None:
+            out = torch.empty((self.B, self.levels.num_levels * rd * rd, self.H1, self.W1), dtype=torch.float32, device=coords.device)
+        f1p = self.maps[0][0]
+        L.check(L.lib().ufr_altcorr_planes_forward(L.ptr(f1p), f1p.stride(0), C.byref(self.levels), L.ptr(coords), L.ptr(out), self.B, self.H1,
+                                                   self.W1, self.C, int(radius), float(scale), L.stream()), "alt_corr planes forward")
+        return out
+
+
 class AltCorrPyramidFunction(torch.autograd.Function):
     """All levels of one AlternateCorrBlock lookup (corr.py:121-137) as ONE launch of the matrix-core kernel
     (csrc/raft_altcorr_mfma.hip): out [B, L*(2r+1)^2, H, W] = stack_l alt_corr(fmap1, fmap2_l, coords / 2^l) / sqrt(dim).

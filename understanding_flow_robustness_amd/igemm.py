@@ -331,6 +331,31 @@ class Launch:
 # pair on the step's own buffers and writes the winners to `igemm_tuning.json`, keyed by `launch_signature`; `tuned()` is asked
 # by every engine right after its rule of thumb.  UFR_IGEMM_TUNING=0 switches the table off (the sweep tool does, to see the rule).
 _TUNING = None
+# Split-K without the second launch (csrc/igemm.hip `tickets`, round 6): the last workgroup to arrive at a tile adds the tile's slabs in
+# ascending order and runs the epilogue -- bit-identical to the reduce kernel (tests/test_igemm_gpu.py).  BUILT AND MEASURED SLOWER on every
+# config, both forms in one call (profiles/r6_fused_splitk_ab.jsonl: RAFT 15.29 -> 18.14 ms, FlowNet2 9.45 -> 11.46, PWC-Net 16.20 -> 17.30,
+# FlowNetC 4.29 -> 4.66): every slice's workgroup pays an agent-scope release (a write-back of its XCD's L2) where the two-launch form pays
+# one kernel boundary.  It stays an opt-in: UFR_IGEMM_FUSE_REDUCE=1, or `fuse_reduce=True` per launch.
+FUSE_REDUCE = os.environ.get("UFR_IGEMM_FUSE_REDUCE", "0") == "1"
+# Products per float32 product of the launches being built: 6 everywhere; RAFT's engines build theirs inside `with products(1):` when
+# the caller opted into reduced precision (flownets/raft.py `raft_precision`).
+_PRODUCTS = [6]
+
+
+class products:
+    """`with igemm.products(n):` -- launches made inside compute n (6, 3 or 1) bf16 products per float32 product."""
+    def __init__(self, n: int):
+        if n not in (6, 3, 1):
+            raise ValueError("igemm.products: 6, 3 or 1")
+        self.n = n
+
+    def __enter__(self):
+        _PRODUCTS.append(self.n)
+
+    def __exit__(self, *exc):
+        _PRODUCTS.pop()
+
+
 RECORD = None            # a list while tools/sweep_engine_launches.py builds a step: every make_launch() appends its arguments
 
 
@@ -373,9 +398,9 @@ def make_launch(wi: WeightImage, x: Planes, in_chunk0: int, rows_hw, out_hw, *, 
                 out_chunk0: int = 0, out_f32: GradSum | None = None, out_f32_chunk0: int = 0, bias: torch.Tensor | None = None,
                 add: GradSum | None = None, add_chunk0: int = 0, mask: Planes | None = None, mask_chunk0: int = 0,
                 slope: float = LEAKY, splitk: int = 1, ws: torch.Tensor | None = None, row_band=None, in_band=None,
-                products: int = 6, variant: int = 0, tail: GradSum | None = None, tail_n0: int = 0, tail_chunk0: int = 0,
+                products: int | None = None, variant: int = 0, tail: GradSum | None = None, tail_n0: int = 0, tail_chunk0: int = 0,
                 tail_accumulate: bool = False, out_rowmajor=None, planes_chunks: int = 0, f32_first_chunk: int = 0,
-                no_reduce: bool = False) -> Launch:
+                no_reduce: bool = False, fuse_reduce: bool | None = None) -> Launch:
     """Descriptor for `wi` applied to the chunks [in_chunk0, in_chunk0 + KC) of `x`.
     rows_hw = (Hr, Wr) row grid; out_hw = (Ho, Wo) output grid.  row_band = (origins int32 tensor, element stride, divisor):
     tail / tail_n0: the launch's output columns >= tail_n0 are a LATER layer's partial sum over these input chunks and leave raw
@@ -456,7 +481,13 @@ def make_launch(wi: WeightImage, x: Planes, in_chunk0: int, rows_hw, out_hw, *, 
             raise RuntimeError(f"igemm: split-K workspace of {need} floats needed")
         d.ws = ws.data_ptr()
     d.no_reduce = 1 if (no_reduce and splitk > 1) else 0      # the consumer adds the slabs (single-phase launches)
-    d.products = int(products)
+    if splitk > 1 and not d.no_reduce and (FUSE_REDUCE if fuse_reduce is None else fuse_reduce):
+        # one arrival counter per (phase, row tile, column tile), owned by this launch (two launches in flight on two streams must
+        # not share them); zero now, and the last arriver of a tile leaves its counter at zero
+        tickets = torch.zeros(d.nphase * (-(-(x.B * d.Hr * d.Wr) // 64)) * (wi.Npad // 64), dtype=torch.int32, device=x.t.device)
+        d.tickets = tickets.data_ptr()
+        keep.append(tickets)
+    d.products = int(_PRODUCTS[-1] if products is None else products)
     d.k_order = int(wi.k_order)
     d.variant = int(variant)               # 0 / 2 = single-stage tiles, 4 = 64 x 128, 5 = pipelined, 6 = ping-pong (csrc/igemm.hip)
     return Launch(d, keep)

@@ -252,7 +252,7 @@ def encode(enc, images: torch.Tensor) -> torch.Tensor:
     """BasicEncoder.forward on the native engine (one engine per encoder, batch and frame size, cached on the module)."""
     from .flownetc_engine import _weights_stamp
     n, _, H, W = images.shape
-    key = (int(n), int(H), int(W), str(images.device))
+    key = (int(n), int(H), int(W), str(images.device), ig._PRODUCTS[-1])       # (the launches bake the products of their arithmetic in)
     cache = _engine_cache(enc, "_ufr_encoder_engines")
     stamp = _weights_stamp(enc) + tuple((b.data_ptr(), b._version) for b in enc.buffers())
     eng = cache.get(key)

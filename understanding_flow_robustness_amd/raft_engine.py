@@ -277,7 +277,9 @@ class RaftUpdateEngine:
 
     def _lookup_forward(self, src, coords):
         lib, B, h, w = L.lib(), self.B, self.h, self.w
-        if src["alt"]:
+        if src["alt"] and src.get("planes") is not None:
+            src["planes"].forward(coords, self.radius, src["scale"], out=self.corr)
+        elif src["alt"]:
             lv = self._alt_levels(src["f2"])
             L.check(lib.ufr_altcorr_pyramid_forward(L.ptr(src["f1"]), C.byref(lv), L.ptr(coords), L.ptr(self.corr), B, h, w,
                                                     src["f1"].shape[3], self.radius, src["scale"], L.stream()), "alt_corr forward")
@@ -448,6 +450,9 @@ class _RaftRefine(torch.autograd.Function):
     def forward(ctx, net0, inp, engine, alt, scale, f1, *rest):
         if alt:
             src = dict(alt=True, f1=f1, f2=list(rest), scale=float(scale))
+            from .flownets.raft_corr import AltCorrPlanes
+            if AltCorrPlanes.served(f1, rest, engine.radius):      # the maps as split planes, once per forward: the 12 lookups read them
+                src["planes"] = AltCorrPlanes(f1, list(rest))
         else:
             src = dict(alt=False, vols=list(rest))
         flow_lr, up_mask = engine.forward(net0, inp, src)
@@ -476,7 +481,7 @@ class _RaftRefine(torch.autograd.Function):
 def get_engine(net, B: int, H: int, W: int, device) -> RaftUpdateEngine:
     from .flownetc_engine import _weights_stamp
     a = net.args            # the launch schedule bakes these in: a changed `args.iters` on a live model must rebuild it
-    key = (int(B), int(H), int(W), str(torch.device(device)), int(a.iters), int(a.corr_radius), int(a.corr_levels))
+    key = (int(B), int(H), int(W), str(torch.device(device)), int(a.iters), int(a.corr_radius), int(a.corr_levels), ig._PRODUCTS[-1])
     cache = _engine_cache(net, "_ufr_head_engines")
     stamp = _weights_stamp(net)
     eng = cache.get(key)
