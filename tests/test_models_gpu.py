@@ -103,7 +103,7 @@ def test_raft_vs_reference(alternate, frozen):
         # the worst entry is the conditioning's (5e-2); the bulk is gated 30x tighter (measured: median 8e-6 .. 2.3e-4, 90 % within
         # 4e-5 .. 1.2e-3 over the four legs -- the largest is the alt_corr + engines leg's ReLU flip, test_raft_gradient_against_float64_truth)
         _check(z, net, args, gtol=5e-2, g_atol=5e-2, bulk=(1e-3, 5e-3))
-    _attack_check(z, net, args, "attack_it2_patch", 1e4, 2, tol=5e-3)     # (round 6: 5e-2 -> 5e-3; the measured value is printed)
+    _attack_check(z, net, args, "attack_it2_patch", 1e4, 2, tol=1e-4)     # (round 6: 5e-2 -> north_star's own 1e-4; measured 8.8e-6 / 9.8e-6 of the update)
 
 
 @FROZEN

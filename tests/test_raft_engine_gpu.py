@@ -110,9 +110,11 @@ def test_raft_attack_at_full_size_engine_vs_torch_spelling(raft, monkeypatch, al
     print(f"RAFT alt={alternate} 384x1280, one iteration, of the update: engines vs float64 {e_eng:.2e}, torch spelling vs float64 "
           f"{e_torch:.2e}, engines vs torch spelling {e_same:.2e}; loss {lf:.6f} / {le:.6f}")
     assert nf == ne == 1 and abs(lf - le) <= 1e-5 and 0.3 < upd < 1.9
-    # round 6: the gates at what is measured (engines vs float64 4.8e-5 all-pairs / 1.4e-4 alt_corr, torch spelling 1.4e-3;
-    # engines vs torch spelling 1.4e-3) instead of round 5's 1e-3 / 1e-2
-    assert e_eng <= max(1.5 * e_torch, 3e-4) and e_same <= 3e-3
+    # round 6: the gates at what is measured instead of round 5's 1e-3 / 1e-2.  Engines vs float64: 4.4e-5 (all-pairs) and
+    # 6.8e-5 (alt_corr) of the update -- the alt_corr leg was 1.4e-4 while its lookup ran on `v_mfma_f32_16x16x4_f32` (raft_altcorr_mfma.hip);
+    # on the three-plane bf16 form (raft_altcorr_planes.hip, the igemm's arithmetic) both legs are under north_star's 1e-4, which is now the
+    # gate.  The torch spelling on this device is at 1.4e-3 of the same truth, so engines-vs-torch sits there too (gate 3e-3).
+    assert e_eng <= 1e-4 and e_same <= 3e-3
 
 
 @pytest.mark.parametrize("mode,products", [("bf16", 1), ("bf16x3", 3)])

@@ -10,7 +10,7 @@
 //     12 lookups): bf16 [3][C / 32][pixels][32], the igemm's activation layout -- a pixel's 32-channel chunk is one 64-byte row;
 //   * a workgroup owns a 2-D tile of 8 x 16 pixels (eight waves, one per pixel row) on one level; the eight rows' windows overlap
 //     almost completely when the flow is smooth, so the workgroup walks the BOUNDING BOX of all 128 windows once: one fmap2 row x
-//     32 columns x all channels (48 KB) per stage by LDS-DMA into a double buffer (XOR-swizzled rows as in igemm.hip), every wave
+//     32 columns x 128 channels (24 KB) per stage by LDS-DMA, three stages in flight (XOR-swizzled rows as in igemm.hip), every wave
 //     multiplies its 16 pixels against the 16-column segments of the stage that meet ITS OWN box: S[p, q] = <fmap1[p], fmap2[q]>,
 //     48 `v_mfma_f32_16x16x32_bf16` per segment (8 chunks x 6 products);
 //   * every pixel keeps the entries that fall into its own (2r + 2)^2 window (LDS, wave-private) and blends them bilinearly at
@@ -20,6 +20,8 @@
 // matrix work 2.7x cheaper per product and ~1.6x fewer products (8 rows share the box's row walk, a 16-pixel tile walks its own).
 #include <climits>
 #include <cstdint>
+#include <cstdlib>
+#include <type_traits>
 
 #include "ufr_common.h"
 
@@ -32,7 +34,7 @@ __device__ constexpr int PROD_A[6] = {2, 0, 1, 1, 0, 0};   // (a plane, b plane)
 __device__ constexpr int PROD_B[6] = {0, 2, 1, 0, 1, 0};
 __device__ __attribute__((aligned(64))) unsigned acp_zero_page[16];
 
-constexpr int TH = 8, TW = 16, TP = TH * TW;      // pixel tile: 8 rows (one wave each) x 16 columns
+constexpr int TW = 16;                            // pixel tile: TH rows (one wave each) x 16 columns
 constexpr int SW = 32;                            // fmap2 columns per stage
 
 struct PlaneLevels {                              // by value in the kernel arguments
@@ -78,19 +80,25 @@ __global__ __launch_bounds__(256) void altcorr_planes_prepare_kernel(const float
   }
 }
 
-// LDS (bytes): two stages [3 planes][KCH chunks][SW pixels][32 ch] bf16 | s [TH waves][TW pixels][npt] float | cx, cy [TP] int | dx, dy [TP] float | box [4] int
-template <int R, int KCH>
-constexpr int acp_lds_bytes() { return 2 * 3 * KCH * SW * 32 * 2 + TH * TW * (2 * R + 2) * (2 * R + 2) * 4 + 4 * TP * 4 + 16; }
+// A STAGE = one fmap2 row x SW columns x KS = 4 chunks x three planes = 24 KB; NBUF = 4 of them: one being multiplied, three in
+// flight (a first form with two whole-K stages of 48 KB -- one in flight -- ran at the LDS-DMA's LATENCY: 66 us per lookup, 1.5 - 2.5 us
+// per stage for 0.5 us of matrix work, gpurun r6_tr1).
+// -> the kernel takes (TH, KS, NBUF) as template parameters; the launch picks the measured best (UFR_ALTCORR_PLANES_FORM sweeps them).
+// LDS (bytes): NBUF stages [3 planes][KS chunks][SW pixels][32 ch] bf16 | s [TH waves][TW pixels][npt] float | cx, cy [TP] int | dx, dy [TP] float | box [4] int
+template <int R, int TH, int KS, int NBUF>
+constexpr int acp_lds_bytes() { return NBUF * 3 * KS * SW * 32 * 2 + TH * TW * (2 * R + 2) * (2 * R + 2) * 4 + 4 * TH * TW * 4 + 16; }
 
-template <int R, int KCH>
-__global__ __launch_bounds__(512) void altcorr_planes_fwd(const __bf16* __restrict__ f1, long f1_stride, const PlaneLevels lv,
+template <int R, int KCH, int TH, int KS, int NBUF>
+__global__ __launch_bounds__(64 * TH) void altcorr_planes_fwd(const __bf16* __restrict__ f1, long f1_stride, const PlaneLevels lv,
                                                           const float* __restrict__ coords, float* __restrict__ out, int B, int H1,
                                                           int W1, float scale) {
-  constexpr int rd = 2 * R + 1, gd = rd + 1, npt = gd * gd;
-  constexpr int STAGE = 3 * KCH * SW * 32;                               // elements of one stage
+  constexpr int rd = 2 * R + 1, gd = rd + 1, npt = gd * gd, TP = TH * TW, NT = 64 * TH;
+  constexpr int STAGE = 3 * KS * SW * 32;                                // elements of one stage
+  constexpr int NSPLIT = KCH / KS;                                       // stages per (row, strip) piece
+  static_assert(SW == 32 && KCH % KS == 0, "whole stages");
   extern __shared__ __attribute__((aligned(16))) unsigned char acp_lds[];
   __bf16* const bufs = reinterpret_cast<__bf16*>(acp_lds);
-  float* const s_all = reinterpret_cast<float*>(acp_lds + 2 * STAGE * 2);
+  float* const s_all = reinterpret_cast<float*>(acp_lds + NBUF * STAGE * 2);
   int* const cxs = reinterpret_cast<int*>(s_all + TH * TW * npt);
   int* const cys = cxs + TP;
   float* const dxs = reinterpret_cast<float*>(cys + TP);
@@ -174,51 +182,86 @@ __global__ __launch_bounds__(512) void altcorr_planes_fwd(const __bf16* __restri
 #pragma unroll
   for (int j = 0; j < 4; ++j) { cyr[j] = cys[wave * TW + 4 * kg + j]; cxr[j] = cxs[wave * TW + 4 * kg + j]; }
 
-  // ---- stages: piece i = (row Y0 + i / nstrip, columns X0 + 32 (i % nstrip) ..)
+  // ---- stages: stage i = chunks KS (i % NSPLIT) .. of piece i / NSPLIT = (row Y0 + piece / nstrip, columns X0 + 32 (piece % nstrip) ..)
   const __bf16* zero = reinterpret_cast<const __bf16*>(acp_zero_page);
-  constexpr int ITEMS = 3 * KCH * SW * 4 / 512;                           // 16-byte transfers per lane and stage (6 at 256 channels)
-  auto stage = [&](int piece, int buf) {
+  constexpr int ITEMS = 3 * KS * SW * 4 / NT;                             // 16-byte transfers per lane and stage
+  static_assert(3 * KS * SW * 4 % NT == 0, "whole transfers per lane");
+  const int nstage = npiece * NSPLIT;
+  auto stage = [&](int i) {
+    const int piece = i / NSPLIT, kh = i - piece * NSPLIT;
     const int y = Y0 + piece / nstrip, xs = X0 + (piece - (piece / nstrip) * nstrip) * SW;
     const long rowpix = ((long)b * H2 + y) * W2;
+    __bf16* dst = bufs + (i % NBUF) * STAGE;
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
-      const int it = k * 512 + tid, slot = it & 3, px = (it >> 2) & (SW - 1), pc = it >> 7, p = pc / KCH, c = pc - p * KCH;
+      const int it = k * NT + tid, slot = it & 3, px = (it >> 2) & (SW - 1), pc = it >> 7, p = pc / KS, c = pc - p * KS;
       const int x = xs + px;
-      const __bf16* src = x < W2 ? f2 + p * f2_stride + ((long)c * npix2 + rowpix + x) * 32 + ((slot ^ ((px >> 1) & 3)) << 3) : zero;
-      glds16(src, bufs + buf * STAGE + (k * 512 + wave * 64) * 8);      // lane l lands 16 l bytes behind the wave's base
+      const __bf16* src = x < W2 ? f2 + p * f2_stride + ((long)(kh * KS + c) * npix2 + rowpix + x) * 32 + ((slot ^ ((px >> 1) & 3)) << 3) : zero;
+      glds16(src, dst + (k * NT + wave * 64) * 8);                      // lane l lands 16 l bytes behind the wave's base
     }
   };
   const int frow = lane & 15;
-  if (npiece > 0) stage(0, 0);
-  for (int i = 0; i < npiece; ++i) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // my transfers of piece i have landed ...
-    __syncthreads();                                                      // ... everybody's have, and everybody is done reading the other buffer
-    if (i + 1 < npiece) stage(i + 1, (i + 1) & 1);
-    const int y = Y0 + i / nstrip, xs = X0 + (i - (i / nstrip) * nstrip) * SW;
+  for (int i = 0; i < NBUF - 1 && i < nstage; ++i) stage(i);
+  f32x4 acc[4];                                                          // two segments x (even, odd products)
+  for (int i = 0; i < nstage; ++i) {
+    // my transfers of stage i have landed (the younger stages' -- ITEMS instructions each -- may still fly) ...
+    const int ahead = min(nstage - 1 - i, NBUF - 2);
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ITEMS) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ITEMS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                                      // ... everybody's have, and everybody is done with stage i - 1's buffer
+    if (i + NBUF - 1 < nstage) stage(i + NBUF - 1);                       // into the buffer of stage i - 1
+    const int piece = i / NSPLIT, kh = i - piece * NSPLIT;
+    const int y = Y0 + piece / nstrip, xs = X0 + (piece - (piece / nstrip) * nstrip) * SW;
     if (y < wy0 || y >= wy1) continue;                                    // (wave-uniform; no barrier inside)
-    const __bf16* sB = bufs + (i & 1) * STAGE;
+    const __bf16* sB = bufs + (i % NBUF) * STAGE;
+    // the stage's two 16-column segments that meet this wave's box, their MFMA chains INTERLEAVED and each split over two
+    // accumulators (even / odd products): one chain of 48 dependent MFMAs per segment ran at the instruction's latency, not its rate
+    const bool m0 = xs < wx1 && xs + 16 > wx0, m1 = xs + 16 < wx1 && xs + 32 > wx0;
+    if (kh == 0) {
 #pragma unroll
-    for (int nt = 0; nt < SW / 16; ++nt) {
-      const int q0 = xs + nt * 16;
-      if (q0 >= wx1 || q0 + 16 <= wx0) continue;
-      const int r = nt * 16 + frow;
-      const int boff = r * 32 + ((kg ^ ((r >> 1) & 3)) << 3);
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int a = 0; a < 4; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int r0 = frow, r1 = 16 + frow;
+    const int boff0 = r0 * 32 + ((kg ^ ((r0 >> 1) & 3)) << 3), boff1 = r1 * 32 + ((kg ^ ((r1 >> 1) & 3)) << 3);
+    auto run = [&](auto M0, auto M1) {
 #pragma unroll
-      for (int c = 0; c < KCH; ++c) {
-        bf16x8 fb[3];
+      for (int c = 0; c < KS; ++c) {
+        bf16x8 fb0[3], fb1[3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) fb[p] = *reinterpret_cast<const bf16x8*>(sB + (p * KCH + c) * (SW * 32) + boff);
+        for (int p = 0; p < 3; ++p) {
+          if (decltype(M0)::value) fb0[p] = *reinterpret_cast<const bf16x8*>(sB + (p * KS + c) * (SW * 32) + boff0);
+          if (decltype(M1)::value) fb1[p] = *reinterpret_cast<const bf16x8*>(sB + (p * KS + c) * (SW * 32) + boff1);
+        }
 #pragma unroll
-        for (int t = 0; t < 6; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[c][PROD_A[t]], fb[PROD_B[t]], acc, 0, 0, 0);
+        for (int h = 0; h < NSPLIT; ++h)                                  // (fa[] indexed statically)
+          if (h == kh) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+              if (decltype(M0)::value)
+                acc[t & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[h * KS + c][PROD_A[t]], fb0[PROD_B[t]], acc[t & 1], 0, 0, 0);
+              if (decltype(M1)::value)
+                acc[2 + (t & 1)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[h * KS + c][PROD_A[t]], fb1[PROD_B[t]], acc[2 + (t & 1)], 0, 0, 0);
+            }
+          }
       }
-      // D[row = pixel 4 kg + j][col = fmap2 column q0 + (lane & 15)]: keep what falls into that pixel's window
-      const int q = q0 + frow;
+    };
+    using T_ = std::integral_constant<bool, true>;
+    using F_ = std::integral_constant<bool, false>;
+    if (m0 && m1) run(T_{}, T_{});
+    else if (m0) run(T_{}, F_{});
+    else if (m1) run(F_{}, T_{});
+    if (kh != NSPLIT - 1) continue;
+    // D[row = pixel 4 kg + j][col = fmap2 column q0 + (lane & 15)]: keep what falls into that pixel's window
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      if (!(nt ? m1 : m0)) continue;
+      const int q = xs + nt * 16 + frow;
       if (q < W2) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int iy = y - cyr[j], ix = q - cxr[j];
-          if ((unsigned)iy < (unsigned)gd && (unsigned)ix < (unsigned)gd) s[(4 * kg + j) * npt + iy * gd + ix] = acc[j];
+          if ((unsigned)iy < (unsigned)gd && (unsigned)ix < (unsigned)gd) s[(4 * kg + j) * npt + iy * gd + ix] = acc[2 * nt][j] + acc[2 * nt + 1][j];
         }
       }
     }
@@ -238,14 +281,28 @@ __global__ __launch_bounds__(512) void altcorr_planes_fwd(const __bf16* __restri
   }
 }
 
+template <int R, int KCH, int TH, int KS, int NBUF>
+int launch_planes_form(const __bf16* f1, long f1_stride, const PlaneLevels& lv, const float* coords, float* out, int B, int H1, int W1, float scale,
+                       hipStream_t st) {
+  constexpr int lds = acp_lds_bytes<R, TH, KS, NBUF>();
+  static_assert(lds <= 160 * 1024, "LDS");
+  hipError_t e = ufr::ensure_dynamic_lds(reinterpret_cast<const void*>(altcorr_planes_fwd<R, KCH, TH, KS, NBUF>), lds);
+  if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "altcorr planes forward: %s", hipGetErrorString(e));
+  const int ntiles = B * ((H1 + TH - 1) / TH) * ((W1 + TW - 1) / TW);
+  altcorr_planes_fwd<R, KCH, TH, KS, NBUF><<<ntiles * lv.n, 64 * TH, lds, st>>>(f1, f1_stride, lv, coords, out, B, H1, W1, scale);
+  return ufr::launched("altcorr_planes_fwd");
+}
+
+// forms: 0 = 8 rows, whole-K stages, double buffer (one stage in flight); 1 = 8 rows, 4-chunk stages, three in flight;
+//        2 = 4 rows, 4-chunk stages, double buffer (75 KB of LDS: two workgroups per CU); 3 = 4 rows, whole-K stages, double buffer
 template <int R, int KCH>
 int launch_planes_fwd(const __bf16* f1, long f1_stride, const PlaneLevels& lv, const float* coords, float* out, int B, int H1, int W1, float scale,
                       hipStream_t st) {
-  hipError_t e = ufr::ensure_dynamic_lds(reinterpret_cast<const void*>(altcorr_planes_fwd<R, KCH>), acp_lds_bytes<R, KCH>());
-  if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "altcorr planes forward: %s", hipGetErrorString(e));
-  const int ntiles = B * ((H1 + TH - 1) / TH) * ((W1 + TW - 1) / TW);
-  altcorr_planes_fwd<R, KCH><<<ntiles * lv.n, 512, acp_lds_bytes<R, KCH>(), st>>>(f1, f1_stride, lv, coords, out, B, H1, W1, scale);
-  return ufr::launched("altcorr_planes_fwd");
+  static const int form = [] { const char* e = getenv("UFR_ALTCORR_PLANES_FORM"); return e ? atoi(e) : 0; }();
+  if (form == 1) return launch_planes_form<R, KCH, 8, 4, 4>(f1, f1_stride, lv, coords, out, B, H1, W1, scale, st);
+  if (form == 2) return launch_planes_form<R, KCH, 4, 4, 2>(f1, f1_stride, lv, coords, out, B, H1, W1, scale, st);
+  if (form == 3) return launch_planes_form<R, KCH, 4, KCH, 2>(f1, f1_stride, lv, coords, out, B, H1, W1, scale, st);
+  return launch_planes_form<R, KCH, 8, KCH, 2>(f1, f1_stride, lv, coords, out, B, H1, W1, scale, st);
 }
 
 }  // namespace
