@@ -647,6 +647,9 @@ typedef struct {
                                                   epilogue and leaves the counter at zero for the next launch.  NULL: the reduce kernel follows. */
 } ufr_igemm_desc;
 int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream);
+/* (ABI 9) Launches since load that asked for variant 8 (direct 3 x 3) or 7 (tap reuse) and ran as a plain tile form because their
+ * geometry is not covered: a tuning-table entry that reached a launch it was not swept for shows here (speed only, never results). */
+int ufr_igemm_variant_fallbacks(void);
 /* Measurement aid (tools/measure_clock.py): with a device buffer of 8 x capacity_workgroups uint64 set, every workgroup of the
  * ping-pong kernel (variant 6) records {s_memtime at entry, at exit, s_memrealtime at entry, at exit, s_memtime before and after
  * the K loop, HW_ID, K steps}: core cycles against the constant 100 MHz counter = the clock the kernel really ran at, and the

@@ -104,3 +104,41 @@ def test_flownet2_with_the_fused_glue_equals_the_torch_glue(monkeypatch, branch_
         # another order of additions, so a few pixels may move (tests/test_models_gpu.py::test_flownet2_vs_reference_wiring)
         tol = 1e-5 if name == "flow" else 2e-2
         assert _rel(a, b) <= tol, f"{name}: {_rel(a, b):.2e}"
+
+
+def test_input_gradients_survive_the_next_forward():
+    """inside FlowNet2's native path the engines hand aliases of their static buffers to each other
+    (`_lib.static_handoff`).  The gradients of the stacked frames `x` -- five consumers -- must NOT be such aliases: whichever
+    arrives first may be kept by reference in autograd's accumulation buffer, and the next forward would overwrite it.  A frame
+    gradient read AFTER a second forward / backward on other frames equals the copy taken right after the first."""
+    from argparse import Namespace
+
+    from understanding_flow_robustness_amd import _lib as L
+    from understanding_flow_robustness_amd.flownets.utils_model import fetch_model, predict_flow
+    args = Namespace(flownet="FlowNet2")
+    net = fetch_model(args, synthetic_seed=3).to(DEV).requires_grad_(False)
+    g = torch.Generator().manual_seed(5)
+    H, W = 64, 128
+    frames = [torch.rand(1, 3, H, W, generator=g).to(DEV) for _ in range(4)]
+    go = torch.randn(1, 2, H, W, generator=g).to(DEV)
+    a, b = frames[0].clone().requires_grad_(True), frames[1].clone().requires_grad_(True)
+    before = dict(L.VENDOR_FALLBACKS)
+    predict_flow(net, None, a, b, args).backward(go)
+    assert dict(L.VENDOR_FALLBACKS) == before, "the forward left the native path"
+    kept = (a.grad.clone(), b.grad.clone())
+    c, d = frames[2].clone().requires_grad_(True), frames[3].clone().requires_grad_(True)
+    predict_flow(net, None, c, d, args).backward(go)
+    torch.cuda.synchronize()
+    assert torch.equal(a.grad, kept[0]) and torch.equal(b.grad, kept[1]), "a frame gradient was a view of an engine buffer"
+    assert not torch.equal(c.grad, kept[0])
+    # the hand-off state is thread-local and empty outside the composition
+    assert not L.static_ok() and not L.static_grads_ok()
+    import threading
+    seen = []
+    with L.static_handoff():
+        t = threading.Thread(target=lambda: seen.append((L.static_ok(), L.static_grads_ok())))
+        t.start(); t.join()
+        assert L.static_ok() and L.static_grads_ok()
+        with L.static_handoff(input_grads=False):
+            assert L.static_ok() and not L.static_grads_ok()
+    assert seen == [(False, False)]

@@ -71,7 +71,10 @@ def _three_way(make, cin, B, H, W, monkeypatch, out_hw, seed):
     e_nt = _rel(ng, tg)
     print(f"native {e_out:.2e} / {e_g:.2e} (90 % within {q90:.2e}, {beyond:.2e} of the entries beyond 5e-6)   torch {t_out:.2e} / {t_g:.2e}   "
           f"native vs torch gradient {e_nt:.2e}")
-    assert e_out <= 5e-6 and q90 <= 5e-6 and e_g <= 2e-2 and beyond <= 5e-2, f"gradient vs float64: max {e_g:.2e}, 90 % within {q90:.2e}"
+    # (round 6, ADVICE r5: the worst entry bounded at ~2x the measured flip, 3.7e-3, instead of 2e-2, and the share of entries beyond
+    # rounding at the measured ~2 % of the cone instead of 5 %: a defect confined to a border tap or one tile moves its entries by O(1))
+    assert e_out <= 5e-6 and q90 <= 5e-6 and e_g <= 8e-3 and beyond <= 3e-2, \
+        f"gradient vs float64: max {e_g:.2e}, 90 % within {q90:.2e}, {beyond:.2e} of the entries beyond 5e-6"
     # second call through the cached schedule: same bits
     nout2, ng2 = _run(m, x, gy, monkeypatch, True)
     assert torch.equal(nout, nout2) and torch.equal(ng, ng2)

@@ -117,6 +117,15 @@ def main():
                                                                          nb, B, 3, H, W, st())))
             emit(f"resample2d_bwd, owner-computes (the default; image + flow gradients, {kind} flow)", cfg, ms,
                  (img.numel() + flow.numel() + gout.numel() + gimg.numel() + gflow.numel()) * 4)
+            if kind == "gentle":
+                # the FLOOR of that adjoint on this box: the same bytes -- image, flow and output gradient in, image and
+                # flow gradients out -- moved by two streaming kernels that compute nothing (gimg = img + gout; gflow = flow)
+                def floor():
+                    torch.add(img, gout, out=gimg)
+                    gflow.copy_(flow)
+                ms = timed(floor)
+                emit("resample2d_bwd FLOOR: the adjoint's bytes moved by two streaming kernels (gimg = img + gout; gflow = flow)", cfg, ms,
+                     (img.numel() + flow.numel() + gout.numel() + gimg.numel() + gflow.numel()) * 4)
         for C in (3, 2):
             x = rnd(B, C, H, W)
             nrm, gn, gx = torch.empty(B, 1, H, W, device=DEV), rnd(B, 1, H, W), torch.empty_like(x)

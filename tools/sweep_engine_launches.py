@@ -110,7 +110,7 @@ def sweep(config, out_dir):
         if kw.get("row_band") is not None or kw.get("in_band") is not None:
             continue
         M = r["x"].B * r["rows"][0] * r["rows"][1]
-        sig = ig.launch_signature(r["wi"], M, kw)
+        sig = ig.launch_signature(r["wi"], M, kw, r["rows"])     # (the long form: with the row grid)
         if sig in seen:
             seen[sig]["count"] += 1
             continue

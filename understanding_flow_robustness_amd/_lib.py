@@ -218,6 +218,7 @@ SIGNATURES = {
 }
 PLAIN = {"ufr_abi_version": (C.c_int, []), "ufr_last_error": (C.c_char_p, []),
          "ufr_device_count": (C.c_int, []), "ufr_build_manifest": (C.c_char_p, []),
+         "ufr_igemm_variant_fallbacks": (C.c_int, []),
          "ufr_conv3x3_c2_workspace_floats": (C.c_long, [_i, _i, _i, _i]),
          "ufr_cm_norm_workspace_doubles": (C.c_long, [_l, _i, _i]),
          "ufr_resample2d_backward_workspace_bytes": (C.c_long, [_i, _i, _i]),
@@ -423,19 +424,44 @@ class EngineCache(dict):
 # keeps nothing (FlowNet2's native path: fn2_glue.py Functions and engine Functions feeding each other) says so with
 # `with static_handoff():` around its sub-network calls; the Functions then pass aliases of the static buffers, forward and
 # (the choice is remembered in ctx) backward -- ~30 copy kernels per FlowNet2 iteration less.
-_STATIC_HANDOFF = [0]
+# Round 6: the state is THREAD-LOCAL (another thread's forward must not inherit it), and the input GRADIENTS are aliased only
+# where the composition says the differentiated tensor has ONE consumer (`input_grads=True`, the default inside the context): a gradient
+# that feeds a tensor with several consumers -- FlowNet2's stacked frames `x`, read by FlowNetC, FlowNet-SD, two warp stages and the
+# fusion input -- goes into autograd's accumulation buffer, where the FIRST arrival may be kept by reference: such calls are wrapped in
+# `static_handoff(input_grads=False)` and hand autograd clones, so no `.grad` can end up a view of an engine buffer that the next
+# forward overwrites (tests/test_fn2_glue_gpu.py::test_input_gradients_survive_the_next_forward).
+import threading
+
+_STATIC_HANDOFF = threading.local()
+
+
+def _handoff_stack() -> list:
+    st = getattr(_STATIC_HANDOFF, "stack", None)
+    if st is None:
+        st = _STATIC_HANDOFF.stack = []
+    return st
 
 
 class static_handoff:
+    def __init__(self, input_grads: bool = True):
+        self.input_grads = bool(input_grads)
+
     def __enter__(self):
-        _STATIC_HANDOFF[0] += 1
+        _handoff_stack().append(self.input_grads)
 
     def __exit__(self, *exc):
-        _STATIC_HANDOFF[0] -= 1
+        _handoff_stack().pop()
 
 
 def static_ok() -> bool:
-    return _STATIC_HANDOFF[0] > 0
+    """Forward results may be aliases of the engines' static buffers (every consumer reads at once)."""
+    return len(_handoff_stack()) > 0
+
+
+def static_grads_ok() -> bool:
+    """Input gradients may be aliases too: the innermost context says the differentiated inputs have one consumer each."""
+    st = _handoff_stack()
+    return len(st) > 0 and st[-1]
 
 
 _GRAD_FLAGS_ATTR = "_ufr_grad_flags"

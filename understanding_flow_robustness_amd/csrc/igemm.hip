@@ -28,6 +28,9 @@
 // Epilogues: forward  = bias + LeakyReLU -> planes;  gradient = (+ fp32 addend) * LeakyReLU'(mask) -> planes and / or
 // fp32.  Split-K (small layers: 6x20 and 12x40 grids cannot fill 256 CUs with 128x128 tiles) writes fp32 slabs that a
 // second kernel adds in a fixed order -- no float atomics anywhere, results are bit-reproducible.
+#include <atomic>
+#include <cstdlib>
+
 #include "ufr_common.h"
 
 namespace {
@@ -165,6 +168,8 @@ __device__ __forceinline__ void epilogue_store8(const Epilogue& e, long pout, in
       q0[j] = x; q1[j] = y; q2[j] = z;
     }
     __bf16* o = e.out_planes + (long)e.out_chunk0 * e.Mout * 32 + cm;
+    // (write-through `sc1` stores, which drop the line from the XCD's L2 instead of keeping it, measured SLOWER: FlowNetC 4.281 -> 4.315 ms,
+    // PWC-Net 16.52 -> 16.60, FlowNet2 9.52 -> 9.66, RAFT 14.90 -> 15.27 per iteration, one call, gpurun r6_wt)
     *reinterpret_cast<bf16x8*>(o) = q0;
     *reinterpret_cast<bf16x8*>(o + e.out_plane_stride) = q1;
     *reinterpret_cast<bf16x8*>(o + 2 * e.out_plane_stride) = q2;
@@ -213,6 +218,7 @@ struct Args {
   int per_k, sk[4], zoff[4];         // K tiles per slice; slices of each phase; first slice (z) of each phase
   float* ws;                         // split-K slabs [sum of sk][M][Npad]
   int* tickets;                      // fused split-K reduction: one arrival counter per (phase, row tile, column tile), zero between launches
+  int skip_out;                      // MEASUREMENT ONLY (UFR_IGEMM_DEBUG_SKIP_EPILOGUE=1): the accumulators are dropped -- what a launch costs without its epilogue
   Phase ph[4];
 };
 
@@ -284,6 +290,15 @@ template <int NPL, int MT, int WGR, int BNT>
 __device__ __forceinline__ void igemm_write_out(const Args& a, const Phase& ph, f32x4 (&acc)[MT][4], float* lds_f32, int* flag, int z, int phase,
                                                 int tile_id, int bm0, int bm, int bn0, int bn, int wrow, int wcol, int lane, int wave) {
   // C/D layout of the 16x16 forms: col = lane & 15, row = (lane >> 4) * 4 + reg
+  if (a.skip_out) {                  // measurement only: the upper bound of what hiding the epilogue under the next tile's K loop could return
+    float keep = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) keep += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+    if (keep == 1.2345678e-30f && a.ws) a.ws[0] = keep;      // (never true in practice: keeps the K loop alive)
+    return;
+  }
   if (a.splitk > 1) {
     float* slab = a.ws + (long)z * a.g.M * a.Npad;
 #pragma unroll
@@ -1094,6 +1109,11 @@ extern "C" int ufr_igemm_clock_probe(unsigned long long* buf, int capacity_workg
   return UFR_OK;
 }
 
+namespace {
+std::atomic<int> g_variant_fallbacks{0};     // launches that asked for variant 8 / 7 and ran as a plain tile form (geometry not covered)
+}
+extern "C" int ufr_igemm_variant_fallbacks(void) { return g_variant_fallbacks.load(); }
+
 extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   UFR_REQUIRE(d, "igemm: null descriptor");
   UFR_REQUIRE(d->x && d->w, "igemm: null operand");
@@ -1138,6 +1158,8 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   a.e.Mout = (long)d->B * d->Ho * d->Wo; a.e.N = d->N; a.e.Nchunks32 = (d->N + 31) / 32;
   a.nphase = d->nphase; a.splitk = d->splitk; a.ws = d->ws;
   a.tickets = (d->splitk > 1 && !d->no_reduce) ? d->tickets : nullptr;
+  static const int skip_out = [] { const char* e = getenv("UFR_IGEMM_DEBUG_SKIP_EPILOGUE"); return e && e[0] == '1' ? 1 : 0; }();
+  a.skip_out = skip_out;
   a.xcd = 1;                              // XCD-aware tile order (off: +0.2 ms per iteration, profiles/r2_bench_engine_v4_no_xcd_order)
   a.korder = d->k_order ? 1 : 0;
   for (int z = 0; z < 4; ++z) {
@@ -1219,6 +1241,8 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
              !d->out_rowmajor && d->k_order && d->N <= 64 && d->products == 6;
   for (int t = 0; d33 && t < 9; ++t)
     d33 = d->phase[0].dy[t] >= -1 && d->phase[0].dy[t] <= 1 && d->phase[0].dx[t] >= -1 && d->phase[0].dx[t] <= 1;
+  if ((variant == 8 && !d33) || (variant == 7 && !(d->k_order && (d->in_sx == 1 || d->in_sx == 2) && d->Wr >= 22 && d->products == 6)))
+    g_variant_fallbacks.fetch_add(1);        // (speed only: the plain forms compute the same sums; igemm.variant_fallbacks() shows it)
   if (d33) {
     const int nt = d->N <= 16 ? 1 : (d->N <= 32 ? 2 : 4);
     const int tiles = d->B * ((d->Hi + 3) / 4) * ((d->Wi + 31) / 32);

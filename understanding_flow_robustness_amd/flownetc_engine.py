@@ -115,7 +115,7 @@ class FlowNetCHeadEngine:
             kw.setdefault("variant", self._variant_for(wi))
             bm, target = self._tile_rows_and_slots(wi, kw)
             S = ig.splitk_for(M, wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target)
-            kw["variant"], S = ig.tuned(wi, M, kw, kw["variant"], S)
+            kw["variant"], S = ig.tuned(wi, M, kw, kw["variant"], S, rows=rows)
             plans.append((wi, x, in_chunk0, rows, out_hw, S, kw))
             return len(plans) - 1
 
@@ -739,7 +739,7 @@ class _EngineHead(torch.autograd.Function):
         engine.generation = ctx.generation = getattr(engine, "generation", 0) + 1
         # the engine's flow2 is a static buffer: hand autograd its own (2-channel, tiny) tensor -- or, inside a composition that
         # declared every consumer immediate (`_lib.static_handoff`), an alias of it
-        ctx.static = L.static_ok()
+        ctx.static, ctx.static_grads = L.static_ok(), L.static_grads_ok()
         flow2 = engine.forward(c2a.contiguous(), c3a.contiguous(), c3b.contiguous() if c3b is not None else None, band)
         return flow2.detach() if ctx.static else flow2.clone()
 
@@ -750,7 +750,7 @@ class _EngineHead(torch.autograd.Function):
                                "backward; its activations are gone.  Call backward() before the next forward, or set "
                                "UFR_ENGINE=0 for interleaved forwards")
         g2a, g3a, g3b = ctx.engine.backward(g_flow2.contiguous(), ctx.band, fused_window=False)
-        if ctx.static:
+        if ctx.static_grads:
             return g2a, g3a, g3b, None, None
         # static buffers as well: autograd (and a caller who retains .grad) gets its own copies
         return (g2a.clone() if g2a is not None else None, g3a.clone() if g3a is not None else None,

@@ -367,7 +367,10 @@ class FlowNet2(nn.Module):
         x = normalize_pair(x1, x2, self._mean64.reshape(-1))               # :93-96, :124-125 in one pass (bit-exact)
         fork = os.environ.get("UFR_FN2_BRANCH_STREAM", "1") != "0"
         main, side = torch.cuda.current_stream(x.device), _branch_stream(x.device)
-        sd = lambda: upscale4(self.flownets_d(x)[0], False, self.div_flow, divide=True)     # sic: divided (:176); nearest x4
+        # (FlowNet-SD and FlowNetC differentiate `x` itself, which has five consumers: their input gradients are handed over as clones)
+        def sd():
+            with _L.static_handoff(input_grads=False):
+                return upscale4(self.flownets_d(x)[0], False, self.div_flow, divide=True)    # sic: divided (:176); nearest x4
         # every sub-network's flow is read at once by `upscale4` / the next stage and kept by nobody: the engines hand over aliases
         # of their static buffers instead of clones (`_lib.static_handoff`); the fusion network's result goes to the caller and is
         # cloned as ever
@@ -376,7 +379,8 @@ class FlowNet2(nn.Module):
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     flow_sd = sd()
-            flow_c = upscale4(self.flownetc(x)[0], True, self.div_flow)    # == interpolate(flow * div_flow, x4, bilinear)
+            with _L.static_handoff(input_grads=False):
+                flow_c = upscale4(self.flownetc(x)[0], True, self.div_flow)    # == interpolate(flow * div_flow, x4, bilinear)
             flow_s1 = upscale4(self.flownets_1(warp_stage(x, flow_c, self.div_flow))[0], True, self.div_flow)
             flow_s2 = upscale4(self.flownets_2(warp_stage(x, flow_s1, self.div_flow))[0], False, self.div_flow)
             if fork:

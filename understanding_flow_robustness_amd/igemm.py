@@ -359,13 +359,16 @@ class products:
 RECORD = None            # a list while tools/sweep_engine_launches.py builds a step: every make_launch() appends its arguments
 
 
-def launch_signature(wi: "WeightImage", M: int, kw: dict) -> str:
-    """What decides a launch's best form: rows, padded columns, K chunks, taps per phase, strides, and how the result leaves."""
+def launch_signature(wi: "WeightImage", M: int, kw: dict, rows=None) -> str:
+    """What decides a launch's best form: rows, padded columns, K chunks, taps per phase, strides, and how the result leaves; with
+    `rows` = (Hr, Wr) also the row grid's shape (round 6, ADVICE r5: variant 8 needs stride-1 3 x 3 launches, variant 7 a grid of at
+    least 22 columns -- two launches with equal M and different grids are different launches; new sweeps write the long form)."""
     out = ("slabs" if kw.get("no_reduce") else "rowmajor" if kw.get("out_rowmajor") is not None else
            ("planes" if kw.get("out_planes") is not None else "") + ("f32" if kw.get("out_f32") is not None else ""))
     out += ("+add" if kw.get("add") is not None else "") + ("+mask" if kw.get("mask") is not None else "") + ("+tail" if kw.get("tail") is not None else "")
     taps = "-".join(str(len(t)) for _, _, t in wi.phases)
-    return f"M{M}_N{wi.Npad}_KC{wi.KC}_t{taps}_s{wi.geometry['in_s']}{wi.geometry['out_s']}_{out}"
+    grid = f"_g{int(rows[0])}x{int(rows[1])}" if rows is not None else ""
+    return f"M{M}_N{wi.Npad}_KC{wi.KC}_t{taps}_s{wi.geometry['in_s']}{wi.geometry['out_s']}_{out}{grid}"
 
 
 def _tuning_table() -> dict:
@@ -377,15 +380,25 @@ def _tuning_table() -> dict:
         if os.environ.get("UFR_IGEMM_TUNING", "1") != "0" and os.path.exists(path):
             import json
             with open(path) as f:
-                _TUNING = {k: tuple(v) for k, v in json.load(f).items() if not k.startswith("_")}
+                raw = json.load(f)
+            if raw.get("_arch", "gfx950") == "gfx950":          # the table is this chip's (the library is built for gfx950 only)
+                _TUNING = {k: tuple(v) for k, v in raw.items() if not k.startswith("_")}
     return _TUNING
 
 
-def tuned(wi: "WeightImage", M: int, kw: dict, variant: int, splitk: int):
+def variant_fallbacks() -> int:
+    """Launches since load that asked for the direct 3 x 3 form (variant 8) or the tap-reuse form (variant 7) and ran as a plain tile form
+    because their geometry is not covered (csrc/igemm.hip counts them): a tuning-table entry that reached the wrong launch shows here."""
+    return int(L.lib().ufr_igemm_variant_fallbacks())
+
+
+def tuned(wi: "WeightImage", M: int, kw: dict, variant: int, splitk: int, rows=None):
     """(variant, splitk) of the tuning table for this launch, else the engine's own choice.  A launch whose twin with (without) the
     epilogue's `add` was swept takes the twin's entry: the addend is one more 32-byte read per output row of the epilogue, nothing
     the choice of form depends on (PlaneGraph drops the `add` of a segment's first writer: plane_graph._plan_first_writers)."""
     table, sig = _tuning_table(), launch_signature(wi, M, kw)
+    if rows is not None and launch_signature(wi, M, kw, rows) in table:       # the long form (with the row grid) first
+        return table[launch_signature(wi, M, kw, rows)]
     if sig in table:
         return table[sig]
     head, _, out = sig.rpartition("_")

@@ -278,7 +278,7 @@ class PlaneGraph:
             pk = [len(t) * wi.KC for _, _, t in wi.phases]
             bm, target = (256, 256) if kw["variant"] in (6, 7) else (128, 768)
             S = ig.splitk_for(B * rows[0] * rows[1], wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target, min_ktiles=4)
-            kw["variant"], S = ig.tuned(wi, B * rows[0] * rows[1], kw, kw["variant"], S)
+            kw["variant"], S = ig.tuned(wi, B * rows[0] * rows[1], kw, kw["variant"], S, rows=rows)
             sized.append(S)
         need = max([len(p[1].phases) * S * B * p[4][0] * p[4][1] * p[1].Npad for p, S in zip(self._plans, sized) if S > 1] + [1])
         self.ws = torch.empty(need, dtype=torch.float32, device=self.dev)
@@ -386,6 +386,7 @@ class _GraphFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, graph, *inputs):
         ctx.static = L.static_ok()            # (`_lib.static_handoff`: every consumer reads at once -> aliases instead of clones)
+        ctx.static_grads = L.static_grads_ok()   # (... and the inputs have one consumer each: their gradients may be aliases too)
         outs = [o.detach() if ctx.static else o.clone() for o in graph.forward(*inputs)]
         ctx.graph, ctx.generation = graph, graph.generation
         return tuple(outs)
@@ -396,7 +397,7 @@ class _GraphFunction(torch.autograd.Function):
             raise RuntimeError("native sub-network: another forward (same batch and frame size) ran before this backward; its "
                                "activations are gone.  Call backward() before the next forward, or set UFR_ENGINE=0")
         gs = ctx.graph.backward(*[g.contiguous() for g in grads])
-        return (None, *[g if ctx.static else g.clone() for g in gs])
+        return (None, *[g if ctx.static_grads else g.clone() for g in gs])
 
 
 def run(graph: PlaneGraph, *inputs):

@@ -202,7 +202,7 @@ class PwcHeadEngine:
             bm, target = self._tile(wi, kw["variant"])
             S = ig.splitk_for(n * g[rows_k][0] * g[rows_k][1], wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target,
                               min_ktiles=4)
-            kw["variant"], S = ig.tuned(wi, n * g[rows_k][0] * g[rows_k][1], kw, kw["variant"], S)
+            kw["variant"], S = ig.tuned(wi, n * g[rows_k][0] * g[rows_k][1], kw, kw["variant"], S, rows=g[rows_k])
             plans.append((key, kind, wi, x, in_chunk0, g[rows_k], g[out_k], S, kw))
 
         bias = lambda name: self._conv(name).bias.detach().float().contiguous()

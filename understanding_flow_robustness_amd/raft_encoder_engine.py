@@ -168,7 +168,7 @@ class RaftEncoderEngine:
             v = kw["variant"]
             bm, target = (256, 256) if v in (6, 7) else (128, 768)
             S = ig.splitk_for(n * rows[0] * rows[1], wi.Npad, max(pk), len(wi.phases), phase_ktiles=pk, bm=bm, target=target, min_ktiles=4)
-            kw["variant"], S = ig.tuned(wi, n * rows[0] * rows[1], kw, v, S)
+            kw["variant"], S = ig.tuned(wi, n * rows[0] * rows[1], kw, v, S, rows=rows)
             sized.append(S)
         need = max([len(p[1].phases) * S * n * p[3][0] * p[3][1] * p[1].Npad for p, S in zip(self._plans, sized) if S > 1] + [1])
         self.ws = torch.empty(need, dtype=torch.float32, device=dev)

@@ -174,7 +174,7 @@ class RaftUpdateEngine:
             kw.setdefault("variant", 6 if wi.Npad % 128 == 0 else 2)
             bm, target = (256, 256) if kw["variant"] == 6 else (128, 768)
             S = ig.splitk_for(self.M, wi.Npad, max(pk), 1, phase_ktiles=pk, bm=bm, target=target, min_ktiles=4)
-            kw["variant"], S = ig.tuned(wi, self.M, kw, kw["variant"], S)
+            kw["variant"], S = ig.tuned(wi, self.M, kw, kw["variant"], S, rows=(h, w))
             # (capping the split because a second stream fills the chip anyway measured SLOWER: 16.02 ms -> 16.47 at <= 2 slices, 20.16
             # without split-K, gpurun r5_call11: a lone ping-pong workgroup per CU is latency-bound, short slices are the cure)
             if ctx is not None and not (kw.get("no_reduce") and S > 1):
