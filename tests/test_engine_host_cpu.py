@@ -320,3 +320,34 @@ def test_igemm_host_arithmetic_runs_up_to_the_launch_without_a_device():
     bad.splitk = 65
     assert lib.ufr_igemm(C.byref(bad), None) == -1 and b"split" in lib.ufr_last_error()
     bad.splitk = keep
+
+
+def test_frozen_module_deep_copy_keeps_the_callers_flags_and_workspace_caches_are_lru():
+    """(a) `freeze_parameters` records the caller's `requires_grad` flags once per module; a deep copy of the frozen module
+    carries the record re-keyed onto ITS parameters, so `restore_parameters(copy)` restores the copy (it used to get an empty record
+    and stayed frozen for good); (b) the module-level workspace caches evict the least recently used entry instead of being cleared."""
+    import copy
+
+    from understanding_flow_robustness_amd import _lib as L
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.Conv2d(4, 2, 3))
+    net[1].weight.requires_grad_(False)                                    # the caller froze one tensor himself
+    want = [p.requires_grad for p in net.parameters()]
+    L.freeze_parameters(net)
+    assert not any(p.requires_grad for p in net.parameters())
+    twin = copy.deepcopy(net)
+    assert not any(p.requires_grad for p in twin.parameters())
+    rec = twin.__dict__[L._GRAD_FLAGS_ATTR]
+    assert {id(p) for p in twin.parameters()} == set(rec) and all(rec[id(p)][0] is p for p in twin.parameters())
+    L.restore_parameters(twin)
+    assert [p.requires_grad for p in twin.parameters()] == want
+    assert not any(p.requires_grad for p in net.parameters())              # the original is still frozen ...
+    L.restore_parameters(net)
+    assert [p.requires_grad for p in net.parameters()] == want             # ... until its own restore
+    c = L.LruDict(3)
+    for k in "abc":
+        c[k] = k.upper()
+    assert c.get("a") == "A"                                               # a hit makes "a" the most recently used
+    c["d"] = "D"
+    assert sorted(c) == ["a", "c", "d"] and c.get("b") is None
+    c["c"] = "C2"                                                          # an existing key never evicts
+    assert len(c) == 3

@@ -468,7 +468,9 @@ _GRAD_FLAGS_ATTR = "_ufr_grad_flags"
 
 
 def freeze_parameters(module) -> None:
-    """The fused steps compute data gradients only: they freeze the caller's parameters.  The flags the CALLER had are
+    """(A caller who changes `requires_grad` by hand between two attacks calls `patch_attack.release(net)` FIRST: the record is made
+    once per module and `release()` / `restore_parameters()` write it back as it was made.)
+    The fused steps compute data gradients only: they freeze the caller's parameters.  The flags the CALLER had are
     recorded ONCE per module (`module.__dict__[_GRAD_FLAGS_ATTR]`, an EngineCache-like dict that copies / pickles empty), at the
     first freeze -- a later step sees parameters that are already frozen and must not overwrite the record, and the record must
     not depend on which step the LRU step cache happens to hold or to iterate first."""
@@ -486,10 +488,41 @@ def restore_parameters(module) -> None:
 
 class _GradFlags(dict):
     def __deepcopy__(self, memo):
-        return _GradFlags()
+        """A deep copy of a frozen module is frozen too, so it carries the CALLER's flags for its own parameters: the record is
+        re-keyed onto the copies (`memo` maps every original parameter onto its copy), and `restore_parameters(copy)` gives the
+        copy's parameters back what the caller had set (round 6, ADVICE r5: the copy used to get an empty record and stayed frozen)."""
+        import copy as _copy
+        out = _GradFlags()
+        for p, flag in self.values():
+            q = _copy.deepcopy(p, memo)
+            out[id(q)] = (q, flag)
+        return out
 
     def __reduce__(self):
         return (_GradFlags, ())
+
+
+class LruDict(dict):
+    """A small module-level workspace cache: `get` makes an entry the most recently used one, an insert beyond `capacity` drops the
+    LEAST recently used one (round 6, ADVICE r5: these caches used to be cleared whole at a fixed count)."""
+
+    def __init__(self, capacity: int):
+        super().__init__()
+        self.capacity = int(capacity)
+
+    def get(self, key, default=None):
+        if key in self:
+            value = super().pop(key)
+            super().__setitem__(key, value)
+            return value
+        return default
+
+    def __setitem__(self, key, value):
+        if key in self:
+            super().pop(key)
+        elif len(self) >= self.capacity:
+            del self[next(iter(self))]
+        super().__setitem__(key, value)
 
 
 def engine_cache(module, attr: str) -> EngineCache:

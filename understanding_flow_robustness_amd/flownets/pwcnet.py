@@ -31,7 +31,7 @@ def correlate(input1, input2):
     return _correlate(input1, input2, patch_size=9, dilation_patch=1)
 
 
-_WARP_WORKSPACES: dict = {}       # (device, stream, B, H, W) -> the owner-computes adjoint's table of sampling boxes
+_WARP_WORKSPACES = L.LruDict(32)       # (device, stream, B, H, W) -> the owner-computes adjoint's table of sampling boxes
 
 
 def warp_backward(x, flo, g, gx, gf):
@@ -46,8 +46,6 @@ def warp_backward(x, flo, g, gx, gf):
     key = (x.device, torch.cuda.current_stream(x.device).cuda_stream, B, H, W)
     ws = _WARP_WORKSPACES.get(key)
     if ws is None:
-        if len(_WARP_WORKSPACES) >= 32:
-            _WARP_WORKSPACES.clear()
         nbytes = int(lib.ufr_pwc_warp_backward_workspace_bytes(B, H, W))
         ws = _WARP_WORKSPACES[key] = (torch.empty((nbytes + 15) // 16 * 4, dtype=torch.int32, device=x.device), nbytes)
     L.check(lib.ufr_pwc_warp_backward_owner(L.ptr(x), L.ptr(flo), L.ptr(g), L.ptr(gx), L.ptr(gf), L.ptr(ws[0]), ws[1], B, Cn, H, W,

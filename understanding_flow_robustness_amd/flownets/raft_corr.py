@@ -96,7 +96,7 @@ def corr_lookup(pyramid, coords, radius, shared=None):
     return CorrLookupFunction.apply(coords, radius, shared, *pyramid)
 
 
-_ALL_PAIRS_PLANES: dict = {}
+_ALL_PAIRS_PLANES = L.LruDict(8)
 
 
 def _all_pairs_planes(device, H, W, chunks):
@@ -105,13 +105,11 @@ def _all_pairs_planes(device, H, W, chunks):
     from .. import igemm as ig
     key = (device, H, W, chunks)
     if key not in _ALL_PAIRS_PLANES:
-        if len(_ALL_PAIRS_PLANES) >= 8:
-            _ALL_PAIRS_PLANES.clear()
         _ALL_PAIRS_PLANES[key] = (ig.Planes(1, H, W, chunks, device), ig.Planes(1, H, W, chunks, device))
-    return _ALL_PAIRS_PLANES[key]
+    return _ALL_PAIRS_PLANES.get(key)
 
 
-_ALL_PAIRS_ADJOINT: dict = {}
+_ALL_PAIRS_ADJOINT = L.LruDict(4)
 
 
 def _all_pairs_adjoint(fmap1, fmap2, g, scale, needs):
@@ -122,8 +120,6 @@ def _all_pairs_adjoint(fmap1, fmap2, g, scale, needs):
     key = (dev, H, W, C_)
     st = _ALL_PAIRS_ADJOINT.get(key)
     if st is None:
-        if len(_ALL_PAIRS_ADJOINT) >= 4:
-            _ALL_PAIRS_ADJOINT.clear()
         st = _ALL_PAIRS_ADJOINT[key] = dict(A=ig.Planes(1, H, W, HW // 32, dev),            # the gradient as the activation
                                             Wf=ig.Planes(1, 1, C_, HW // 32, dev),           # a feature map [C, HW] as the weights
                                             out=ig.GradSum(1, H, W, C_ // 32, dev))

@@ -25,7 +25,7 @@ def _check(**tensors):
             raise RuntimeError(f"{n} must be 4-D")
 
 
-_WORKSPACES: dict = {}            # (device, stream, B, H, W) -> int32 workspace of the owner-computes adjoint (sampling boxes per tile)
+_WORKSPACES = L.LruDict(16)            # (device, stream, B, H, W) -> int32 workspace of the owner-computes adjoint (sampling boxes per tile)
 
 
 def _workspace(device, B, H, W):
@@ -34,8 +34,6 @@ def _workspace(device, B, H, W):
     key = (device, torch.cuda.current_stream(device).cuda_stream, B, H, W)
     ws = _WORKSPACES.get(key)
     if ws is None:
-        if len(_WORKSPACES) >= 16:
-            _WORKSPACES.clear()
         nbytes = int(L.lib().ufr_resample2d_backward_workspace_bytes(B, H, W))
         ws = _WORKSPACES[key] = (torch.empty((nbytes + 15) // 16 * 4, dtype=torch.int32, device=device), nbytes)
     return ws
