@@ -25,6 +25,10 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 constexpr int AC_TP = 16;                    // pixels per tile (one MFMA M block)
+// (The two adjoint kernels run on the update engine's SIDE stream next to the GRU adjoint of the previous iteration and fill six of a
+// SIMD's eight wave slots; the main chain's small streaming kernels then wait for slots -- gates_bwd 9 us alone, up to 90 us beside
+// altcorr_mfma_bwd2.  Capping these kernels at 3 / 2 waves per SIMD measured SLOWER, 15.49 -> 15.58 / 16.05 ms per iteration at one pair,
+// 85.6 -> 89.1 / 93.2 at eight, one call, gpurun r6_occ: the side chain is the backward's critical path, see profiles/r6_side_occupancy_rejected.txt.)
 
 struct AcLevels {                            // by value in the kernel arguments
   int n;

@@ -386,6 +386,57 @@ __global__ void lookup_bwd(ufr_pyramid pyr, const float* __restrict__ coords,
   }
 }
 
+// The same adjoint with the (2r + 2)^2 grid points of a pixel dealt to the LANES (round 6): the one-thread-per-(pixel, level) form above
+// walks its 100 read-modify-writes one after the other -- 30,720 threads on a 48 x 160 grid, ~1 us per dependent round trip: 100 us
+// per lookup, 1.2 ms of a RAFT iteration (profiles/r6_c3_step_trace.md).  Here a workgroup owns 16 consecutive pixels of one level:
+// their (2r+1)^2 x 16 output gradients are staged through LDS (coalesced: 16 pixels of a channel are 64 contiguous bytes), then
+// consecutive lanes take consecutive grid points of ONE pixel -- a grid row is one contiguous 40-byte run of that pixel's volume
+// slice -- and every (pixel, point) is one independent read-modify-write.  Still one writer per slice (the tile owns its pixels): no
+// atomics, and the same four products in the same order as above: bit-identical results.
+template <int RADIUS>
+__global__ __launch_bounds__(256) void lookup_bwd_tiled(ufr_pyramid pyr, const float* __restrict__ coords, const float* __restrict__ gout,
+                                                        int B, int H1, int W1) {
+  constexpr int r = RADIUS, rd = 2 * RADIUS + 1, gd = rd + 1, TP = 16;
+  __shared__ float sg[rd * rd][TP];
+  __shared__ float sax[TP], say[TP];
+  __shared__ int sxb[TP], syb[TP];
+  const int L = pyr.num_levels;
+  const size_t plane = (size_t)H1 * W1;
+  const int tiles = (int)((plane + TP - 1) / TP);
+  const int l = blockIdx.y, tile = blockIdx.x % tiles, b = blockIdx.x / tiles;
+  const size_t q0 = (size_t)tile * TP;
+  const int Hl = pyr.Hl[l], Wl = pyr.Wl[l], tid = threadIdx.x;
+  const float* g = gout + ((size_t)b * L * rd * rd + (size_t)l * rd * rd) * plane + q0;
+  for (int t = tid; t < rd * rd * TP; t += 256) {
+    const int ch = t >> 4, i = t & 15;
+    sg[ch][i] = q0 + i < plane ? g[(size_t)ch * plane + i] : 0.f;
+  }
+  if (tid < TP) {
+    const size_t q = min(q0 + tid, plane - 1);
+    const float inv = 1.0f / (float)(1 << l);
+    const float cx = coords[((size_t)b * 2 + 0) * plane + q] * inv, cy = coords[((size_t)b * 2 + 1) * plane + q] * inv;
+    const float x0f = floorf(cx), y0f = floorf(cy);
+    sax[tid] = cx - x0f; say[tid] = cy - y0f;
+    sxb[tid] = (int)x0f - r; syb[tid] = (int)y0f - r;
+  }
+  __syncthreads();
+  for (int t = tid; t < TP * gd * gd; t += 256) {
+    const int i = t / (gd * gd), pt = t - i * (gd * gd), gy = pt / gd, gx = pt - gy * gd;
+    if (q0 + i >= plane) continue;
+    const int yy = syb[i] + gy, xx = sxb[i] + gx;
+    if (yy < 0 || yy >= Hl || xx < 0 || xx >= Wl) continue;
+    const float ax = sax[i], ay = say[i];
+    // grid point (gy, gx) receives from samples (j, i) in {gy-1, gy} x {gx-1, gx}: gcur = g[.][gy], gprev = g[.][gy - 1] (0 outside)
+    const float c0 = (gx < rd && gy < rd) ? sg[gx * rd + gy][i] : 0.f, p0 = (gx < rd && gy > 0) ? sg[gx * rd + gy - 1][i] : 0.f;
+    const float c1 = (gx > 0 && gy < rd) ? sg[(gx - 1) * rd + gy][i] : 0.f, p1 = (gx > 0 && gy > 0) ? sg[(gx - 1) * rd + gy - 1][i] : 0.f;
+    float acc = 0.f;
+    if (gx < rd) acc += c0 * (1 - ax) * (1 - ay) + p0 * (1 - ax) * ay;
+    if (gx > 0) acc += c1 * ax * (1 - ay) + p1 * ax * ay;
+    float* gv = pyr.grad_vol[l] + ((size_t)b * plane + q0 + i) * Hl * Wl;
+    gv[(size_t)yy * Wl + xx] += acc;
+  }
+}
+
 }  // namespace
 
 extern "C" int ufr_altcorr_forward(const float* fmap1, const float* fmap2, const float* coords,
@@ -486,6 +537,13 @@ extern "C" int ufr_corr_lookup_backward(const ufr_pyramid* pyr, const float* coo
   const long total = (long)B * H1 * W1 * pyr->num_levels;
   const dim3 grid(ufr::stream_grid(total, 128)), block(128);
   hipStream_t st = ufr::as_stream(stream);
+  static const bool tiled = [] { const char* e = getenv("UFR_LOOKUP_BWD_TILED"); return !(e && e[0] == '0'); }();
+  if (tiled && (radius == 4 || radius == 3) && (long)B * ((H1 * W1 + 15) / 16) < (1L << 31)) {   // RAFT's radii: grid points over the lanes
+    const dim3 gt((unsigned)(B * ((H1 * W1 + 15) / 16)), pyr->num_levels);
+    if (radius == 4) lookup_bwd_tiled<4><<<gt, 256, 0, st>>>(*pyr, coords, grad_out, B, H1, W1);
+    else lookup_bwd_tiled<3><<<gt, 256, 0, st>>>(*pyr, coords, grad_out, B, H1, W1);
+    return ufr::launched("lookup_bwd_tiled");
+  }
   switch (radius) {
     case 0: hipLaunchKernelGGL(lookup_bwd<0>, grid, block, 0, st, *pyr, coords, grad_out, B, H1, W1); break;
     case 1: hipLaunchKernelGGL(lookup_bwd<1>, grid, block, 0, st, *pyr, coords, grad_out, B, H1, W1); break;
