@@ -104,7 +104,7 @@ def event_time(fn, iters, warm=2):
 
 
 # PMC summaries of the latest passes over this command (tools/gpu_call.sh `traffic` step -> tools/pmc_step_traffic.py)
-IGEMM_TRAFFIC, STEP_TRAFFIC, CORR_TRAFFIC = "r5_igemm_traffic.json", "r5_step_traffic.json", "r4_corr_planes_traffic.json"
+IGEMM_TRAFFIC, STEP_TRAFFIC, CORR_TRAFFIC = "r6_igemm_traffic.json", "r6_step_traffic.json", "r4_corr_planes_traffic.json"
 
 
 def _pmc(name):
@@ -699,7 +699,19 @@ def c2_line(line, opt, ctx, world, device, ms, mc):
                 line["config"][f"{w}_ms"] = r["ms_per_iteration"]
                 if r.get("roofline"):
                     line["config"][f"{w}_igemm_frac"] = r["roofline"]["frac"]
-            line["config"]["other_configs"] = [r for _, r in others]
+            # RAFT's opt-in reduced precision as a SECOND C3 figure (flownets/raft.py: args.mixed_precision AND UFR_RAFT_PRECISION=bf16 --
+            # one bf16 product per float32 product in the encoders and the update block, the reference's autocast; the C3 line above is float32)
+            saved = os.environ.get("UFR_RAFT_PRECISION")
+            os.environ["UFR_RAFT_PRECISION"] = "bf16"
+            try:
+                low = bench_configs.measure("c3alt", 6)
+            finally:
+                if saved is None:
+                    os.environ.pop("UFR_RAFT_PRECISION", None)
+                else:
+                    os.environ["UFR_RAFT_PRECISION"] = saved
+            line["config"]["c3alt_bf16_ms"] = low["ms_per_iteration"]
+            line["config"]["other_configs"] = [r for _, r in others] + [low]
         if step.cone is not None and not opt.no_full_frame:
             # the same protocol with every frame-sized shortcut off (UFR_CONE=0): what the windowed prefix,
             # band and incremental forward are worth, measured in this very process
