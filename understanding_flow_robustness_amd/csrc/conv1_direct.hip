@@ -15,8 +15,8 @@
 //     8 = (two adjacent input pixels) x (4 channels) is ONE aligned ds_read_b128.  A K tile of 32 = one kernel row ky: 4 pixel
 //     pairs (kx = 0..7; kx = 7 and channel 3 carry zero weights).  K = 7 x 32 = 224.
 //   * MFMA roles are swapped against the igemm: A = weights (16 output channels x 32 k), B = pixels (16 pixels x 32 k), so the
-//     accumulator of a lane is FOUR CONSECUTIVE CHANNELS of one pixel: the epilogue needs no LDS transpose, a lane writes 8
-//     bytes per plane, the four lane groups of a pixel 32 contiguous bytes.
+//     accumulator of a lane is FOUR CONSECUTIVE CHANNELS of one pixel: the epilogue needs no LDS transpose; round 6 pairs the two runs of
+//     a tile row and exchanges between lane groups so that a lane writes 16 bytes (eight consecutive channels) per plane.
 //   * a wave owns 16 output channels and keeps their whole weight image in registers (7 K tiles x 3 planes = 84 VGPRs, loaded
 //     once per workgroup): no weight traffic in the loop, LDS is read for the pixels only (21 ds_read_b128 per 42 MFMAs).
 //     Eight waves = 4 channel quarters x 2 halves of the tile's rows.
@@ -161,34 +161,57 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // the epilogue of run pt - 1 (bias, LeakyReLU, the three-plane split, three 8-byte stores: ~70 vector instructions) is emitted
     // INSIDE run pt's MFMA stream: an MFMA holds the issue port for 8 of its 16 cycles, so two vector instructions per MFMA
     // ride in its shadow (the sched_group_barrier pattern below asks for exactly that interleaving)
+    // Round 6: 16-byte stores.  A lane's accumulator is four consecutive channels of one pixel; the two 16-pixel runs of a tile row (pt even /
+    // odd) are paired: lane groups g and g ^ 1 (lanes l and l ^ 16) hold channels 4g .. 4g + 3 of the SAME pixel, so one exchange gives the
+    // even group eight consecutive channels of its pixel of the even run and the odd group eight of its pixel of the odd run: three 16-byte
+    // stores per lane and pair of runs instead of six 8-byte ones (8-byte accesses run at 0.54 - 0.70 of the 16-byte rate,
+    // MI355X_MICROARCH.md).  The even run's epilogue only keeps its four activated values (`vkeep`), the odd run's does the exchange.
+    float vkeep[4] = {0.f, 0.f, 0.f, 0.f};
     auto epilogue = [&](int pt, const f32x4 (&acc)[4]) {
-      const int yy = half * 4 + (pt >> 1);
-      const int y = Y0 + yy, x = X0 + (pt & 1) * 16 + li;
-      bf16x4 o0, o1, o2;
+      float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]) + bias4[r];
-        v = v > 0.f ? v : v * a.slope;
+        v[r] = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]) + bias4[r];
+        v[r] = v[r] > 0.f ? v[r] : v[r] * a.slope;
+      }
+      if (!(pt & 1)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vkeep[r] = v[r];
+        return;
+      }
+      const bool even = !(g & 1);
+      float out8[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float got = __shfl_xor(even ? v[r] : vkeep[r], 16);   // the partner group's four channels of MY pixel
+        out8[r] = even ? vkeep[r] : got;                            // even group: its pixel of the even run, channels 4g .. 4g + 7
+        out8[4 + r] = even ? got : v[r];                            // odd group: its pixel of the odd run, channels 4(g - 1) .. 4(g - 1) + 7
+      }
+      bf16x8 o0, o1, o2;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
         __bf16 b0, b1, b2;
-        split3(v, b0, b1, b2);
+        split3(out8[r], b0, b1, b2);
         o0[r] = b0; o1[r] = b1; o2[r] = b2;
       }
+      const int yy = half * 4 + (pt >> 1);
+      const int y = Y0 + yy, x = X0 + (even ? 0 : 16) + li;
       const long m = ((long)n * Hh + y) * Wh + x;
-      const long e = ((long)(a.out_chunk0 + (q >> 1)) * M + m) * 32 + (q & 1) * 16 + g * 4;        // element inside plane 0
+      const long e = ((long)(a.out_chunk0 + (q >> 1)) * M + m) * 32 + (q & 1) * 16 + (g & 2) * 4;  // element inside plane 0
       const bool live = y < Hh && x < Wh;
       if constexpr (BUF_) {
         // unconditional buffer stores (a pixel outside the grid gets an out-of-range offset: the hardware drops it), so that the
-        // compiler can COUNT the stores between the prefetched loads and their use (vmcnt(24), not a drain of the stores)
+        // compiler can COUNT the stores between the prefetched loads and their use, not drain them
         const unsigned off = live ? (unsigned)(e * 2) : 0x80000000u;
-        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o0), rsrc, off, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o1), rsrc, off, (unsigned)(a.plane_stride * 2), 0);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o2), rsrc, off, (unsigned)(a.plane_stride * 4), 0);
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rsrc, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rsrc, off, (unsigned)(a.plane_stride * 2), 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o2), rsrc, off, (unsigned)(a.plane_stride * 4), 0);
       } else if (live) {
         __bf16* o = a.out + e;
-        *reinterpret_cast<bf16x4*>(o) = o0;
-        *reinterpret_cast<bf16x4*>(o + a.plane_stride) = o1;
-        *reinterpret_cast<bf16x4*>(o + 2 * a.plane_stride) = o2;
+        *reinterpret_cast<bf16x8*>(o) = o0;
+        *reinterpret_cast<bf16x8*>(o + a.plane_stride) = o1;
+        *reinterpret_cast<bf16x8*>(o + 2 * a.plane_stride) = o2;
       }
     };
     f32x4 acc_prev[4];
