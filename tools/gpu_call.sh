@@ -68,7 +68,8 @@ for step in "$@"; do
              timeout -k 10 1100 python tools/bench_configs.py $arg > $cl 2>&1; rc=$?; tail -n 12 $cl
              [ $rc -ne 0 ] && exit $rc ;;
     env)     export $arg ;;                      # env:NAME=VALUE for the steps behind it
-    py)      timeout -k 10 1100 python $arg > $out/py.log 2>&1; rc=$?; tail -n 40 $out/py.log
+    py)      np=$((${np:-0} + 1)); pl=$out/py$([ $np -gt 1 ] && echo _$np).log          # a second py step of a call: py_2.log
+             timeout -k 10 1100 python $arg > $pl 2>&1; rc=$?; tail -n 40 $pl
              [ $rc -ne 0 ] && exit $rc ;;
     *)       echo "unknown step $step"; exit 2 ;;
   esac

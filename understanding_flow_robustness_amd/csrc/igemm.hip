@@ -68,6 +68,7 @@ struct Epilogue {
   float* out_rm; long out_ld;         // optional ROW-MAJOR fp32 output [Mout][out_ld] (RAFT's all-pairs volume: a row = one pixel's N sums)
   float* tail; int tail_n0, tail_acc; // columns >= tail_n0 (a multiple of 32): raw sums to (tail_acc: added onto) this fp32 chunk-major tensor
   long Mout; int N, Nchunks32;        // channels < Nchunks32*32 are written (zeros beyond N: the chunk's padding)
+  int nostore;                        // MEASUREMENT ONLY (UFR_IGEMM_DEBUG_SKIP_EPILOGUE=2): the epilogue computes everything and stores nothing
 };
 
 __device__ __forceinline__ void epilogue_store(const Epilogue& e, long pout, int n, float v) {
@@ -170,6 +171,10 @@ __device__ __forceinline__ void epilogue_store8(const Epilogue& e, long pout, in
     __bf16* o = e.out_planes + (long)e.out_chunk0 * e.Mout * 32 + cm;
     // (write-through `sc1` stores, which drop the line from the XCD's L2 instead of keeping it, measured SLOWER: FlowNetC 4.281 -> 4.315 ms,
     // PWC-Net 16.52 -> 16.60, FlowNet2 9.52 -> 9.66, RAFT 14.90 -> 15.27 per iteration, one call, gpurun r6_wt)
+    if (e.nostore) {                   // measurement only: the planes are computed and dropped
+      asm volatile("" ::"v"(q0), "v"(q1), "v"(q2), "v"(o));
+      return;
+    }
     *reinterpret_cast<bf16x8*>(o) = q0;
     *reinterpret_cast<bf16x8*>(o + e.out_plane_stride) = q1;
     *reinterpret_cast<bf16x8*>(o + 2 * e.out_plane_stride) = q2;
@@ -1158,8 +1163,9 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   a.e.Mout = (long)d->B * d->Ho * d->Wo; a.e.N = d->N; a.e.Nchunks32 = (d->N + 31) / 32;
   a.nphase = d->nphase; a.splitk = d->splitk; a.ws = d->ws;
   a.tickets = (d->splitk > 1 && !d->no_reduce) ? d->tickets : nullptr;
-  static const int skip_out = [] { const char* e = getenv("UFR_IGEMM_DEBUG_SKIP_EPILOGUE"); return e && e[0] == '1' ? 1 : 0; }();
-  a.skip_out = skip_out;
+  static const int skip_out = [] { const char* e = getenv("UFR_IGEMM_DEBUG_SKIP_EPILOGUE"); return e ? atoi(e) : 0; }();
+  a.skip_out = skip_out == 1;
+  a.e.nostore = skip_out == 2;
   a.xcd = 1;                              // XCD-aware tile order (off: +0.2 ms per iteration, profiles/r2_bench_engine_v4_no_xcd_order)
   a.korder = d->k_order ? 1 : 0;
   for (int z = 0; z < 4; ++z) {
