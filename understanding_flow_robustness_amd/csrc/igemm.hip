@@ -1175,7 +1175,7 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
     UFR_REQUIRE(p.w_off + (long)p.ntaps * d->KC * d->Npad * BK <= d->w_plane_stride, "igemm: phase %d weights out of range", z);
     a.ph[z].ntaps = p.ntaps; a.ph[z].oy0 = p.oy0; a.ph[z].ox0 = p.ox0; a.ph[z].w_off = p.w_off;
     for (int t = 0; t < UFR_IGEMM_MAX_TAPS; ++t)
-      a.ph[z].dyx[t] = t < p.ntaps ? (((int)p.dy[t] & 0xffff) | ((int)p.dx[t] << 16)) : 0;
+      a.ph[z].dyx[t] = t < p.ntaps ? (int)(((unsigned)(int)p.dy[t] & 0xffffu) | ((unsigned)(int)p.dx[t] << 16)) : 0;   // (unsigned: a negative dx shifted left is UB -- found by `make sanitize`)
     for (int t = 0; t < UFR_IGEMM_MAX_TAPS; ++t) a.ph[z].run[t] = 1 << 4;         // default: every tap its own run
     // maximal runs of <= 3 taps with equal dy whose dx step by one CELL of the row grid (+-in_sx input pixels: a stride-2 launch
     // pairs the taps of one parity, igemm.py orders them so); shift = cells behind the run's first pixel
