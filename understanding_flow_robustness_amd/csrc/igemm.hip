@@ -170,7 +170,8 @@ __device__ __forceinline__ void epilogue_store8(const Epilogue& e, long pout, in
     }
     __bf16* o = e.out_planes + (long)e.out_chunk0 * e.Mout * 32 + cm;
     // (write-through `sc1` stores, which drop the line from the XCD's L2 instead of keeping it, measured SLOWER: FlowNetC 4.281 -> 4.315 ms,
-    // PWC-Net 16.52 -> 16.60, FlowNet2 9.52 -> 9.66, RAFT 14.90 -> 15.27 per iteration, one call, gpurun r6_wt)
+    // PWC-Net 16.52 -> 16.60, FlowNet2 9.52 -> 9.66, RAFT 14.90 -> 15.27 per iteration, one call, gpurun r6_wt; non-temporal (`nt`) stores measured the same:
+    // FlowNetC 4.297 / 4.285 -> 4.305, FlowNet2 9.432 -> 9.426, gpurun r6_nt)
     if (e.nostore) {                   // measurement only: the planes are computed and dropped
       asm volatile("" ::"v"(q0), "v"(q1), "v"(q2), "v"(o));
       return;
