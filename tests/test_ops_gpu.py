@@ -328,6 +328,50 @@ def test_altcorr_lookup_on_split_planes_vs_oracle(oracle, B, H, W, C, r, spread)
     assert_close(o2 * ok, torch.where(ok, old2, torch.zeros_like(old2)), rtol=1e-4, atol_scale=2e-6, what="non-finite coordinates: the other pixels")
 
 
+@pytest.mark.parametrize("B,H,W,C,r,spread", [(1, 48, 160, 256, 4, 3.0), (2, 24, 40, 128, 3, 0.4), (1, 16, 40, 256, 4, 40.0)])
+def test_altcorr_dense_adjoint_vs_oracle(oracle, B, H, W, C, r, spread):
+    """Round 6: the adjoints of ALL lookups of one AlternateCorrBlock at once (flownets/raft_corr.py::alt_dense_adjoint): every lookup's
+    window adjoints are scattered into dense gradient volumes (`ufr_corr_lookup_backward`, one writer per pixel slice), the volumes of
+    the lookups ADD, and d / d fmap1, d / d fmap2_l are 2 x levels igemm products at the end.  Against the CPU oracle's
+    alt_cuda_corr backward (correlation_kernel.cu:122-256 restated), two lookups accumulated, level by level: the same gate as the
+    on-the-fly adjoint kernels hold (test_altcorr_pyramid_on_the_matrix_cores_vs_oracle)."""
+    import ctypes
+    import math
+    from understanding_flow_robustness_amd import _lib as L
+    from understanding_flow_robustness_amd.flownets.raft_corr import (_pyramid_struct, alt_dense_adjoint, alt_dense_adjoint_served,
+                                                                      alt_dense_volumes)
+    g = torch.Generator().manual_seed(B * 1000 + H + int(spread))
+    nl = 4 if H % 8 == 0 else 2
+    f1 = torch.randn(B, H, W, C, generator=g)
+    f2s = [torch.randn(B, max(H >> i, 1), max(W >> i, 1), C, generator=g) for i in range(nl)]
+    xs = torch.arange(W).float().view(1, 1, 1, W).expand(B, 1, H, W)
+    ys = torch.arange(H).float().view(1, 1, H, 1).expand(B, 1, H, W)
+    lookups = [(torch.cat([xs, ys], 1) + spread * torch.randn(B, 2, H, W, generator=g)).contiguous() for _ in range(2)]
+    scale, rd = 1.0 / math.sqrt(C), 2 * r + 1
+    gos = [torch.randn(B, nl * rd * rd, H, W, generator=g) for _ in lookups]
+    want1, want2 = torch.zeros_like(f1), [torch.zeros_like(f) for f in f2s]
+    for c, go in zip(lookups, gos):
+        for i in range(nl):
+            ci = (c.permute(0, 2, 3, 1) / 2 ** i).reshape(B, 1, H, W, 2).contiguous()
+            r1, r2, _ = oracle.altcorr_backward(f1, f2s[i], ci, (go[:, i * rd * rd:(i + 1) * rd * rd] * scale).unsqueeze(1).contiguous(), r)
+            want1 += r1
+            want2[i] += r2
+    f1d, f2d = f1.to(DEV), [f.to(DEV) for f in f2s]
+    assert alt_dense_adjoint_served(f1d, f2d, r)
+    vols = alt_dense_volumes(f1d, f2d)
+    assert [tuple(v.shape) for v in vols] == [(B * H * W, 1, f.shape[1], f.shape[2]) for f in f2s]
+    pyr = _pyramid_struct(vols, vols)
+    for c, go in zip(lookups, gos):
+        L.check(L.lib().ufr_corr_lookup_backward(ctypes.byref(pyr), L.ptr(c.to(DEV)), L.ptr(go.to(DEV)), B, H, W, r, L.stream()), "lookup adjoint")
+    g1, g2 = alt_dense_adjoint(f1d, f2d, vols, scale)
+    assert_close(g1, want1, rtol=1e-4, atol_scale=5e-6, what="d / d fmap1 (two lookups, all levels, dense adjoint)")
+    for i in range(nl):
+        assert_close(g2[i], want2[i], rtol=1e-4, atol_scale=1e-5, what=f"d / d fmap2 level {i} (dense adjoint)")
+    # a second call through the cached launches, another batch element order: same bits
+    g1b, g2b = alt_dense_adjoint(f1d, f2d, vols, scale)
+    assert torch.equal(g1, g1b) and all(torch.equal(a, b) for a, b in zip(g2, g2b))
+
+
 # ---------------------------------------------------------------------------- CorrBlock lookup
 def test_lookup_matches_corrblock_golden_and_oracle(ops, oracle):
     from understanding_flow_robustness_amd.flownets.raft_corr import corr_lookup

@@ -147,6 +147,80 @@ def _all_pairs_adjoint(fmap1, fmap2, g, scale, needs):
     return g1, g2
 
 
+_ALT_DENSE = L.LruDict(4)
+
+
+def alt_dense_adjoint_served(f1, f2s, radius) -> bool:
+    """The dense adjoint of AlternateCorrBlock's lookups (below) serves HIP float32 maps whose channel count the igemm takes as a
+    weight image (a multiple of 64) and RAFT's radii; UFR_ALTCORR_DENSE_ADJOINT=0 keeps the on-the-fly adjoint kernels."""
+    return (f1.is_cuda and f1.dtype == torch.float32 and f1.shape[3] % 64 == 0 and int(radius) in (3, 4) and 1 <= len(f2s) <= 4
+            and os.environ.get("UFR_ALTCORR_DENSE_ADJOINT", "1") != "0")
+
+
+def alt_dense_volumes(f1, f2s):
+    """Zeroed gradient volumes of the lookups' windows, level l: [B * H1 * W1, 1, H_l, W_l] (the layout `ufr_corr_lookup_backward` adds into)."""
+    B, H1, W1, _ = f1.shape
+    return [torch.zeros(B * H1 * W1, 1, f.shape[1], f.shape[2], dtype=torch.float32, device=f1.device) for f in f2s]
+
+
+def alt_dense_adjoint(f1, f2s, g_vols, scale):
+    """d / d fmap1 and d / d fmap2_l of ALL lookups of one AlternateCorrBlock at once (round 6).  Every lookup's adjoint is a sparse
+    matrix G_l[p, q] (pixel p, window point q of level l) times a feature map: d f1[p] = sum_l sum_q G_l[p, q] f2_l[q],
+    d f2_l[q] = sum_p G_l[p, q] f1[p] (corr.py:121-137 is linear in both maps, coords are detached, raft.py:190).  RAFT's 12 lookups
+    share the maps, so their G_l are ADDED first -- `lookup_bwd_tiled` scatters a lookup's window adjoints into dense volumes in 31 us
+    (one writer per pixel slice, no atomics) -- and the products are taken ONCE, as 2 x levels launches of the hand-written igemm with the
+    volume as the activation and a feature map's planes as the weight image (`_all_pairs_adjoint`'s form, per level and rectangular).
+    That replaces 12 x (pre-pass + two gather-GEMM adjoints + two fixed-order sums) = 3.2 ms of kernel time per RAFT iteration by
+    12 x 0.04 + ~0.8 ms, at the price of 313 MB of volume gradient per pair -- nothing on a 288 GB part.  f1 [B,H1,W1,C], f2s[l] [B,Hl,Wl,C]
+    (NHWC float32), g_vols[l] [B*H1*W1, 1, Hl, Wl]; returns (g_f1, [g_f2_l]) in NHWC, multiplied by `scale`."""
+    from .. import igemm as ig
+    B, H1, W1, C_ = f1.shape
+    HW1, dev = H1 * W1, f1.device
+    shapes = tuple((int(f.shape[1]), int(f.shape[2])) for f in f2s)
+    key = (dev, H1, W1, C_, shapes)
+    st = _ALT_DENSE.get(key)
+    if st is None:
+        kc1 = (HW1 + 31) // 32
+        st = dict(W1=ig.Planes(1, 1, C_, kc1, dev), out1=ig.GradSum(1, H1, W1, C_ // 32, dev), levels=[])
+        big = None                                      # level 0's two activation buffers have one shape: one allocation
+        for l, (Hl, Wl) in enumerate(shapes):
+            kcl = (Hl * Wl + 31) // 32
+            A1 = ig.Planes(1, H1, W1, kcl, dev)         # G_l as [pixels p][window points q]
+            if (Hl, Wl) == (H1, W1):
+                big = A2 = A1
+            else:
+                A2 = ig.Planes(1, Hl, Wl, kc1, dev)     # G_l^T as [points q][pixels p]
+            Wf = ig.Planes(1, 1, C_, kcl, dev)          # fmap2_l as the weight image [C][q]
+            out2 = ig.GradSum(1, Hl, Wl, C_ // 32, dev)
+            lv = dict(A1=A1, A2=A2, Wf=Wf, out2=out2)
+            for name, A, W_, out, rows, extra in (("p1", A1, Wf, st["out1"], (H1, W1), dict(add=st["out1"]) if l else {}),
+                                                  ("p2", A2, st["W1"], out2, (Hl, Wl), {})):
+                wi = ig.planes_as_weights(W_)
+                M = rows[0] * rows[1]
+                kw = dict(out_f32=out, **extra)
+                S = ig.splitk_for(M, wi.Npad, wi.KC, 1, bm=256, target=256, min_ktiles=4)
+                variant, S = ig.tuned(wi, M, kw, 6, S, rows=rows)
+                ws = torch.empty(max(1, S * M * wi.Npad), dtype=torch.float32, device=dev) if S > 1 else None
+                lv[name] = ig.make_launch(wi, A, 0, rows, rows, splitk=S, ws=ws, variant=variant, **kw)
+            st["levels"].append(lv)
+        _ALT_DENSE[key] = st
+    g_f1 = torch.empty_like(f1)
+    g_f2 = [torch.empty_like(f) for f in f2s]
+    with torch.cuda.device(dev):
+        for b in range(B):
+            st["W1"].load_rowmajor(f1[b].reshape(HW1, C_).t().contiguous())                 # W[c][p] = fmap1[p, c]
+            for l, ((Hl, Wl), lv) in enumerate(zip(shapes, st["levels"])):
+                G = g_vols[l][b * HW1:(b + 1) * HW1]
+                lv["Wf"].load_rowmajor(f2s[l][b].reshape(Hl * Wl, C_).t().contiguous())       # W[c][q] = fmap2_l[q, c]
+                lv["A1"].load_rowmajor(G.view(HW1, Hl * Wl))                                  # A[p][q] = G_l[p, q]
+                lv["p1"]()                                                                    # out1[p, c] (+)= sum_q G_l[p, q] fmap2_l[q, c]
+                lv["A2"].load_nchw(G.view(1, HW1, Hl, Wl))                                    # A[q][p] = G_l[p, q]: channels = G's rows
+                lv["p2"]()                                                                    # out2[q, c] = sum_p G_l[p, q] fmap1[p, c]
+                torch.mul(lv["out2"].t.permute(1, 0, 2).reshape(Hl, Wl, C_), scale, out=g_f2[l][b])
+            torch.mul(st["out1"].t.permute(1, 0, 2).reshape(H1, W1, C_), scale, out=g_f1[b])
+    return g_f1, g_f2
+
+
 class AllPairsCorrFunction(torch.autograd.Function):
     """corr[b, p, q] = <fmap1[b, :, p], fmap2[b, :, q]> / sqrt(C) (models/raft/corr.py:57-64) on the hand-written igemm
     (csrc/igemm.hip): per frame pair ONE 1x1 launch whose activation is fmap1's planes and whose "weight image" is fmap2's planes

@@ -291,7 +291,7 @@ class RaftUpdateEngine:
 
     def _lookup_backward(self, src, coords, first):
         lib, B, h, w = L.lib(), self.B, self.h, self.w
-        if src["alt"]:
+        if src["alt"] and not src.get("dense"):
             lv = self._alt_levels(src["f2"], src["g_f2"])
             # (the cost volume's gradient is read as convc1^T left it, chunk-major: no NCHW copy in between)
             L.check(lib.ufr_altcorr_pyramid_backward_cm(L.ptr(src["f1"]), C.byref(lv), L.ptr(coords), L.ptr(self.G_corr.t), L.ptr(src["g_f1"]),
@@ -299,7 +299,9 @@ class RaftUpdateEngine:
                                                      0 if first else 1, L.stream()), "alt_corr backward")
         else:
             from .flownets.raft_corr import _pyramid_struct
-            pyr = _pyramid_struct(src["vols"], src["g_vols"])          # accumulates (+=): the buffers were zeroed
+            # (alt_cuda_corr with the dense adjoint: the window adjoints go into gradient volumes too, raft_corr.alt_dense_adjoint; the
+            #  adjoint kernel reads the levels' SHAPES from the first list only)
+            pyr = _pyramid_struct(src["g_vols"] if src["alt"] else src["vols"], src["g_vols"])   # accumulates (+=): the buffers were zeroed
             L.check(lib.ufr_corr_lookup_backward(C.byref(pyr), L.ptr(coords), L.ptr(self.g_corr), B, h, w, self.radius, L.stream()),
                     "corr lookup backward")
 
@@ -425,7 +427,7 @@ class RaftUpdateEngine:
             with pending.start():
                 for name in ("conv^T", "convc2^T", "convc1^T"):
                     self.launch[(name, it)]()
-                if not src["alt"]:                                     # (alt_corr's adjoint reads the chunk-major sum itself)
+                if not src["alt"] or src.get("dense"):                 # (alt_corr's on-the-fly adjoint reads the chunk-major sum itself)
                     self.G_corr.to_nchw(self.cor_planes, 0, slope=1.0, out=self.g_corr)
                 self._lookup_backward(src, self._coords[it], first=(it == IT - 1))
         if pending is not None:
@@ -465,7 +467,10 @@ class _RaftRefine(torch.autograd.Function):
         if eng.generation != ctx.generation:
             raise RuntimeError("RAFT engine: another forward of this network (same batch and frame size) ran before this backward; its "
                                "activations are gone.  Call backward() before the next forward, or set UFR_ENGINE=0")
-        if src["alt"]:
+        from .flownets.raft_corr import alt_dense_adjoint, alt_dense_adjoint_served, alt_dense_volumes
+        if src["alt"] and alt_dense_adjoint_served(src["f1"], src["f2"], eng.radius):
+            src["dense"], src["g_vols"] = True, alt_dense_volumes(src["f1"], src["f2"])
+        elif src["alt"]:
             f1 = src["f1"]
             src["g_f1"], src["g_f2"] = torch.empty_like(f1), [torch.empty_like(f) for f in src["f2"]]
             nbytes = L.lib().ufr_altcorr_pyramid_workspace_bytes(eng.B, eng.h, eng.w, f1.shape[3], eng.radius, len(src["f2"]))
@@ -473,6 +478,10 @@ class _RaftRefine(torch.autograd.Function):
         else:
             src["g_vols"] = [torch.zeros_like(v) for v in src["vols"]]
         g_net0, g_inp = eng.backward(g_flow, g_mask)
+        if src["alt"] and src.get("dense"):
+            g_f1, g_f2 = alt_dense_adjoint(src["f1"], src["f2"], src["g_vols"], src["scale"])
+            src["g_vols"] = None                                       # (313 MB per pair: released with this backward)
+            return (g_net0.clone(), g_inp.clone(), None, None, None, g_f1, *g_f2)
         if src["alt"]:
             return (g_net0.clone(), g_inp.clone(), None, None, None, src["g_f1"], *src["g_f2"])
         return (g_net0.clone(), g_inp.clone(), None, None, None, None, *src["g_vols"])
