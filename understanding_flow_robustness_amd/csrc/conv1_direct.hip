@@ -22,6 +22,8 @@
 //     Eight waves = 4 channel quarters x 2 halves of the tile's rows.
 //   * double-buffered input tiles: the next tile's pixels are fetched into registers before this tile's MFMAs and written to
 //     the other buffer after them; ONE workgroup barrier per tile.
+#include <atomic>
+
 #include "ufr_common.h"
 
 namespace {
@@ -272,14 +274,12 @@ extern "C" int ufr_conv1_direct(const float* frames_a, const float* frames_b, in
   a.tiles = (int)tiles;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ufr::fail(UFR_ELAUNCH, "conv1 direct: no current device");
-  static bool raised[64] = {};
-  if (!raised[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_direct_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_B) !=
-            hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_direct_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_B) !=
-            hipSuccess)
-      return ufr::fail(UFR_ELAUNCH, "conv1 direct: %s", hipGetErrorString(hipGetLastError()));
-    raised[dev] = true;
+  static std::atomic<bool> raised[64] = {};      // (published with release / acquire; the slow path is ufr::ensure_dynamic_lds' mutex)
+  if (!raised[dev].load(std::memory_order_acquire)) {
+    hipError_t e = ufr::ensure_dynamic_lds(reinterpret_cast<const void*>(conv1_direct_kernel<true>), 2 * BUF_B);
+    if (e == hipSuccess) e = ufr::ensure_dynamic_lds(reinterpret_cast<const void*>(conv1_direct_kernel<false>), 2 * BUF_B);
+    if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "conv1 direct: %s", hipGetErrorString(e));
+    raised[dev].store(true, std::memory_order_release);
   }
   const int grid = (int)(tiles < ufr::kNumCU ? tiles : ufr::kNumCU);          // one persistent workgroup per CU
   // every plane the kernel writes must lie inside the buffer resource: three planes of at least (out_chunk0 + 2) chunks

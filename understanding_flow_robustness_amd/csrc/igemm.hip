@@ -1222,24 +1222,17 @@ extern "C" int ufr_igemm(const ufr_igemm_desc* d, ufr_stream_t stream) {
   const bool use_buf = 6L * d->x_plane_stride < 0x7fffffffL;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ufr::fail(UFR_ELAUNCH, "igemm: no current device");
-  static bool raised[64] = {};              // per device: a process may drive more than one
-  if (!raised[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_pp_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       pp_lds_bytes(128));
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_pp_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              pp_lds_bytes(128));
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_glds_kernel<128, 128, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS_BYTES);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_pp3_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              pp3_lds_bytes(128));
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_pp3_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              pp3_lds_bytes(64));
+  // per device (a process may drive more than one) and safe between host threads: the flag is published with release / acquire,
+  // two threads that race here both raise the limits (idempotent) -- the slow path goes through ufr::ensure_dynamic_lds' mutex
+  static std::atomic<bool> raised[64] = {};
+  if (!raised[dev].load(std::memory_order_acquire)) {
+    hipError_t e = ufr::ensure_dynamic_lds(reinterpret_cast<const void*>(igemm_pp_kernel<128>), pp_lds_bytes(128));
+    if (e == hipSuccess) e = ufr::ensure_dynamic_lds(reinterpret_cast<const void*>(igemm_pp_kernel<128, true>), pp_lds_bytes(128));
+    if (e == hipSuccess) e = ufr::ensure_dynamic_lds(reinterpret_cast<const void*>(igemm_glds_kernel<128, 128, true>), PIPE_LDS_BYTES);
+    if (e == hipSuccess) e = ufr::ensure_dynamic_lds(reinterpret_cast<const void*>(igemm_pp3_kernel<128>), pp3_lds_bytes(128));
+    if (e == hipSuccess) e = ufr::ensure_dynamic_lds(reinterpret_cast<const void*>(igemm_pp3_kernel<64>), pp3_lds_bytes(64));
     if (e != hipSuccess) return ufr::fail(UFR_ELAUNCH, "igemm: %s", hipGetErrorString(e));
-    raised[dev] = true;
+    raised[dev].store(true, std::memory_order_release);
   }
   // 8 = the direct 3 x 3 form: one phase of nine taps within +-1, stride 1 in and out, row grid = input grid = output grid, no band,
   // no split, no tail / row-major output, chunk-major K order, <= 64 columns (anything else falls through to the tile forms)
