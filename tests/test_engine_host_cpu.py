@@ -351,3 +351,51 @@ def test_frozen_module_deep_copy_keeps_the_callers_flags_and_workspace_caches_ar
     assert sorted(c) == ["a", "c", "d"] and c.get("b") is None
     c["c"] = "C2"                                                          # an existing key never evicts
     assert len(c) == 3
+
+
+def test_round6_host_switches(monkeypatch):
+    """Host logic added in round 6, no device needed: RAFT's precision is an explicit opt-in (`args.mixed_precision` AND the environment
+    -- models/utils_model.py:51 sets the flag for every non-"adv" RAFT, the build stays float32 unless asked twice); `igemm.products` nests
+    and restores; the tuning key carries the row grid when the caller gives it and falls back to the short form; the split-plane lookup
+    and the dense adjoint decline CPU tensors (the callers then take the other path or raise: there is no CPU fallback)."""
+    import pytest
+    from argparse import Namespace
+
+    from understanding_flow_robustness_amd.flownets.raft import RAFT
+    from understanding_flow_robustness_amd.flownets.raft_corr import AltCorrPlanes, alt_dense_adjoint_served
+    net = RAFT(Namespace(small=False, mixed_precision=False))
+    monkeypatch.delenv("UFR_RAFT_PRECISION", raising=False)
+    assert net.products() == 6
+    net.args.mixed_precision = True
+    assert net.products() == 6                                             # the flag alone
+    for mode, want in (("bf16", 1), ("bf16x3", 3), ("fp32", 6), ("FLOAT32", 6)):
+        monkeypatch.setenv("UFR_RAFT_PRECISION", mode)
+        assert net.products() == want
+    net.args.mixed_precision = False
+    monkeypatch.setenv("UFR_RAFT_PRECISION", "bf16")
+    assert net.products() == 6                                             # the environment alone
+    monkeypatch.setenv("UFR_RAFT_PRECISION", "fp16")
+    with pytest.raises(ValueError):
+        net.products()
+    assert ig._PRODUCTS[-1] == 6
+    with ig.products(1):
+        assert ig._PRODUCTS[-1] == 1
+        with ig.products(3):
+            assert ig._PRODUCTS[-1] == 3
+        assert ig._PRODUCTS[-1] == 1
+    assert ig._PRODUCTS == [6]
+    with pytest.raises(ValueError):
+        ig.products(2)
+    wi = ig.conv_forward_weights(torch.randn(64, 32, 3, 3), 1, 1)
+    kw = dict(out_planes=object())
+    short, long_ = ig.launch_signature(wi, 7680, kw), ig.launch_signature(wi, 7680, kw, (48, 160))
+    assert long_ == short + "_g48x160" and short.startswith("M7680_N64_KC1_t9_s11_planes")
+    monkeypatch.setattr(ig, "_TUNING", {short: (4, 2), long_: (8, 1)})
+    assert ig.tuned(wi, 7680, kw, 6, 3, rows=(48, 160)) == (8, 1)          # the long form first
+    assert ig.tuned(wi, 7680, kw, 6, 3, rows=(24, 320)) == (4, 2)          # another grid: the short form
+    assert ig.tuned(wi, 7680, kw, 6, 3) == (4, 2)
+    monkeypatch.setattr(ig, "_TUNING", {})
+    assert ig.tuned(wi, 7680, kw, 6, 3, rows=(48, 160)) == (6, 3)          # nothing swept: the engine's own choice
+    f1 = torch.zeros(1, 8, 16, 256)
+    f2 = [torch.zeros(1, 8 >> l, 16 >> l, 256) for l in range(4)]
+    assert not AltCorrPlanes.served(f1, f2, 4) and not alt_dense_adjoint_served(f1, f2, 4)
